@@ -1,0 +1,71 @@
+// ORACLE (test infrastructure, NOT product code).
+// Flat character / scenario description handed to the oracle by oracle/model.py (which reads the reference's
+// JSON + arg files with Python's json module, independently of the product's C++ loader).
+// Field meanings follow anim/KinTree.h:24-64 (joint + body tables), sim/PDController.h (eParam*),
+// sim/DogController.h:12-44 (param layout), scenarios/ScenarioSimChar.cpp:76-108 (scenario args).
+#pragma once
+#include <cstdint>
+
+#define ORC_MAXL 24
+#define ORC_MAXD 26
+#define ORC_MAXP 40
+#define ORC_MAXSETS 8
+#define ORC_MAXACT 16
+#define ORC_MAXTP 4
+
+extern "C" {
+
+struct OrcModel {
+	int32_t char_type;   // 0 = dog (also goat), 1 = raptor
+	int32_t ctrl_type;   // 0 = FSM without net ("dog"/"raptor": cDogControllerQ w/o net), 1 = MACE
+	int32_t L, D;
+	int32_t parent[ORC_MAXL];
+	int32_t joint_type[ORC_MAXL];          // cKinTree::eJointType (0 revolute, 1 planar)
+	double attach[ORC_MAXL][3];            // joint attach point in parent joint frame
+	double lim_lo[ORC_MAXL], lim_hi[ORC_MAXL];
+	double body_attach[ORC_MAXL][3];       // body COM in joint frame
+	double body_theta[ORC_MAXL];
+	double body_size[ORC_MAXL][3];
+	double body_mass[ORC_MAXL];
+	int32_t col_group[ORC_MAXL];           // 0 = collides with nothing (sim/SimDog.cpp:5-33)
+	double kp[ORC_MAXL], kd[ORC_MAXL], torque_lim[ORC_MAXL], target_theta[ORC_MAXL];
+	int32_t use_world[ORC_MAXL];
+	int32_t n_sets, n_params;
+	double ctrl_params[ORC_MAXSETS][ORC_MAXP];
+	int32_t n_actions;
+	int32_t act_idx0[ORC_MAXACT], act_idx1[ORC_MAXACT];
+	double act_blend[ORC_MAXACT];
+	int32_t act_cyclic[ORC_MAXACT];
+	int32_t default_action;
+	int32_t enable_grav_comp;
+	int32_t enable_virtual_forces;
+	double target_vel_x;
+	double pose0[ORC_MAXD], vel0[ORC_MAXD];
+	int32_t valid_init_pos_x;
+	double init_pos_x;
+	int32_t num_update_steps, num_sim_substeps;
+	double world_scale;
+	int32_t terrain_type;
+	int32_t n_terrain_sets;
+	double terrain_params[ORC_MAXTP][40];
+	double terrain_blend;
+	int32_t scenario;     // 0 = sim_char (no auto reset), 1 = exp (tuples, reset on fall), 2 = poli_eval (reset on fall, dist log)
+	int32_t tuple_buffer_size;
+	int32_t enable_explore;
+	double exp_rate, exp_temp, exp_base_rate;
+};
+
+// MACE network family of data/policies/*/nets/*_mace3_deploy.prototxt
+struct OrcNetDesc {
+	int32_t n_terrain;      // 200 (slice_point)
+	int32_t n_char;         // input_dim - 200
+	int32_t conv_ch[3];     // 16, 32, 32
+	int32_t conv_k[3];      // 8, 4, 4
+	int32_t fc_terr;        // 64
+	int32_t fc_trunk;       // 256
+	int32_t fc_head;        // 128
+	int32_t n_frags;        // 3
+	int32_t frag_size;      // 29 / 28
+};
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// ORACLE (test infrastructure, NOT product code).
+// The documented planar articulated-body + contact integrator that stands in for Bullet
+// (cWorld::Update -> btDiscreteDynamicsWorld::stepSimulation, /root/reference/sim/World.cpp:96-105).
+// Bullet is an un-vendored, un-pinned external of the reference and is absent here, so this part is
+// "by documented model" (DESIGN.md section "Integrator v1"), PARITY UNPINNED against Bullet. The reference-visible
+// parameters are preserved: gravity (0,-9.8,0) util/MathUtil.h:19; fixed substep dt/n (sim/World.cpp:101-102);
+// friction 0.9*0.9 (sim/SimCharacter.cpp:17, sim/GroundVar2D.cpp:10); restitution 0; no damping (sim/World.cpp:52-53);
+// joint limits with lo > hi => free (sim/World.cpp:28-29,625); per-joint torque clamp (sim/Joint.cpp:257-264,
+// sim/PDController.cpp:98-100); collision groups (sim/SimDog.cpp:5-33); torques held over all substeps.
+//
+// Model (one substep of length h):
+//   H(q) v+ = H v + h (tau - b(q,v)) + J^T lambda,   q+ = q + h v+
+//   rows of J: violated joint limits (unit rows) and, per penetrating contact sample point, a normal and a
+//   tangent row; lambda solved by 10 sweeps of projected Gauss-Seidel in a fixed row order, no warm start;
+//   normal target velocity = min(ERP * max(depth - slop, 0) / h, v_depen_max); friction box |lt| <= mu * ln.
+//   Contact sample points per box link: 4 corners + midpoints of the two long edges, tested against the
+//   heightfield polyline; depth measured along the cell normal.
+#pragma once
+#include "or_rbd.h"
+#include "or_terrain.h"
+
+namespace orc {
+
+struct SimConst {
+	static constexpr double erp = 0.2;
+	static constexpr double slop = 0.001;
+	static constexpr double mu = 0.9 * 0.9;
+	static constexpr double v_depen_max = 1.0;
+	static constexpr double limit_erp = 0.2;
+	static constexpr int pgs_iters = 10;
+	static constexpr int max_rows = 64;
+	static constexpr int pts_per_link = 6;
+};
+
+struct Bodies {
+	// per-link planar kinematics derived from (q, qd)
+	double phi[ORC_MAXL];          // world angle of the joint frame
+	double px[ORC_MAXL], py[ORC_MAXL];  // joint world position
+	double cx[ORC_MAXL], cy[ORC_MAXL];  // body COM world position
+	double psi[ORC_MAXL];          // body world angle = phi + body_theta
+	double w[ORC_MAXL];            // angular velocity
+	double vpx[ORC_MAXL], vpy[ORC_MAXL];  // velocity of the joint origin
+	double vcx[ORC_MAXL], vcy[ORC_MAXL];  // velocity of the COM
+};
+
+inline void ForwardKin(const OrcModel& M, const double* q, const double* qd, Bodies& B)
+{
+	for (int j = 0; j < M.L; ++j) {
+		int p = M.parent[j];
+		if (p < 0) {
+			B.phi[j] = q[2]; B.px[j] = q[0]; B.py[j] = q[1];
+			B.w[j] = qd[2]; B.vpx[j] = qd[0]; B.vpy[j] = qd[1];
+		} else {
+			double c = std::cos(B.phi[p]), s = std::sin(B.phi[p]);
+			double ax = M.attach[j][0], ay = M.attach[j][1];
+			double rx = c * ax - s * ay, ry = s * ax + c * ay;
+			B.px[j] = B.px[p] + rx; B.py[j] = B.py[p] + ry;
+			B.phi[j] = B.phi[p] + q[j + 2];
+			B.vpx[j] = B.vpx[p] - B.w[p] * ry; B.vpy[j] = B.vpy[p] + B.w[p] * rx;
+			B.w[j] = B.w[p] + qd[j + 2];
+		}
+		double c = std::cos(B.phi[j]), s = std::sin(B.phi[j]);
+		double bx = M.body_attach[j][0], by = M.body_attach[j][1];
+		double rx = c * bx - s * by, ry = s * bx + c * by;
+		B.cx[j] = B.px[j] + rx; B.cy[j] = B.py[j] + ry;
+		B.psi[j] = B.phi[j] + M.body_theta[j];
+		B.vcx[j] = B.vpx[j] - B.w[j] * ry; B.vcy[j] = B.vpy[j] + B.w[j] * rx;
+	}
+}
+
+// body-frame sample points of link j (documented contact model)
+inline void LinkSamplePoint(const OrcModel& M, int j, int k, double& sx, double& sy)
+{
+	double hx = 0.5 * M.body_size[j][0], hy = 0.5 * M.body_size[j][1];
+	switch (k) {
+	case 0: sx = -hx; sy = -hy; break;
+	case 1: sx = hx; sy = -hy; break;
+	case 2: sx = hx; sy = hy; break;
+	case 3: sx = -hx; sy = hy; break;
+	case 4: if (hx >= hy) { sx = 0; sy = -hy; } else { sx = -hx; sy = 0; } break;
+	default: if (hx >= hy) { sx = 0; sy = hy; } else { sx = hx; sy = 0; } break;
+	}
+}
+
+struct ContactPoint { int link; double x, y, depth, nx, ny; };
+
+// contact detection at the current configuration; fills in-contact flags per link
+inline int DetectContacts(const OrcModel& M, const Bodies& B, const Ground& g, ContactPoint* out, int cap, bool* flags)
+{
+	int n = 0;
+	for (int j = 0; j < M.L; ++j) {
+		flags[j] = false;
+		if (M.col_group[j] == 0) continue;
+		double c = std::cos(B.psi[j]), s = std::sin(B.psi[j]);
+		for (int k = 0; k < SimConst::pts_per_link; ++k) {
+			double sx, sy; LinkSamplePoint(M, j, k, sx, sy);
+			double x = B.cx[j] + c * sx - s * sy;
+			double y = B.cy[j] + s * sx + c * sy;
+			double h = g.SampleHeight(x);
+			double slope = g.SampleSlope(x);
+			double inv = 1.0 / std::sqrt(1.0 + slope * slope);
+			double nx = -slope * inv, ny = inv;
+			double depth = (h - y) * ny;
+			if (depth > 0) {
+				flags[j] = true;
+				if (n < cap) { out[n].link = j; out[n].x = x; out[n].y = y; out[n].depth = depth; out[n].nx = nx; out[n].ny = ny; ++n; }
+			}
+		}
+	}
+	return n;
+}
+
+// one substep. H and b (true bias, fix_cj) come from the caller's RBDModel evaluated at (q, qd).
+struct Integrator {
+	double Jr[SimConst::max_rows][ORC_MAXD];
+	double Yr[SimConst::max_rows][ORC_MAXD];
+	double Arr[SimConst::max_rows], tgt[SimConst::max_rows], lam[SimConst::max_rows];
+	int kind[SimConst::max_rows];  // 0 = limit (lambda >= 0), 1 = contact normal, 2 = contact tangent (paired with previous row)
+
+	void PointJacobian(const OrcModel& M, const Bodies& B, int link, double x, double y, double dx, double dy, double* row, int D) const
+	{
+		for (int i = 0; i < D; ++i) row[i] = 0;
+		row[0] = dx; row[1] = dy;
+		int j = link;
+		while (j >= 0) {
+			// d(point)/d(theta_j) = z x (point - p_j)
+			double rx = x - B.px[j], ry = y - B.py[j];
+			row[j + 2] = dx * (-ry) + dy * rx;
+			j = M.parent[j];
+		}
+	}
+
+	void Substep(const OrcModel& M, RBDModel& rbd, const Ground& ground, double h, double* q, double* qd, const double* tau)
+	{
+		const int D = rbd.D;
+		rbd.Update(q, qd, /*fix_cj=*/true);
+		Bodies B; ForwardKin(M, q, qd, B);
+		double Hm[ORC_MAXD * ORC_MAXD];
+		for (int i = 0; i < D; ++i) for (int k = 0; k < D; ++k) Hm[i * D + k] = rbd.H[i][k];
+		double rhs[ORC_MAXD], dv[ORC_MAXD], v[ORC_MAXD];
+		for (int i = 0; i < D; ++i) rhs[i] = tau[i] - rbd.C[i];
+		SolveLDLT(D, Hm, D, rhs, dv);
+		for (int i = 0; i < D; ++i) v[i] = qd[i] + h * dv[i];
+
+		int R = 0;
+		for (int j = 1; j < M.L; ++j) {
+			if (M.lim_lo[j] > M.lim_hi[j]) continue;
+			double th = q[j + 2];
+			if (th <= M.lim_lo[j] && R < SimConst::max_rows) {
+				for (int i = 0; i < D; ++i) Jr[R][i] = 0;
+				Jr[R][j + 2] = 1; kind[R] = 0; tgt[R] = SimConst::limit_erp * (M.lim_lo[j] - th) / h; ++R;
+			} else if (th >= M.lim_hi[j] && R < SimConst::max_rows) {
+				for (int i = 0; i < D; ++i) Jr[R][i] = 0;
+				Jr[R][j + 2] = -1; kind[R] = 0; tgt[R] = SimConst::limit_erp * (th - M.lim_hi[j]) / h; ++R;
+			}
+		}
+		ContactPoint cps[SimConst::max_rows / 2];
+		bool flags[ORC_MAXL];
+		int cap = (SimConst::max_rows - R) / 2;
+		int nc = DetectContacts(M, B, ground, cps, cap, flags);
+		for (int c = 0; c < nc; ++c) {
+			const ContactPoint& cp = cps[c];
+			PointJacobian(M, B, cp.link, cp.x, cp.y, cp.nx, cp.ny, Jr[R], D);
+			kind[R] = 1;
+			double t = SimConst::erp * std::max(cp.depth - SimConst::slop, 0.0) / h;
+			tgt[R] = std::min(t, SimConst::v_depen_max); ++R;
+			PointJacobian(M, B, cp.link, cp.x, cp.y, cp.ny, -cp.nx, Jr[R], D);
+			kind[R] = 2; tgt[R] = 0; ++R;
+		}
+		for (int r = 0; r < R; ++r) {
+			SolveLDLT(D, Hm, D, Jr[r], Yr[r]);
+			double a = 0; for (int i = 0; i < D; ++i) a += Jr[r][i] * Yr[r][i];
+			Arr[r] = a; lam[r] = 0;
+		}
+		for (int it = 0; it < SimConst::pgs_iters; ++it) {
+			for (int r = 0; r < R; ++r) {
+				if (Arr[r] < 1e-12) continue;
+				double w = 0; for (int i = 0; i < D; ++i) w += Jr[r][i] * v[i];
+				double nl = lam[r] + (tgt[r] - w) / Arr[r];
+				if (kind[r] == 2) { double lim = SimConst::mu * lam[r - 1]; nl = std::min(std::max(nl, -lim), lim); }
+				else nl = std::max(nl, 0.0);
+				double dl = nl - lam[r];
+				lam[r] = nl;
+				for (int i = 0; i < D; ++i) v[i] += Yr[r][i] * dl;
+			}
+		}
+		for (int i = 0; i < D; ++i) { qd[i] = v[i]; q[i] += h * v[i]; }
+	}
+};
+
+}  // namespace orc
