@@ -1,0 +1,237 @@
+"""deepterrainrl_amd -- MI355X-native batched rollout engine for the DeepTerrainRL environments.
+
+Python host-side mirror of the reference's scenario interface for the rollout path, bound over the C ABI of
+``include/dtrl.h`` with ctypes (plain pointers and sizes, no torch types cross the boundary).
+
+    cScenarioExp / cScenarioPoliEval (one env)        ->  BatchScenario (N envs, one HIP device)
+      ParseArgs + Init                                  ->  BatchScenario(arg_file=..., num_envs=...)
+      Update(dt)                                        ->  .Update(dt)
+      Reset()                                           ->  .Reset(env_ids=None)
+      IsTupleBufferFull/GetTuples/ResetTupleBuffer      ->  .DrainTuples()
+      EnableExplore/SetExpRate/SetExpTemp/...           ->  .SetExplore(enable, rate, temp, base_rate)
+      SetTerrainParamsLerp                              ->  .SetTerrainParamsLerp(lerp)
+      GetCharacter()->BuildPose/BuildVel/SetPose/SetVel ->  .BuildPose() / .BuildVel() / .SetPoseVel()
+      GetNNController()->RecordPoliState / LoadNet...   ->  .RecordPoliState() / .SetPolicy(weights, scales)
+      GetAvgDist/GetNumEpisodes/GetNumCycles            ->  .EvalStats()
+
+The product path is the HIP library ``lib/libdtrl.so``; importing works anywhere, but constructing a BatchScenario
+raises ``DtrlError`` when the library or a HIP device is missing -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdtrl.so")
+
+DTRL_OK = 0
+FLAG_FALLEN, FLAG_STUMBLED, FLAG_NEW_CYCLE, FLAG_STATE_SHIFT = 1, 2, 4, 8
+TUPLE_FAIL, TUPLE_EXP_CRITIC, TUPLE_EXP_ACTOR = 1, 2, 4
+
+# every symbol include/dtrl.h declares (tests check the built library exports all of them)
+ABI_SYMBOLS = [
+    "dtrl_create", "dtrl_destroy", "dtrl_reset", "dtrl_step", "dtrl_step_updates", "dtrl_run_frames", "dtrl_set_policy",
+    "dtrl_policy_num_params", "dtrl_build_output_offset_scale", "dtrl_set_explore", "dtrl_set_terrain_lerp", "dtrl_drain_tuples",
+    "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
+    "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
+]
+
+
+class DtrlError(RuntimeError):
+    pass
+
+
+def _bind(path):
+    if not os.path.exists(path):
+        raise DtrlError("HIP extension missing: %s (run __graft_entry__.build() / make -C deepterrainrl_amd/csrc)" % path)
+    L = C.CDLL(path)
+    vp, i32p, u32p, u64p, dp, fp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_float)
+    L.dtrl_create.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.dtrl_destroy.argtypes = [vp]
+    L.dtrl_reset.argtypes = [vp, vp, C.c_int, vp]
+    L.dtrl_step.argtypes = [vp, C.c_double]
+    L.dtrl_step_updates.argtypes = [vp, C.c_int]
+    L.dtrl_run_frames.argtypes = [vp, C.c_int, C.c_double]
+    L.dtrl_set_policy.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, vp]
+    L.dtrl_policy_num_params.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.dtrl_build_output_offset_scale.argtypes = [vp, vp, vp]
+    L.dtrl_set_explore.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double]
+    L.dtrl_set_terrain_lerp.argtypes = [vp, C.c_double]
+    L.dtrl_drain_tuples.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    for name in ("dtrl_get_pose_vel", "dtrl_get_torques"):
+        getattr(L, name).argtypes = [vp, vp, C.c_int, vp, vp]
+    L.dtrl_set_pose_vel.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.dtrl_get_poli_state.argtypes = [vp, vp, C.c_int, vp]
+    L.dtrl_get_flags.argtypes = [vp, vp, C.c_int, vp]
+    L.dtrl_get_contacts.argtypes = [vp, vp, C.c_int, vp]
+    L.dtrl_get_ctrl.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.dtrl_sample_ground.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.dtrl_eval_stats.argtypes = [vp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.dtrl_dims.argtypes = [vp] + [C.POINTER(C.c_int)] * 8
+    L.dtrl_kernel_time_ms.argtypes = [vp, dp, C.POINTER(C.c_int64)]
+    L.dtrl_last_error.restype = C.c_char_p
+    L.dtrl_last_error.argtypes = [vp]
+    L.dtrl_version.restype = C.c_char_p
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class BatchScenario:
+    """N reference-shaped scenarios (cScenarioExp / cScenarioPoliEval / cScenarioSimChar) stepped as one batch on one GPU."""
+
+    def __init__(self, arg_file=None, num_envs=1, data_root=None, device_id=-1, extra_args=None, _lib_path=None):
+        self._lib = _bind(_lib_path or LIB_PATH)
+        argv = []
+        if extra_args:
+            for k, v in extra_args.items():
+                argv += ["-%s=" % k, str(v)]
+        if data_root is not None:
+            argv += ["-data_root=", str(data_root)]
+        if arg_file is not None:
+            argv += ["-arg_file=", str(arg_file)]
+        arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+        h = C.c_void_p()
+        rc = self._lib.dtrl_create(arr, len(argv), int(num_envs), int(device_id), C.byref(h))
+        if rc != DTRL_OK:
+            raise DtrlError("dtrl_create failed (%d): %s" % (rc, self._lib.dtrl_last_error(None).decode()))
+        self._h = h
+        self.num_envs = int(num_envs)
+        d = [C.c_int() for _ in range(8)]
+        self._lib.dtrl_dims(self._h, *[C.byref(x) for x in d])
+        self.L, self.D, self.S, self.A, self.P, self.nn_out, self.num_frags, self.frag_size = (x.value for x in d)
+        self.W = 1 + 2 * self.S + self.A
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dtrl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != DTRL_OK:
+            raise DtrlError("dtrl call failed (%d): %s" % (rc, self._lib.dtrl_last_error(self._h).decode()))
+
+    def _ids(self, env_ids):
+        if env_ids is None:
+            return None, self.num_envs
+        a = np.ascontiguousarray(env_ids, np.int32)
+        return a, len(a)
+
+    # ---- cScenario interface ----
+    def Update(self, dt=1.0 / 30.0):
+        self._chk(self._lib.dtrl_step(self._h, float(dt)))
+
+    def StepUpdates(self, n):
+        self._chk(self._lib.dtrl_step_updates(self._h, int(n)))
+
+    def RunFrames(self, frames, dt=1.0 / 30.0):
+        self._chk(self._lib.dtrl_run_frames(self._h, int(frames), float(dt)))
+
+    def Reset(self, env_ids=None, terrain_seeds=None):
+        ids, n = self._ids(env_ids)
+        seeds = None if terrain_seeds is None else np.ascontiguousarray(terrain_seeds, np.uint64)
+        self._chk(self._lib.dtrl_reset(self._h, _p(ids), n, _p(seeds)))
+
+    def SetPolicy(self, weights, in_off=None, in_scale=None, out_off=None, out_scale=None):
+        w = np.ascontiguousarray(weights, np.float32)
+        arrs = [None if a is None else np.ascontiguousarray(a, np.float64) for a in (in_off, in_scale, out_off, out_scale)]
+        self._chk(self._lib.dtrl_set_policy(self._h, _p(w), w.size, *[_p(a) for a in arrs]))
+
+    def PolicyNumParams(self):
+        n = C.c_size_t()
+        self._chk(self._lib.dtrl_policy_num_params(self._h, C.byref(n)))
+        return n.value
+
+    def BuildNNOutputOffsetScale(self):
+        off = np.zeros(self.nn_out); sc = np.zeros(self.nn_out)
+        self._chk(self._lib.dtrl_build_output_offset_scale(self._h, _p(off), _p(sc)))
+        return off, sc
+
+    def SetExplore(self, enable, rate, temp, base_rate):
+        self._chk(self._lib.dtrl_set_explore(self._h, int(enable), float(rate), float(temp), float(base_rate)))
+
+    def SetTerrainParamsLerp(self, lerp):
+        self._chk(self._lib.dtrl_set_terrain_lerp(self._h, float(lerp)))
+
+    def DrainTuples(self, cap=None):
+        cap = cap or max(2 * self.num_envs, 64)
+        rows = np.zeros((cap, self.W), np.float32); fl = np.zeros(cap, np.uint32); ids = np.zeros(cap, np.int32); n = C.c_int()
+        self._chk(self._lib.dtrl_drain_tuples(self._h, _p(rows), _p(fl), _p(ids), cap, C.byref(n)))
+        return rows[:n.value], fl[:n.value], ids[:n.value]
+
+    # ---- character / controller observability ----
+    def PoseVel(self, env_ids=None):
+        ids, n = self._ids(env_ids)
+        q = np.zeros((n, self.D)); qd = np.zeros((n, self.D))
+        self._chk(self._lib.dtrl_get_pose_vel(self._h, _p(ids), n, _p(q), _p(qd)))
+        return q, qd
+
+    def BuildPose(self, env_ids=None):
+        return self.PoseVel(env_ids)[0]
+
+    def BuildVel(self, env_ids=None):
+        return self.PoseVel(env_ids)[1]
+
+    def SetPoseVel(self, q, qd, env_ids=None):
+        ids, n = self._ids(env_ids)
+        q = np.ascontiguousarray(q, np.float64).reshape(n, self.D); qd = np.ascontiguousarray(qd, np.float64).reshape(n, self.D)
+        self._chk(self._lib.dtrl_set_pose_vel(self._h, _p(ids), n, _p(q), _p(qd)))
+
+    def RecordPoliState(self, env_ids=None):
+        ids, n = self._ids(env_ids)
+        s = np.zeros((n, self.S))
+        self._chk(self._lib.dtrl_get_poli_state(self._h, _p(ids), n, _p(s)))
+        return s
+
+    def Flags(self, env_ids=None):
+        ids, n = self._ids(env_ids)
+        f = np.zeros(n, np.uint32)
+        self._chk(self._lib.dtrl_get_flags(self._h, _p(ids), n, _p(f)))
+        return f
+
+    def Torques(self, env_ids=None):
+        ids, n = self._ids(env_ids)
+        a = np.zeros((n, self.D)); b = np.zeros((n, self.D))
+        self._chk(self._lib.dtrl_get_torques(self._h, _p(ids), n, _p(a), _p(b)))
+        return a, b
+
+    def Contacts(self, env_ids=None):
+        ids, n = self._ids(env_ids)
+        f = np.zeros((n, self.L), np.int32)
+        self._chk(self._lib.dtrl_get_contacts(self._h, _p(ids), n, _p(f)))
+        return f
+
+    def Ctrl(self, env_ids=None):
+        ids, n = self._ids(env_ids)
+        st = np.zeros(n, np.int32); ph = np.zeros(n); aid = np.zeros(n, np.int32); prm = np.zeros((n, self.P)); tg = np.zeros((n, self.L))
+        self._chk(self._lib.dtrl_get_ctrl(self._h, _p(ids), n, _p(st), _p(ph), _p(aid), _p(prm), _p(tg)))
+        return st, ph, aid, prm, tg
+
+    def SampleGround(self, env, xs):
+        xs = np.ascontiguousarray(xs, np.float64); n = len(xs)
+        h = np.zeros(n); seg = np.zeros(n, np.int32); i = np.zeros(n, np.int32); j = np.zeros(n, np.int32)
+        self._chk(self._lib.dtrl_sample_ground(self._h, int(env), n, _p(xs), _p(h), _p(seg), _p(i), _p(j)))
+        return h, seg, i, j
+
+    def EvalStats(self):
+        a = C.c_double(); e, c, r = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self._lib.dtrl_eval_stats(self._h, C.byref(a), C.byref(e), C.byref(c), C.byref(r)))
+        return {"avg_dist": a.value, "episodes": e.value, "cycles": c.value, "resets": r.value}
+
+    def KernelTimeMs(self):
+        a = C.c_double(); n = C.c_int64()
+        self._chk(self._lib.dtrl_kernel_time_ms(self._h, C.byref(a), C.byref(n)))
+        return a.value, n.value
+
+
+def version():
+    return _bind(LIB_PATH).dtrl_version().decode()

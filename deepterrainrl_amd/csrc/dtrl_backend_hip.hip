@@ -1,0 +1,79 @@
+// dtrl_backend_hip.hip -- the product backend: HIP runtime + the gfx950 frame kernel.
+//
+// Launch geometry: one 64-lane wavefront (one workgroup) per environment, so every __syncthreads() in the lane-phase
+// code is a single-wave barrier; a 4096-env batch is 4096 workgroups (16 per CU), enough to fill all 256 CUs / 8 XCDs.
+// Workgroup b lands on XCD b % 8 (observed dispatch order), i.e. consecutive envs spread across XCDs and each XCD's L2
+// holds only its own envs' state/terrain records -- the per-env records are private, nothing is shared between XCDs
+// except the read-only model and policy weights.
+#include "dtrl_engine.h"
+#include <hip/hip_runtime.h>
+#include <vector>
+
+namespace dtrl {
+
+__global__ void __launch_bounds__(kGroup) dtrl_frame_kernel(const DevModel* __restrict__ gm, RunParams rp, DevBuffers buf, int n_envs, int n_steps, real dt, int frame_end)
+{
+	__shared__ WS ws;
+	const int env = static_cast<int>(blockIdx.x);
+	if (env >= n_envs) return;
+	env_frame(ws, *gm, rp, buf, env, n_steps, dt, frame_end != 0);
+}
+
+class HipBackend : public Backend {
+public:
+	~HipBackend() override
+	{
+		for (auto& ev : events_) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+		if (stream_) hipStreamDestroy(stream_);
+	}
+	bool Init(int device_id, std::string& err) override
+	{
+		int count = 0;
+		hipError_t e = hipGetDeviceCount(&count);
+		if (e != hipSuccess || count <= 0) { err = std::string("no usable HIP device (") + hipGetErrorString(e) + "); the engine has no CPU fallback"; return false; }
+		if (device_id >= 0) { e = hipSetDevice(device_id); if (e != hipSuccess) { err = std::string("hipSetDevice: ") + hipGetErrorString(e); return false; } }
+		e = hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
+		if (e != hipSuccess) { err = std::string("hipStreamCreate: ") + hipGetErrorString(e); return false; }
+		return true;
+	}
+	void* Alloc(size_t bytes) override
+	{
+		void* p = nullptr;
+		if (!Check(hipMalloc(&p, bytes), "hipMalloc")) return nullptr;
+		if (!Check(hipMemsetAsync(p, 0, bytes, stream_), "hipMemset")) return nullptr;
+		return p;
+	}
+	void Free(void* p) override { hipFree(p); }
+	bool H2D(void* dst, const void* src, size_t n) override { return Check(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream_), "hipMemcpy H2D") && Check(hipStreamSynchronize(stream_), "sync"); }
+	bool D2H(void* dst, const void* src, size_t n) override { return Check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream_), "hipMemcpy D2H") && Check(hipStreamSynchronize(stream_), "sync"); }
+	bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) override
+	{
+		std::pair<hipEvent_t, hipEvent_t> ev;
+		if (free_events_.empty()) { hipEventCreate(&ev.first); hipEventCreate(&ev.second); events_.push_back(ev); }
+		else { ev = free_events_.back(); free_events_.pop_back(); }
+		hipEventRecord(ev.first, stream_);
+		hipLaunchKernelGGL(dtrl_frame_kernel, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
+		hipEventRecord(ev.second, stream_);
+		pending_.push_back(ev);
+		return Check(hipGetLastError(), "kernel launch");
+	}
+	bool Sync() override { return Check(hipStreamSynchronize(stream_), "hipStreamSynchronize"); }
+	void KernelTime(double* avg_ms, int64_t* launches) override
+	{
+		hipStreamSynchronize(stream_);
+		double sum = 0; int64_t n = 0;
+		for (auto& ev : pending_) { float ms = 0; if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { sum += ms; ++n; } free_events_.push_back(ev); }
+		pending_.clear();
+		if (avg_ms) *avg_ms = n > 0 ? sum / n : 0.0;
+		if (launches) *launches = n;
+	}
+	const char* Name() const override { return "hip"; }
+private:
+	bool Check(hipError_t e, const char* what) { if (e == hipSuccess) return true; err_ = std::string(what) + ": " + hipGetErrorString(e); return false; }
+	hipStream_t stream_ = nullptr;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> events_, free_events_, pending_;
+};
+
+Backend* MakeBackend() { return new HipBackend(); }
+
+}  // namespace dtrl

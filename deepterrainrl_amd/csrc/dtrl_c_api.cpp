@@ -1,0 +1,146 @@
+// dtrl_c_api.cpp -- extern "C" surface declared in include/dtrl.h; thin wrappers over dtrl::Engine.
+#include "../../include/dtrl.h"
+#include "dtrl_engine.h"
+#include <new>
+
+using dtrl::Engine;
+using dtrl::EnvState;
+
+struct dtrl_batch { Engine eng; };
+
+static thread_local std::string g_create_error;
+
+extern "C" {
+
+const char* dtrl_version(void) { return "dtrl-mi355x 0.1 (round 1)"; }
+
+const char* dtrl_last_error(const dtrl_batch* b) { return b ? b->eng.error().c_str() : g_create_error.c_str(); }
+
+dtrl_status dtrl_create(const char* const* argv, int argc, int num_envs, int device_id, dtrl_batch** out)
+{
+	if (!out) return DTRL_ERR_ARG;
+	*out = nullptr;
+	dtrl_batch* b = new (std::nothrow) dtrl_batch();
+	if (!b) return DTRL_ERR_DEVICE;
+	int rc = b->eng.Create(argv, argc, num_envs, device_id);
+	if (rc != DTRL_OK) { g_create_error = b->eng.error(); delete b; return static_cast<dtrl_status>(rc); }
+	*out = b;
+	return DTRL_OK;
+}
+dtrl_status dtrl_destroy(dtrl_batch* b) { delete b; return DTRL_OK; }
+
+#define CHECK_B() do { if (!b) return DTRL_ERR_ARG; } while (0)
+
+dtrl_status dtrl_reset(dtrl_batch* b, const int32_t* env_ids, int n, const uint64_t* seeds) { CHECK_B(); return static_cast<dtrl_status>(b->eng.Reset(env_ids, n, seeds)); }
+dtrl_status dtrl_step(dtrl_batch* b, double dt) { CHECK_B(); return static_cast<dtrl_status>(b->eng.Step(dt)); }
+dtrl_status dtrl_step_updates(dtrl_batch* b, int n) { CHECK_B(); return static_cast<dtrl_status>(b->eng.StepUpdates(n)); }
+dtrl_status dtrl_run_frames(dtrl_batch* b, int frames, double dt) { CHECK_B(); return static_cast<dtrl_status>(b->eng.RunFrames(frames, dt)); }
+dtrl_status dtrl_set_policy(dtrl_batch* b, const float* w, size_t n, const double* io, const double* is, const double* oo, const double* os)
+{
+	CHECK_B(); return static_cast<dtrl_status>(b->eng.SetPolicy(w, n, io, is, oo, os));
+}
+dtrl_status dtrl_policy_num_params(const dtrl_batch* b, size_t* n)
+{
+	CHECK_B(); if (!b->eng.cfg().has_policy_net) { *n = 0; return DTRL_OK; }
+	*n = static_cast<size_t>(b->eng.cfg().net.num_params); return DTRL_OK;
+}
+dtrl_status dtrl_build_output_offset_scale(const dtrl_batch* b, double* out_off, double* out_scale)
+{
+	CHECK_B();
+	if (!b->eng.cfg().has_policy_net) return DTRL_ERR_ARG;
+	std::vector<double> off, sc;
+	dtrl::BuildOutputOffsetScale(b->eng.cfg().model, b->eng.cfg().net, off, sc);
+	for (size_t i = 0; i < off.size(); ++i) { out_off[i] = off[i]; out_scale[i] = sc[i]; }
+	return DTRL_OK;
+}
+dtrl_status dtrl_set_explore(dtrl_batch* b, int enable, double rate, double temp, double base_rate) { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetExplore(enable, rate, temp, base_rate)); }
+dtrl_status dtrl_set_terrain_lerp(dtrl_batch* b, double lerp) { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetTerrainLerp(lerp)); }
+dtrl_status dtrl_drain_tuples(dtrl_batch* b, float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n)
+{
+	CHECK_B(); return static_cast<dtrl_status>(b->eng.DrainTuples(rows, flags, env_ids, cap, out_n));
+}
+
+dtrl_status dtrl_get_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, double* q, double* qd)
+{
+	CHECK_B();
+	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
+	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
+	const int D = b->eng.cfg().model.D;
+	for (int i = 0; i < n; ++i) for (int k = 0; k < D; ++k) { if (q) q[i * D + k] = st[i].q[k]; if (qd) qd[i * D + k] = st[i].qd[k]; }
+	return DTRL_OK;
+}
+dtrl_status dtrl_set_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, const double* q, const double* qd) { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetPoseVel(env_ids, n, q, qd)); }
+dtrl_status dtrl_get_poli_state(dtrl_batch* b, const int32_t* env_ids, int n, double* s) { CHECK_B(); return static_cast<dtrl_status>(b->eng.GetPoliState(env_ids, n, s)); }
+
+dtrl_status dtrl_get_flags(dtrl_batch* b, const int32_t* env_ids, int n, uint32_t* bits)
+{
+	CHECK_B();
+	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
+	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
+	const int L = b->eng.cfg().model.L;
+	for (int i = 0; i < n; ++i) {
+		const EnvState& s = st[i];
+		bool flipped = std::fabs(dtrl::wrap_pi(s.q[2])) > 3.14159265358979323846 * 0.8;
+		bool fallen = s.sum_fall_contact > 0.25 || s.fail_fall_dist != 0 || flipped;
+		uint32_t stumble_mask = ~((1u << dtrl::jToe) | (1u << dtrl::jFinger) | (1u << dtrl::jAnkle) | (1u << dtrl::jWrist));
+		bool stumbled = (s.contact_bits & stumble_mask & ((1u << L) - 1u)) != 0;
+		bool new_cycle = s.state == 0 && s.phase == 0;
+		bits[i] = (fallen ? DTRL_FLAG_FALLEN : 0u) | (stumbled ? DTRL_FLAG_STUMBLED : 0u) | (new_cycle ? DTRL_FLAG_NEW_CYCLE : 0u) | (static_cast<uint32_t>(s.state) << DTRL_FLAG_STATE_SHIFT);
+	}
+	return DTRL_OK;
+}
+dtrl_status dtrl_get_torques(dtrl_batch* b, const int32_t* env_ids, int n, double* tau_ctrl, double* tau_applied)
+{
+	CHECK_B();
+	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
+	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
+	const int D = b->eng.cfg().model.D;
+	for (int i = 0; i < n; ++i) for (int k = 0; k < D; ++k) { if (tau_ctrl) tau_ctrl[i * D + k] = st[i].tau_ctrl[k]; if (tau_applied) tau_applied[i * D + k] = st[i].tau[k]; }
+	return DTRL_OK;
+}
+dtrl_status dtrl_get_contacts(dtrl_batch* b, const int32_t* env_ids, int n, int32_t* flags)
+{
+	CHECK_B();
+	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
+	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
+	const int L = b->eng.cfg().model.L;
+	for (int i = 0; i < n; ++i) for (int j = 0; j < L; ++j) flags[i * L + j] = (st[i].contact_bits >> j) & 1u;
+	return DTRL_OK;
+}
+dtrl_status dtrl_get_ctrl(dtrl_batch* b, const int32_t* env_ids, int n, int32_t* state, double* phase, int32_t* action_id, double* params, double* pd_targets)
+{
+	CHECK_B();
+	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
+	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
+	const int L = b->eng.cfg().model.L, P = b->eng.cfg().model.P;
+	for (int i = 0; i < n; ++i) {
+		if (state) state[i] = st[i].state;
+		if (phase) phase[i] = st[i].phase;
+		if (action_id) action_id[i] = st[i].action_id;
+		if (params) for (int k = 0; k < P; ++k) params[i * P + k] = st[i].params[k];
+		if (pd_targets) for (int j = 0; j < L; ++j) pd_targets[i * L + j] = st[i].pd_target[j];
+	}
+	return DTRL_OK;
+}
+dtrl_status dtrl_sample_ground(dtrl_batch* b, int env, int n, const double* x, double* h, int32_t* seg, int32_t* i, int32_t* j)
+{
+	CHECK_B(); return static_cast<dtrl_status>(b->eng.SampleGround(env, n, x, h, seg, i, j));
+}
+dtrl_status dtrl_eval_stats(dtrl_batch* b, double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets) { CHECK_B(); return static_cast<dtrl_status>(b->eng.EvalStats(avg_dist, episodes, cycles, resets)); }
+dtrl_status dtrl_dims(const dtrl_batch* b, int* L, int* D, int* S, int* A, int* P, int* nn_out, int* num_frags, int* frag_size)
+{
+	CHECK_B();
+	const dtrl::ScenarioConfig& c = b->eng.cfg();
+	if (L) *L = c.model.L;
+	if (D) *D = c.model.D;
+	if (S) *S = b->eng.S();
+	if (A) *A = b->eng.A();
+	if (P) *P = c.model.P;
+	if (nn_out) *nn_out = c.has_policy_net ? c.net.out_size : 0;
+	if (num_frags) *num_frags = c.has_policy_net ? c.net.n_frags : 0;
+	if (frag_size) *frag_size = c.model.n_opt;
+	return DTRL_OK;
+}
+dtrl_status dtrl_kernel_time_ms(dtrl_batch* b, double* avg_ms, int64_t* launches) { CHECK_B(); return static_cast<dtrl_status>(b->eng.KernelTime(avg_ms, launches)); }
+
+}  // extern "C"

@@ -1,0 +1,308 @@
+// dtrl_engine.cpp -- batch engine logic (host side of the frame loop). See dtrl_engine.h.
+//
+// Frame loop = cScenarioExp::Update / cScenarioPoliEval::Update over the whole batch
+// (scenarios/ScenarioExp.cpp:83-98, scenarios/ScenarioPoliEval.cpp:110-125):
+//   1. one kernel launch advances every env by num_update_steps env-steps and runs the end-of-frame fall logic;
+//   2. the host reads back 16 B per env (root x, reset request);
+//   3. envs that fell get a fresh terrain window (cScenarioSimChar::ResetGround, scenarios/ScenarioSimChar.cpp:574-583)
+//      and are flagged so the next launch performs the character/controller reset on device;
+//   4. every other env's window slides if the character came within view distance of its end
+//      (cScenarioSimChar::UpdateGround, :564-572). Doing this at frame boundaries instead of every env-step is
+//      equivalent because the window is rebuilt 1 m before any sample can reach its end (DESIGN.md "Ground").
+#include "dtrl_engine.h"
+#include "../../include/dtrl.h"
+#include <cstddef>
+#include <cstring>
+
+namespace dtrl {
+
+namespace {
+constexpr double kViewDist = 10.0;          // cCharController view distance (sim/TerrainRLCharController.cpp:12)
+constexpr double kGroundSpawnOffset = -1.0; // scenarios/ScenarioSimChar.cpp:19
+constexpr double kViewPad = 1.0;            // gCharViewDistPad, scenarios/ScenarioSimChar.cpp:18
+}
+
+Engine::~Engine()
+{
+	if (be_) {
+		be_->Sync();
+		for (void* p : allocs_) be_->Free(p);
+		delete be_;
+	}
+}
+
+int Engine::Create(const char* const* argv, int argc, int num_envs, int device_id)
+{
+	if (num_envs <= 0) return Fail(DTRL_ERR_ARG, "num_envs must be positive");
+	// optimizer/Main.cpp:19-32: command line first, then the arg file appended (first match wins -> command line overrides)
+	ArgParser args(argv, argc);
+	std::string arg_file;
+	if (args.ParseString("arg_file", arg_file)) {
+		std::string root; args.ParseString("data_root", root);
+		std::string path = (arg_file.empty() || arg_file[0] == '/' || root.empty()) ? arg_file : root + "/" + arg_file;
+		if (!args.AppendArgs(path)) return Fail(DTRL_ERR_IO, "Failed to load args from: " + path);
+	}
+	if (!LoadScenario(args, cfg_, err_)) return DTRL_ERR_IO;
+	n_ = num_envs;
+	const DevModel& m = cfg_.model;
+	S_ = kNumGroundSamples + (2 * m.L - 1) + 2 * m.L;   // sim/TerrainRLCharController.cpp:308-342
+	A_ = 1 + m.n_opt;                                   // sim/BaseControllerMACE.cpp:28-31
+	W_ = 1 + 2 * S_ + A_;                               // learning/MACETrainer.cpp:373-376
+
+	be_ = MakeBackend();
+	if (!be_->Init(device_id, err_)) return DTRL_ERR_NO_DEVICE;
+
+	auto alloc = [&](size_t bytes) -> void* { void* p = be_->Alloc(bytes); if (p) allocs_.push_back(p); return p; };
+	d_model_ = static_cast<DevModel*>(alloc(sizeof(DevModel)));
+	buf_.st = static_cast<EnvState*>(alloc(sizeof(EnvState) * n_));
+	buf_.gr = static_cast<GroundRec*>(alloc(sizeof(GroundRec) * n_));
+	buf_.status = static_cast<EnvStatus*>(alloc(sizeof(EnvStatus) * n_));
+	buf_.poli_state = static_cast<real*>(alloc(sizeof(real) * S_ * n_));
+	buf_.tup_s0 = static_cast<real*>(alloc(sizeof(real) * S_ * n_));
+	buf_.tup_a = static_cast<real*>(alloc(sizeof(real) * A_ * n_));
+	buf_.S = S_; buf_.A = A_; buf_.W = W_;
+	// a tuple per env per cycle (~13 frames) at most; room for 2 per env between drains, at least the reference's ring size
+	buf_.tuple_cap = std::max(2 * n_, cfg_.tuple_buffer_size);
+	buf_.tuple_rows = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(W_) * buf_.tuple_cap));
+	buf_.tuple_flags = static_cast<uint32_t*>(alloc(sizeof(uint32_t) * buf_.tuple_cap));
+	buf_.tuple_env = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
+	buf_.tuple_count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));
+	if (!d_model_ || !buf_.st || !buf_.gr || !buf_.status || !buf_.poli_state || !buf_.tup_s0 || !buf_.tup_a || !buf_.tuple_rows || !buf_.tuple_flags || !buf_.tuple_env || !buf_.tuple_count)
+		return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
+	if (cfg_.has_policy_net) {
+		const NetDesc& d = cfg_.net;
+		buf_.net = d;
+		int cin = 1, w = d.n_terrain, mx = d.n_terrain;
+		for (int l = 0; l < 3; ++l) { w = w - d.conv_k[l] + 1; cin = d.conv_ch[l]; mx = std::max(mx, cin * w); }
+		mx = std::max(mx, d.fc_trunk + d.fc_head);
+		buf_.nn_scratch_stride = ((mx + d.fc_terr + d.n_char + 63) / 64) * 64;
+		buf_.nn_scratch = static_cast<real*>(alloc(sizeof(real) * 2 * static_cast<size_t>(buf_.nn_scratch_stride) * n_));
+		buf_.nn_out = static_cast<real*>(alloc(sizeof(real) * static_cast<size_t>(d.out_size) * n_));
+		float* w_dev = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(d.num_params)));
+		real* io = static_cast<real*>(alloc(sizeof(real) * d.in_size)); real* is = static_cast<real*>(alloc(sizeof(real) * d.in_size));
+		real* oo = static_cast<real*>(alloc(sizeof(real) * d.out_size)); real* os = static_cast<real*>(alloc(sizeof(real) * d.out_size));
+		if (!buf_.nn_scratch || !buf_.nn_out || !w_dev || !io || !is || !oo || !os) return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
+		buf_.weights = w_dev; buf_.in_off = io; buf_.in_scale = is; buf_.out_off = oo; buf_.out_scale = os;
+		cfg_.model.has_net = 1;
+	}
+	if (!be_->H2D(d_model_, &cfg_.model, sizeof(DevModel))) return Fail(DTRL_ERR_DEVICE, be_->error());
+
+	// per-env grounds: cGroundVar2D seeded per env (terrain_seed + global env id) so a trajectory is shard-invariant
+	grounds_.resize(n_);
+	status_.resize(n_);
+	double params[kNumTerrainParams];
+	LerpTerrainParams(cfg_, cfg_.terrain_blend, params);
+	std::vector<GroundRec> recs(n_);
+	for (int e = 0; e < n_; ++e) {
+		GroundWindow& g = grounds_[e];
+		g.Configure(cfg_.terrain_type, params, cfg_.model.world_scale, 2 * kViewDist);
+		g.SeedRand(static_cast<unsigned long>(cfg_.terrain_seed + static_cast<uint64_t>(cfg_.run.env_id_base) + e));
+		g.InitSegments(-kViewDist + kGroundSpawnOffset, kViewDist + kGroundSpawnOffset);   // scenarios/ScenarioSimChar.cpp:344-369
+		if (!g.FillRecord(recs[e], err_)) return DTRL_ERR_CAPACITY;
+	}
+	if (!be_->H2D(buf_.gr, recs.data(), sizeof(GroundRec) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	std::vector<EnvState> st(n_);
+	std::memset(st.data(), 0, sizeof(EnvState) * n_);
+	for (int e = 0; e < n_; ++e) { st[e].do_init = 1; st[e].cmd_action = -1; }
+	if (!be_->H2D(buf_.st, st.data(), sizeof(EnvState) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	return DTRL_OK;
+}
+
+bool Engine::UploadGround(int env)
+{
+	if (!grounds_[env].FillRecord(tmp_rec_, err_)) return false;
+	if (!be_->H2D(&buf_.gr[env], &tmp_rec_, sizeof(GroundRec))) { err_ = be_->error(); return false; }
+	return true;
+}
+
+int Engine::HostFrameWork()
+{
+	if (!be_->D2H(status_.data(), buf_.status, sizeof(EnvStatus) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	const int32_t one = 1;
+	for (int e = 0; e < n_; ++e) {
+		const EnvStatus& s = status_[e];
+		GroundWindow& g = grounds_[e];
+		if (s.need_reset) {
+			// cScenarioSimChar::ResetGround: Clear + Update around the spawn point -> InitSegments with the SAME rng stream
+			g.Clear();
+			g.Update(-kViewDist + kGroundSpawnOffset, kViewDist + kGroundSpawnOffset);
+			if (!UploadGround(e)) return DTRL_ERR_CAPACITY;
+			if (!be_->H2D(reinterpret_cast<char*>(&buf_.st[e]) + offsetof(EnvState, do_reset), &one, sizeof(one))) return Fail(DTRL_ERR_DEVICE, be_->error());
+		} else if (g.Update(s.root_x - 2, s.root_x + kViewDist + kViewPad)) {
+			if (!UploadGround(e)) return DTRL_ERR_CAPACITY;
+		}
+	}
+	return DTRL_OK;
+}
+
+int Engine::Step(double dt)
+{
+	if (dt <= 0) return DTRL_OK;   // cScenarioSimChar::Update returns early (scenarios/ScenarioSimChar.cpp:148-151)
+	if (cfg_.model.has_net && !policy_set_) return Fail(DTRL_ERR_ARG, "policy_net was given but dtrl_set_policy has not been called");
+	const int steps = cfg_.model.num_update_steps;
+	if (!be_->Launch(d_model_, cfg_.run, buf_, n_, steps, dt / steps, true)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	return HostFrameWork();
+}
+
+int Engine::StepUpdates(int n)
+{
+	if (n <= 0) return DTRL_OK;
+	if (cfg_.model.has_net && !policy_set_) return Fail(DTRL_ERR_ARG, "policy_net was given but dtrl_set_policy has not been called");
+	const double dt = (1.0 / 30.0) / cfg_.model.num_update_steps;
+	if (!be_->Launch(d_model_, cfg_.run, buf_, n_, n, dt, false)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	return HostFrameWork();
+}
+
+int Engine::RunFrames(int frames, double dt)
+{
+	for (int f = 0; f < frames; ++f) { int rc = Step(dt); if (rc != DTRL_OK) return rc; }
+	return DTRL_OK;
+}
+
+int Engine::Reset(const int32_t* env_ids, int n, const uint64_t* seeds)
+{
+	const int cnt = env_ids ? n : n_;
+	const int32_t one = 1;
+	for (int i = 0; i < cnt; ++i) {
+		int e = EnvIndex(env_ids, i);
+		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
+		GroundWindow& g = grounds_[e];
+		if (seeds) g.SeedRand(static_cast<unsigned long>(seeds[i]));
+		g.Clear();
+		g.Update(-kViewDist + kGroundSpawnOffset, kViewDist + kGroundSpawnOffset);
+		if (!UploadGround(e)) return DTRL_ERR_CAPACITY;
+		if (!be_->H2D(reinterpret_cast<char*>(&buf_.st[e]) + offsetof(EnvState, do_reset), &one, sizeof(one))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	}
+	// perform the device-side part now so getters observe the reset state (0 env-steps)
+	if (!be_->Launch(d_model_, cfg_.run, buf_, n_, 0, 0.0, false)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!be_->Sync()) return Fail(DTRL_ERR_DEVICE, be_->error());
+	return DTRL_OK;
+}
+
+int Engine::SetPolicy(const float* w, size_t n, const double* io, const double* is, const double* oo, const double* os)
+{
+	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
+	const NetDesc& d = cfg_.net;
+	if (n != static_cast<size_t>(d.num_params)) return Fail(DTRL_ERR_ARG, "weight count does not match the deploy prototxt");
+	be_->Sync();
+	std::vector<double> ones_i(d.in_size, 1.0), zeros_i(d.in_size, 0.0), ones_o(d.out_size, 1.0), zeros_o(d.out_size, 0.0);
+	// cNeuralNet without a scale file: identity normalisation (learning/NeuralNet.cpp:925-933)
+	bool ok = be_->H2D(const_cast<float*>(buf_.weights), w, sizeof(float) * n)
+		&& be_->H2D(const_cast<real*>(buf_.in_off), io ? io : zeros_i.data(), sizeof(real) * d.in_size)
+		&& be_->H2D(const_cast<real*>(buf_.in_scale), is ? is : ones_i.data(), sizeof(real) * d.in_size)
+		&& be_->H2D(const_cast<real*>(buf_.out_off), oo ? oo : zeros_o.data(), sizeof(real) * d.out_size)
+		&& be_->H2D(const_cast<real*>(buf_.out_scale), os ? os : ones_o.data(), sizeof(real) * d.out_size);
+	if (!ok) return Fail(DTRL_ERR_DEVICE, be_->error());
+	policy_set_ = true;
+	return DTRL_OK;
+}
+
+int Engine::SetExplore(int enable, double rate, double temp, double base_rate)
+{
+	cfg_.run.enable_exp = enable ? 1 : 0; cfg_.run.exp_rate = rate; cfg_.run.exp_temp = temp; cfg_.run.exp_base_rate = base_rate;
+	return DTRL_OK;
+}
+
+int Engine::SetTerrainLerp(double lerp)
+{
+	double params[kNumTerrainParams];
+	LerpTerrainParams(cfg_, lerp, params);
+	for (GroundWindow& g : grounds_) g.SetParams(params);   // takes effect at the next segment build, as in the reference
+	return DTRL_OK;
+}
+
+int Engine::DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n)
+{
+	int32_t cnt = 0;
+	be_->Sync();
+	if (!be_->D2H(&cnt, buf_.tuple_count, sizeof(cnt))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (cnt > buf_.tuple_cap) cnt = buf_.tuple_cap;   // overflowed tuples were dropped by the kernel
+	int n = std::min<int>(cnt, cap);
+	if (n > 0) {
+		if (!be_->D2H(rows, buf_.tuple_rows, sizeof(float) * static_cast<size_t>(W_) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (flags && !be_->D2H(flags, buf_.tuple_flags, sizeof(uint32_t) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (env_ids && !be_->D2H(env_ids, buf_.tuple_env, sizeof(int32_t) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	}
+	if (n < cnt) return Fail(DTRL_ERR_CAPACITY, "caller buffer smaller than the number of pending tuples");
+	const int32_t zero = 0;
+	if (!be_->H2D(buf_.tuple_count, &zero, sizeof(zero))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	*out_n = n;
+	return DTRL_OK;
+}
+
+int Engine::GetStates(const int32_t* env_ids, int n, std::vector<EnvState>& out)
+{
+	be_->Sync();
+	out.resize(n);
+	if (!env_ids) {
+		if (n > n_) return Fail(DTRL_ERR_ARG, "env id out of range");
+		if (!be_->D2H(out.data(), buf_.st, sizeof(EnvState) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+		return DTRL_OK;
+	}
+	for (int i = 0; i < n; ++i) {
+		int e = env_ids[i];
+		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
+		if (!be_->D2H(&out[i], &buf_.st[e], sizeof(EnvState))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	}
+	return DTRL_OK;
+}
+
+int Engine::SetPoseVel(const int32_t* env_ids, int n, const double* q, const double* qd)
+{
+	be_->Sync();
+	const int D = cfg_.model.D;
+	EnvState st;
+	for (int i = 0; i < n; ++i) {
+		int e = EnvIndex(env_ids, i);
+		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
+		if (!be_->D2H(&st, &buf_.st[e], sizeof(EnvState))) return Fail(DTRL_ERR_DEVICE, be_->error());
+		for (int k = 0; k < D; ++k) { st.q[k] = q[i * D + k]; st.qd[k] = qd[i * D + k]; }
+		if (!be_->H2D(&buf_.st[e], &st, sizeof(EnvState))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	}
+	return DTRL_OK;
+}
+
+int Engine::GetPoliState(const int32_t* env_ids, int n, double* s)
+{
+	be_->Sync();
+	for (int i = 0; i < n; ++i) {
+		int e = EnvIndex(env_ids, i);
+		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
+		if (!be_->D2H(s + static_cast<size_t>(i) * S_, buf_.poli_state + static_cast<size_t>(e) * S_, sizeof(real) * S_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	}
+	return DTRL_OK;
+}
+
+int Engine::SampleGround(int env, int n, const double* x, double* h, int32_t* seg, int32_t* oi, int32_t* oj)
+{
+	if (env < 0 || env >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
+	be_->Sync();
+	// reads back the DEVICE copy of the env's ground record and applies the same sampling routine the kernel uses
+	if (!be_->D2H(&tmp_rec_, &buf_.gr[env], sizeof(GroundRec))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	for (int i = 0; i < n; ++i) {
+		int a, b, s;
+		h[i] = sample_ground(tmp_rec_, x[i], nullptr, &a, &b, &s);
+		if (seg) seg[i] = s;
+		if (oi) oi[i] = a;
+		if (oj) oj[i] = b;
+	}
+	return DTRL_OK;
+}
+
+int Engine::EvalStats(double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets)
+{
+	std::vector<EnvState> st;
+	int rc = GetStates(nullptr, n_, st);
+	if (rc != DTRL_OK) return rc;
+	double sum = 0; int64_t ep = 0, cy = 0, rs = 0;
+	for (const EnvState& s : st) { sum += s.avg_dist * s.num_episodes; ep += s.num_episodes; cy += s.num_cycles; rs += s.num_resets; }
+	if (avg_dist) *avg_dist = ep > 0 ? sum / ep : 0.0;
+	if (episodes) *episodes = ep;
+	if (cycles) *cycles = cy;
+	if (resets) *resets = rs;
+	return DTRL_OK;
+}
+
+int Engine::KernelTime(double* avg_ms, int64_t* launches) { be_->KernelTime(avg_ms, launches); return DTRL_OK; }
+
+}  // namespace dtrl

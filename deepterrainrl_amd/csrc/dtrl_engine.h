@@ -1,0 +1,76 @@
+// dtrl_engine.h -- batch engine: owns the device slabs, the per-env ground windows and the frame loop.
+// The backend interface isolates the HIP runtime (dtrl_backend_hip.hip) from the engine logic so that the same logic can
+// be unit-tested on a CPU-only box against the lane-loop build of the kernel math (csrc/emul/, tests only).
+#pragma once
+#include "dtrl_host.h"
+#include "dtrl_kernel.h"
+#include <string>
+#include <vector>
+
+namespace dtrl {
+
+class Backend {
+public:
+	virtual ~Backend() {}
+	virtual bool Init(int device_id, std::string& err) = 0;
+	virtual void* Alloc(size_t bytes) = 0;   // zero-filled
+	virtual void Free(void* p) = 0;
+	virtual bool H2D(void* dst, const void* src, size_t n) = 0;
+	virtual bool D2H(void* dst, const void* src, size_t n) = 0;
+	virtual bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) = 0;
+	virtual bool Sync() = 0;
+	virtual void KernelTime(double* avg_ms, int64_t* launches) = 0;
+	virtual const char* Name() const = 0;
+	const std::string& error() const { return err_; }
+protected:
+	std::string err_;
+};
+Backend* MakeBackend();   // resolved at link time: HIP in libdtrl.so, lane-loop in the test-only libdtrl_emul.so
+
+class Engine {
+public:
+	Engine() {}
+	~Engine();
+	int Create(const char* const* argv, int argc, int num_envs, int device_id);
+	int Reset(const int32_t* env_ids, int n, const uint64_t* seeds);
+	int Step(double dt);
+	int StepUpdates(int n);
+	int RunFrames(int frames, double dt);
+	int SetPolicy(const float* w, size_t n, const double* io, const double* is, const double* oo, const double* os);
+	int SetExplore(int enable, double rate, double temp, double base_rate);
+	int SetTerrainLerp(double lerp);
+	int DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n);
+	int GetStates(const int32_t* env_ids, int n, std::vector<EnvState>& out);
+	int SetPoseVel(const int32_t* env_ids, int n, const double* q, const double* qd);
+	int GetPoliState(const int32_t* env_ids, int n, double* s);
+	int SampleGround(int env, int n, const double* x, double* h, int32_t* seg, int32_t* oi, int32_t* oj);
+	int EvalStats(double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets);
+	int KernelTime(double* avg_ms, int64_t* launches);
+
+	const ScenarioConfig& cfg() const { return cfg_; }
+	int num_envs() const { return n_; }
+	int S() const { return S_; }
+	int A() const { return A_; }
+	const std::string& error() const { return err_; }
+	void set_error(const std::string& e) { err_ = e; }
+
+private:
+	int Fail(int code, const std::string& msg) { err_ = msg; return code; }
+	int HostFrameWork();
+	bool UploadGround(int env);
+	int EnvIndex(const int32_t* env_ids, int i) const { return env_ids ? env_ids[i] : i; }
+
+	ScenarioConfig cfg_;
+	Backend* be_ = nullptr;
+	int n_ = 0, S_ = 0, A_ = 0, W_ = 0;
+	bool policy_set_ = false;
+	DevModel* d_model_ = nullptr;
+	DevBuffers buf_{};
+	std::vector<void*> allocs_;
+	std::vector<GroundWindow> grounds_;
+	std::vector<EnvStatus> status_;
+	GroundRec tmp_rec_;
+	std::string err_;
+};
+
+}  // namespace dtrl

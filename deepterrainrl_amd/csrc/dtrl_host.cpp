@@ -1,0 +1,664 @@
+// dtrl_host.cpp -- see dtrl_host.h. Reference citations are file:line relative to the reference repo root.
+#include "dtrl_host.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <regex>
+#include <sstream>
+
+namespace dtrl {
+
+// =====================================================================================================================
+// JSON
+namespace {
+struct JsonParser {
+	const std::string& s; size_t p = 0; std::string err;
+	explicit JsonParser(const std::string& t) : s(t) {}
+	void ws() { while (p < s.size() && (s[p] == ' ' || s[p] == '\t' || s[p] == '\n' || s[p] == '\r')) ++p; }
+	bool fail(const char* m) { if (err.empty()) { err = std::string(m) + " at offset " + std::to_string(p); } return false; }
+	bool value(Json& out)
+	{
+		ws();
+		if (p >= s.size()) return fail("unexpected end");
+		char c = s[p];
+		if (c == '{') {
+			out.type = Json::kObj; ++p; ws();
+			if (p < s.size() && s[p] == '}') { ++p; return true; }
+			while (true) {
+				ws(); Json key;
+				if (p >= s.size() || s[p] != '"' || !string(key.str)) return fail("expected key");
+				ws(); if (p >= s.size() || s[p] != ':') return fail("expected ':'");
+				++p; Json v; if (!value(v)) return false;
+				out.obj.emplace_back(key.str, std::move(v));
+				ws(); if (p < s.size() && s[p] == ',') { ++p; continue; }
+				if (p < s.size() && s[p] == '}') { ++p; return true; }
+				return fail("expected ',' or '}'");
+			}
+		}
+		if (c == '[') {
+			out.type = Json::kArr; ++p; ws();
+			if (p < s.size() && s[p] == ']') { ++p; return true; }
+			while (true) {
+				Json v; if (!value(v)) return false;
+				out.arr.push_back(std::move(v));
+				ws(); if (p < s.size() && s[p] == ',') { ++p; continue; }
+				if (p < s.size() && s[p] == ']') { ++p; return true; }
+				return fail("expected ',' or ']'");
+			}
+		}
+		if (c == '"') { out.type = Json::kStr; return string(out.str); }
+		if (s.compare(p, 4, "true") == 0) { out.type = Json::kBool; out.b = true; p += 4; return true; }
+		if (s.compare(p, 5, "false") == 0) { out.type = Json::kBool; out.b = false; p += 5; return true; }
+		if (s.compare(p, 4, "null") == 0) { out.type = Json::kNull; p += 4; return true; }
+		char* end = nullptr;
+		double v = std::strtod(s.c_str() + p, &end);
+		if (end == s.c_str() + p) return fail("bad value");
+		out.type = Json::kNum; out.num = v; p = static_cast<size_t>(end - s.c_str());
+		return true;
+	}
+	bool string(std::string& out)
+	{
+		++p; out.clear();
+		while (p < s.size() && s[p] != '"') {
+			if (s[p] == '\\' && p + 1 < s.size()) { char e = s[p + 1]; out += (e == 'n' ? '\n' : e == 't' ? '\t' : e); p += 2; }
+			else out += s[p++];
+		}
+		if (p >= s.size()) return fail("unterminated string");
+		++p; return true;
+	}
+};
+}  // namespace
+
+const Json* Json::find(const std::string& key) const
+{
+	for (const auto& kv : obj) if (kv.first == key) return &kv.second;
+	return nullptr;
+}
+bool Json::parse(const std::string& text, Json& out, std::string& err)
+{
+	JsonParser jp(text);
+	if (!jp.value(out)) { err = jp.err; return false; }
+	return true;
+}
+bool Json::parse_file(const std::string& path, Json& out, std::string& err)
+{
+	std::ifstream f(path);
+	if (!f.is_open()) { err = "cannot open " + path; return false; }
+	std::stringstream ss; ss << f.rdbuf();
+	if (!parse(ss.str(), out, err)) { err = path + ": " + err; return false; }
+	return true;
+}
+
+// =====================================================================================================================
+// cArgParser (util/ArgParser.cpp)
+void ArgParser::AppendArgs(const char* const* args, int n) { for (int i = 0; i < n; ++i) mArgs.emplace_back(args[i]); }
+
+bool ArgParser::AppendArgs(const std::string& file)
+{
+	// util/ArgParser.cpp:42-108: character scanner; whitespace separates tokens, "//" starts a comment up to end of line,
+	// a single '/' followed by another character is kept as part of the token.
+	FILE* fp = std::fopen(file.c_str(), "r");
+	if (!fp) return false;
+	std::string tok; bool comment = false; int slashes = 0; int ch;
+	while ((ch = std::fgetc(fp)) != EOF) {
+		char c = static_cast<char>(ch);
+		if (!comment) {
+			if (c != '/' && slashes == 1) { tok += '/'; slashes = 0; }
+			if (c == ' ' || c == '\t' || c == '\n' || c == '\r') { if (!tok.empty()) { mArgs.push_back(tok); tok.clear(); } }
+			else if (c == '/') { if (++slashes >= 2) comment = true; }
+			else tok += c;
+		}
+		if (c == '\n') { comment = false; slashes = 0; }
+	}
+	if (!tok.empty()) mArgs.push_back(tok);
+	std::fclose(fp);
+	return true;
+}
+bool ArgParser::IsKey(const std::string& s) { return s.size() >= 3 && s[0] == '-' && s[s.size() - 1] == '='; }
+int ArgParser::FindKeyIndex(const std::string& key) const
+{
+	std::string k = key;
+	if (k.empty()) return -1;
+	if (k[0] != '-') k = "-" + k;
+	if (k[k.size() - 1] != '=') k += "=";
+	for (size_t i = 0; i < mArgs.size(); ++i) if (mArgs[i] == k) return static_cast<int>(i);
+	return -1;
+}
+bool ArgParser::ParseString(const std::string& key, std::string& out) const
+{
+	int i = FindKeyIndex(key);
+	if (i < 0 || i + 1 >= static_cast<int>(mArgs.size())) return false;
+	const std::string& v = mArgs[i + 1];
+	if (IsKey(v)) return false;
+	out = v; return true;
+}
+bool ArgParser::ParseInt(const std::string& key, int& out) const { std::string s; if (!ParseString(key, s)) return false; out = std::atoi(s.c_str()); return true; }
+bool ArgParser::ParseDouble(const std::string& key, double& out) const { std::string s; if (!ParseString(key, s)) return false; out = std::atof(s.c_str()); return true; }
+bool ArgParser::ParseBool(const std::string& key, bool& out) const
+{
+	std::string s; if (!ParseString(key, s)) return false;
+	if (s == "true" || s == "1" || s == "True" || s == "T" || s == "t") { out = true; return true; }
+	if (s == "false" || s == "0" || s == "False" || s == "F" || s == "f") { out = false; return true; }
+	return false;
+}
+
+// =====================================================================================================================
+// terrain generator (cTerrainGen2D). Strips are emitted through a small builder; the sequence of RNG draws and the
+// float/double conversions follow sim/TerrainGen2D.cpp:185-706 so profiles are bit-identical for a given seed.
+const char* const kTerrainTypeNames[kTerrTypeMax] = {"flat", "gaps", "steps", "walls", "bumps", "mixed", "narrow_gaps", "slopes", "slopes_gaps",
+	"slopes_steps", "slopes_walls", "slopes_mixed", "slopes_narrow_gaps", "cliffs"};
+const char* const kTerrainParamNames[kNumTerrainParams] = {
+	"GapSpacingMin", "GapSpacingMax", "GapWMin", "GapWMax", "GapHMin", "GapHMax",
+	"WallSpacingMin", "WallSpacingMax", "WallWMin", "WallWMax", "WallHMin", "WallHMax",
+	"StepSpacingMin", "StepSpacingMax", "StepH0Min", "StepH0Max", "StepH1Min", "StepH1Max",
+	"BumpHMin", "BumpHMax",
+	"NarrowGapSpacingMin", "NarrowGapSpacingMax", "NarrowGapDistMin", "NarrowGapDistMax", "NarrowGapWMin", "NarrowGapWMax",
+	"NarrowGapDepthMin", "NarrowGapDepthMax", "NarrowGapCountMin", "NarrowGapCountMax",
+	"CliffSpacingMin", "CliffSpacingMax", "CliffH0Min", "CliffH0Max", "CliffH1Min", "CliffH1Max", "CliffMiniCountMax",
+	"SlopeDeltaRange", "SlopeDeltaMin", "SlopeDeltaMax"};
+const double kTerrainParamDefaults[kNumTerrainParams] = {4, 7, 0.5, 2, -2, -2, 6, 8, 0.2, 0.2, 0.25, 0.5, 5, 7, 0.1, 0.4, -0.4, -0.1, 0, 0.03,
+	3, 6, 0.1, 0.4, 0.15, 0.5, -2, -2, 1, 4, 5, 7, 0.1, 0.4, -0.4, -0.1, 0, 0.25, -0.35, 0.35};
+
+namespace {
+enum { GSmin, GSmax, GWmin, GWmax, GHmin, GHmax, WSmin, WSmax, WWmin, WWmax, WHmin, WHmax, SSmin, SSmax, SH0min, SH0max, SH1min, SH1max,
+	BHmin, BHmax, NSmin, NSmax, NDmin, NDmax, NWmin, NWmax, NDpmin, NDpmax, NCmin, NCmax, CSmin, CSmax, CH0min, CH0max, CH1min, CH1max, CMini,
+	SlRange, SlMin, SlMax };
+
+const float kSpacing = 0.1f;  // cTerrainGen2D::gVertSpacing (float)
+
+// a run of vertices appended to a height strip; knows whether the strip started empty (first vertex is shared otherwise)
+struct Strip {
+	std::vector<float>& h;
+	explicit Strip(std::vector<float>& v) : h(v) {}
+	static int verts_for(double w) { return static_cast<int>(std::ceil(w / kSpacing)) + 1; }
+	// common prologue of AddFlat/AddBox/AddStep: hold the current height for `w` metres; returns (n0, was_empty, base)
+	float hold(double w, size_t& n0, bool& empty)
+	{
+		int n = verts_for(w);
+		n0 = h.size(); empty = h.empty();
+		float base = 0;
+		if (!empty) { --n; base = h.back(); }
+		for (int i = 0; i < n; ++i) h.push_back(base);
+		return base;
+	}
+	double added(size_t n0, bool empty) const
+	{
+		int verts = static_cast<int>(h.size() - n0);
+		if (empty) --verts;
+		return verts * kSpacing;   // int * float -> float, widened on return (as in the reference)
+	}
+	double flat(double w) { size_t n0; bool e; hold(w, n0, e); return added(n0, e); }
+	double box(double spacing, double w, double depth)
+	{
+		size_t n0; bool e; float base = hold(spacing, n0, e);
+		int n = verts_for(w) - 1;
+		float lvl = static_cast<float>(base + depth);
+		for (int i = 0; i < n; ++i) h.push_back(lvl);
+		h.push_back(base);
+		return added(n0, e);
+	}
+	double step(double w, double dh)
+	{
+		size_t n0; bool e; float base = hold(w, n0, e);
+		h.push_back(static_cast<float>(base + dh));
+		return added(n0, e);
+	}
+};
+
+void overlay_slopes(const double* p, size_t beg, size_t end, TerrainRand& rnd, std::vector<float>& h)
+{
+	const double range = std::abs(p[SlRange]), mean = 0.5 * (p[SlMin] + p[SlMax]), half = 0.5 * (p[SlMax] - p[SlMin]);
+	double slope = 0, dh = 0;
+	for (size_t i = beg; i < end; ++i) {
+		double delta = rnd.RandDouble(0, range);
+		double sign_rand = rnd.RandDouble(-1, 1);
+		if (sign_rand < (slope - mean) / half) delta = -delta;
+		slope += delta;
+		dh += slope * kSpacing;
+		h[i] += static_cast<float>(dh);
+	}
+}
+void overlay_bumps(double mn, double mx, size_t beg, size_t end, TerrainRand& rnd, std::vector<float>& h)
+{
+	for (size_t i = beg; i + 1 < end; ++i) { double d = rnd.RandSign() * rnd.RandDouble(mn, mx); h[i] += static_cast<float>(d); }
+}
+void pick_range(double a0, double a1, double b0, double b1, TerrainRand& rnd, double& mn, double& mx)
+{
+	bool va = (a0 != 0 || a1 != 0), vb = (b0 != 0 || b1 != 0);
+	if (va && vb) { bool heads = rnd.FlipCoin(); mn = heads ? a0 : b0; mx = heads ? a1 : b1; }
+	else if (va) { mn = a0; mx = a1; }
+	else { mn = b0; mx = b1; }
+}
+double base_feature(int kind, double width, const double* p, TerrainRand& rnd, std::vector<float>& h);
+
+double gaps(double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
+{
+	Strip s(h); double tot = 0;
+	while (tot < width) { double sp = rnd.RandDouble(p[GSmin], p[GSmax]); double w = rnd.RandDouble(p[GWmin], p[GWmax]); double d = rnd.RandDouble(p[GHmin], p[GHmax]); tot += s.box(sp, w, d); }
+	return tot;
+}
+double walls(double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
+{
+	Strip s(h); double tot = 0;
+	while (tot < width) { double sp = rnd.RandDouble(p[WSmin], p[WSmax]); double w = rnd.RandDouble(p[WWmin], p[WWmax]); double d = rnd.RandDouble(p[WHmin], p[WHmax]); tot += s.box(sp, w, d); }
+	return tot;
+}
+double steps(double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
+{
+	Strip s(h); double tot = 0;
+	while (tot < width) {
+		double mn, mx; pick_range(p[SH0min], p[SH0max], p[SH1min], p[SH1max], rnd, mn, mx);
+		double w = rnd.RandDouble(p[SSmin], p[SSmax]); double dh = rnd.RandDouble(mn, mx);
+		tot += s.step(w, dh);
+	}
+	return tot;
+}
+double narrow_gaps(double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
+{
+	Strip s(h); double tot = 0;
+	int cmin = std::max(1, static_cast<int>(p[NCmin])), cmax = std::max(1, static_cast<int>(p[NCmax]));
+	while (tot < width) {
+		double sp = rnd.RandDouble(p[NSmin], p[NSmax]);
+		int count = rnd.RandInt(cmin, cmax + 1);
+		for (int i = 0; i < count; ++i) {
+			double w = rnd.RandDouble(p[NWmin], p[NWmax]); double d = rnd.RandDouble(p[NDpmin], p[NDpmax]);
+			tot += s.box(sp, w, d);
+			sp = rnd.RandDouble(p[NDmin], p[NDmax]);
+		}
+	}
+	return tot;
+}
+double mixed(double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
+{
+	double tot = 0; const double dummy = kSpacing;
+	while (tot < width) {
+		int t = rnd.RandInt(0, 3);
+		tot += (t == 0) ? gaps(dummy, p, rnd, h) : (t == 1) ? steps(dummy, p, rnd, h) : walls(dummy, p, rnd, h);
+	}
+	return tot;
+}
+double cliffs(double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
+{
+	Strip s(h); double tot = 0; size_t beg = h.size();
+	int mini_max = static_cast<int>(p[CMini]);
+	while (tot < width) {
+		double mn, mx; pick_range(p[CH0min], p[CH0max], p[CH1min], p[CH1max], rnd, mn, mx);
+		double w = rnd.RandDouble(p[CSmin], p[CSmax]); double dh = rnd.RandDouble(mn, mx);
+		double cur_w = 0, cur_dh = 0;
+		int n_mini = rnd.RandInt(0, mini_max + 1);
+		for (int i = 0; i < n_mini + 1; ++i) {
+			double mw = (i == 0) ? w : 0.1;
+			double mh = rnd.RandDouble(cur_dh, dh);
+			if (i == n_mini) mh = dh;
+			cur_w += s.step(mw, mh - cur_dh);
+			cur_dh = mh;
+		}
+		tot += cur_w;
+	}
+	size_t end = h.size();
+	overlay_slopes(p, beg, end, rnd, h);
+	overlay_bumps(p[BHmin], p[BHmax], beg, end, rnd, h);
+	return tot;
+}
+// kind: 0 flat 1 gaps 2 steps 3 walls 4 mixed 5 narrow gaps
+double base_feature(int kind, double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
+{
+	switch (kind) {
+	case 1: return gaps(width, p, rnd, h);
+	case 2: return steps(width, p, rnd, h);
+	case 3: return walls(width, p, rnd, h);
+	case 4: return mixed(width, p, rnd, h);
+	case 5: return narrow_gaps(width, p, rnd, h);
+	default: { Strip s(h); return s.flat(width); }
+	}
+}
+}  // namespace
+
+double BuildTerrain(int type, double width, const double* p, TerrainRand& rnd, std::vector<float>& out)
+{
+	// (base feature, slopes overlay, bumps overlay) per terrain type: sim/TerrainGen2D.cpp:148-181 + the Build* bodies
+	static const struct { int base; bool slopes; bool bumps; } kRecipe[kTerrTypeMax] = {
+		{0, false, false}, {1, false, false}, {2, false, false}, {3, false, false}, {0, false, true}, {4, false, false}, {5, false, false},
+		{0, true, false}, {1, true, false}, {2, true, false}, {3, true, false}, {4, true, false}, {5, true, false}, {-1, false, false}};
+	if (type == kTerrCliffs) return cliffs(width, p, rnd, out);
+	if (type < 0 || type >= kTerrTypeMax) type = kTerrFlat;
+	size_t beg = out.size();
+	double tot = base_feature(kRecipe[type].base, width, p, rnd, out);
+	size_t end = out.size();
+	if (kRecipe[type].slopes) overlay_slopes(p, beg, end, rnd, out);
+	if (kRecipe[type].bumps) overlay_bumps(p[BHmin], p[BHmax], beg, end, rnd, out);
+	return tot;
+}
+
+// =====================================================================================================================
+// cGroundVar2D window (sim/GroundVar2D.cpp)
+double GroundWindow::Seg::MinX() const { return data.empty() ? std::numeric_limits<double>::infinity() : min_x; }
+double GroundWindow::Seg::MaxX() const { return data.empty() ? -std::numeric_limits<double>::infinity() : min_x + (data.size() - 1) * static_cast<double>(kSpacing); }
+
+void GroundWindow::Configure(int type, const double* params, double world_scale, double segment_width)
+{
+	type_ = type; world_scale_ = world_scale; segment_width_ = segment_width; SetParams(params);
+}
+void GroundWindow::SetParams(const double* params) { std::memcpy(params_, params, sizeof(params_)); }
+void GroundWindow::Clear() { segs_[0].data.clear(); segs_[1].data.clear(); flip_ = false; }
+
+void GroundWindow::BuildSegment(int seg_id, double bmin, double bmax, bool align_min, double fix_y)
+{
+	// sim/GroundVar2D.cpp:312-355: optional flat padding around x = 0, terrain strip, C0 alignment at the seam, then
+	// tSegment::Init (:392-455) whose Bullet round trips fix the float-rounded origin / x scaling used by CalcGridCoord.
+	Seg& seg = segs_[seg_id];
+	seg.data.clear();
+	if (bmin <= 0 && bmax >= 0) { Strip s(seg.data); s.flat(std::min(bmax - bmin, 1 - bmin)); }
+	BuildTerrain(type_, bmax - bmin, params_, rand_, seg.data);
+	const int n = static_cast<int>(seg.data.size());
+	float end_h = n > 0 ? (align_min ? seg.data[0] : seg.data[n - 1]) : 0.f;
+	float off = static_cast<float>(fix_y - end_h);
+	for (float& v : seg.data) v += off;
+	const double sp = static_cast<double>(kSpacing);
+	seg.min_x = align_min ? bmin : (bmax - (n - 1) * sp);
+	double centre = 0.5 * (seg.min_x + (seg.min_x + (seg.data.size() - 1) * sp));
+	float bt_origin = static_cast<float>(world_scale_) * static_cast<float>(centre);
+	seg.origin_x = static_cast<double>(bt_origin) / world_scale_;
+	seg.scale_x = static_cast<double>(static_cast<float>(sp * world_scale_)) / world_scale_;
+	++builds_;
+}
+void GroundWindow::InitSegments(double bound_min_x, double bound_max_x)
+{
+	Clear();
+	double mid = 0.5 * (bound_max_x + bound_min_x);
+	for (int i = 0; i < 2; ++i) {
+		bool align_min = flip_ ? (i == 0) : (i != 0);
+		double w = segment_width_;
+		BuildSegment(SegID(i), (align_min ? 0 : -w) + mid, (align_min ? w : 0) + mid, align_min, 0.0);
+	}
+}
+bool GroundWindow::Update(double bmin, double bmax)
+{
+	const Seg& lo = segs_[SegID(0)]; const Seg& hi = segs_[SegID(1)];
+	double min_x = lo.MinX(), max_x = hi.MaxX();
+	if (bmax < max_x && bmin > min_x) return false;
+	if (bmax <= min_x || bmin >= max_x) { InitSegments(bmin, bmax); return true; }
+	bool unflipped = (SegID(0) == 0);
+	if (bmax >= max_x) BuildSegment(SegID(0), max_x, max_x + segment_width_, true, hi.data.back());
+	else BuildSegment(SegID(1), min_x - segment_width_, min_x, false, lo.data.front());
+	flip_ = unflipped;
+	return true;
+}
+bool GroundWindow::FillRecord(GroundRec& rec, std::string& err) const
+{
+	for (int s = 0; s < 2; ++s) {
+		const Seg& seg = segs_[SegID(s)];
+		if (static_cast<int>(seg.data.size()) > kSegCap) { err = "terrain segment exceeds kSegCap vertices"; return false; }
+		rec.origin_x[s] = seg.origin_x; rec.scale_x[s] = seg.scale_x; rec.min_x[s] = seg.MinX(); rec.max_x[s] = seg.MaxX();
+		rec.w[s] = static_cast<int32_t>(seg.data.size());
+		std::memcpy(rec.data[s], seg.data.data(), seg.data.size() * sizeof(float));
+	}
+	return true;
+}
+
+// =====================================================================================================================
+// scenario loading
+namespace {
+std::string JoinPath(const std::string& root, const std::string& rel)
+{
+	if (rel.empty() || rel[0] == '/' || root.empty()) return rel;
+	return root + (root.back() == '/' ? "" : "/") + rel;
+}
+const char* const kDogMisc[6] = {"TransTime", "Cv", "BackForceX", "BackForceY", "FrontForceX", "FrontForceY"};
+const char* const kDogStates[4] = {"BackStance", "Extend", "FrontStance", "Gather"};
+const char* const kDogStateParams[6] = {"SpineCurve", "Shoulder", "Elbow", "Hip", "Knee", "Ankle"};
+// sim/SimDog.cpp:5-33
+const int kDogCol[21] = {2, 2, 2, 2, 2, 2, 2, 2, 2, 0, 0, 0, 0, 4, 4, 4, 4, 8, 8, 8, 8};
+}  // namespace
+
+bool ParseDeployPrototxt(const std::string& path, NetDesc& d, std::string& err)
+{
+	std::ifstream f(path);
+	if (!f.is_open()) { err = "cannot open " + path; return false; }
+	std::stringstream ss; ss << f.rdbuf();
+	const std::string txt = ss.str();
+	std::vector<int> dims;
+	{
+		std::regex re("input_dim:\\s*(\\d+)");
+		for (auto it = std::sregex_iterator(txt.begin(), txt.end(), re); it != std::sregex_iterator(); ++it) dims.push_back(std::stoi((*it)[1]));
+	}
+	if (dims.empty()) { err = path + ": no input_dim"; return false; }
+	struct Layer { std::string name, type; int num_output = -1, kernel_w = -1, slice_point = -1; };
+	std::vector<Layer> layers;
+	{
+		std::regex split("\\blayer\\s*\\{");
+		std::sregex_token_iterator it(txt.begin(), txt.end(), split, -1), end;
+		bool first = true;
+		for (; it != end; ++it) {
+			if (first) { first = false; continue; }
+			const std::string blk = *it;
+			Layer l; std::smatch m;
+			if (std::regex_search(blk, m, std::regex("name:\\s*\"([^\"]+)\""))) l.name = m[1];
+			if (std::regex_search(blk, m, std::regex("type:\\s*\"([^\"]+)\""))) l.type = m[1];
+			if (std::regex_search(blk, m, std::regex("num_output:\\s*(\\d+)"))) l.num_output = std::stoi(m[1]);
+			if (std::regex_search(blk, m, std::regex("kernel_w:\\s*(\\d+)"))) l.kernel_w = std::stoi(m[1]);
+			if (std::regex_search(blk, m, std::regex("slice_point:\\s*(\\d+)"))) l.slice_point = std::stoi(m[1]);
+			layers.push_back(l);
+		}
+	}
+	std::map<std::string, int> ips; int nconv = 0; d.n_terrain = -1;
+	for (const Layer& l : layers) {
+		if (l.type == "Slice") d.n_terrain = l.slice_point;
+		else if (l.type == "Convolution") { if (nconv < 3) { d.conv_ch[nconv] = l.num_output; d.conv_k[nconv] = l.kernel_w; } ++nconv; }
+		else if (l.type == "InnerProduct") ips[l.name] = l.num_output;
+	}
+	if (d.n_terrain < 0 || nconv != 3 || !ips.count("terr_ip0") || !ips.count("ip0") || !ips.count("val_ip0") || !ips.count("val_ip1") || !ips.count("a0_ip1")) {
+		err = path + ": not a MACE (slice/3 conv/terr_ip0/ip0/val/a*) deploy net"; return false;
+	}
+	d.n_char = dims.back() - d.n_terrain;
+	d.fc_terr = ips["terr_ip0"]; d.fc_trunk = ips["ip0"]; d.fc_head = ips["val_ip0"]; d.n_frags = ips["val_ip1"]; d.frag_size = ips["a0_ip1"];
+	if (d.n_frags > kMaxFrags) { err = "too many actor fragments"; return false; }
+	d.in_size = d.n_terrain + d.n_char; d.out_size = d.n_frags + d.n_frags * d.frag_size;
+	int64_t n = 0; int cin = 1, w = d.n_terrain;
+	for (int l = 0; l < 3; ++l) { n += static_cast<int64_t>(d.conv_ch[l]) * cin * d.conv_k[l] + d.conv_ch[l]; cin = d.conv_ch[l]; w = w - d.conv_k[l] + 1; }
+	n += static_cast<int64_t>(d.fc_terr) * cin * w + d.fc_terr;
+	n += static_cast<int64_t>(d.fc_trunk) * (d.fc_terr + d.n_char) + d.fc_trunk;
+	n += (static_cast<int64_t>(d.fc_head) * d.fc_trunk + d.fc_head) * (1 + d.n_frags);
+	n += static_cast<int64_t>(d.n_frags) * d.fc_head + d.n_frags + static_cast<int64_t>(d.n_frags) * (static_cast<int64_t>(d.frag_size) * d.fc_head + d.frag_size);
+	d.num_params = n;
+	return true;
+}
+
+void LerpTerrainParams(const ScenarioConfig& cfg, double lerp, double* out)
+{
+	// scenarios/ScenarioSimChar.cpp:255-272
+	const int n = static_cast<int>(cfg.terrain_param_sets.size());
+	if (n == 0) { std::memcpy(out, kTerrainParamDefaults, sizeof(kTerrainParamDefaults)); return; }
+	lerp = std::min(std::max(lerp, 0.0), n - 1.0);
+	int i0 = static_cast<int>(lerp), i1 = std::min(i0 + 1, n - 1);
+	lerp -= i0;
+	for (int k = 0; k < kNumTerrainParams; ++k) out[k] = (1 - lerp) * cfg.terrain_param_sets[i0][k] + lerp * cfg.terrain_param_sets[i1][k];
+}
+
+void BuildOutputOffsetScale(const DevModel& m, const NetDesc& d, std::vector<double>& off, std::vector<double>& scale)
+{
+	// sim/BaseControllerMACE.cpp:75-168 with cDogControllerMACE::BuildActorBias (sim/DogControllerMACE.cpp:93-99)
+	const int frag = m.n_opt, nf = d.n_frags;
+	auto action_opt = [&](int a, std::vector<double>& out) {
+		out.resize(frag);
+		const real* p0 = m.ctrl_params[m.act_idx0[a]]; const real* p1 = m.ctrl_params[m.act_idx1[a]]; double b = m.act_blend[a];
+		for (int k = 0; k < frag; ++k) { int i = m.opt_index[k]; out[k] = (1 - b) * p0[i] + b * p1[i]; }
+	};
+	std::vector<double> f_off, f_scale(frag, 1.0), tmp;
+	int da = m.default_action < 0 ? 0 : m.default_action;
+	action_opt(da, f_off);
+	for (double& v : f_off) v = -v;
+	if (m.n_actions > 1) {
+		std::fill(f_scale.begin(), f_scale.end(), 0.0);
+		for (int a = 0; a < m.n_actions; ++a) if (a != da) { action_opt(a, tmp); for (int k = 0; k < frag; ++k) f_scale[k] = std::max(f_scale[k], std::fabs(tmp[k] + f_off[k])); }
+		for (double& v : f_scale) v = 1.0 / v;
+	}
+	off.assign(nf + nf * frag, 0.0); scale.assign(nf + nf * frag, 1.0);
+	for (int f = 0; f < nf; ++f) {
+		off[f] = -0.5; scale[f] = 2;
+		const real* bias = m.ctrl_params[f % m.n_sets];
+		for (int k = 0; k < frag; ++k) { off[nf + f * frag + k] = -bias[m.opt_index[k]]; scale[nf + f * frag + k] = f_scale[k]; }
+	}
+}
+
+bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
+{
+	DevModel& m = cfg.model;
+	std::string root; args.ParseString("data_root", root); cfg.data_root = root;
+	std::string char_file, state_file, char_type, char_ctrl, terrain_file, scenario;
+	if (!args.ParseString("character_file", char_file)) { err = "No character file specified."; return false; }
+	args.ParseString("state_file", state_file);
+	args.ParseString("char_type", char_type); args.ParseString("char_ctrl", char_ctrl);
+	args.ParseString("terrain_file", terrain_file); args.ParseString("scenario", scenario);
+	double world_scale = 1; int num_update_steps = 20, num_sim_substeps = 1;   // scenarios/ScenarioSimChar.cpp:51-53
+	args.ParseDouble("world_scale", world_scale); args.ParseInt("num_update_steps", num_update_steps); args.ParseInt("num_sim_substeps", num_sim_substeps);
+	m.world_scale = world_scale; m.num_update_steps = num_update_steps; m.num_sim_substeps = num_sim_substeps;
+
+	// scenarios/ScenarioSimChar.cpp:19-36 controller names
+	if (char_ctrl == "dog") { m.char_type = 0; m.ctrl_type = 0; }
+	else if (char_ctrl == "dog_mace" || char_ctrl == "goat_mace") { m.char_type = 0; m.ctrl_type = 1; }
+	else { err = "char_ctrl '" + char_ctrl + "' is not supported by this build (dog, dog_mace, goat_mace)"; return false; }
+	if (!char_type.empty() && char_type != "dog") { err = "char_type '" + char_type + "' does not match the controller"; return false; }
+	m.target_vel_x = (char_ctrl == "goat_mace") ? 2.0 : 4.0;   // sim/GoatControllerMACE.cpp:11-14, sim/DogController.cpp:625-628
+	if (scenario == "train_mace" || scenario == "exp" || scenario == "exp_mace") m.scenario = kScnExp;
+	else if (scenario == "poli_eval") m.scenario = kScnPoliEval;
+	else m.scenario = kScnSimChar;
+
+	Json chr;
+	if (!Json::parse_file(JoinPath(root, char_file), chr, err)) return false;
+	const Json* skel = chr.find("Skeleton"); const Json* joints = skel ? skel->find("Joints") : nullptr;
+	const Json* bodies = chr.find("BodyDefs"); const Json* pds = chr.find("PDControllers"); const Json* ctrls = chr.find("Controllers");
+	if (!joints || !bodies || !pds || !ctrls) { err = char_file + ": missing Skeleton/BodyDefs/PDControllers/Controllers"; return false; }
+	const int L = static_cast<int>(joints->arr.size());
+	if (L > kMaxL || L != static_cast<int>(bodies->arr.size()) || L != static_cast<int>(pds->arr.size())) { err = char_file + ": inconsistent joint/body/PD counts"; return false; }
+	if (m.char_type == 0 && L != 21) { err = "dog controller expects 21 joints"; return false; }
+	m.L = L;
+	int D = 0;
+	for (int j = 0; j < L; ++j) {
+		const Json& jd = joints->arr[j];
+		int type = static_cast<int>(jd.get_num("Type", 0)); int parent = static_cast<int>(jd.get_num("Parent", -1));
+		if (parent >= j) { err = "Parent id must be < child id"; return false; }     // anim/KinTree.cpp:441-447
+		if ((j == 0) != (type == 1) || (j > 0 && type != 0)) { err = "only planar root + revolute joints are supported"; return false; }
+		m.parent[j] = parent;
+		bool is_root = parent < 0;
+		m.attach[j][0] = is_root ? 0 : jd.get_num("AttachX", 0); m.attach[j][1] = is_root ? 0 : jd.get_num("AttachY", 0);
+		m.lim_lo[j] = jd.get_num("LimLow", 1); m.lim_hi[j] = jd.get_num("LimHigh", 0);                // anim/KinTree.cpp:990-1006
+		D += (type == 1) ? 3 : 1;
+	}
+	m.D = D;
+	if (D != L + 2 || D > kMaxD) { err = "unexpected DoF count"; return false; }
+	m.total_mass = 0;
+	for (int j = 0; j < L; ++j) {
+		const Json& bd = bodies->arr[j];
+		const Json* shape = bd.find("Shape");
+		if (!shape || shape->str != "box") { err = "only box bodies are supported"; return false; }
+		m.mass[j] = bd.get_num("Mass", 0); m.total_mass += m.mass[j];
+		m.body_attach[j][0] = bd.get_num("AttachX", 0); m.body_attach[j][1] = bd.get_num("AttachY", 0);
+		m.body_theta[j] = bd.get_num("Theta", 0);
+		double sx = bd.get_num("Param0", 0), sy = bd.get_num("Param1", 0);
+		m.body_half[j][0] = 0.5 * sx; m.body_half[j][1] = 0.5 * sy;
+		m.inertia[j] = m.mass[j] / 12.0 * (sx * sx + sy * sy);                                     // sim/RBDUtil.cpp:562-583 (zz term)
+		m.col[j] = kDogCol[j];
+		const Json& pd = pds->arr[j];
+		m.kp[j] = pd.get_num("Kp", 0); m.kd[j] = pd.get_num("Kd", 0); m.torque_lim[j] = pd.get_num("TorqueLim", 0);
+		m.target_theta[j] = pd.get_num("TargetTheta", 0); m.use_world[j] = pd.get_num("UseWorldCoord", 0) != 0;
+	}
+	// tree tables: root->link paths and subtree masks
+	for (int j = 0; j < L; ++j) {
+		int chain[kMaxL]; int n = 0;
+		for (int c = j; c >= 0; c = m.parent[c]) chain[n++] = c;
+		if (n > kMaxDepth) { err = "kinematic chain too deep"; return false; }
+		m.depth[j] = n - 1;
+		for (int k = 0; k < n; ++k) m.path[j][k] = static_cast<int8_t>(chain[n - 1 - k]);
+		m.sub_mask[j] = 0;
+	}
+	for (int k = 0; k < L; ++k) for (int c = k; c >= 0; c = m.parent[c]) m.sub_mask[c] |= (1u << k);
+
+	// controllers (sim/DogController.cpp:629-700, 399-454)
+	const Json* files = ctrls->find("Files"); const Json* acts = ctrls->find("Actions");
+	if (!files || !acts) { err = "Controllers block needs Files and Actions"; return false; }
+	m.P = 30; m.n_opt = 0;
+	for (int i = 0; i < m.P; ++i) if (i != 0) m.opt_index[m.n_opt++] = i;   // gParamInfo: only TransTime is not optimisable
+	m.n_sets = static_cast<int>(files->arr.size());
+	if (m.n_sets > kMaxSets) { err = "too many controller files"; return false; }
+	for (int s = 0; s < m.n_sets; ++s) {
+		Json cf;
+		if (!Json::parse_file(JoinPath(root, files->arr[s].str), cf, err)) return false;
+		const Json* misc = cf.find("MiscParams"); const Json* sps = cf.find("StateParams");
+		if (!misc || !sps) { err = files->arr[s].str + ": missing MiscParams/StateParams"; return false; }
+		int idx = 0;
+		for (int i = 0; i < 6; ++i) m.ctrl_params[s][idx++] = misc->get_num(kDogMisc[i], 0);
+		for (int st = 0; st < 4; ++st) { const Json* sp = sps->find(kDogStates[st]); for (int i = 0; i < 6; ++i) m.ctrl_params[s][idx++] = sp ? sp->get_num(kDogStateParams[i], 0) : 0; }
+		m.ctrl_params[s][0] = std::fabs(m.ctrl_params[s][0]); m.ctrl_params[s][1] = std::fabs(m.ctrl_params[s][1]);   // PostProcessParams
+	}
+	m.n_actions = static_cast<int>(acts->arr.size());
+	if (m.n_actions > kMaxAct) { err = "too many actions"; return false; }
+	for (int a = 0; a < m.n_actions; ++a) {
+		const Json& ad = acts->arr[a];
+		if (!ad.has("ParamIdx0") || !ad.has("ParamIdx1") || !ad.has("Blend") || !ad.has("Cyclic")) { err = "failed to parse actions"; return false; }
+		m.act_idx0[a] = static_cast<int>(ad.get_num("ParamIdx0", 0)); m.act_idx1[a] = static_cast<int>(ad.get_num("ParamIdx1", 0));
+		m.act_blend[a] = ad.get_num("Blend", 0); m.act_cyclic[a] = ad.get_bool("Cyclic", false);
+	}
+	m.default_action = m.n_actions > 0 ? static_cast<int>(ctrls->get_num("DefaultAction", 0)) : -1;
+	m.enable_grav_comp = ctrls->get_bool("EnableGravityCompensation", true);   // ctor default sim/DogController.cpp:172
+	m.enable_vf = 1;
+
+	// initial state (anim/Character.cpp:239-262)
+	for (int i = 0; i < D; ++i) { m.pose0[i] = 0; m.vel0[i] = 0; }
+	if (!state_file.empty()) {
+		Json st;
+		if (!Json::parse_file(JoinPath(root, state_file), st, err)) return false;
+		const Json* pose = st.find("Pose"); const Json* vel = st.find("Vel");
+		if (!pose || !vel || static_cast<int>(pose->arr.size()) != D || static_cast<int>(vel->arr.size()) != D) { err = state_file + ": Pose/Vel size mismatch"; return false; }
+		for (int i = 0; i < D; ++i) { m.pose0[i] = pose->arr[i].num; m.vel0[i] = vel->arr[i].num; }
+	}
+	double init_x = 0; m.valid_init_pos_x = args.ParseDouble("char_init_pos_x", init_x); m.init_pos_x = init_x;
+
+	// terrain (scenarios/ScenarioSimChar.cpp:670-706, sim/TerrainGen2D.cpp:58-146)
+	cfg.terrain_type = kTerrFlat; cfg.terrain_param_sets.clear();
+	if (!terrain_file.empty()) {
+		Json tf;
+		if (!Json::parse_file(JoinPath(root, terrain_file), tf, err)) return false;
+		const Json* ty = tf.find("Type");
+		std::string tname = ty ? ty->str : "";
+		if (tname.empty()) tname = "flat";
+		int found = -1;
+		for (int i = 0; i < kTerrTypeMax; ++i) if (tname == kTerrainTypeNames[i]) found = i;
+		if (found < 0) { err = "unsupported terrain type " + tname; return false; }
+		cfg.terrain_type = found;
+		const Json* ps = tf.find("Params");
+		if (ps) for (const Json& obj : ps->arr) {
+			std::vector<double> v(kNumTerrainParams);
+			for (int k = 0; k < kNumTerrainParams; ++k) v[k] = obj.get_num(kTerrainParamNames[k], kTerrainParamDefaults[k]);
+			cfg.terrain_param_sets.push_back(v);
+		}
+	}
+	args.ParseDouble("terrain_blend", cfg.terrain_blend);
+	int seed = 0; if (args.ParseInt("terrain_seed", seed)) cfg.terrain_seed = static_cast<uint64_t>(seed);
+
+	// exploration (scenarios/ScenarioExp.cpp:16-45)
+	cfg.tuple_buffer_size = 16; args.ParseInt("tuple_buffer_size", cfg.tuple_buffer_size);
+	double exp_rate = 0.1, exp_temp = 1, exp_base = 0.01;   // cScenarioExp ctor defaults; mExpTemp is uninitialised there -> controller default 1
+	args.ParseDouble("exp_rate", exp_rate); args.ParseDouble("exp_temp", exp_temp); args.ParseDouble("exp_base_rate", exp_base);
+	cfg.run.enable_exp = (m.scenario == kScnExp) ? 1 : 0;
+	cfg.run.exp_rate = exp_rate; cfg.run.exp_temp = exp_temp; cfg.run.exp_base_rate = exp_base; cfg.run.exp_noise = 0.2;   // mExpNoise, sim/DogControllerMACE.cpp:7
+	int rseed = 0; args.ParseInt("rand_seed", rseed); cfg.run.rng_seed = static_cast<uint64_t>(rseed);
+	int goff = 0; args.ParseInt("global_env_offset", goff); cfg.run.env_id_base = goff;
+
+	// policy net topology (weights arrive through dtrl_set_policy: the shipped *.h5 blobs are not in the reference checkout)
+	cfg.has_policy_net = false; m.has_net = 0;
+	if (args.ParseString("policy_net", cfg.policy_net_file) && m.ctrl_type == 1) {
+		if (!ParseDeployPrototxt(JoinPath(root, cfg.policy_net_file), cfg.net, err)) return false;
+		const int S = kNumGroundSamples + (2 * L - 1) + 2 * L;
+		if (cfg.net.in_size != S) { err = "Network input dimension does not match expected input size"; return false; }      // sim/NNController.cpp:58-75
+		if (cfg.net.frag_size != m.n_opt) { err = "Network output dimension does not match expected output size"; return false; }
+		cfg.has_policy_net = true;
+	}
+	args.ParseString("policy_model", cfg.policy_model_file);
+	return true;
+}
+
+}  // namespace dtrl

@@ -1,0 +1,1149 @@
+// dtrl_kernel.h -- the rollout hot path as wavefront-cooperative code: ONE 64-lane wavefront owns ONE environment.
+//
+// What runs here is the body of the loop at /root/reference/scenarios/ScenarioSimChar.cpp:162-173 for a batch of envs:
+//   cWorld::Update            sim/World.cpp:96-105          -> substep(): planar articulated dynamics + contact (Integrator v1)
+//   cContactManager::Update   sim/ContactManager.cpp:57-102 -> detect_contacts() link flags
+//   cSimCharacter::Update     sim/SimCharacter.cpp:91-107   -> controller_update(): cDogController::Update
+//     cRBDModel::Update / cRBDUtil::BuildMassMat / BuildBiasForce   sim/RBDModel.cpp:39-55, sim/RBDUtil.cpp:4-84,110-176
+//     cDogController::UpdateState / ApplyFeedback                    sim/DogController.cpp:805-845, 903-945
+//     cImpPDController::CalcControlForces                            sim/ImpPDController.cpp:234-278
+//     ApplyGravityCompensation / ApplyVirtualForces                  sim/DogController.cpp:947-1029
+//     cTerrainRLCharController::ParseGround / BuildPoliState         sim/TerrainRLCharController.cpp:168-285
+//     cBaseControllerMACE::DecideActionBoltzmann + cNeuralNet::Eval  sim/BaseControllerMACE.cpp:254-318, learning/NeuralNet.cpp:352-375
+//   cSimCharSoftFall fall checks sim/SimCharSoftFall.cpp:74-125, cScenarioExp::NewCycleUpdate scenarios/ScenarioExp.cpp:209-243
+//
+// MI355X mapping (not a translation of the reference's per-object C++):
+//   * all characters are planar, so the reference's 6-D spatial algebra collapses to 3-D planar twists in
+//     WORLD coordinates: H_ij = I_o - (p_i + p_j).mc + m p_i.p_j for ancestor pairs, RNEA = one path walk + one subtree sum;
+//   * per-env working set (kinematics, H, constraint rows, Delassus matrix) is staged in LDS; lanes map to links / DoFs /
+//     constraint rows / contact sample points; tree sweeps become path walks and subtree-mask sums with no level barriers;
+//   * the contact solve is projected Gauss-Seidel in lambda space on the dense Delassus matrix so a row update is one
+//     broadcast + one FMA per lane (see pgs_solve; the register/readlane form is in dtrl_engine.hip);
+//   * one kernel launch advances a whole outer frame (20 env-steps); state touches HBM only at frame boundaries.
+//
+// The code is written once in "lane-phase" form: LANES_BEGIN/LANES_END delimit a phase executed by every lane, with a
+// workgroup barrier at the end. Under hipcc a phase body runs once per thread; under g++ (tests only, see
+// csrc/emul/README) the same body runs in a for-loop over lanes so the math can be checked on a CPU-only box. The
+// C-ABI never dispatches to the lane-loop build: the product path is the HIP kernel or an error.
+#pragma once
+#include "dtrl_types.h"
+#include <cmath>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DTRL_HD __host__ __device__
+#else
+#define DTRL_HD
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LANES_BEGIN { const int lane = static_cast<int>(threadIdx.x);
+#define LANES_END } __syncthreads();
+#else
+#define LANES_BEGIN for (int lane = 0; lane < ::dtrl::kGroup; ++lane) {
+#define LANES_END }
+#endif
+
+namespace dtrl {
+
+// hot, read-mostly model fields staged in LDS
+struct HotModel {
+	int32_t L, D;
+	int32_t parent[kMaxL], depth[kMaxL], col[kMaxL], use_world[kMaxL];
+	int8_t path[kMaxL][kMaxDepth];
+	uint32_t sub_mask[kMaxL];
+	real attach[kMaxL][2], lim_lo[kMaxL], lim_hi[kMaxL];
+	real body_attach[kMaxL][2], body_theta[kMaxL], body_half[kMaxL][2];
+	real mass[kMaxL], inertia[kMaxL], kp[kMaxL], kd[kMaxL], torque_lim[kMaxL];
+};
+
+struct DevBuffers {
+	EnvState* st;
+	GroundRec* gr;
+	EnvStatus* status;
+	real* poli_state;     // [N][S]
+	real* tup_s0;         // [N][S]
+	real* tup_a;          // [N][A]
+	real* nn_scratch;     // [N][2][nn_scratch_stride]
+	real* nn_out;         // [N][out_size]
+	float* tuple_rows;    // [cap][W]  MACE replay row layout [r | s | a | s'] (learning/MACETrainer.cpp:373-401)
+	uint32_t* tuple_flags;
+	int32_t* tuple_env;
+	int32_t* tuple_count; // device-wide atomic cursor
+	int32_t tuple_cap;
+	int32_t S, A, W;
+	int32_t nn_scratch_stride;
+	const float* weights;
+	const real* in_off; const real* in_scale; const real* out_off; const real* out_scale;
+	NetDesc net;
+};
+
+// per-env LDS workspace
+struct WS {
+	HotModel M;
+	EnvState st;
+	// kinematics (positions relative to the root joint origin; world x = st.q[0] + px)
+	real phi[kMaxL], cs[kMaxL], sn[kMaxL], w[kMaxL];
+	real px[kMaxL], py[kMaxL], cx[kMaxL], cy[kMaxL], psi[kMaxL];
+	real vpx[kMaxL], vpy[kMaxL], vcx[kMaxL], vcy[kMaxL];
+	// composite (subtree) quantities about the root origin
+	real sm[kMaxL], smx[kMaxL], smy[kMaxL], sI[kMaxL];
+	real fx[kMaxL], fy[kMaxL];
+	real H[kMaxD][kMaxD + 1];   // after factorisation: diag = d_k, upper H[k][i] = L_ik (i > k)
+	real dinv[kMaxD];
+	real b[kMaxD];
+	real u[kMaxD];
+	// constraint rows
+	int32_t R, n_pts_active;
+	int32_t row_kind[kMaxRows], row_link[kMaxRows];
+	real row_x[kMaxRows], row_y[kMaxRows], row_dx[kMaxRows], row_dy[kMaxRows], row_tgt[kMaxRows];
+	real wv[kMaxRows], lam[kMaxRows];
+	real dl;
+	// time-multiplexed LDS: the contact sample points are dead once build_rows() has consumed them, which is before the
+	// Delassus matrix is written; the controller scratch is only live outside substep() where Z rows >= 1 are unused.
+	union {
+		real A[kMaxRows][kMaxRows + 1];
+		struct {
+			real pt_x[kMaxPts], pt_y[kMaxPts], pt_depth[kMaxPts], pt_nx[kMaxPts], pt_ny[kMaxPts];
+			int32_t pt_active[kMaxPts];
+		};
+	};
+	union {
+		real Z[kMaxRows + 1][kMaxD];
+		struct {
+			real z0_[kMaxD];
+			real basis[kMaxD][4];
+			real tau_g[kMaxD];
+			real kpv[kMaxD], kdv[kMaxD], perr[kMaxD], verr[kMaxD];
+		};
+	};
+	real red[8];
+	int32_t flag_update_action, flag_new_cycle, flag_misc, pad_;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// small helpers
+
+DTRL_HD inline real wrap_pi(real a)
+{
+	const real pi = 3.14159265358979323846, two_pi = 6.283185307179586476925286766559;
+	real r = fmod(a + pi, two_pi);
+	if (r < 0) r += two_pi;
+	return r - pi;
+}
+
+// counter-based per-env RNG (same stream definition as oracle/or_ctrl.h EnvRng; the reference's global RNG is racy and
+// time-seeded, SURVEY Appendix B.10, so only distributions are preserved)
+DTRL_HD inline uint64_t rng_mix(uint64_t x)
+{
+	x += 0x9E3779B97F4A7C15ULL;
+	x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+	return x ^ (x >> 31);
+}
+struct Rng {
+	uint64_t key; uint64_t* ctr;
+	DTRL_HD real uniform() { uint64_t z = rng_mix(key + (*ctr) * 0xD1342543DE82EF95ULL); ++(*ctr); return static_cast<real>(z >> 11) * (1.0 / 9007199254740992.0); }
+	DTRL_HD real uniform(real mn, real mx) { return mn + uniform() * (mx - mn); }
+	DTRL_HD int rand_int(int mn, int mx) { if (mn == mx) return mn; int r = mn + static_cast<int>(uniform() * (mx - mn)); return r >= mx ? mx - 1 : r; }
+	DTRL_HD bool flip() { return uniform() < 0.5; }
+	DTRL_HD real normal(real mean, real stdev)
+	{
+		real u1 = 1.0 - uniform(), u2 = uniform();
+		return mean + stdev * sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+	}
+};
+DTRL_HD inline Rng make_rng(const RunParams& rp, int env, uint64_t* ctr)
+{
+	Rng r; r.key = rng_mix(rp.rng_seed ^ rng_mix(static_cast<uint64_t>(rp.env_id_base + env))); r.ctr = ctr; return r;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// heightfield sampling: /root/reference/sim/GroundVar2D.cpp:98-114 (segment pick) + :559-619 (grid coord, clamp, lerp).
+// Grid coordinates are computed in double with the float-rounded Bullet origin / scaling the host stored in GroundRec,
+// so the cell indices i, j are bit-exact with the reference's arithmetic.
+DTRL_HD inline real sample_ground(const GroundRec& g, real x, real* slope, int* oi, int* oj, int* oseg)
+{
+	int seg = (x >= g.max_x[0]) ? 1 : 0;
+	const int w = g.w[seg];
+	const real tol = 0.0001;
+	real c = x - g.origin_x[seg];
+	c /= g.scale_x[seg];
+	c += ((w - 1) * 0.5);
+	if (c > -tol && c < w - 1 + tol) { c = c < 0.0 ? 0.0 : (c > w - 1.0 ? w - 1.0 : c); }
+	c = c < 0.0 ? 0.0 : (c > w - 1.0 ? w - 1.0 : c);
+	int i = static_cast<int>(c);
+	int j = (i + 1 < w - 1) ? i + 1 : w - 1;
+	real lerp = c - i;
+	real a = g.data[seg][i];
+	real b = g.data[seg][j];
+	if (slope) *slope = (j == i) ? 0.0 : (b - a) / (g.scale_x[seg] * (j - i));
+	if (oi) *oi = i;
+	if (oj) *oj = j;
+	if (oseg) *oseg = seg;
+	return (1 - lerp) * a + lerp * b;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// kinematics: joint frames, COMs and their velocities by walking each link's root->link path (no level barriers)
+DTRL_HD inline void forward_kinematics(WS& ws)
+{
+	LANES_BEGIN
+	if (lane < ws.M.L) {
+		const int j = lane;
+		real phi = 0, w = 0;
+		for (int k = 0; k <= ws.M.depth[j]; ++k) { int a = ws.M.path[j][k]; phi += ws.st.q[a + 2]; w += ws.st.qd[a + 2]; }
+		ws.phi[j] = phi; ws.w[j] = w;
+		real s, c; sincos(phi, &s, &c);
+		ws.cs[j] = c; ws.sn[j] = s;
+	}
+	LANES_END
+	LANES_BEGIN
+	if (lane < ws.M.L) {
+		const int j = lane;
+		real px = 0, py = 0, vx = ws.st.qd[0], vy = ws.st.qd[1];
+		for (int k = 1; k <= ws.M.depth[j]; ++k) {
+			int a = ws.M.path[j][k], pa = ws.M.path[j][k - 1];
+			real rx = ws.cs[pa] * ws.M.attach[a][0] - ws.sn[pa] * ws.M.attach[a][1];
+			real ry = ws.sn[pa] * ws.M.attach[a][0] + ws.cs[pa] * ws.M.attach[a][1];
+			px += rx; py += ry;
+			vx -= ws.w[pa] * ry; vy += ws.w[pa] * rx;
+		}
+		ws.px[j] = px; ws.py[j] = py; ws.vpx[j] = vx; ws.vpy[j] = vy;
+		real rx = ws.cs[j] * ws.M.body_attach[j][0] - ws.sn[j] * ws.M.body_attach[j][1];
+		real ry = ws.sn[j] * ws.M.body_attach[j][0] + ws.cs[j] * ws.M.body_attach[j][1];
+		ws.cx[j] = px + rx; ws.cy[j] = py + ry;
+		ws.vcx[j] = vx - ws.w[j] * ry; ws.vcy[j] = vy + ws.w[j] * rx;
+		ws.psi[j] = ws.phi[j] + ws.M.body_theta[j];
+	}
+	LANES_END
+}
+
+// subtree mass / first moment / inertia about the root origin, then the joint-space inertia matrix in closed form
+DTRL_HD inline void mass_matrix(WS& ws)
+{
+	LANES_BEGIN
+	if (lane < ws.M.L) {
+		const int j = lane;
+		const uint32_t mask = ws.M.sub_mask[j];
+		real m = 0, mx = 0, my = 0, I = 0;
+		for (int k = j; k < ws.M.L; ++k) if ((mask >> k) & 1u) {
+			real mk = ws.M.mass[k], x = ws.cx[k], y = ws.cy[k];
+			m += mk; mx += mk * x; my += mk * y; I += ws.M.inertia[k] + mk * (x * x + y * y);
+		}
+		ws.sm[j] = m; ws.smx[j] = mx; ws.smy[j] = my; ws.sI[j] = I;
+	}
+	for (int e = lane; e < kMaxD * (kMaxD + 1); e += kGroup) (&ws.H[0][0])[e] = 0;
+	LANES_END
+	LANES_BEGIN
+	const int D = ws.M.D;
+	if (lane < D) {
+		const int d = lane;
+		if (d < 2) { ws.H[d][d] = ws.sm[0]; }
+		else {
+			const int l = d - 2;
+			real m = ws.sm[l], mx = ws.smx[l], my = ws.smy[l], I = ws.sI[l];
+			real plx = ws.px[l], ply = ws.py[l];
+			real hx = -(my - m * ply), hy = (mx - m * plx);
+			ws.H[d][0] = hx; ws.H[0][d] = hx; ws.H[d][1] = hy; ws.H[1][d] = hy;
+			for (int k = 0; k <= ws.M.depth[l]; ++k) {
+				int a = ws.M.path[l][k], da = a + 2;
+				real pax = ws.px[a], pay = ws.py[a];
+				real v = I - ((plx + pax) * mx + (ply + pay) * my) + m * (plx * pax + ply * pay);
+				ws.H[d][da] = v; ws.H[da][d] = v;
+			}
+		}
+	}
+	LANES_END
+}
+
+// generalised bias force C(q, qd) incl. gravity (planar RNEA in world coordinates).
+// quirk=true reproduces cRBDUtil::BuildCjPlanar as shipped (sim/RBDUtil.cpp:809-836: theta read from q_dot and
+// s = cos(theta)) which the reference's implicit-PD controller sees; quirk=false is the textbook bias used by the integrator.
+DTRL_HD inline void bias_force(WS& ws, bool quirk)
+{
+	real ax0 = 0, ay0 = -kGravityY;
+	if (quirk) {
+		real vx = ws.st.qd[0], vy = ws.st.qd[1], om = ws.st.qd[2];
+		real c = ws.cs[0], s = ws.sn[0];
+		real cq = cos(om);
+		real tx = (-s * vx + c * vy) * om, ty = (-c * vx - s * vy) * om;     // textbook cj (body frame)
+		real qx = (-cq * vx + cq * vy) * om, qy = (-cq * vx - cq * vy) * om; // shipped cj
+		real dx = qx - tx, dy = qy - ty;
+		ax0 += c * dx - s * dy; ay0 += s * dx + c * dy;                      // back to world frame
+	}
+	LANES_BEGIN
+	if (lane < ws.M.L) {
+		const int j = lane;
+		real ax = ax0, ay = ay0;
+		for (int k = 1; k <= ws.M.depth[j]; ++k) {
+			int a = ws.M.path[j][k], pa = ws.M.path[j][k - 1];
+			real w2 = ws.w[pa] * ws.w[pa];
+			ax -= w2 * (ws.px[a] - ws.px[pa]); ay -= w2 * (ws.py[a] - ws.py[pa]);
+		}
+		real w2 = ws.w[j] * ws.w[j];
+		ax -= w2 * (ws.cx[j] - ws.px[j]); ay -= w2 * (ws.cy[j] - ws.py[j]);
+		ws.fx[j] = ws.M.mass[j] * ax; ws.fy[j] = ws.M.mass[j] * ay;
+	}
+	LANES_END
+	LANES_BEGIN
+	if (lane < ws.M.D) {
+		const int d = lane;
+		real s = 0;
+		if (d == 0) { for (int k = 0; k < ws.M.L; ++k) s += ws.fx[k]; }
+		else if (d == 1) { for (int k = 0; k < ws.M.L; ++k) s += ws.fy[k]; }
+		else {
+			const int l = d - 2;
+			const uint32_t mask = ws.M.sub_mask[l];
+			real plx = ws.px[l], ply = ws.py[l];
+			for (int k = l; k < ws.M.L; ++k) if ((mask >> k) & 1u) s += (ws.cx[k] - plx) * ws.fy[k] - (ws.cy[k] - ply) * ws.fx[k];
+		}
+		ws.b[d] = s;
+	}
+	LANES_END
+}
+
+// in-place LDL^T of ws.H (right-looking; lane i owns row i). Afterwards: diag = d_k, H[k][i] (i > k) = L_ik, dinv = 1/d.
+DTRL_HD inline void factorize(WS& ws)
+{
+	const int D = ws.M.D;
+	for (int k = 0; k < D - 1; ++k) {
+		LANES_BEGIN
+		if (lane > k && lane < D) {
+			const int i = lane;
+			real lik = ws.H[i][k] / ws.H[k][k];
+			for (int j = k + 1; j <= i; ++j) ws.H[i][j] -= lik * ws.H[j][k];
+			ws.H[k][i] = lik;
+		}
+		LANES_END
+	}
+	LANES_BEGIN
+	if (lane < D) ws.dinv[lane] = 1.0 / ws.H[lane][lane];
+	LANES_END
+}
+
+// J_r[i] for a point row (link, x, y rel. root, direction d): translation DoFs see d, hinge a on the path sees d . z x (pt - p_a)
+DTRL_HD inline real row_jac(const WS& ws, int r, int i)
+{
+	if (ws.row_kind[r] == 0) return (i == ws.row_link[r] + 2) ? ws.row_dx[r] : 0.0;
+	if (i == 0) return ws.row_dx[r];
+	if (i == 1) return ws.row_dy[r];
+	const int a = i - 2;
+	if (!((ws.M.sub_mask[a] >> ws.row_link[r]) & 1u)) return 0.0;
+	return ws.row_dx[r] * (-(ws.row_y[r] - ws.py[a])) + ws.row_dy[r] * (ws.row_x[r] - ws.px[a]);
+}
+
+// contact sample points of every colliding link against the env's heightfield (2 points per lane)
+DTRL_HD inline void detect_contacts(WS& ws, const GroundRec& g)
+{
+	LANES_BEGIN
+	for (int pt = lane; pt < ws.M.L * kPtsPerLink; pt += kGroup) {
+		const int j = pt / kPtsPerLink, k = pt - j * kPtsPerLink;
+		int active = 0;
+		if (ws.M.col[j] != 0) {
+			real hx = ws.M.body_half[j][0], hy = ws.M.body_half[j][1];
+			real sx, sy;
+			switch (k) {
+			case 0: sx = -hx; sy = -hy; break;
+			case 1: sx = hx; sy = -hy; break;
+			case 2: sx = hx; sy = hy; break;
+			case 3: sx = -hx; sy = hy; break;
+			case 4: if (hx >= hy) { sx = 0; sy = -hy; } else { sx = -hx; sy = 0; } break;
+			default: if (hx >= hy) { sx = 0; sy = hy; } else { sx = hx; sy = 0; } break;
+			}
+			real s, c; sincos(ws.psi[j], &s, &c);
+			real x = ws.cx[j] + c * sx - s * sy;
+			real y = ws.cy[j] + s * sx + c * sy;
+			real slope;
+			real h = sample_ground(g, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
+			real inv = 1.0 / sqrt(1.0 + slope * slope);
+			real nx = -slope * inv, ny = inv;
+			real depth = (h - (ws.st.q[1] + y)) * ny;
+			if (depth > 0) { active = 1; ws.pt_x[pt] = x; ws.pt_y[pt] = y; ws.pt_depth[pt] = depth; ws.pt_nx[pt] = nx; ws.pt_ny[pt] = ny; }
+		}
+		ws.pt_active[pt] = active;
+	}
+	LANES_END
+	LANES_BEGIN
+	if (lane == 0) {
+		uint32_t bits = 0;
+		for (int j = 0; j < ws.M.L; ++j) { int any = 0; for (int k = 0; k < kPtsPerLink; ++k) any |= ws.pt_active[j * kPtsPerLink + k]; if (any) bits |= (1u << j); }
+		ws.st.contact_bits = bits;
+	}
+	LANES_END
+}
+
+// build the ordered row list: violated joint limits first (by joint id), then normal+tangent per active contact point
+DTRL_HD inline void build_rows(WS& ws, real h)
+{
+	LANES_BEGIN
+	if (lane == 0) {
+		int R = 0;
+		for (int j = 1; j < ws.M.L; ++j) {
+			if (ws.M.lim_lo[j] > ws.M.lim_hi[j]) continue;
+			real th = ws.st.q[j + 2];
+			if (th <= ws.M.lim_lo[j] && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_dx[R] = 1; ws.row_tgt[R] = kLimitErp * (ws.M.lim_lo[j] - th) / h; ++R; }
+			else if (th >= ws.M.lim_hi[j] && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_dx[R] = -1; ws.row_tgt[R] = kLimitErp * (th - ws.M.lim_hi[j]) / h; ++R; }
+		}
+		int cap = (kMaxRows - R) / 2, nc = 0;
+		for (int pt = 0; pt < ws.M.L * kPtsPerLink && nc < cap; ++pt) if (ws.pt_active[pt]) {
+			const int j = pt / kPtsPerLink;
+			real t = kErp * fmax(ws.pt_depth[pt] - kSlop, 0.0) / h;
+			ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_x[R] = ws.pt_x[pt]; ws.row_y[R] = ws.pt_y[pt];
+			ws.row_dx[R] = ws.pt_nx[pt]; ws.row_dy[R] = ws.pt_ny[pt]; ws.row_tgt[R] = fmin(t, kVDepenMax); ++R;
+			ws.row_kind[R] = 2; ws.row_link[R] = j; ws.row_x[R] = ws.pt_x[pt]; ws.row_y[R] = ws.pt_y[pt];
+			ws.row_dx[R] = ws.pt_ny[pt]; ws.row_dy[R] = -ws.pt_nx[pt]; ws.row_tgt[R] = 0; ++R;
+			++nc;
+		}
+		ws.R = R;
+	}
+	LANES_END
+}
+
+// Z_r = L^-1 J_r^T for every row (lane r) and z_0 = L^-1 rhs (lane R), forward substitution per lane
+DTRL_HD inline void forward_subst_rows(WS& ws, const real* rhs)
+{
+	const int D = ws.M.D, R = ws.R;
+	LANES_BEGIN
+	if (lane <= R) {
+		const int r = lane;
+		real* z = ws.Z[r];
+		for (int i = 0; i < D; ++i) {
+			real s = (r < R) ? row_jac(ws, r, i) : rhs[i];
+			for (int k = 0; k < i; ++k) s -= ws.H[k][i] * z[k];
+			z[i] = s;
+		}
+	}
+	LANES_END
+}
+
+// Delassus matrix A = Z D^-1 Z^T (lane s owns row s), initial w = J v_free - target
+DTRL_HD inline void build_delassus(WS& ws, real h)
+{
+	const int D = ws.M.D, R = ws.R;
+	LANES_BEGIN
+	if (lane < R) {
+		const int s = lane;
+		for (int r = 0; r <= s; ++r) {
+			real a = 0;
+			for (int i = 0; i < D; ++i) a += ws.Z[s][i] * ws.Z[r][i] * ws.dinv[i];
+			ws.A[s][r] = a;
+		}
+		real jv;
+		if (ws.row_kind[s] == 0) jv = ws.row_dx[s] * ws.st.qd[ws.row_link[s] + 2];
+		else {
+			const int l = ws.row_link[s];
+			real vx = ws.vpx[l] - ws.w[l] * (ws.row_y[s] - ws.py[l]);
+			real vy = ws.vpy[l] + ws.w[l] * (ws.row_x[s] - ws.px[l]);
+			jv = ws.row_dx[s] * vx + ws.row_dy[s] * vy;
+		}
+		real zz = 0;
+		for (int i = 0; i < D; ++i) zz += ws.Z[s][i] * ws.dinv[i] * ws.Z[R][i];
+		ws.wv[s] = jv + h * zz - ws.row_tgt[s];
+		ws.lam[s] = 0;
+	}
+	LANES_END
+	LANES_BEGIN
+	if (lane < R) { const int s = lane; for (int r = s + 1; r < R; ++r) ws.A[s][r] = ws.A[r][s]; }
+	LANES_END
+}
+
+// projected Gauss-Seidel in lambda space, fixed row order, kPgsIters sweeps, no warm start.
+// LDS form (reference for the register/readlane form used by the tuned kernel).
+DTRL_HD inline void pgs_solve(WS& ws)
+{
+	const int R = ws.R;
+	for (int it = 0; it < kPgsIters; ++it) {
+		for (int r = 0; r < R; ++r) {
+			LANES_BEGIN
+			if (lane == 0) {
+				real arr = ws.A[r][r], dl = 0;
+				if (arr >= 1e-12) {
+					real nl = ws.lam[r] - ws.wv[r] / arr;
+					if (ws.row_kind[r] == 2) { real lim = kMu * ws.lam[r - 1]; nl = fmin(fmax(nl, -lim), lim); }
+					else nl = fmax(nl, 0.0);
+					dl = nl - ws.lam[r];
+					ws.lam[r] = nl;
+				}
+				ws.dl = dl;
+			}
+			LANES_END
+			LANES_BEGIN
+			if (lane < R) ws.wv[lane] += ws.A[lane][r] * ws.dl;
+			LANES_END
+		}
+	}
+}
+
+// v+ = qd + L^-T D^-1 (h z_0 + sum_r Z_r lambda_r); q+ = q + h v+
+DTRL_HD inline void finish_substep(WS& ws, real h)
+{
+	const int D = ws.M.D, R = ws.R;
+	LANES_BEGIN
+	if (lane < D) {
+		const int i = lane;
+		real s = h * ws.Z[R][i];
+		for (int r = 0; r < R; ++r) s += ws.Z[r][i] * ws.lam[r];
+		ws.u[i] = s * ws.dinv[i];
+	}
+	LANES_END
+	for (int i = D - 1; i >= 1; --i) {
+		LANES_BEGIN
+		if (lane < i) ws.u[lane] -= ws.H[lane][i] * ws.u[i];
+		LANES_END
+	}
+	LANES_BEGIN
+	if (lane < D) { const int i = lane; real v = ws.st.qd[i] + ws.u[i]; ws.st.qd[i] = v; ws.st.q[i] += h * v; }
+	LANES_END
+}
+
+// one physics substep (stand-in for one Bullet internal step of sim/World.cpp:101-102)
+DTRL_HD inline void substep(WS& ws, const GroundRec& g, real h)
+{
+	forward_kinematics(ws);
+	mass_matrix(ws);
+	bias_force(ws, false);
+	factorize(ws);
+	detect_contacts(ws, g);
+	build_rows(ws, h);
+	LANES_BEGIN
+	if (lane < ws.M.D) ws.u[lane] = ws.st.tau[lane] - ws.b[lane];
+	LANES_END
+	forward_subst_rows(ws, ws.u);
+	if (ws.R > 0) { build_delassus(ws, h); pgs_solve(ws); }
+	finish_substep(ws, h);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// controller (cDogController family)
+
+enum { jRoot, jSpine0, jSpine1, jSpine2, jSpine3, jTorso, jNeck0, jNeck1, jHead, jTail0, jTail1, jTail2, jTail3,
+	jShoulder, jElbow, jWrist, jFinger, jHip, jKnee, jAnkle, jToe };
+enum { spSpineCurve, spShoulder, spElbow, spHip, spKnee, spAnkle, spMax };
+enum { mpTransTime, mpCv, mpBackForceX, mpBackForceY, mpFrontForceX, mpFrontForceY, mpMax };
+enum { stBackStance, stExtend, stFrontStance, stGather, stMax, stInvalid };
+
+DTRL_HD inline bool in_contact(const WS& ws, int j) { return (ws.st.contact_bits >> j) & 1u; }
+
+DTRL_HD inline void calc_com(const WS& ws, real* out)
+{
+	real sx = 0, sy = 0, m = 0;
+	for (int j = 0; j < ws.M.L; ++j) { sx += ws.M.mass[j] * (ws.st.q[0] + ws.cx[j]); sy += ws.M.mass[j] * (ws.st.q[1] + ws.cy[j]); m += ws.M.mass[j]; }
+	out[0] = sx / m; out[1] = sy / m;
+}
+DTRL_HD inline void set_state_params(WS& ws)  // sim/DogController.cpp:1042-1054
+{
+	const real* sp = ws.st.params + mpMax + ws.st.state * spMax;
+	ws.st.pd_target[jSpine0] = sp[spSpineCurve]; ws.st.pd_target[jSpine1] = sp[spSpineCurve]; ws.st.pd_target[jSpine2] = sp[spSpineCurve];
+	ws.st.pd_target[jSpine3] = sp[spSpineCurve]; ws.st.pd_target[jTorso] = sp[spSpineCurve];
+	ws.st.pd_target[jShoulder] = sp[spShoulder]; ws.st.pd_target[jElbow] = sp[spElbow];
+	ws.st.pd_target[jHip] = sp[spHip]; ws.st.pd_target[jKnee] = sp[spKnee]; ws.st.pd_target[jAnkle] = sp[spAnkle];
+}
+DTRL_HD inline void transition_state(WS& ws, int s) { ws.st.state = s; ws.st.phase = 0; set_state_params(ws); }
+DTRL_HD inline bool has_stumbled(const WS& ws)  // sim/SimDog.cpp:83-105
+{
+	uint32_t mask = ~((1u << jToe) | (1u << jFinger) | (1u << jAnkle) | (1u << jWrist));
+	return (ws.st.contact_bits & mask & ((1u << ws.M.L) - 1u)) != 0;
+}
+DTRL_HD inline bool check_fall_contact(const WS& ws) { return (ws.st.contact_bits & ((1u << (jHead + 1)) - 1u)) != 0; }  // sim/SimDog.cpp:112-141
+DTRL_HD inline bool has_fallen(const WS& ws)  // sim/SimCharSoftFall.cpp:53-61, sim/SimDog.cpp:143-161
+{
+	bool flipped = fabs(wrap_pi(ws.st.q[2])) > 3.14159265358979323846 * 0.8;
+	return ws.st.sum_fall_contact > 0.25 || ws.st.fail_fall_dist != 0 || flipped;
+}
+DTRL_HD inline bool is_new_cycle(const WS& ws) { return ws.st.state == 0 && ws.st.phase == 0; }  // sim/CharController.cpp:72-75
+
+DTRL_HD inline void blend_ctrl_params(const DevModel& gm, int a, real* out)  // sim/DogController.cpp:1335-1341
+{
+	const real* p0 = gm.ctrl_params[gm.act_idx0[a]]; const real* p1 = gm.ctrl_params[gm.act_idx1[a]];
+	real b = gm.act_blend[a];
+	for (int i = 0; i < gm.P; ++i) out[i] = (1 - b) * p0[i] + b * p1[i];
+}
+DTRL_HD inline void post_process_params(real* p) { p[mpTransTime] = fabs(p[mpTransTime]); p[mpCv] = fabs(p[mpCv]); }
+DTRL_HD inline int assign_frag_id(const DevModel& gm, int num_frags, int a_id, Rng& rng)  // sim/DogControllerMACE.cpp:44-91
+{
+	int frag_id = 0;
+	if (num_frags > 0) {
+		int id0 = gm.act_idx0[a_id], id1 = gm.act_idx1[a_id];
+		if (id0 >= num_frags && id1 >= num_frags) frag_id = rng.rand_int(0, num_frags);
+		else if (id0 >= num_frags) frag_id = id1;
+		else if (id1 >= num_frags) frag_id = id0;
+		else {
+			frag_id = rng.flip() ? id0 : id1;
+			int num_copies = num_frags / gm.n_sets;
+			if (frag_id < num_frags % gm.n_sets) ++num_copies;
+			int offset = rng.rand_int(0, num_copies);
+			frag_id += offset * gm.n_sets;
+		}
+	}
+	return frag_id;
+}
+DTRL_HD inline void build_base_action(const DevModel& gm, int num_frags, int a_id, Rng& rng, int* out_id, real* out_params)
+{
+	*out_id = a_id;
+	blend_ctrl_params(gm, a_id, out_params);
+	if (gm.ctrl_type == 1) *out_id = assign_frag_id(gm, num_frags, a_id, rng);
+}
+// cTerrainRLCharController::ApplyAction + cDogController::NewCycleUpdate + TransitionState(BackStance); lane-0 code
+DTRL_HD inline void apply_action(WS& ws, int id, const real* params, int P)
+{
+	ws.st.action_id = id;
+	for (int i = 0; i < P; ++i) ws.st.params[i] = params[i];
+	post_process_params(ws.st.params);
+	ws.st.prev_cycle_time = ws.st.curr_cycle_time; ws.st.curr_cycle_time = 0;
+	ws.st.prev_stumble = ws.st.curr_stumble; ws.st.curr_stumble = 0;
+	real com[2]; calc_com(ws, com);
+	ws.st.prev_dist[0] = com[0] - ws.st.prev_com[0]; ws.st.prev_dist[1] = com[1] - ws.st.prev_com[1];
+	ws.st.prev_com[0] = com[0]; ws.st.prev_com[1] = com[1];
+	transition_state(ws, stBackStance);
+}
+
+// ---- policy network: learning/NeuralNet.cpp:352-375 Eval on the dog_mace3 topology, all 64 lanes of the env's wavefront.
+// Activations ping-pong through a per-env HBM scratch slab (L2-resident: only envs at a cycle boundary touch theirs).
+DTRL_HD inline void fc_layer(WS& ws, const float* W, const float* b, int nout, int nin, const real* x, real* y, bool relu)
+{
+	for (int o0 = 0; o0 < nout; o0 += kGroup) {
+		// lane-per-output when the layer is wide enough to fill the wavefront; weights of a row are streamed by one lane
+		LANES_BEGIN
+		const int o = o0 + lane;
+		if (o < nout) {
+			real s = b[o];
+			const float* wr = W + static_cast<int64_t>(o) * nin;
+			for (int i = 0; i < nin; ++i) s += static_cast<real>(wr[i]) * x[i];
+			y[o] = (relu && s < 0) ? 0 : s;
+		}
+		LANES_END
+	}
+	(void)ws;
+}
+DTRL_HD inline void nn_eval(WS& ws, const DevBuffers& buf, int env)
+{
+	const NetDesc& d = buf.net;
+	real* s0 = buf.nn_scratch + static_cast<int64_t>(env) * 2 * buf.nn_scratch_stride;
+	real* s1 = s0 + buf.nn_scratch_stride;
+	const real* xin = buf.poli_state + static_cast<int64_t>(env) * buf.S;
+	real* y = buf.nn_out + static_cast<int64_t>(env) * d.out_size;
+	// normalised char features are kept at the tail of s1's slab until the trunk layer consumes them
+	real* xchar = s1 + buf.nn_scratch_stride - d.n_char;
+	LANES_BEGIN
+	for (int i = lane; i < d.n_terrain; i += kGroup) s0[i] = (xin[i] + buf.in_off[i]) * buf.in_scale[i];
+	for (int i = lane; i < d.n_char; i += kGroup) xchar[i] = (xin[d.n_terrain + i] + buf.in_off[d.n_terrain + i]) * buf.in_scale[d.n_terrain + i];
+	LANES_END
+	const float* p = buf.weights;
+	real* a = s0; real* bo = s1;
+	int cin = 1, wdt = d.n_terrain;
+	for (int l = 0; l < 3; ++l) {
+		const int co = d.conv_ch[l], k = d.conv_k[l], wo = wdt - k + 1;
+		const float* W = p; const float* bias = p + static_cast<int64_t>(co) * cin * k;
+		LANES_BEGIN
+		for (int e = lane; e < co * wo; e += kGroup) {
+			const int o = e / wo, t = e - o * wo;
+			real s = bias[o];
+			for (int c = 0; c < cin; ++c) for (int uu = 0; uu < k; ++uu) s += static_cast<real>(W[(o * cin + c) * k + uu]) * a[c * wdt + t + uu];
+			bo[e] = s < 0 ? 0 : s;
+		}
+		LANES_END
+		p = bias + co; real* t2 = a; a = bo; bo = t2; cin = co; wdt = wo;
+	}
+	const int nflat = cin * wdt;
+	// terr_ip0: 5984 -> 64, output written right before the char features so the trunk input is contiguous
+	real* trunk_in = xchar - d.fc_terr;
+	fc_layer(ws, p, p + static_cast<int64_t>(d.fc_terr) * nflat, d.fc_terr, nflat, a, trunk_in, true);
+	p += static_cast<int64_t>(d.fc_terr) * nflat + d.fc_terr;
+	const int ntr = d.fc_terr + d.n_char;
+	real* trunk = s0;               // conv activations are dead now (a == s1 after three swaps, trunk_in lives in s1's tail)
+	real* head = s0 + d.fc_trunk;
+	fc_layer(ws, p, p + static_cast<int64_t>(d.fc_trunk) * ntr, d.fc_trunk, ntr, trunk_in, trunk, true);
+	p += static_cast<int64_t>(d.fc_trunk) * ntr + d.fc_trunk;
+	fc_layer(ws, p, p + static_cast<int64_t>(d.fc_head) * d.fc_trunk, d.fc_head, d.fc_trunk, trunk, head, true);
+	p += static_cast<int64_t>(d.fc_head) * d.fc_trunk + d.fc_head;
+	fc_layer(ws, p, p + static_cast<int64_t>(d.n_frags) * d.fc_head, d.n_frags, d.fc_head, head, y, false);
+	p += static_cast<int64_t>(d.n_frags) * d.fc_head + d.n_frags;
+	for (int f = 0; f < d.n_frags; ++f) {
+		fc_layer(ws, p, p + static_cast<int64_t>(d.fc_head) * d.fc_trunk, d.fc_head, d.fc_trunk, trunk, head, true);
+		p += static_cast<int64_t>(d.fc_head) * d.fc_trunk + d.fc_head;
+		fc_layer(ws, p, p + static_cast<int64_t>(d.frag_size) * d.fc_head, d.frag_size, d.fc_head, head, y + d.n_frags + f * d.frag_size, false);
+		p += static_cast<int64_t>(d.frag_size) * d.fc_head + d.frag_size;
+	}
+	LANES_BEGIN
+	for (int i = lane; i < d.out_size; i += kGroup) y[i] = y[i] / buf.out_scale[i] - buf.out_off[i];
+	LANES_END
+}
+
+// cDogController(MACE)::UpdateAction: ParseGround + BuildPoliState + action decision + ApplyAction
+DTRL_HD inline void update_action(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env)
+{
+	real* ps = buf.poli_state + static_cast<int64_t>(env) * buf.S;
+	const int L = ws.M.L;
+	// ParseGround, sim/TerrainRLCharController.cpp:168-213
+	real origin_x = ws.st.q[0];
+	real origin_y = sample_ground(g, origin_x, nullptr, nullptr, nullptr, nullptr);
+	LANES_BEGIN
+	for (int s = lane; s < kNumGroundSamples; s += kGroup) {
+		real dist = ((10.0 - (-0.5)) * s) / (kNumGroundSamples - 1) + (-0.5);
+		ps[s] = sample_ground(g, dist + origin_x, nullptr, nullptr, nullptr, nullptr) - origin_y;
+	}
+	// BuildPoliState, :215-285 (ENABLE_MAX_COORD_POSE)
+	if (lane == 0) { ps[kNumGroundSamples] = ws.st.q[1] - origin_y; ws.st.sample_origin[0] = origin_x; ws.st.sample_origin[1] = origin_y; }
+	if (lane >= 1 && lane < L) { ps[kNumGroundSamples + 1 + 2 * (lane - 1)] = ws.cx[lane]; ps[kNumGroundSamples + 2 + 2 * (lane - 1)] = ws.cy[lane]; }
+	if (lane < L) { ps[kNumGroundSamples + 2 * L - 1 + 2 * lane] = ws.vcx[lane]; ps[kNumGroundSamples + 2 * L + 2 * lane] = ws.vcy[lane]; }
+	LANES_END
+	// decide which branch of UpdateAction runs (lane 0 draws the random numbers; the branch flag is broadcast via LDS)
+	LANES_BEGIN
+	if (lane == 0) {
+		if (gm.ctrl_type == 1) { ws.st.exp_actor = 0; ws.st.exp_critic = 0; }
+		ws.st.is_off_policy = 1;
+		int mode = 0;  // 0: keep / default action, 1: command, 2: net, 3: random base action (exploration)
+		if (ws.st.cmd_action >= 0) mode = 1;
+		else if (gm.has_net) {
+			Rng rng = make_rng(rp, env, &ws.st.rng_ctr);
+			ws.st.is_off_policy = 0;
+			real base_rand = rng.uniform();
+			mode = (rp.enable_exp && base_rand < rp.exp_base_rate) ? 3 : 2;
+		}
+		ws.flag_misc = mode;
+	}
+	LANES_END
+	if (ws.flag_misc == 2) nn_eval(ws, buf, env);
+	LANES_BEGIN
+	if (lane == 0) {
+		Rng rng = make_rng(rp, env, &ws.st.rng_ctr);
+		const int P = gm.P, nf = buf.net.n_frags;
+		const int num_frags = gm.has_net ? nf : 0;
+		int id = ws.st.action_id; real prm[kMaxP];
+		for (int i = 0; i < P; ++i) prm[i] = ws.st.params[i];
+		const int mode = ws.flag_misc;
+		if (mode == 1) {
+			int cmd = ws.st.cmd_action; ws.st.cmd_action = -1;
+			if (gm.ctrl_type == 1) { ws.st.exp_actor = 1; ws.st.exp_critic = 1; }
+			build_base_action(gm, num_frags, cmd, rng, &id, prm);
+		} else if (mode == 3) {
+			int a = rng.rand_int(0, gm.n_actions);
+			build_base_action(gm, num_frags, a, rng, &id, prm);
+			ws.st.is_off_policy = 1; ws.st.exp_actor = 1; ws.st.exp_critic = 1;
+		} else if (mode == 2) {
+			// sim/BaseControllerMACE.cpp:267-296
+			const real* y = buf.nn_out + static_cast<int64_t>(env) * buf.net.out_size;
+			int a_max = 0; for (int i = 1; i < nf; ++i) if (y[i] > y[a_max]) a_max = i;
+			int a = a_max;
+			if (rp.enable_exp && rp.exp_temp != 0) {
+				real vb[kMaxFrags]; real max_val = y[a_max], sum = 0;
+				for (int i = 0; i < nf; ++i) { vb[i] = exp((y[i] - max_val) / rp.exp_temp); sum += vb[i]; }
+				real r = rng.uniform(0, sum);
+				for (int i = 0; i < nf; ++i) { r -= vb[i]; if (r <= 0) { a = i; break; } }
+			}
+			id = a;
+			const real* frag = y + nf + a * buf.net.frag_size;
+			for (int k = 0; k < gm.n_opt; ++k) prm[gm.opt_index[k]] = frag[k];
+			post_process_params(prm);
+			if (rp.enable_exp) {
+				real rand_noise = rng.uniform();
+				if (rand_noise < rp.exp_rate) {
+					for (int k = 0; k < gm.n_opt; ++k) { real noise = rng.normal(0, rp.exp_noise); prm[gm.opt_index[k]] += noise * (1.0 / buf.out_scale[nf + k]); }
+					ws.st.exp_actor = 1;
+				}
+				ws.st.exp_critic = (a != a_max) ? 1 : 0;
+				ws.st.is_off_policy = (ws.st.exp_actor || ws.st.exp_critic) ? 1 : 0;
+			}
+		} else {
+			bool cyclic = (gm.ctrl_type == 1) ? false : (gm.act_cyclic[ws.st.action_id] != 0);
+			if (!cyclic) build_base_action(gm, num_frags, gm.default_action, rng, &id, prm);
+		}
+		apply_action(ws, id, prm, P);
+	}
+	LANES_END
+}
+
+// effector contact position (body-local (0, -size_y/2)), relative to the root origin; sim/DogController.cpp:1372-1387
+DTRL_HD inline void effector_pos(const WS& ws, int j, real* out)
+{
+	real s, c; sincos(ws.psi[j], &s, &c);
+	real ly = -ws.M.body_half[j][1];
+	out[0] = ws.cx[j] - s * ly; out[1] = ws.cy[j] + c * ly;
+}
+// J_d^T applied to a world force f acting at pos (relative to root): translation DoFs see f, hinge a sees (pos - p_a) x f
+DTRL_HD inline real jt_force(const WS& ws, int d, const real* pos, const real* f)
+{
+	if (d == 0) return f[0];
+	if (d == 1) return f[1];
+	const int a = d - 2;
+	return (pos[0] - ws.px[a]) * f[1] - (pos[1] - ws.py[a]) * f[0];
+}
+
+// cDogController::Update, sim/DogController.cpp:229-268
+DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, real dt)
+{
+	const int D = ws.M.D, L = ws.M.L;
+	// UpdateRBDModel: H and the (quirk) bias at the post-step configuration; kinematics are already current
+	mass_matrix(ws);
+	bias_force(ws, true);
+	LANES_BEGIN
+	if (lane == 0) {
+		ws.st.curr_cycle_time += dt;
+		if (has_stumbled(ws)) ws.st.curr_stumble += dt;
+		// UpdateState :805-845
+		bool advance = ws.st.first_cycle != 0;
+		real trans_time = ws.st.params[mpTransTime];
+		ws.st.phase += dt / trans_time;
+		const int state = ws.st.state;
+		if ((state == stBackStance || state == stFrontStance) && ws.st.phase >= 1) advance = true;
+		int trans_contact = (state == stExtend) ? jFinger : ((state == stGather) ? jToe : -1);
+		if (trans_contact >= 0 && in_contact(ws, trans_contact)) advance = true;
+		int do_update = 0;
+		if (advance) {
+			int next = ws.st.first_cycle ? stBackStance : ((state == stGather) ? stInvalid : state + 1);
+			bool end_step = (next == stInvalid) || ws.st.first_cycle;
+			if (end_step) do_update = 1; else transition_state(ws, next);
+		}
+		ws.flag_update_action = do_update;
+	}
+	LANES_END
+	if (ws.flag_update_action) {
+		update_action(ws, gm, rp, buf, g, env);
+		LANES_BEGIN
+		if (lane == 0) ws.st.first_cycle = 0;
+		LANES_END
+	}
+	LANES_BEGIN
+	if (lane == 0) {
+		// ApplyFeedback :903-945 (COM velocity feedback on hip / shoulder while the matching effector is airborne)
+		real sx = 0, m = 0;
+		for (int j = 0; j < L; ++j) { sx += ws.M.mass[j] * ws.vcx[j]; m += ws.M.mass[j]; }
+		real com_vx = sx / m;
+		const int joints[2] = {jHip, jShoulder}, effs[2] = {jToe, jFinger}, prm[2] = {spHip, spShoulder};
+		for (int k = 0; k < 2; ++k) if (!in_contact(ws, effs[k])) {
+			real default_theta = ws.st.params[mpMax + ws.st.state * spMax + prm[k]];
+			ws.st.pd_target[joints[k]] = default_theta + com_vx * ws.st.params[mpCv];
+		}
+	}
+	LANES_END
+	// cImpPDController::CalcControlForces: (H + dt Kd) acc = Kp (e - dt qd) + Kd e_dot - C;  tau = Kp (e - dt qd) + Kd (e_dot - dt acc)
+	LANES_BEGIN
+	if (lane < D) {
+		const int i = lane;
+		real kp = 0, kd = 0, pe = 0, ve = 0;
+		if (i >= 3) {
+			const int j = i - 2;
+			kp = ws.M.kp[j]; kd = ws.M.kd[j];
+			real theta = ws.M.use_world[j] ? wrap_pi(ws.psi[j]) : wrap_pi(ws.st.q[i]);
+			pe = ws.st.pd_target[j] - theta;
+			ve = 0 - ws.st.qd[i];
+		}
+		ws.kpv[i] = kp; ws.kdv[i] = kd; ws.perr[i] = pe; ws.verr[i] = ve;
+		ws.H[i][i] += dt * kd;
+		ws.u[i] = kp * (pe - dt * ws.st.qd[i]) + kd * ve - ws.b[i];
+	}
+	LANES_END
+	factorize(ws);
+	LANES_BEGIN
+	if (lane == 0) { ws.R = 0; }
+	LANES_END
+	forward_subst_rows(ws, ws.u);   // R = 0: only z_0 = L^-1 rhs (lane 0)
+	LANES_BEGIN
+	if (lane < D) ws.u[lane] = ws.Z[0][lane] * ws.dinv[lane];
+	LANES_END
+	for (int i = D - 1; i >= 1; --i) {
+		LANES_BEGIN
+		if (lane < i) ws.u[lane] -= ws.H[lane][i] * ws.u[i];
+		LANES_END
+	}
+	LANES_BEGIN
+	if (lane < D) { const int i = lane; ws.tau_g[i] = 0; ws.st.tau_ctrl[i] = ws.kpv[i] * (ws.perr[i] - dt * ws.st.qd[i]) + ws.kdv[i] * (ws.verr[i] - dt * ws.u[i]); }
+	LANES_END
+	// ApplyGravityCompensation :947-995 (+ BuildContactBasis :1120-1175)
+	const bool toe_c = in_contact(ws, jToe), fin_c = in_contact(ws, jFinger);
+	if (gm.enable_grav_comp && (toe_c || fin_c)) {
+		LANES_BEGIN
+		if (lane < D) {
+			const int d = lane;
+			// -Q_g: torque that counters gravity
+			real tg;
+			const real gy = kGravityY;
+			if (d == 0) tg = 0;
+			else if (d == 1) tg = -(ws.sm[0] * gy);
+			else { const int l = d - 2; tg = -((ws.smx[l] - ws.sm[l] * ws.px[l]) * gy); }
+			ws.tau_g[d] = tg;
+			const int effs[2] = {jToe, jFinger};
+			for (int e = 0; e < 2; ++e) {
+				const int jid = effs[e];
+				real b0 = 0, b1 = 0;
+				bool on_path = (d < 3) || ((ws.M.sub_mask[d - 2] >> jid) & 1u);
+				if (in_contact(ws, jid) && on_path) {
+					real pos[2]; effector_pos(ws, jid, pos);
+					const real fy[2] = {0, 1}, fxv[2] = {1, 0};
+					b0 = jt_force(ws, d, pos, fy); b1 = jt_force(ws, d, pos, fxv);
+				}
+				ws.basis[d][e * 2 + 0] = b0; ws.basis[d][e * 2 + 1] = b1;
+			}
+		}
+		LANES_END
+		LANES_BEGIN
+		if (lane == 0) {
+			// ridge least squares on the 3 root rows: (A^T A + 1e-4 I) x = A^T b, 4x4, partial-pivot elimination
+			real M4[4][5];
+			for (int a = 0; a < 4; ++a) {
+				for (int c = 0; c < 4; ++c) { real s = 0; for (int r = 0; r < 3; ++r) s += ws.basis[r][a] * ws.basis[r][c]; M4[a][c] = s; }
+				real s = 0; for (int r = 0; r < 3; ++r) s += ws.basis[r][a] * ws.tau_g[r];
+				M4[a][4] = s; M4[a][a] += 0.0001;
+			}
+			for (int c = 0; c < 4; ++c) {
+				int p = c; for (int r = c + 1; r < 4; ++r) if (fabs(M4[r][c]) > fabs(M4[p][c])) p = r;
+				if (p != c) for (int k = 0; k < 5; ++k) { real t = M4[c][k]; M4[c][k] = M4[p][k]; M4[p][k] = t; }
+				for (int r = c + 1; r < 4; ++r) { real f = M4[r][c] / M4[c][c]; for (int k = c; k < 5; ++k) M4[r][k] -= f * M4[c][k]; }
+			}
+			real x[4];
+			for (int i = 3; i >= 0; --i) { real s = M4[i][4]; for (int k = i + 1; k < 4; ++k) s -= M4[i][k] * x[k]; x[i] = s / M4[i][i]; }
+			for (int k = 0; k < 4; ++k) ws.red[k] = x[k];
+		}
+		LANES_END
+		LANES_BEGIN
+		if (lane >= 3 && lane < D) {
+			const int d = lane;
+			real s = 0; for (int k = 0; k < 4; ++k) s += ws.basis[d][k] * ws.red[k];
+			ws.st.tau_ctrl[d] += ws.tau_g[d] - s;
+		}
+		LANES_END
+	}
+	// ApplyVirtualForces :997-1029
+	if (gm.enable_vf) {
+		LANES_BEGIN
+		if (lane >= 3 && lane < D) {
+			const int d = lane, a = d - 2;
+			const int effs[2] = {jToe, jFinger};
+			const int state = ws.st.state;
+			for (int e = 0; e < 2; ++e) {
+				const int jid = effs[e];
+				bool valid = ((state == stBackStance || state == stExtend) && jid == jToe) || ((state == stFrontStance || state == stGather) && jid == jFinger);
+				if (!(valid && in_contact(ws, jid))) continue;
+				// chain: effector up to (excluding) root / torso
+				bool on_chain = ((ws.M.sub_mask[a] >> jid) & 1u) && a != jRoot && a != jTorso;
+				if (on_chain && jid == jFinger) on_chain = !((ws.M.sub_mask[a] >> jTorso) & 1u);  // strictly below the torso
+				if (!on_chain) continue;
+				real f[2];
+				if (jid == jToe) { f[0] = -ws.st.params[mpBackForceX]; f[1] = -ws.st.params[mpBackForceY]; }
+				else { f[0] = -ws.st.params[mpFrontForceX]; f[1] = -ws.st.params[mpFrontForceY]; }
+				real pos[2]; effector_pos(ws, jid, pos);
+				ws.st.tau_ctrl[d] += jt_force(ws, d, pos, f);
+			}
+		}
+		LANES_END
+	}
+	// cSimCharacter::ApplyControlForces + cJoint::ApplyTorque clamp (sim/Joint.cpp:171-201, 257-264)
+	LANES_BEGIN
+	if (lane < D) {
+		const int d = lane;
+		real t = 0;
+		if (d >= 3) { t = ws.st.tau_ctrl[d]; real lim = ws.M.torque_lim[d - 2]; if (fabs(t) > lim) t *= lim / fabs(t); }
+		ws.st.tau[d] = t;
+	}
+	LANES_END
+}
+
+// dog reward, sim/DogController.cpp:594-628
+DTRL_HD inline real calc_reward(const WS& ws, const DevModel& gm)
+{
+	real vel_reward = 0, stumble_reward = 0;
+	if (!has_fallen(ws)) {
+		real cycle_time = ws.st.prev_cycle_time;
+		real avg_vel = ws.st.prev_dist[0] / cycle_time;
+		real vel_err = gm.target_vel_x - avg_vel;
+		vel_reward = exp(-0.5 * vel_err * vel_err);
+		real avg_stumble = ws.st.prev_stumble / cycle_time;
+		stumble_reward = 1.0 / (1 + 10 * avg_stumble);
+	}
+	return 0.8 * vel_reward + 0.2 * stumble_reward;
+}
+
+// cScenarioExp::NewCycleUpdate (+ cScenarioExpMACE flags): finish the running tuple, start the next one
+DTRL_HD inline void scenario_new_cycle(WS& ws, const DevModel& gm, const DevBuffers& buf, int env)
+{
+	LANES_BEGIN
+	if (lane == 0) { ws.st.num_cycles += 1; ws.flag_new_cycle = -1; }
+	LANES_END
+	if (gm.scenario != kScnExp) return;
+	const real* ps = buf.poli_state + static_cast<int64_t>(env) * buf.S;
+	real* s0 = buf.tup_s0 + static_cast<int64_t>(env) * buf.S;
+	real* ta = buf.tup_a + static_cast<int64_t>(env) * buf.A;
+	LANES_BEGIN
+	if (lane == 0) {
+		int slot = -1;
+		if (ws.st.cycle_count > 1) {  // gNumWarmupCycles = 1 (scenarios/ScenarioExp.cpp:12, 314-318)
+#if defined(__HIP_DEVICE_COMPILE__)
+			slot = atomicAdd(buf.tuple_count, 1);
+#else
+			slot = (*buf.tuple_count)++;
+#endif
+			if (slot >= buf.tuple_cap) slot = -1;
+		}
+		ws.flag_new_cycle = slot;
+		if (slot >= 0) {
+			bool fail = has_fallen(ws);
+			uint32_t flags = (static_cast<uint32_t>(ws.st.tuple_flags) & ~1u) | (fail ? 1u : 0u);
+			buf.tuple_flags[slot] = flags;
+			buf.tuple_env[slot] = env;
+			buf.tuple_rows[static_cast<int64_t>(slot) * buf.W] = static_cast<float>(calc_reward(ws, gm));
+		}
+	}
+	LANES_END
+	LANES_BEGIN
+	const int slot = ws.flag_new_cycle;
+	if (slot >= 0) {
+		float* row = buf.tuple_rows + static_cast<int64_t>(slot) * buf.W;
+		for (int i = lane; i < buf.S; i += kGroup) { row[1 + i] = static_cast<float>(s0[i]); row[1 + buf.S + buf.A + i] = static_cast<float>(ps[i]); }
+		for (int i = lane; i < buf.A; i += kGroup) row[1 + buf.S + i] = static_cast<float>(ta[i]);
+	}
+	LANES_END
+	LANES_BEGIN
+	for (int i = lane; i < buf.S; i += kGroup) s0[i] = ps[i];
+	if (lane == 0) {
+		ta[0] = ws.st.action_id;
+		for (int k = 0; k < gm.n_opt; ++k) ta[1 + k] = ws.st.params[gm.opt_index[k]];
+		int flags = 0;
+		if (gm.ctrl_type == 1) flags |= (ws.st.exp_critic ? 2 : 0) | (ws.st.exp_actor ? 4 : 0);
+		ws.st.tuple_flags = flags;
+		ws.st.cycle_count += 1;
+	}
+	LANES_END
+}
+
+// one iteration of scenarios/ScenarioSimChar.cpp:162-173
+DTRL_HD inline void env_step(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, real dt)
+{
+	const real h = dt / gm.num_sim_substeps;
+	for (int s = 0; s < gm.num_sim_substeps; ++s) substep(ws, g, h);   // UpdateWorld
+	forward_kinematics(ws);
+	detect_contacts(ws, g);                                               // cContactManager::Update
+	// UpdateGround is host-side at frame boundaries (the 1 m look-ahead margin makes that equivalent; DESIGN.md "Ground")
+	controller_update(ws, gm, rp, buf, g, env, dt);                       // UpdateCharacter
+	LANES_BEGIN
+	if (lane == 0) {
+		// cSimCharSoftFall::UpdateFallDistCheck / UpdateFallContactCheck
+		ws.st.fall_dist_counter -= dt;
+		if (ws.st.fall_dist_counter <= 0) {
+			real dx = ws.st.q[0] - ws.st.prev_check[0], dy = ws.st.q[1] - ws.st.prev_check[1];
+			if (dx * dx + dy * dy < 0.5 * 0.5) ws.st.fail_fall_dist = 1;
+			ws.st.prev_check[0] = ws.st.q[0]; ws.st.prev_check[1] = ws.st.q[1]; ws.st.fall_dist_counter = 5;
+		}
+		ws.st.fall_contact_counter -= dt;
+		if (ws.st.fall_contact_counter <= 0) {
+			const real discount = 0.9, norm = (1 + 1 / (1 - discount));
+			real val = check_fall_contact(ws) ? 1 : 0;
+			ws.st.sum_fall_contact = val / norm + discount * ws.st.sum_fall_contact;
+			ws.st.fall_contact_counter = 0.1;
+		}
+		ws.st.time += dt;
+		ws.flag_misc = is_new_cycle(ws) ? 1 : 0;
+	}
+	LANES_END
+	if (ws.flag_misc) scenario_new_cycle(ws, gm, buf, env);              // PostSubstepUpdate
+}
+
+// cSimCharacter::Reset + controller Reset; init=true additionally follows cScenarioSimChar::Init ordering
+DTRL_HD inline void reset_env(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, bool init)
+{
+	LANES_BEGIN
+	if (lane < gm.D) { ws.st.q[lane] = gm.pose0[lane]; ws.st.qd[lane] = gm.vel0[lane]; ws.st.tau[lane] = 0; ws.st.tau_ctrl[lane] = 0; }
+	if (init && lane < gm.L) ws.st.pd_target[lane] = gm.target_theta[lane];
+	LANES_END
+	forward_kinematics(ws);
+	LANES_BEGIN
+	if (lane == 0) {
+		Rng rng = make_rng(rp, env, &ws.st.rng_ctr);
+		const int num_frags = gm.has_net ? buf.net.n_frags : 0;
+		ws.st.exp_actor = 0; ws.st.exp_critic = 0;
+		int id; real prm[kMaxP];
+		build_base_action(gm, num_frags, gm.default_action, rng, &id, prm);
+		apply_action(ws, id, prm, gm.P);
+		ws.st.state = 0; ws.st.phase = 0; ws.st.first_cycle = 1; ws.st.is_off_policy = 0;
+		ws.st.sample_origin[0] = 0; ws.st.sample_origin[1] = 0;
+		ws.st.prev_cycle_time = 0; ws.st.prev_dist[0] = 0; ws.st.prev_dist[1] = 0; ws.st.curr_cycle_time = 0;
+		ws.st.prev_stumble = 0; ws.st.curr_stumble = 0;
+		ws.st.cmd_action = -1;
+		calc_com(ws, ws.st.prev_com);
+		ws.st.fall_dist_counter = 5; ws.st.prev_check[0] = ws.st.q[0]; ws.st.prev_check[1] = ws.st.q[1]; ws.st.fail_fall_dist = 0;
+		ws.st.fall_contact_counter = 0.1; ws.st.sum_fall_contact = 0;
+		ws.st.contact_bits = 0;
+		ws.st.time = 0;
+		// cScenarioSimChar::InitCharacterPos
+		if (gm.valid_init_pos_x) ws.st.q[0] = gm.init_pos_x;
+		ws.st.q[1] += sample_ground(g, ws.st.q[0], nullptr, nullptr, nullptr, nullptr);
+		if (init) { real com[2]; calc_com(ws, com); ws.st.prev_com[0] = com[0]; ws.st.prev_com[1] = com[1]; }
+		else ws.st.num_resets += 1;
+		if (gm.scenario == kScnExp) { ws.st.cycle_count = 0; ws.st.cmd_action = rng.rand_int(0, gm.n_actions); }
+		if (gm.scenario == kScnPoliEval) ws.st.pos_start_x = ws.st.q[0];
+		ws.st.do_reset = 0; ws.st.do_init = 0; ws.st.need_reset = 0;
+	}
+	LANES_END
+	forward_kinematics(ws);
+}
+
+// end-of-frame scenario logic: cScenarioExp::Update / cScenarioPoliEval::Update tail (fall -> NewCycleUpdate, request reset)
+DTRL_HD inline void frame_end(WS& ws, const DevModel& gm, const DevBuffers& buf, int env)
+{
+	LANES_BEGIN
+	if (lane == 0) {
+		int mode = 0;
+		if (gm.scenario == kScnExp) { if (!is_new_cycle(ws) && has_fallen(ws)) mode = 1; }
+		else if (gm.scenario == kScnPoliEval) {
+			if (has_fallen(ws)) {
+				real dist = ws.st.q[0] - ws.st.pos_start_x;
+				ws.st.avg_dist = (ws.st.num_episodes * ws.st.avg_dist + dist) / (ws.st.num_episodes + 1.0);
+				ws.st.num_episodes += 1;
+				mode = 2;
+			}
+		}
+		ws.flag_misc = mode;
+	}
+	LANES_END
+	if (ws.flag_misc == 1) scenario_new_cycle(ws, gm, buf, env);
+	LANES_BEGIN
+	if (lane == 0 && ws.flag_misc != 0) ws.st.need_reset = 1;
+	LANES_END
+}
+
+DTRL_HD inline void load_hot_model(WS& ws, const DevModel& gm)
+{
+	LANES_BEGIN
+	if (lane == 0) { ws.M.L = gm.L; ws.M.D = gm.D; }
+	if (lane < gm.L) {
+		const int j = lane;
+		ws.M.parent[j] = gm.parent[j]; ws.M.depth[j] = gm.depth[j]; ws.M.col[j] = gm.col[j]; ws.M.use_world[j] = gm.use_world[j];
+		for (int k = 0; k < kMaxDepth; ++k) ws.M.path[j][k] = gm.path[j][k];
+		ws.M.sub_mask[j] = gm.sub_mask[j];
+		ws.M.attach[j][0] = gm.attach[j][0]; ws.M.attach[j][1] = gm.attach[j][1];
+		ws.M.lim_lo[j] = gm.lim_lo[j]; ws.M.lim_hi[j] = gm.lim_hi[j];
+		ws.M.body_attach[j][0] = gm.body_attach[j][0]; ws.M.body_attach[j][1] = gm.body_attach[j][1];
+		ws.M.body_theta[j] = gm.body_theta[j]; ws.M.body_half[j][0] = gm.body_half[j][0]; ws.M.body_half[j][1] = gm.body_half[j][1];
+		ws.M.mass[j] = gm.mass[j]; ws.M.inertia[j] = gm.inertia[j]; ws.M.kp[j] = gm.kp[j]; ws.M.kd[j] = gm.kd[j]; ws.M.torque_lim[j] = gm.torque_lim[j];
+	}
+	LANES_END
+}
+
+// the whole per-env frame: load -> (reset) -> n_steps env-steps -> frame-end logic -> store
+DTRL_HD inline void env_frame(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, int env, int n_steps, real dt, bool do_frame_end)
+{
+	load_hot_model(ws, gm);
+	{
+		const uint64_t* src = reinterpret_cast<const uint64_t*>(&buf.st[env]);
+		uint64_t* dst = reinterpret_cast<uint64_t*>(&ws.st);
+		LANES_BEGIN
+		for (int i = lane; i < static_cast<int>(sizeof(EnvState) / 8); i += kGroup) dst[i] = src[i];
+		LANES_END
+	}
+	const GroundRec& g = buf.gr[env];
+	if (ws.st.do_init) reset_env(ws, gm, rp, buf, g, env, true);
+	else if (ws.st.do_reset) reset_env(ws, gm, rp, buf, g, env, false);
+	else forward_kinematics(ws);
+	for (int s = 0; s < n_steps; ++s) env_step(ws, gm, rp, buf, g, env, dt);
+	if (do_frame_end) frame_end(ws, gm, buf, env);
+	{
+		uint64_t* dst = reinterpret_cast<uint64_t*>(&buf.st[env]);
+		const uint64_t* src = reinterpret_cast<const uint64_t*>(&ws.st);
+		LANES_BEGIN
+		for (int i = lane; i < static_cast<int>(sizeof(EnvState) / 8); i += kGroup) dst[i] = src[i];
+		if (lane == 0) { buf.status[env].root_x = ws.st.q[0]; buf.status[env].need_reset = ws.st.need_reset; buf.status[env].n_tuples = 0; }
+		LANES_END
+	}
+}
+
+}  // namespace dtrl

@@ -1,0 +1,126 @@
+// dtrl_types.h -- plain-old-data layouts shared by the host loader, the HIP kernels and the lane-loop unit-test
+// build of the kernel math. Everything here is trivially copyable so the host can hipMemcpy it verbatim.
+//
+// Data layout in HBM (one record per env, records contiguous; a 64-lane wavefront owns one env and its lanes read
+// consecutive elements of that env's record, so every load of a record field is a coalesced burst):
+//   EnvState   persistent simulation + controller state              (~4.5 KB, fp64)
+//   GroundRec  the env's two sliding heightfield segments (float)    (~4.2 KB)
+//   policy-state / tuple scratch and NN activation scratch live in separate per-env slabs (DevBuffers in the engine)
+#pragma once
+#include <cstdint>
+
+namespace dtrl {
+
+typedef double real;
+
+constexpr int kGroup = 64;       // lanes per env = one CDNA wavefront
+constexpr int kMaxL = 24;        // links
+constexpr int kMaxD = 26;        // generalised coordinates (planar root = 3, one per hinge)
+constexpr int kMaxP = 40;        // controller params per action (dog 30, raptor 37)
+constexpr int kMaxSets = 8;
+constexpr int kMaxAct = 16;
+constexpr int kMaxDepth = 12;    // longest root->link path (dog: 10)
+constexpr int kMaxRows = 32;     // constraint rows per substep (joint limits + 2 per contact point)
+constexpr int kPtsPerLink = 6;   // contact sample points per box link (4 corners + 2 long-edge midpoints)
+constexpr int kMaxPts = kMaxL * kPtsPerLink;
+constexpr int kSegCap = 512;     // floats per heightfield segment slot (51 m at 0.1 m spacing)
+constexpr int kNumGroundSamples = 200;
+constexpr int kMaxFrags = 4;
+
+// Integrator v1 constants (DESIGN.md "Integrator v1"; mirrored by oracle/or_sim.h SimConst)
+constexpr real kErp = 0.2;
+constexpr real kSlop = 0.001;
+constexpr real kMu = 0.9 * 0.9;
+constexpr real kVDepenMax = 1.0;
+constexpr real kLimitErp = 0.2;
+constexpr int kPgsIters = 10;
+constexpr real kGravityY = -9.8;
+
+enum Scenario { kScnSimChar = 0, kScnExp = 1, kScnPoliEval = 2 };
+
+struct DevModel {
+	int32_t L, D, P, n_opt;
+	int32_t char_type, ctrl_type, scenario;
+	int32_t num_update_steps, num_sim_substeps;
+	int32_t n_sets, n_actions, default_action, enable_grav_comp, enable_vf;
+	int32_t valid_init_pos_x, has_net;
+	int32_t parent[kMaxL];
+	int32_t depth[kMaxL];
+	int8_t path[kMaxL][kMaxDepth];   // path[j][0..depth[j]] = root .. j
+	uint32_t sub_mask[kMaxL];        // bit k set <=> link k is in the subtree rooted at j (incl. j)
+	int32_t col[kMaxL];
+	int32_t use_world[kMaxL];
+	int32_t act_idx0[kMaxAct], act_idx1[kMaxAct], act_cyclic[kMaxAct];
+	int32_t opt_index[kMaxP];        // opt_index[k] = param index of the k-th optimisable param
+	real attach[kMaxL][2];
+	real lim_lo[kMaxL], lim_hi[kMaxL];
+	real body_attach[kMaxL][2];
+	real body_theta[kMaxL];
+	real body_half[kMaxL][2];        // half extents
+	real mass[kMaxL];
+	real inertia[kMaxL];             // Izz about the COM: m/12 (sx^2 + sy^2)
+	real kp[kMaxL], kd[kMaxL], torque_lim[kMaxL], target_theta[kMaxL];
+	real act_blend[kMaxAct];
+	real ctrl_params[kMaxSets][kMaxP];
+	real pose0[kMaxD], vel0[kMaxD];
+	real init_pos_x, target_vel_x, total_mass;
+	real world_scale;
+};
+
+// exploration knobs + seeds: may change between launches (dtrl_set_explore)
+struct RunParams {
+	int32_t enable_exp;
+	real exp_rate, exp_temp, exp_base_rate, exp_noise;
+	uint64_t rng_seed;
+	int64_t env_id_base;   // global env id of local env 0 (multi-GPU sharding keeps per-env streams shard-invariant)
+};
+
+struct EnvState {
+	real q[kMaxD], qd[kMaxD];
+	real tau[kMaxD];        // clamped joint torques held during the next world update
+	real tau_ctrl[kMaxD];   // controller output before clamping (observability / parity tests)
+	real pd_target[kMaxL];
+	real params[kMaxP];     // current action parameters (mCurrAction.mParams)
+	real phase, curr_cycle_time, prev_cycle_time, prev_stumble, curr_stumble;
+	real prev_com[2], prev_dist[2];
+	real fall_dist_counter, fall_contact_counter, sum_fall_contact, prev_check[2];
+	real sample_origin[2];
+	real time;
+	real pos_start_x, avg_dist;
+	uint64_t rng_ctr;
+	int64_t num_cycles, num_resets, num_episodes;
+	int32_t action_id, state, first_cycle, is_off_policy;
+	int32_t exp_actor, exp_critic, cmd_action, fail_fall_dist;
+	uint32_t contact_bits;
+	int32_t cycle_count, tuple_flags;
+	int32_t need_reset;      // set by the kernel at frame end (fall); host regenerates terrain, then sets do_reset
+	int32_t do_reset;        // consumed by the kernel at frame start
+	int32_t do_init;         // first launch: full cScenario::Init ordering
+	int32_t pad_;
+};
+
+struct GroundRec {
+	// logical order: slot 0 = min segment, slot 1 = max segment (the host resolves the reference's mFlipSeg)
+	double origin_x[2], scale_x[2], min_x[2], max_x[2];
+	int32_t w[2];
+	int32_t pad_[2];
+	float data[2][kSegCap];
+};
+
+// per-env status the host reads back after each frame (16 B, coalesced)
+struct EnvStatus {
+	double root_x;
+	int32_t need_reset;
+	int32_t n_tuples;
+};
+
+// MACE network family (data/policies/*/nets/*_mace3_deploy.prototxt)
+struct NetDesc {
+	int32_t n_terrain, n_char;
+	int32_t conv_ch[3], conv_k[3];
+	int32_t fc_terr, fc_trunk, fc_head, n_frags, frag_size;
+	int32_t in_size, out_size;
+	int64_t num_params;
+};
+
+}  // namespace dtrl

@@ -1,0 +1,43 @@
+// dtrl_backend_emul.cpp -- TEST-ONLY backend: runs the very same lane-phase kernel source (dtrl_kernel.h) with the lane
+// loop expanded on the host, so tests can check the kernel math and the engine's host logic on a box without a GPU.
+// It is linked ONLY into libdtrl_emul.so, which nothing in the product loads (deepterrainrl_amd/__init__.py loads
+// libdtrl.so and raises if the HIP library or device is missing). It is not a CPU fallback and is never benchmarked.
+#include "../dtrl_engine.h"
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace dtrl {
+
+class EmulBackend : public Backend {
+public:
+	bool Init(int, std::string&) override { return true; }
+	void* Alloc(size_t bytes) override { return std::calloc(1, bytes ? bytes : 1); }
+	void Free(void* p) override { std::free(p); }
+	bool H2D(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
+	bool D2H(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
+	bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) override
+	{
+		int nt = std::min<int>(n_envs, std::max(1u, std::thread::hardware_concurrency()));
+		if (buf.tuple_count && nt > 1 && gm->scenario == kScnExp) nt = 1;   // the tuple cursor is a plain int on the host
+		std::vector<std::thread> th;
+		for (int t = 0; t < nt; ++t) th.emplace_back([=]() {
+			WS* ws = new WS();
+			for (int e = t; e < n_envs; e += nt) env_frame(*ws, *gm, rp, buf, e, n_steps, dt, frame_end);
+			delete ws;
+		});
+		for (auto& x : th) x.join();
+		++launches_;
+		return true;
+	}
+	bool Sync() override { return true; }
+	void KernelTime(double* avg_ms, int64_t* launches) override { if (avg_ms) *avg_ms = 0; if (launches) *launches = launches_; launches_ = 0; }
+	const char* Name() const override { return "emul"; }
+private:
+	int64_t launches_ = 0;
+};
+
+Backend* MakeBackend() { return new EmulBackend(); }
+
+}  // namespace dtrl

@@ -1,0 +1,131 @@
+/* dtrl.h -- C ABI of the MI355X batched rollout engine (libdtrl.so).
+ *
+ * The reference (xbpeng/DeepTerrainRL) has no FFI; its seam is the C++ virtual interface between the scenario
+ * drivers (cScenarioTrain::ExpHelper, cOptScenarioPoliEval::EvalHelper) and ONE environment object. This header is
+ * that seam for a BATCH of environments: every entry point names the reference interface it replaces
+ * (file:line relative to the reference repo root). All buffers are caller-owned host memory; no torch types.
+ * A batch handle is driven from one host thread (like one reference scenario object, scenarios/ScenarioTrain.cpp:467-475).
+ *
+ * Error behaviour mirrors the reference's bool-return + message convention (no exceptions): every call returns a
+ * dtrl_status; dtrl_last_error() gives the message. There is NO CPU fallback: dtrl_create fails with
+ * DTRL_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef DTRL_H_
+#define DTRL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dtrl_batch dtrl_batch;
+
+typedef enum {
+	DTRL_OK = 0,
+	DTRL_ERR_ARG = 1,        /* bad argument / arg file */
+	DTRL_ERR_IO = 2,         /* missing or malformed data file */
+	DTRL_ERR_NO_DEVICE = 3,  /* no usable HIP device (product never falls back to CPU) */
+	DTRL_ERR_DEVICE = 4,     /* HIP runtime error */
+	DTRL_ERR_UNSUPPORTED = 5,
+	DTRL_ERR_CAPACITY = 6
+} dtrl_status;
+
+/* flags returned by dtrl_get_flags */
+#define DTRL_FLAG_FALLEN 1u
+#define DTRL_FLAG_STUMBLED 2u
+#define DTRL_FLAG_NEW_CYCLE 4u
+#define DTRL_FLAG_STATE_SHIFT 8
+
+/* tuple flag bits: learning/MACETrainer.h:11-17 (eFlagFail, eFlagExpCritic, eFlagExpActor) */
+#define DTRL_TUPLE_FAIL 1u
+#define DTRL_TUPLE_EXP_CRITIC 2u
+#define DTRL_TUPLE_EXP_ACTOR 4u
+
+/* Build a batch of num_envs environments from reference-format arguments.
+ * Replaces: cArgParser(argv) + AppendArgs(-arg_file) (optimizer/Main.cpp:19-32, util/ArgParser.cpp:42-108) and, per env,
+ * cScenarioExp/cScenarioPoliEval::ParseArgs + Init (scenarios/ScenarioSimChar.cpp:76-119, scenarios/ScenarioExp.cpp:31-61),
+ * i.e. cScenarioTrain::BuildScenePool (scenarios/ScenarioTrain.cpp:197-222).
+ * Relative paths inside the arg file resolve against the value of "-data_root=" if given, else the current directory
+ * (the reference is run from its repo root). Extra keys understood: -data_root=, -terrain_seed= (env i uses seed+i),
+ * -rand_seed= (exploration streams), -global_env_offset= (first global env id of this shard).
+ * device_id < 0 selects the current HIP device. */
+dtrl_status dtrl_create(const char* const* argv, int argc, int num_envs, int device_id, dtrl_batch** out);
+
+/* Replaces: cScenario::Clear/Shutdown + destructor (scenarios/Scenario.h:15-23). */
+dtrl_status dtrl_destroy(dtrl_batch* b);
+
+/* Replaces: cScenarioExp::Reset / cScenarioPoliEval::Reset on the listed envs (scenarios/ScenarioSimChar.cpp:121-132,
+ * scenarios/ScenarioExp.cpp:63-73). env_ids == NULL resets all. terrain_seeds != NULL re-seeds those envs' ground RNG
+ * first (cScenarioPoliEval::SetRandSeed, scenarios/ScenarioPoliEval.cpp:153-160). */
+dtrl_status dtrl_reset(dtrl_batch* b, const int32_t* env_ids, int n, const uint64_t* terrain_seeds);
+
+/* Replaces: cScenarioExp::Update(dt) / cScenarioPoliEval::Update(dt) on every env
+ * (scenarios/ScenarioExp.cpp:83-98, scenarios/ScenarioPoliEval.cpp:110-125): num_update_steps iterations of the loop at
+ * scenarios/ScenarioSimChar.cpp:162-173, then fall handling (tuple + reset). dt is normally 1/30. */
+dtrl_status dtrl_step(dtrl_batch* b, double dt);
+
+/* Finer grain: n iterations of the loop body only (no end-of-frame fall handling); used by parity tests and to count in
+ * env-steps. The step length is (1/30)/num_update_steps. */
+dtrl_status dtrl_step_updates(dtrl_batch* b, int n);
+
+/* Asynchronous variant of dtrl_step for throughput runs: enqueue `frames` outer frames back-to-back on the batch's HIP
+ * stream, doing the per-frame host work (terrain window slides, fall resets) between launches. Returns after the last
+ * frame completed. */
+dtrl_status dtrl_run_frames(dtrl_batch* b, int frames, double dt);
+
+/* Replaces: cNNController::LoadNet + LoadModel + LoadScale (sim/NNController.cpp:49-91; learning/NeuralNet.cpp:81-215)
+ * and cNeuralNet::CopyModel pushes from the trainer (learning/NeuralNetLearner.cpp:85-89). weights: flat float32 in Caffe
+ * blob order of the deploy prototxt named by -policy_net= (W then b per layer). Offsets/scales follow
+ * learning/NeuralNet.cpp:977-986,1027-1036. n must equal dtrl_policy_num_params(). */
+dtrl_status dtrl_set_policy(dtrl_batch* b, const float* weights, size_t n, const double* in_off, const double* in_scale, const double* out_off, const double* out_scale);
+dtrl_status dtrl_policy_num_params(const dtrl_batch* b, size_t* n);
+
+/* Replaces: cNNController::BuildNNOutputOffsetScale (sim/BaseControllerMACE.cpp:75-113, sim/DogControllerMACE.cpp:93-99);
+ * used by cScenarioTrain::SetupTrainerOutputOffsetScale (scenarios/ScenarioTrain.cpp:322-338). */
+dtrl_status dtrl_build_output_offset_scale(const dtrl_batch* b, double* out_off, double* out_scale);
+
+/* Replaces: cScenarioExp::EnableExplore / SetExpRate / SetExpTemp / SetExpBaseActionRate (scenarios/ScenarioExp.cpp:161-206). */
+dtrl_status dtrl_set_explore(dtrl_batch* b, int enable, double rate, double temp, double base_rate);
+
+/* Replaces: cScenarioSimChar::SetTerrainParamsLerp (scenarios/ScenarioSimChar.cpp:255-272). */
+dtrl_status dtrl_set_terrain_lerp(dtrl_batch* b, double lerp);
+
+/* Replaces: cScenarioExp::IsTupleBufferFull/GetTuples/ResetTupleBuffer (scenarios/ScenarioExp.h:16-38) for the whole batch.
+ * rows: [cap][1 + 2S + A] float32 in the MACE replay row layout [r | s | a | s'] (learning/MACETrainer.cpp:373-401). */
+dtrl_status dtrl_drain_tuples(dtrl_batch* b, float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n);
+
+/* Replaces: cSimCharacter::BuildPose / BuildVel (sim/SimCharacter.cpp:166-225). env_ids == NULL -> envs 0..n-1. */
+dtrl_status dtrl_get_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, double* q, double* qd);
+/* Replaces: cSimCharacter::SetPose / SetVel (sim/SimCharacter.cpp:665-683, 227-315). */
+dtrl_status dtrl_set_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, const double* q, const double* qd);
+/* Replaces: cNNController::RecordPoliState (sim/TerrainRLCharController.cpp:120-123). */
+dtrl_status dtrl_get_poli_state(dtrl_batch* b, const int32_t* env_ids, int n, double* s);
+/* fallen | stumbled<<1 | new_cycle<<2 | fsm_state<<8: cSimCharacter::HasFallen/HasStumbled, cCharController::IsNewCycle/GetState. */
+dtrl_status dtrl_get_flags(dtrl_batch* b, const int32_t* env_ids, int n, uint32_t* bits);
+/* observability for parity tests: controller torque before / after the cJoint clamp (sim/Joint.cpp:171-201), per-link contact flags */
+dtrl_status dtrl_get_torques(dtrl_batch* b, const int32_t* env_ids, int n, double* tau_ctrl, double* tau_applied);
+dtrl_status dtrl_get_contacts(dtrl_batch* b, const int32_t* env_ids, int n, int32_t* flags);
+/* current action: cTerrainRLCharController::GetCurrActionID + mCurrAction.mParams, PD targets */
+dtrl_status dtrl_get_ctrl(dtrl_batch* b, const int32_t* env_ids, int n, int32_t* state, double* phase, int32_t* action_id, double* params, double* pd_targets);
+/* ground observability: cGround::SampleHeight (sim/GroundVar2D.cpp:98-114) with the grid cell it used (terrain-index parity) */
+dtrl_status dtrl_sample_ground(dtrl_batch* b, int env, int n, const double* x, double* h, int32_t* seg, int32_t* i, int32_t* j);
+
+/* Replaces: cScenarioPoliEval::GetAvgDist / GetNumEpisodes / GetNumCycles (scenarios/ScenarioPoliEval.h:20-26), batch aggregate. */
+dtrl_status dtrl_eval_stats(dtrl_batch* b, double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets);
+
+/* sizes: L links, D dofs, S policy-state, A policy-action (1 + frag), P controller params, nn_out, num_frags, frag_size */
+dtrl_status dtrl_dims(const dtrl_batch* b, int* L, int* D, int* S, int* A, int* P, int* nn_out, int* num_frags, int* frag_size);
+
+/* HIP stream the batch launches on (so callers can bracket it with their own events), and the last kernel timing:
+ * average duration in ms of the frame kernel over the launches since the previous call, measured with hipEvents on that stream. */
+dtrl_status dtrl_kernel_time_ms(dtrl_batch* b, double* avg_ms, int64_t* launches);
+
+const char* dtrl_last_error(const dtrl_batch* b);
+const char* dtrl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTRL_H_ */

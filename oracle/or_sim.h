@@ -28,7 +28,7 @@ struct SimConst {
 	static constexpr double v_depen_max = 1.0;
 	static constexpr double limit_erp = 0.2;
 	static constexpr int pgs_iters = 10;
-	static constexpr int max_rows = 64;
+	static constexpr int max_rows = 32;
 	static constexpr int pts_per_link = 6;
 };
 
