@@ -14,8 +14,8 @@ namespace dtrl {
 __global__ void __launch_bounds__(kGroup) dtrl_frame_kernel(const DevModel* __restrict__ gm, RunParams rp, DevBuffers buf, int n_envs, int n_steps, real dt, int frame_end)
 {
 	__shared__ WS ws;
-	const int env = static_cast<int>(blockIdx.x);
-	if (env >= n_envs) return;
+	if (static_cast<int>(blockIdx.x) >= n_envs) return;
+	const int env = buf.env_list ? buf.env_list[blockIdx.x] : static_cast<int>(blockIdx.x);
 	env_frame(ws, *gm, rp, buf, env, n_steps, dt, frame_end != 0);
 }
 

@@ -67,6 +67,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	buf_.tuple_flags = static_cast<uint32_t*>(alloc(sizeof(uint32_t) * buf_.tuple_cap));
 	buf_.tuple_env = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
 	buf_.tuple_count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));
+	d_env_list_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
 	if (!d_model_ || !buf_.st || !buf_.gr || !buf_.status || !buf_.poli_state || !buf_.tup_s0 || !buf_.tup_a || !buf_.tuple_rows || !buf_.tuple_flags || !buf_.tuple_env || !buf_.tuple_count)
 		return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
 	if (cfg_.has_policy_net) {
@@ -115,10 +116,23 @@ bool Engine::UploadGround(int env)
 	return true;
 }
 
+// device-side half of a reset (cSimCharacter::Reset + controller reset + InitCharacterPos), on the listed envs only:
+// a compact 0-step launch, so getters observe the reset state right after Update() as with the reference
+int Engine::ApplyResets(const std::vector<int32_t>& ids)
+{
+	if (ids.empty()) return DTRL_OK;
+	if (!be_->H2D(d_env_list_, ids.data(), sizeof(int32_t) * ids.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
+	DevBuffers b = buf_;
+	b.env_list = d_env_list_;
+	if (!be_->Launch(d_model_, cfg_.run, b, static_cast<int>(ids.size()), 0, 0.0, false)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	return DTRL_OK;
+}
+
 int Engine::HostFrameWork()
 {
 	if (!be_->D2H(status_.data(), buf_.status, sizeof(EnvStatus) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	const int32_t one = 1;
+	reset_ids_.clear();
 	for (int e = 0; e < n_; ++e) {
 		const EnvStatus& s = status_[e];
 		GroundWindow& g = grounds_[e];
@@ -128,11 +142,12 @@ int Engine::HostFrameWork()
 			g.Update(-kViewDist + kGroundSpawnOffset, kViewDist + kGroundSpawnOffset);
 			if (!UploadGround(e)) return DTRL_ERR_CAPACITY;
 			if (!be_->H2D(reinterpret_cast<char*>(&buf_.st[e]) + offsetof(EnvState, do_reset), &one, sizeof(one))) return Fail(DTRL_ERR_DEVICE, be_->error());
+			reset_ids_.push_back(e);
 		} else if (g.Update(s.root_x - 2, s.root_x + kViewDist + kViewPad)) {
 			if (!UploadGround(e)) return DTRL_ERR_CAPACITY;
 		}
 	}
-	return DTRL_OK;
+	return ApplyResets(reset_ids_);
 }
 
 int Engine::Step(double dt)
@@ -163,6 +178,7 @@ int Engine::Reset(const int32_t* env_ids, int n, const uint64_t* seeds)
 {
 	const int cnt = env_ids ? n : n_;
 	const int32_t one = 1;
+	reset_ids_.clear();
 	for (int i = 0; i < cnt; ++i) {
 		int e = EnvIndex(env_ids, i);
 		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
@@ -172,9 +188,10 @@ int Engine::Reset(const int32_t* env_ids, int n, const uint64_t* seeds)
 		g.Update(-kViewDist + kGroundSpawnOffset, kViewDist + kGroundSpawnOffset);
 		if (!UploadGround(e)) return DTRL_ERR_CAPACITY;
 		if (!be_->H2D(reinterpret_cast<char*>(&buf_.st[e]) + offsetof(EnvState, do_reset), &one, sizeof(one))) return Fail(DTRL_ERR_DEVICE, be_->error());
+		reset_ids_.push_back(e);
 	}
-	// perform the device-side part now so getters observe the reset state (0 env-steps)
-	if (!be_->Launch(d_model_, cfg_.run, buf_, n_, 0, 0.0, false)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	int rc = ApplyResets(reset_ids_);
+	if (rc != DTRL_OK) return rc;
 	if (!be_->Sync()) return Fail(DTRL_ERR_DEVICE, be_->error());
 	return DTRL_OK;
 }

@@ -57,6 +57,9 @@ public:
 private:
 	int Fail(int code, const std::string& msg) { err_ = msg; return code; }
 	int HostFrameWork();
+	int ApplyResets(const std::vector<int32_t>& ids);
+	int32_t* d_env_list_ = nullptr;
+	std::vector<int32_t> reset_ids_;
 	bool UploadGround(int env);
 	int EnvIndex(const int32_t* env_ids, int i) const { return env_ids ? env_ids[i] : i; }
 

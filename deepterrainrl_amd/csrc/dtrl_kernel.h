@@ -73,6 +73,7 @@ struct DevBuffers {
 	int32_t tuple_cap;
 	int32_t S, A, W;
 	int32_t nn_scratch_stride;
+	const int32_t* env_list;   // optional indirection: workgroup b handles env_list[b] (compact reset launches)
 	const float* weights;
 	const real* in_off; const real* in_scale; const real* out_off; const real* out_scale;
 	NetDesc net;
@@ -382,8 +383,8 @@ DTRL_HD inline void build_rows(WS& ws, real h)
 		for (int j = 1; j < ws.M.L; ++j) {
 			if (ws.M.lim_lo[j] > ws.M.lim_hi[j]) continue;
 			real th = ws.st.q[j + 2];
-			if (th <= ws.M.lim_lo[j] && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_dx[R] = 1; ws.row_tgt[R] = kLimitErp * (ws.M.lim_lo[j] - th) / h; ++R; }
-			else if (th >= ws.M.lim_hi[j] && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_dx[R] = -1; ws.row_tgt[R] = kLimitErp * (th - ws.M.lim_hi[j]) / h; ++R; }
+			if (th <= ws.M.lim_lo[j] + kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_dx[R] = 1; ws.row_tgt[R] = kLimitErp * fmax(ws.M.lim_lo[j] - th, 0.0) / h; ++R; }
+			else if (th >= ws.M.lim_hi[j] - kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_dx[R] = -1; ws.row_tgt[R] = kLimitErp * fmax(th - ws.M.lim_hi[j], 0.0) / h; ++R; }
 		}
 		int cap = (kMaxRows - R) / 2, nc = 0;
 		for (int pt = 0; pt < ws.M.L * kPtsPerLink && nc < cap; ++pt) if (ws.pt_active[pt]) {

@@ -33,6 +33,7 @@ constexpr real kSlop = 0.001;
 constexpr real kMu = 0.9 * 0.9;
 constexpr real kVDepenMax = 1.0;
 constexpr real kLimitErp = 0.2;
+constexpr real kLimitSlop = 0.005;
 constexpr int kPgsIters = 10;
 constexpr real kGravityY = -9.8;
 

@@ -10,7 +10,7 @@
 //
 // Model (one substep of length h):
 //   H(q) v+ = H v + h (tau - b(q,v)) + J^T lambda,   q+ = q + h v+
-//   rows of J: violated joint limits (unit rows) and, per penetrating contact sample point, a normal and a
+//   rows of J: joint limits within limit_slop of a stop (unit rows) and, per penetrating contact sample point, a normal and a
 //   tangent row; lambda solved by 10 sweeps of projected Gauss-Seidel in a fixed row order, no warm start;
 //   normal target velocity = min(ERP * max(depth - slop, 0) / h, v_depen_max); friction box |lt| <= mu * ln.
 //   Contact sample points per box link: 4 corners + midpoints of the two long edges, tested against the
@@ -27,6 +27,7 @@ struct SimConst {
 	static constexpr double mu = 0.9 * 0.9;
 	static constexpr double v_depen_max = 1.0;
 	static constexpr double limit_erp = 0.2;
+	static constexpr double limit_slop = 0.005;  // a limit row is active within this band of the stop (robust activation)
 	static constexpr int pgs_iters = 10;
 	static constexpr int max_rows = 32;
 	static constexpr int pts_per_link = 6;
@@ -146,12 +147,12 @@ struct Integrator {
 		for (int j = 1; j < M.L; ++j) {
 			if (M.lim_lo[j] > M.lim_hi[j]) continue;
 			double th = q[j + 2];
-			if (th <= M.lim_lo[j] && R < SimConst::max_rows) {
+			if (th <= M.lim_lo[j] + SimConst::limit_slop && R < SimConst::max_rows) {
 				for (int i = 0; i < D; ++i) Jr[R][i] = 0;
-				Jr[R][j + 2] = 1; kind[R] = 0; tgt[R] = SimConst::limit_erp * (M.lim_lo[j] - th) / h; ++R;
-			} else if (th >= M.lim_hi[j] && R < SimConst::max_rows) {
+				Jr[R][j + 2] = 1; kind[R] = 0; tgt[R] = SimConst::limit_erp * std::max(M.lim_lo[j] - th, 0.0) / h; ++R;
+			} else if (th >= M.lim_hi[j] - SimConst::limit_slop && R < SimConst::max_rows) {
 				for (int i = 0; i < D; ++i) Jr[R][i] = 0;
-				Jr[R][j + 2] = -1; kind[R] = 0; tgt[R] = SimConst::limit_erp * (th - M.lim_hi[j]) / h; ++R;
+				Jr[R][j + 2] = -1; kind[R] = 0; tgt[R] = SimConst::limit_erp * std::max(th - M.lim_hi[j], 0.0) / h; ++R;
 			}
 		}
 		ContactPoint cps[SimConst::max_rows / 2];

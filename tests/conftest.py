@@ -1,0 +1,51 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+REFDATA = os.path.join(REPO, "tests", "golden", "refdata")
+GOLDEN = os.path.join(REPO, "tests", "golden")
+EMUL_LIB = os.path.join(REPO, "deepterrainrl_amd", "lib", "libdtrl_emul.so")
+HIP_LIB = os.path.join(REPO, "deepterrainrl_amd", "lib", "libdtrl.so")
+REFERENCE = "/root/reference"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_built():
+    """Build the oracle + both libraries on demand (CPU box: hipcc cross-compiles gfx950 without a GPU)."""
+    need = [os.path.join(REPO, "oracle", "_ref", "libdtrl_oracle.so"), EMUL_LIB, HIP_LIB]
+    if all(os.path.exists(p) for p in need):
+        return
+    import __graft_entry__
+    __graft_entry__.build()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built():
+    _ensure_built()
+
+
+@pytest.fixture(scope="session")
+def om():
+    from oracle import model
+    return model
+
+
+@pytest.fixture(scope="session")
+def da():
+    import deepterrainrl_amd
+    return deepterrainrl_amd
+
+
+def dog_policy(om, scale="data/policies/dog/models/dog_mace3_slopes_mixed_model_scale.txt", seed=1234):
+    desc = om.parse_deploy_prototxt(os.path.join(REFDATA, "data/policies/dog/nets/dog_mace3_deploy.prototxt"))
+    w = om.xavier_weights(desc, seed)
+    io, isc, oo, osc = om.load_scale_file(os.path.join(REFDATA, scale))
+    return desc, w, io, isc, oo, osc

