@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched rollout hot path (BASELINE.json metric) on N MI355X GPUs of one node.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+Workload = BASELINE.json configs[1]: dog + GroundVar2D slopes_mixed, 4096 envs per MI355X, implicit PD + MACE actor/critic
+forward (args/dog_slopes_mixed_args.txt; synthetic xavier weights seed 1234 in the dog_mace3_deploy topology -- the trained
+*.h5 blobs are not in the reference checkout -- with the shipped dog_mace3_slopes_mixed_model_scale.txt normaliser; fixed-seed
+synthetic terrain, seed0 + global env id). One bench "step" = one pass of the hot path over the batch = one outer frame
+(cScenarioPoliEval::Update(1/30) on every env) = num_update_steps (20) env-steps per env. 1 env-step = one iteration of the
+loop at scenarios/ScenarioSimChar.cpp:162-173 = 1 controller update + 5 physics substeps.
+Envs shard across ranks by global env id (weak scaling, no data-path collective: envs are independent); the timed region is
+bracketed by barrier + torch.cuda.synchronize() on both sides and the max over ranks is taken.
+Inputs (state, terrain windows, weights) are resident in HBM when the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+ROOT = os.path.join(REPO, "tests", "golden", "refdata")
+ARG_FILE = "args/dog_slopes_mixed_args.txt"
+ENVS_PER_GPU = 4096
+B_ALG = 1053.0          # algorithmic bytes per env-step, dog (SURVEY 8d / BASELINE.md 4)
+F_ALG = 0.6e6           # algorithmic flops per env-step, dog
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s
+FP64_VEC_PEAK_TF = 78.6 # the engine computes in fp64 (reference controller/net precision); fp32 vector peak is 157.3
+
+
+def xavier_weights(num_params_check, seed=1234):
+    """Same synthetic weights as oracle/model.py xavier_weights (kept here so the timed product leg does not import oracle/)."""
+    rng = np.random.RandomState(seed)
+    out = []
+
+    def blob(nout, fan_in):
+        s = np.sqrt(3.0 / fan_in)
+        out.append(rng.uniform(-s, s, size=nout * fan_in).astype(np.float32)); out.append(np.zeros(nout, np.float32))
+    blob(16, 8); blob(32, 64); blob(32, 128); blob(64, 5984); blob(256, 147); blob(128, 256); blob(3, 128)
+    for _ in range(3):
+        blob(128, 256); blob(29, 128)
+    w = np.concatenate(out)
+    assert w.size == num_params_check
+    return w
+
+
+def load_scale():
+    d = json.load(open(os.path.join(ROOT, "data/policies/dog/models/dog_mace3_slopes_mixed_model_scale.txt")))
+    return [np.asarray(d[k], np.float64) for k in ("InputOffset", "InputScale", "OutputOffset", "OutputScale")]
+
+
+def cpu_baseline():
+    """The oracle restatement (NOT Bullet -- the reference cannot be built here) timed on the host cores, bounded sample."""
+    from oracle import model as om
+    m, info = om.build_model(ARG_FILE, ROOT)
+    desc = om.parse_deploy_prototxt(os.path.join(ROOT, info["args"]["policy_net"]))
+    w = om.xavier_weights(desc, 1234)
+    io, isc, oo, osc = load_scale()
+    cores = os.cpu_count() or 1
+    envs_per_thread, frames = 8, 100
+    n_envs = cores * envs_per_thread
+    t0 = time.time()
+    rate, resets, cycles = om.batch_run(m, n_envs, cores, frames, terrain_seed0=0, rng_seed=0, policy=(desc, w, io, isc, oo, osc))
+    return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs (%d per thread) x %d frames x 20 env-steps of the same workload on the fp64 oracle restatement (not Bullet), %.1f s wall" % (n_envs, envs_per_thread, frames, time.time() - t0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    import deepterrainrl_amd as da
+    n = a.envs_per_gpu
+    b = da.BatchScenario(ARG_FILE, n, data_root=ROOT, device_id=local_rank,
+                         extra_args={"terrain_seed": 20260925, "rand_seed": 1, "global_env_offset": rank * n})
+    w = xavier_weights(b.PolicyNumParams())
+    b.SetPolicy(w, *load_scale())
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    b.RunFrames(a.warmup)
+    b.KernelTimeMs()   # drop warm-up launches from the kernel-time average
+    fence()
+    t0 = time.perf_counter()
+    b.RunFrames(a.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    kern_ms, launches = b.KernelTimeMs()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    steps_per_frame = 20
+    total_env_steps = float(world) * n * a.steps * steps_per_frame
+    value = total_env_steps / dt
+    if rank == 0:
+        env_steps_per_launch = n * steps_per_frame
+        ach = B_ALG * env_steps_per_launch / (kern_ms * 1e-3) / 1e9
+        traffic = os.environ.get("DTRL_PMC_TRAFFIC_BYTES")   # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if provided
+        line = {
+            "metric": "env-steps/sec (batched rollout) dog/slopes_mixed", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: dog + GroundVar2D slopes_mixed, %d envs per MI355X, ImpPD + MACE actor/critic forward, poli_eval (args/dog_slopes_mixed_args.txt)" % n,
+                       "envs_per_gpu": n, "global_envs": n * world, "env_steps_per_step": n * world * steps_per_frame,
+                       "substeps_per_env_step": 5, "parallelism": "env-sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": float(traffic) if traffic else None,
+                         "kernel": "dtrl_frame_kernel", "kernel_avg_ms": kern_ms, "kernel_launches": launches,
+                         "algorithmic_bytes_per_env_step": B_ALG, "env_steps_per_launch": env_steps_per_launch,
+                         "note": "the fused path is latency/VALU/LDS-bound, not HBM-bound (SURVEY 8d); companion figure below",
+                         "valu": {"achieved": F_ALG * env_steps_per_launch / (kern_ms * 1e-3) / 1e12, "peak": FP64_VEC_PEAK_TF, "unit": "TFLOP/s (fp64 vector)",
+                                  "frac": F_ALG * env_steps_per_launch / (kern_ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TF, "algorithmic_flops_per_env_step": F_ALG}},
+            "substeps_per_sec": value * 5, "stats": b.EvalStats(),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,13 +48,16 @@ public:
 	bool D2H(void* dst, const void* src, size_t n) override { return Check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream_), "hipMemcpy D2H") && Check(hipStreamSynchronize(stream_), "sync"); }
 	bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) override
 	{
-		std::pair<hipEvent_t, hipEvent_t> ev;
-		if (free_events_.empty()) { hipEventCreate(&ev.first); hipEventCreate(&ev.second); events_.push_back(ev); }
-		else { ev = free_events_.back(); free_events_.pop_back(); }
-		hipEventRecord(ev.first, stream_);
+		// only stepping launches are timed (the compact 0-step reset launches would skew the per-frame average)
+		const bool timed = n_steps > 0;
+		std::pair<hipEvent_t, hipEvent_t> ev{};
+		if (timed) {
+			if (free_events_.empty()) { hipEventCreate(&ev.first); hipEventCreate(&ev.second); events_.push_back(ev); }
+			else { ev = free_events_.back(); free_events_.pop_back(); }
+			hipEventRecord(ev.first, stream_);
+		}
 		hipLaunchKernelGGL(dtrl_frame_kernel, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
-		hipEventRecord(ev.second, stream_);
-		pending_.push_back(ev);
+		if (timed) { hipEventRecord(ev.second, stream_); pending_.push_back(ev); }
 		return Check(hipGetLastError(), "kernel launch");
 	}
 	bool Sync() override { return Check(hipStreamSynchronize(stream_), "hipStreamSynchronize"); }

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Summarise a tools/gpu_profile.sh output directory (rocprofv3 rocpd sqlite files) into a small text file for profiles/.
+Usage: tools/rocpd_summary.py gpurun_out/<tag> profiles/<name>.txt"""
+import json
+import os
+import sqlite3
+import sys
+
+KERNEL = "dtrl_frame_kernel"
+
+
+def main(src, dst):
+    out = []
+    bj = os.path.join(src, "bench.json")
+    if os.path.exists(bj):
+        for line in open(bj):
+            line = line.strip()
+            if line.startswith("{"):
+                out.append("## bench.py line (python bench.py --steps 60 --warmup 20)\n" + line + "\n")
+    db = os.path.join(src, "stats", "stats_results.db")
+    if os.path.exists(db):
+        cur = sqlite3.connect(db).cursor()
+        out.append("## rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 10 --no-cpu-baseline")
+        out.append("%-60s %8s %14s %14s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+        for r in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+            out.append("%-60s %8d %14.1f %14.1f %8.3f" % (r[0][:60], r[1], r[2], r[3], r[4]))
+        rows = list(cur.execute("select grid_x, count(*), avg(duration), min(duration), max(duration), max(vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size) from kernels where name like '%" + KERNEL + "%' group by grid_x"))
+        out.append("\n%s dispatches by grid size (threads): grid, n, avg_ms, min_ms, max_ms, vgpr, sgpr, lds_bytes, scratch_bytes" % KERNEL)
+        for r in rows:
+            out.append("  %8d %4d %10.3f %10.3f %10.3f %5s %5s %7s %7s" % (r[0], r[1], r[2] / 1e6, r[3] / 1e6, r[4] / 1e6, r[5], r[6], r[7], r[8]))
+        out.append("")
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+        db = os.path.join(src, sub, "pmc_results.db")
+        if not os.path.exists(db):
+            continue
+        cur = sqlite3.connect(db).cursor()
+        out.append("## rocprofv3 --pmc (%s pass) -- per-dispatch averages for %s (grid = full batch launches only)" % (sub, KERNEL))
+        q = ("select counter_name, count(*), avg(value), max(grid_size) from counters_collection where kernel_name like '%" + KERNEL + "%' "
+             "and grid_size = (select max(grid_size) from counters_collection where kernel_name like '%" + KERNEL + "%') group by counter_name order by counter_name")
+        for r in cur.execute(q):
+            extra = ""
+            if r[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                extra = "  (KB; = %.1f MB per launch)" % (r[2] / 1024.0)
+            out.append("  %-24s n=%3d avg=%.6g%s" % (r[0], r[1], r[2], extra))
+        out.append("")
+    open(dst, "w").write("\n".join(out) + "\n")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
