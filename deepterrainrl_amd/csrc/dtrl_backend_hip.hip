@@ -6,7 +6,10 @@
 // holds only its own envs' state/terrain records -- the per-env records are private, nothing is shared between XCDs
 // except the read-only model and policy weights.
 #include "dtrl_engine.h"
+#include "dtrl_kernel_fast.h"
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace dtrl {
@@ -16,7 +19,19 @@ __global__ void __launch_bounds__(kGroup) dtrl_frame_kernel(const DevModel* __re
 	__shared__ WS ws;
 	if (static_cast<int>(blockIdx.x) >= n_envs) return;
 	const int env = buf.env_list ? buf.env_list[blockIdx.x] : static_cast<int>(blockIdx.x);
-	env_frame(ws, *gm, rp, buf, env, n_steps, dt, frame_end != 0);
+	env_frame<RefPath>(ws, *gm, rp, buf, env, n_steps, dt, frame_end != 0);
+}
+
+// register-resident fast path (dtrl_kernel_fast.h), one instantiation per DoF count of the shipped characters
+template <int D>
+__global__ void __launch_bounds__(kGroup) dtrl_frame_kernel_fast(const DevModel* __restrict__ gm, RunParams rp, DevBuffers buf, int n_envs, int n_steps, real dt, int frame_end)
+{
+	__shared__ WS ws;
+	if (static_cast<int>(blockIdx.x) >= n_envs) return;
+	const int env = buf.env_list ? buf.env_list[blockIdx.x] : static_cast<int>(blockIdx.x);
+#if defined(__HIP_DEVICE_COMPILE__)
+	env_frame<FastPath<D>>(ws, *gm, rp, buf, env, n_steps, dt, frame_end != 0);
+#endif
 }
 
 class HipBackend : public Backend {
@@ -56,7 +71,15 @@ public:
 			else { ev = free_events_.back(); free_events_.pop_back(); }
 			hipEventRecord(ev.first, stream_);
 		}
-		hipLaunchKernelGGL(dtrl_frame_kernel, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
+		// DTRL_KERNEL=ref selects the LDS-phase reference kernel (A/B and bitwise cross-check); default is the fast path
+		const char* sel = std::getenv("DTRL_KERNEL");
+		const bool use_ref = sel && std::strcmp(sel, "ref") == 0;
+		if (!use_ref && buf.model_D == 23)
+			hipLaunchKernelGGL(dtrl_frame_kernel_fast<23>, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
+		else if (!use_ref && buf.model_D == 21)
+			hipLaunchKernelGGL(dtrl_frame_kernel_fast<21>, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
+		else
+			hipLaunchKernelGGL(dtrl_frame_kernel, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
 		if (timed) { hipEventRecord(ev.second, stream_); pending_.push_back(ev); }
 		return Check(hipGetLastError(), "kernel launch");
 	}

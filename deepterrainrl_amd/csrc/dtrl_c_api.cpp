@@ -143,4 +143,7 @@ dtrl_status dtrl_dims(const dtrl_batch* b, int* L, int* D, int* S, int* A, int* 
 }
 dtrl_status dtrl_kernel_time_ms(dtrl_batch* b, double* avg_ms, int64_t* launches) { CHECK_B(); return static_cast<dtrl_status>(b->eng.KernelTime(avg_ms, launches)); }
 
+// not part of include/dtrl.h: developer hook used by tools/gpu_sections.py with the DTRL_PROFILE build
+int dtrlx_profile_sections(dtrl_batch* b, unsigned long long* out, int cap) { return b ? b->eng.ProfileSections(out, cap) : 1; }
+
 }  // extern "C"

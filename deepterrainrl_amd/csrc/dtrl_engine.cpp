@@ -60,7 +60,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	buf_.poli_state = static_cast<real*>(alloc(sizeof(real) * S_ * n_));
 	buf_.tup_s0 = static_cast<real*>(alloc(sizeof(real) * S_ * n_));
 	buf_.tup_a = static_cast<real*>(alloc(sizeof(real) * A_ * n_));
-	buf_.S = S_; buf_.A = A_; buf_.W = W_;
+	buf_.S = S_; buf_.A = A_; buf_.W = W_; buf_.model_D = m.D;
 	// a tuple per env per cycle (~13 frames) at most; room for 2 per env between drains, at least the reference's ring size
 	buf_.tuple_cap = std::max(2 * n_, cfg_.tuple_buffer_size);
 	buf_.tuple_rows = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(W_) * buf_.tuple_cap));
@@ -68,6 +68,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	buf_.tuple_env = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
 	buf_.tuple_count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));
 	d_env_list_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
+	buf_.prof = static_cast<unsigned long long*>(alloc(sizeof(unsigned long long) * kProfMax * n_));
 	if (!d_model_ || !buf_.st || !buf_.gr || !buf_.status || !buf_.poli_state || !buf_.tup_s0 || !buf_.tup_a || !buf_.tuple_rows || !buf_.tuple_flags || !buf_.tuple_env || !buf_.tuple_count)
 		return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
 	if (cfg_.has_policy_net) {
@@ -321,5 +322,14 @@ int Engine::EvalStats(double* avg_dist, int64_t* episodes, int64_t* cycles, int6
 }
 
 int Engine::KernelTime(double* avg_ms, int64_t* launches) { be_->KernelTime(avg_ms, launches); return DTRL_OK; }
+
+int Engine::ProfileSections(unsigned long long* out, int cap)
+{
+	be_->Sync();
+	std::vector<unsigned long long> all(static_cast<size_t>(kProfMax) * n_);
+	if (!be_->D2H(all.data(), buf_.prof, all.size() * sizeof(unsigned long long))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	for (int k = 0; k < kProfMax && k < cap; ++k) { unsigned long long s = 0; for (int e = 0; e < n_; ++e) s += all[static_cast<size_t>(e) * kProfMax + k]; out[k] = s; }
+	return DTRL_OK;
+}
 
 }  // namespace dtrl

@@ -44,7 +44,18 @@
 #define LANES_END }
 #endif
 
+// optional per-section cycle accounting (device builds with -DDTRL_PROFILE only; s_memtime ticks of lane 0)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DTRL_PROFILE)
+#define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
+#define PROF_ADD(ws, id) do { if (threadIdx.x == 0) (ws).prof[id] += __builtin_readcyclecounter() - prof_t0_; } while (0)
+#else
+#define PROF_T0() do {} while (0)
+#define PROF_ADD(ws, id) do {} while (0)
+#endif
+
 namespace dtrl {
+
+enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfRows, kProfFsub, kProfDelassus, kProfPgs, kProfFinish, kProfCtrl, kProfAction, kProfFrameIO, kProfTotal, kProfRowsSum, kProfSubsteps, kProfMax };
 
 // hot, read-mostly model fields staged in LDS
 struct HotModel {
@@ -73,6 +84,8 @@ struct DevBuffers {
 	int32_t tuple_cap;
 	int32_t S, A, W;
 	int32_t nn_scratch_stride;
+	int32_t model_D;           // host-known DoF count (selects the register-resident kernel instantiation)
+	unsigned long long* prof;  // [N][kProfMax] cycle counters (DTRL_PROFILE builds), else null
 	const int32_t* env_list;   // optional indirection: workgroup b handles env_list[b] (compact reset launches)
 	const float* weights;
 	const real* in_off; const real* in_scale; const real* out_off; const real* out_scale;
@@ -120,6 +133,9 @@ struct WS {
 	};
 	real red[8];
 	int32_t flag_update_action, flag_new_cycle, flag_misc, pad_;
+#if defined(DTRL_PROFILE)
+	unsigned long long prof[kProfMax];
+#endif
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -221,7 +237,7 @@ DTRL_HD inline void forward_kinematics(WS& ws)
 }
 
 // subtree mass / first moment / inertia about the root origin, then the joint-space inertia matrix in closed form
-DTRL_HD inline void mass_matrix(WS& ws)
+DTRL_HD inline void composite_inertia(WS& ws, bool zero_H)
 {
 	LANES_BEGIN
 	if (lane < ws.M.L) {
@@ -234,8 +250,12 @@ DTRL_HD inline void mass_matrix(WS& ws)
 		}
 		ws.sm[j] = m; ws.smx[j] = mx; ws.smy[j] = my; ws.sI[j] = I;
 	}
-	for (int e = lane; e < kMaxD * (kMaxD + 1); e += kGroup) (&ws.H[0][0])[e] = 0;
+	if (zero_H) for (int e = lane; e < kMaxD * (kMaxD + 1); e += kGroup) (&ws.H[0][0])[e] = 0;
 	LANES_END
+}
+DTRL_HD inline void mass_matrix(WS& ws)
+{
+	composite_inertia(ws, true);
 	LANES_BEGIN
 	const int D = ws.M.D;
 	if (lane < D) {
@@ -499,20 +519,27 @@ DTRL_HD inline void finish_substep(WS& ws, real h)
 }
 
 // one physics substep (stand-in for one Bullet internal step of sim/World.cpp:101-102)
-DTRL_HD inline void substep(WS& ws, const GroundRec& g, real h)
+DTRL_HD inline void substep_ref(WS& ws, const GroundRec& g, real h)
 {
-	forward_kinematics(ws);
-	mass_matrix(ws);
-	bias_force(ws, false);
-	factorize(ws);
-	detect_contacts(ws, g);
-	build_rows(ws, h);
+	{ PROF_T0(); forward_kinematics(ws); PROF_ADD(ws, kProfFK); }
+	{ PROF_T0(); mass_matrix(ws); PROF_ADD(ws, kProfMass); }
+	{ PROF_T0(); bias_force(ws, false); PROF_ADD(ws, kProfBias); }
+	{ PROF_T0(); factorize(ws); PROF_ADD(ws, kProfFact); }
+	{ PROF_T0(); detect_contacts(ws, g); PROF_ADD(ws, kProfDetect); }
+	{ PROF_T0(); build_rows(ws, h);
 	LANES_BEGIN
 	if (lane < ws.M.D) ws.u[lane] = ws.st.tau[lane] - ws.b[lane];
 	LANES_END
-	forward_subst_rows(ws, ws.u);
-	if (ws.R > 0) { build_delassus(ws, h); pgs_solve(ws); }
-	finish_substep(ws, h);
+	PROF_ADD(ws, kProfRows); }
+	{ PROF_T0(); forward_subst_rows(ws, ws.u); PROF_ADD(ws, kProfFsub); }
+	if (ws.R > 0) {
+		{ PROF_T0(); build_delassus(ws, h); PROF_ADD(ws, kProfDelassus); }
+		{ PROF_T0(); pgs_solve(ws); PROF_ADD(ws, kProfPgs); }
+	}
+	{ PROF_T0(); finish_substep(ws, h); PROF_ADD(ws, kProfFinish); }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DTRL_PROFILE)
+	if (threadIdx.x == 0) { ws.prof[kProfRowsSum] += ws.R; ws.prof[kProfSubsteps] += 1; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -771,12 +798,40 @@ DTRL_HD inline real jt_force(const WS& ws, int d, const real* pos, const real* f
 	return (pos[0] - ws.px[a]) * f[1] - (pos[1] - ws.py[a]) * f[0];
 }
 
+// reference (LDS-phase) implicit-PD solve: ws.u holds the right-hand side on entry and the acceleration on exit
+DTRL_HD inline void pd_solve_ref(WS& ws, real dt)
+{
+	const int D = ws.M.D;
+	mass_matrix(ws);
+	LANES_BEGIN
+	if (lane < D) ws.H[lane][lane] += dt * ws.kdv[lane];
+	if (lane == 0) { ws.R = 0; }
+	LANES_END
+	factorize(ws);
+	forward_subst_rows(ws, ws.u);   // R = 0: only z_0 = L^-1 rhs (lane 0)
+	LANES_BEGIN
+	if (lane < D) ws.u[lane] = ws.Z[0][lane] * ws.dinv[lane];
+	LANES_END
+	for (int i = D - 1; i >= 1; --i) {
+		LANES_BEGIN
+		if (lane < i) ws.u[lane] -= ws.H[lane][i] * ws.u[i];
+		LANES_END
+	}
+}
+struct RefPath {
+	static DTRL_HD void substep(WS& ws, const GroundRec& g, real h) { substep_ref(ws, g, h); }
+	static DTRL_HD void pd_solve(WS& ws, real dt) { pd_solve_ref(ws, dt); }
+	static DTRL_HD void contacts(WS& ws, const GroundRec& g) { detect_contacts(ws, g); }
+};
+
 // cDogController::Update, sim/DogController.cpp:229-268
+template <class Path>
 DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, real dt)
 {
 	const int D = ws.M.D, L = ws.M.L;
-	// UpdateRBDModel: H and the (quirk) bias at the post-step configuration; kinematics are already current
-	mass_matrix(ws);
+	// UpdateRBDModel: composite inertias (H itself is assembled inside the PD solve) and the (quirk) bias at the
+	// post-step configuration; kinematics are already current
+	composite_inertia(ws, false);
 	bias_force(ws, true);
 	LANES_BEGIN
 	if (lane == 0) {
@@ -800,7 +855,9 @@ DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParam
 	}
 	LANES_END
 	if (ws.flag_update_action) {
+		PROF_T0();
 		update_action(ws, gm, rp, buf, g, env);
+		PROF_ADD(ws, kProfAction);
 		LANES_BEGIN
 		if (lane == 0) ws.st.first_cycle = 0;
 		LANES_END
@@ -831,23 +888,10 @@ DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParam
 			ve = 0 - ws.st.qd[i];
 		}
 		ws.kpv[i] = kp; ws.kdv[i] = kd; ws.perr[i] = pe; ws.verr[i] = ve;
-		ws.H[i][i] += dt * kd;
 		ws.u[i] = kp * (pe - dt * ws.st.qd[i]) + kd * ve - ws.b[i];
 	}
 	LANES_END
-	factorize(ws);
-	LANES_BEGIN
-	if (lane == 0) { ws.R = 0; }
-	LANES_END
-	forward_subst_rows(ws, ws.u);   // R = 0: only z_0 = L^-1 rhs (lane 0)
-	LANES_BEGIN
-	if (lane < D) ws.u[lane] = ws.Z[0][lane] * ws.dinv[lane];
-	LANES_END
-	for (int i = D - 1; i >= 1; --i) {
-		LANES_BEGIN
-		if (lane < i) ws.u[lane] -= ws.H[lane][i] * ws.u[i];
-		LANES_END
-	}
+	Path::pd_solve(ws, dt);
 	LANES_BEGIN
 	if (lane < D) { const int i = lane; ws.tau_g[i] = 0; ws.st.tau_ctrl[i] = ws.kpv[i] * (ws.perr[i] - dt * ws.st.qd[i]) + ws.kdv[i] * (ws.verr[i] - dt * ws.u[i]); }
 	LANES_END
@@ -1008,14 +1052,15 @@ DTRL_HD inline void scenario_new_cycle(WS& ws, const DevModel& gm, const DevBuff
 }
 
 // one iteration of scenarios/ScenarioSimChar.cpp:162-173
+template <class Path>
 DTRL_HD inline void env_step(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, real dt)
 {
 	const real h = dt / gm.num_sim_substeps;
-	for (int s = 0; s < gm.num_sim_substeps; ++s) substep(ws, g, h);   // UpdateWorld
+	for (int s = 0; s < gm.num_sim_substeps; ++s) Path::substep(ws, g, h);   // UpdateWorld
 	forward_kinematics(ws);
-	detect_contacts(ws, g);                                               // cContactManager::Update
+	Path::contacts(ws, g);                                                  // cContactManager::Update
 	// UpdateGround is host-side at frame boundaries (the 1 m look-ahead margin makes that equivalent; DESIGN.md "Ground")
-	controller_update(ws, gm, rp, buf, g, env, dt);                       // UpdateCharacter
+	{ PROF_T0(); controller_update<Path>(ws, gm, rp, buf, g, env, dt); PROF_ADD(ws, kProfCtrl); }   // UpdateCharacter
 	LANES_BEGIN
 	if (lane == 0) {
 		// cSimCharSoftFall::UpdateFallDistCheck / UpdateFallContactCheck
@@ -1121,8 +1166,14 @@ DTRL_HD inline void load_hot_model(WS& ws, const DevModel& gm)
 }
 
 // the whole per-env frame: load -> (reset) -> n_steps env-steps -> frame-end logic -> store
+template <class Path>
 DTRL_HD inline void env_frame(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, int env, int n_steps, real dt, bool do_frame_end)
 {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DTRL_PROFILE)
+	const unsigned long long prof_frame_t0 = __builtin_readcyclecounter();
+	if (threadIdx.x < kProfMax) ws.prof[threadIdx.x] = 0;
+	__syncthreads();
+#endif
 	load_hot_model(ws, gm);
 	{
 		const uint64_t* src = reinterpret_cast<const uint64_t*>(&buf.st[env]);
@@ -1135,7 +1186,7 @@ DTRL_HD inline void env_frame(WS& ws, const DevModel& gm, const RunParams& rp, c
 	if (ws.st.do_init) reset_env(ws, gm, rp, buf, g, env, true);
 	else if (ws.st.do_reset) reset_env(ws, gm, rp, buf, g, env, false);
 	else forward_kinematics(ws);
-	for (int s = 0; s < n_steps; ++s) env_step(ws, gm, rp, buf, g, env, dt);
+	for (int s = 0; s < n_steps; ++s) env_step<Path>(ws, gm, rp, buf, g, env, dt);
 	if (do_frame_end) frame_end(ws, gm, buf, env);
 	{
 		uint64_t* dst = reinterpret_cast<uint64_t*>(&buf.st[env]);
@@ -1145,6 +1196,13 @@ DTRL_HD inline void env_frame(WS& ws, const DevModel& gm, const RunParams& rp, c
 		if (lane == 0) { buf.status[env].root_x = ws.st.q[0]; buf.status[env].need_reset = ws.st.need_reset; buf.status[env].n_tuples = 0; }
 		LANES_END
 	}
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DTRL_PROFILE)
+	if (buf.prof && n_steps > 0) {
+		if (threadIdx.x == 0) ws.prof[kProfTotal] += __builtin_readcyclecounter() - prof_frame_t0;
+		__syncthreads();
+		if (threadIdx.x < kProfMax) buf.prof[static_cast<int64_t>(env) * kProfMax + threadIdx.x] += ws.prof[threadIdx.x];
+	}
+#endif
 }
 
 }  // namespace dtrl

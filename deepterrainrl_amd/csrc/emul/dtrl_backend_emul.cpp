@@ -24,7 +24,7 @@ public:
 		std::vector<std::thread> th;
 		for (int t = 0; t < nt; ++t) th.emplace_back([=]() {
 			WS* ws = new WS();
-			for (int e = t; e < n_envs; e += nt) env_frame(*ws, *gm, rp, buf, buf.env_list ? buf.env_list[e] : e, n_steps, dt, frame_end);
+			for (int e = t; e < n_envs; e += nt) env_frame<RefPath>(*ws, *gm, rp, buf, buf.env_list ? buf.env_list[e] : e, n_steps, dt, frame_end);
 			delete ws;
 		});
 		for (auto& x : th) x.join();

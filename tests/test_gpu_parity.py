@@ -105,3 +105,22 @@ def test_full_size_4096_properties(da, om):
     assert np.isfinite(h).all() and ((j - i) >= 0).all() and ((j - i) <= 1).all()
     ms, n = full.KernelTimeMs()
     assert n >= frames and ms > 0
+
+
+def test_fast_kernel_equals_reference_kernel_bitwise(da, om, monkeypatch):
+    """The register-resident gfx950 kernel (default) and the LDS-phase reference kernel (DTRL_KERNEL=ref) perform the same
+    arithmetic in the same order: 256 envs x 30 frames (falls, resets, policy forwards included) must agree bit for bit."""
+    pol = dog_policy(om)
+    def run(kernel):
+        if kernel:
+            monkeypatch.setenv("DTRL_KERNEL", kernel)
+        else:
+            monkeypatch.delenv("DTRL_KERNEL", raising=False)
+        b = T.batch(da, "args/dog_slopes_mixed_args.txt", 256, terrain_seed=77)
+        b.SetPolicy(pol[1], *pol[2:])
+        b.RunFrames(30)
+        return b.PoseVel(), b.Torques(), b.EvalStats(), b.Ctrl()
+    (qf, qdf), (tcf, taf), sf, cf = run(None)
+    (qr, qdr), (tcr, tar), sr, cr = run("ref")
+    assert np.array_equal(qf, qr) and np.array_equal(qdf, qdr) and np.array_equal(tcf, tcr) and np.array_equal(taf, tar)
+    assert sf == sr and all(np.array_equal(a, b) for a, b in zip(cf, cr))
