@@ -1,0 +1,73 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the sharded rollout (lane-loop test backend) -- shard-invariant trajectories,
+tuple gather to the trainer rank and policy broadcast equal a single-process run over the same global env ids."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import REPO, REFDATA, EMUL_LIB
+
+WORKER = r'''
+import os, sys, numpy as np
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import torch, torch.distributed as dist
+from conftest import REFDATA, EMUL_LIB, dog_policy
+from oracle import model as om
+import deepterrainrl_amd as da
+from deepterrainrl_amd.sharding import ShardedRollout
+dist.init_process_group(backend="gloo")
+rank = dist.get_rank()
+def make(n, off):
+    return da.BatchScenario("args/opt_args_train_mace.txt", n, data_root=REFDATA, extra_args=dict(terrain_seed=300, rand_seed=9, global_env_offset=off), _lib_path=EMUL_LIB)
+sr = ShardedRollout(make, 4, dist=dist)
+pol = dog_policy(om)
+if rank == 0:
+    sr.broadcast_policy(pol[1], pol[2], pol[3], pol[4], pol[5], src=0)
+else:
+    sr.broadcast_policy(src=0)
+rows, flags, ids = [], [], []
+for f in range(70):
+    sr.Update()
+    g = sr.gather_tuples(dst=0)
+    if rank == 0:
+        rows.append(g[0]); flags.append(g[1]); ids.append(g[2])
+q, qd = sr.batch.PoseVel()
+np.save(os.path.join({out!r}, "q_rank%d.npy" % rank), q)
+if rank == 0:
+    np.savez(os.path.join({out!r}, "tuples.npz"), rows=np.concatenate(rows), flags=np.concatenate(flags), ids=np.concatenate(ids))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_matches_single_process(tmp_path, da, om):
+    from conftest import dog_policy
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(repo=REPO, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # single process over the same 4 global envs
+    pol = dog_policy(om)
+    b = da.BatchScenario("args/opt_args_train_mace.txt", 4, data_root=REFDATA, extra_args=dict(terrain_seed=300, rand_seed=9), _lib_path=EMUL_LIB)
+    b.SetPolicy(pol[1], *pol[2:])
+    rows, flags, ids = [], [], []
+    for f in range(70):
+        b.Update()
+        rr, ff, ii = b.DrainTuples()
+        rows.append(rr); flags.append(ff); ids.append(ii)
+    rows = np.concatenate(rows); flags = np.concatenate(flags); ids = np.concatenate(ids)
+    q, _ = b.PoseVel()
+    q0 = np.load(tmp_path / "q_rank0.npy"); q1 = np.load(tmp_path / "q_rank1.npy")
+    assert np.array_equal(q[:2], q0) and np.array_equal(q[2:], q1)              # shard-invariant trajectories
+    t = np.load(tmp_path / "tuples.npz")
+    assert len(t["rows"]) == len(rows) and len(rows) >= 8
+    for e in range(4):                                                            # same tuples per global env, same order
+        assert np.array_equal(t["rows"][t["ids"] == e], rows[ids == e]) and np.array_equal(t["flags"][t["ids"] == e], flags[ids == e])
+
+
+def test_shard_range():
+    from deepterrainrl_amd.sharding import shard_range
+    assert [shard_range(32768, 8, r) for r in (0, 7)] == [(0, 4096), (28672, 4096)]
+    assert [shard_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
