@@ -203,6 +203,22 @@ int Engine::SetPolicy(const float* w, size_t n, const double* io, const double* 
 	const NetDesc& d = cfg_.net;
 	if (n != static_cast<size_t>(d.num_params)) return Fail(DTRL_ERR_ARG, "weight count does not match the deploy prototxt");
 	be_->Sync();
+	// device layout: conv blobs as given; every InnerProduct weight blob transposed to [nin][nout] (lanes <-> outputs read
+	// consecutive floats); biases unchanged. Same element count, same blob order.
+	std::vector<float> dev_w(w, w + n);
+	{
+		size_t off = 0; int cin = 1, wdt = d.n_terrain;
+		for (int l = 0; l < 3; ++l) { off += static_cast<size_t>(d.conv_ch[l]) * cin * d.conv_k[l] + d.conv_ch[l]; cin = d.conv_ch[l]; wdt = wdt - d.conv_k[l] + 1; }
+		auto transpose = [&](int nout, int nin) {
+			for (int o = 0; o < nout; ++o) for (int i = 0; i < nin; ++i) dev_w[off + static_cast<size_t>(i) * nout + o] = w[off + static_cast<size_t>(o) * nin + i];
+			off += static_cast<size_t>(nout) * nin + nout;
+		};
+		transpose(d.fc_terr, cin * wdt);
+		transpose(d.fc_trunk, d.fc_terr + d.n_char);
+		transpose(d.fc_head, d.fc_trunk); transpose(d.n_frags, d.fc_head);
+		for (int f = 0; f < d.n_frags; ++f) { transpose(d.fc_head, d.fc_trunk); transpose(d.frag_size, d.fc_head); }
+	}
+	w = dev_w.data();
 	std::vector<double> ones_i(d.in_size, 1.0), zeros_i(d.in_size, 0.0), ones_o(d.out_size, 1.0), zeros_o(d.out_size, 0.0);
 	// cNeuralNet without a scale file: identity normalisation (learning/NeuralNet.cpp:925-933)
 	bool ok = be_->H2D(const_cast<float*>(buf_.weights), w, sizeof(float) * n)

@@ -566,6 +566,19 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		m.kp[j] = pd.get_num("Kp", 0); m.kd[j] = pd.get_num("Kd", 0); m.torque_lim[j] = pd.get_num("TorqueLim", 0);
 		m.target_theta[j] = pd.get_num("TargetTheta", 0); m.use_world[j] = pd.get_num("UseWorldCoord", 0) != 0;
 	}
+	// contact sample points (4 corners + long-edge midpoints, DESIGN.md "Integrator v1") and end-effector points, joint frame
+	for (int j = 0; j < L; ++j) {
+		const double hx = m.body_half[j][0], hy = m.body_half[j][1];
+		const double c = std::cos(m.body_theta[j]), s = std::sin(m.body_theta[j]);
+		const double loc[kPtsPerLink][2] = {{-hx, -hy}, {hx, -hy}, {hx, hy}, {-hx, hy},
+			{hx >= hy ? 0.0 : -hx, hx >= hy ? -hy : 0.0}, {hx >= hy ? 0.0 : hx, hx >= hy ? hy : 0.0}};
+		for (int k = 0; k < kPtsPerLink; ++k) {
+			m.pt_joint[j][k][0] = m.body_attach[j][0] + c * loc[k][0] - s * loc[k][1];
+			m.pt_joint[j][k][1] = m.body_attach[j][1] + s * loc[k][0] + c * loc[k][1];
+		}
+		m.eff_joint[j][0] = m.body_attach[j][0] - s * (-hy);
+		m.eff_joint[j][1] = m.body_attach[j][1] + c * (-hy);
+	}
 	// tree tables: root->link paths and subtree masks
 	for (int j = 0; j < L; ++j) {
 		int chain[kMaxL]; int n = 0;
@@ -575,7 +588,7 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		for (int k = 0; k < n; ++k) m.path[j][k] = static_cast<int8_t>(chain[n - 1 - k]);
 		m.sub_mask[j] = 0;
 	}
-	for (int k = 0; k < L; ++k) for (int c = k; c >= 0; c = m.parent[c]) m.sub_mask[c] |= (1u << k);
+	for (int k = 0; k < L; ++k) { m.anc_mask[k] = 0; for (int c = k; c >= 0; c = m.parent[c]) { m.sub_mask[c] |= (1u << k); m.anc_mask[k] |= (1u << c); } }
 
 	// controllers (sim/DogController.cpp:629-700, 399-454)
 	const Json* files = ctrls->find("Files"); const Json* acts = ctrls->find("Actions");

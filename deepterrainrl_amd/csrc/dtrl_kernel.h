@@ -55,7 +55,7 @@
 
 namespace dtrl {
 
-enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfRows, kProfFsub, kProfDelassus, kProfPgs, kProfFinish, kProfCtrl, kProfAction, kProfFrameIO, kProfTotal, kProfRowsSum, kProfSubsteps, kProfMax };
+enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfRows, kProfFsub, kProfDelassus, kProfPgs, kProfFinish, kProfCtrl, kProfAction, kProfFrameIO, kProfTotal, kProfRowsSum, kProfSubsteps, kProfP1, kProfP2, kProfP3, kProfP4, kProfMax };
 
 // hot, read-mostly model fields staged in LDS
 struct HotModel {
@@ -63,6 +63,7 @@ struct HotModel {
 	int32_t parent[kMaxL], depth[kMaxL], col[kMaxL], use_world[kMaxL];
 	int8_t path[kMaxL][kMaxDepth];
 	uint32_t sub_mask[kMaxL];
+	uint32_t anc_mask[kMaxL];   // bit a set <=> link a is an ancestor of j or j itself
 	real attach[kMaxL][2], lim_lo[kMaxL], lim_hi[kMaxL];
 	real body_attach[kMaxL][2], body_theta[kMaxL], body_half[kMaxL][2];
 	real mass[kMaxL], inertia[kMaxL], kp[kMaxL], kd[kMaxL], torque_lim[kMaxL];
@@ -102,7 +103,9 @@ struct WS {
 	real vpx[kMaxL], vpy[kMaxL], vcx[kMaxL], vcy[kMaxL];
 	// composite (subtree) quantities about the root origin
 	real sm[kMaxL], smx[kMaxL], smy[kMaxL], sI[kMaxL];
-	real fx[kMaxL], fy[kMaxL];
+	real fx[kMaxL], fy[kMaxL], fn[kMaxL];
+	real bx[kMaxL], by[kMaxL], ux[kMaxL], uy[kMaxL], gx[kMaxL], gy[kMaxL];   // bone vectors and their velocity / centripetal terms
+	real mcx[kMaxL], mcy[kMaxL], Io[kMaxL];
 	real H[kMaxD][kMaxD + 1];   // after factorisation: diag = d_k, upper H[k][i] = L_ik (i > k)
 	real dinv[kMaxD];
 	real b[kMaxD];
@@ -111,7 +114,7 @@ struct WS {
 	int32_t R, n_pts_active;
 	int32_t row_kind[kMaxRows], row_link[kMaxRows];
 	real row_x[kMaxRows], row_y[kMaxRows], row_dx[kMaxRows], row_dy[kMaxRows], row_tgt[kMaxRows];
-	real wv[kMaxRows], lam[kMaxRows];
+	real wv[kMaxRows], lam[kMaxRows], rinv[kMaxRows];
 	real dl;
 	// time-multiplexed LDS: the contact sample points are dead once build_rows() has consumed them, which is before the
 	// Delassus matrix is written; the controller scratch is only live outside substep() where Z rows >= 1 are unused.
@@ -202,60 +205,116 @@ DTRL_HD inline real sample_ground(const GroundRec& g, real x, real* slope, int* 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// kinematics: joint frames, COMs and their velocities by walking each link's root->link path (no level barriers)
-DTRL_HD inline void forward_kinematics(WS& ws)
+// kinematics + composite inertias + generalised bias force in four lane phases.
+//   P1  phi_j, w_j = sums of q, qd along the root->j path; cos/sin(phi_j)
+//   P2  per link: world "bone" vector r_j = R(phi_parent) attach_j and its velocity / centripetal contributions
+//   P3  per link: joint position, velocity, path part of the acceleration = sums of the P2 quantities along the path
+//       (one LDS read per quantity and path element, fixed-trip predicated loops so the loads pipeline); COM, inertial force
+//   P4  per link: subtree sums (mass, first moments, inertia about the root origin, force, moment) with one masked loop
+// then b_d (planar RNEA in world coordinates) falls out without further loops.
+// quirk=true reproduces cRBDUtil::BuildCjPlanar as shipped (sim/RBDUtil.cpp:809-836: theta read from q_dot and
+// s = cos(theta)) as an extra base acceleration -- that is the bias the reference's implicit-PD controller sees;
+// quirk=false is the textbook bias used by the integrator.
+DTRL_HD inline void kin_dyn_terms(WS& ws, bool quirk)
 {
+	PROF_T0();
 	LANES_BEGIN
 	if (lane < ws.M.L) {
 		const int j = lane;
+		const int dep = ws.M.depth[j];
 		real phi = 0, w = 0;
-		for (int k = 0; k <= ws.M.depth[j]; ++k) { int a = ws.M.path[j][k]; phi += ws.st.q[a + 2]; w += ws.st.qd[a + 2]; }
+#pragma unroll 6
+		for (int k = 0; k < kMaxDepth; ++k) {
+			const int a = ws.M.path[j][k <= dep ? k : 0];
+			const real qa = ws.st.q[a + 2], wa = ws.st.qd[a + 2];
+			if (k <= dep) { phi += qa; w += wa; }
+		}
 		ws.phi[j] = phi; ws.w[j] = w;
 		real s, c; sincos(phi, &s, &c);
 		ws.cs[j] = c; ws.sn[j] = s;
+		ws.psi[j] = phi + ws.M.body_theta[j];
 	}
 	LANES_END
+	PROF_ADD(ws, kProfP1);
 	LANES_BEGIN
 	if (lane < ws.M.L) {
 		const int j = lane;
-		real px = 0, py = 0, vx = ws.st.qd[0], vy = ws.st.qd[1];
-		for (int k = 1; k <= ws.M.depth[j]; ++k) {
-			int a = ws.M.path[j][k], pa = ws.M.path[j][k - 1];
-			real rx = ws.cs[pa] * ws.M.attach[a][0] - ws.sn[pa] * ws.M.attach[a][1];
-			real ry = ws.sn[pa] * ws.M.attach[a][0] + ws.cs[pa] * ws.M.attach[a][1];
-			px += rx; py += ry;
-			vx -= ws.w[pa] * ry; vy += ws.w[pa] * rx;
+		const int pa = ws.M.parent[j];
+		real rx = 0, ry = 0, ux = 0, uy = 0, gx = 0, gy = 0;
+		if (pa >= 0) {
+			const real c = ws.cs[pa], s = ws.sn[pa], wp = ws.w[pa];
+			rx = c * ws.M.attach[j][0] - s * ws.M.attach[j][1];
+			ry = s * ws.M.attach[j][0] + c * ws.M.attach[j][1];
+			ux = -(wp * ry); uy = wp * rx;
+			const real w2 = wp * wp;
+			gx = -(w2 * rx); gy = -(w2 * ry);
 		}
-		ws.px[j] = px; ws.py[j] = py; ws.vpx[j] = vx; ws.vpy[j] = vy;
-		real rx = ws.cs[j] * ws.M.body_attach[j][0] - ws.sn[j] * ws.M.body_attach[j][1];
-		real ry = ws.sn[j] * ws.M.body_attach[j][0] + ws.cs[j] * ws.M.body_attach[j][1];
-		ws.cx[j] = px + rx; ws.cy[j] = py + ry;
-		ws.vcx[j] = vx - ws.w[j] * ry; ws.vcy[j] = vy + ws.w[j] * rx;
-		ws.psi[j] = ws.phi[j] + ws.M.body_theta[j];
+		ws.bx[j] = rx; ws.by[j] = ry; ws.ux[j] = ux; ws.uy[j] = uy; ws.gx[j] = gx; ws.gy[j] = gy;
 	}
 	LANES_END
-}
-
-// subtree mass / first moment / inertia about the root origin, then the joint-space inertia matrix in closed form
-DTRL_HD inline void composite_inertia(WS& ws, bool zero_H)
-{
+	PROF_ADD(ws, kProfP2);
+	LANES_BEGIN
+	if (lane < ws.M.L) {
+		const int j = lane;
+		const int dep = ws.M.depth[j];
+		real ax0 = 0, ay0 = -kGravityY;
+		if (quirk) {
+			const real vx0 = ws.st.qd[0], vy0 = ws.st.qd[1], om = ws.st.qd[2];
+			const real c = ws.cs[0], s = ws.sn[0];
+			const real cq = cos(om);
+			const real tx = (-s * vx0 + c * vy0) * om, ty = (-c * vx0 - s * vy0) * om;     // textbook cj (body frame)
+			const real qx = (-cq * vx0 + cq * vy0) * om, qy = (-cq * vx0 - cq * vy0) * om; // shipped cj
+			const real dx = qx - tx, dy = qy - ty;
+			ax0 += c * dx - s * dy; ay0 += s * dx + c * dy;                                 // back to world frame
+		}
+		real px = 0, py = 0, vx = ws.st.qd[0], vy = ws.st.qd[1], ax = 0, ay = 0;
+#pragma unroll 4
+		for (int k = 1; k < kMaxDepth; ++k) {
+			const int a = ws.M.path[j][k <= dep ? k : 0];
+			const real rx = ws.bx[a], ry = ws.by[a], dux = ws.ux[a], duy = ws.uy[a], dgx = ws.gx[a], dgy = ws.gy[a];
+			if (k <= dep) { px += rx; py += ry; vx += dux; vy += duy; ax += dgx; ay += dgy; }
+		}
+		ws.px[j] = px; ws.py[j] = py; ws.vpx[j] = vx; ws.vpy[j] = vy;
+		const real c = ws.cs[j], s = ws.sn[j], wj = ws.w[j];
+		const real rx = c * ws.M.body_attach[j][0] - s * ws.M.body_attach[j][1];
+		const real ry = s * ws.M.body_attach[j][0] + c * ws.M.body_attach[j][1];
+		const real cx = px + rx, cy = py + ry;
+		ws.cx[j] = cx; ws.cy[j] = cy;
+		ws.vcx[j] = vx - wj * ry; ws.vcy[j] = vy + wj * rx;
+		const real w2 = wj * wj, m = ws.M.mass[j];
+		const real fx = m * ((ax0 + ax) - w2 * rx), fy = m * ((ay0 + ay) - w2 * ry);
+		ws.fx[j] = fx; ws.fy[j] = fy; ws.fn[j] = cx * fy - cy * fx;
+		ws.mcx[j] = m * cx; ws.mcy[j] = m * cy; ws.Io[j] = ws.M.inertia[j] + m * (cx * cx + cy * cy);
+	}
+	LANES_END
+	PROF_ADD(ws, kProfP3);
 	LANES_BEGIN
 	if (lane < ws.M.L) {
 		const int j = lane;
 		const uint32_t mask = ws.M.sub_mask[j];
-		real m = 0, mx = 0, my = 0, I = 0;
-		for (int k = j; k < ws.M.L; ++k) if ((mask >> k) & 1u) {
-			real mk = ws.M.mass[k], x = ws.cx[k], y = ws.cy[k];
-			m += mk; mx += mk * x; my += mk * y; I += ws.M.inertia[k] + mk * (x * x + y * y);
+		real m = 0, mx = 0, my = 0, I = 0, sfx = 0, sfy = 0, sfn = 0;
+#pragma unroll 6
+		for (int k = 0; k < kMaxL; ++k) {
+			const real mk = ws.M.mass[k], a1 = ws.mcx[k], a2 = ws.mcy[k], a3 = ws.Io[k], a4 = ws.fx[k], a5 = ws.fy[k], a6 = ws.fn[k];
+			if ((mask >> k) & 1u) { m += mk; mx += a1; my += a2; I += a3; sfx += a4; sfy += a5; sfn += a6; }
 		}
 		ws.sm[j] = m; ws.smx[j] = mx; ws.smy[j] = my; ws.sI[j] = I;
+		// generalised bias: translations see the total force (root subtree = everything), hinge l the subtree moment about p_l
+		const real bl = sfn - ws.px[j] * sfy + ws.py[j] * sfx;
+		ws.b[j + 2] = bl;
+		if (j == 0) { ws.b[0] = sfx; ws.b[1] = sfy; }
 	}
-	if (zero_H) for (int e = lane; e < kMaxD * (kMaxD + 1); e += kGroup) (&ws.H[0][0])[e] = 0;
 	LANES_END
+	PROF_ADD(ws, kProfP4);
 }
+DTRL_HD inline void forward_kinematics(WS& ws) { kin_dyn_terms(ws, false); }
+
+// joint-space inertia matrix in closed form from the composite quantities (LDS copy, reference path)
 DTRL_HD inline void mass_matrix(WS& ws)
 {
-	composite_inertia(ws, true);
+	LANES_BEGIN
+	for (int e = lane; e < kMaxD * (kMaxD + 1); e += kGroup) (&ws.H[0][0])[e] = 0;
+	LANES_END
 	LANES_BEGIN
 	const int D = ws.M.D;
 	if (lane < D) {
@@ -274,52 +333,6 @@ DTRL_HD inline void mass_matrix(WS& ws)
 				ws.H[d][da] = v; ws.H[da][d] = v;
 			}
 		}
-	}
-	LANES_END
-}
-
-// generalised bias force C(q, qd) incl. gravity (planar RNEA in world coordinates).
-// quirk=true reproduces cRBDUtil::BuildCjPlanar as shipped (sim/RBDUtil.cpp:809-836: theta read from q_dot and
-// s = cos(theta)) which the reference's implicit-PD controller sees; quirk=false is the textbook bias used by the integrator.
-DTRL_HD inline void bias_force(WS& ws, bool quirk)
-{
-	real ax0 = 0, ay0 = -kGravityY;
-	if (quirk) {
-		real vx = ws.st.qd[0], vy = ws.st.qd[1], om = ws.st.qd[2];
-		real c = ws.cs[0], s = ws.sn[0];
-		real cq = cos(om);
-		real tx = (-s * vx + c * vy) * om, ty = (-c * vx - s * vy) * om;     // textbook cj (body frame)
-		real qx = (-cq * vx + cq * vy) * om, qy = (-cq * vx - cq * vy) * om; // shipped cj
-		real dx = qx - tx, dy = qy - ty;
-		ax0 += c * dx - s * dy; ay0 += s * dx + c * dy;                      // back to world frame
-	}
-	LANES_BEGIN
-	if (lane < ws.M.L) {
-		const int j = lane;
-		real ax = ax0, ay = ay0;
-		for (int k = 1; k <= ws.M.depth[j]; ++k) {
-			int a = ws.M.path[j][k], pa = ws.M.path[j][k - 1];
-			real w2 = ws.w[pa] * ws.w[pa];
-			ax -= w2 * (ws.px[a] - ws.px[pa]); ay -= w2 * (ws.py[a] - ws.py[pa]);
-		}
-		real w2 = ws.w[j] * ws.w[j];
-		ax -= w2 * (ws.cx[j] - ws.px[j]); ay -= w2 * (ws.cy[j] - ws.py[j]);
-		ws.fx[j] = ws.M.mass[j] * ax; ws.fy[j] = ws.M.mass[j] * ay;
-	}
-	LANES_END
-	LANES_BEGIN
-	if (lane < ws.M.D) {
-		const int d = lane;
-		real s = 0;
-		if (d == 0) { for (int k = 0; k < ws.M.L; ++k) s += ws.fx[k]; }
-		else if (d == 1) { for (int k = 0; k < ws.M.L; ++k) s += ws.fy[k]; }
-		else {
-			const int l = d - 2;
-			const uint32_t mask = ws.M.sub_mask[l];
-			real plx = ws.px[l], ply = ws.py[l];
-			for (int k = l; k < ws.M.L; ++k) if ((mask >> k) & 1u) s += (ws.cx[k] - plx) * ws.fy[k] - (ws.cy[k] - ply) * ws.fx[k];
-		}
-		ws.b[d] = s;
 	}
 	LANES_END
 }
@@ -354,36 +367,31 @@ DTRL_HD inline real row_jac(const WS& ws, int r, int i)
 	return ws.row_dx[r] * (-(ws.row_y[r] - ws.py[a])) + ws.row_dy[r] * (ws.row_x[r] - ws.px[a]);
 }
 
+// world position of contact sample point pt (relative to the root origin) + ground test; shared by both kernel paths
+DTRL_HD inline int sample_contact_point(WS& ws, const DevModel& gm, const GroundRec& g, int pt)
+{
+	const int j = pt / kPtsPerLink, k = pt - j * kPtsPerLink;
+	int active = 0;
+	if (ws.M.col[j] != 0) {
+		const real lx = gm.pt_joint[j][k][0], ly = gm.pt_joint[j][k][1];
+		const real c = ws.cs[j], s = ws.sn[j];
+		const real x = ws.px[j] + c * lx - s * ly;
+		const real y = ws.py[j] + s * lx + c * ly;
+		real slope;
+		const real h = sample_ground(g, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
+		const real inv = 1.0 / sqrt(1.0 + slope * slope);
+		const real nx = -slope * inv, ny = inv;
+		const real depth = (h - (ws.st.q[1] + y)) * ny;
+		if (depth > 0) { active = 1; ws.pt_x[pt] = x; ws.pt_y[pt] = y; ws.pt_depth[pt] = depth; ws.pt_nx[pt] = nx; ws.pt_ny[pt] = ny; }
+	}
+	ws.pt_active[pt] = active;
+	return active;
+}
 // contact sample points of every colliding link against the env's heightfield (2 points per lane)
-DTRL_HD inline void detect_contacts(WS& ws, const GroundRec& g)
+DTRL_HD inline void detect_contacts(WS& ws, const DevModel& gm, const GroundRec& g)
 {
 	LANES_BEGIN
-	for (int pt = lane; pt < ws.M.L * kPtsPerLink; pt += kGroup) {
-		const int j = pt / kPtsPerLink, k = pt - j * kPtsPerLink;
-		int active = 0;
-		if (ws.M.col[j] != 0) {
-			real hx = ws.M.body_half[j][0], hy = ws.M.body_half[j][1];
-			real sx, sy;
-			switch (k) {
-			case 0: sx = -hx; sy = -hy; break;
-			case 1: sx = hx; sy = -hy; break;
-			case 2: sx = hx; sy = hy; break;
-			case 3: sx = -hx; sy = hy; break;
-			case 4: if (hx >= hy) { sx = 0; sy = -hy; } else { sx = -hx; sy = 0; } break;
-			default: if (hx >= hy) { sx = 0; sy = hy; } else { sx = hx; sy = 0; } break;
-			}
-			real s, c; sincos(ws.psi[j], &s, &c);
-			real x = ws.cx[j] + c * sx - s * sy;
-			real y = ws.cy[j] + s * sx + c * sy;
-			real slope;
-			real h = sample_ground(g, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
-			real inv = 1.0 / sqrt(1.0 + slope * slope);
-			real nx = -slope * inv, ny = inv;
-			real depth = (h - (ws.st.q[1] + y)) * ny;
-			if (depth > 0) { active = 1; ws.pt_x[pt] = x; ws.pt_y[pt] = y; ws.pt_depth[pt] = depth; ws.pt_nx[pt] = nx; ws.pt_ny[pt] = ny; }
-		}
-		ws.pt_active[pt] = active;
-	}
+	for (int pt = lane; pt < ws.M.L * kPtsPerLink; pt += kGroup) sample_contact_point(ws, gm, g, pt);
 	LANES_END
 	LANES_BEGIN
 	if (lane == 0) {
@@ -447,7 +455,8 @@ DTRL_HD inline void build_delassus(WS& ws, real h)
 		const int s = lane;
 		for (int r = 0; r <= s; ++r) {
 			real a = 0;
-			for (int i = 0; i < D; ++i) a += ws.Z[s][i] * ws.Z[r][i] * ws.dinv[i];
+#pragma unroll 13
+			for (int i = 0; i < kMaxD; ++i) { const real zs = ws.Z[s][i], zr = ws.Z[r][i], di = ws.dinv[i]; if (i < D) a += zs * zr * di; }
 			ws.A[s][r] = a;
 		}
 		real jv;
@@ -459,9 +468,11 @@ DTRL_HD inline void build_delassus(WS& ws, real h)
 			jv = ws.row_dx[s] * vx + ws.row_dy[s] * vy;
 		}
 		real zz = 0;
-		for (int i = 0; i < D; ++i) zz += ws.Z[s][i] * ws.dinv[i] * ws.Z[R][i];
+#pragma unroll 13
+		for (int i = 0; i < kMaxD; ++i) { const real zs = ws.Z[s][i], di = ws.dinv[i], z0 = ws.Z[R][i]; if (i < D) zz += zs * di * z0; }
 		ws.wv[s] = jv + h * zz - ws.row_tgt[s];
 		ws.lam[s] = 0;
+		ws.rinv[s] = (ws.A[s][s] >= 1e-12) ? 1.0 / ws.A[s][s] : 0.0;   // rows with a vanishing effective mass are skipped
 	}
 	LANES_END
 	LANES_BEGIN
@@ -478,9 +489,9 @@ DTRL_HD inline void pgs_solve(WS& ws)
 		for (int r = 0; r < R; ++r) {
 			LANES_BEGIN
 			if (lane == 0) {
-				real arr = ws.A[r][r], dl = 0;
-				if (arr >= 1e-12) {
-					real nl = ws.lam[r] - ws.wv[r] / arr;
+				real ri = ws.rinv[r], dl = 0;
+				if (ri != 0.0) {
+					real nl = ws.lam[r] - ws.wv[r] * ri;
 					if (ws.row_kind[r] == 2) { real lim = kMu * ws.lam[r - 1]; nl = fmin(fmax(nl, -lim), lim); }
 					else nl = fmax(nl, 0.0);
 					dl = nl - ws.lam[r];
@@ -519,13 +530,12 @@ DTRL_HD inline void finish_substep(WS& ws, real h)
 }
 
 // one physics substep (stand-in for one Bullet internal step of sim/World.cpp:101-102)
-DTRL_HD inline void substep_ref(WS& ws, const GroundRec& g, real h)
+DTRL_HD inline void substep_ref(WS& ws, const DevModel& gm, const GroundRec& g, real h)
 {
-	{ PROF_T0(); forward_kinematics(ws); PROF_ADD(ws, kProfFK); }
+	{ PROF_T0(); kin_dyn_terms(ws, false); PROF_ADD(ws, kProfFK); }
 	{ PROF_T0(); mass_matrix(ws); PROF_ADD(ws, kProfMass); }
-	{ PROF_T0(); bias_force(ws, false); PROF_ADD(ws, kProfBias); }
 	{ PROF_T0(); factorize(ws); PROF_ADD(ws, kProfFact); }
-	{ PROF_T0(); detect_contacts(ws, g); PROF_ADD(ws, kProfDetect); }
+	{ PROF_T0(); detect_contacts(ws, gm, g); PROF_ADD(ws, kProfDetect); }
 	{ PROF_T0(); build_rows(ws, h);
 	LANES_BEGIN
 	if (lane < ws.M.D) ws.u[lane] = ws.st.tau[lane] - ws.b[lane];
@@ -628,24 +638,53 @@ DTRL_HD inline void apply_action(WS& ws, int id, const real* params, int P)
 
 // ---- policy network: learning/NeuralNet.cpp:352-375 Eval on the dog_mace3 topology, all 64 lanes of the env's wavefront.
 // Activations ping-pong through a per-env HBM scratch slab (L2-resident: only envs at a cycle boundary touch theirs).
-DTRL_HD inline void fc_layer(WS& ws, const float* W, const float* b, int nout, int nin, const real* x, real* y, bool relu)
+// conv1d: lanes <-> output positions (coalesced activation reads), output channels blocked by 8 so every loaded input
+// feeds 8 FMAs, weights are wave-uniform loads. FC: the engine stores FC weights TRANSPOSED ([nin][nout]) so that
+// lanes <-> outputs read consecutive floats; inputs are wave-uniform loads. Accumulation order per output is the
+// reference order (channel-major, then tap; input index ascending), so results do not depend on the blocking.
+constexpr int kConvBlock = 8;
+DTRL_HD inline void conv_layer(const float* W, const float* bias, int co, int cin, int k, int wdt, const real* a, real* out)
+{
+	const int wo = wdt - k + 1;
+	for (int t0 = 0; t0 < wo; t0 += kGroup) {
+		LANES_BEGIN
+		const int t = t0 + lane;
+		if (t < wo) {
+			for (int o0 = 0; o0 < co; o0 += kConvBlock) {
+				real acc[kConvBlock];
+#pragma unroll
+				for (int bq = 0; bq < kConvBlock; ++bq) acc[bq] = (o0 + bq < co) ? static_cast<real>(bias[o0 + bq]) : 0.0;
+				for (int c = 0; c < cin; ++c) {
+					for (int u = 0; u < k; ++u) {
+						const real x = a[c * wdt + t + u];
+#pragma unroll
+						for (int bq = 0; bq < kConvBlock; ++bq) if (o0 + bq < co) acc[bq] += static_cast<real>(W[((o0 + bq) * cin + c) * k + u]) * x;
+					}
+				}
+#pragma unroll
+				for (int bq = 0; bq < kConvBlock; ++bq) if (o0 + bq < co) out[(o0 + bq) * wo + t] = acc[bq] < 0 ? 0 : acc[bq];
+			}
+		}
+		LANES_END
+	}
+}
+DTRL_HD inline void fc_layer(const float* Wt, const float* b, int nout, int nin, const real* x, real* y, bool relu)
 {
 	for (int o0 = 0; o0 < nout; o0 += kGroup) {
-		// lane-per-output when the layer is wide enough to fill the wavefront; weights of a row are streamed by one lane
 		LANES_BEGIN
 		const int o = o0 + lane;
 		if (o < nout) {
 			real s = b[o];
-			const float* wr = W + static_cast<int64_t>(o) * nin;
-			for (int i = 0; i < nin; ++i) s += static_cast<real>(wr[i]) * x[i];
+#pragma unroll 8
+			for (int i = 0; i < nin; ++i) s += static_cast<real>(Wt[static_cast<int64_t>(i) * nout + o]) * x[i];
 			y[o] = (relu && s < 0) ? 0 : s;
 		}
 		LANES_END
 	}
-	(void)ws;
 }
 DTRL_HD inline void nn_eval(WS& ws, const DevBuffers& buf, int env)
 {
+	(void)ws;
 	const NetDesc& d = buf.net;
 	real* s0 = buf.nn_scratch + static_cast<int64_t>(env) * 2 * buf.nn_scratch_stride;
 	real* s1 = s0 + buf.nn_scratch_stride;
@@ -663,34 +702,27 @@ DTRL_HD inline void nn_eval(WS& ws, const DevBuffers& buf, int env)
 	for (int l = 0; l < 3; ++l) {
 		const int co = d.conv_ch[l], k = d.conv_k[l], wo = wdt - k + 1;
 		const float* W = p; const float* bias = p + static_cast<int64_t>(co) * cin * k;
-		LANES_BEGIN
-		for (int e = lane; e < co * wo; e += kGroup) {
-			const int o = e / wo, t = e - o * wo;
-			real s = bias[o];
-			for (int c = 0; c < cin; ++c) for (int uu = 0; uu < k; ++uu) s += static_cast<real>(W[(o * cin + c) * k + uu]) * a[c * wdt + t + uu];
-			bo[e] = s < 0 ? 0 : s;
-		}
-		LANES_END
+		conv_layer(W, bias, co, cin, k, wdt, a, bo);
 		p = bias + co; real* t2 = a; a = bo; bo = t2; cin = co; wdt = wo;
 	}
 	const int nflat = cin * wdt;
 	// terr_ip0: 5984 -> 64, output written right before the char features so the trunk input is contiguous
 	real* trunk_in = xchar - d.fc_terr;
-	fc_layer(ws, p, p + static_cast<int64_t>(d.fc_terr) * nflat, d.fc_terr, nflat, a, trunk_in, true);
+	fc_layer(p, p + static_cast<int64_t>(d.fc_terr) * nflat, d.fc_terr, nflat, a, trunk_in, true);
 	p += static_cast<int64_t>(d.fc_terr) * nflat + d.fc_terr;
 	const int ntr = d.fc_terr + d.n_char;
 	real* trunk = s0;               // conv activations are dead now (a == s1 after three swaps, trunk_in lives in s1's tail)
 	real* head = s0 + d.fc_trunk;
-	fc_layer(ws, p, p + static_cast<int64_t>(d.fc_trunk) * ntr, d.fc_trunk, ntr, trunk_in, trunk, true);
+	fc_layer(p, p + static_cast<int64_t>(d.fc_trunk) * ntr, d.fc_trunk, ntr, trunk_in, trunk, true);
 	p += static_cast<int64_t>(d.fc_trunk) * ntr + d.fc_trunk;
-	fc_layer(ws, p, p + static_cast<int64_t>(d.fc_head) * d.fc_trunk, d.fc_head, d.fc_trunk, trunk, head, true);
+	fc_layer(p, p + static_cast<int64_t>(d.fc_head) * d.fc_trunk, d.fc_head, d.fc_trunk, trunk, head, true);
 	p += static_cast<int64_t>(d.fc_head) * d.fc_trunk + d.fc_head;
-	fc_layer(ws, p, p + static_cast<int64_t>(d.n_frags) * d.fc_head, d.n_frags, d.fc_head, head, y, false);
+	fc_layer(p, p + static_cast<int64_t>(d.n_frags) * d.fc_head, d.n_frags, d.fc_head, head, y, false);
 	p += static_cast<int64_t>(d.n_frags) * d.fc_head + d.n_frags;
 	for (int f = 0; f < d.n_frags; ++f) {
-		fc_layer(ws, p, p + static_cast<int64_t>(d.fc_head) * d.fc_trunk, d.fc_head, d.fc_trunk, trunk, head, true);
+		fc_layer(p, p + static_cast<int64_t>(d.fc_head) * d.fc_trunk, d.fc_head, d.fc_trunk, trunk, head, true);
 		p += static_cast<int64_t>(d.fc_head) * d.fc_trunk + d.fc_head;
-		fc_layer(ws, p, p + static_cast<int64_t>(d.frag_size) * d.fc_head, d.frag_size, d.fc_head, head, y + d.n_frags + f * d.frag_size, false);
+		fc_layer(p, p + static_cast<int64_t>(d.frag_size) * d.fc_head, d.frag_size, d.fc_head, head, y + d.n_frags + f * d.frag_size, false);
 		p += static_cast<int64_t>(d.frag_size) * d.fc_head + d.frag_size;
 	}
 	LANES_BEGIN
@@ -783,11 +815,11 @@ DTRL_HD inline void update_action(WS& ws, const DevModel& gm, const RunParams& r
 }
 
 // effector contact position (body-local (0, -size_y/2)), relative to the root origin; sim/DogController.cpp:1372-1387
-DTRL_HD inline void effector_pos(const WS& ws, int j, real* out)
+DTRL_HD inline void effector_pos(const WS& ws, const DevModel& gm, int j, real* out)
 {
-	real s, c; sincos(ws.psi[j], &s, &c);
-	real ly = -ws.M.body_half[j][1];
-	out[0] = ws.cx[j] - s * ly; out[1] = ws.cy[j] + c * ly;
+	const real lx = gm.eff_joint[j][0], ly = gm.eff_joint[j][1];
+	out[0] = ws.px[j] + ws.cs[j] * lx - ws.sn[j] * ly;
+	out[1] = ws.py[j] + ws.sn[j] * lx + ws.cs[j] * ly;
 }
 // J_d^T applied to a world force f acting at pos (relative to root): translation DoFs see f, hinge a sees (pos - p_a) x f
 DTRL_HD inline real jt_force(const WS& ws, int d, const real* pos, const real* f)
@@ -819,9 +851,9 @@ DTRL_HD inline void pd_solve_ref(WS& ws, real dt)
 	}
 }
 struct RefPath {
-	static DTRL_HD void substep(WS& ws, const GroundRec& g, real h) { substep_ref(ws, g, h); }
+	static DTRL_HD void substep(WS& ws, const DevModel& gm, const GroundRec& g, real h) { substep_ref(ws, gm, g, h); }
 	static DTRL_HD void pd_solve(WS& ws, real dt) { pd_solve_ref(ws, dt); }
-	static DTRL_HD void contacts(WS& ws, const GroundRec& g) { detect_contacts(ws, g); }
+	static DTRL_HD void contacts(WS& ws, const DevModel& gm, const GroundRec& g) { detect_contacts(ws, gm, g); }
 };
 
 // cDogController::Update, sim/DogController.cpp:229-268
@@ -829,10 +861,8 @@ template <class Path>
 DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, real dt)
 {
 	const int D = ws.M.D, L = ws.M.L;
-	// UpdateRBDModel: composite inertias (H itself is assembled inside the PD solve) and the (quirk) bias at the
-	// post-step configuration; kinematics are already current
-	composite_inertia(ws, false);
-	bias_force(ws, true);
+	// UpdateRBDModel: kinematics, composite inertias and the (quirk) bias at the post-step configuration were produced by
+	// kin_dyn_terms(ws, true) in env_step; H itself is assembled inside the PD solve
 	LANES_BEGIN
 	if (lane == 0) {
 		ws.st.curr_cycle_time += dt;
@@ -914,7 +944,7 @@ DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParam
 				real b0 = 0, b1 = 0;
 				bool on_path = (d < 3) || ((ws.M.sub_mask[d - 2] >> jid) & 1u);
 				if (in_contact(ws, jid) && on_path) {
-					real pos[2]; effector_pos(ws, jid, pos);
+					real pos[2]; effector_pos(ws, gm, jid, pos);
 					const real fy[2] = {0, 1}, fxv[2] = {1, 0};
 					b0 = jt_force(ws, d, pos, fy); b1 = jt_force(ws, d, pos, fxv);
 				}
@@ -967,7 +997,7 @@ DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParam
 				real f[2];
 				if (jid == jToe) { f[0] = -ws.st.params[mpBackForceX]; f[1] = -ws.st.params[mpBackForceY]; }
 				else { f[0] = -ws.st.params[mpFrontForceX]; f[1] = -ws.st.params[mpFrontForceY]; }
-				real pos[2]; effector_pos(ws, jid, pos);
+				real pos[2]; effector_pos(ws, gm, jid, pos);
 				ws.st.tau_ctrl[d] += jt_force(ws, d, pos, f);
 			}
 		}
@@ -1056,9 +1086,9 @@ template <class Path>
 DTRL_HD inline void env_step(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, real dt)
 {
 	const real h = dt / gm.num_sim_substeps;
-	for (int s = 0; s < gm.num_sim_substeps; ++s) Path::substep(ws, g, h);   // UpdateWorld
-	forward_kinematics(ws);
-	Path::contacts(ws, g);                                                  // cContactManager::Update
+	for (int s = 0; s < gm.num_sim_substeps; ++s) Path::substep(ws, gm, g, h);   // UpdateWorld
+	kin_dyn_terms(ws, true);                                                // post-step kinematics + the controller's RBD terms
+	Path::contacts(ws, gm, g);                                                  // cContactManager::Update
 	// UpdateGround is host-side at frame boundaries (the 1 m look-ahead margin makes that equivalent; DESIGN.md "Ground")
 	{ PROF_T0(); controller_update<Path>(ws, gm, rp, buf, g, env, dt); PROF_ADD(ws, kProfCtrl); }   // UpdateCharacter
 	LANES_BEGIN
@@ -1155,7 +1185,7 @@ DTRL_HD inline void load_hot_model(WS& ws, const DevModel& gm)
 		const int j = lane;
 		ws.M.parent[j] = gm.parent[j]; ws.M.depth[j] = gm.depth[j]; ws.M.col[j] = gm.col[j]; ws.M.use_world[j] = gm.use_world[j];
 		for (int k = 0; k < kMaxDepth; ++k) ws.M.path[j][k] = gm.path[j][k];
-		ws.M.sub_mask[j] = gm.sub_mask[j];
+		ws.M.sub_mask[j] = gm.sub_mask[j]; ws.M.anc_mask[j] = gm.anc_mask[j];
 		ws.M.attach[j][0] = gm.attach[j][0]; ws.M.attach[j][1] = gm.attach[j][1];
 		ws.M.lim_lo[j] = gm.lim_lo[j]; ws.M.lim_hi[j] = gm.lim_hi[j];
 		ws.M.body_attach[j][0] = gm.body_attach[j][0]; ws.M.body_attach[j][1] = gm.body_attach[j][1];

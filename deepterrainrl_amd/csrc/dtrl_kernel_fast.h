@@ -24,42 +24,52 @@ __device__ __forceinline__ real bcast(real v, int src)   // src must be wave-uni
 	return __hiloint2double(hi, lo);
 }
 
-// row `lane` of the joint-space inertia matrix from the composite quantities in LDS (same formulas as mass_matrix())
+// row `lane` of the joint-space inertia matrix from the composite quantities in LDS (same formulas and operand order as
+// mass_matrix()). Each hinge lane evaluates the closed form once per ancestor and parks the values in LDS (the storage of
+// the unused LDS copy of H); every lane then assembles its row with one LDS read per column: the entry (d, c) lives in
+// the table row of the DEEPER link at the path position of the shallower one.
 template <int D>
-__device__ __forceinline__ void mass_row(const WS& ws, real (&h)[D])
+__device__ __forceinline__ void mass_row(WS& ws, real (&h)[D])
 {
 	const int d = static_cast<int>(threadIdx.x);
-	const int l = d >= 2 ? d - 2 : 0;                       // my link (lanes >= D compute garbage that is never used)
+	const int l = d >= 2 ? d - 2 : 0;
 	const bool valid = d < D;
+	real (*T)[kMaxDepth + 2] = reinterpret_cast<real (*)[kMaxDepth + 2]>(&ws.H[0][0]);   // T[link][0..depth] + hx, hy at [kMaxDepth], [kMaxDepth+1]
+	if (valid && d >= 2) {
+		const real m = ws.sm[l], mx = ws.smx[l], my = ws.smy[l], I = ws.sI[l];
+		const real plx = ws.px[l], ply = ws.py[l];
+		T[l][kMaxDepth] = -(my - m * ply);
+		T[l][kMaxDepth + 1] = (mx - m * plx);
+		const int dep = ws.M.depth[l];
+		for (int k = 0; k <= dep; ++k) {
+			const int a = ws.M.path[l][k];
+			const real pax = ws.px[a], pay = ws.py[a];
+			T[l][k] = I - ((plx + pax) * mx + (ply + pay) * my) + m * (plx * pax + ply * pay);
+		}
+	}
+	__syncthreads();
 	const real M0 = ws.sm[0];
+	const uint32_t my_sub = valid ? ws.M.sub_mask[l] : 0u, my_anc = valid ? ws.M.anc_mask[l] : 0u;
+	const int my_depth = ws.M.depth[l];
 #pragma unroll
 	for (int c = 0; c < D; ++c) {
 		real v = 0;
 		if (valid) {
 			if (d < 2) {
-				// translation rows: H[d][d] = M, H[x][c>=2] / H[y][c>=2] from the composite of link(c)
 				if (c == d) v = M0;
-				else if (c >= 2) {
-					const int lc = c - 2;
-					v = (d == 0) ? -(ws.smy[lc] - ws.sm[lc] * ws.py[lc]) : (ws.smx[lc] - ws.sm[lc] * ws.px[lc]);
-				}
+				else if (c >= 2) v = T[c - 2][kMaxDepth + d];
 			} else if (c < 2) {
-				v = (c == 0) ? -(ws.smy[l] - ws.sm[l] * ws.py[l]) : (ws.smx[l] - ws.sm[l] * ws.px[l]);
+				v = T[l][kMaxDepth + c];
 			} else {
 				const int lc = c - 2;
-				// deeper link of the pair carries the composite; pairs that are not ancestor-related are zero
-				const bool c_anc_of_me = (ws.M.sub_mask[lc] >> l) & 1u;
-				const bool me_anc_of_c = (ws.M.sub_mask[l] >> lc) & 1u;
-				if (c_anc_of_me || me_anc_of_c) {
-					const int deep = c_anc_of_me ? l : lc, anc = c_anc_of_me ? lc : l;
-					const real m = ws.sm[deep], mx = ws.smx[deep], my = ws.smy[deep], I = ws.sI[deep];
-					const real plx = ws.px[deep], ply = ws.py[deep], pax = ws.px[anc], pay = ws.py[anc];
-					v = I - ((plx + pax) * mx + (ply + pay) * my) + m * (plx * pax + ply * pay);
-				}
+				const int dc = __builtin_amdgcn_readlane(my_depth, c);          // depth of link lc (lane c = lc + 2 holds it)
+				if ((my_anc >> lc) & 1u) v = T[l][dc];                           // lc is an ancestor of (or is) my link
+				else if ((my_sub >> lc) & 1u) v = T[lc][my_depth];               // lc is a descendant
 			}
 		}
 		h[c] = v;
 	}
+	__syncthreads();   // T is dead; the storage may be reused
 }
 
 // in-register LDL^T; returns 1/d_lane. Same elimination order and operations as factorize().
@@ -130,36 +140,11 @@ __device__ __forceinline__ void contact_bits_fast(WS& ws)
 	const unsigned long long lm = __ballot(any);
 	if (lane == 0) ws.st.contact_bits = static_cast<uint32_t>(lm);
 }
-__device__ __forceinline__ void detect_contacts_fast(WS& ws, const GroundRec& g)
+__device__ __forceinline__ void detect_contacts_fast(WS& ws, const DevModel& gm, const GroundRec& g)
 {
-	// first phase of detect_contacts() (sample points), then ballot instead of the serial flag scan
+	// first phase of detect_contacts() (sample points), then ballots instead of the serial flag scan
 	const int lane = static_cast<int>(threadIdx.x);
-	for (int pt = lane; pt < ws.M.L * kPtsPerLink; pt += kGroup) {
-		const int j = pt / kPtsPerLink, k = pt - j * kPtsPerLink;
-		int active = 0;
-		if (ws.M.col[j] != 0) {
-			real hx = ws.M.body_half[j][0], hy = ws.M.body_half[j][1];
-			real sx, sy;
-			switch (k) {
-			case 0: sx = -hx; sy = -hy; break;
-			case 1: sx = hx; sy = -hy; break;
-			case 2: sx = hx; sy = hy; break;
-			case 3: sx = -hx; sy = hy; break;
-			case 4: if (hx >= hy) { sx = 0; sy = -hy; } else { sx = -hx; sy = 0; } break;
-			default: if (hx >= hy) { sx = 0; sy = hy; } else { sx = hx; sy = 0; } break;
-			}
-			real s, c; sincos(ws.psi[j], &s, &c);
-			real x = ws.cx[j] + c * sx - s * sy;
-			real y = ws.cy[j] + s * sx + c * sy;
-			real slope;
-			real h = sample_ground(g, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
-			real inv = 1.0 / sqrt(1.0 + slope * slope);
-			real nx = -slope * inv, ny = inv;
-			real depth = (h - (ws.st.q[1] + y)) * ny;
-			if (depth > 0) { active = 1; ws.pt_x[pt] = x; ws.pt_y[pt] = y; ws.pt_depth[pt] = depth; ws.pt_nx[pt] = nx; ws.pt_ny[pt] = ny; }
-		}
-		ws.pt_active[pt] = active;
-	}
+	for (int pt = lane; pt < ws.M.L * kPtsPerLink; pt += kGroup) sample_contact_point(ws, gm, g, pt);
 	__syncthreads();
 	contact_bits_fast(ws);
 	__syncthreads();
@@ -207,25 +192,70 @@ __device__ __forceinline__ void build_rows_fast(WS& ws, real h)
 	__syncthreads();
 }
 
+// projected Gauss-Seidel in lambda space with the row state in registers: lane s owns row s (w_s, lambda_s, 1/A_ss, kind);
+// a row update is a handful of v_readlane broadcasts + one FMA per lane against column r of the Delassus matrix (LDS,
+// conflict-free 8-byte reads). Same operations and order as pgs_solve().
+__device__ __forceinline__ void pgs_solve_fast(WS& ws)
+{
+	const int lane = static_cast<int>(threadIdx.x);
+	const int R = ws.R;
+	const bool mine = lane < R;
+	real w = mine ? ws.wv[lane] : 0.0, lam = 0.0;
+	const real rinv = mine ? ws.rinv[lane] : 0.0;
+	const int kind = mine ? ws.row_kind[lane] : 0;
+	for (int it = 0; it < kPgsIters; ++it) {
+		for (int r = 0; r < R; ++r) {
+			const real a_sr = mine ? ws.A[lane][r] : 0.0;
+			const real ri = bcast(rinv, r);
+			if (ri != 0.0) {
+				const real lam_r = bcast(lam, r);
+				real nl = lam_r - bcast(w, r) * ri;
+				if (__builtin_amdgcn_readlane(kind, r) == 2) { const real lim = kMu * bcast(lam, r - 1); nl = fmin(fmax(nl, -lim), lim); }
+				else nl = fmax(nl, 0.0);
+				const real dl = nl - lam_r;
+				if (lane == r) lam = nl;
+				w += a_sr * dl;
+			}
+		}
+	}
+	if (mine) ws.lam[lane] = lam;
+	__syncthreads();
+}
+
 template <int D>
 struct FastPath {
-	static __device__ void substep(WS& ws, const GroundRec& g, real h)
+	static __device__ void substep(WS& ws, const DevModel& gm, const GroundRec& g, real h)
 	{
 		const int lane = static_cast<int>(threadIdx.x);
-		{ PROF_T0(); forward_kinematics(ws); PROF_ADD(ws, kProfFK); }
+		{ PROF_T0(); kin_dyn_terms(ws, false); PROF_ADD(ws, kProfFK); }
 		real hrow[D];
-		{ PROF_T0(); composite_inertia(ws, false); mass_row<D>(ws, hrow); PROF_ADD(ws, kProfMass); }
-		{ PROF_T0(); bias_force(ws, false); PROF_ADD(ws, kProfBias); }
+		{ PROF_T0(); mass_row<D>(ws, hrow); PROF_ADD(ws, kProfMass); }
 		real dinv;
 		{ PROF_T0(); dinv = factorize_regs<D>(hrow); PROF_ADD(ws, kProfFact); }
-		{ PROF_T0(); detect_contacts_fast(ws, g); PROF_ADD(ws, kProfDetect); }
+		{ PROF_T0(); detect_contacts_fast(ws, gm, g); PROF_ADD(ws, kProfDetect); }
 		{ PROF_T0(); build_rows_fast(ws, h); PROF_ADD(ws, kProfRows); }
 		const int R = ws.R;
 		{
 			PROF_T0();
+			// J_r[lane] from wave-uniform row descriptors and the lane's own joint position (registers): same value as row_jac()
+			const bool hinge = lane >= 2 && lane < D;
+			const real mypx = hinge ? ws.px[lane - 2] : 0.0, mypy = hinge ? ws.py[lane - 2] : 0.0;
+			const uint32_t mysub = hinge ? ws.M.sub_mask[lane - 2] : 0u;
+			const real rhs0 = (lane < D) ? (ws.st.tau[lane] - ws.b[lane]) : 0.0;
 			for (int r = 0; r <= R; ++r) {
-				real z = 0;
-				if (lane < D) z = (r < R) ? row_jac(ws, r, lane) : (ws.st.tau[lane] - ws.b[lane]);
+				real z = rhs0;
+				if (r < R) {
+					const int kind = ws.row_kind[r], link = ws.row_link[r];
+					const real dx = ws.row_dx[r];
+					if (kind == 0) z = (lane == link + 2) ? dx : 0.0;
+					else {
+						const real dy = ws.row_dy[r], x = ws.row_x[r], y = ws.row_y[r];
+						z = 0.0;
+						if (lane == 0) z = dx;
+						else if (lane == 1) z = dy;
+						else if ((mysub >> link) & 1u) z = dx * (-(y - mypy)) + dy * (x - mypx);
+					}
+				}
 				z = fsub_regs<D>(hrow, z);
 				if (lane < D) ws.Z[r][lane] = z;
 			}
@@ -235,7 +265,7 @@ struct FastPath {
 		}
 		if (R > 0) {
 			{ PROF_T0(); build_delassus(ws, h); PROF_ADD(ws, kProfDelassus); }
-			{ PROF_T0(); pgs_solve(ws); PROF_ADD(ws, kProfPgs); }
+			{ PROF_T0(); pgs_solve_fast(ws); PROF_ADD(ws, kProfPgs); }
 		}
 		{
 			PROF_T0();
@@ -258,7 +288,7 @@ struct FastPath {
 	{
 		const int lane = static_cast<int>(threadIdx.x);
 		real hrow[D];
-		mass_row<D>(ws, hrow);   // composite_inertia() already ran at the top of controller_update
+		mass_row<D>(ws, hrow);   // composite inertias come from kin_dyn_terms(ws, true) in env_step
 		const real add = (lane < D) ? dt * ws.kdv[lane] : 0.0;
 #pragma unroll
 		for (int k = 0; k < D; ++k) if (lane == k) hrow[k] += add;
@@ -272,7 +302,7 @@ struct FastPath {
 		if (lane == 0) ws.R = 0;
 		__syncthreads();
 	}
-	static __device__ void contacts(WS& ws, const GroundRec& g) { detect_contacts_fast(ws, g); }
+	static __device__ void contacts(WS& ws, const DevModel& gm, const GroundRec& g) { detect_contacts_fast(ws, gm, g); }
 };
 
 }  // namespace dtrl

@@ -49,6 +49,7 @@ struct DevModel {
 	int32_t depth[kMaxL];
 	int8_t path[kMaxL][kMaxDepth];   // path[j][0..depth[j]] = root .. j
 	uint32_t sub_mask[kMaxL];        // bit k set <=> link k is in the subtree rooted at j (incl. j)
+	uint32_t anc_mask[kMaxL];        // bit a set <=> link a is an ancestor of j or j itself
 	int32_t col[kMaxL];
 	int32_t use_world[kMaxL];
 	int32_t act_idx0[kMaxAct], act_idx1[kMaxAct], act_cyclic[kMaxAct];
@@ -64,6 +65,8 @@ struct DevModel {
 	real act_blend[kMaxAct];
 	real ctrl_params[kMaxSets][kMaxP];
 	real pose0[kMaxD], vel0[kMaxD];
+	real pt_joint[kMaxL][kPtsPerLink][2];   // contact sample points in the JOINT frame: body_attach + R(body_theta) * corner
+	real eff_joint[kMaxL][2];               // body-local (0, -size_y/2) in the joint frame (end-effector contact position)
 	real init_pos_x, target_vel_x, total_mass;
 	real world_scale;
 };

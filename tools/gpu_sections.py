@@ -6,23 +6,23 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import deepterrainrl_amd as da
 import bench
-NAMES = ["FK", "Mass", "Bias", "Fact", "Detect", "Rows", "Fsub", "Delassus", "Pgs", "Finish", "Ctrl(incl Action)", "Action", "FrameIO", "Total", "RowsSum", "Substeps"]
+NAMES = ["FK", "Mass", "Bias", "Fact", "Detect", "Rows", "Fsub", "Delassus", "Pgs", "Finish", "Ctrl(incl Action)", "Action", "FrameIO", "Total", "RowsSum", "Substeps", "P1cum", "P2cum", "P3cum", "P4cum"]
 lib = os.path.join(REPO, "deepterrainrl_amd", "lib", "libdtrl_prof.so")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 b = da.BatchScenario(bench.ARG_FILE, n, data_root=bench.ROOT, extra_args={"terrain_seed": 20260925, "rand_seed": 1}, _lib_path=lib)
 b.SetPolicy(bench.xavier_weights(b.PolicyNumParams()), *bench.load_scale())
 b.RunFrames(30)
-out = (C.c_ulonglong * 16)()
-b._lib.dtrlx_profile_sections(b._h, out, 16)
+out = (C.c_ulonglong * 24)()
+b._lib.dtrlx_profile_sections(b._h, out, 24)
 base = np.array(list(out), dtype=np.float64)
 frames = 20
 b.KernelTimeMs(); b.RunFrames(frames); ms, nl = b.KernelTimeMs()
-b._lib.dtrlx_profile_sections(b._h, out, 16)
+b._lib.dtrlx_profile_sections(b._h, out, 24)
 v = np.array(list(out), dtype=np.float64) - base
 steps = n * frames * 20
 print("kernel %.3f ms/frame; per env-step per wave (s_memtime ticks @100MHz -> x24 ~ shader cycles):" % ms)
 tot = v[13]
 for k, name in enumerate(NAMES):
-    if k < 14:
+    if k < 14 or k >= 16:
         print("  %-18s %10.1f ticks/env-step  %5.1f%%" % (name, v[k] / steps, 100 * v[k] / tot))
 print("  avg rows per substep: %.2f" % (v[14] / max(v[15], 1)))
