@@ -82,7 +82,9 @@ dtrl_status dtrl_get_flags(dtrl_batch* b, const int32_t* env_ids, int n, uint32_
 		const EnvState& s = st[i];
 		bool flipped = std::fabs(dtrl::wrap_pi(s.q[2])) > 3.14159265358979323846 * 0.8;
 		bool fallen = s.sum_fall_contact > 0.25 || s.fail_fall_dist != 0 || flipped;
-		uint32_t stumble_mask = ~((1u << dtrl::jToe) | (1u << dtrl::jFinger) | (1u << dtrl::jAnkle) | (1u << dtrl::jWrist));
+		uint32_t stumble_mask = (b->eng.cfg().model.char_type == 1)
+			? ~((1u << dtrl::rRightToe) | (1u << dtrl::rLeftToe) | (1u << dtrl::rRightAnkle) | (1u << dtrl::rLeftAnkle))
+			: ~((1u << dtrl::jToe) | (1u << dtrl::jFinger) | (1u << dtrl::jAnkle) | (1u << dtrl::jWrist));
 		bool stumbled = (s.contact_bits & stumble_mask & ((1u << L) - 1u)) != 0;
 		bool new_cycle = s.state == 0 && s.phase == 0;
 		bits[i] = (fallen ? DTRL_FLAG_FALLEN : 0u) | (stumbled ? DTRL_FLAG_STUMBLED : 0u) | (new_cycle ? DTRL_FLAG_NEW_CYCLE : 0u) | (static_cast<uint32_t>(s.state) << DTRL_FLAG_STATE_SHIFT);

@@ -412,6 +412,12 @@ const char* const kDogStates[4] = {"BackStance", "Extend", "FrontStance", "Gathe
 const char* const kDogStateParams[6] = {"SpineCurve", "Shoulder", "Elbow", "Hip", "Knee", "Ankle"};
 // sim/SimDog.cpp:5-33
 const int kDogCol[21] = {2, 2, 2, 2, 2, 2, 2, 2, 2, 0, 0, 0, 0, 4, 4, 4, 4, 8, 8, 8, 8};
+// raptor: sim/RaptorController.cpp:37-55 parameter names, :71-114 gOptParamsMasks, sim/SimRaptor.cpp:5-29 collision groups
+const char* const kRaptorMisc[5] = {"TransTime", "Cv", "Cd", "ForceX", "ForceY"};
+const char* const kRaptorStates[4] = {"Contact", "Down", "Passing", "Up"};
+const char* const kRaptorStateParams[8] = {"RootPitch", "SpineCurve", "StanceHip", "StanceKnee", "StanceAnkle", "SwingHip", "SwingKnee", "SwingAnkle"};
+const int kRaptorOptMask[37] = {0, 1, 1, 0, 0, 1, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 1, 1, 1};
+const int kRaptorCol[19] = {2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 4, 4, 4, 4, 4, 4, 4, 4};
 }  // namespace
 
 bool ParseDeployPrototxt(const std::string& path, NetDesc& d, std::string& err)
@@ -520,8 +526,10 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	// scenarios/ScenarioSimChar.cpp:19-36 controller names
 	if (char_ctrl == "dog") { m.char_type = 0; m.ctrl_type = 0; }
 	else if (char_ctrl == "dog_mace" || char_ctrl == "goat_mace") { m.char_type = 0; m.ctrl_type = 1; }
-	else { err = "char_ctrl '" + char_ctrl + "' is not supported by this build (dog, dog_mace, goat_mace)"; return false; }
-	if (!char_type.empty() && char_type != "dog") { err = "char_type '" + char_type + "' does not match the controller"; return false; }
+	else if (char_ctrl == "raptor") { m.char_type = 1; m.ctrl_type = 0; }
+	else if (char_ctrl == "raptor_mace") { m.char_type = 1; m.ctrl_type = 1; }
+	else { err = "char_ctrl '" + char_ctrl + "' is not supported by this build (dog, dog_mace, goat_mace, raptor, raptor_mace; Q/CACLA heads are out of scope)"; return false; }
+	if (!char_type.empty() && char_type != (m.char_type == 0 ? "dog" : "raptor")) { err = "char_type '" + char_type + "' does not match the controller"; return false; }
 	m.target_vel_x = (char_ctrl == "goat_mace") ? 2.0 : 4.0;   // sim/GoatControllerMACE.cpp:11-14, sim/DogController.cpp:625-628
 	if (scenario == "train_mace" || scenario == "exp" || scenario == "exp_mace") m.scenario = kScnExp;
 	else if (scenario == "poli_eval") m.scenario = kScnPoliEval;
@@ -535,6 +543,7 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	const int L = static_cast<int>(joints->arr.size());
 	if (L > kMaxL || L != static_cast<int>(bodies->arr.size()) || L != static_cast<int>(pds->arr.size())) { err = char_file + ": inconsistent joint/body/PD counts"; return false; }
 	if (m.char_type == 0 && L != 21) { err = "dog controller expects 21 joints"; return false; }
+	if (m.char_type == 1 && L != 19) { err = "raptor controller expects 19 joints"; return false; }
 	m.L = L;
 	int D = 0;
 	for (int j = 0; j < L; ++j) {
@@ -561,7 +570,7 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		double sx = bd.get_num("Param0", 0), sy = bd.get_num("Param1", 0);
 		m.body_half[j][0] = 0.5 * sx; m.body_half[j][1] = 0.5 * sy;
 		m.inertia[j] = m.mass[j] / 12.0 * (sx * sx + sy * sy);                                     // sim/RBDUtil.cpp:562-583 (zz term)
-		m.col[j] = kDogCol[j];
+		m.col[j] = (m.char_type == 0) ? kDogCol[j] : kRaptorCol[j];
 		const Json& pd = pds->arr[j];
 		m.kp[j] = pd.get_num("Kp", 0); m.kd[j] = pd.get_num("Kd", 0); m.torque_lim[j] = pd.get_num("TorqueLim", 0);
 		m.target_theta[j] = pd.get_num("TargetTheta", 0); m.use_world[j] = pd.get_num("UseWorldCoord", 0) != 0;
@@ -593,8 +602,9 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	// controllers (sim/DogController.cpp:629-700, 399-454)
 	const Json* files = ctrls->find("Files"); const Json* acts = ctrls->find("Actions");
 	if (!files || !acts) { err = "Controllers block needs Files and Actions"; return false; }
-	m.P = 30; m.n_opt = 0;
-	for (int i = 0; i < m.P; ++i) if (i != 0) m.opt_index[m.n_opt++] = i;   // gParamInfo: only TransTime is not optimisable
+	const bool raptor = m.char_type == 1;
+	m.P = raptor ? 37 : 30; m.n_opt = 0;
+	for (int i = 0; i < m.P; ++i) if (raptor ? kRaptorOptMask[i] != 0 : i != 0) m.opt_index[m.n_opt++] = i;   // dog gParamInfo: only TransTime is not optimisable
 	m.n_sets = static_cast<int>(files->arr.size());
 	if (m.n_sets > kMaxSets) { err = "too many controller files"; return false; }
 	for (int s = 0; s < m.n_sets; ++s) {
@@ -603,8 +613,14 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		const Json* misc = cf.find("MiscParams"); const Json* sps = cf.find("StateParams");
 		if (!misc || !sps) { err = files->arr[s].str + ": missing MiscParams/StateParams"; return false; }
 		int idx = 0;
-		for (int i = 0; i < 6; ++i) m.ctrl_params[s][idx++] = misc->get_num(kDogMisc[i], 0);
-		for (int st = 0; st < 4; ++st) { const Json* sp = sps->find(kDogStates[st]); for (int i = 0; i < 6; ++i) m.ctrl_params[s][idx++] = sp ? sp->get_num(kDogStateParams[i], 0) : 0; }
+		if (raptor) {   // sim/RaptorController.cpp:442-495
+			for (int i = 0; i < 5; ++i) m.ctrl_params[s][idx++] = misc->get_num(kRaptorMisc[i], 0);
+			for (int st = 0; st < 4; ++st) { const Json* sp = sps->find(kRaptorStates[st]); for (int i = 0; i < 8; ++i) m.ctrl_params[s][idx++] = sp ? sp->get_num(kRaptorStateParams[i], 0) : 0; }
+			m.ctrl_params[s][2] = std::fabs(m.ctrl_params[s][2]);
+		} else {
+			for (int i = 0; i < 6; ++i) m.ctrl_params[s][idx++] = misc->get_num(kDogMisc[i], 0);
+			for (int st = 0; st < 4; ++st) { const Json* sp = sps->find(kDogStates[st]); for (int i = 0; i < 6; ++i) m.ctrl_params[s][idx++] = sp ? sp->get_num(kDogStateParams[i], 0) : 0; }
+		}
 		m.ctrl_params[s][0] = std::fabs(m.ctrl_params[s][0]); m.ctrl_params[s][1] = std::fabs(m.ctrl_params[s][1]);   // PostProcessParams
 	}
 	m.n_actions = static_cast<int>(acts->arr.size());
@@ -617,7 +633,7 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	}
 	m.default_action = m.n_actions > 0 ? static_cast<int>(ctrls->get_num("DefaultAction", 0)) : -1;
 	m.enable_grav_comp = ctrls->get_bool("EnableGravityCompensation", true);   // ctor default sim/DogController.cpp:172
-	m.enable_vf = 1;
+	m.enable_vf = raptor ? ctrls->get_bool("EnableVirtualForces", true) : 1;   // sim/RaptorController.cpp:705-708; the dog always applies them
 
 	// initial state (anim/Character.cpp:239-262)
 	for (int i = 0; i < D; ++i) { m.pose0[i] = 0; m.vel0[i] = 0; }
@@ -657,7 +673,7 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	double exp_rate = 0.1, exp_temp = 1, exp_base = 0.01;   // cScenarioExp ctor defaults; mExpTemp is uninitialised there -> controller default 1
 	args.ParseDouble("exp_rate", exp_rate); args.ParseDouble("exp_temp", exp_temp); args.ParseDouble("exp_base_rate", exp_base);
 	cfg.run.enable_exp = (m.scenario == kScnExp) ? 1 : 0;
-	cfg.run.exp_rate = exp_rate; cfg.run.exp_temp = exp_temp; cfg.run.exp_base_rate = exp_base; cfg.run.exp_noise = 0.2;   // mExpNoise, sim/DogControllerMACE.cpp:7
+	cfg.run.exp_rate = exp_rate; cfg.run.exp_temp = exp_temp; cfg.run.exp_base_rate = exp_base; cfg.run.exp_noise = (m.char_type == 1) ? 0.15 : 0.2;   // mExpNoise, sim/DogControllerMACE.cpp:7, sim/RaptorControllerMACE.cpp:7
 	int rseed = 0; args.ParseInt("rand_seed", rseed); cfg.run.rng_seed = static_cast<uint64_t>(rseed);
 	int goff = 0; args.ParseInt("global_env_offset", goff); cfg.run.env_id_base = goff;
 

@@ -59,7 +59,7 @@ enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfR
 
 // hot, read-mostly model fields staged in LDS
 struct HotModel {
-	int32_t L, D;
+	int32_t L, D, char_type, pad_;
 	int32_t parent[kMaxL], depth[kMaxL], col[kMaxL], use_world[kMaxL];
 	int8_t path[kMaxL][kMaxDepth];
 	uint32_t sub_mask[kMaxL];
@@ -131,7 +131,7 @@ struct WS {
 			real z0_[kMaxD];
 			real basis[kMaxD][4];
 			real tau_g[kMaxD];
-			real kpv[kMaxD], kdv[kMaxD], perr[kMaxD], verr[kMaxD];
+			real kpv[kMaxD], kdv[kMaxD], kdm[kMaxD], perr[kMaxD], verr[kMaxD];
 		};
 	};
 	real red[8];
@@ -569,8 +569,24 @@ DTRL_HD inline void calc_com(const WS& ws, real* out)
 	for (int j = 0; j < ws.M.L; ++j) { sx += ws.M.mass[j] * (ws.st.q[0] + ws.cx[j]); sy += ws.M.mass[j] * (ws.st.q[1] + ws.cy[j]); m += ws.M.mass[j]; }
 	out[0] = sx / m; out[1] = sy / m;
 }
-DTRL_HD inline void set_state_params(WS& ws)  // sim/DogController.cpp:1042-1054
+// raptor joint ids (sim/SimRaptor.h:11-33), params (5 misc + 4 states x 8) and FSM states (sim/RaptorController.h)
+enum { rRoot, rSpine0, rSpine1, rSpine2, rSpine3, rHead, rTail0, rTail1, rTail2, rTail3, rTail4,
+	rRightHip, rRightKnee, rRightAnkle, rRightToe, rLeftHip, rLeftKnee, rLeftAnkle, rLeftToe };
+enum { rspRootPitch, rspSpineCurve, rspStanceHip, rspStanceKnee, rspStanceAnkle, rspSwingHip, rspSwingKnee, rspSwingAnkle, rspMax };
+enum { rmpTransTime, rmpCv, rmpCd, rmpForceX, rmpForceY, rmpMax };
+enum { rstContact, rstDown, rstPassing, rstUp, rstMax, rstInvalid };
+DTRL_HD inline int stance_joint(const WS& ws, int k) { return (ws.st.stance == 0 ? rRightHip : rLeftHip) + k; }   // k: 0 hip .. 3 toe
+DTRL_HD inline int swing_joint(const WS& ws, int k) { return (ws.st.stance == 0 ? rLeftHip : rRightHip) + k; }
+
+DTRL_HD inline void set_state_params(WS& ws)  // sim/DogController.cpp:1042-1054, sim/RaptorController.cpp:1108-1126
 {
+	if (ws.M.char_type == 1) {
+		const real* sp = ws.st.params + rmpMax + ws.st.state * rspMax;
+		const int sh = stance_joint(ws, 0), wh = swing_joint(ws, 0);
+		ws.st.pd_target[sh] = sp[rspStanceHip]; ws.st.pd_target[sh + 1] = sp[rspStanceKnee]; ws.st.pd_target[sh + 2] = sp[rspStanceAnkle];
+		ws.st.pd_target[wh] = sp[rspSwingHip]; ws.st.pd_target[wh + 1] = sp[rspSwingKnee]; ws.st.pd_target[wh + 2] = sp[rspSwingAnkle];
+		return;
+	}
 	const real* sp = ws.st.params + mpMax + ws.st.state * spMax;
 	ws.st.pd_target[jSpine0] = sp[spSpineCurve]; ws.st.pd_target[jSpine1] = sp[spSpineCurve]; ws.st.pd_target[jSpine2] = sp[spSpineCurve];
 	ws.st.pd_target[jSpine3] = sp[spSpineCurve]; ws.st.pd_target[jTorso] = sp[spSpineCurve];
@@ -578,12 +594,30 @@ DTRL_HD inline void set_state_params(WS& ws)  // sim/DogController.cpp:1042-1054
 	ws.st.pd_target[jHip] = sp[spHip]; ws.st.pd_target[jKnee] = sp[spKnee]; ws.st.pd_target[jAnkle] = sp[spAnkle];
 }
 DTRL_HD inline void transition_state(WS& ws, int s) { ws.st.state = s; ws.st.phase = 0; set_state_params(ws); }
-DTRL_HD inline bool has_stumbled(const WS& ws)  // sim/SimDog.cpp:83-105
+// cRaptorController::SetStance, sim/RaptorController.cpp:1439-1446
+DTRL_HD inline void set_stance(WS& ws, int st)
 {
-	uint32_t mask = ~((1u << jToe) | (1u << jFinger) | (1u << jAnkle) | (1u << jWrist));
+	ws.st.stance = st;
+	ws.st.pd_active_bits &= ~(1u << stance_joint(ws, 0));
+	ws.st.pd_active_bits |= (1u << swing_joint(ws, 0));
+	set_state_params(ws);
+}
+// cRaptorController::IsActiveVFEffector, :1157-1163
+DTRL_HD inline bool raptor_active_effector(const WS& ws, int j)
+{
+	return j == stance_joint(ws, 3) && (ws.st.state == rstContact || ws.st.state == rstDown) && ((ws.st.contact_bits >> j) & 1u);
+}
+DTRL_HD inline bool has_stumbled(const WS& ws)  // sim/SimDog.cpp:83-105, sim/SimRaptor.cpp:78-101
+{
+	uint32_t mask = (ws.M.char_type == 1) ? ~((1u << rRightToe) | (1u << rLeftToe) | (1u << rRightAnkle) | (1u << rLeftAnkle))
+										   : ~((1u << jToe) | (1u << jFinger) | (1u << jAnkle) | (1u << jWrist));
 	return (ws.st.contact_bits & mask & ((1u << ws.M.L) - 1u)) != 0;
 }
-DTRL_HD inline bool check_fall_contact(const WS& ws) { return (ws.st.contact_bits & ((1u << (jHead + 1)) - 1u)) != 0; }  // sim/SimDog.cpp:112-141
+DTRL_HD inline bool check_fall_contact(const WS& ws)  // sim/SimDog.cpp:112-141 (root..head), sim/SimRaptor.cpp:108-137 (root..head)
+{
+	const int last = (ws.M.char_type == 1) ? rHead : jHead;
+	return (ws.st.contact_bits & ((1u << (last + 1)) - 1u)) != 0;
+}
 DTRL_HD inline bool has_fallen(const WS& ws)  // sim/SimCharSoftFall.cpp:53-61, sim/SimDog.cpp:143-161
 {
 	bool flipped = fabs(wrap_pi(ws.st.q[2])) > 3.14159265358979323846 * 0.8;
@@ -597,7 +631,11 @@ DTRL_HD inline void blend_ctrl_params(const DevModel& gm, int a, real* out)  // 
 	real b = gm.act_blend[a];
 	for (int i = 0; i < gm.P; ++i) out[i] = (1 - b) * p0[i] + b * p1[i];
 }
-DTRL_HD inline void post_process_params(real* p) { p[mpTransTime] = fabs(p[mpTransTime]); p[mpCv] = fabs(p[mpCv]); }
+DTRL_HD inline void post_process_params(real* p, int char_type)
+{
+	p[0] = fabs(p[0]); p[1] = fabs(p[1]);                 // TransTime, Cv
+	if (char_type == 1) p[rmpCd] = fabs(p[rmpCd]);         // sim/RaptorController.cpp:1401-1406
+}
 DTRL_HD inline int assign_frag_id(const DevModel& gm, int num_frags, int a_id, Rng& rng)  // sim/DogControllerMACE.cpp:44-91
 {
 	int frag_id = 0;
@@ -627,7 +665,7 @@ DTRL_HD inline void apply_action(WS& ws, int id, const real* params, int P)
 {
 	ws.st.action_id = id;
 	for (int i = 0; i < P; ++i) ws.st.params[i] = params[i];
-	post_process_params(ws.st.params);
+	post_process_params(ws.st.params, ws.M.char_type);
 	ws.st.prev_cycle_time = ws.st.curr_cycle_time; ws.st.curr_cycle_time = 0;
 	ws.st.prev_stumble = ws.st.curr_stumble; ws.st.curr_stumble = 0;
 	real com[2]; calc_com(ws, com);
@@ -748,6 +786,19 @@ DTRL_HD inline void update_action(WS& ws, const DevModel& gm, const RunParams& r
 	if (lane >= 1 && lane < L) { ps[kNumGroundSamples + 1 + 2 * (lane - 1)] = ws.cx[lane]; ps[kNumGroundSamples + 2 + 2 * (lane - 1)] = ws.cy[lane]; }
 	if (lane < L) { ps[kNumGroundSamples + 2 * L - 1 + 2 * lane] = ws.vcx[lane]; ps[kNumGroundSamples + 2 * L + 2 * lane] = ws.vcy[lane]; }
 	LANES_END
+	if (gm.char_type == 1 && ws.st.stance != 0) {
+		// cRaptorController::BuildPoliStatePose/Vel -> FlipPoliPoseStance (sim/RaptorController.cpp:1414-1488): mirror the two
+		// trailing leg blocks (4 links x 2) of the pose and of the velocity features when the left leg is the stance leg
+		LANES_BEGIN
+		if (lane < 16) {
+			const int nleg = 8;
+			const int end = (lane < 8) ? kNumGroundSamples + (2 * L - 1) : kNumGroundSamples + (2 * L - 1) + 2 * L;
+			const int i = lane & 7;
+			real a = ps[end - 1 - i], b2 = ps[end - nleg - 1 - i];
+			ps[end - 1 - i] = b2; ps[end - nleg - 1 - i] = a;
+		}
+		LANES_END
+	}
 	// decide which branch of UpdateAction runs (lane 0 draws the random numbers; the branch flag is broadcast via LDS)
 	LANES_BEGIN
 	if (lane == 0) {
@@ -795,7 +846,7 @@ DTRL_HD inline void update_action(WS& ws, const DevModel& gm, const RunParams& r
 			id = a;
 			const real* frag = y + nf + a * buf.net.frag_size;
 			for (int k = 0; k < gm.n_opt; ++k) prm[gm.opt_index[k]] = frag[k];
-			post_process_params(prm);
+			post_process_params(prm, gm.char_type);
 			if (rp.enable_exp) {
 				real rand_noise = rng.uniform();
 				if (rand_noise < rp.exp_rate) {
@@ -836,7 +887,7 @@ DTRL_HD inline void pd_solve_ref(WS& ws, real dt)
 	const int D = ws.M.D;
 	mass_matrix(ws);
 	LANES_BEGIN
-	if (lane < D) ws.H[lane][lane] += dt * ws.kdv[lane];
+	if (lane < D) ws.H[lane][lane] += dt * ws.kdm[lane];
 	if (lane == 0) { ws.R = 0; }
 	LANES_END
 	factorize(ws);
@@ -856,30 +907,59 @@ struct RefPath {
 	static DTRL_HD void contacts(WS& ws, const DevModel& gm, const GroundRec& g) { detect_contacts(ws, gm, g); }
 };
 
-// cDogController::Update, sim/DogController.cpp:229-268
+// 4x4 ridge solve of the contact-basis least squares (partial-pivot elimination), shared by both characters
+DTRL_HD inline void solve_ls4(const real (*basis)[4], const real* tau_g, const real* W, real* x)
+{
+	real M4[4][5];
+	for (int a = 0; a < 4; ++a) {
+		for (int c = 0; c < 4; ++c) { real s = 0; for (int r = 0; r < 3; ++r) s += basis[r][a] * W[r] * basis[r][c]; M4[a][c] = s; }
+		real s = 0; for (int r = 0; r < 3; ++r) s += basis[r][a] * W[r] * tau_g[r];
+		M4[a][4] = s; M4[a][a] += 0.0001;
+	}
+	for (int c = 0; c < 4; ++c) {
+		int p = c; for (int r = c + 1; r < 4; ++r) if (fabs(M4[r][c]) > fabs(M4[p][c])) p = r;
+		if (p != c) for (int k = 0; k < 5; ++k) { real t = M4[c][k]; M4[c][k] = M4[p][k]; M4[p][k] = t; }
+		for (int r = c + 1; r < 4; ++r) { real f = M4[r][c] / M4[c][c]; for (int k = c; k < 5; ++k) M4[r][k] -= f * M4[c][k]; }
+	}
+	for (int i = 3; i >= 0; --i) { real s = M4[i][4]; for (int k = i + 1; k < 4; ++k) s -= M4[i][k] * x[k]; x[i] = s / M4[i][i]; }
+}
+
+// cDogController::Update (sim/DogController.cpp:229-268) / cRaptorController::Update (sim/RaptorController.cpp:195-233)
 template <class Path>
 DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, real dt)
 {
 	const int D = ws.M.D, L = ws.M.L;
+	const bool raptor = gm.char_type == 1;
 	// UpdateRBDModel: kinematics, composite inertias and the (quirk) bias at the post-step configuration were produced by
 	// kin_dyn_terms(ws, true) in env_step; H itself is assembled inside the PD solve
 	LANES_BEGIN
 	if (lane == 0) {
 		ws.st.curr_cycle_time += dt;
 		if (has_stumbled(ws)) ws.st.curr_stumble += dt;
-		// UpdateState :805-845
+		// UpdateState: dog :805-845, raptor :804-849
 		bool advance = ws.st.first_cycle != 0;
-		real trans_time = ws.st.params[mpTransTime];
+		real trans_time = ws.st.params[0];
 		ws.st.phase += dt / trans_time;
 		const int state = ws.st.state;
-		if ((state == stBackStance || state == stFrontStance) && ws.st.phase >= 1) advance = true;
-		int trans_contact = (state == stExtend) ? jFinger : ((state == stGather) ? jToe : -1);
-		if (trans_contact >= 0 && in_contact(ws, trans_contact)) advance = true;
 		int do_update = 0;
-		if (advance) {
-			int next = ws.st.first_cycle ? stBackStance : ((state == stGather) ? stInvalid : state + 1);
-			bool end_step = (next == stInvalid) || ws.st.first_cycle;
-			if (end_step) do_update = 1; else transition_state(ws, next);
+		if (raptor) {
+			if (state != rstUp && ws.st.phase >= 1) advance = true;
+			if (state == rstUp && in_contact(ws, swing_joint(ws, 3))) advance = true;
+			if (advance) {
+				int next = ws.st.first_cycle ? rstContact : ((state == rstUp) ? rstInvalid : state + 1);
+				bool end_step = (next == rstInvalid) || ws.st.first_cycle;
+				if (end_step) { if (!ws.st.first_cycle) set_stance(ws, ws.st.stance == 0 ? 1 : 0); do_update = 1; }   // FlipStance precedes UpdateAction
+				else transition_state(ws, next);
+			}
+		} else {
+			if ((state == stBackStance || state == stFrontStance) && ws.st.phase >= 1) advance = true;
+			int trans_contact = (state == stExtend) ? jFinger : ((state == stGather) ? jToe : -1);
+			if (trans_contact >= 0 && in_contact(ws, trans_contact)) advance = true;
+			if (advance) {
+				int next = ws.st.first_cycle ? stBackStance : ((state == stGather) ? stInvalid : state + 1);
+				bool end_step = (next == stInvalid) || ws.st.first_cycle;
+				if (end_step) do_update = 1; else transition_state(ws, next);
+			}
 		}
 		ws.flag_update_action = do_update;
 	}
@@ -894,30 +974,45 @@ DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParam
 	}
 	LANES_BEGIN
 	if (lane == 0) {
-		// ApplyFeedback :903-945 (COM velocity feedback on hip / shoulder while the matching effector is airborne)
 		real sx = 0, m = 0;
 		for (int j = 0; j < L; ++j) { sx += ws.M.mass[j] * ws.vcx[j]; m += ws.M.mass[j]; }
 		real com_vx = sx / m;
-		const int joints[2] = {jHip, jShoulder}, effs[2] = {jToe, jFinger}, prm[2] = {spHip, spShoulder};
-		for (int k = 0; k < 2; ++k) if (!in_contact(ws, effs[k])) {
-			real default_theta = ws.st.params[mpMax + ws.st.state * spMax + prm[k]];
-			ws.st.pd_target[joints[k]] = default_theta + com_vx * ws.st.params[mpCv];
+		if (raptor) {
+			// UpdateStanceHip :899-905
+			const int sh = stance_joint(ws, 0), st_toe = stance_joint(ws, 3);
+			if (raptor_active_effector(ws, st_toe)) ws.st.pd_active_bits &= ~(1u << sh); else ws.st.pd_active_bits |= (1u << sh);
+			// ApplySwingFeedback :907-931 (SIMBICON-style: cd * d + cv * v on the swing hip, every step)
+			real cv = ws.st.params[rmpCv], cd = ws.st.params[rmpCd];
+			const bool first_half = ws.st.state == rstContact || ws.st.state == rstDown;
+			cd = first_half ? 0 : cd; cv = first_half ? cv : 0;
+			real com[2]; calc_com(ws, com);
+			real d_theta = cd * (com[0] - (ws.st.q[0] + ws.cx[st_toe])) + cv * com_vx;
+			ws.st.pd_target[swing_joint(ws, 0)] = ws.st.params[rmpMax + ws.st.state * rspMax + rspSwingHip] + d_theta;
+		} else {
+			// ApplyFeedback :903-945 (COM velocity feedback on hip / shoulder while the matching effector is airborne)
+			const int joints[2] = {jHip, jShoulder}, effs[2] = {jToe, jFinger}, prm[2] = {spHip, spShoulder};
+			for (int k = 0; k < 2; ++k) if (!in_contact(ws, effs[k])) {
+				real default_theta = ws.st.params[mpMax + ws.st.state * spMax + prm[k]];
+				ws.st.pd_target[joints[k]] = default_theta + com_vx * ws.st.params[mpCv];
+			}
 		}
 	}
 	LANES_END
 	// cImpPDController::CalcControlForces: (H + dt Kd) acc = Kp (e - dt qd) + Kd e_dot - C;  tau = Kp (e - dt qd) + Kd (e_dot - dt acc)
+	// inactive controllers (raptor stance hip) drop out of Kp/Kd but their raw Kd stays on the diagonal (sim/ImpPDController.cpp:244-258)
 	LANES_BEGIN
 	if (lane < D) {
 		const int i = lane;
-		real kp = 0, kd = 0, pe = 0, ve = 0;
+		real kp = 0, kd = 0, kdm = 0, pe = 0, ve = 0;
 		if (i >= 3) {
 			const int j = i - 2;
-			kp = ws.M.kp[j]; kd = ws.M.kd[j];
+			kdm = ws.M.kd[j];
+			if ((ws.st.pd_active_bits >> j) & 1u) { kp = ws.M.kp[j]; kd = kdm; }
 			real theta = ws.M.use_world[j] ? wrap_pi(ws.psi[j]) : wrap_pi(ws.st.q[i]);
 			pe = ws.st.pd_target[j] - theta;
 			ve = 0 - ws.st.qd[i];
 		}
-		ws.kpv[i] = kp; ws.kdv[i] = kd; ws.perr[i] = pe; ws.verr[i] = ve;
+		ws.kpv[i] = kp; ws.kdv[i] = kd; ws.kdm[i] = kdm; ws.perr[i] = pe; ws.verr[i] = ve;
 		ws.u[i] = kp * (pe - dt * ws.st.qd[i]) + kd * ve - ws.b[i];
 	}
 	LANES_END
@@ -925,9 +1020,11 @@ DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParam
 	LANES_BEGIN
 	if (lane < D) { const int i = lane; ws.tau_g[i] = 0; ws.st.tau_ctrl[i] = ws.kpv[i] * (ws.perr[i] - dt * ws.st.qd[i]) + ws.kdv[i] * (ws.verr[i] - dt * ws.u[i]); }
 	LANES_END
-	// ApplyGravityCompensation :947-995 (+ BuildContactBasis :1120-1175)
-	const bool toe_c = in_contact(ws, jToe), fin_c = in_contact(ws, jFinger);
-	if (gm.enable_grav_comp && (toe_c || fin_c)) {
+	// gravity compensation: dog :947-995 (+ BuildContactBasis :1120-1175), raptor :985-1028 (+ :1170-1240)
+	const int eff0 = raptor ? rRightToe : jToe, eff1 = raptor ? rLeftToe : jFinger;
+	const bool sup0 = raptor ? raptor_active_effector(ws, eff0) : in_contact(ws, eff0);
+	const bool sup1 = raptor ? raptor_active_effector(ws, eff1) : in_contact(ws, eff1);
+	if (gm.enable_grav_comp && (sup0 || sup1)) {
 		LANES_BEGIN
 		if (lane < D) {
 			const int d = lane;
@@ -938,12 +1035,11 @@ DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParam
 			else if (d == 1) tg = -(ws.sm[0] * gy);
 			else { const int l = d - 2; tg = -((ws.smx[l] - ws.sm[l] * ws.px[l]) * gy); }
 			ws.tau_g[d] = tg;
-			const int effs[2] = {jToe, jFinger};
 			for (int e = 0; e < 2; ++e) {
-				const int jid = effs[e];
+				const int jid = e ? eff1 : eff0;
 				real b0 = 0, b1 = 0;
 				bool on_path = (d < 3) || ((ws.M.sub_mask[d - 2] >> jid) & 1u);
-				if (in_contact(ws, jid) && on_path) {
+				if ((e ? sup1 : sup0) && on_path) {
 					real pos[2]; effector_pos(ws, gm, jid, pos);
 					const real fy[2] = {0, 1}, fxv[2] = {1, 0};
 					b0 = jt_force(ws, d, pos, fy); b1 = jt_force(ws, d, pos, fxv);
@@ -954,51 +1050,64 @@ DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParam
 		LANES_END
 		LANES_BEGIN
 		if (lane == 0) {
-			// ridge least squares on the 3 root rows: (A^T A + 1e-4 I) x = A^T b, 4x4, partial-pivot elimination
-			real M4[4][5];
-			for (int a = 0; a < 4; ++a) {
-				for (int c = 0; c < 4; ++c) { real s = 0; for (int r = 0; r < 3; ++r) s += ws.basis[r][a] * ws.basis[r][c]; M4[a][c] = s; }
-				real s = 0; for (int r = 0; r < 3; ++r) s += ws.basis[r][a] * ws.tau_g[r];
-				M4[a][4] = s; M4[a][a] += 0.0001;
-			}
-			for (int c = 0; c < 4; ++c) {
-				int p = c; for (int r = c + 1; r < 4; ++r) if (fabs(M4[r][c]) > fabs(M4[p][c])) p = r;
-				if (p != c) for (int k = 0; k < 5; ++k) { real t = M4[c][k]; M4[c][k] = M4[p][k]; M4[p][k] = t; }
-				for (int r = c + 1; r < 4; ++r) { real f = M4[r][c] / M4[c][c]; for (int k = c; k < 5; ++k) M4[r][k] -= f * M4[c][k]; }
-			}
+			// ridge least squares on the 3 root rows: (A^T W A + 1e-4 I) x = A^T W b; W = I (dog), diag(1e-4, 1e-4, 1) (raptor)
+			const real Wd[3] = {1, 1, 1}, Wr[3] = {0.0001, 0.0001, 1};
 			real x[4];
-			for (int i = 3; i >= 0; --i) { real s = M4[i][4]; for (int k = i + 1; k < 4; ++k) s -= M4[i][k] * x[k]; x[i] = s / M4[i][i]; }
+			solve_ls4(ws.basis, ws.tau_g, raptor ? Wr : Wd, x);
 			for (int k = 0; k < 4; ++k) ws.red[k] = x[k];
 		}
 		LANES_END
 		LANES_BEGIN
-		if (lane >= 3 && lane < D) {
+		if (lane < D && (raptor || lane >= 3)) {   // the dog zeroes the root rows; the raptor keeps them (they are never applied)
 			const int d = lane;
 			real s = 0; for (int k = 0; k < 4; ++k) s += ws.basis[d][k] * ws.red[k];
 			ws.st.tau_ctrl[d] += ws.tau_g[d] - s;
 		}
 		LANES_END
 	}
-	// ApplyVirtualForces :997-1029
+	if (raptor) {
+		// ApplyStanceFeedback :933-983: the stance hip balances the swing hip torque and servoes the root pitch
+		LANES_BEGIN
+		if (lane == 0 && raptor_active_effector(ws, stance_joint(ws, 3))) {
+			const int sh = stance_joint(ws, 0), wh = swing_joint(ws, 0);
+			real hip_tau = -ws.st.tau_ctrl[wh + 2];
+			real target_pitch = ws.st.params[rmpMax + ws.st.state * rspMax + rspRootPitch];
+			real root_tau = ws.M.kp[sh] * (target_pitch - wrap_pi(ws.st.q[2])) + ws.M.kd[sh] * (-ws.st.qd[2]);
+			hip_tau += -root_tau;
+			ws.st.tau_ctrl[sh + 2] += hip_tau;
+		}
+		LANES_END
+	}
+	// virtual forces: dog :997-1029, raptor :1030-1075
 	if (gm.enable_vf) {
 		LANES_BEGIN
 		if (lane >= 3 && lane < D) {
 			const int d = lane, a = d - 2;
-			const int effs[2] = {jToe, jFinger};
-			const int state = ws.st.state;
-			for (int e = 0; e < 2; ++e) {
-				const int jid = effs[e];
-				bool valid = ((state == stBackStance || state == stExtend) && jid == jToe) || ((state == stFrontStance || state == stGather) && jid == jFinger);
-				if (!(valid && in_contact(ws, jid))) continue;
-				// chain: effector up to (excluding) root / torso
-				bool on_chain = ((ws.M.sub_mask[a] >> jid) & 1u) && a != jRoot && a != jTorso;
-				if (on_chain && jid == jFinger) on_chain = !((ws.M.sub_mask[a] >> jTorso) & 1u);  // strictly below the torso
-				if (!on_chain) continue;
-				real f[2];
-				if (jid == jToe) { f[0] = -ws.st.params[mpBackForceX]; f[1] = -ws.st.params[mpBackForceY]; }
-				else { f[0] = -ws.st.params[mpFrontForceX]; f[1] = -ws.st.params[mpFrontForceY]; }
-				real pos[2]; effector_pos(ws, gm, jid, pos);
-				ws.st.tau_ctrl[d] += jt_force(ws, d, pos, f);
+			if (raptor) {
+				const int jid = stance_joint(ws, 3);
+				if (raptor_active_effector(ws, jid)) {
+					const real f[2] = {-ws.st.params[rmpForceX], -ws.st.params[rmpForceY]};
+					real pos[2]; effector_pos(ws, gm, jid, pos);
+					if ((ws.M.sub_mask[a] >> jid) & 1u) ws.st.tau_ctrl[d] += jt_force(ws, d, pos, f);   // toe .. hip (root excluded: d >= 3)
+					if (a == swing_joint(ws, 0)) ws.st.tau_ctrl[d] += -jt_force(ws, stance_joint(ws, 0) + 2, pos, f);
+				}
+			} else {
+				const int effs[2] = {jToe, jFinger};
+				const int state = ws.st.state;
+				for (int e = 0; e < 2; ++e) {
+					const int jid = effs[e];
+					bool valid = ((state == stBackStance || state == stExtend) && jid == jToe) || ((state == stFrontStance || state == stGather) && jid == jFinger);
+					if (!(valid && in_contact(ws, jid))) continue;
+					// chain: effector up to (excluding) root / torso
+					bool on_chain = ((ws.M.sub_mask[a] >> jid) & 1u) && a != jRoot && a != jTorso;
+					if (on_chain && jid == jFinger) on_chain = !((ws.M.sub_mask[a] >> jTorso) & 1u);  // strictly below the torso
+					if (!on_chain) continue;
+					real f[2];
+					if (jid == jToe) { f[0] = -ws.st.params[mpBackForceX]; f[1] = -ws.st.params[mpBackForceY]; }
+					else { f[0] = -ws.st.params[mpFrontForceX]; f[1] = -ws.st.params[mpFrontForceY]; }
+					real pos[2]; effector_pos(ws, gm, jid, pos);
+					ws.st.tau_ctrl[d] += jt_force(ws, d, pos, f);
+				}
 			}
 		}
 		LANES_END
@@ -1025,6 +1134,7 @@ DTRL_HD inline real calc_reward(const WS& ws, const DevModel& gm)
 		vel_reward = exp(-0.5 * vel_err * vel_err);
 		real avg_stumble = ws.st.prev_stumble / cycle_time;
 		stumble_reward = 1.0 / (1 + 10 * avg_stumble);
+		if (gm.char_type == 1 && avg_vel < 0) { vel_reward = 0; stumble_reward = 0; }   // sim/RaptorController.cpp:584-588
 	}
 	return 0.8 * vel_reward + 0.2 * stumble_reward;
 }
@@ -1135,6 +1245,8 @@ DTRL_HD inline void reset_env(WS& ws, const DevModel& gm, const RunParams& rp, c
 		ws.st.prev_cycle_time = 0; ws.st.prev_dist[0] = 0; ws.st.prev_dist[1] = 0; ws.st.curr_cycle_time = 0;
 		ws.st.prev_stumble = 0; ws.st.curr_stumble = 0;
 		ws.st.cmd_action = -1;
+		ws.st.pd_active_bits = 0xffffffffu; ws.st.stance = 0;
+		if (gm.char_type == 1) set_stance(ws, 0);   // ResetParams + mImpPDCtrl.Reset + SetStance(gDefaultStance)
 		calc_com(ws, ws.st.prev_com);
 		ws.st.fall_dist_counter = 5; ws.st.prev_check[0] = ws.st.q[0]; ws.st.prev_check[1] = ws.st.q[1]; ws.st.fail_fall_dist = 0;
 		ws.st.fall_contact_counter = 0.1; ws.st.sum_fall_contact = 0;
@@ -1180,7 +1292,7 @@ DTRL_HD inline void frame_end(WS& ws, const DevModel& gm, const DevBuffers& buf,
 DTRL_HD inline void load_hot_model(WS& ws, const DevModel& gm)
 {
 	LANES_BEGIN
-	if (lane == 0) { ws.M.L = gm.L; ws.M.D = gm.D; }
+	if (lane == 0) { ws.M.L = gm.L; ws.M.D = gm.D; ws.M.char_type = gm.char_type; }
 	if (lane < gm.L) {
 		const int j = lane;
 		ws.M.parent[j] = gm.parent[j]; ws.M.depth[j] = gm.depth[j]; ws.M.col[j] = gm.col[j]; ws.M.use_world[j] = gm.use_world[j];

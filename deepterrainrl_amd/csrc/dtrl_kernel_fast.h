@@ -289,7 +289,7 @@ struct FastPath {
 		const int lane = static_cast<int>(threadIdx.x);
 		real hrow[D];
 		mass_row<D>(ws, hrow);   // composite inertias come from kin_dyn_terms(ws, true) in env_step
-		const real add = (lane < D) ? dt * ws.kdv[lane] : 0.0;
+		const real add = (lane < D) ? dt * ws.kdm[lane] : 0.0;
 #pragma unroll
 		for (int k = 0; k < D; ++k) if (lane == k) hrow[k] += add;
 		const real dinv = factorize_regs<D>(hrow);

@@ -95,12 +95,14 @@ struct EnvState {
 	int64_t num_cycles, num_resets, num_episodes;
 	int32_t action_id, state, first_cycle, is_off_policy;
 	int32_t exp_actor, exp_critic, cmd_action, fail_fall_dist;
+	int32_t stance;          // raptor: 0 = right leg is the stance leg (gDefaultStance), 1 = left
+	uint32_t pd_active_bits; // raptor: cPDController active flags per joint (dog: all active)
 	uint32_t contact_bits;
 	int32_t cycle_count, tuple_flags;
 	int32_t need_reset;      // set by the kernel at frame end (fall); host regenerates terrain, then sets do_reset
 	int32_t do_reset;        // consumed by the kernel at frame start
 	int32_t do_init;         // first launch: full cScenario::Init ordering
-	int32_t pad_;
+	int32_t pad_[3];
 };
 
 struct GroundRec {

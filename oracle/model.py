@@ -44,6 +44,7 @@ class OrcModel(C.Structure):
         ("use_world", C.c_int32 * MAXL),
         ("n_sets", C.c_int32), ("n_params", C.c_int32),
         ("ctrl_params", (C.c_double * MAXP) * MAXSETS),
+        ("opt_mask", C.c_int32 * MAXP), ("exp_noise", C.c_double),
         ("n_actions", C.c_int32),
         ("act_idx0", C.c_int32 * MAXACT), ("act_idx1", C.c_int32 * MAXACT),
         ("act_blend", C.c_double * MAXACT), ("act_cyclic", C.c_int32 * MAXACT),
@@ -106,6 +107,13 @@ DOG_STATES = ["BackStance", "Extend", "FrontStance", "Gather"]
 DOG_STATE_PARAMS = ["SpineCurve", "Shoulder", "Elbow", "Hip", "Knee", "Ankle"]
 # sim/SimDog.cpp:5-33: body=2, front leg=4, back leg=8, tail=0
 DOG_COL = [2] * 9 + [0] * 4 + [4] * 4 + [8] * 4
+# sim/SimRaptor.cpp:5-29: body (incl. tail) = 2, legs = 4
+RAPTOR_COL = [2] * 11 + [4] * 8
+RAPTOR_MISC = ["TransTime", "Cv", "Cd", "ForceX", "ForceY"]
+RAPTOR_STATES = ["Contact", "Down", "Passing", "Up"]
+RAPTOR_STATE_PARAMS = ["RootPitch", "SpineCurve", "StanceHip", "StanceKnee", "StanceAnkle", "SwingHip", "SwingKnee", "SwingAnkle"]
+# sim/RaptorController.cpp:71-114 gOptParamsMasks
+RAPTOR_OPT_MASK = [0, 1, 1, 0, 0] + [1, 0, 1, 1, 1, 1, 1, 1] * 2 + [0, 0, 1, 1, 1, 1, 1, 1] * 2
 CTRL_NAMES = {"dog": ("dog", 0), "dog_mace": ("dog", 1), "goat_mace": ("dog", 1), "raptor": ("raptor", 0), "raptor_mace": ("raptor", 1)}
 SCENARIOS = {"sim_char": 0, "train_mace": 1, "exp": 1, "exp_mace": 1, "poli_eval": 2}
 
@@ -122,6 +130,16 @@ def read_dog_ctrl_params(path):
     for s in DOG_STATES:
         v += [float(d["StateParams"][s][k]) for k in DOG_STATE_PARAMS]
     v[0] = abs(v[0]); v[1] = abs(v[1])  # PostProcessParams
+    return v
+
+
+def read_raptor_ctrl_params(path):
+    """sim/RaptorController.cpp:442-495"""
+    d = load_json(path)
+    v = [float(d["MiscParams"][k]) for k in RAPTOR_MISC]
+    for s in RAPTOR_STATES:
+        v += [float(d["StateParams"][s][k]) for k in RAPTOR_STATE_PARAMS]
+    v[0] = abs(v[0]); v[1] = abs(v[1]); v[2] = abs(v[2])  # PostProcessParams
     return v
 
 
@@ -177,13 +195,19 @@ def build_model(arg_file, root, overrides=None):
         for j in range(L):
             m.col_group[j] = DOG_COL[j]
     else:
-        raise NotImplementedError("raptor controller is not restated yet")
+        assert L == 19
+        for j in range(L):
+            m.col_group[j] = RAPTOR_COL[j]
     ctrl = char["Controllers"]
     files = ctrl["Files"]
     m.n_sets = len(files)
-    m.n_params = 30
+    m.n_params = 30 if m.char_type == 0 else 37
+    mask = [0] + [1] * 29 if m.char_type == 0 else RAPTOR_OPT_MASK
+    for i, b in enumerate(mask):
+        m.opt_mask[i] = b
+    m.exp_noise = 0.2 if m.char_type == 0 else 0.15
     for s, fpath in enumerate(files):
-        v = read_dog_ctrl_params(os.path.join(root, fpath))
+        v = (read_dog_ctrl_params if m.char_type == 0 else read_raptor_ctrl_params)(os.path.join(root, fpath))
         for i, x in enumerate(v):
             m.ctrl_params[s][i] = x
     acts = ctrl["Actions"]
@@ -193,7 +217,7 @@ def build_model(arg_file, root, overrides=None):
         m.act_blend[a] = float(ad["Blend"]); m.act_cyclic[a] = int(bool(ad["Cyclic"]))
     m.default_action = int(ctrl.get("DefaultAction", 0))
     m.enable_grav_comp = int(bool(ctrl.get("EnableGravityCompensation", True)))
-    m.enable_virtual_forces = 1
+    m.enable_virtual_forces = int(bool(ctrl.get("EnableVirtualForces", True)))   # only cRaptorController reads this key; dog VF is always on
     m.target_vel_x = 2.0 if args.get("char_ctrl") == "goat_mace" else 4.0
     state = load_json(os.path.join(root, args["state_file"]))
     assert len(state["Pose"]) == D and len(state["Vel"]) == D
@@ -226,7 +250,9 @@ def build_model(arg_file, root, overrides=None):
     m.exp_rate = float(args.get("exp_rate", 0.1))
     m.exp_temp = float(args.get("exp_temp", 1))
     m.exp_base_rate = float(args.get("exp_base_rate", 0.01))
-    info = {"args": args, "char": char, "S": 200 + (2 * L - 1) + 2 * L, "n_opt": 29, "root": root}
+    if m.char_type == 0:
+        m.enable_virtual_forces = 1
+    info = {"args": args, "char": char, "S": 200 + (2 * L - 1) + 2 * L, "n_opt": int(sum(mask)), "root": root}
     return m, info
 
 
@@ -287,7 +313,7 @@ def load_scale_file(path):
 def build_output_offset_scale(m, n_frags):
     """sim/BaseControllerMACE.cpp:75-168 + sim/DogControllerMACE.cpp:93-99: NN output offset/scale from controller files."""
     P = m.n_params
-    opt = [i for i in range(P) if i != 0]
+    opt = [i for i in range(P) if m.opt_mask[i]]
 
     def action_opt(a):
         p0 = np.array(m.ctrl_params[m.act_idx0[a]][:P]); p1 = np.array(m.ctrl_params[m.act_idx1[a]][:P])

@@ -1,5 +1,8 @@
 // ORACLE (test infrastructure, NOT product code).
-// CPU fp64 restatement of the reference's character controller stack for the dog/goat:
+// CPU fp64 restatement of the reference's character controller stack for the dog/goat and the raptor
+// (sim/RaptorController.cpp:195-233 Update, :804-849 UpdateState, :899-983 stance hip / swing + stance feedback,
+//  :985-1075 gravity compensation + virtual forces, :561-600 reward, :1414-1488 stance-mirrored policy state,
+//  :1434-1446 FlipStance/SetStance; sim/SimRaptor.cpp:78-153 stumble / fall parts):
 //   sim/DogController.cpp:229-268 Update, :805-845 UpdateState, :847-868 UpdateAction, :894-945 feedback,
 //   :947-995 gravity compensation, :997-1029 virtual forces, :1042-1054 SetStateParams, :1120-1175 contact basis,
 //   :594-628 CalcReward, :1323-1352 NewCycleUpdate/BlendCtrlParams/PostProcessParams, :1372-1393 contact pos/dist
@@ -140,6 +143,13 @@ enum { spSpineCurve, spShoulder, spElbow, spHip, spKnee, spAnkle, spMax };
 enum { mpTransTime, mpCv, mpBackForceX, mpBackForceY, mpFrontForceX, mpFrontForceY, mpMax };
 enum { stBackStance, stExtend, stFrontStance, stGather, stMax, stInvalid };
 
+// raptor joint ids: sim/SimRaptor.h:11-33; params: sim/RaptorController.h (5 misc + 4 states x 8)
+enum RaptorJoint { rRoot, rSpine0, rSpine1, rSpine2, rSpine3, rHead, rTail0, rTail1, rTail2, rTail3, rTail4,
+	rRightHip, rRightKnee, rRightAnkle, rRightToe, rLeftHip, rLeftKnee, rLeftAnkle, rLeftToe, rRaptorMax };
+enum { rspRootPitch, rspSpineCurve, rspStanceHip, rspStanceKnee, rspStanceAnkle, rspSwingHip, rspSwingKnee, rspSwingAnkle, rspMax };
+enum { rmpTransTime, rmpCv, rmpCd, rmpForceX, rmpForceY, rmpMax };
+enum { rstContact, rstDown, rstPassing, rstUp, rstMax, rstInvalid };
+
 struct Action { int id = -1; double params[ORC_MAXP]; };
 
 struct Tuple { double reward; unsigned flags; std::vector<double> s0, a, s1; };
@@ -176,6 +186,9 @@ struct Env {
 	std::vector<int> commands;
 	bool exp_actor = false, exp_critic = false;
 	bool enable_exp = false; double exp_rate = 0.2, exp_temp = 1, exp_base_rate = 0.2; double exp_noise = 0.2;
+	// raptor: stance leg (0 = right = gDefaultStance, 1 = left) and per-joint cPDController active flags
+	int stance = 0; bool pd_active[ORC_MAXL];
+	bool IsRaptor() const { return M.char_type == 1; }
 	std::vector<double> ground_samples, poli_state;
 	double sample_origin[2] = {0, 0};
 	std::vector<double> nn_out;
@@ -188,12 +201,13 @@ struct Env {
 	double avg_dist = 0, pos_start_x = 0;
 	std::vector<double> dist_log;
 
-	static bool IsOptParam(int i) { return i != mpTransTime; }  // sim/DogController.cpp:75-115 gParamInfo
+	bool IsOptParam(int i) const { return M.opt_mask[i] != 0; }  // sim/DogController.cpp:75-115 gParamInfo, sim/RaptorController.cpp:71-114 gOptParamsMasks
 
 	void Init(const OrcModel& m, uint64_t terrain_seed, uint64_t rng_seed, uint64_t env_id)
 	{
 		M = m; rbd.Init(&M); L = rbd.L; D = rbd.D; P = M.n_params;
 		nOpt = 0; for (int i = 0; i < P; ++i) if (IsOptParam(i)) ++nOpt;
+		exp_noise = M.exp_noise; stance = 0; for (int j = 0; j < ORC_MAXL; ++j) pd_active[j] = true;
 		rng.Seed(rng_seed, env_id);
 		ground.type = M.terrain_type; ground.world_scale = M.world_scale;
 		SetTerrainParamsLerp(M.terrain_blend);
@@ -259,6 +273,7 @@ struct Env {
 		prev_cycle_time = 0; prev_dist[0] = prev_dist[1] = 0; curr_cycle_time = 0; prev_stumble = curr_stumble = 0;
 		std::fill(ground_samples.begin(), ground_samples.end(), 0.0);
 		commands.clear();
+		if (IsRaptor()) { for (int j = 0; j < L; ++j) pd_active[j] = true; stance = 0; SetStance(0); }  // ResetParams + mImpPDCtrl.Reset + SetStance(default)
 		CalcCOM(prev_com);                                    // cDogController::Reset: mPrevCOM = CalcCOM()
 	}
 	// scenario-level Reset: scenarios/ScenarioSimChar.cpp:121-132 (+ ScenarioExp.cpp:63-73 / ScenarioPoliEval.cpp:72-78)
@@ -294,7 +309,11 @@ struct Env {
 		double b = M.act_blend[a];
 		for (int i = 0; i < P; ++i) out[i] = (1 - b) * p0[i] + b * p1[i];
 	}
-	static void PostProcessParams(double* p) { p[mpTransTime] = std::fabs(p[mpTransTime]); p[mpCv] = std::fabs(p[mpCv]); }
+	void PostProcessParams(double* p) const
+	{
+		p[0] = std::fabs(p[0]); p[1] = std::fabs(p[1]);                       // TransTime, Cv (both characters)
+		if (IsRaptor()) p[rmpCd] = std::fabs(p[rmpCd]);                         // sim/RaptorController.cpp:1401-1406
+	}
 	int NumFrags() const { return (net && net->valid) ? net->d.n_frags : 0; }
 	// sim/DogControllerMACE.cpp:44-91
 	int AssignFragID(int a_id)
@@ -322,8 +341,16 @@ struct Env {
 		BlendCtrlParams(a_id, out.params);
 		if (M.ctrl_type == 1) out.id = AssignFragID(a_id);
 	}
-	void SetStateParams()  // sim/DogController.cpp:1042-1054
+	int StanceJ(int k) const { return (stance == 0 ? rRightHip : rLeftHip) + k; }   // k: 0 hip, 1 knee, 2 ankle, 3 toe
+	int SwingJ(int k) const { return (stance == 0 ? rLeftHip : rRightHip) + k; }
+	void SetStateParams()  // sim/DogController.cpp:1042-1054, sim/RaptorController.cpp:1108-1126 (ENABLE_SPINE_CURVE is not defined)
 	{
+		if (IsRaptor()) {
+			const double* sp = curr.params + rmpMax + state * rspMax;
+			pd_target[StanceJ(0)] = sp[rspStanceHip]; pd_target[StanceJ(1)] = sp[rspStanceKnee]; pd_target[StanceJ(2)] = sp[rspStanceAnkle];
+			pd_target[SwingJ(0)] = sp[rspSwingHip]; pd_target[SwingJ(1)] = sp[rspSwingKnee]; pd_target[SwingJ(2)] = sp[rspSwingAnkle];
+			return;
+		}
 		const double* sp = curr.params + mpMax + state * spMax;
 		const int spine[5] = {jSpine0, jSpine1, jSpine2, jSpine3, jTorso};
 		for (int i = 0; i < 5; ++i) pd_target[spine[i]] = sp[spSpineCurve];
@@ -331,6 +358,9 @@ struct Env {
 		pd_target[jHip] = sp[spHip]; pd_target[jKnee] = sp[spKnee]; pd_target[jAnkle] = sp[spAnkle];
 	}
 	void TransitionState(int s) { state = s; phase = 0; SetStateParams(); }
+	// cRaptorController::SetStance, sim/RaptorController.cpp:1439-1446
+	void SetStance(int st) { stance = st; pd_active[StanceJ(0)] = false; pd_active[SwingJ(0)] = true; SetStateParams(); }
+	bool IsActiveVFEffector(int j) const { return j == StanceJ(3) && (state == rstContact || state == rstDown) && contact[j]; }  // :1157-1163
 	void NewCycleUpdateCtrl()  // sim/DogController.cpp:1323-1333
 	{
 		prev_cycle_time = curr_cycle_time; curr_cycle_time = 0;
@@ -351,10 +381,11 @@ struct Env {
 	// sim/SimDog.cpp:83-105
 	bool HasStumbled() const
 	{
+		if (IsRaptor()) { for (int j = 0; j < L; ++j) if (j != rRightToe && j != rLeftToe && j != rRightAnkle && j != rLeftAnkle && contact[j]) return true; return false; }
 		for (int j = 0; j < L; ++j) if (j != jToe && j != jFinger && j != jAnkle && j != jWrist && contact[j]) return true;
 		return false;
 	}
-	bool CheckFallContact() const { for (int j = jRoot; j <= jHead; ++j) if (contact[j]) return true; return false; }  // sim/SimDog.cpp:112-141
+	bool CheckFallContact() const { int last = IsRaptor() ? rHead : jHead; for (int j = 0; j <= last; ++j) if (contact[j]) return true; return false; }  // sim/SimDog.cpp:112-141
 	bool HasFallen() const  // sim/SimCharSoftFall.cpp:53-61, sim/SimDog.cpp:143-161
 	{
 		bool fall_contact = sum_fall_contact > 0.25;
@@ -381,6 +412,11 @@ struct Env {
 		poli_state[idx++] = q[1] - ground_h;
 		for (int j = 1; j < L; ++j) { poli_state[idx++] = B.cx[j] - q[0]; poli_state[idx++] = B.cy[j] - q[1]; }
 		for (int j = 0; j < L; ++j) { poli_state[idx++] = B.vcx[j]; poli_state[idx++] = B.vcy[j]; }
+		if (IsRaptor() && stance != 0) {
+			// FlipPoliPoseStance on the pose block and on the vel block: swap the trailing right-leg / left-leg blocks
+			const int nleg = 4 * 2, pose_end = 200 + (2 * L - 1), vel_end = pose_end + 2 * L;
+			for (int i = 0; i < nleg; ++i) { std::swap(poli_state[pose_end - 1 - i], poli_state[pose_end - nleg - 1 - i]); std::swap(poli_state[vel_end - 1 - i], poli_state[vel_end - nleg - 1 - i]); }
+		}
 	}
 	void GetOptParams(const double* p, double* out) const { int k = 0; for (int i = 0; i < P; ++i) if (IsOptParam(i)) out[k++] = p[i]; }
 	void SetOptParams(const double* opt, double* p) const { int k = 0; for (int i = 0; i < P; ++i) if (IsOptParam(i)) p[i] = opt[k++]; PostProcessParams(p); }
@@ -455,8 +491,114 @@ struct Env {
 	double CalcTheta(int j) const { return M.use_world[j] ? WrapPi(B.psi[j]) : WrapPi(q[j + 2]); }
 
 	// ---- cDogController::Update, sim/DogController.cpp:229-268 -------------------------------------------
+	void ImpPD(double dt, double* tau)  // cImpPDController::CalcControlForces, sim/ImpPDController.cpp:234-278
+	{
+		double Mm[ORC_MAXD * ORC_MAXD], rhs[ORC_MAXD], acc[ORC_MAXD], kp[ORC_MAXD], kd[ORC_MAXD], kdm[ORC_MAXD], perr[ORC_MAXD], verr[ORC_MAXD];
+		for (int i = 0; i < D; ++i) { kp[i] = kd[i] = kdm[i] = perr[i] = verr[i] = 0; }
+		for (int j = 1; j < L; ++j) {  // root has no cJoint -> its cPDController is never Init'ed (invalid)
+			kdm[j + 2] = M.kd[j];        // M.diagonal() += t * mKd uses the raw gains even for inactive controllers (:258)
+			perr[j + 2] = pd_target[j] - CalcTheta(j);
+			verr[j + 2] = 0 - qd[j + 2];
+			if (pd_active[j]) { kp[j + 2] = M.kp[j]; kd[j + 2] = M.kd[j]; }   // inactive -> Kp_mat / Kd_mat rows zeroed (:244-255)
+		}
+		for (int i = 0; i < D; ++i) for (int k = 0; k < D; ++k) Mm[i * D + k] = rbd.H[i][k];
+		for (int i = 0; i < D; ++i) Mm[i * D + i] += dt * kdm[i];
+		for (int i = 0; i < D; ++i) rhs[i] = kp[i] * (perr[i] - dt * qd[i]) + kd[i] * verr[i] - rbd.C[i];
+		SolveLDLT(D, Mm, D, rhs, acc);
+		for (int i = 0; i < D; ++i) tau[i] += kp[i] * (perr[i] - dt * qd[i]) + kd[i] * (verr[i] - dt * acc[i]);
+	}
+	void ClampAndApply(const double* tau)  // cSimCharacter::ApplyControlForces + cJoint::ApplyTorque, sim/Joint.cpp:171-201,257-264
+	{
+		for (int i = 0; i < D; ++i) { tau_ctrl[i] = tau[i]; tau_applied[i] = 0; }
+		for (int j = 1; j < L; ++j) {
+			double t = tau[j + 2], lim = M.torque_lim[j];
+			if (std::fabs(t) > lim) t *= lim / std::fabs(t);
+			tau_applied[j + 2] = t;
+		}
+	}
+	// cRaptorController::Update, sim/RaptorController.cpp:195-233
+	void RaptorControllerUpdate(double dt)
+	{
+		double tau[ORC_MAXD];
+		for (int i = 0; i < D; ++i) tau[i] = 0;
+		curr_cycle_time += dt;
+		if (HasStumbled()) curr_stumble += dt;
+		rbd.Update(q, qd, /*fix_cj=*/false);
+		{   // UpdateState :804-849
+			bool advance = first_cycle;
+			phase += dt / curr.params[rmpTransTime];
+			if (state != rstUp && phase >= 1) advance = true;
+			if (state == rstUp && contact[SwingJ(3)]) advance = true;
+			if (advance) {
+				int next = first_cycle ? rstContact : ((state == rstUp) ? rstInvalid : state + 1);
+				bool end_step = (next == rstInvalid) || first_cycle;
+				if (end_step) { if (!first_cycle) SetStance(stance == 0 ? 1 : 0); UpdateAction(); first_cycle = false; }
+				else TransitionState(next);
+			}
+		}
+		pd_active[StanceJ(0)] = !IsActiveVFEffector(StanceJ(3));   // UpdateStanceHip :899-905
+		{   // ApplySwingFeedback :907-931
+			double cv = curr.params[rmpCv], cd = curr.params[rmpCd];
+			bool first_half = state == rstContact || state == rstDown;
+			cd = first_half ? 0 : cd; cv = first_half ? cv : 0;
+			double com[2], com_vel[2]; CalcCOM(com); CalcCOMVel(com_vel);
+			double d_theta = cd * (com[0] - B.cx[StanceJ(3)]) + cv * com_vel[0];
+			pd_target[SwingJ(0)] = curr.params[rmpMax + state * rspMax + rspSwingHip] + d_theta;
+		}
+		ImpPD(dt, tau);
+		if (M.enable_grav_comp) {   // :985-1028 (weighted ridge LS, support = active stance effector only)
+			double basis[ORC_MAXD][4];
+			for (int i = 0; i < D; ++i) for (int k = 0; k < 4; ++k) basis[i][k] = 0;
+			bool has_support = false;
+			const int effs[2] = {rRightToe, rLeftToe};
+			for (int e = 0; e < 2; ++e) {
+				int jid = effs[e];
+				if (!IsActiveVFEffector(jid)) continue;
+				has_support = true;
+				double pos[2]; EffectorContactPos(jid, pos);
+				const double fb[2][2] = {{0, 1}, {1, 0}};
+				for (int c = jid; c >= 0; c = M.parent[c]) for (int a = 0; a < rbd.kt.dim[c]; ++a) for (int b = 0; b < 2; ++b) basis[rbd.kt.off[c] + a][e * 2 + b] = JtF(rbd.kt.off[c] + a, pos, fb[b]);
+			}
+			if (has_support) {
+				double tau_g[ORC_MAXD]; rbd.CalcGravityForce(tau_g);
+				for (int i = 0; i < D; ++i) tau_g[i] = -tau_g[i];
+				const double W[3] = {0.0001, 0.0001, 1};
+				double AtA[16], Atb[4], x[4];
+				for (int a = 0; a < 4; ++a) {
+					for (int b = 0; b < 4; ++b) { double s = 0; for (int r = 0; r < 3; ++r) s += basis[r][a] * W[r] * basis[r][b]; AtA[a * 4 + b] = s; }
+					double s = 0; for (int r = 0; r < 3; ++r) s += basis[r][a] * W[r] * tau_g[r];
+					Atb[a] = s; AtA[a * 4 + a] += 0.0001;
+				}
+				SolveGE(4, AtA, Atb, x);
+				for (int i = 0; i < D; ++i) { double s = 0; for (int k = 0; k < 4; ++k) s += basis[i][k] * x[k]; tau[i] += tau_g[i] - s; }
+			}
+		}
+		if (IsActiveVFEffector(StanceJ(3))) {   // ApplyStanceFeedback :933-983
+			double hip_tau = -tau[SwingJ(0) + 2];
+			const int sh = StanceJ(0);
+			double root_tau = M.kp[sh] * (curr.params[rmpMax + state * rspMax + rspRootPitch] - WrapPi(q[2])) + M.kd[sh] * (-qd[2]);
+			hip_tau += -root_tau;
+			tau[sh + 2] += hip_tau;
+		}
+		if (M.enable_virtual_forces) {   // :1030-1075
+			const int effs[2] = {rRightToe, rLeftToe};
+			for (int e = 0; e < 2; ++e) {
+				int jid = effs[e];
+				if (!IsActiveVFEffector(jid)) continue;
+				double f[2] = {-curr.params[rmpForceX], -curr.params[rmpForceY]};
+				double pos[2]; EffectorContactPos(jid, pos);
+				for (int c = jid; c != rRoot; c = M.parent[c]) {
+					double t = JtF(c + 2, pos, f);
+					tau[c + 2] += t;
+					if (c == StanceJ(0)) tau[SwingJ(0) + 2] += -t;
+				}
+			}
+		}
+		ClampAndApply(tau);
+	}
 	void ControllerUpdate(double dt)
 	{
+		if (IsRaptor()) { RaptorControllerUpdate(dt); return; }
 		double tau[ORC_MAXD];
 		for (int i = 0; i < D; ++i) tau[i] = 0;
 		curr_cycle_time += dt;
@@ -487,30 +629,10 @@ struct Env {
 				pd_target[joints[k]] = default_theta + com_vel[0] * curr.params[mpCv];
 			}
 		}
-		// UpdatePDCtrls -> cImpPDController::CalcControlForces, sim/ImpPDController.cpp:234-278
-		{
-			double Mm[ORC_MAXD * ORC_MAXD], rhs[ORC_MAXD], acc[ORC_MAXD], kp[ORC_MAXD], kd[ORC_MAXD], perr[ORC_MAXD], verr[ORC_MAXD];
-			for (int i = 0; i < D; ++i) { kp[i] = kd[i] = perr[i] = verr[i] = 0; }
-			for (int j = 1; j < L; ++j) {  // root has no cJoint -> its cPDController is never Init'ed (invalid)
-				kp[j + 2] = M.kp[j]; kd[j + 2] = M.kd[j];
-				perr[j + 2] = pd_target[j] - CalcTheta(j);
-				verr[j + 2] = 0 - qd[j + 2];
-			}
-			for (int i = 0; i < D; ++i) for (int k = 0; k < D; ++k) Mm[i * D + k] = rbd.H[i][k];
-			for (int i = 0; i < D; ++i) Mm[i * D + i] += dt * kd[i];
-			for (int i = 0; i < D; ++i) rhs[i] = kp[i] * (perr[i] - dt * qd[i]) + kd[i] * verr[i] - rbd.C[i];
-			SolveLDLT(D, Mm, D, rhs, acc);
-			for (int i = 0; i < D; ++i) tau[i] += kp[i] * (perr[i] - dt * qd[i]) + kd[i] * (verr[i] - dt * acc[i]);
-		}
+		ImpPD(dt, tau);   // UpdatePDCtrls
 		if (M.enable_grav_comp) ApplyGravityCompensation(tau);
 		if (M.enable_virtual_forces) ApplyVirtualForces(tau);
-		// cSimCharacter::ApplyControlForces + cJoint::ApplyTorque (clamp to TorqueLim), sim/Joint.cpp:171-201,257-264
-		for (int i = 0; i < D; ++i) { tau_ctrl[i] = tau[i]; tau_applied[i] = 0; }
-		for (int j = 1; j < L; ++j) {
-			double t = tau[j + 2], lim = M.torque_lim[j];
-			if (std::fabs(t) > lim) t *= lim / std::fabs(t);
-			tau_applied[j + 2] = t;
-		}
+		ClampAndApply(tau);
 	}
 	void EffectorContactPos(int j, double* out) const  // sim/DogController.cpp:1372-1387
 	{
@@ -585,6 +707,7 @@ struct Env {
 			vel_reward = std::exp(-0.5 * vel_err * vel_err);
 			double avg_stumble = prev_stumble / cycle_time;
 			stumble_reward = 1.0 / (1 + 10 * avg_stumble);
+			if (IsRaptor() && avg_vel < 0) { vel_reward = 0; stumble_reward = 0; }   // sim/RaptorController.cpp:584-588
 		}
 		return 0.8 * vel_reward + 0.2 * stumble_reward;
 	}

@@ -32,6 +32,8 @@ struct OrcModel {
 	int32_t use_world[ORC_MAXL];
 	int32_t n_sets, n_params;
 	double ctrl_params[ORC_MAXSETS][ORC_MAXP];
+	int32_t opt_mask[ORC_MAXP];            // gParamInfo / gOptParamsMasks: 1 = optimisable (part of the action fragment)
+	double exp_noise;                      // mExpNoise: dog 0.2 (sim/DogControllerMACE.cpp:7), raptor 0.15 (sim/RaptorControllerMACE.cpp:7)
 	int32_t n_actions;
 	int32_t act_idx0[ORC_MAXACT], act_idx1[ORC_MAXACT];
 	double act_blend[ORC_MAXACT];

@@ -35,6 +35,13 @@ def main():
         e.step(20); q, qd = e.pose_vel(); qs.append(q); qds.append(qd)
     np.savez_compressed(os.path.join(HERE, "sim_dog_trace.npz"), q=np.array(qs), qd=np.array(qds), terrain_seed=5)
 
+    mr, _ = om.build_model("args/sim_raptor_args.txt", ROOT)
+    e = om.OracleEnv(mr, terrain_seed=5)
+    qs, qds = [], []
+    for _ in range(12):
+        e.step(20); q, qd = e.pose_vel(); qs.append(q); qds.append(qd)
+    np.savez_compressed(os.path.join(HERE, "sim_raptor_trace.npz"), q=np.array(qs), qd=np.array(qds), terrain_seed=5)
+
     desc = om.parse_deploy_prototxt(os.path.join(ROOT, "data/policies/dog/nets/dog_mace3_deploy.prototxt"))
     w = om.xavier_weights(desc, 1234)
     io, isc, oo, osc = om.load_scale_file(os.path.join(ROOT, "data/policies/dog/models/dog_mace3_slopes_mixed_model_scale.txt"))

@@ -60,6 +60,27 @@ def test_set_pose_reset(da, om):
     T.test_set_pose_vel_and_reset_roundtrip(da, om)
 
 
+def test_raptor_flat_and_narrow_gaps(da, om):
+    """BASELINE config 2 (raptor, different KinTree topology, D = 21 kernel instantiation)."""
+    T.test_raptor_flat_1200_substeps_vs_oracle(da, om)
+    T.test_raptor_narrow_gaps_with_policy(da, om)
+
+
+def test_raptor_full_size_8192(da, om):
+    """BASELINE config 2 at full size: 8192 raptor envs on narrow_gaps, determinism + finiteness + episode accounting."""
+    pol = T.raptor_policy(om)
+    def run():
+        b = T.batch(da, "args/raptor_narrow_gaps_args.txt", 8192, terrain_seed=5)
+        b.SetPolicy(pol[1], *pol[2:])
+        b.RunFrames(20)
+        return b
+    a = run(); c = run()
+    qa, qda = a.PoseVel(); qc, qdc = c.PoseVel()
+    assert np.isfinite(qa).all() and np.array_equal(qa, qc) and np.array_equal(qda, qdc)
+    st = a.EvalStats()
+    assert st["cycles"] >= 8192 * 2 and st["episodes"] == st["resets"]
+
+
 def test_config1_slopes_mixed_1200_substeps_64_envs(da, om):
     """BASELINE config 1 at reduced width for the oracle side: 64 envs, dog + slopes_mixed + MACE forward, 12 frames = 1200
     substeps, per-frame |dq| < 1e-4 (north-star bound; observed ~1e-10)."""

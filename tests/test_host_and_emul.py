@@ -237,3 +237,78 @@ def test_set_pose_vel_and_reset_roundtrip(da, om):
     qr, qdr = b.PoseVel()
     assert np.allclose(qr[1][2:], np.array(m.pose0[2:23])) and np.array_equal(qr[0], q2[0])
     assert b.EvalStats()["resets"] == 1
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# raptor (BASELINE config 2: different KinTree topology, biped FSM with stance flipping, stance-mirrored policy state)
+
+def raptor_policy(om):
+    desc = om.parse_deploy_prototxt(os.path.join(REFDATA, "data/policies/raptor/nets/raptor_mace3_deploy.prototxt"))
+    w = om.xavier_weights(desc, 4321)
+    io, isc, oo, osc = om.load_scale_file(os.path.join(REFDATA, "data/policies/raptor/models/raptor_mace3_narrow_gaps_model_scale.txt"))
+    return desc, w, io, isc, oo, osc
+
+
+def test_raptor_loader_and_scale_kat(da, om):
+    m, info = om.build_model("args/raptor_narrow_gaps_args.txt", REFDATA)
+    assert (m.L, m.D, info["S"], info["n_opt"]) == (19, 21, 275, 28)
+    assert list(m.parent[:19]) == [-1, 0, 1, 2, 3, 4, 0, 6, 7, 8, 9, 0, 11, 12, 13, 0, 15, 16, 17]
+    assert abs(sum(m.body_mass[:19]) - 32.95) < 1e-9 and m.enable_grav_comp == 0 and m.enable_virtual_forces == 0
+    b = batch(da, "args/raptor_narrow_gaps_args.txt", 1, terrain_seed=3)
+    assert (b.L, b.D, b.S, b.A, b.P, b.nn_out, b.num_frags, b.frag_size) == (19, 21, 275, 29, 37, 87, 3, 28)
+    off, sc = b.BuildNNOutputOffsetScale()
+    o2, s2 = om.build_output_offset_scale(m, 3)
+    _, _, oo, osc = om.load_scale_file(os.path.join(REFDATA, "data/policies/raptor/models/raptor_mace3_narrow_gaps_model_scale.txt"))
+    assert np.array_equal(off, o2) and np.allclose(sc, s2, rtol=1e-15)
+    assert np.abs(off - oo).max() < 5e-7 and np.abs(sc / osc - 1).max() < 2e-4      # shipped normaliser reproduced
+
+
+def test_raptor_flat_1200_substeps_vs_oracle(da, om):
+    m, _ = om.build_model("args/sim_raptor_args.txt", REFDATA)
+    e = om.OracleEnv(m, terrain_seed=5)
+    b = batch(da, "args/sim_raptor_args.txt", 1, terrain_seed=5)
+    for k in range(240):
+        b.StepUpdates(1); e.step(1)
+        q, qd = b.PoseVel(); qo, qdo = e.pose_vel()
+        tc, ta = b.Torques(); tco, tao = e.tau()
+        assert np.abs(q[0] - qo).max() < 1e-10 and np.abs(qd[0] - qdo).max() < 1e-8, k
+        assert np.abs(tc[0][3:] - tco[3:]).max() < 1e-7 and np.abs(ta[0] - tao).max() < 1e-7
+        assert np.array_equal(b.Contacts()[0], e.contacts()) and b.Flags()[0] == e.flags()
+        st, ph, aid, prm, tg = b.Ctrl(); so, pho, aido, prmo, tgo = e.ctrl()
+        assert st[0] == so and np.abs(tg[0] - tgo).max() < 1e-9
+    assert e.stats()["cycles"] >= 2 and q[0][0] > 1.0           # alternating stance steps happened
+
+
+def test_raptor_narrow_gaps_with_policy(da, om):
+    """BASELINE config 2 shape: raptor + narrow_gaps + MACE (275 -> 87 net), resets included, sync-window comparison."""
+    m, _ = om.build_model("args/raptor_narrow_gaps_args.txt", REFDATA)
+    pol = raptor_policy(om)
+    n = 4
+    b = batch(da, "args/raptor_narrow_gaps_args.txt", n, terrain_seed=60)
+    b.SetPolicy(pol[1], *pol[2:])
+    es = [om.OracleEnv(m, terrain_seed=60 + i, rng_seed=0, env_id=i, policy=pol) for i in range(n)]
+    windows, coincide, resets = run_synced_episodes(b, es, 120)
+    assert windows >= n, (windows, coincide, resets)
+    ps = b.RecordPoliState()
+    assert ps.shape == (n, 275)
+
+
+def test_raptor_gravity_comp_and_virtual_forces_paths(da, om, tmp_path):
+    """raptor.txt ships with EnableGravityCompensation/EnableVirtualForces = false; flip both on in a copy of the fixture tree
+    so the weighted contact-basis least squares and the stance/swing-hip virtual-force coupling are exercised in both implementations."""
+    import json
+    import shutil
+    root = tmp_path / "refdata"
+    shutil.copytree(REFDATA, root)
+    cf = root / "data" / "characters" / "raptor.txt"
+    d = json.load(open(cf)); d["Controllers"]["EnableGravityCompensation"] = True; d["Controllers"]["EnableVirtualForces"] = True
+    json.dump(d, open(cf, "w"))
+    m, _ = om.build_model("args/sim_raptor_args.txt", str(root))
+    assert m.enable_grav_comp == 1 and m.enable_virtual_forces == 1
+    e = om.OracleEnv(m, terrain_seed=2)
+    b = da.BatchScenario("args/sim_raptor_args.txt", 1, data_root=str(root), extra_args={"terrain_seed": 2}, _lib_path=EMUL_LIB)
+    for k in range(120):
+        b.StepUpdates(1); e.step(1)
+        q, qd = b.PoseVel(); qo, qdo = e.pose_vel()
+        tc, _ = b.Torques(); tco, _ = e.tau()
+        assert np.abs(q[0] - qo).max() < 1e-9 and np.abs(tc[0] - tco).max() < 1e-6, k

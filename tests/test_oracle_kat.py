@@ -123,6 +123,25 @@ def test_golden_trace_sim_dog(om):
     assert e.stats()["cycles"] >= 1 and q[0] > 1.2 and not (e.flags() & 1)
 
 
+def test_golden_trace_sim_raptor(om):
+    g = np.load(os.path.join(GOLDEN, "sim_raptor_trace.npz"))
+    m, _ = om.build_model("args/sim_raptor_args.txt", REFDATA)
+    e = om.OracleEnv(m, terrain_seed=int(g["terrain_seed"]))
+    for k in range(g["q"].shape[0]):
+        e.step(20)
+        q, qd = e.pose_vel()
+        assert np.abs(q - g["q"][k]).max() < 1e-9 and np.abs(qd - g["qd"][k]).max() < 1e-7
+
+
+def test_raptor_runs_20s_on_flat(om):
+    m, _ = om.build_model("args/sim_raptor_args.txt", REFDATA)
+    e = om.OracleEnv(m, terrain_seed=1)
+    for _ in range(200):
+        e.update()
+    q, _ = e.pose_vel()
+    assert q[0] > 20.0 and not (e.flags() & 1) and e.stats()["cycles"] > 20
+
+
 def test_dog_runs_30s_on_flat(om):
     m, _ = om.build_model("args/sim_dog_args.txt", REFDATA)
     e = om.OracleEnv(m, terrain_seed=1)
