@@ -16,7 +16,7 @@ namespace dtrl {
 
 __global__ void __launch_bounds__(kGroup) dtrl_frame_kernel(const DevModel* __restrict__ gm, RunParams rp, DevBuffers buf, int n_envs, int n_steps, real dt, int frame_end)
 {
-	__shared__ WS ws;
+	__shared__ WSRef ws;
 	if (static_cast<int>(blockIdx.x) >= n_envs) return;
 	const int env = buf.env_list ? buf.env_list[blockIdx.x] : static_cast<int>(blockIdx.x);
 	env_frame<RefPath>(ws, *gm, rp, buf, env, n_steps, dt, frame_end != 0);
@@ -24,9 +24,9 @@ __global__ void __launch_bounds__(kGroup) dtrl_frame_kernel(const DevModel* __re
 
 // register-resident fast path (dtrl_kernel_fast.h), one instantiation per DoF count of the shipped characters
 template <int D>
-__global__ void __launch_bounds__(kGroup) dtrl_frame_kernel_fast(const DevModel* __restrict__ gm, RunParams rp, DevBuffers buf, int n_envs, int n_steps, real dt, int frame_end)
+__global__ void __launch_bounds__(kGroup, 2) dtrl_frame_kernel_fast(const DevModel* __restrict__ gm, RunParams rp, DevBuffers buf, int n_envs, int n_steps, real dt, int frame_end)
 {
-	__shared__ WS ws;
+	__shared__ WSFast ws;
 	if (static_cast<int>(blockIdx.x) >= n_envs) return;
 	const int env = buf.env_list ? buf.env_list[blockIdx.x] : static_cast<int>(blockIdx.x);
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -57,16 +57,17 @@ namespace dtrl {
 
 enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfRows, kProfFsub, kProfDelassus, kProfPgs, kProfFinish, kProfCtrl, kProfAction, kProfFrameIO, kProfTotal, kProfRowsSum, kProfSubsteps, kProfP1, kProfP2, kProfP3, kProfP4, kProfMax };
 
-// hot, read-mostly model fields staged in LDS
+// hot, read-mostly model fields staged in LDS (per-substep readers only; the controller's once-per-env-step gains, torque
+// limits and body angles stay in the HBM/L2-resident DevModel)
 struct HotModel {
 	int32_t L, D, char_type, pad_;
-	int32_t parent[kMaxL], depth[kMaxL], col[kMaxL], use_world[kMaxL];
+	int32_t parent[kMaxL], depth[kMaxL], col[kMaxL];
 	int8_t path[kMaxL][kMaxDepth];
 	uint32_t sub_mask[kMaxL];
 	uint32_t anc_mask[kMaxL];   // bit a set <=> link a is an ancestor of j or j itself
 	real attach[kMaxL][2], lim_lo[kMaxL], lim_hi[kMaxL];
-	real body_attach[kMaxL][2], body_theta[kMaxL], body_half[kMaxL][2];
-	real mass[kMaxL], inertia[kMaxL], kp[kMaxL], kd[kMaxL], torque_lim[kMaxL];
+	real body_attach[kMaxL][2];
+	real mass[kMaxL], inertia[kMaxL];
 };
 
 struct DevBuffers {
@@ -93,20 +94,24 @@ struct DevBuffers {
 	NetDesc net;
 };
 
-// per-env LDS workspace
-struct WS {
+// per-env LDS workspace. WSRef (reference / lane-loop path) keeps the joint-space inertia matrix, the square Delassus matrix
+// and the contact sample points in LDS; the register-resident gfx950 path (WSFast) never materialises H or the sample
+// points and stores the Delassus matrix packed, which is what lets 8 workgroups (2 waves per SIMD) share a CU's 160 KB.
+constexpr int kZStride = kMaxD + 1;   // odd row stride: lane s walking row s of Z is LDS-bank-conflict free
+struct WSBase {
 	HotModel M;
 	EnvState st;
 	// kinematics (positions relative to the root joint origin; world x = st.q[0] + px)
 	real phi[kMaxL], cs[kMaxL], sn[kMaxL], w[kMaxL];
-	real px[kMaxL], py[kMaxL], cx[kMaxL], cy[kMaxL], psi[kMaxL];
+	real px[kMaxL], py[kMaxL], cx[kMaxL], cy[kMaxL];
 	real vpx[kMaxL], vpy[kMaxL], vcx[kMaxL], vcy[kMaxL];
-	// composite (subtree) quantities about the root origin
-	real sm[kMaxL], smx[kMaxL], smy[kMaxL], sI[kMaxL];
 	real fx[kMaxL], fy[kMaxL], fn[kMaxL];
-	real bx[kMaxL], by[kMaxL], ux[kMaxL], uy[kMaxL], gx[kMaxL], gy[kMaxL];   // bone vectors and their velocity / centripetal terms
 	real mcx[kMaxL], mcy[kMaxL], Io[kMaxL];
-	real H[kMaxD][kMaxD + 1];   // after factorisation: diag = d_k, upper H[k][i] = L_ik (i > k)
+	// time-multiplexed: the bone vectors (kin_dyn_terms P2 -> P3) are dead when P4 writes the composite (subtree) sums
+	union {
+		struct { real bx[kMaxL], by[kMaxL], ux[kMaxL], uy[kMaxL], gx[kMaxL], gy[kMaxL]; };   // bone vectors, their velocity / centripetal terms
+		struct { real sm[kMaxL], smx[kMaxL], smy[kMaxL], sI[kMaxL]; };                         // composite quantities about the root origin
+	};
 	real dinv[kMaxD];
 	real b[kMaxD];
 	real u[kMaxD];
@@ -116,19 +121,11 @@ struct WS {
 	real row_x[kMaxRows], row_y[kMaxRows], row_dx[kMaxRows], row_dy[kMaxRows], row_tgt[kMaxRows];
 	real wv[kMaxRows], lam[kMaxRows], rinv[kMaxRows];
 	real dl;
-	// time-multiplexed LDS: the contact sample points are dead once build_rows() has consumed them, which is before the
-	// Delassus matrix is written; the controller scratch is only live outside substep() where Z rows >= 1 are unused.
+	// time-multiplexed: the controller scratch is only live outside substep(), where Z rows >= 1 are unused
 	union {
-		real A[kMaxRows][kMaxRows + 1];
+		real Z[kMaxRows + 1][kZStride];
 		struct {
-			real pt_x[kMaxPts], pt_y[kMaxPts], pt_depth[kMaxPts], pt_nx[kMaxPts], pt_ny[kMaxPts];
-			int32_t pt_active[kMaxPts];
-		};
-	};
-	union {
-		real Z[kMaxRows + 1][kMaxD];
-		struct {
-			real z0_[kMaxD];
+			real z0_[kZStride];
 			real basis[kMaxD][4];
 			real tau_g[kMaxD];
 			real kpv[kMaxD], kdv[kMaxD], kdm[kMaxD], perr[kMaxD], verr[kMaxD];
@@ -139,6 +136,25 @@ struct WS {
 #if defined(DTRL_PROFILE)
 	unsigned long long prof[kProfMax];
 #endif
+};
+struct WSRef : WSBase {
+	real H[kMaxD][kMaxD + 1];   // after factorisation: diag = d_k, upper H[k][i] = L_ik (i > k)
+	// the contact sample points are dead once build_rows() has consumed them, which is before the Delassus matrix is written
+	union {
+		real A[kMaxRows][kMaxRows + 1];
+		struct {
+			real pt_x[kMaxPts], pt_y[kMaxPts], pt_depth[kMaxPts], pt_nx[kMaxPts], pt_ny[kMaxPts];
+			int32_t pt_active[kMaxPts];
+		};
+	};
+};
+constexpr int kPackedA = kMaxRows * (kMaxRows + 1) / 2;
+constexpr int kMassTab = kMaxL * (kMaxDepth + 2);
+struct WSFast : WSBase {
+	// lower triangle of the Delassus matrix, row-major packed (entry (s, r), r <= s, at s (s + 1) / 2 + r: the triangular
+	// numbers are distinct mod 32, so 24 lanes reading column r hit distinct banks); the same storage holds mass_row()'s
+	// table before the rows are built
+	real Apk[kPackedA > kMassTab ? kPackedA : kMassTab];
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -215,7 +231,8 @@ DTRL_HD inline real sample_ground(const GroundRec& g, real x, real* slope, int* 
 // quirk=true reproduces cRBDUtil::BuildCjPlanar as shipped (sim/RBDUtil.cpp:809-836: theta read from q_dot and
 // s = cos(theta)) as an extra base acceleration -- that is the bias the reference's implicit-PD controller sees;
 // quirk=false is the textbook bias used by the integrator.
-DTRL_HD inline void kin_dyn_terms(WS& ws, bool quirk)
+template <class W>
+DTRL_HD inline void kin_dyn_terms(W& ws, bool quirk)
 {
 	PROF_T0();
 	LANES_BEGIN
@@ -232,7 +249,6 @@ DTRL_HD inline void kin_dyn_terms(WS& ws, bool quirk)
 		ws.phi[j] = phi; ws.w[j] = w;
 		real s, c; sincos(phi, &s, &c);
 		ws.cs[j] = c; ws.sn[j] = s;
-		ws.psi[j] = phi + ws.M.body_theta[j];
 	}
 	LANES_END
 	PROF_ADD(ws, kProfP1);
@@ -307,10 +323,12 @@ DTRL_HD inline void kin_dyn_terms(WS& ws, bool quirk)
 	LANES_END
 	PROF_ADD(ws, kProfP4);
 }
-DTRL_HD inline void forward_kinematics(WS& ws) { kin_dyn_terms(ws, false); }
+template <class W>
+DTRL_HD inline void forward_kinematics(W& ws) { kin_dyn_terms(ws, false); }
 
 // joint-space inertia matrix in closed form from the composite quantities (LDS copy, reference path)
-DTRL_HD inline void mass_matrix(WS& ws)
+template <class W>
+DTRL_HD inline void mass_matrix(W& ws)
 {
 	LANES_BEGIN
 	for (int e = lane; e < kMaxD * (kMaxD + 1); e += kGroup) (&ws.H[0][0])[e] = 0;
@@ -338,7 +356,8 @@ DTRL_HD inline void mass_matrix(WS& ws)
 }
 
 // in-place LDL^T of ws.H (right-looking; lane i owns row i). Afterwards: diag = d_k, H[k][i] (i > k) = L_ik, dinv = 1/d.
-DTRL_HD inline void factorize(WS& ws)
+template <class W>
+DTRL_HD inline void factorize(W& ws)
 {
 	const int D = ws.M.D;
 	for (int k = 0; k < D - 1; ++k) {
@@ -357,7 +376,8 @@ DTRL_HD inline void factorize(WS& ws)
 }
 
 // J_r[i] for a point row (link, x, y rel. root, direction d): translation DoFs see d, hinge a on the path sees d . z x (pt - p_a)
-DTRL_HD inline real row_jac(const WS& ws, int r, int i)
+template <class W>
+DTRL_HD inline real row_jac(const W& ws, int r, int i)
 {
 	if (ws.row_kind[r] == 0) return (i == ws.row_link[r] + 2) ? ws.row_dx[r] : 0.0;
 	if (i == 0) return ws.row_dx[r];
@@ -368,27 +388,36 @@ DTRL_HD inline real row_jac(const WS& ws, int r, int i)
 }
 
 // world position of contact sample point pt (relative to the root origin) + ground test; shared by both kernel paths
-DTRL_HD inline int sample_contact_point(WS& ws, const DevModel& gm, const GroundRec& g, int pt)
+template <class W>
+DTRL_HD inline int contact_point_eval(const W& ws, const DevModel& gm, const GroundRec& g, int pt, real* ox, real* oy, real* odepth, real* onx, real* ony)
 {
 	const int j = pt / kPtsPerLink, k = pt - j * kPtsPerLink;
-	int active = 0;
-	if (ws.M.col[j] != 0) {
-		const real lx = gm.pt_joint[j][k][0], ly = gm.pt_joint[j][k][1];
-		const real c = ws.cs[j], s = ws.sn[j];
-		const real x = ws.px[j] + c * lx - s * ly;
-		const real y = ws.py[j] + s * lx + c * ly;
-		real slope;
-		const real h = sample_ground(g, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
-		const real inv = 1.0 / sqrt(1.0 + slope * slope);
-		const real nx = -slope * inv, ny = inv;
-		const real depth = (h - (ws.st.q[1] + y)) * ny;
-		if (depth > 0) { active = 1; ws.pt_x[pt] = x; ws.pt_y[pt] = y; ws.pt_depth[pt] = depth; ws.pt_nx[pt] = nx; ws.pt_ny[pt] = ny; }
-	}
+	*ox = 0; *oy = 0; *odepth = 0; *onx = 0; *ony = 0;
+	if (ws.M.col[j] == 0) return 0;
+	const real lx = gm.pt_joint[j][k][0], ly = gm.pt_joint[j][k][1];
+	const real c = ws.cs[j], s = ws.sn[j];
+	const real x = ws.px[j] + c * lx - s * ly;
+	const real y = ws.py[j] + s * lx + c * ly;
+	real slope;
+	const real h = sample_ground(g, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
+	const real inv = 1.0 / sqrt(1.0 + slope * slope);
+	const real nx = -slope * inv, ny = inv;
+	const real depth = (h - (ws.st.q[1] + y)) * ny;
+	*ox = x; *oy = y; *odepth = depth; *onx = nx; *ony = ny;
+	return depth > 0 ? 1 : 0;
+}
+template <class W>
+DTRL_HD inline int sample_contact_point(W& ws, const DevModel& gm, const GroundRec& g, int pt)
+{
+	real x, y, depth, nx, ny;
+	const int active = contact_point_eval(ws, gm, g, pt, &x, &y, &depth, &nx, &ny);
+	if (active) { ws.pt_x[pt] = x; ws.pt_y[pt] = y; ws.pt_depth[pt] = depth; ws.pt_nx[pt] = nx; ws.pt_ny[pt] = ny; }
 	ws.pt_active[pt] = active;
 	return active;
 }
 // contact sample points of every colliding link against the env's heightfield (2 points per lane)
-DTRL_HD inline void detect_contacts(WS& ws, const DevModel& gm, const GroundRec& g)
+template <class W>
+DTRL_HD inline void detect_contacts(W& ws, const DevModel& gm, const GroundRec& g)
 {
 	LANES_BEGIN
 	for (int pt = lane; pt < ws.M.L * kPtsPerLink; pt += kGroup) sample_contact_point(ws, gm, g, pt);
@@ -403,7 +432,8 @@ DTRL_HD inline void detect_contacts(WS& ws, const DevModel& gm, const GroundRec&
 }
 
 // build the ordered row list: violated joint limits first (by joint id), then normal+tangent per active contact point
-DTRL_HD inline void build_rows(WS& ws, real h)
+template <class W>
+DTRL_HD inline void build_rows(W& ws, real h)
 {
 	LANES_BEGIN
 	if (lane == 0) {
@@ -430,7 +460,8 @@ DTRL_HD inline void build_rows(WS& ws, real h)
 }
 
 // Z_r = L^-1 J_r^T for every row (lane r) and z_0 = L^-1 rhs (lane R), forward substitution per lane
-DTRL_HD inline void forward_subst_rows(WS& ws, const real* rhs)
+template <class W>
+DTRL_HD inline void forward_subst_rows(W& ws, const real* rhs)
 {
 	const int D = ws.M.D, R = ws.R;
 	LANES_BEGIN
@@ -447,7 +478,8 @@ DTRL_HD inline void forward_subst_rows(WS& ws, const real* rhs)
 }
 
 // Delassus matrix A = Z D^-1 Z^T (lane s owns row s), initial w = J v_free - target
-DTRL_HD inline void build_delassus(WS& ws, real h)
+template <class W>
+DTRL_HD inline void build_delassus(W& ws, real h)
 {
 	const int D = ws.M.D, R = ws.R;
 	LANES_BEGIN
@@ -482,7 +514,8 @@ DTRL_HD inline void build_delassus(WS& ws, real h)
 
 // projected Gauss-Seidel in lambda space, fixed row order, kPgsIters sweeps, no warm start.
 // LDS form (reference for the register/readlane form used by the tuned kernel).
-DTRL_HD inline void pgs_solve(WS& ws)
+template <class W>
+DTRL_HD inline void pgs_solve(W& ws)
 {
 	const int R = ws.R;
 	for (int it = 0; it < kPgsIters; ++it) {
@@ -508,7 +541,8 @@ DTRL_HD inline void pgs_solve(WS& ws)
 }
 
 // v+ = qd + L^-T D^-1 (h z_0 + sum_r Z_r lambda_r); q+ = q + h v+
-DTRL_HD inline void finish_substep(WS& ws, real h)
+template <class W>
+DTRL_HD inline void finish_substep(W& ws, real h)
 {
 	const int D = ws.M.D, R = ws.R;
 	LANES_BEGIN
@@ -530,7 +564,8 @@ DTRL_HD inline void finish_substep(WS& ws, real h)
 }
 
 // one physics substep (stand-in for one Bullet internal step of sim/World.cpp:101-102)
-DTRL_HD inline void substep_ref(WS& ws, const DevModel& gm, const GroundRec& g, real h)
+template <class W>
+DTRL_HD inline void substep_ref(W& ws, const DevModel& gm, const GroundRec& g, real h)
 {
 	{ PROF_T0(); kin_dyn_terms(ws, false); PROF_ADD(ws, kProfFK); }
 	{ PROF_T0(); mass_matrix(ws); PROF_ADD(ws, kProfMass); }
@@ -561,9 +596,11 @@ enum { spSpineCurve, spShoulder, spElbow, spHip, spKnee, spAnkle, spMax };
 enum { mpTransTime, mpCv, mpBackForceX, mpBackForceY, mpFrontForceX, mpFrontForceY, mpMax };
 enum { stBackStance, stExtend, stFrontStance, stGather, stMax, stInvalid };
 
-DTRL_HD inline bool in_contact(const WS& ws, int j) { return (ws.st.contact_bits >> j) & 1u; }
+template <class W>
+DTRL_HD inline bool in_contact(const W& ws, int j) { return (ws.st.contact_bits >> j) & 1u; }
 
-DTRL_HD inline void calc_com(const WS& ws, real* out)
+template <class W>
+DTRL_HD inline void calc_com(const W& ws, real* out)
 {
 	real sx = 0, sy = 0, m = 0;
 	for (int j = 0; j < ws.M.L; ++j) { sx += ws.M.mass[j] * (ws.st.q[0] + ws.cx[j]); sy += ws.M.mass[j] * (ws.st.q[1] + ws.cy[j]); m += ws.M.mass[j]; }
@@ -575,10 +612,13 @@ enum { rRoot, rSpine0, rSpine1, rSpine2, rSpine3, rHead, rTail0, rTail1, rTail2,
 enum { rspRootPitch, rspSpineCurve, rspStanceHip, rspStanceKnee, rspStanceAnkle, rspSwingHip, rspSwingKnee, rspSwingAnkle, rspMax };
 enum { rmpTransTime, rmpCv, rmpCd, rmpForceX, rmpForceY, rmpMax };
 enum { rstContact, rstDown, rstPassing, rstUp, rstMax, rstInvalid };
-DTRL_HD inline int stance_joint(const WS& ws, int k) { return (ws.st.stance == 0 ? rRightHip : rLeftHip) + k; }   // k: 0 hip .. 3 toe
-DTRL_HD inline int swing_joint(const WS& ws, int k) { return (ws.st.stance == 0 ? rLeftHip : rRightHip) + k; }
+template <class W>
+DTRL_HD inline int stance_joint(const W& ws, int k) { return (ws.st.stance == 0 ? rRightHip : rLeftHip) + k; }   // k: 0 hip .. 3 toe
+template <class W>
+DTRL_HD inline int swing_joint(const W& ws, int k) { return (ws.st.stance == 0 ? rLeftHip : rRightHip) + k; }
 
-DTRL_HD inline void set_state_params(WS& ws)  // sim/DogController.cpp:1042-1054, sim/RaptorController.cpp:1108-1126
+template <class W>
+DTRL_HD inline void set_state_params(W& ws)  // sim/DogController.cpp:1042-1054, sim/RaptorController.cpp:1108-1126
 {
 	if (ws.M.char_type == 1) {
 		const real* sp = ws.st.params + rmpMax + ws.st.state * rspMax;
@@ -593,9 +633,11 @@ DTRL_HD inline void set_state_params(WS& ws)  // sim/DogController.cpp:1042-1054
 	ws.st.pd_target[jShoulder] = sp[spShoulder]; ws.st.pd_target[jElbow] = sp[spElbow];
 	ws.st.pd_target[jHip] = sp[spHip]; ws.st.pd_target[jKnee] = sp[spKnee]; ws.st.pd_target[jAnkle] = sp[spAnkle];
 }
-DTRL_HD inline void transition_state(WS& ws, int s) { ws.st.state = s; ws.st.phase = 0; set_state_params(ws); }
+template <class W>
+DTRL_HD inline void transition_state(W& ws, int s) { ws.st.state = s; ws.st.phase = 0; set_state_params(ws); }
 // cRaptorController::SetStance, sim/RaptorController.cpp:1439-1446
-DTRL_HD inline void set_stance(WS& ws, int st)
+template <class W>
+DTRL_HD inline void set_stance(W& ws, int st)
 {
 	ws.st.stance = st;
 	ws.st.pd_active_bits &= ~(1u << stance_joint(ws, 0));
@@ -603,27 +645,32 @@ DTRL_HD inline void set_stance(WS& ws, int st)
 	set_state_params(ws);
 }
 // cRaptorController::IsActiveVFEffector, :1157-1163
-DTRL_HD inline bool raptor_active_effector(const WS& ws, int j)
+template <class W>
+DTRL_HD inline bool raptor_active_effector(const W& ws, int j)
 {
 	return j == stance_joint(ws, 3) && (ws.st.state == rstContact || ws.st.state == rstDown) && ((ws.st.contact_bits >> j) & 1u);
 }
-DTRL_HD inline bool has_stumbled(const WS& ws)  // sim/SimDog.cpp:83-105, sim/SimRaptor.cpp:78-101
+template <class W>
+DTRL_HD inline bool has_stumbled(const W& ws)  // sim/SimDog.cpp:83-105, sim/SimRaptor.cpp:78-101
 {
 	uint32_t mask = (ws.M.char_type == 1) ? ~((1u << rRightToe) | (1u << rLeftToe) | (1u << rRightAnkle) | (1u << rLeftAnkle))
 										   : ~((1u << jToe) | (1u << jFinger) | (1u << jAnkle) | (1u << jWrist));
 	return (ws.st.contact_bits & mask & ((1u << ws.M.L) - 1u)) != 0;
 }
-DTRL_HD inline bool check_fall_contact(const WS& ws)  // sim/SimDog.cpp:112-141 (root..head), sim/SimRaptor.cpp:108-137 (root..head)
+template <class W>
+DTRL_HD inline bool check_fall_contact(const W& ws)  // sim/SimDog.cpp:112-141 (root..head), sim/SimRaptor.cpp:108-137 (root..head)
 {
-	const int last = (ws.M.char_type == 1) ? rHead : jHead;
+	const int last = (ws.M.char_type == 1) ? int(rHead) : int(jHead);
 	return (ws.st.contact_bits & ((1u << (last + 1)) - 1u)) != 0;
 }
-DTRL_HD inline bool has_fallen(const WS& ws)  // sim/SimCharSoftFall.cpp:53-61, sim/SimDog.cpp:143-161
+template <class W>
+DTRL_HD inline bool has_fallen(const W& ws)  // sim/SimCharSoftFall.cpp:53-61, sim/SimDog.cpp:143-161
 {
 	bool flipped = fabs(wrap_pi(ws.st.q[2])) > 3.14159265358979323846 * 0.8;
 	return ws.st.sum_fall_contact > 0.25 || ws.st.fail_fall_dist != 0 || flipped;
 }
-DTRL_HD inline bool is_new_cycle(const WS& ws) { return ws.st.state == 0 && ws.st.phase == 0; }  // sim/CharController.cpp:72-75
+template <class W>
+DTRL_HD inline bool is_new_cycle(const W& ws) { return ws.st.state == 0 && ws.st.phase == 0; }  // sim/CharController.cpp:72-75
 
 DTRL_HD inline void blend_ctrl_params(const DevModel& gm, int a, real* out)  // sim/DogController.cpp:1335-1341
 {
@@ -661,7 +708,8 @@ DTRL_HD inline void build_base_action(const DevModel& gm, int num_frags, int a_i
 	if (gm.ctrl_type == 1) *out_id = assign_frag_id(gm, num_frags, a_id, rng);
 }
 // cTerrainRLCharController::ApplyAction + cDogController::NewCycleUpdate + TransitionState(BackStance); lane-0 code
-DTRL_HD inline void apply_action(WS& ws, int id, const real* params, int P)
+template <class W>
+DTRL_HD inline void apply_action(W& ws, int id, const real* params, int P)
 {
 	ws.st.action_id = id;
 	for (int i = 0; i < P; ++i) ws.st.params[i] = params[i];
@@ -720,7 +768,8 @@ DTRL_HD inline void fc_layer(const float* Wt, const float* b, int nout, int nin,
 		LANES_END
 	}
 }
-DTRL_HD inline void nn_eval(WS& ws, const DevBuffers& buf, int env)
+template <class W>
+DTRL_HD inline void nn_eval(W& ws, const DevBuffers& buf, int env)
 {
 	(void)ws;
 	const NetDesc& d = buf.net;
@@ -739,8 +788,8 @@ DTRL_HD inline void nn_eval(WS& ws, const DevBuffers& buf, int env)
 	int cin = 1, wdt = d.n_terrain;
 	for (int l = 0; l < 3; ++l) {
 		const int co = d.conv_ch[l], k = d.conv_k[l], wo = wdt - k + 1;
-		const float* W = p; const float* bias = p + static_cast<int64_t>(co) * cin * k;
-		conv_layer(W, bias, co, cin, k, wdt, a, bo);
+		const float* Wc = p; const float* bias = p + static_cast<int64_t>(co) * cin * k;
+		conv_layer(Wc, bias, co, cin, k, wdt, a, bo);
 		p = bias + co; real* t2 = a; a = bo; bo = t2; cin = co; wdt = wo;
 	}
 	const int nflat = cin * wdt;
@@ -769,7 +818,8 @@ DTRL_HD inline void nn_eval(WS& ws, const DevBuffers& buf, int env)
 }
 
 // cDogController(MACE)::UpdateAction: ParseGround + BuildPoliState + action decision + ApplyAction
-DTRL_HD inline void update_action(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env)
+template <class W>
+DTRL_HD inline void update_action(W& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env)
 {
 	real* ps = buf.poli_state + static_cast<int64_t>(env) * buf.S;
 	const int L = ws.M.L;
@@ -866,14 +916,16 @@ DTRL_HD inline void update_action(WS& ws, const DevModel& gm, const RunParams& r
 }
 
 // effector contact position (body-local (0, -size_y/2)), relative to the root origin; sim/DogController.cpp:1372-1387
-DTRL_HD inline void effector_pos(const WS& ws, const DevModel& gm, int j, real* out)
+template <class W>
+DTRL_HD inline void effector_pos(const W& ws, const DevModel& gm, int j, real* out)
 {
 	const real lx = gm.eff_joint[j][0], ly = gm.eff_joint[j][1];
 	out[0] = ws.px[j] + ws.cs[j] * lx - ws.sn[j] * ly;
 	out[1] = ws.py[j] + ws.sn[j] * lx + ws.cs[j] * ly;
 }
 // J_d^T applied to a world force f acting at pos (relative to root): translation DoFs see f, hinge a sees (pos - p_a) x f
-DTRL_HD inline real jt_force(const WS& ws, int d, const real* pos, const real* f)
+template <class W>
+DTRL_HD inline real jt_force(const W& ws, int d, const real* pos, const real* f)
 {
 	if (d == 0) return f[0];
 	if (d == 1) return f[1];
@@ -882,7 +934,8 @@ DTRL_HD inline real jt_force(const WS& ws, int d, const real* pos, const real* f
 }
 
 // reference (LDS-phase) implicit-PD solve: ws.u holds the right-hand side on entry and the acceleration on exit
-DTRL_HD inline void pd_solve_ref(WS& ws, real dt)
+template <class W>
+DTRL_HD inline void pd_solve_ref(W& ws, real dt)
 {
 	const int D = ws.M.D;
 	mass_matrix(ws);
@@ -902,9 +955,9 @@ DTRL_HD inline void pd_solve_ref(WS& ws, real dt)
 	}
 }
 struct RefPath {
-	static DTRL_HD void substep(WS& ws, const DevModel& gm, const GroundRec& g, real h) { substep_ref(ws, gm, g, h); }
-	static DTRL_HD void pd_solve(WS& ws, real dt) { pd_solve_ref(ws, dt); }
-	static DTRL_HD void contacts(WS& ws, const DevModel& gm, const GroundRec& g) { detect_contacts(ws, gm, g); }
+	template <class W> static DTRL_HD void substep(W& ws, const DevModel& gm, const GroundRec& g, real h) { substep_ref(ws, gm, g, h); }
+	template <class W> static DTRL_HD void pd_solve(W& ws, real dt) { pd_solve_ref(ws, dt); }
+	template <class W> static DTRL_HD void contacts(W& ws, const DevModel& gm, const GroundRec& g) { detect_contacts(ws, gm, g); }
 };
 
 // 4x4 ridge solve of the contact-basis least squares (partial-pivot elimination), shared by both characters
@@ -925,8 +978,8 @@ DTRL_HD inline void solve_ls4(const real (*basis)[4], const real* tau_g, const r
 }
 
 // cDogController::Update (sim/DogController.cpp:229-268) / cRaptorController::Update (sim/RaptorController.cpp:195-233)
-template <class Path>
-DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, real dt)
+template <class Path, class W>
+DTRL_HD inline void controller_update(W& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, real dt)
 {
 	const int D = ws.M.D, L = ws.M.L;
 	const bool raptor = gm.char_type == 1;
@@ -1006,9 +1059,9 @@ DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParam
 		real kp = 0, kd = 0, kdm = 0, pe = 0, ve = 0;
 		if (i >= 3) {
 			const int j = i - 2;
-			kdm = ws.M.kd[j];
-			if ((ws.st.pd_active_bits >> j) & 1u) { kp = ws.M.kp[j]; kd = kdm; }
-			real theta = ws.M.use_world[j] ? wrap_pi(ws.psi[j]) : wrap_pi(ws.st.q[i]);
+			kdm = gm.kd[j];
+			if ((ws.st.pd_active_bits >> j) & 1u) { kp = gm.kp[j]; kd = kdm; }
+			real theta = gm.use_world[j] ? wrap_pi(ws.phi[j] + gm.body_theta[j]) : wrap_pi(ws.st.q[i]);
 			pe = ws.st.pd_target[j] - theta;
 			ve = 0 - ws.st.qd[i];
 		}
@@ -1021,7 +1074,7 @@ DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParam
 	if (lane < D) { const int i = lane; ws.tau_g[i] = 0; ws.st.tau_ctrl[i] = ws.kpv[i] * (ws.perr[i] - dt * ws.st.qd[i]) + ws.kdv[i] * (ws.verr[i] - dt * ws.u[i]); }
 	LANES_END
 	// gravity compensation: dog :947-995 (+ BuildContactBasis :1120-1175), raptor :985-1028 (+ :1170-1240)
-	const int eff0 = raptor ? rRightToe : jToe, eff1 = raptor ? rLeftToe : jFinger;
+	const int eff0 = raptor ? int(rRightToe) : int(jToe), eff1 = raptor ? int(rLeftToe) : int(jFinger);
 	const bool sup0 = raptor ? raptor_active_effector(ws, eff0) : in_contact(ws, eff0);
 	const bool sup1 = raptor ? raptor_active_effector(ws, eff1) : in_contact(ws, eff1);
 	if (gm.enable_grav_comp && (sup0 || sup1)) {
@@ -1072,7 +1125,7 @@ DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParam
 			const int sh = stance_joint(ws, 0), wh = swing_joint(ws, 0);
 			real hip_tau = -ws.st.tau_ctrl[wh + 2];
 			real target_pitch = ws.st.params[rmpMax + ws.st.state * rspMax + rspRootPitch];
-			real root_tau = ws.M.kp[sh] * (target_pitch - wrap_pi(ws.st.q[2])) + ws.M.kd[sh] * (-ws.st.qd[2]);
+			real root_tau = gm.kp[sh] * (target_pitch - wrap_pi(ws.st.q[2])) + gm.kd[sh] * (-ws.st.qd[2]);
 			hip_tau += -root_tau;
 			ws.st.tau_ctrl[sh + 2] += hip_tau;
 		}
@@ -1117,14 +1170,15 @@ DTRL_HD inline void controller_update(WS& ws, const DevModel& gm, const RunParam
 	if (lane < D) {
 		const int d = lane;
 		real t = 0;
-		if (d >= 3) { t = ws.st.tau_ctrl[d]; real lim = ws.M.torque_lim[d - 2]; if (fabs(t) > lim) t *= lim / fabs(t); }
+		if (d >= 3) { t = ws.st.tau_ctrl[d]; real lim = gm.torque_lim[d - 2]; if (fabs(t) > lim) t *= lim / fabs(t); }
 		ws.st.tau[d] = t;
 	}
 	LANES_END
 }
 
 // dog reward, sim/DogController.cpp:594-628
-DTRL_HD inline real calc_reward(const WS& ws, const DevModel& gm)
+template <class W>
+DTRL_HD inline real calc_reward(const W& ws, const DevModel& gm)
 {
 	real vel_reward = 0, stumble_reward = 0;
 	if (!has_fallen(ws)) {
@@ -1140,7 +1194,8 @@ DTRL_HD inline real calc_reward(const WS& ws, const DevModel& gm)
 }
 
 // cScenarioExp::NewCycleUpdate (+ cScenarioExpMACE flags): finish the running tuple, start the next one
-DTRL_HD inline void scenario_new_cycle(WS& ws, const DevModel& gm, const DevBuffers& buf, int env)
+template <class W>
+DTRL_HD inline void scenario_new_cycle(W& ws, const DevModel& gm, const DevBuffers& buf, int env)
 {
 	LANES_BEGIN
 	if (lane == 0) { ws.st.num_cycles += 1; ws.flag_new_cycle = -1; }
@@ -1192,8 +1247,8 @@ DTRL_HD inline void scenario_new_cycle(WS& ws, const DevModel& gm, const DevBuff
 }
 
 // one iteration of scenarios/ScenarioSimChar.cpp:162-173
-template <class Path>
-DTRL_HD inline void env_step(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, real dt)
+template <class Path, class W>
+DTRL_HD inline void env_step(W& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, real dt)
 {
 	const real h = dt / gm.num_sim_substeps;
 	for (int s = 0; s < gm.num_sim_substeps; ++s) Path::substep(ws, gm, g, h);   // UpdateWorld
@@ -1225,7 +1280,8 @@ DTRL_HD inline void env_step(WS& ws, const DevModel& gm, const RunParams& rp, co
 }
 
 // cSimCharacter::Reset + controller Reset; init=true additionally follows cScenarioSimChar::Init ordering
-DTRL_HD inline void reset_env(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, bool init)
+template <class W>
+DTRL_HD inline void reset_env(W& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, bool init)
 {
 	LANES_BEGIN
 	if (lane < gm.D) { ws.st.q[lane] = gm.pose0[lane]; ws.st.qd[lane] = gm.vel0[lane]; ws.st.tau[lane] = 0; ws.st.tau_ctrl[lane] = 0; }
@@ -1266,7 +1322,8 @@ DTRL_HD inline void reset_env(WS& ws, const DevModel& gm, const RunParams& rp, c
 }
 
 // end-of-frame scenario logic: cScenarioExp::Update / cScenarioPoliEval::Update tail (fall -> NewCycleUpdate, request reset)
-DTRL_HD inline void frame_end(WS& ws, const DevModel& gm, const DevBuffers& buf, int env)
+template <class W>
+DTRL_HD inline void frame_end(W& ws, const DevModel& gm, const DevBuffers& buf, int env)
 {
 	LANES_BEGIN
 	if (lane == 0) {
@@ -1289,27 +1346,27 @@ DTRL_HD inline void frame_end(WS& ws, const DevModel& gm, const DevBuffers& buf,
 	LANES_END
 }
 
-DTRL_HD inline void load_hot_model(WS& ws, const DevModel& gm)
+template <class W>
+DTRL_HD inline void load_hot_model(W& ws, const DevModel& gm)
 {
 	LANES_BEGIN
 	if (lane == 0) { ws.M.L = gm.L; ws.M.D = gm.D; ws.M.char_type = gm.char_type; }
 	if (lane < gm.L) {
 		const int j = lane;
-		ws.M.parent[j] = gm.parent[j]; ws.M.depth[j] = gm.depth[j]; ws.M.col[j] = gm.col[j]; ws.M.use_world[j] = gm.use_world[j];
+		ws.M.parent[j] = gm.parent[j]; ws.M.depth[j] = gm.depth[j]; ws.M.col[j] = gm.col[j];
 		for (int k = 0; k < kMaxDepth; ++k) ws.M.path[j][k] = gm.path[j][k];
 		ws.M.sub_mask[j] = gm.sub_mask[j]; ws.M.anc_mask[j] = gm.anc_mask[j];
 		ws.M.attach[j][0] = gm.attach[j][0]; ws.M.attach[j][1] = gm.attach[j][1];
 		ws.M.lim_lo[j] = gm.lim_lo[j]; ws.M.lim_hi[j] = gm.lim_hi[j];
 		ws.M.body_attach[j][0] = gm.body_attach[j][0]; ws.M.body_attach[j][1] = gm.body_attach[j][1];
-		ws.M.body_theta[j] = gm.body_theta[j]; ws.M.body_half[j][0] = gm.body_half[j][0]; ws.M.body_half[j][1] = gm.body_half[j][1];
-		ws.M.mass[j] = gm.mass[j]; ws.M.inertia[j] = gm.inertia[j]; ws.M.kp[j] = gm.kp[j]; ws.M.kd[j] = gm.kd[j]; ws.M.torque_lim[j] = gm.torque_lim[j];
+		ws.M.mass[j] = gm.mass[j]; ws.M.inertia[j] = gm.inertia[j];
 	}
 	LANES_END
 }
 
 // the whole per-env frame: load -> (reset) -> n_steps env-steps -> frame-end logic -> store
-template <class Path>
-DTRL_HD inline void env_frame(WS& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, int env, int n_steps, real dt, bool do_frame_end)
+template <class Path, class W>
+DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, int env, int n_steps, real dt, bool do_frame_end)
 {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DTRL_PROFILE)
 	const unsigned long long prof_frame_t0 = __builtin_readcyclecounter();

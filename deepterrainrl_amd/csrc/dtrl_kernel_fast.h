@@ -25,16 +25,16 @@ __device__ __forceinline__ real bcast(real v, int src)   // src must be wave-uni
 }
 
 // row `lane` of the joint-space inertia matrix from the composite quantities in LDS (same formulas and operand order as
-// mass_matrix()). Each hinge lane evaluates the closed form once per ancestor and parks the values in LDS (the storage of
-// the unused LDS copy of H); every lane then assembles its row with one LDS read per column: the entry (d, c) lives in
+// mass_matrix()). Each hinge lane evaluates the closed form once per ancestor and parks the values in LDS (in the storage of
+// the Delassus matrix, which is dead at that point); every lane then assembles its row with one LDS read per column: the entry (d, c) lives in
 // the table row of the DEEPER link at the path position of the shallower one.
 template <int D>
-__device__ __forceinline__ void mass_row(WS& ws, real (&h)[D])
+__device__ __forceinline__ void mass_row(WSFast& ws, real (&h)[D])
 {
 	const int d = static_cast<int>(threadIdx.x);
 	const int l = d >= 2 ? d - 2 : 0;
 	const bool valid = d < D;
-	real (*T)[kMaxDepth + 2] = reinterpret_cast<real (*)[kMaxDepth + 2]>(&ws.H[0][0]);   // T[link][0..depth] + hx, hy at [kMaxDepth], [kMaxDepth+1]
+	real (*T)[kMaxDepth + 2] = reinterpret_cast<real (*)[kMaxDepth + 2]>(&ws.Apk[0]);   // T[link][0..depth] + hx, hy at [kMaxDepth], [kMaxDepth+1]; the Delassus storage is dead here
 	if (valid && d >= 2) {
 		const real m = ws.sm[l], mx = ws.smx[l], my = ws.smy[l], I = ws.sI[l];
 		const real plx = ws.px[l], ply = ws.py[l];
@@ -121,35 +121,50 @@ __device__ __forceinline__ real bsub_regs(const real (&h)[D], real u)
 	return u;
 }
 
-// contact flags + ordered constraint-row list with wave ballots (same order as detect_contacts()/build_rows())
-__device__ __forceinline__ void contact_bits_fast(WS& ws)
+// contact sample points in registers: lane owns points lane, lane + 64, lane + 128; wave ballots give the per-link contact
+// flags and the ordered constraint-row list (same order as detect_contacts()/build_rows()) without touching LDS.
+constexpr int kPtHalves = (kMaxPts + kGroup - 1) / kGroup;
+struct ContactPts {
+	real x[kPtHalves], y[kPtHalves], depth[kPtHalves], nx[kPtHalves], ny[kPtHalves];
+	int act[kPtHalves];
+	unsigned long long m[kPtHalves];
+};
+__device__ __forceinline__ void eval_points(const WSFast& ws, const DevModel& gm, const GroundRec& g, ContactPts& c)
 {
 	const int lane = static_cast<int>(threadIdx.x);
 	const int npts = ws.M.L * kPtsPerLink;
-	const int a0 = (lane < npts) ? ws.pt_active[lane] : 0;
-	const int a1 = (lane + kGroup < npts) ? ws.pt_active[lane + kGroup] : 0;
-	const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
+#pragma unroll
+	for (int hf = 0; hf < kPtHalves; ++hf) {
+		const int pt = lane + hf * kGroup;
+		c.act[hf] = 0; c.x[hf] = 0; c.y[hf] = 0; c.depth[hf] = 0; c.nx[hf] = 0; c.ny[hf] = 0;
+		if (pt < npts) c.act[hf] = contact_point_eval(ws, gm, g, pt, &c.x[hf], &c.y[hf], &c.depth[hf], &c.nx[hf], &c.ny[hf]);
+		c.m[hf] = __ballot(c.act[hf]);
+	}
+}
+__device__ __forceinline__ void contact_bits_fast(WSFast& ws, const ContactPts& c)
+{
+	static_assert(kPtHalves == 3, "bit-string extraction below is written for 3 ballot words");
+	const int lane = static_cast<int>(threadIdx.x);
 	int any = 0;
 	if (lane < ws.M.L) {
-		const int b = lane * kPtsPerLink;
-		unsigned long long bits = (b < 64) ? (m0 >> b) : 0ull;
-		if (b < 64 && b + kPtsPerLink > 64) bits |= m1 << (64 - b);
-		if (b >= 64) bits = m1 >> (b - 64);
+		const int b = lane * kPtsPerLink, word = b >> 6, off = b & 63;
+		const unsigned long long lo = word == 0 ? c.m[0] : (word == 1 ? c.m[1] : c.m[2]);
+		const unsigned long long hi = word == 0 ? c.m[1] : (word == 1 ? c.m[2] : 0ull);
+		unsigned long long bits = lo >> off;
+		if (off + kPtsPerLink > 64) bits |= hi << (64 - off);
 		any = (bits & ((1ull << kPtsPerLink) - 1ull)) != 0;
 	}
 	const unsigned long long lm = __ballot(any);
 	if (lane == 0) ws.st.contact_bits = static_cast<uint32_t>(lm);
 }
-__device__ __forceinline__ void detect_contacts_fast(WS& ws, const DevModel& gm, const GroundRec& g)
+__device__ __forceinline__ void detect_contacts_fast(WSFast& ws, const DevModel& gm, const GroundRec& g)
 {
-	// first phase of detect_contacts() (sample points), then ballots instead of the serial flag scan
-	const int lane = static_cast<int>(threadIdx.x);
-	for (int pt = lane; pt < ws.M.L * kPtsPerLink; pt += kGroup) sample_contact_point(ws, gm, g, pt);
-	__syncthreads();
-	contact_bits_fast(ws);
+	ContactPts c;
+	eval_points(ws, gm, g, c);
+	contact_bits_fast(ws, c);
 	__syncthreads();
 }
-__device__ __forceinline__ void build_rows_fast(WS& ws, real h)
+__device__ __forceinline__ void build_rows_fast(WSFast& ws, const ContactPts& c, real h)
 {
 	const int lane = static_cast<int>(threadIdx.x);
 	const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -166,46 +181,88 @@ __device__ __forceinline__ void build_rows_fast(WS& ws, real h)
 	if (lim != 0 && rl < kMaxRows) { ws.row_kind[rl] = 0; ws.row_link[rl] = lane; ws.row_dx[rl] = lim; ws.row_tgt[rl] = tgt; }
 	// contacts, ordered by sample-point index
 	const int cap = (kMaxRows - R0) / 2;
-	const int npts = ws.M.L * kPtsPerLink;
-	const int a0 = (lane < npts) ? ws.pt_active[lane] : 0;
-	const int a1 = (lane + kGroup < npts) ? ws.pt_active[lane + kGroup] : 0;
-	const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
-	const int n0 = __popcll(m0), n1 = __popcll(m1);
+	int before = 0;
 #pragma unroll
-	for (int half = 0; half < 2; ++half) {
-		const int a = half ? a1 : a0;
-		const int pt = lane + half * kGroup;
-		const int rank = half ? (n0 + __popcll(m1 & below)) : __popcll(m0 & below);
-		if (a && rank < cap) {
+	for (int hf = 0; hf < kPtHalves; ++hf) {
+		const int pt = lane + hf * kGroup;
+		const int rank = before + __popcll(c.m[hf] & below);
+		if (c.act[hf] && rank < cap) {
 			const int R = R0 + 2 * rank;
 			const int j = pt / kPtsPerLink;
-			const real t = kErp * fmax(ws.pt_depth[pt] - kSlop, 0.0) / h;
-			// NOTE: the point arrays alias the Delassus matrix, not the row arrays, so reading them here is safe
-			ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_x[R] = ws.pt_x[pt]; ws.row_y[R] = ws.pt_y[pt];
-			ws.row_dx[R] = ws.pt_nx[pt]; ws.row_dy[R] = ws.pt_ny[pt]; ws.row_tgt[R] = fmin(t, kVDepenMax);
-			ws.row_kind[R + 1] = 2; ws.row_link[R + 1] = j; ws.row_x[R + 1] = ws.pt_x[pt]; ws.row_y[R + 1] = ws.pt_y[pt];
-			ws.row_dx[R + 1] = ws.pt_ny[pt]; ws.row_dy[R + 1] = -ws.pt_nx[pt]; ws.row_tgt[R + 1] = 0;
+			const real t = kErp * fmax(c.depth[hf] - kSlop, 0.0) / h;
+			ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_x[R] = c.x[hf]; ws.row_y[R] = c.y[hf];
+			ws.row_dx[R] = c.nx[hf]; ws.row_dy[R] = c.ny[hf]; ws.row_tgt[R] = fmin(t, kVDepenMax);
+			ws.row_kind[R + 1] = 2; ws.row_link[R + 1] = j; ws.row_x[R + 1] = c.x[hf]; ws.row_y[R + 1] = c.y[hf];
+			ws.row_dx[R + 1] = c.ny[hf]; ws.row_dy[R + 1] = -c.nx[hf]; ws.row_tgt[R + 1] = 0;
 		}
+		before += __popcll(c.m[hf]);
 	}
-	int nc = n0 + n1; if (nc > cap) nc = cap;
+	int nc = before; if (nc > cap) nc = cap;
 	if (lane == 0) ws.R = R0 + 2 * nc;
 	__syncthreads();
 }
 
+// Delassus matrix A = Z D^-1 Z^T, entry-parallel: the R (R + 1) / 2 lower-triangle entries are dealt round-robin to all 64
+// lanes (entry e = packed index), so a 16-row system is 3 passes of 23-long dot products instead of 16; the rows of Z are
+// read from LDS (odd row stride: lanes on different rows hit different banks, lanes on the same row broadcast).
+// Per-entry operation order is the one of build_delassus(), so the bits are the same.
+template <int D>
+__device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real dinv_mine)
+{
+	const int lane = static_cast<int>(threadIdx.x);
+	const int R = ws.R;
+	const int n_ent = R * (R + 1) / 2;
+	real di[D];
+#pragma unroll
+	for (int i = 0; i < D; ++i) di[i] = bcast(dinv_mine, i);   // wave-uniform (SGPR pairs)
+	for (int e = lane; e < n_ent; e += kGroup) {
+		int s = static_cast<int>((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+		while (s * (s + 1) / 2 > e) --s;
+		while ((s + 1) * (s + 2) / 2 <= e) ++s;
+		const int r = e - s * (s + 1) / 2;
+		const real* zs = ws.Z[s];
+		const real* zr = ws.Z[r];
+		real a = 0;
+#pragma unroll
+		for (int i = 0; i < D; ++i) a += zs[i] * zr[i] * di[i];
+		ws.Apk[e] = a;
+	}
+	if (lane < R) {
+		const int s = lane;
+		real jv;
+		if (ws.row_kind[s] == 0) jv = ws.row_dx[s] * ws.st.qd[ws.row_link[s] + 2];
+		else {
+			const int l = ws.row_link[s];
+			const real vx = ws.vpx[l] - ws.w[l] * (ws.row_y[s] - ws.py[l]);
+			const real vy = ws.vpy[l] + ws.w[l] * (ws.row_x[s] - ws.px[l]);
+			jv = ws.row_dx[s] * vx + ws.row_dy[s] * vy;
+		}
+		const real* zs = ws.Z[s];
+		const real* z0 = ws.Z[R];
+		real zz = 0;
+#pragma unroll
+		for (int i = 0; i < D; ++i) zz += zs[i] * di[i] * z0[i];
+		ws.wv[s] = jv + h * zz - ws.row_tgt[s];
+	}
+	__syncthreads();
+}
+
 // projected Gauss-Seidel in lambda space with the row state in registers: lane s owns row s (w_s, lambda_s, 1/A_ss, kind);
-// a row update is a handful of v_readlane broadcasts + one FMA per lane against column r of the Delassus matrix (LDS,
-// conflict-free 8-byte reads). Same operations and order as pgs_solve().
-__device__ __forceinline__ void pgs_solve_fast(WS& ws)
+// a row update is a handful of v_readlane broadcasts + one multiply-add per lane against column r of the packed Delassus
+// matrix (LDS). Same operations and order as pgs_solve().
+__device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 {
 	const int lane = static_cast<int>(threadIdx.x);
 	const int R = ws.R;
 	const bool mine = lane < R;
 	real w = mine ? ws.wv[lane] : 0.0, lam = 0.0;
-	const real rinv = mine ? ws.rinv[lane] : 0.0;
+	real rinv = 0.0;
+	if (mine) { const real ass = ws.Apk[lane * (lane + 3) / 2]; rinv = (ass >= 1e-12) ? 1.0 / ass : 0.0; }   // rows with a vanishing effective mass are skipped
 	const int kind = mine ? ws.row_kind[lane] : 0;
+	const int tri = lane * (lane + 1) / 2;
 	for (int it = 0; it < kPgsIters; ++it) {
 		for (int r = 0; r < R; ++r) {
-			const real a_sr = mine ? ws.A[lane][r] : 0.0;
+			const real a_sr = mine ? ws.Apk[lane >= r ? tri + r : r * (r + 1) / 2 + lane] : 0.0;
 			const real ri = bcast(rinv, r);
 			if (ri != 0.0) {
 				const real lam_r = bcast(lam, r);
@@ -224,7 +281,7 @@ __device__ __forceinline__ void pgs_solve_fast(WS& ws)
 
 template <int D>
 struct FastPath {
-	static __device__ void substep(WS& ws, const DevModel& gm, const GroundRec& g, real h)
+	static __device__ void substep(WSFast& ws, const DevModel& gm, const GroundRec& g, real h)
 	{
 		const int lane = static_cast<int>(threadIdx.x);
 		{ PROF_T0(); kin_dyn_terms(ws, false); PROF_ADD(ws, kProfFK); }
@@ -232,8 +289,11 @@ struct FastPath {
 		{ PROF_T0(); mass_row<D>(ws, hrow); PROF_ADD(ws, kProfMass); }
 		real dinv;
 		{ PROF_T0(); dinv = factorize_regs<D>(hrow); PROF_ADD(ws, kProfFact); }
-		{ PROF_T0(); detect_contacts_fast(ws, gm, g); PROF_ADD(ws, kProfDetect); }
-		{ PROF_T0(); build_rows_fast(ws, h); PROF_ADD(ws, kProfRows); }
+		{
+			ContactPts cp;
+			{ PROF_T0(); eval_points(ws, gm, g, cp); contact_bits_fast(ws, cp); PROF_ADD(ws, kProfDetect); }
+			{ PROF_T0(); build_rows_fast(ws, cp, h); PROF_ADD(ws, kProfRows); }
+		}
 		const int R = ws.R;
 		{
 			PROF_T0();
@@ -259,12 +319,11 @@ struct FastPath {
 				z = fsub_regs<D>(hrow, z);
 				if (lane < D) ws.Z[r][lane] = z;
 			}
-			if (lane < D) ws.dinv[lane] = dinv;
 			__syncthreads();
 			PROF_ADD(ws, kProfFsub);
 		}
 		if (R > 0) {
-			{ PROF_T0(); build_delassus(ws, h); PROF_ADD(ws, kProfDelassus); }
+			{ PROF_T0(); build_delassus_fast<D>(ws, h, dinv); PROF_ADD(ws, kProfDelassus); }
 			{ PROF_T0(); pgs_solve_fast(ws); PROF_ADD(ws, kProfPgs); }
 		}
 		{
@@ -284,7 +343,7 @@ struct FastPath {
 		if (threadIdx.x == 0) { ws.prof[kProfRowsSum] += R; ws.prof[kProfSubsteps] += 1; }
 #endif
 	}
-	static __device__ void pd_solve(WS& ws, real dt)
+	static __device__ void pd_solve(WSFast& ws, real dt)
 	{
 		const int lane = static_cast<int>(threadIdx.x);
 		real hrow[D];
@@ -302,7 +361,7 @@ struct FastPath {
 		if (lane == 0) ws.R = 0;
 		__syncthreads();
 	}
-	static __device__ void contacts(WS& ws, const DevModel& gm, const GroundRec& g) { detect_contacts_fast(ws, gm, g); }
+	static __device__ void contacts(WSFast& ws, const DevModel& gm, const GroundRec& g) { detect_contacts_fast(ws, gm, g); }
 };
 
 }  // namespace dtrl

@@ -15,12 +15,12 @@ typedef double real;
 
 constexpr int kGroup = 64;       // lanes per env = one CDNA wavefront
 constexpr int kMaxL = 24;        // links
-constexpr int kMaxD = 26;        // generalised coordinates (planar root = 3, one per hinge)
+constexpr int kMaxD = 24;        // generalised coordinates (planar root = 3, one per hinge)
 constexpr int kMaxP = 40;        // controller params per action (dog 30, raptor 37)
 constexpr int kMaxSets = 8;
 constexpr int kMaxAct = 16;
 constexpr int kMaxDepth = 12;    // longest root->link path (dog: 10)
-constexpr int kMaxRows = 32;     // constraint rows per substep (joint limits + 2 per contact point)
+constexpr int kMaxRows = 24;     // constraint rows per substep (joint limits + 2 per contact point)
 constexpr int kPtsPerLink = 6;   // contact sample points per box link (4 corners + 2 long-edge midpoints)
 constexpr int kMaxPts = kMaxL * kPtsPerLink;
 constexpr int kSegCap = 512;     // floats per heightfield segment slot (51 m at 0.1 m spacing)

@@ -23,7 +23,7 @@ public:
 		if (buf.tuple_count && nt > 1 && gm->scenario == kScnExp) nt = 1;   // the tuple cursor is a plain int on the host
 		std::vector<std::thread> th;
 		for (int t = 0; t < nt; ++t) th.emplace_back([=]() {
-			WS* ws = new WS();
+			WSRef* ws = new WSRef();
 			for (int e = t; e < n_envs; e += nt) env_frame<RefPath>(*ws, *gm, rp, buf, buf.env_list ? buf.env_list[e] : e, n_steps, dt, frame_end);
 			delete ws;
 		});

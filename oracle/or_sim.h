@@ -29,7 +29,7 @@ struct SimConst {
 	static constexpr double limit_erp = 0.2;
 	static constexpr double limit_slop = 0.005;  // a limit row is active within this band of the stop (robust activation)
 	static constexpr int pgs_iters = 10;
-	static constexpr int max_rows = 32;
+	static constexpr int max_rows = 24;
 	static constexpr int pts_per_link = 6;
 };
 
