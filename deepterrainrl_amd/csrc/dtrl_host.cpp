@@ -598,6 +598,8 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		m.sub_mask[j] = 0;
 	}
 	for (int k = 0; k < L; ++k) { m.anc_mask[k] = 0; for (int c = k; c >= 0; c = m.parent[c]) { m.sub_mask[c] |= (1u << k); m.anc_mask[k] |= (1u << c); } }
+	m.n_pairs = 0;
+	for (int l = 0; l < L; ++l) for (int k = 0; k <= m.depth[l]; ++k) { m.pair_l[m.n_pairs] = static_cast<int8_t>(l); m.pair_k[m.n_pairs] = static_cast<int8_t>(k); ++m.n_pairs; }
 
 	// controllers (sim/DogController.cpp:629-700, 399-454)
 	const Json* files = ctrls->find("Files"); const Json* acts = ctrls->find("Actions");

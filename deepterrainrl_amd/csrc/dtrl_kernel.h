@@ -60,8 +60,9 @@ enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfR
 // hot, read-mostly model fields staged in LDS (per-substep readers only; the controller's once-per-env-step gains, torque
 // limits and body angles stay in the HBM/L2-resident DevModel)
 struct HotModel {
-	int32_t L, D, char_type, pad_;
+	int32_t L, D, char_type, n_pairs;
 	int32_t parent[kMaxL], depth[kMaxL], col[kMaxL];
+	int8_t pair_l[kMaxPairs], pair_k[kMaxPairs];
 	int8_t path[kMaxL][kMaxDepth];
 	uint32_t sub_mask[kMaxL];
 	uint32_t anc_mask[kMaxL];   // bit a set <=> link a is an ancestor of j or j itself
@@ -309,10 +310,14 @@ DTRL_HD inline void kin_dyn_terms(W& ws, bool quirk)
 		const int j = lane;
 		const uint32_t mask = ws.M.sub_mask[j];
 		real m = 0, mx = 0, my = 0, I = 0, sfx = 0, sfy = 0, sfn = 0;
-#pragma unroll 6
-		for (int k = 0; k < kMaxL; ++k) {
-			const real mk = ws.M.mass[k], a1 = ws.mcx[k], a2 = ws.mcy[k], a3 = ws.Io[k], a4 = ws.fx[k], a5 = ws.fy[k], a6 = ws.fn[k];
-			if ((mask >> k) & 1u) { m += mk; mx += a1; my += a2; I += a3; sfx += a4; sfy += a5; sfn += a6; }
+		const int nL = ws.M.L;
+		for (int k0 = 0; k0 < nL; k0 += 7) {   // chunks of 7 (3 chunks cover the 19- and 21-link characters) so the loads of a chunk pipeline
+#pragma unroll
+			for (int kk = 0; kk < 7; ++kk) {
+				const int k = (k0 + kk < kMaxL) ? k0 + kk : 0;
+				const real mk = ws.M.mass[k], a1 = ws.mcx[k], a2 = ws.mcy[k], a3 = ws.Io[k], a4 = ws.fx[k], a5 = ws.fy[k], a6 = ws.fn[k];
+				if (k0 + kk < nL && ((mask >> k) & 1u)) { m += mk; mx += a1; my += a2; I += a3; sfx += a4; sfy += a5; sfn += a6; }
+			}
 		}
 		ws.sm[j] = m; ws.smx[j] = mx; ws.smy[j] = my; ws.sI[j] = I;
 		// generalised bias: translations see the total force (root subtree = everything), hinge l the subtree moment about p_l
@@ -400,9 +405,11 @@ DTRL_HD inline int contact_point_eval(const W& ws, const DevModel& gm, const Gro
 	const real y = ws.py[j] + s * lx + c * ly;
 	real slope;
 	const real h = sample_ground(g, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
+	const real gap = h - (ws.st.q[1] + y);
+	if (!(gap > 0)) return 0;   // depth = gap * ny with ny > 0: the normal is only needed for penetrating points
 	const real inv = 1.0 / sqrt(1.0 + slope * slope);
 	const real nx = -slope * inv, ny = inv;
-	const real depth = (h - (ws.st.q[1] + y)) * ny;
+	const real depth = gap * ny;
 	*ox = x; *oy = y; *odepth = depth; *onx = nx; *ony = ny;
 	return depth > 0 ? 1 : 0;
 }
@@ -1350,7 +1357,8 @@ template <class W>
 DTRL_HD inline void load_hot_model(W& ws, const DevModel& gm)
 {
 	LANES_BEGIN
-	if (lane == 0) { ws.M.L = gm.L; ws.M.D = gm.D; ws.M.char_type = gm.char_type; }
+	if (lane == 0) { ws.M.L = gm.L; ws.M.D = gm.D; ws.M.char_type = gm.char_type; ws.M.n_pairs = gm.n_pairs; }
+	for (int e = lane; e < gm.n_pairs; e += kGroup) { ws.M.pair_l[e] = gm.pair_l[e]; ws.M.pair_k[e] = gm.pair_k[e]; }
 	if (lane < gm.L) {
 		const int j = lane;
 		ws.M.parent[j] = gm.parent[j]; ws.M.depth[j] = gm.depth[j]; ws.M.col[j] = gm.col[j];

@@ -17,6 +17,7 @@
 
 namespace dtrl {
 
+__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x); }
 __device__ __forceinline__ real bcast(real v, int src)   // src must be wave-uniform
 {
 	int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -36,16 +37,21 @@ __device__ __forceinline__ void mass_row(WSFast& ws, real (&h)[D])
 	const bool valid = d < D;
 	real (*T)[kMaxDepth + 2] = reinterpret_cast<real (*)[kMaxDepth + 2]>(&ws.Apk[0]);   // T[link][0..depth] + hx, hy at [kMaxDepth], [kMaxDepth+1]; the Delassus storage is dead here
 	if (valid && d >= 2) {
-		const real m = ws.sm[l], mx = ws.smx[l], my = ws.smy[l], I = ws.sI[l];
-		const real plx = ws.px[l], ply = ws.py[l];
-		T[l][kMaxDepth] = -(my - m * ply);
-		T[l][kMaxDepth + 1] = (mx - m * plx);
-		const int dep = ws.M.depth[l];
-		for (int k = 0; k <= dep; ++k) {
-			const int a = ws.M.path[l][k];
-			const real pax = ws.px[a], pay = ws.py[a];
-			T[l][k] = I - ((plx + pax) * mx + (ply + pay) * my) + m * (plx * pax + ply * pay);
-		}
+		const real m = ws.sm[l], mx = ws.smx[l], my = ws.smy[l];
+		T[l][kMaxDepth] = -(my - m * ws.py[l]);
+		T[l][kMaxDepth + 1] = (mx - m * ws.px[l]);
+	}
+	// hinge-hinge entries: the (link, ancestor) pairs are dealt round-robin to all 64 lanes (a deep link has up to 12 ancestors;
+	// one lane per link would leave most of the wave idle behind the deepest chains)
+	const int n_pairs = ws.M.n_pairs;
+#pragma unroll 2
+	for (int e = lane_id(); e < n_pairs; e += kGroup) {
+		const int pl = ws.M.pair_l[e], pk = ws.M.pair_k[e];
+		const int a = ws.M.path[pl][pk];
+		const real m = ws.sm[pl], mx = ws.smx[pl], my = ws.smy[pl], I = ws.sI[pl];
+		const real plx = ws.px[pl], ply = ws.py[pl];
+		const real pax = ws.px[a], pay = ws.py[a];
+		T[pl][pk] = I - ((plx + pax) * mx + (ply + pay) * my) + m * (plx * pax + ply * pay);
 	}
 	__syncthreads();
 	const real M0 = ws.sm[0];
@@ -72,9 +78,11 @@ __device__ __forceinline__ void mass_row(WSFast& ws, real (&h)[D])
 	__syncthreads();   // T is dead; the storage may be reused
 }
 
-// in-register LDL^T; returns 1/d_lane. Same elimination order and operations as factorize().
+// in-register LDL^T; returns 1/d_lane. Same elimination order and operations as factorize(). The transposed copy of L
+// (needed by bsub_regs) is produced with one pass through LDS (packed lower triangle in the Apk storage, which is dead
+// between mass_row() and the Delassus build) instead of per-entry lane selects.
 template <int D>
-__device__ __forceinline__ real factorize_regs(real (&h)[D])
+__device__ __forceinline__ real factorize_regs(WSFast& ws, real (&h)[D])
 {
 	const int lane = static_cast<int>(threadIdx.x);
 #pragma unroll
@@ -85,15 +93,21 @@ __device__ __forceinline__ real factorize_regs(real (&h)[D])
 #pragma unroll
 		for (int j = k + 1; j < D; ++j) {
 			const real ajk = bcast(ak, j);
-			const real ljk = bcast(lik, j);
 			if (lane >= j) h[j] -= lik * ajk;
-			if (lane == k) h[j] = ljk;
 		}
 		if (lane > k) h[k] = lik;
 	}
 	real dinv = 0;
 #pragma unroll
 	for (int k = 0; k < D; ++k) if (lane == k) dinv = 1.0 / h[k];
+	real* S = ws.Apk;
+	const int base = lane * (lane - 1) / 2;
+#pragma unroll
+	for (int k = 0; k < D - 1; ++k) if (lane > k && lane < D) S[base + k] = h[k];
+	__syncthreads();
+#pragma unroll
+	for (int k = 1; k < D; ++k) if (lane < k) h[k] = S[k * (k - 1) / 2 + lane];
+	__syncthreads();
 	return dinv;
 }
 // z = L^-1 rhs (lane i holds component i)
@@ -260,9 +274,12 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 	if (mine) { const real ass = ws.Apk[lane * (lane + 3) / 2]; rinv = (ass >= 1e-12) ? 1.0 / ass : 0.0; }   // rows with a vanishing effective mass are skipped
 	const int kind = mine ? ws.row_kind[lane] : 0;
 	const int tri = lane * (lane + 1) / 2;
+	real a_nx = mine ? ws.Apk[tri] : 0.0;   // column 0; the column of the next row update is fetched one update ahead
 	for (int it = 0; it < kPgsIters; ++it) {
 		for (int r = 0; r < R; ++r) {
-			const real a_sr = mine ? ws.Apk[lane >= r ? tri + r : r * (r + 1) / 2 + lane] : 0.0;
+			const real a_sr = a_nx;
+			const int rn = (r + 1 < R) ? r + 1 : 0;
+			a_nx = mine ? ws.Apk[lane >= rn ? tri + rn : rn * (rn + 1) / 2 + lane] : 0.0;
 			const real ri = bcast(rinv, r);
 			if (ri != 0.0) {
 				const real lam_r = bcast(lam, r);
@@ -288,7 +305,7 @@ struct FastPath {
 		real hrow[D];
 		{ PROF_T0(); mass_row<D>(ws, hrow); PROF_ADD(ws, kProfMass); }
 		real dinv;
-		{ PROF_T0(); dinv = factorize_regs<D>(hrow); PROF_ADD(ws, kProfFact); }
+		{ PROF_T0(); dinv = factorize_regs<D>(ws, hrow); PROF_ADD(ws, kProfFact); }
 		{
 			ContactPts cp;
 			{ PROF_T0(); eval_points(ws, gm, g, cp); contact_bits_fast(ws, cp); PROF_ADD(ws, kProfDetect); }
@@ -351,7 +368,7 @@ struct FastPath {
 		const real add = (lane < D) ? dt * ws.kdm[lane] : 0.0;
 #pragma unroll
 		for (int k = 0; k < D; ++k) if (lane == k) hrow[k] += add;
-		const real dinv = factorize_regs<D>(hrow);
+		const real dinv = factorize_regs<D>(ws, hrow);
 		real z = (lane < D) ? ws.u[lane] : 0.0;
 		z = fsub_regs<D>(hrow, z);
 		real u = z * dinv;

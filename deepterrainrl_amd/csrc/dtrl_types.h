@@ -26,6 +26,7 @@ constexpr int kMaxPts = kMaxL * kPtsPerLink;
 constexpr int kSegCap = 512;     // floats per heightfield segment slot (51 m at 0.1 m spacing)
 constexpr int kNumGroundSamples = 200;
 constexpr int kMaxFrags = 4;
+constexpr int kMaxPairs = kMaxL * kMaxDepth;
 
 // Integrator v1 constants (DESIGN.md "Integrator v1"; mirrored by oracle/or_sim.h SimConst)
 constexpr real kErp = 0.2;
@@ -52,6 +53,8 @@ struct DevModel {
 	uint32_t anc_mask[kMaxL];        // bit a set <=> link a is an ancestor of j or j itself
 	int32_t col[kMaxL];
 	int32_t use_world[kMaxL];
+	int32_t n_pairs;                 // (link, path position) pairs = nonzero hinge-hinge entries of the lower triangle of H
+	int8_t pair_l[kMaxPairs], pair_k[kMaxPairs];
 	int32_t act_idx0[kMaxAct], act_idx1[kMaxAct], act_cyclic[kMaxAct];
 	int32_t opt_index[kMaxP];        // opt_index[k] = param index of the k-th optimisable param
 	real attach[kMaxL][2];
