@@ -32,8 +32,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define DTRL_HD __host__ __device__
+#define DTRL_HD_INLINE __host__ __device__ __forceinline__
 #else
 #define DTRL_HD
+#define DTRL_HD_INLINE inline
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -199,7 +201,7 @@ DTRL_HD inline Rng make_rng(const RunParams& rp, int env, uint64_t* ctr)
 // heightfield sampling: /root/reference/sim/GroundVar2D.cpp:98-114 (segment pick) + :559-619 (grid coord, clamp, lerp).
 // Grid coordinates are computed in double with the float-rounded Bullet origin / scaling the host stored in GroundRec,
 // so the cell indices i, j are bit-exact with the reference's arithmetic.
-DTRL_HD inline real sample_ground(const GroundRec& g, real x, real* slope, int* oi, int* oj, int* oseg)
+DTRL_HD_INLINE real sample_ground(const GroundRec& g, real x, real* slope, int* oi, int* oj, int* oseg)
 {
 	int seg = (x >= g.max_x[0]) ? 1 : 0;
 	const int w = g.w[seg];
@@ -393,12 +395,13 @@ DTRL_HD inline real row_jac(const W& ws, int r, int i)
 }
 
 // world position of contact sample point pt (relative to the root origin) + ground test; shared by both kernel paths
+struct PtVal { real x, y, depth, nx, ny; int active; };
 template <class W>
-DTRL_HD inline int contact_point_eval(const W& ws, const DevModel& gm, const GroundRec& g, int pt, real* ox, real* oy, real* odepth, real* onx, real* ony)
+DTRL_HD_INLINE PtVal contact_point_eval(const W& ws, const DevModel& gm, const GroundRec& g, int pt)
 {
+	PtVal r; r.x = 0; r.y = 0; r.depth = 0; r.nx = 0; r.ny = 0; r.active = 0;
 	const int j = pt / kPtsPerLink, k = pt - j * kPtsPerLink;
-	*ox = 0; *oy = 0; *odepth = 0; *onx = 0; *ony = 0;
-	if (ws.M.col[j] == 0) return 0;
+	if (ws.M.col[j] == 0) return r;
 	const real lx = gm.pt_joint[j][k][0], ly = gm.pt_joint[j][k][1];
 	const real c = ws.cs[j], s = ws.sn[j];
 	const real x = ws.px[j] + c * lx - s * ly;
@@ -406,21 +409,21 @@ DTRL_HD inline int contact_point_eval(const W& ws, const DevModel& gm, const Gro
 	real slope;
 	const real h = sample_ground(g, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
 	const real gap = h - (ws.st.q[1] + y);
-	if (!(gap > 0)) return 0;   // depth = gap * ny with ny > 0: the normal is only needed for penetrating points
+	if (!(gap > 0)) return r;   // depth = gap * ny with ny > 0: the normal is only needed for penetrating points
 	const real inv = 1.0 / sqrt(1.0 + slope * slope);
-	const real nx = -slope * inv, ny = inv;
-	const real depth = gap * ny;
-	*ox = x; *oy = y; *odepth = depth; *onx = nx; *ony = ny;
-	return depth > 0 ? 1 : 0;
+	r.nx = -slope * inv; r.ny = inv;
+	r.depth = gap * r.ny;
+	r.x = x; r.y = y;
+	r.active = r.depth > 0 ? 1 : 0;
+	return r;
 }
 template <class W>
 DTRL_HD inline int sample_contact_point(W& ws, const DevModel& gm, const GroundRec& g, int pt)
 {
-	real x, y, depth, nx, ny;
-	const int active = contact_point_eval(ws, gm, g, pt, &x, &y, &depth, &nx, &ny);
-	if (active) { ws.pt_x[pt] = x; ws.pt_y[pt] = y; ws.pt_depth[pt] = depth; ws.pt_nx[pt] = nx; ws.pt_ny[pt] = ny; }
-	ws.pt_active[pt] = active;
-	return active;
+	const PtVal v = contact_point_eval(ws, gm, g, pt);
+	if (v.active) { ws.pt_x[pt] = v.x; ws.pt_y[pt] = v.y; ws.pt_depth[pt] = v.depth; ws.pt_nx[pt] = v.nx; ws.pt_ny[pt] = v.ny; }
+	ws.pt_active[pt] = v.active;
+	return v.active;
 }
 // contact sample points of every colliding link against the env's heightfield (2 points per lane)
 template <class W>

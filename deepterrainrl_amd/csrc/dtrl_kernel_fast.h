@@ -137,33 +137,31 @@ __device__ __forceinline__ real bsub_regs(const real (&h)[D], real u)
 
 // contact sample points in registers: lane owns points lane, lane + 64, lane + 128; wave ballots give the per-link contact
 // flags and the ordered constraint-row list (same order as detect_contacts()/build_rows()) without touching LDS.
-constexpr int kPtHalves = (kMaxPts + kGroup - 1) / kGroup;
-struct ContactPts {
-	real x[kPtHalves], y[kPtHalves], depth[kPtHalves], nx[kPtHalves], ny[kPtHalves];
-	int act[kPtHalves];
-	unsigned long long m[kPtHalves];
-};
-__device__ __forceinline__ void eval_points(const WSFast& ws, const DevModel& gm, const GroundRec& g, ContactPts& c)
+// (three named values, not an array: the struct must stay in VGPRs, never in scratch)
+static_assert((kMaxPts + kGroup - 1) / kGroup == 3, "written for 3 sample points per lane");
+struct ContactPts { PtVal p0, p1, p2; unsigned long long m0, m1, m2; };
+__device__ __forceinline__ ContactPts eval_points(const WSFast& ws, const DevModel& gm, const GroundRec& g)
 {
 	const int lane = static_cast<int>(threadIdx.x);
 	const int npts = ws.M.L * kPtsPerLink;
-#pragma unroll
-	for (int hf = 0; hf < kPtHalves; ++hf) {
-		const int pt = lane + hf * kGroup;
-		c.act[hf] = 0; c.x[hf] = 0; c.y[hf] = 0; c.depth[hf] = 0; c.nx[hf] = 0; c.ny[hf] = 0;
-		if (pt < npts) c.act[hf] = contact_point_eval(ws, gm, g, pt, &c.x[hf], &c.y[hf], &c.depth[hf], &c.nx[hf], &c.ny[hf]);
-		c.m[hf] = __ballot(c.act[hf]);
-	}
+	ContactPts c;
+	PtVal z; z.x = 0; z.y = 0; z.depth = 0; z.nx = 0; z.ny = 0; z.active = 0;
+	c.p0 = z; c.p1 = z; c.p2 = z;
+	if (lane < npts) c.p0 = contact_point_eval(ws, gm, g, lane);
+	if (lane + kGroup < npts) c.p1 = contact_point_eval(ws, gm, g, lane + kGroup);
+	if (lane + 2 * kGroup < npts) c.p2 = contact_point_eval(ws, gm, g, lane + 2 * kGroup);
+	c.m0 = __ballot(c.p0.active); c.m1 = __ballot(c.p1.active); c.m2 = __ballot(c.p2.active);
+	return c;
 }
-__device__ __forceinline__ void contact_bits_fast(WSFast& ws, const ContactPts& c)
+__device__ __forceinline__ void contact_bits_fast(WSFast& ws, unsigned long long m0, unsigned long long m1, unsigned long long m2)
 {
-	static_assert(kPtHalves == 3, "bit-string extraction below is written for 3 ballot words");
 	const int lane = static_cast<int>(threadIdx.x);
 	int any = 0;
 	if (lane < ws.M.L) {
 		const int b = lane * kPtsPerLink, word = b >> 6, off = b & 63;
-		const unsigned long long lo = word == 0 ? c.m[0] : (word == 1 ? c.m[1] : c.m[2]);
-		const unsigned long long hi = word == 0 ? c.m[1] : (word == 1 ? c.m[2] : 0ull);
+		unsigned long long lo = m0, hi = m1;   // (plain selects on by-value scalars: an indexable aggregate here would be demoted to scratch)
+		if (word == 1) { lo = m1; hi = m2; }
+		if (word == 2) { lo = m2; hi = 0ull; }
 		unsigned long long bits = lo >> off;
 		if (off + kPtsPerLink > 64) bits |= hi << (64 - off);
 		any = (bits & ((1ull << kPtsPerLink) - 1ull)) != 0;
@@ -173,10 +171,21 @@ __device__ __forceinline__ void contact_bits_fast(WSFast& ws, const ContactPts& 
 }
 __device__ __forceinline__ void detect_contacts_fast(WSFast& ws, const DevModel& gm, const GroundRec& g)
 {
-	ContactPts c;
-	eval_points(ws, gm, g, c);
-	contact_bits_fast(ws, c);
+	const ContactPts c = eval_points(ws, gm, g);
+	contact_bits_fast(ws, c.m0, c.m1, c.m2);
 	__syncthreads();
+}
+__device__ __forceinline__ void emit_contact_rows(WSFast& ws, const PtVal& p, int pt, int rank, int cap, int R0, real h)
+{
+	if (p.active && rank < cap) {
+		const int R = R0 + 2 * rank;
+		const int j = pt / kPtsPerLink;
+		const real t = kErp * fmax(p.depth - kSlop, 0.0) / h;
+		ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_x[R] = p.x; ws.row_y[R] = p.y;
+		ws.row_dx[R] = p.nx; ws.row_dy[R] = p.ny; ws.row_tgt[R] = fmin(t, kVDepenMax);
+		ws.row_kind[R + 1] = 2; ws.row_link[R + 1] = j; ws.row_x[R + 1] = p.x; ws.row_y[R + 1] = p.y;
+		ws.row_dx[R + 1] = p.ny; ws.row_dy[R + 1] = -p.nx; ws.row_tgt[R + 1] = 0;
+	}
 }
 __device__ __forceinline__ void build_rows_fast(WSFast& ws, const ContactPts& c, real h)
 {
@@ -195,23 +204,11 @@ __device__ __forceinline__ void build_rows_fast(WSFast& ws, const ContactPts& c,
 	if (lim != 0 && rl < kMaxRows) { ws.row_kind[rl] = 0; ws.row_link[rl] = lane; ws.row_dx[rl] = lim; ws.row_tgt[rl] = tgt; }
 	// contacts, ordered by sample-point index
 	const int cap = (kMaxRows - R0) / 2;
-	int before = 0;
-#pragma unroll
-	for (int hf = 0; hf < kPtHalves; ++hf) {
-		const int pt = lane + hf * kGroup;
-		const int rank = before + __popcll(c.m[hf] & below);
-		if (c.act[hf] && rank < cap) {
-			const int R = R0 + 2 * rank;
-			const int j = pt / kPtsPerLink;
-			const real t = kErp * fmax(c.depth[hf] - kSlop, 0.0) / h;
-			ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_x[R] = c.x[hf]; ws.row_y[R] = c.y[hf];
-			ws.row_dx[R] = c.nx[hf]; ws.row_dy[R] = c.ny[hf]; ws.row_tgt[R] = fmin(t, kVDepenMax);
-			ws.row_kind[R + 1] = 2; ws.row_link[R + 1] = j; ws.row_x[R + 1] = c.x[hf]; ws.row_y[R + 1] = c.y[hf];
-			ws.row_dx[R + 1] = c.ny[hf]; ws.row_dy[R + 1] = -c.nx[hf]; ws.row_tgt[R + 1] = 0;
-		}
-		before += __popcll(c.m[hf]);
-	}
-	int nc = before; if (nc > cap) nc = cap;
+	const int n0 = __popcll(c.m0), n1 = __popcll(c.m1), n2 = __popcll(c.m2);
+	emit_contact_rows(ws, c.p0, lane, __popcll(c.m0 & below), cap, R0, h);
+	emit_contact_rows(ws, c.p1, lane + kGroup, n0 + __popcll(c.m1 & below), cap, R0, h);
+	emit_contact_rows(ws, c.p2, lane + 2 * kGroup, n0 + n1 + __popcll(c.m2 & below), cap, R0, h);
+	int nc = n0 + n1 + n2; if (nc > cap) nc = cap;
 	if (lane == 0) ws.R = R0 + 2 * nc;
 	__syncthreads();
 }
@@ -308,7 +305,7 @@ struct FastPath {
 		{ PROF_T0(); dinv = factorize_regs<D>(ws, hrow); PROF_ADD(ws, kProfFact); }
 		{
 			ContactPts cp;
-			{ PROF_T0(); eval_points(ws, gm, g, cp); contact_bits_fast(ws, cp); PROF_ADD(ws, kProfDetect); }
+			{ PROF_T0(); cp = eval_points(ws, gm, g); contact_bits_fast(ws, cp.m0, cp.m1, cp.m2); PROF_ADD(ws, kProfDetect); }
 			{ PROF_T0(); build_rows_fast(ws, cp, h); PROF_ADD(ws, kProfRows); }
 		}
 		const int R = ws.R;
