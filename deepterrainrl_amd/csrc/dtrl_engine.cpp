@@ -31,6 +31,18 @@ Engine::~Engine()
 	}
 }
 
+// number of floats of the device-side weight layout (InnerProduct blobs are padded to 4-input blocks)
+static int64_t DevNumParams(const NetDesc& d)
+{
+	int64_t n = 0; int cin = 1, w = d.n_terrain;
+	for (int l = 0; l < 3; ++l) { n += pad4(static_cast<int64_t>(d.conv_ch[l]) * cin * d.conv_k[l]) + pad4(d.conv_ch[l]); cin = d.conv_ch[l]; w = w - d.conv_k[l] + 1; }
+	n += fc_dev_size(d.fc_terr, cin * w) + pad4(d.fc_terr);
+	n += fc_dev_size(d.fc_trunk, d.fc_terr + d.n_char) + pad4(d.fc_trunk);
+	n += (fc_dev_size(d.fc_head, d.fc_trunk) + pad4(d.fc_head)) * (1 + d.n_frags);
+	n += fc_dev_size(d.n_frags, d.fc_head) + pad4(d.n_frags) + static_cast<int64_t>(d.n_frags) * (fc_dev_size(d.frag_size, d.fc_head) + pad4(d.frag_size));
+	return n;
+}
+
 int Engine::Create(const char* const* argv, int argc, int num_envs, int device_id)
 {
 	if (num_envs <= 0) return Fail(DTRL_ERR_ARG, "num_envs must be positive");
@@ -80,7 +92,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 		buf_.nn_scratch_stride = ((mx + d.fc_terr + d.n_char + 63) / 64) * 64;
 		buf_.nn_scratch = static_cast<real*>(alloc(sizeof(real) * 2 * static_cast<size_t>(buf_.nn_scratch_stride) * n_));
 		buf_.nn_out = static_cast<real*>(alloc(sizeof(real) * static_cast<size_t>(d.out_size) * n_));
-		float* w_dev = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(d.num_params)));
+		float* w_dev = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(DevNumParams(d))));
 		real* io = static_cast<real*>(alloc(sizeof(real) * d.in_size)); real* is = static_cast<real*>(alloc(sizeof(real) * d.in_size));
 		real* oo = static_cast<real*>(alloc(sizeof(real) * d.out_size)); real* os = static_cast<real*>(alloc(sizeof(real) * d.out_size));
 		if (!buf_.nn_scratch || !buf_.nn_out || !w_dev || !io || !is || !oo || !os) return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
@@ -203,25 +215,35 @@ int Engine::SetPolicy(const float* w, size_t n, const double* io, const double* 
 	const NetDesc& d = cfg_.net;
 	if (n != static_cast<size_t>(d.num_params)) return Fail(DTRL_ERR_ARG, "weight count does not match the deploy prototxt");
 	be_->Sync();
-	// device layout: conv blobs as given; every InnerProduct weight blob transposed to [nin][nout] (lanes <-> outputs read
-	// consecutive floats); biases unchanged. Same element count, same blob order.
-	std::vector<float> dev_w(w, w + n);
+	// device layout (dtrl_kernel.h conv_layer/fc_layer): conv blobs [cout][cin][k] -> [cin][k][cout]; InnerProduct blobs
+	// [nout][nin] -> [ceil(nin/4)][nout][4] (zero padded); biases unchanged; same blob order.
+	std::vector<float> dev_w(static_cast<size_t>(DevNumParams(d)), 0.0f);
 	{
-		size_t off = 0; int cin = 1, wdt = d.n_terrain;
-		for (int l = 0; l < 3; ++l) { off += static_cast<size_t>(d.conv_ch[l]) * cin * d.conv_k[l] + d.conv_ch[l]; cin = d.conv_ch[l]; wdt = wdt - d.conv_k[l] + 1; }
-		auto transpose = [&](int nout, int nin) {
-			for (int o = 0; o < nout; ++o) for (int i = 0; i < nin; ++i) dev_w[off + static_cast<size_t>(i) * nout + o] = w[off + static_cast<size_t>(o) * nin + i];
-			off += static_cast<size_t>(nout) * nin + nout;
+		size_t src = 0, dst = 0; int cin = 1, wdt = d.n_terrain;
+		for (int l = 0; l < 3; ++l) {
+			const int co = d.conv_ch[l], k = d.conv_k[l];
+			for (int o = 0; o < co; ++o) for (int c = 0; c < cin; ++c) for (int u = 0; u < k; ++u)
+				dev_w[dst + (static_cast<size_t>(c) * k + u) * co + o] = w[src + (static_cast<size_t>(o) * cin + c) * k + u];
+			src += static_cast<size_t>(co) * cin * k; dst += static_cast<size_t>(pad4(static_cast<int64_t>(co) * cin * k));
+			for (int o = 0; o < co; ++o) dev_w[dst + o] = w[src + o];
+			src += co; dst += static_cast<size_t>(pad4(co)); cin = co; wdt = wdt - k + 1;
+		}
+		auto block = [&](int nout, int nin) {
+			for (int o = 0; o < nout; ++o) for (int i = 0; i < nin; ++i)
+				dev_w[dst + (static_cast<size_t>(i / 4) * nout + o) * 4 + (i % 4)] = w[src + static_cast<size_t>(o) * nin + i];
+			src += static_cast<size_t>(nout) * nin; dst += static_cast<size_t>(fc_dev_size(nout, nin));
+			for (int o = 0; o < nout; ++o) dev_w[dst + o] = w[src + o];
+			src += nout; dst += static_cast<size_t>(pad4(nout));
 		};
-		transpose(d.fc_terr, cin * wdt);
-		transpose(d.fc_trunk, d.fc_terr + d.n_char);
-		transpose(d.fc_head, d.fc_trunk); transpose(d.n_frags, d.fc_head);
-		for (int f = 0; f < d.n_frags; ++f) { transpose(d.fc_head, d.fc_trunk); transpose(d.frag_size, d.fc_head); }
+		block(d.fc_terr, cin * wdt);
+		block(d.fc_trunk, d.fc_terr + d.n_char);
+		block(d.fc_head, d.fc_trunk); block(d.n_frags, d.fc_head);
+		for (int f = 0; f < d.n_frags; ++f) { block(d.fc_head, d.fc_trunk); block(d.frag_size, d.fc_head); }
 	}
 	w = dev_w.data();
 	std::vector<double> ones_i(d.in_size, 1.0), zeros_i(d.in_size, 0.0), ones_o(d.out_size, 1.0), zeros_o(d.out_size, 0.0);
 	// cNeuralNet without a scale file: identity normalisation (learning/NeuralNet.cpp:925-933)
-	bool ok = be_->H2D(const_cast<float*>(buf_.weights), w, sizeof(float) * n)
+	bool ok = be_->H2D(const_cast<float*>(buf_.weights), w, sizeof(float) * dev_w.size())
 		&& be_->H2D(const_cast<real*>(buf_.in_off), io ? io : zeros_i.data(), sizeof(real) * d.in_size)
 		&& be_->H2D(const_cast<real*>(buf_.in_scale), is ? is : ones_i.data(), sizeof(real) * d.in_size)
 		&& be_->H2D(const_cast<real*>(buf_.out_off), oo ? oo : zeros_o.data(), sizeof(real) * d.out_size)

@@ -33,9 +33,11 @@
 #include <hip/hip_runtime.h>
 #define DTRL_HD __host__ __device__
 #define DTRL_HD_INLINE __host__ __device__ __forceinline__
+#define DTRL_HD_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define DTRL_HD
 #define DTRL_HD_INLINE inline
+#define DTRL_HD_NOINLINE inline
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -57,7 +59,7 @@
 
 namespace dtrl {
 
-enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfRows, kProfFsub, kProfDelassus, kProfPgs, kProfFinish, kProfCtrl, kProfAction, kProfFrameIO, kProfTotal, kProfRowsSum, kProfSubsteps, kProfP1, kProfP2, kProfP3, kProfP4, kProfMax };
+enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfRows, kProfFsub, kProfDelassus, kProfPgs, kProfFinish, kProfCtrl, kProfAction, kProfFrameIO, kProfTotal, kProfRowsSum, kProfSubsteps, kProfP1, kProfP2, kProfP3, kProfP4, kProfR0, kProfR1_6, kProfR7_12, kProfR13_18, kProfR19_24, kProfT0, kProfT1_6, kProfT7_12, kProfT13_18, kProfT19_24, kProfMax };
 
 // hot, read-mostly model fields staged in LDS (per-substep readers only; the controller's once-per-env-step gains, torque
 // limits and body angles stay in the HBM/L2-resident DevModel)
@@ -732,56 +734,150 @@ DTRL_HD inline void apply_action(W& ws, int id, const real* params, int P)
 	transition_state(ws, stBackStance);
 }
 
-// ---- policy network: learning/NeuralNet.cpp:352-375 Eval on the dog_mace3 topology, all 64 lanes of the env's wavefront.
+// ---- policy network: learning/NeuralNet.cpp:352-375 Eval on the MACE topology, all 64 lanes of the env's wavefront.
 // Activations ping-pong through a per-env HBM scratch slab (L2-resident: only envs at a cycle boundary touch theirs).
-// conv1d: lanes <-> output positions (coalesced activation reads), output channels blocked by 8 so every loaded input
-// feeds 8 FMAs, weights are wave-uniform loads. FC: the engine stores FC weights TRANSPOSED ([nin][nout]) so that
-// lanes <-> outputs read consecutive floats; inputs are wave-uniform loads. Accumulation order per output is the
-// reference order (channel-major, then tap; input index ascending), so results do not depend on the blocking.
-constexpr int kConvBlock = 8;
-DTRL_HD inline void conv_layer(const float* W, const float* bias, int co, int cin, int k, int wdt, const real* a, real* out)
+// A forward pass by one wave is latency-bound unless every global load is issued a full block ahead of its use, so both
+// layer kinds are software-pipelined across lane phases (per-lane values that survive a phase boundary live in LANE_LOCAL
+// storage: registers under hipcc, a [lane] array in the lane-loop test build):
+//   conv1d: lanes <-> output positions; all (<= 32) output channels accumulate in registers so an input window is loaded
+//           once; the engine re-lays conv blobs as [cin][k][cout], the slice of input channel c+1 (k*cout <= 128 floats)
+//           is fetched coalesced and parked as doubles in LDS while channel c is consumed with ds_read broadcasts;
+//   FC:     lanes <-> outputs; the engine re-lays InnerProduct blobs as [nin/4][nout][4] so a lane fetches the weights of
+//           4 inputs with one 16-byte load; inputs are staged 64 at a time in LDS; weights of block b+1 are in flight
+//           while block b is consumed.
+// Accumulation order per output is the reference order (channel-major, then tap; input index ascending), so results do
+// not depend on the blocking. LDS scratch = the Z storage (dead while the controller picks an action).
+constexpr int kMaxConvCh = 32, kMaxConvK = 8, kConvSlice = 128, kFcChunk = 32;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LANE_LOCAL(type, name, n) type name##_ll[1][n]
+#define LL(name) name##_ll[0]
+#else
+#define LANE_LOCAL(type, name, n) type name##_ll[::dtrl::kGroup][n]
+#define LL(name) name##_ll[lane]
+#endif
+DTRL_HD inline int64_t fc_dev_size(int nout, int nin) { return static_cast<int64_t>((nin + 3) / 4) * 4 * nout; }
+DTRL_HD inline int64_t pad4(int64_t n) { return (n + 3) / 4 * 4; }   // every device blob starts 16-byte aligned
+struct alignas(16) F4 { float v[4]; };
+
+template <class W>
+DTRL_HD inline void conv_layer(W& ws, const float* Wd, const float* bias, int co, int cin, int k, int wdt, const real* a, real* out)
 {
-	const int wo = wdt - k + 1;
+	real* lds = &ws.Z[0][0];   // two slices of kConvSlice doubles
+	const int wo = wdt - k + 1, nw = k * co;
 	for (int t0 = 0; t0 < wo; t0 += kGroup) {
+		LANE_LOCAL(real, acc, kMaxConvCh);
+		LANE_LOCAL(real, xc, kMaxConvK);
+		LANES_BEGIN
+		for (int e = lane; e < nw; e += kGroup) lds[e] = static_cast<real>(Wd[e]);
+		const int tt = (t0 + lane < wo) ? t0 + lane : wo - 1;
+#pragma unroll
+		for (int u = 0; u < kMaxConvK; ++u) LL(xc)[u] = (u < k) ? a[tt + u] : 0.0;
+#pragma unroll
+		for (int o = 0; o < kMaxConvCh; ++o) LL(acc)[o] = (o < co) ? static_cast<real>(bias[o]) : 0.0;
+		LANES_END
+		for (int c = 0; c < cin; ++c) {
+			LANES_BEGIN
+			const int cur = (c & 1) * kConvSlice, nxt = kConvSlice - cur;
+			const bool more = c + 1 < cin;
+			const int tt = (t0 + lane < wo) ? t0 + lane : wo - 1;
+			// issue the loads of channel c + 1 before the multiply-adds of channel c
+			float wn0 = 0, wn1 = 0; real xn[kMaxConvK];
+			const float* Wn = Wd + static_cast<int64_t>(c + 1) * nw;
+			if (more && lane < nw) wn0 = Wn[lane];
+			if (more && lane + kGroup < nw) wn1 = Wn[lane + kGroup];
+#pragma unroll
+			for (int u = 0; u < kMaxConvK; ++u) xn[u] = (more && u < k) ? a[(c + 1) * wdt + tt + u] : 0.0;
+#pragma unroll
+			for (int u = 0; u < kMaxConvK; ++u) {
+				if (u >= k) break;
+				const real x = LL(xc)[u];
+				const real* wr = lds + cur + u * co;
+#pragma unroll
+				for (int ob = 0; ob < kMaxConvCh; ob += 8) {
+					if (ob >= co) break;
+#pragma unroll
+					for (int o = ob; o < ob + 8; ++o) LL(acc)[o] += wr[o] * x;
+				}
+			}
+			if (more) {
+				if (lane < nw) lds[nxt + lane] = static_cast<real>(wn0);
+				if (lane + kGroup < nw) lds[nxt + lane + kGroup] = static_cast<real>(wn1);
+#pragma unroll
+				for (int u = 0; u < kMaxConvK; ++u) LL(xc)[u] = xn[u];
+			}
+			LANES_END
+		}
 		LANES_BEGIN
 		const int t = t0 + lane;
 		if (t < wo) {
-			for (int o0 = 0; o0 < co; o0 += kConvBlock) {
-				real acc[kConvBlock];
 #pragma unroll
-				for (int bq = 0; bq < kConvBlock; ++bq) acc[bq] = (o0 + bq < co) ? static_cast<real>(bias[o0 + bq]) : 0.0;
-				for (int c = 0; c < cin; ++c) {
-					for (int u = 0; u < k; ++u) {
-						const real x = a[c * wdt + t + u];
-#pragma unroll
-						for (int bq = 0; bq < kConvBlock; ++bq) if (o0 + bq < co) acc[bq] += static_cast<real>(W[((o0 + bq) * cin + c) * k + u]) * x;
-					}
-				}
-#pragma unroll
-				for (int bq = 0; bq < kConvBlock; ++bq) if (o0 + bq < co) out[(o0 + bq) * wo + t] = acc[bq] < 0 ? 0 : acc[bq];
-			}
+			for (int o = 0; o < kMaxConvCh; ++o) if (o < co) out[o * wo + t] = LL(acc)[o] < 0 ? 0 : LL(acc)[o];
 		}
 		LANES_END
 	}
 }
-DTRL_HD inline void fc_layer(const float* Wt, const float* b, int nout, int nin, const real* x, real* y, bool relu)
+template <class W>
+DTRL_HD inline void fc_layer(W& ws, const float* Wb, const float* b, int nout, int nin, const real* x, real* y, bool relu)
 {
+	real* lds = &ws.Z[0][0];   // two chunks of kFcChunk inputs
+	const int nblk = (nin + 3) / 4;
+	constexpr int kQ = kFcChunk / 4;   // 16-byte weight loads per lane and chunk
 	for (int o0 = 0; o0 < nout; o0 += kGroup) {
+		LANE_LOCAL(real, s, 1);
+		LANE_LOCAL(float, wc, kFcChunk);
 		LANES_BEGIN
 		const int o = o0 + lane;
-		if (o < nout) {
-			real s = b[o];
-#pragma unroll 8
-			for (int i = 0; i < nin; ++i) s += static_cast<real>(Wt[static_cast<int64_t>(i) * nout + o]) * x[i];
-			y[o] = (relu && s < 0) ? 0 : s;
+		if (lane < kFcChunk) lds[lane] = (lane < nin) ? x[lane] : 0.0;
+		LL(s)[0] = (o < nout) ? static_cast<real>(b[o]) : 0.0;
+#pragma unroll
+		for (int q = 0; q < kQ; ++q) {
+			const bool ok = o < nout && q < nblk;
+			const F4 w4 = *reinterpret_cast<const F4*>(Wb + (static_cast<int64_t>(ok ? q : 0) * nout + (ok ? o : 0)) * 4);
+#pragma unroll
+			for (int r = 0; r < 4; ++r) LL(wc)[4 * q + r] = ok ? w4.v[r] : 0.0f;
 		}
+		LANES_END
+		for (int i0 = 0; i0 < nin; i0 += kFcChunk) {
+			LANES_BEGIN
+			const int o = o0 + lane;
+			const int cur = ((i0 / kFcChunk) & 1) * kFcChunk, nxt = kFcChunk - cur;
+			const bool more = i0 + kFcChunk < nin;
+			// next chunk: one input per lane, 16 weights per lane
+			const real xn = (more && lane < kFcChunk && i0 + kFcChunk + lane < nin) ? x[i0 + kFcChunk + lane] : 0.0;
+			float wn[kFcChunk];
+			const int b1 = (i0 + kFcChunk) / 4;
+#pragma unroll
+			for (int q = 0; q < kQ; ++q) {
+				const bool ok = more && o < nout && b1 + q < nblk;
+				const F4 w4 = *reinterpret_cast<const F4*>(Wb + (static_cast<int64_t>(ok ? b1 + q : 0) * nout + (ok ? o : 0)) * 4);
+#pragma unroll
+				for (int r = 0; r < 4; ++r) wn[4 * q + r] = ok ? w4.v[r] : 0.0f;
+			}
+			real acc = LL(s)[0];
+			const int nhere = (nin - i0 < kFcChunk) ? nin - i0 : kFcChunk;
+#pragma unroll
+			for (int q = 0; q < kQ; ++q) {
+				if (4 * q >= nhere) break;
+#pragma unroll
+				for (int r = 0; r < 4; ++r) if (4 * q + r < nhere) acc += static_cast<real>(LL(wc)[4 * q + r]) * lds[cur + 4 * q + r];
+			}
+			LL(s)[0] = acc;
+			if (more) {
+				if (lane < kFcChunk) lds[nxt + lane] = xn;
+#pragma unroll
+				for (int e = 0; e < kFcChunk; ++e) LL(wc)[e] = wn[e];
+			}
+			LANES_END
+		}
+		LANES_BEGIN
+		const int o = o0 + lane;
+		if (o < nout) y[o] = (relu && LL(s)[0] < 0) ? 0 : LL(s)[0];
 		LANES_END
 	}
 }
 template <class W>
 DTRL_HD inline void nn_eval(W& ws, const DevBuffers& buf, int env)
 {
-	(void)ws;
 	const NetDesc& d = buf.net;
 	real* s0 = buf.nn_scratch + static_cast<int64_t>(env) * 2 * buf.nn_scratch_stride;
 	real* s1 = s0 + buf.nn_scratch_stride;
@@ -798,29 +894,29 @@ DTRL_HD inline void nn_eval(W& ws, const DevBuffers& buf, int env)
 	int cin = 1, wdt = d.n_terrain;
 	for (int l = 0; l < 3; ++l) {
 		const int co = d.conv_ch[l], k = d.conv_k[l], wo = wdt - k + 1;
-		const float* Wc = p; const float* bias = p + static_cast<int64_t>(co) * cin * k;
-		conv_layer(Wc, bias, co, cin, k, wdt, a, bo);
-		p = bias + co; real* t2 = a; a = bo; bo = t2; cin = co; wdt = wo;
+		const float* Wc = p; const float* bias = p + pad4(static_cast<int64_t>(co) * cin * k);
+		conv_layer(ws, Wc, bias, co, cin, k, wdt, a, bo);
+		p = bias + pad4(co); real* t2 = a; a = bo; bo = t2; cin = co; wdt = wo;
 	}
 	const int nflat = cin * wdt;
 	// terr_ip0: 5984 -> 64, output written right before the char features so the trunk input is contiguous
 	real* trunk_in = xchar - d.fc_terr;
-	fc_layer(p, p + static_cast<int64_t>(d.fc_terr) * nflat, d.fc_terr, nflat, a, trunk_in, true);
-	p += static_cast<int64_t>(d.fc_terr) * nflat + d.fc_terr;
+	fc_layer(ws, p, p + fc_dev_size(d.fc_terr, nflat), d.fc_terr, nflat, a, trunk_in, true);
+	p += fc_dev_size(d.fc_terr, nflat) + pad4(d.fc_terr);
 	const int ntr = d.fc_terr + d.n_char;
 	real* trunk = s0;               // conv activations are dead now (a == s1 after three swaps, trunk_in lives in s1's tail)
 	real* head = s0 + d.fc_trunk;
-	fc_layer(p, p + static_cast<int64_t>(d.fc_trunk) * ntr, d.fc_trunk, ntr, trunk_in, trunk, true);
-	p += static_cast<int64_t>(d.fc_trunk) * ntr + d.fc_trunk;
-	fc_layer(p, p + static_cast<int64_t>(d.fc_head) * d.fc_trunk, d.fc_head, d.fc_trunk, trunk, head, true);
-	p += static_cast<int64_t>(d.fc_head) * d.fc_trunk + d.fc_head;
-	fc_layer(p, p + static_cast<int64_t>(d.n_frags) * d.fc_head, d.n_frags, d.fc_head, head, y, false);
-	p += static_cast<int64_t>(d.n_frags) * d.fc_head + d.n_frags;
+	fc_layer(ws, p, p + fc_dev_size(d.fc_trunk, ntr), d.fc_trunk, ntr, trunk_in, trunk, true);
+	p += fc_dev_size(d.fc_trunk, ntr) + pad4(d.fc_trunk);
+	fc_layer(ws, p, p + fc_dev_size(d.fc_head, d.fc_trunk), d.fc_head, d.fc_trunk, trunk, head, true);
+	p += fc_dev_size(d.fc_head, d.fc_trunk) + pad4(d.fc_head);
+	fc_layer(ws, p, p + fc_dev_size(d.n_frags, d.fc_head), d.n_frags, d.fc_head, head, y, false);
+	p += fc_dev_size(d.n_frags, d.fc_head) + pad4(d.n_frags);
 	for (int f = 0; f < d.n_frags; ++f) {
-		fc_layer(p, p + static_cast<int64_t>(d.fc_head) * d.fc_trunk, d.fc_head, d.fc_trunk, trunk, head, true);
-		p += static_cast<int64_t>(d.fc_head) * d.fc_trunk + d.fc_head;
-		fc_layer(p, p + static_cast<int64_t>(d.frag_size) * d.fc_head, d.frag_size, d.fc_head, head, y + d.n_frags + f * d.frag_size, false);
-		p += static_cast<int64_t>(d.frag_size) * d.fc_head + d.frag_size;
+		fc_layer(ws, p, p + fc_dev_size(d.fc_head, d.fc_trunk), d.fc_head, d.fc_trunk, trunk, head, true);
+		p += fc_dev_size(d.fc_head, d.fc_trunk) + pad4(d.fc_head);
+		fc_layer(ws, p, p + fc_dev_size(d.frag_size, d.fc_head), d.frag_size, d.fc_head, head, y + d.n_frags + f * d.frag_size, false);
+		p += fc_dev_size(d.frag_size, d.fc_head) + pad4(d.frag_size);
 	}
 	LANES_BEGIN
 	for (int i = lane; i < d.out_size; i += kGroup) y[i] = y[i] / buf.out_scale[i] - buf.out_off[i];
@@ -1027,7 +1123,7 @@ DTRL_HD inline void controller_update(W& ws, const DevModel& gm, const RunParams
 		ws.flag_update_action = do_update;
 	}
 	LANES_END
-	if (ws.flag_update_action) {
+	if (__builtin_expect(ws.flag_update_action != 0, 0)) {   // once per gait cycle: cold, keep its register pressure out of the step loop
 		PROF_T0();
 		update_action(ws, gm, rp, buf, g, env);
 		PROF_ADD(ws, kProfAction);
@@ -1286,7 +1382,7 @@ DTRL_HD inline void env_step(W& ws, const DevModel& gm, const RunParams& rp, con
 		ws.flag_misc = is_new_cycle(ws) ? 1 : 0;
 	}
 	LANES_END
-	if (ws.flag_misc) scenario_new_cycle(ws, gm, buf, env);              // PostSubstepUpdate
+	if (__builtin_expect(ws.flag_misc != 0, 0)) scenario_new_cycle(ws, gm, buf, env);   // PostSubstepUpdate
 }
 
 // cSimCharacter::Reset + controller Reset; init=true additionally follows cScenarioSimChar::Init ordering
@@ -1393,8 +1489,8 @@ DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, co
 		LANES_END
 	}
 	const GroundRec& g = buf.gr[env];
-	if (ws.st.do_init) reset_env(ws, gm, rp, buf, g, env, true);
-	else if (ws.st.do_reset) reset_env(ws, gm, rp, buf, g, env, false);
+	if (__builtin_expect(ws.st.do_init != 0, 0)) reset_env(ws, gm, rp, buf, g, env, true);
+	else if (__builtin_expect(ws.st.do_reset != 0, 0)) reset_env(ws, gm, rp, buf, g, env, false);
 	else forward_kinematics(ws);
 	for (int s = 0; s < n_steps; ++s) env_step<Path>(ws, gm, rp, buf, g, env, dt);
 	if (do_frame_end) frame_end(ws, gm, buf, env);

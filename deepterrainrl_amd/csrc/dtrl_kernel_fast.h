@@ -298,6 +298,9 @@ struct FastPath {
 	static __device__ void substep(WSFast& ws, const DevModel& gm, const GroundRec& g, real h)
 	{
 		const int lane = static_cast<int>(threadIdx.x);
+#if defined(DTRL_PROFILE)
+		const unsigned long long prof_sub_t0 = __builtin_readcyclecounter();
+#endif
 		{ PROF_T0(); kin_dyn_terms(ws, false); PROF_ADD(ws, kProfFK); }
 		real hrow[D];
 		{ PROF_T0(); mass_row<D>(ws, hrow); PROF_ADD(ws, kProfMass); }
@@ -354,7 +357,7 @@ struct FastPath {
 			PROF_ADD(ws, kProfFinish);
 		}
 #if defined(DTRL_PROFILE)
-		if (threadIdx.x == 0) { ws.prof[kProfRowsSum] += R; ws.prof[kProfSubsteps] += 1; }
+		if (threadIdx.x == 0) { ws.prof[kProfRowsSum] += R; ws.prof[kProfSubsteps] += 1; const int bk = R == 0 ? 0 : (R <= 6 ? 1 : (R <= 12 ? 2 : (R <= 18 ? 3 : 4))); ws.prof[kProfR0 + bk] += 1; ws.prof[kProfT0 + bk] += __builtin_readcyclecounter() - prof_sub_t0; }
 #endif
 	}
 	static __device__ void pd_solve(WSFast& ws, real dt)
