@@ -52,14 +52,20 @@
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DTRL_PROFILE)
 #define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
 #define PROF_ADD(ws, id) do { if (threadIdx.x == 0) (ws).prof[id] += __builtin_readcyclecounter() - prof_t0_; } while (0)
+#define PROF_NOW() __builtin_readcyclecounter()
+#define PROF_ADD_SINCE(ws, id, t0) do { if (threadIdx.x == 0) (ws).prof[id] += __builtin_readcyclecounter() - (t0); } while (0)
+#define PROF_COUNT(ws, id) do { if (threadIdx.x == 0) (ws).prof[id] += 1; } while (0)
 #else
 #define PROF_T0() do {} while (0)
 #define PROF_ADD(ws, id) do {} while (0)
+#define PROF_NOW() 0ull
+#define PROF_ADD_SINCE(ws, id, t0) do { (void)(t0); } while (0)
+#define PROF_COUNT(ws, id) do {} while (0)
 #endif
 
 namespace dtrl {
 
-enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfRows, kProfFsub, kProfDelassus, kProfPgs, kProfFinish, kProfCtrl, kProfAction, kProfFrameIO, kProfTotal, kProfRowsSum, kProfSubsteps, kProfP1, kProfP2, kProfP3, kProfP4, kProfR0, kProfR1_6, kProfR7_12, kProfR13_18, kProfR19_24, kProfT0, kProfT1_6, kProfT7_12, kProfT13_18, kProfT19_24, kProfMax };
+enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfRows, kProfFsub, kProfDelassus, kProfPgs, kProfFinish, kProfCtrl, kProfAction, kProfFrameIO, kProfTotal, kProfRowsSum, kProfSubsteps, kProfP1, kProfP2, kProfP3, kProfP4, kProfR0, kProfR1_6, kProfR7_12, kProfR13_18, kProfR19_24, kProfT0, kProfT1_6, kProfT7_12, kProfT13_18, kProfT19_24, kProfNNConv, kProfNNFcTerr, kProfNNRest, kProfNNEvals, kProfMax };
 
 // hot, read-mostly model fields staged in LDS (per-substep readers only; the controller's once-per-env-step gains, torque
 // limits and body angles stay in the HBM/L2-resident DevModel)
@@ -771,22 +777,25 @@ DTRL_HD inline void conv_layer(W& ws, const float* Wd, const float* bias, int co
 		for (int e = lane; e < nw; e += kGroup) lds[e] = static_cast<real>(Wd[e]);
 		const int tt = (t0 + lane < wo) ? t0 + lane : wo - 1;
 #pragma unroll
-		for (int u = 0; u < kMaxConvK; ++u) LL(xc)[u] = (u < k) ? a[tt + u] : 0.0;
+		for (int u = 0; u < kMaxConvK; ++u) LL(xc)[u] = a[tt + (u < k ? u : 0)];
 #pragma unroll
-		for (int o = 0; o < kMaxConvCh; ++o) LL(acc)[o] = (o < co) ? static_cast<real>(bias[o]) : 0.0;
+		for (int o = 0; o < kMaxConvCh; ++o) LL(acc)[o] = static_cast<real>(bias[o < co ? o : 0]);   // clamped, not predicated: one memory wait for all
 		LANES_END
 		for (int c = 0; c < cin; ++c) {
 			LANES_BEGIN
 			const int cur = (c & 1) * kConvSlice, nxt = kConvSlice - cur;
 			const bool more = c + 1 < cin;
 			const int tt = (t0 + lane < wo) ? t0 + lane : wo - 1;
-			// issue the loads of channel c + 1 before the multiply-adds of channel c
-			float wn0 = 0, wn1 = 0; real xn[kMaxConvK];
-			const float* Wn = Wd + static_cast<int64_t>(c + 1) * nw;
-			if (more && lane < nw) wn0 = Wn[lane];
-			if (more && lane + kGroup < nw) wn1 = Wn[lane + kGroup];
+			// issue the loads of channel c + 1 before the multiply-adds of channel c. Addresses are clamped instead of the
+			// loads being predicated or their results selected: any use of a loaded value ahead of the multiply-add blocks
+			// would put the memory wait in front of them (the scheduler does not move code across the uniform branches)
+			const int cn = more ? c + 1 : c;
+			const float* Wn = Wd + static_cast<int64_t>(cn) * nw;
+			const float wn0 = Wn[lane < nw ? lane : nw - 1];
+			const float wn1 = Wn[lane + kGroup < nw ? lane + kGroup : nw - 1];
+			real xn[kMaxConvK];
 #pragma unroll
-			for (int u = 0; u < kMaxConvK; ++u) xn[u] = (more && u < k) ? a[(c + 1) * wdt + tt + u] : 0.0;
+			for (int u = 0; u < kMaxConvK; ++u) xn[u] = a[cn * wdt + tt + (u < k ? u : 0)];
 #pragma unroll
 			for (int u = 0; u < kMaxConvK; ++u) {
 				if (u >= k) break;
@@ -842,24 +851,27 @@ DTRL_HD inline void fc_layer(W& ws, const float* Wb, const float* b, int nout, i
 			const int o = o0 + lane;
 			const int cur = ((i0 / kFcChunk) & 1) * kFcChunk, nxt = kFcChunk - cur;
 			const bool more = i0 + kFcChunk < nin;
-			// next chunk: one input per lane, 16 weights per lane
-			const real xn = (more && lane < kFcChunk && i0 + kFcChunk + lane < nin) ? x[i0 + kFcChunk + lane] : 0.0;
+			// next chunk: one input per lane, kQ 16-byte weight loads per lane; clamped addresses, no selects (see conv_layer)
+			const int in = i0 + kFcChunk + (lane < kFcChunk ? lane : 0);
+			const real xn = x[in < nin ? in : nin - 1];
 			float wn[kFcChunk];
 			const int b1 = (i0 + kFcChunk) / 4;
+			const int oc = o < nout ? o : nout - 1;
 #pragma unroll
 			for (int q = 0; q < kQ; ++q) {
-				const bool ok = more && o < nout && b1 + q < nblk;
-				const F4 w4 = *reinterpret_cast<const F4*>(Wb + (static_cast<int64_t>(ok ? b1 + q : 0) * nout + (ok ? o : 0)) * 4);
+				const int bq = b1 + q < nblk ? b1 + q : nblk - 1;
+				const F4 w4 = *reinterpret_cast<const F4*>(Wb + (static_cast<int64_t>(bq) * nout + oc) * 4);
 #pragma unroll
-				for (int r = 0; r < 4; ++r) wn[4 * q + r] = ok ? w4.v[r] : 0.0f;
+				for (int r = 0; r < 4; ++r) wn[4 * q + r] = w4.v[r];
 			}
 			real acc = LL(s)[0];
 			const int nhere = (nin - i0 < kFcChunk) ? nin - i0 : kFcChunk;
+			if (nhere == kFcChunk) {   // straight-line block for full chunks
 #pragma unroll
-			for (int q = 0; q < kQ; ++q) {
-				if (4 * q >= nhere) break;
+				for (int e = 0; e < kFcChunk; ++e) acc += static_cast<real>(LL(wc)[e]) * lds[cur + e];
+			} else {
 #pragma unroll
-				for (int r = 0; r < 4; ++r) if (4 * q + r < nhere) acc += static_cast<real>(LL(wc)[4 * q + r]) * lds[cur + 4 * q + r];
+				for (int e = 0; e < kFcChunk; ++e) if (e < nhere) acc += static_cast<real>(LL(wc)[e]) * lds[cur + e];
 			}
 			LL(s)[0] = acc;
 			if (more) {
@@ -892,16 +904,19 @@ DTRL_HD inline void nn_eval(W& ws, const DevBuffers& buf, int env)
 	const float* p = buf.weights;
 	real* a = s0; real* bo = s1;
 	int cin = 1, wdt = d.n_terrain;
+	PROF_T0();
 	for (int l = 0; l < 3; ++l) {
 		const int co = d.conv_ch[l], k = d.conv_k[l], wo = wdt - k + 1;
 		const float* Wc = p; const float* bias = p + pad4(static_cast<int64_t>(co) * cin * k);
 		conv_layer(ws, Wc, bias, co, cin, k, wdt, a, bo);
 		p = bias + pad4(co); real* t2 = a; a = bo; bo = t2; cin = co; wdt = wo;
 	}
+	PROF_ADD(ws, kProfNNConv);
 	const int nflat = cin * wdt;
 	// terr_ip0: 5984 -> 64, output written right before the char features so the trunk input is contiguous
 	real* trunk_in = xchar - d.fc_terr;
-	fc_layer(ws, p, p + fc_dev_size(d.fc_terr, nflat), d.fc_terr, nflat, a, trunk_in, true);
+	{ PROF_T0(); fc_layer(ws, p, p + fc_dev_size(d.fc_terr, nflat), d.fc_terr, nflat, a, trunk_in, true); PROF_ADD(ws, kProfNNFcTerr); }
+	const unsigned long long prof_rest_t0 = PROF_NOW();
 	p += fc_dev_size(d.fc_terr, nflat) + pad4(d.fc_terr);
 	const int ntr = d.fc_terr + d.n_char;
 	real* trunk = s0;               // conv activations are dead now (a == s1 after three swaps, trunk_in lives in s1's tail)
@@ -921,6 +936,8 @@ DTRL_HD inline void nn_eval(W& ws, const DevBuffers& buf, int env)
 	LANES_BEGIN
 	for (int i = lane; i < d.out_size; i += kGroup) y[i] = y[i] / buf.out_scale[i] - buf.out_off[i];
 	LANES_END
+	PROF_ADD_SINCE(ws, kProfNNRest, prof_rest_t0);
+	PROF_COUNT(ws, kProfNNEvals);
 }
 
 // cDogController(MACE)::UpdateAction: ParseGround + BuildPoliState + action decision + ApplyAction
