@@ -10,6 +10,7 @@
 //      (cScenarioSimChar::UpdateGround, :564-572). Doing this at frame boundaries instead of every env-step is
 //      equivalent because the window is rebuilt 1 m before any sample can reach its end (DESIGN.md "Ground").
 #include "dtrl_engine.h"
+#include <algorithm>
 #include "../../include/dtrl.h"
 #include <cstddef>
 #include <cstring>
@@ -80,6 +81,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	buf_.tuple_env = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
 	buf_.tuple_count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));
 	d_env_list_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
+	d_order_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
 	buf_.prof = static_cast<unsigned long long*>(alloc(sizeof(unsigned long long) * kProfMax * n_));
 	if (!d_model_ || !buf_.st || !buf_.gr || !buf_.status || !buf_.poli_state || !buf_.tup_s0 || !buf_.tup_a || !buf_.tuple_rows || !buf_.tuple_flags || !buf_.tuple_env || !buf_.tuple_count)
 		return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
@@ -160,6 +162,13 @@ int Engine::HostFrameWork()
 			if (!UploadGround(e)) return DTRL_ERR_CAPACITY;
 		}
 	}
+	// longest-processing-time-first: a launch is as long as its slowest wavefront (a stumbling character with ~20 constraint
+	// rows per substep costs 3x a running one), so the envs that were costliest last frame are dispatched first
+	order_.resize(n_);
+	for (int e = 0; e < n_; ++e) order_[e] = e;
+	std::stable_sort(order_.begin(), order_.end(), [&](int32_t a, int32_t b) { return status_[a].cost > status_[b].cost; });
+	if (!be_->H2D(d_order_, order_.data(), sizeof(int32_t) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	order_valid_ = true;
 	return ApplyResets(reset_ids_);
 }
 
@@ -168,7 +177,9 @@ int Engine::Step(double dt)
 	if (dt <= 0) return DTRL_OK;   // cScenarioSimChar::Update returns early (scenarios/ScenarioSimChar.cpp:148-151)
 	if (cfg_.model.has_net && !policy_set_) return Fail(DTRL_ERR_ARG, "policy_net was given but dtrl_set_policy has not been called");
 	const int steps = cfg_.model.num_update_steps;
-	if (!be_->Launch(d_model_, cfg_.run, buf_, n_, steps, dt / steps, true)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	DevBuffers b = buf_;
+	if (order_valid_) b.env_list = d_order_;
+	if (!be_->Launch(d_model_, cfg_.run, b, n_, steps, dt / steps, true)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	return HostFrameWork();
 }
 
@@ -177,7 +188,9 @@ int Engine::StepUpdates(int n)
 	if (n <= 0) return DTRL_OK;
 	if (cfg_.model.has_net && !policy_set_) return Fail(DTRL_ERR_ARG, "policy_net was given but dtrl_set_policy has not been called");
 	const double dt = (1.0 / 30.0) / cfg_.model.num_update_steps;
-	if (!be_->Launch(d_model_, cfg_.run, buf_, n_, n, dt, false)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	DevBuffers b = buf_;
+	if (order_valid_) b.env_list = d_order_;
+	if (!be_->Launch(d_model_, cfg_.run, b, n_, n, dt, false)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	return HostFrameWork();
 }
 

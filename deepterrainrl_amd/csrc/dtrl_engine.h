@@ -60,6 +60,9 @@ private:
 	int HostFrameWork();
 	int ApplyResets(const std::vector<int32_t>& ids);
 	int32_t* d_env_list_ = nullptr;
+	int32_t* d_order_ = nullptr;         // launch order of the full-batch frame launches (costliest env first)
+	std::vector<int32_t> order_;
+	bool order_valid_ = false;
 	std::vector<int32_t> reset_ids_;
 	bool UploadGround(int env);
 	int EnvIndex(const int32_t* env_ids, int i) const { return env_ids ? env_ids[i] : i; }

@@ -462,7 +462,7 @@ bool ParseDeployPrototxt(const std::string& path, NetDesc& d, std::string& err)
 	d.n_char = dims.back() - d.n_terrain;
 	d.fc_terr = ips["terr_ip0"]; d.fc_trunk = ips["ip0"]; d.fc_head = ips["val_ip0"]; d.n_frags = ips["val_ip1"]; d.frag_size = ips["a0_ip1"];
 	if (d.n_frags > kMaxFrags) { err = "too many actor fragments"; return false; }
-	for (int l = 0; l < 3; ++l) if (d.conv_ch[l] % 8 != 0 || d.conv_ch[l] > 32 || d.conv_k[l] > 8 || d.conv_ch[l] * d.conv_k[l] > 128) { err = path + ": conv layer outside the supported family (channels multiple of 8 and <= 32, kernel <= 8, channels*kernel <= 128)"; return false; }
+	for (int l = 0; l < 3; ++l) if (d.conv_ch[l] % 16 != 0 || d.conv_ch[l] > 32 || d.conv_k[l] > 8 || d.conv_ch[l] * d.conv_k[l] > 128) { err = path + ": conv layer outside the supported family (channels 16 or 32, kernel <= 8, channels*kernel <= 128)"; return false; }
 	d.in_size = d.n_terrain + d.n_char; d.out_size = d.n_frags + d.n_frags * d.frag_size;
 	int64_t n = 0; int cin = 1, w = d.n_terrain;
 	for (int l = 0; l < 3; ++l) { n += static_cast<int64_t>(d.conv_ch[l]) * cin * d.conv_k[l] + d.conv_ch[l]; cin = d.conv_ch[l]; w = w - d.conv_k[l] + 1; }

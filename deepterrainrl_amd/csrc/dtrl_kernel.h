@@ -143,7 +143,8 @@ struct WSBase {
 		};
 	};
 	real red[8];
-	int32_t flag_update_action, flag_new_cycle, flag_misc, pad_;
+	int32_t flag_update_action, flag_new_cycle, flag_misc;
+	int32_t cost;   // see EnvStatus::cost (the host launches the costliest envs first: longest-processing-time-first)
 #if defined(DTRL_PROFILE)
 	unsigned long long prof[kProfMax];
 #endif
@@ -592,6 +593,7 @@ DTRL_HD inline void substep_ref(W& ws, const DevModel& gm, const GroundRec& g, r
 	{ PROF_T0(); build_rows(ws, h);
 	LANES_BEGIN
 	if (lane < ws.M.D) ws.u[lane] = ws.st.tau[lane] - ws.b[lane];
+	if (lane == 0) ws.cost += 8 + ws.R;
 	LANES_END
 	PROF_ADD(ws, kProfRows); }
 	{ PROF_T0(); forward_subst_rows(ws, ws.u); PROF_ADD(ws, kProfFsub); }
@@ -938,6 +940,9 @@ DTRL_HD inline void nn_eval(W& ws, const DevBuffers& buf, int env)
 	LANES_END
 	PROF_ADD_SINCE(ws, kProfNNRest, prof_rest_t0);
 	PROF_COUNT(ws, kProfNNEvals);
+	LANES_BEGIN
+	if (lane == 0) ws.cost += 280;
+	LANES_END
 }
 
 // cDogController(MACE)::UpdateAction: ParseGround + BuildPoliState + action decision + ApplyAction
@@ -1498,6 +1503,9 @@ DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, co
 	__syncthreads();
 #endif
 	load_hot_model(ws, gm);
+	LANES_BEGIN
+	if (lane == 0) ws.cost = 0;
+	LANES_END
 	{
 		const uint64_t* src = reinterpret_cast<const uint64_t*>(&buf.st[env]);
 		uint64_t* dst = reinterpret_cast<uint64_t*>(&ws.st);
@@ -1516,7 +1524,7 @@ DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, co
 		const uint64_t* src = reinterpret_cast<const uint64_t*>(&ws.st);
 		LANES_BEGIN
 		for (int i = lane; i < static_cast<int>(sizeof(EnvState) / 8); i += kGroup) dst[i] = src[i];
-		if (lane == 0) { buf.status[env].root_x = ws.st.q[0]; buf.status[env].need_reset = ws.st.need_reset; buf.status[env].n_tuples = 0; }
+		if (lane == 0) { buf.status[env].root_x = ws.st.q[0]; buf.status[env].need_reset = ws.st.need_reset; buf.status[env].cost = ws.cost; }
 		LANES_END
 	}
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DTRL_PROFILE)

@@ -312,6 +312,7 @@ struct FastPath {
 			{ PROF_T0(); build_rows_fast(ws, cp, h); PROF_ADD(ws, kProfRows); }
 		}
 		const int R = ws.R;
+		if (lane == 0) ws.cost += 8 + R;
 		{
 			PROF_T0();
 			// J_r[lane] from wave-uniform row descriptors and the lane's own joint position (registers): same value as row_jac()

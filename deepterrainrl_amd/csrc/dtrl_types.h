@@ -120,7 +120,7 @@ struct GroundRec {
 struct EnvStatus {
 	double root_x;
 	int32_t need_reset;
-	int32_t n_tuples;
+	int32_t cost;   // work estimate of the env's last frame: sum over substeps of (8 + constraint rows) + 280 per policy forward
 };
 
 // MACE network family (data/policies/*/nets/*_mace3_deploy.prototxt)
