@@ -258,9 +258,18 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 	__syncthreads();
 }
 
-// projected Gauss-Seidel in lambda space with the row state in registers: lane s owns row s (w_s, lambda_s, 1/A_ss, kind);
-// a row update is a handful of v_readlane broadcasts + one multiply-add per lane against column r of the packed Delassus
-// matrix (LDS). Same operations and order as pgs_solve().
+// projected Gauss-Seidel in lambda space with the row state in registers: lane s owns row s (w_s, lambda_s, 1/A_ss, kind).
+// The solve is one long dependent chain (10 sweeps x R row updates), so what matters is the number of DEPENDENT instructions
+// per update, not the instruction count. Every lane evaluates its own candidate update each step (lane r's is the one that
+// counts): the projection bounds [lo, hi] (normal rows [0, inf), tangent rows +-mu * lambda of the row before it, fetched with
+// a wave_shr:1 DPP move) are off the chain, leaving w -> mul -> sub -> max -> min -> sub -> readlane -> mul -> add.
+// Same operations on the same operands as pgs_solve(), hence the same bits; rows with a vanishing effective mass are skipped.
+__device__ __forceinline__ real wave_shr1(real v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);   // DPP wave_shr:1
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 {
 	const int lane = static_cast<int>(threadIdx.x);
@@ -268,25 +277,24 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 	const bool mine = lane < R;
 	real w = mine ? ws.wv[lane] : 0.0, lam = 0.0;
 	real rinv = 0.0;
-	if (mine) { const real ass = ws.Apk[lane * (lane + 3) / 2]; rinv = (ass >= 1e-12) ? 1.0 / ass : 0.0; }   // rows with a vanishing effective mass are skipped
-	const int kind = mine ? ws.row_kind[lane] : 0;
+	if (mine) { const real ass = ws.Apk[lane * (lane + 3) / 2]; rinv = (ass >= 1e-12) ? 1.0 / ass : 0.0; }
+	const bool tang = mine && ws.row_kind[lane] == 2;
+	const unsigned long long act = __ballot(rinv != 0.0);
 	const int tri = lane * (lane + 1) / 2;
+	const real inf = __builtin_huge_val();
 	real a_nx = mine ? ws.Apk[tri] : 0.0;   // column 0; the column of the next row update is fetched one update ahead
 	for (int it = 0; it < kPgsIters; ++it) {
 		for (int r = 0; r < R; ++r) {
 			const real a_sr = a_nx;
 			const int rn = (r + 1 < R) ? r + 1 : 0;
-			a_nx = mine ? ws.Apk[lane >= rn ? tri + rn : rn * (rn + 1) / 2 + lane] : 0.0;
-			const real ri = bcast(rinv, r);
-			if (ri != 0.0) {
-				const real lam_r = bcast(lam, r);
-				real nl = lam_r - bcast(w, r) * ri;
-				if (__builtin_amdgcn_readlane(kind, r) == 2) { const real lim = kMu * bcast(lam, r - 1); nl = fmin(fmax(nl, -lim), lim); }
-				else nl = fmax(nl, 0.0);
-				const real dl = nl - lam_r;
-				if (lane == r) lam = nl;
-				w += a_sr * dl;
-			}
+			{ const int mx = lane > rn ? lane : rn, mn = lane < rn ? lane : rn; a_nx = ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0]; }   // branch-free packed index
+			if (!((act >> r) & 1ull)) continue;
+			const real lim = kMu * wave_shr1(lam);
+			const real lo = tang ? -lim : 0.0, hi = tang ? lim : inf;
+			const real nl = fmin(fmax(lam - w * rinv, lo), hi);
+			const real dl = bcast(nl - lam, r);
+			if (lane == r) lam = nl;
+			w += a_sr * dl;
 		}
 	}
 	if (mine) ws.lam[lane] = lam;
