@@ -122,6 +122,23 @@ __device__ __forceinline__ real fsub_regs(const real (&h)[D], real z)
 	}
 	return z;
 }
+// NR right-hand sides at once: the substitution is a 22-step dependent chain per right-hand side, so interleaving independent
+// chains divides the exposed latency at the same instruction count
+template <int D, int NR>
+__device__ __forceinline__ void fsub_regs_n(const real (&h)[D], real (&z)[NR])
+{
+	const int lane = static_cast<int>(threadIdx.x);
+#pragma unroll
+	for (int k = 0; k < D - 1; ++k) {
+		real zk[NR];
+#pragma unroll
+		for (int j = 0; j < NR; ++j) zk[j] = bcast(z[j], k);
+		if (lane > k) {
+#pragma unroll
+			for (int j = 0; j < NR; ++j) z[j] -= h[k] * zk[j];
+		}
+	}
+}
 // x = L^-T u
 template <int D>
 __device__ __forceinline__ real bsub_regs(const real (&h)[D], real u)
@@ -328,22 +345,34 @@ struct FastPath {
 			const real mypx = hinge ? ws.px[lane - 2] : 0.0, mypy = hinge ? ws.py[lane - 2] : 0.0;
 			const uint32_t mysub = hinge ? ws.M.sub_mask[lane - 2] : 0u;
 			const real rhs0 = (lane < D) ? (ws.st.tau[lane] - ws.b[lane]) : 0.0;
-			for (int r = 0; r <= R; ++r) {
-				real z = rhs0;
-				if (r < R) {
-					const int kind = ws.row_kind[r], link = ws.row_link[r];
-					const real dx = ws.row_dx[r];
-					if (kind == 0) z = (lane == link + 2) ? dx : 0.0;
-					else {
-						const real dy = ws.row_dy[r], x = ws.row_x[r], y = ws.row_y[r];
-						z = 0.0;
-						if (lane == 0) z = dx;
-						else if (lane == 1) z = dy;
-						else if ((mysub >> link) & 1u) z = dx * (-(y - mypy)) + dy * (x - mypx);
-					}
-				}
-				z = fsub_regs<D>(hrow, z);
-				if (lane < D) ws.Z[r][lane] = z;
+			// J_r^T for row r (r < R), the free right-hand side for r == R
+			auto rhs_of = [&](int r) -> real {
+				if (r >= R) return rhs0;
+				const int kind = ws.row_kind[r], link = ws.row_link[r];
+				const real dx = ws.row_dx[r];
+				if (kind == 0) return (lane == link + 2) ? dx : 0.0;
+				const real dy = ws.row_dy[r], x = ws.row_x[r], y = ws.row_y[r];
+				if (lane == 0) return dx;
+				if (lane == 1) return dy;
+				return ((mysub >> link) & 1u) ? dx * (-(y - mypy)) + dy * (x - mypx) : 0.0;
+			};
+			int r0 = 0;
+			for (; r0 + 4 <= R + 1; r0 += 4) {
+				real z[4] = {rhs_of(r0), rhs_of(r0 + 1), rhs_of(r0 + 2), rhs_of(r0 + 3)};
+				fsub_regs_n<D, 4>(hrow, z);
+#pragma unroll
+				for (int j = 0; j < 4; ++j) if (lane < D) ws.Z[r0 + j][lane] = z[j];
+			}
+			if (r0 + 2 <= R + 1) {
+				real z[2] = {rhs_of(r0), rhs_of(r0 + 1)};
+				fsub_regs_n<D, 2>(hrow, z);
+				if (lane < D) { ws.Z[r0][lane] = z[0]; ws.Z[r0 + 1][lane] = z[1]; }
+				r0 += 2;
+			}
+			if (r0 <= R) {
+				real z[1] = {rhs_of(r0)};
+				fsub_regs_n<D, 1>(hrow, z);
+				if (lane < D) ws.Z[r0][lane] = z[0];
 			}
 			__syncthreads();
 			PROF_ADD(ws, kProfFsub);
