@@ -65,7 +65,7 @@
 
 namespace dtrl {
 
-enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfRows, kProfFsub, kProfDelassus, kProfPgs, kProfFinish, kProfCtrl, kProfAction, kProfFrameIO, kProfTotal, kProfRowsSum, kProfSubsteps, kProfP1, kProfP2, kProfP3, kProfP4, kProfR0, kProfR1_6, kProfR7_12, kProfR13_18, kProfR19_24, kProfT0, kProfT1_6, kProfT7_12, kProfT13_18, kProfT19_24, kProfNNConv, kProfNNFcTerr, kProfNNRest, kProfNNEvals, kProfMax };
+enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfRows, kProfFsub, kProfDelassus, kProfPgs, kProfFinish, kProfCtrl, kProfAction, kProfFrameIO, kProfTotal, kProfRowsSum, kProfSubsteps, kProfP1, kProfP2, kProfP3, kProfP4, kProfR0, kProfR1_6, kProfR7_12, kProfR13_18, kProfR19_24, kProfT0, kProfT1_6, kProfT7_12, kProfT13_18, kProfT19_24, kProfNNConv, kProfNNFcTerr, kProfNNRest, kProfNNEvals, kProfC_Fsm, kProfC_Feedback, kProfC_PdSetup, kProfC_PdSolve, kProfC_Grav, kProfC_Tail, kProfMax };
 
 // hot, read-mostly model fields staged in LDS (per-substep readers only; the controller's once-per-env-step gains, torque
 // limits and body angles stay in the HBM/L2-resident DevModel)
@@ -1111,6 +1111,7 @@ DTRL_HD inline void controller_update(W& ws, const DevModel& gm, const RunParams
 {
 	const int D = ws.M.D, L = ws.M.L;
 	const bool raptor = gm.char_type == 1;
+	unsigned long long pc_t = PROF_NOW();
 	// UpdateRBDModel: kinematics, composite inertias and the (quirk) bias at the post-step configuration were produced by
 	// kin_dyn_terms(ws, true) in env_step; H itself is assembled inside the PD solve
 	LANES_BEGIN
@@ -1145,6 +1146,7 @@ DTRL_HD inline void controller_update(W& ws, const DevModel& gm, const RunParams
 		ws.flag_update_action = do_update;
 	}
 	LANES_END
+	PROF_ADD_SINCE(ws, kProfC_Fsm, pc_t); pc_t = PROF_NOW();
 	if (__builtin_expect(ws.flag_update_action != 0, 0)) {   // once per gait cycle: cold, keep its register pressure out of the step loop
 		PROF_T0();
 		update_action(ws, gm, rp, buf, g, env);
@@ -1179,6 +1181,7 @@ DTRL_HD inline void controller_update(W& ws, const DevModel& gm, const RunParams
 		}
 	}
 	LANES_END
+	PROF_ADD_SINCE(ws, kProfC_Feedback, pc_t); pc_t = PROF_NOW();
 	// cImpPDController::CalcControlForces: (H + dt Kd) acc = Kp (e - dt qd) + Kd e_dot - C;  tau = Kp (e - dt qd) + Kd (e_dot - dt acc)
 	// inactive controllers (raptor stance hip) drop out of Kp/Kd but their raw Kd stays on the diagonal (sim/ImpPDController.cpp:244-258)
 	LANES_BEGIN
@@ -1197,7 +1200,9 @@ DTRL_HD inline void controller_update(W& ws, const DevModel& gm, const RunParams
 		ws.u[i] = kp * (pe - dt * ws.st.qd[i]) + kd * ve - ws.b[i];
 	}
 	LANES_END
+	PROF_ADD_SINCE(ws, kProfC_PdSetup, pc_t); pc_t = PROF_NOW();
 	Path::pd_solve(ws, dt);
+	PROF_ADD_SINCE(ws, kProfC_PdSolve, pc_t); pc_t = PROF_NOW();
 	LANES_BEGIN
 	if (lane < D) { const int i = lane; ws.tau_g[i] = 0; ws.st.tau_ctrl[i] = ws.kpv[i] * (ws.perr[i] - dt * ws.st.qd[i]) + ws.kdv[i] * (ws.verr[i] - dt * ws.u[i]); }
 	LANES_END
@@ -1246,6 +1251,7 @@ DTRL_HD inline void controller_update(W& ws, const DevModel& gm, const RunParams
 		}
 		LANES_END
 	}
+	PROF_ADD_SINCE(ws, kProfC_Grav, pc_t); pc_t = PROF_NOW();
 	if (raptor) {
 		// ApplyStanceFeedback :933-983: the stance hip balances the swing hip torque and servoes the root pitch
 		LANES_BEGIN
@@ -1302,6 +1308,7 @@ DTRL_HD inline void controller_update(W& ws, const DevModel& gm, const RunParams
 		ws.st.tau[d] = t;
 	}
 	LANES_END
+	PROF_ADD_SINCE(ws, kProfC_Tail, pc_t);
 }
 
 // dog reward, sim/DogController.cpp:594-628

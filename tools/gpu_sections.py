@@ -6,7 +6,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import deepterrainrl_amd as da
 import bench
-NAMES = ["FK", "Mass", "Bias", "Fact", "Detect", "Rows", "Fsub", "Delassus", "Pgs", "Finish", "Ctrl(incl Action)", "Action", "FrameIO", "Total", "RowsSum", "Substeps", "P1cum", "P2cum", "P3cum", "P4cum", "nR0", "nR1_6", "nR7_12", "nR13_18", "nR19_24", "tR0", "tR1_6", "tR7_12", "tR13_18", "tR19_24", "nnConv", "nnFcTerr", "nnRest", "nnEvals"]
+NAMES = ["FK", "Mass", "Bias", "Fact", "Detect", "Rows", "Fsub", "Delassus", "Pgs", "Finish", "Ctrl(incl Action)", "Action", "FrameIO", "Total", "RowsSum", "Substeps", "P1cum", "P2cum", "P3cum", "P4cum", "nR0", "nR1_6", "nR7_12", "nR13_18", "nR19_24", "tR0", "tR1_6", "tR7_12", "tR13_18", "tR19_24", "nnConv", "nnFcTerr", "nnRest", "nnEvals", "cFsm", "cFeedback(+action)", "cPdSetup", "cPdSolve", "cGrav", "cTail"]
 lib = os.path.join(REPO, "deepterrainrl_amd", "lib", "libdtrl_prof.so")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 b = da.BatchScenario(bench.ARG_FILE, n, data_root=bench.ROOT, extra_args={"terrain_seed": 20260925, "rand_seed": 1}, _lib_path=lib)
@@ -31,3 +31,5 @@ for k, nm in enumerate(["R=0", "R 1-6", "R 7-12", "R 13-18", "R 19-24"]):
     print("  substeps with %-8s %5.1f%% of substeps, %5.1f%% of substep time, %8.0f ticks each" % (nm, 100 * ns[k] / max(ns.sum(), 1), 100 * ts[k] / max(ts.sum(), 1), ts[k] / max(ns[k], 1)))
 ne = max(v[33], 1)
 print("  policy forward: %d evals, per eval: conv %.0f, terr_ip0 %.0f, rest %.0f ticks" % (v[33], v[30] / ne, v[31] / ne, v[32] / ne))
+for k in range(34, 40):
+    print("  ctrl %-20s %10.1f ticks/env-step" % (NAMES[k], v[k] / steps))
