@@ -122,7 +122,12 @@ def main():
     if rank == 0:
         env_steps_per_launch = n * steps_per_frame
         ach = B_ALG * env_steps_per_launch / (kern_ms * 1e-3) / 1e9
-        traffic = os.environ.get("DTRL_PMC_TRAFFIC_BYTES")   # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if provided
+        # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure comes from the latest committed
+        # rocprofv3 --pmc passes of this same command (tools/gpu_profile.sh -> tools/rocpd_summary.py -> profiles/hbm_traffic.json)
+        traffic = None
+        tj = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        if os.path.exists(tj) and n == ENVS_PER_GPU:
+            traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
         line = {
             "metric": "env-steps/sec (batched rollout) dog/slopes_mixed", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
