@@ -28,6 +28,7 @@ Engine::~Engine()
 	if (be_) {
 		be_->Sync();
 		for (void* p : allocs_) be_->Free(p);
+		be_->FreeHostStaging(pin_recs_); be_->FreeHostStaging(pin_order_); be_->FreeHostStaging(pin_ids_);
 		delete be_;
 	}
 }
@@ -82,6 +83,10 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	buf_.tuple_count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));
 	d_env_list_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
 	d_order_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
+	pin_recs_ = static_cast<GroundRec*>(be_->HostStaging(sizeof(GroundRec) * n_));
+	pin_order_ = static_cast<int32_t*>(be_->HostStaging(sizeof(int32_t) * n_));
+	pin_ids_ = static_cast<int32_t*>(be_->HostStaging(sizeof(int32_t) * n_));
+	if (!pin_recs_ || !pin_order_ || !pin_ids_) return Fail(DTRL_ERR_DEVICE, "host staging allocation failed: " + be_->error());
 	buf_.prof = static_cast<unsigned long long*>(alloc(sizeof(unsigned long long) * kProfMax * n_));
 	if (!d_model_ || !buf_.st || !buf_.gr || !buf_.status || !buf_.poli_state || !buf_.tup_s0 || !buf_.tup_a || !buf_.tuple_rows || !buf_.tuple_flags || !buf_.tuple_env || !buf_.tuple_count)
 		return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
@@ -130,23 +135,36 @@ bool Engine::UploadGround(int env)
 	if (!be_->H2D(&buf_.gr[env], &tmp_rec_, sizeof(GroundRec))) { err_ = be_->error(); return false; }
 	return true;
 }
+// frame-loop variant: the record is written into the page-locked arena and the copy is only queued
+bool Engine::UploadGroundAsync(int env)
+{
+	if (pin_recs_used_ >= n_) return UploadGround(env);
+	GroundRec* slot = &pin_recs_[pin_recs_used_++];
+	if (!grounds_[env].FillRecord(*slot, err_)) return false;
+	if (!be_->H2DAsync(&buf_.gr[env], slot, sizeof(GroundRec))) { err_ = be_->error(); return false; }
+	return true;
+}
 
 // device-side half of a reset (cSimCharacter::Reset + controller reset + InitCharacterPos), on the listed envs only:
 // a compact 0-step launch, so getters observe the reset state right after Update() as with the reference
 int Engine::ApplyResets(const std::vector<int32_t>& ids)
 {
 	if (ids.empty()) return DTRL_OK;
-	if (!be_->H2D(d_env_list_, ids.data(), sizeof(int32_t) * ids.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
+	std::memcpy(pin_ids_, ids.data(), sizeof(int32_t) * ids.size());
+	if (!be_->H2DAsync(d_env_list_, pin_ids_, sizeof(int32_t) * ids.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
 	DevBuffers b = buf_;
 	b.env_list = d_env_list_;
+	b.reset_listed = 1;
 	if (!be_->Launch(d_model_, cfg_.run, b, static_cast<int>(ids.size()), 0, 0.0, false)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	return DTRL_OK;
 }
 
 int Engine::HostFrameWork()
 {
+	// the status read-back synchronises the stream: every upload queued during the previous frame has completed, so the
+	// staging arena can be reused from the start
 	if (!be_->D2H(status_.data(), buf_.status, sizeof(EnvStatus) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
-	const int32_t one = 1;
+	pin_recs_used_ = 0;
 	reset_ids_.clear();
 	for (int e = 0; e < n_; ++e) {
 		const EnvStatus& s = status_[e];
@@ -155,19 +173,22 @@ int Engine::HostFrameWork()
 			// cScenarioSimChar::ResetGround: Clear + Update around the spawn point -> InitSegments with the SAME rng stream
 			g.Clear();
 			g.Update(-kViewDist + kGroundSpawnOffset, kViewDist + kGroundSpawnOffset);
-			if (!UploadGround(e)) return DTRL_ERR_CAPACITY;
-			if (!be_->H2D(reinterpret_cast<char*>(&buf_.st[e]) + offsetof(EnvState, do_reset), &one, sizeof(one))) return Fail(DTRL_ERR_DEVICE, be_->error());
+			if (!UploadGroundAsync(e)) return DTRL_ERR_CAPACITY;
 			reset_ids_.push_back(e);
 		} else if (g.Update(s.root_x - 2, s.root_x + kViewDist + kViewPad)) {
-			if (!UploadGround(e)) return DTRL_ERR_CAPACITY;
+			if (!UploadGroundAsync(e)) return DTRL_ERR_CAPACITY;
 		}
 	}
 	// longest-processing-time-first: a launch is as long as its slowest wavefront (a stumbling character with ~20 constraint
-	// rows per substep costs 3x a running one), so the envs that were costliest last frame are dispatched first
-	order_.resize(n_);
-	for (int e = 0; e < n_; ++e) order_[e] = e;
-	std::stable_sort(order_.begin(), order_.end(), [&](int32_t a, int32_t b) { return status_[a].cost > status_[b].cost; });
-	if (!be_->H2D(d_order_, order_.data(), sizeof(int32_t) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	// rows per substep costs 3x a running one), so the envs that were costliest last frame are dispatched first.
+	// Counting sort on cost / 16 (stable, O(n)).
+	constexpr int kBuckets = 1024;
+	bucket_.assign(kBuckets + 1, 0);
+	auto key = [&](int e) { int k = status_[e].cost >> 4; if (k < 0) k = 0; if (k >= kBuckets) k = kBuckets - 1; return kBuckets - 1 - k; };
+	for (int e = 0; e < n_; ++e) ++bucket_[key(e) + 1];
+	for (int k = 0; k < kBuckets; ++k) bucket_[k + 1] += bucket_[k];
+	for (int e = 0; e < n_; ++e) pin_order_[bucket_[key(e)]++] = e;
+	if (!be_->H2DAsync(d_order_, pin_order_, sizeof(int32_t) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	order_valid_ = true;
 	return ApplyResets(reset_ids_);
 }
@@ -203,7 +224,6 @@ int Engine::RunFrames(int frames, double dt)
 int Engine::Reset(const int32_t* env_ids, int n, const uint64_t* seeds)
 {
 	const int cnt = env_ids ? n : n_;
-	const int32_t one = 1;
 	reset_ids_.clear();
 	for (int i = 0; i < cnt; ++i) {
 		int e = EnvIndex(env_ids, i);
@@ -213,7 +233,6 @@ int Engine::Reset(const int32_t* env_ids, int n, const uint64_t* seeds)
 		g.Clear();
 		g.Update(-kViewDist + kGroundSpawnOffset, kViewDist + kGroundSpawnOffset);
 		if (!UploadGround(e)) return DTRL_ERR_CAPACITY;
-		if (!be_->H2D(reinterpret_cast<char*>(&buf_.st[e]) + offsetof(EnvState, do_reset), &one, sizeof(one))) return Fail(DTRL_ERR_DEVICE, be_->error());
 		reset_ids_.push_back(e);
 	}
 	int rc = ApplyResets(reset_ids_);

@@ -16,6 +16,10 @@ public:
 	virtual void* Alloc(size_t bytes) = 0;   // zero-filled
 	virtual void Free(void* p) = 0;
 	virtual bool H2D(void* dst, const void* src, size_t n) = 0;
+	// stream-ordered upload without a host sync; src must come from HostStaging() and stay untouched until the next Sync()/D2H()
+	virtual bool H2DAsync(void* dst, const void* src, size_t n) = 0;
+	virtual void* HostStaging(size_t bytes) = 0;   // page-locked host memory (plain malloc in the test backend)
+	virtual void FreeHostStaging(void* p) = 0;
 	virtual bool D2H(void* dst, const void* src, size_t n) = 0;
 	virtual bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) = 0;
 	virtual bool Sync() = 0;
@@ -61,10 +65,10 @@ private:
 	int ApplyResets(const std::vector<int32_t>& ids);
 	int32_t* d_env_list_ = nullptr;
 	int32_t* d_order_ = nullptr;         // launch order of the full-batch frame launches (costliest env first)
-	std::vector<int32_t> order_;
 	bool order_valid_ = false;
 	std::vector<int32_t> reset_ids_;
 	bool UploadGround(int env);
+	bool UploadGroundAsync(int env);
 	int EnvIndex(const int32_t* env_ids, int i) const { return env_ids ? env_ids[i] : i; }
 
 	ScenarioConfig cfg_;
@@ -77,6 +81,11 @@ private:
 	std::vector<GroundWindow> grounds_;
 	std::vector<EnvStatus> status_;
 	GroundRec tmp_rec_;
+	// page-locked staging for the per-frame uploads (terrain records, launch order, reset list): the copies are queued on the
+	// stream without a host sync; the arena is recycled after the next frame's status read-back (a stream sync)
+	GroundRec* pin_recs_ = nullptr; int pin_recs_used_ = 0;
+	int32_t* pin_order_ = nullptr; int32_t* pin_ids_ = nullptr;
+	std::vector<int32_t> bucket_;
 	std::string err_;
 };
 

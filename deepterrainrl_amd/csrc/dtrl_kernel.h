@@ -99,7 +99,8 @@ struct DevBuffers {
 	int32_t nn_scratch_stride;
 	int32_t model_D;           // host-known DoF count (selects the register-resident kernel instantiation)
 	unsigned long long* prof;  // [N][kProfMax] cycle counters (DTRL_PROFILE builds), else null
-	const int32_t* env_list;   // optional indirection: workgroup b handles env_list[b] (compact reset launches)
+	const int32_t* env_list;   // optional indirection: workgroup b handles env_list[b] (launch order, compact reset launches)
+	int32_t reset_listed;      // 1: every env of this launch performs the device half of a reset (compact reset launches)
 	const float* weights;
 	const real* in_off; const real* in_scale; const real* out_off; const real* out_scale;
 	NetDesc net;
@@ -1522,7 +1523,7 @@ DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, co
 	}
 	const GroundRec& g = buf.gr[env];
 	if (__builtin_expect(ws.st.do_init != 0, 0)) reset_env(ws, gm, rp, buf, g, env, true);
-	else if (__builtin_expect(ws.st.do_reset != 0, 0)) reset_env(ws, gm, rp, buf, g, env, false);
+	else if (__builtin_expect(ws.st.do_reset != 0 || buf.reset_listed != 0, 0)) reset_env(ws, gm, rp, buf, g, env, false);
 	else forward_kinematics(ws);
 	for (int s = 0; s < n_steps; ++s) env_step<Path>(ws, gm, rp, buf, g, env, dt);
 	if (do_frame_end) frame_end(ws, gm, buf, env);

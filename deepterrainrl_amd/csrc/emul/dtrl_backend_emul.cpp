@@ -16,6 +16,9 @@ public:
 	void* Alloc(size_t bytes) override { return std::calloc(1, bytes ? bytes : 1); }
 	void Free(void* p) override { std::free(p); }
 	bool H2D(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
+	bool H2DAsync(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
+	void* HostStaging(size_t bytes) override { return std::calloc(1, bytes ? bytes : 1); }
+	void FreeHostStaging(void* p) override { std::free(p); }
 	bool D2H(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
 	bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) override
 	{
