@@ -126,6 +126,9 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	std::memset(st.data(), 0, sizeof(EnvState) * n_);
 	for (int e = 0; e < n_; ++e) { st[e].do_init = 1; st[e].cmd_action = -1; }
 	if (!be_->H2D(buf_.st, st.data(), sizeof(EnvState) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	// cScenarioSimChar::Init on every env now (a 0-step launch), so getters and dtrl_set_pose_vel see / act on the initial state
+	// before the first step, as with the reference's Init()
+	if (!be_->Launch(d_model_, cfg_.run, buf_, n_, 0, 0.0, false) || !be_->Sync()) return Fail(DTRL_ERR_DEVICE, be_->error());
 	return DTRL_OK;
 }
 

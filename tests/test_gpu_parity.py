@@ -60,6 +60,10 @@ def test_set_pose_reset(da, om):
     T.test_set_pose_vel_and_reset_roundtrip(da, om)
 
 
+def test_row_cap_prone_character(da, om):
+    T.test_row_cap_prone_character_vs_oracle(da, om)
+
+
 def test_raptor_flat_and_narrow_gaps(da, om):
     """BASELINE config 2 (raptor, different KinTree topology, D = 21 kernel instantiation)."""
     T.test_raptor_flat_1200_substeps_vs_oracle(da, om)
