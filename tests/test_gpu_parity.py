@@ -64,6 +64,10 @@ def test_row_cap_prone_character(da, om):
     T.test_row_cap_prone_character_vs_oracle(da, om)
 
 
+def test_edge_inputs_and_error_paths(da, om):
+    T.test_edge_inputs_and_error_paths(da, om)
+
+
 def test_raptor_flat_and_narrow_gaps(da, om):
     """BASELINE config 2 (raptor, different KinTree topology, D = 21 kernel instantiation)."""
     T.test_raptor_flat_1200_substeps_vs_oracle(da, om)

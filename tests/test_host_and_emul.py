@@ -38,6 +38,41 @@ def test_arg_errors(da):
         b.Update()      # -policy_net= given but no weights pushed yet
 
 
+def test_edge_inputs_and_error_paths(da, om):
+    """Empty / out-of-range / undersized inputs follow the reference's bool + message convention (status + dtrl_last_error)."""
+    for n in (0, -3):
+        with pytest.raises(da.DtrlError):
+            batch(da, "args/sim_dog_args.txt", n)                       # empty batch
+    b = batch(da, "args/sim_dog_args.txt", 3, terrain_seed=4)
+    q0, qd0 = b.PoseVel()
+    b.Update(0.0)                                                       # dt <= 0: cScenarioSimChar::Update returns early
+    assert np.array_equal(b.PoseVel()[0], q0)
+    b.StepUpdates(0)
+    assert np.array_equal(b.PoseVel()[0], q0)
+    for bad in ([3], [-1], [0, 7]):
+        with pytest.raises(da.DtrlError):
+            b.PoseVel(bad)
+        with pytest.raises(da.DtrlError):
+            b.Reset(bad)
+    q, qd = b.PoseVel([2, 0])                                           # ragged / permuted id lists
+    assert np.array_equal(q[0], q0[2]) and np.array_equal(q[1], q0[0])
+    with pytest.raises(da.DtrlError):
+        b.SetPolicy(np.zeros(10, np.float32))                           # no -policy_net= in this batch
+    assert b.PolicyNumParams() == 0 and b.DrainTuples()[0].shape[0] == 0  # sim_char scenario records no tuples
+    # exploration batch: wrong weight count, undersized drain buffer
+    pol = dog_policy(om)
+    bx = batch(da, "args/opt_args_train_mace.txt", 6, terrain_seed=9, exp_base_rate=1.0)
+    with pytest.raises(da.DtrlError):
+        bx.SetPolicy(pol[1][:-1], *pol[2:])
+    bx.SetPolicy(pol[1], *pol[2:])
+    bx.RunFrames(40)
+    with pytest.raises(da.DtrlError):
+        bx.DrainTuples(cap=1)                                           # DTRL_ERR_CAPACITY: more tuples pending than the caller's buffer
+    rows, flags, ids = bx.DrainTuples()
+    assert rows.shape[0] > 1 and rows.shape[1] == 1 + 2 * bx.S + bx.A and set(ids) <= set(range(6))
+    assert bx.DrainTuples()[0].shape[0] == 0                            # ring is empty after a full drain
+
+
 @pytest.mark.parametrize("arg,seed", [("args/dog_slopes_mixed_args.txt", 17), ("args/sim_dog_args.txt", 2), ("args/opt_args_train_goat_mace.txt", 5), ("args/dog_narrow_gaps_args.txt", 9)])
 def test_ground_bit_exact_vs_oracle(da, om, arg, seed):
     """Terrain heights AND grid indices (segment, i, j) of the product's ground equal the oracle's for a sweep of x,
