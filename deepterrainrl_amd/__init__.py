@@ -32,7 +32,7 @@ TUPLE_FAIL, TUPLE_EXP_CRITIC, TUPLE_EXP_ACTOR = 1, 2, 4
 # every symbol include/dtrl.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = [
     "dtrl_create", "dtrl_destroy", "dtrl_reset", "dtrl_step", "dtrl_step_updates", "dtrl_run_frames", "dtrl_set_policy",
-    "dtrl_policy_num_params", "dtrl_build_output_offset_scale", "dtrl_set_explore", "dtrl_set_terrain_lerp", "dtrl_drain_tuples",
+    "dtrl_policy_num_params", "dtrl_build_output_offset_scale", "dtrl_load_scale_file", "dtrl_write_scale_file", "dtrl_set_explore", "dtrl_set_terrain_lerp", "dtrl_drain_tuples",
     "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
 ]
@@ -56,6 +56,8 @@ def _bind(path):
     L.dtrl_set_policy.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, vp]
     L.dtrl_policy_num_params.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.dtrl_build_output_offset_scale.argtypes = [vp, vp, vp]
+    L.dtrl_load_scale_file.argtypes = [vp, C.c_char_p]
+    L.dtrl_write_scale_file.argtypes = [vp, C.c_char_p]
     L.dtrl_set_explore.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double]
     L.dtrl_set_terrain_lerp.argtypes = [vp, C.c_double]
     L.dtrl_drain_tuples.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
@@ -155,6 +157,14 @@ class BatchScenario:
         off = np.zeros(self.nn_out); sc = np.zeros(self.nn_out)
         self._chk(self._lib.dtrl_build_output_offset_scale(self._h, _p(off), _p(sc)))
         return off, sc
+
+    def LoadScale(self, path):
+        """cNeuralNet::LoadScale: install the normaliser vectors of a '<model>_scale.txt' file (weights untouched)."""
+        self._chk(self._lib.dtrl_load_scale_file(self._h, os.fsencode(path)))
+
+    def WriteOffsetScale(self, path):
+        """cNeuralNet::WriteOffsetScale: write the current normalisers in the reference's file format."""
+        self._chk(self._lib.dtrl_write_scale_file(self._h, os.fsencode(path)))
 
     def SetExplore(self, enable, rate, temp, base_rate):
         self._chk(self._lib.dtrl_set_explore(self._h, int(enable), float(rate), float(temp), float(base_rate)))

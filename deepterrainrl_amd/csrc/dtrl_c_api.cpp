@@ -53,6 +53,8 @@ dtrl_status dtrl_build_output_offset_scale(const dtrl_batch* b, double* out_off,
 	for (size_t i = 0; i < off.size(); ++i) { out_off[i] = off[i]; out_scale[i] = sc[i]; }
 	return DTRL_OK;
 }
+dtrl_status dtrl_load_scale_file(dtrl_batch* b, const char* path) { CHECK_B(); return static_cast<dtrl_status>(b->eng.LoadScaleFile(path)); }
+dtrl_status dtrl_write_scale_file(dtrl_batch* b, const char* path) { CHECK_B(); return static_cast<dtrl_status>(b->eng.WriteScaleFile(path)); }
 dtrl_status dtrl_set_explore(dtrl_batch* b, int enable, double rate, double temp, double base_rate) { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetExplore(enable, rate, temp, base_rate)); }
 dtrl_status dtrl_set_terrain_lerp(dtrl_batch* b, double lerp) { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetTerrainLerp(lerp)); }
 dtrl_status dtrl_drain_tuples(dtrl_batch* b, float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n)

@@ -11,6 +11,7 @@
 //      equivalent because the window is rebuilt 1 m before any sample can reach its end (DESIGN.md "Ground").
 #include "dtrl_engine.h"
 #include <algorithm>
+#include <cstdio>
 #include "../../include/dtrl.h"
 #include <cstddef>
 #include <cstring>
@@ -276,15 +277,66 @@ int Engine::SetPolicy(const float* w, size_t n, const double* io, const double* 
 		for (int f = 0; f < d.n_frags; ++f) { block(d.fc_head, d.fc_trunk); block(d.frag_size, d.fc_head); }
 	}
 	w = dev_w.data();
-	std::vector<double> ones_i(d.in_size, 1.0), zeros_i(d.in_size, 0.0), ones_o(d.out_size, 1.0), zeros_o(d.out_size, 0.0);
-	// cNeuralNet without a scale file: identity normalisation (learning/NeuralNet.cpp:925-933)
-	bool ok = be_->H2D(const_cast<float*>(buf_.weights), w, sizeof(float) * dev_w.size())
-		&& be_->H2D(const_cast<real*>(buf_.in_off), io ? io : zeros_i.data(), sizeof(real) * d.in_size)
-		&& be_->H2D(const_cast<real*>(buf_.in_scale), is ? is : ones_i.data(), sizeof(real) * d.in_size)
-		&& be_->H2D(const_cast<real*>(buf_.out_off), oo ? oo : zeros_o.data(), sizeof(real) * d.out_size)
-		&& be_->H2D(const_cast<real*>(buf_.out_scale), os ? os : ones_o.data(), sizeof(real) * d.out_size);
-	if (!ok) return Fail(DTRL_ERR_DEVICE, be_->error());
+	// cNeuralNet without a scale file: identity normalisation (learning/NeuralNet.cpp:925-933) for every vector passed as NULL
+	if (io) in_off_.assign(io, io + d.in_size); else in_off_.assign(d.in_size, 0.0);
+	if (is) in_scale_.assign(is, is + d.in_size); else in_scale_.assign(d.in_size, 1.0);
+	if (oo) out_off_.assign(oo, oo + d.out_size); else out_off_.assign(d.out_size, 0.0);
+	if (os) out_scale_.assign(os, os + d.out_size); else out_scale_.assign(d.out_size, 1.0);
+	if (!be_->H2D(const_cast<float*>(buf_.weights), w, sizeof(float) * dev_w.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
+	int rc = UploadNormalizers();
+	if (rc != DTRL_OK) return rc;
 	policy_set_ = true;
+	return DTRL_OK;
+}
+
+int Engine::UploadNormalizers()
+{
+	const NetDesc& d = cfg_.net;
+	bool ok = be_->H2D(const_cast<real*>(buf_.in_off), in_off_.data(), sizeof(real) * d.in_size)
+		&& be_->H2D(const_cast<real*>(buf_.in_scale), in_scale_.data(), sizeof(real) * d.in_size)
+		&& be_->H2D(const_cast<real*>(buf_.out_off), out_off_.data(), sizeof(real) * d.out_size)
+		&& be_->H2D(const_cast<real*>(buf_.out_scale), out_scale_.data(), sizeof(real) * d.out_size);
+	return ok ? DTRL_OK : Fail(DTRL_ERR_DEVICE, be_->error());
+}
+
+// cNeuralNet::LoadScale, learning/NeuralNet.cpp:137-215
+int Engine::LoadScaleFile(const char* path)
+{
+	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
+	if (!path) return Fail(DTRL_ERR_ARG, "null path");
+	const NetDesc& d = cfg_.net;
+	Json root; std::string err;
+	if (!Json::parse_file(path, root, err)) return Fail(DTRL_ERR_IO, std::string("Failed to read scale file ") + path + ": " + err);
+	if (in_off_.empty()) { in_off_.assign(d.in_size, 0.0); in_scale_.assign(d.in_size, 1.0); out_off_.assign(d.out_size, 0.0); out_scale_.assign(d.out_size, 1.0); }
+	struct Slot { const char* key; std::vector<double>* vec; int size; const char* what; };
+	const Slot slots[4] = {{"InputOffset", &in_off_, d.in_size, "input offset"}, {"InputScale", &in_scale_, d.in_size, "input scale"},
+		{"OutputOffset", &out_off_, d.out_size, "output offset"}, {"OutputScale", &out_scale_, d.out_size, "output scale"}};
+	std::vector<double> tmp[4];
+	for (int k = 0; k < 4; ++k) {
+		const Json* j = root.find(slots[k].key);
+		if (!j || j->type == Json::kNull) continue;
+		if (j->type != Json::kArr) return Fail(DTRL_ERR_IO, std::string(slots[k].key) + " is not an array in " + path);
+		if (static_cast<int>(j->arr.size()) != slots[k].size)
+			return Fail(DTRL_ERR_IO, std::string("Invalid ") + slots[k].what + " size, expecting " + std::to_string(slots[k].size) + ", but got " + std::to_string(j->arr.size()));
+		for (const Json& v : j->arr) tmp[k].push_back(v.num);
+	}
+	for (int k = 0; k < 4; ++k) if (!tmp[k].empty()) *slots[k].vec = tmp[k];
+	be_->Sync();
+	return UploadNormalizers();
+}
+
+// cNeuralNet::WriteOffsetScale, learning/NeuralNet.cpp:1182-1205 (cJsonUtil::BuildVectorJson: std::to_string per element)
+int Engine::WriteScaleFile(const char* path)
+{
+	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
+	const NetDesc& d = cfg_.net;
+	if (in_off_.empty()) { in_off_.assign(d.in_size, 0.0); in_scale_.assign(d.in_size, 1.0); out_off_.assign(d.out_size, 0.0); out_scale_.assign(d.out_size, 1.0); }
+	FILE* f = path ? std::fopen(path, "w") : nullptr;
+	if (!f) return Fail(DTRL_ERR_IO, std::string("Failed to write offset and scale to ") + (path ? path : "(null)"));
+	auto vec_json = [](const std::vector<double>& v) { std::string s = "["; for (size_t i = 0; i < v.size(); ++i) { if (i) s += ", "; s += std::to_string(v[i]); } return s + "]"; };
+	std::fprintf(f, "{\n\"InputOffset\": %s,\n\"InputScale\": %s,\n\"OutputOffset\": %s,\n\"OutputScale\": %s\n}",
+		vec_json(in_off_).c_str(), vec_json(in_scale_).c_str(), vec_json(out_off_).c_str(), vec_json(out_scale_).c_str());
+	std::fclose(f);
 	return DTRL_OK;
 }
 

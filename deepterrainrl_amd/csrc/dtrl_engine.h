@@ -41,6 +41,8 @@ public:
 	int StepUpdates(int n);
 	int RunFrames(int frames, double dt);
 	int SetPolicy(const float* w, size_t n, const double* io, const double* is, const double* oo, const double* os);
+	int LoadScaleFile(const char* path);
+	int WriteScaleFile(const char* path);
 	int SetExplore(int enable, double rate, double temp, double base_rate);
 	int SetTerrainLerp(double lerp);
 	int DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n);
@@ -81,6 +83,8 @@ private:
 	std::vector<GroundWindow> grounds_;
 	std::vector<EnvStatus> status_;
 	GroundRec tmp_rec_;
+	std::vector<double> in_off_, in_scale_, out_off_, out_scale_;   // host copies of the policy normalisers (identity until set)
+	int UploadNormalizers();
 	// page-locked staging for the per-frame uploads (terrain records, launch order, reset list): the copies are queued on the
 	// stream without a host sync; the arena is recycled after the next frame's status read-back (a stream sync)
 	GroundRec* pin_recs_ = nullptr; int pin_recs_used_ = 0;

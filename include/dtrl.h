@@ -86,6 +86,13 @@ dtrl_status dtrl_policy_num_params(const dtrl_batch* b, size_t* n);
  * used by cScenarioTrain::SetupTrainerOutputOffsetScale (scenarios/ScenarioTrain.cpp:322-338). */
 dtrl_status dtrl_build_output_offset_scale(const dtrl_batch* b, double* out_off, double* out_scale);
 
+/* Replaces: cNeuralNet::LoadScale (learning/NeuralNet.cpp:137-215) and cNeuralNet::WriteOffsetScale (:1182-1205): the
+ * "<model>_scale.txt" normaliser files ({"InputOffset": [...], "InputScale": [...], "OutputOffset": [...], "OutputScale": [...]},
+ * values printed with std::to_string). Loading keeps the weights, replaces the vectors present in the file (absent keys keep their
+ * current value, a wrong length is an error, as in the reference); the batch must have been built with -policy_net=. */
+dtrl_status dtrl_load_scale_file(dtrl_batch* b, const char* path);
+dtrl_status dtrl_write_scale_file(dtrl_batch* b, const char* path);
+
 /* Replaces: cScenarioExp::EnableExplore / SetExpRate / SetExpTemp / SetExpBaseActionRate (scenarios/ScenarioExp.cpp:161-206). */
 dtrl_status dtrl_set_explore(dtrl_batch* b, int enable, double rate, double temp, double base_rate);
 

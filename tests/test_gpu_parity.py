@@ -68,6 +68,10 @@ def test_edge_inputs_and_error_paths(da, om):
     T.test_edge_inputs_and_error_paths(da, om)
 
 
+def test_scale_file_roundtrip(da, om, tmp_path):
+    T.test_scale_file_roundtrip(da, om, tmp_path)
+
+
 def test_raptor_flat_and_narrow_gaps(da, om):
     """BASELINE config 2 (raptor, different KinTree topology, D = 21 kernel instantiation)."""
     T.test_raptor_flat_1200_substeps_vs_oracle(da, om)

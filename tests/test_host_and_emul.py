@@ -38,6 +38,30 @@ def test_arg_errors(da):
         b.Update()      # -policy_net= given but no weights pushed yet
 
 
+def test_scale_file_roundtrip(da, om, tmp_path):
+    """cNeuralNet::LoadScale / WriteOffsetScale on the shipped '<model>_scale.txt' files: load -> forward equals pushing the
+    vectors with SetPolicy; write -> reload reproduces the file's 6-decimal values; wrong sizes are refused."""
+    pol = dog_policy(om)
+    scale = os.path.join(REFDATA, "data/policies/dog/models/dog_mace3_slopes_mixed_model_scale.txt")
+    a = batch(da, "args/dog_slopes_mixed_args.txt", 2, terrain_seed=11)
+    c = batch(da, "args/dog_slopes_mixed_args.txt", 2, terrain_seed=11)
+    a.SetPolicy(pol[1], *pol[2:])
+    c.SetPolicy(pol[1]); c.LoadScale(scale)
+    a.RunFrames(30); c.RunFrames(30)
+    assert np.array_equal(a.PoseVel()[0], c.PoseVel()[0]) and a.EvalStats() == c.EvalStats()
+    out = str(tmp_path / "roundtrip_scale.txt")
+    c.WriteOffsetScale(out)
+    io, isc, oo, osc = om.load_scale_file(out)
+    assert np.abs(io - pol[2]).max() < 5e-7 and np.abs(isc - pol[3]).max() < 5e-7 and np.abs(oo - pol[4]).max() < 5e-7 and np.abs(osc - pol[5]).max() < 5e-7
+    assert open(out).read().startswith('{\n"InputOffset": [')
+    with pytest.raises(da.DtrlError):
+        c.LoadScale(os.path.join(REFDATA, "data/policies/raptor/models/raptor_mace3_narrow_gaps_model_scale.txt"))   # 275/87 vs 283/90
+    with pytest.raises(da.DtrlError):
+        c.LoadScale(str(tmp_path / "missing.txt"))
+    with pytest.raises(da.DtrlError):
+        batch(da, "args/sim_dog_args.txt", 1).LoadScale(scale)    # no network in this batch
+
+
 def test_edge_inputs_and_error_paths(da, om):
     """Empty / out-of-range / undersized inputs follow the reference's bool + message convention (status + dtrl_last_error)."""
     for n in (0, -3):
