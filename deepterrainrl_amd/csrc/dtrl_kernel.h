@@ -173,6 +173,10 @@ struct WSFast : WSBase {
 // ------------------------------------------------------------------------------------------------------------------
 // small helpers
 
+// fused multiply-add a*b + c, spelled out (the build runs with -ffp-contract=off): the SAME fused operations in the lane-loop,
+// reference and register-resident builds keep the three bit-identical, and the solver's dependent chains are one op shorter per step
+DTRL_HD_INLINE real fmadd(real a, real b, real c) { return __builtin_fma(a, b, c); }
+
 DTRL_HD inline real wrap_pi(real a)
 {
 	const real pi = 3.14159265358979323846, two_pi = 6.283185307179586476925286766559;
@@ -382,7 +386,7 @@ DTRL_HD inline void factorize(W& ws)
 		if (lane > k && lane < D) {
 			const int i = lane;
 			real lik = ws.H[i][k] / ws.H[k][k];
-			for (int j = k + 1; j <= i; ++j) ws.H[i][j] -= lik * ws.H[j][k];
+			for (int j = k + 1; j <= i; ++j) ws.H[i][j] = fmadd(-lik, ws.H[j][k], ws.H[i][j]);
 			ws.H[k][i] = lik;
 		}
 		LANES_END
@@ -490,7 +494,7 @@ DTRL_HD inline void forward_subst_rows(W& ws, const real* rhs)
 		real* z = ws.Z[r];
 		for (int i = 0; i < D; ++i) {
 			real s = (r < R) ? row_jac(ws, r, i) : rhs[i];
-			for (int k = 0; k < i; ++k) s -= ws.H[k][i] * z[k];
+			for (int k = 0; k < i; ++k) s = fmadd(-ws.H[k][i], z[k], s);
 			z[i] = s;
 		}
 	}
@@ -508,7 +512,7 @@ DTRL_HD inline void build_delassus(W& ws, real h)
 		for (int r = 0; r <= s; ++r) {
 			real a = 0;
 #pragma unroll 13
-			for (int i = 0; i < kMaxD; ++i) { const real zs = ws.Z[s][i], zr = ws.Z[r][i], di = ws.dinv[i]; if (i < D) a += zs * zr * di; }
+			for (int i = 0; i < kMaxD; ++i) { const real zs = ws.Z[s][i], zr = ws.Z[r][i], di = ws.dinv[i]; if (i < D) a = fmadd(zs * zr, di, a); }
 			ws.A[s][r] = a;
 		}
 		real jv;
@@ -521,7 +525,7 @@ DTRL_HD inline void build_delassus(W& ws, real h)
 		}
 		real zz = 0;
 #pragma unroll 13
-		for (int i = 0; i < kMaxD; ++i) { const real zs = ws.Z[s][i], di = ws.dinv[i], z0 = ws.Z[R][i]; if (i < D) zz += zs * di * z0; }
+		for (int i = 0; i < kMaxD; ++i) { const real zs = ws.Z[s][i], di = ws.dinv[i], z0 = ws.Z[R][i]; if (i < D) zz = fmadd(zs * di, z0, zz); }
 		ws.wv[s] = jv + h * zz - ws.row_tgt[s];
 		ws.lam[s] = 0;
 		ws.rinv[s] = (ws.A[s][s] >= 1e-12) ? 1.0 / ws.A[s][s] : 0.0;   // rows with a vanishing effective mass are skipped
@@ -544,7 +548,7 @@ DTRL_HD inline void pgs_solve(W& ws)
 			if (lane == 0) {
 				real ri = ws.rinv[r], dl = 0;
 				if (ri != 0.0) {
-					real nl = ws.lam[r] - ws.wv[r] * ri;
+					real nl = fmadd(-ws.wv[r], ri, ws.lam[r]);
 					if (ws.row_kind[r] == 2) { real lim = kMu * ws.lam[r - 1]; nl = fmin(fmax(nl, -lim), lim); }
 					else nl = fmax(nl, 0.0);
 					dl = nl - ws.lam[r];
@@ -554,7 +558,7 @@ DTRL_HD inline void pgs_solve(W& ws)
 			}
 			LANES_END
 			LANES_BEGIN
-			if (lane < R) ws.wv[lane] += ws.A[lane][r] * ws.dl;
+			if (lane < R) ws.wv[lane] = fmadd(ws.A[lane][r], ws.dl, ws.wv[lane]);
 			LANES_END
 		}
 	}
@@ -569,13 +573,13 @@ DTRL_HD inline void finish_substep(W& ws, real h)
 	if (lane < D) {
 		const int i = lane;
 		real s = h * ws.Z[R][i];
-		for (int r = 0; r < R; ++r) s += ws.Z[r][i] * ws.lam[r];
+		for (int r = 0; r < R; ++r) s = fmadd(ws.Z[r][i], ws.lam[r], s);
 		ws.u[i] = s * ws.dinv[i];
 	}
 	LANES_END
 	for (int i = D - 1; i >= 1; --i) {
 		LANES_BEGIN
-		if (lane < i) ws.u[lane] -= ws.H[lane][i] * ws.u[i];
+		if (lane < i) ws.u[lane] = fmadd(-ws.H[lane][i], ws.u[i], ws.u[lane]);
 		LANES_END
 	}
 	LANES_BEGIN
@@ -808,7 +812,7 @@ DTRL_HD inline void conv_layer(W& ws, const float* Wd, const float* bias, int co
 				for (int ob = 0; ob < kMaxConvCh; ob += 8) {
 					if (ob >= co) break;
 #pragma unroll
-					for (int o = ob; o < ob + 8; ++o) LL(acc)[o] += wr[o] * x;
+					for (int o = ob; o < ob + 8; ++o) LL(acc)[o] = fmadd(wr[o], x, LL(acc)[o]);
 				}
 			}
 			if (more) {
@@ -871,10 +875,10 @@ DTRL_HD inline void fc_layer(W& ws, const float* Wb, const float* b, int nout, i
 			const int nhere = (nin - i0 < kFcChunk) ? nin - i0 : kFcChunk;
 			if (nhere == kFcChunk) {   // straight-line block for full chunks
 #pragma unroll
-				for (int e = 0; e < kFcChunk; ++e) acc += static_cast<real>(LL(wc)[e]) * lds[cur + e];
+				for (int e = 0; e < kFcChunk; ++e) acc = fmadd(static_cast<real>(LL(wc)[e]), lds[cur + e], acc);
 			} else {
 #pragma unroll
-				for (int e = 0; e < kFcChunk; ++e) if (e < nhere) acc += static_cast<real>(LL(wc)[e]) * lds[cur + e];
+				for (int e = 0; e < kFcChunk; ++e) if (e < nhere) acc = fmadd(static_cast<real>(LL(wc)[e]), lds[cur + e], acc);
 			}
 			LL(s)[0] = acc;
 			if (more) {
@@ -1079,7 +1083,7 @@ DTRL_HD inline void pd_solve_ref(W& ws, real dt)
 	LANES_END
 	for (int i = D - 1; i >= 1; --i) {
 		LANES_BEGIN
-		if (lane < i) ws.u[lane] -= ws.H[lane][i] * ws.u[i];
+		if (lane < i) ws.u[lane] = fmadd(-ws.H[lane][i], ws.u[i], ws.u[lane]);
 		LANES_END
 	}
 }

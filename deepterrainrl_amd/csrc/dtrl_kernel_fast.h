@@ -93,7 +93,7 @@ __device__ __forceinline__ real factorize_regs(WSFast& ws, real (&h)[D])
 #pragma unroll
 		for (int j = k + 1; j < D; ++j) {
 			const real ajk = bcast(ak, j);
-			if (lane >= j) h[j] -= lik * ajk;
+			if (lane >= j) h[j] = fmadd(-lik, ajk, h[j]);
 		}
 		if (lane > k) h[k] = lik;
 	}
@@ -118,7 +118,7 @@ __device__ __forceinline__ real fsub_regs(const real (&h)[D], real z)
 #pragma unroll
 	for (int k = 0; k < D - 1; ++k) {
 		const real zk = bcast(z, k);
-		if (lane > k) z -= h[k] * zk;
+		if (lane > k) z = fmadd(-h[k], zk, z);
 	}
 	return z;
 }
@@ -135,7 +135,7 @@ __device__ __forceinline__ void fsub_regs_n(const real (&h)[D], real (&z)[NR])
 		for (int j = 0; j < NR; ++j) zk[j] = bcast(z[j], k);
 		if (lane > k) {
 #pragma unroll
-			for (int j = 0; j < NR; ++j) z[j] -= h[k] * zk[j];
+			for (int j = 0; j < NR; ++j) z[j] = fmadd(-h[k], zk[j], z[j]);
 		}
 	}
 }
@@ -147,7 +147,7 @@ __device__ __forceinline__ real bsub_regs(const real (&h)[D], real u)
 #pragma unroll
 	for (int i = D - 1; i >= 1; --i) {
 		const real ui = bcast(u, i);
-		if (lane < i) u -= h[i] * ui;
+		if (lane < i) u = fmadd(-h[i], ui, u);
 	}
 	return u;
 }
@@ -252,7 +252,7 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 		const real* zr = ws.Z[r];
 		real a = 0;
 #pragma unroll
-		for (int i = 0; i < D; ++i) a += zs[i] * zr[i] * di[i];
+		for (int i = 0; i < D; ++i) a = fmadd(zs[i] * zr[i], di[i], a);
 		ws.Apk[e] = a;
 	}
 	if (lane < R) {
@@ -269,7 +269,7 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 		const real* z0 = ws.Z[R];
 		real zz = 0;
 #pragma unroll
-		for (int i = 0; i < D; ++i) zz += zs[i] * di[i] * z0[i];
+		for (int i = 0; i < D; ++i) zz = fmadd(zs[i] * di[i], z0[i], zz);
 		ws.wv[s] = jv + h * zz - ws.row_tgt[s];
 	}
 	__syncthreads();
@@ -308,10 +308,10 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 			if (!((act >> r) & 1ull)) continue;
 			const real lim = kMu * wave_shr1(lam);
 			const real lo = tang ? -lim : 0.0, hi = tang ? lim : inf;
-			const real nl = fmin(fmax(lam - w * rinv, lo), hi);
+			const real nl = fmin(fmax(fmadd(-w, rinv, lam), lo), hi);
 			const real dl = bcast(nl - lam, r);
 			if (lane == r) lam = nl;
-			w += a_sr * dl;
+			w = fmadd(a_sr, dl, w);
 		}
 	}
 	if (mine) ws.lam[lane] = lam;
@@ -386,7 +386,7 @@ struct FastPath {
 			real u = 0;
 			if (lane < D) {
 				real s = h * ws.Z[R][lane];
-				for (int r = 0; r < R; ++r) s += ws.Z[r][lane] * ws.lam[r];
+				for (int r = 0; r < R; ++r) s = fmadd(ws.Z[r][lane], ws.lam[r], s);
 				u = s * dinv;
 			}
 			u = bsub_regs<D>(hrow, u);
