@@ -21,7 +21,7 @@ def main(src, dst):
     db = os.path.join(src, "stats", "stats_results.db")
     if os.path.exists(db):
         cur = sqlite3.connect(db).cursor()
-        out.append("## rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 10 --no-cpu-baseline")
+        out.append("## rocprofv3 --kernel-trace --stats -- python bench.py --steps 60 --warmup 20 --no-cpu-baseline")
         out.append("%-60s %8s %14s %14s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for r in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
             out.append("%-60s %8d %14.1f %14.1f %8.3f" % (r[0][:60], r[1], r[2], r[3], r[4]))
@@ -29,13 +29,16 @@ def main(src, dst):
         out.append("\n%s dispatches by grid size (threads): grid, n, avg_ms, min_ms, max_ms, vgpr, sgpr, lds_bytes, scratch_bytes" % KERNEL)
         for r in rows:
             out.append("  %8d %4d %10.3f %10.3f %10.3f %5s %5s %7s %7s" % (r[0], r[1], r[2] / 1e6, r[3] / 1e6, r[4] / 1e6, r[5], r[6], r[7], r[8]))
+        last = [r[0] for r in cur.execute("select duration from kernels where name like '%" + KERNEL + "%' and grid_x = (select max(grid_x) from kernels where name like '%" + KERNEL + "%') order by start desc limit 60")]
+        if last:
+            out.append("  timed region = last %d full-batch launches: avg %.3f ms (compare roofline.kernel_avg_ms of the bench line)" % (len(last), sum(last) / len(last) / 1e6))
         out.append("")
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_ic"):
         db = os.path.join(src, sub, "pmc_results.db")
         if not os.path.exists(db):
             continue
         cur = sqlite3.connect(db).cursor()
-        out.append("## rocprofv3 --pmc (%s pass) -- per-dispatch averages for %s (grid = full batch launches only)" % (sub, KERNEL))
+        out.append("## rocprofv3 --pmc (%s pass) -- per-dispatch averages for %s (grid = full batch launches only; bench.py --steps 20 --warmup 10)" % (sub, KERNEL))
         q = ("select counter_name, count(*), avg(value), max(grid_size) from counters_collection where kernel_name like '%" + KERNEL + "%' "
              "and grid_size = (select max(grid_size) from counters_collection where kernel_name like '%" + KERNEL + "%') group by counter_name order by counter_name")
         for r in cur.execute(q):
