@@ -1,0 +1,84 @@
+"""cScenarioTrain for the batched engine: exploration rollouts on the GPU feed the GPU MACE trainer, weights flow back.
+
+Mirrors scenarios/ScenarioTrain.cpp: ParseArgs (:44-73, the -trainer_* / -init_exp_* / *_anneal_iters keys of
+args/opt_args_train_mace.txt), InitTrainer + SetupTrainerOutputOffsetScale (:251-257, 322-338), UpdateExpScene (:369-404: when a
+scene's tuple buffer is full -> learner->Train(tuples) -> annealed exploration parameters and curriculum back into the scene).
+The reference runs one OS thread per scene, each handing 32 tuples (-tuple_buffer_size=) to the trainer per call; here all scenes
+advance together, the drained rows are fed in chunks of that size, and the policy is re-synchronised once per outer frame."""
+import os
+import re
+import time
+
+import numpy as np
+
+from . import BatchScenario
+from .trainer import MACETrainer, anneal
+
+
+def parse_arg_file(path):
+    """util/ArgParser.cpp:42-108 token format: -key= value (comments start with #)."""
+    out = {}
+    toks = re.sub(r"#[^\n]*", "", open(path).read()).split()
+    i = 0
+    while i < len(toks):
+        if toks[i].startswith("-") and toks[i].endswith("="):
+            key = toks[i][1:-1]; i += 1
+            vals = []
+            while i < len(toks) and not (toks[i].startswith("-") and toks[i].endswith("=")):
+                vals.append(toks[i]); i += 1
+            out[key] = " ".join(vals)
+        else:
+            i += 1
+    return out
+
+
+def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, device_id=-1, extra_args=None, seed=0, log_every=0, out_scale_file=None,
+          trainer_device=None, _lib_path=None):
+    """extra_args override / extend the arg file (both for the engine and for the -trainer_* keys read here)."""
+    args = parse_arg_file(os.path.join(data_root, arg_file))
+    args.update({k: str(v) for k, v in (extra_args or {}).items()})
+    geti = lambda k, d: int(args.get(k, d)); getf = lambda k, d: float(args.get(k, d))
+    b = BatchScenario(arg_file, num_envs, data_root=data_root, device_id=device_id, extra_args=extra_args, _lib_path=_lib_path)
+    solver = os.path.join(data_root, args["policy_solver"])
+    train_net = os.path.join(data_root, re.search(r'net:\s*"([^"]+)"', open(solver).read()).group(1)) if re.search(r'net:\s*"', open(solver).read()) \
+        else os.path.join(data_root, args["policy_net"].replace("_deploy", "_train"))
+    t = MACETrainer(train_net, solver, b.S, b.A, mem_size=geti("trainer_replay_mem_size", 500000), num_init_samples=geti("trainer_num_init_samples", 200),
+                    steps_per_iter=geti("trainer_num_steps_per_iters", 1), freeze_target_iters=geti("trainer_freeze_target_iters", 0),
+                    init_input_offset_scale=args.get("trainer_init_input_offset_scale", "false").lower() == "true", seed=seed, device=trainer_device)
+    t.SetOutputOffsetScale(*b.BuildNNOutputOffsetScale())
+    exp = dict(rate=getf("exp_rate", 0.2), temp=getf("exp_temp", 0.025), base=getf("exp_base_rate", 0.002))
+    init = dict(rate=getf("init_exp_rate", 1.0), temp=getf("init_exp_temp", 20.0), base=getf("init_exp_base_rate", 1.0))
+    n_anneal, n_base_anneal = geti("trainer_num_anneal_iters", 1), geti("exp_base_anneal_iters", 1)
+    n_curr = geti("trainer_curriculum_iters", 0)
+    chunk = max(1, geti("tuple_buffer_size", 32))
+    max_iters = max_iters if max_iters is not None else geti("trainer_max_iter", 10 ** 9)
+
+    def sync(it):
+        b.SetPolicy(t.GetWeights(), *t.GetOffsetScale())
+        b.SetExplore(1, anneal(it, n_anneal, init["rate"], exp["rate"]), anneal(it, n_anneal, init["temp"], exp["temp"]), anneal(it, n_base_anneal, init["base"], exp["base"]))
+        phase = 1.0 if n_curr < 1 else min(max(it / float(n_curr), 0.0), 1.0)    # CalcCurriculumPhase (gInitCurriculumPhase at iter 0)
+        b.SetTerrainParamsLerp(phase if it > 0 or n_curr < 1 else 0.0)
+
+    sync(0)
+    frames = tuples = 0
+    t0 = time.time()
+    stats = {"log": []}
+    while t.GetIter() < max_iters and (max_frames is None or frames < max_frames):
+        b.Update(1.0 / 30.0)
+        frames += 1
+        rows, flags, _ = b.DrainTuples()
+        for k in range(0, len(rows), chunk):
+            t.AddTuples(rows[k:k + chunk], flags[k:k + chunk])
+            t.Train()
+        tuples += len(rows)
+        if len(rows):
+            sync(t.GetIter())
+        if log_every and frames % log_every == 0:
+            stats["log"].append((frames, t.GetIter(), t.GetNumTuples(), t.last_loss, b.EvalStats()))
+            print("frame %d iter %d tuples %d critic-loss %s actor-iters %d" % (frames, t.GetIter(), t.GetNumTuples(), t.last_loss, t.actor_iter), flush=True)
+    dt = time.time() - t0
+    if out_scale_file:
+        b.WriteOffsetScale(out_scale_file)
+    stats.update(frames=frames, iters=t.GetIter(), tuples=tuples, seconds=dt, env_steps_per_s=frames * 20.0 * num_envs / dt,
+                 trainer_iters_per_s=t.GetIter() / dt, weights=t.GetWeights(), offset_scale=t.GetOffsetScale())
+    return stats

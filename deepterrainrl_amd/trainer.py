@@ -1,0 +1,369 @@
+"""MACE trainer on the GPU: the learner side of the rollout path, mirroring cMACETrainer / cNeuralNetTrainer.
+
+What the reference does per call and where it lives here:
+  cNeuralNetTrainer::AddTuple  (learning/NeuralNetTrainer.cpp:145-165, CheckTuple :541-576)   -> MACETrainer.AddTuples
+  cMACETrainer::UpdateBuffers  (learning/MACETrainer.cpp:731-799)                              -> MACETrainer._update_buffers
+  cNeuralNetTrainer::Train / UpdateStage / InitStage / UpdateOffsetScale (:175-183, 696-747)   -> MACETrainer.Train
+  cMACETrainer::Step           (learning/MACETrainer.cpp:346-372)                              -> MACETrainer.Step
+  critic targets BuildProblemY / CalcNewCumulativeRewardBatch (:226-250, 478-515)              -> MACETrainer._critic_problem
+  actor UpdateActorBatchBuffer / UpdateActor / StepActor (:577-633), BuildActorProblemY (:285-305)
+  cNeuralNet::LoadTrainData / Eval normalisation (learning/NeuralNet.cpp:1077-1122, 352-375, 964-1036)
+  Caffe SGDSolver step (base_lr, momentum, weight_decay from the solver prototxt; lr_mult / decay_mult per blob from the train
+  prototxt; EuclideanLoss = 1/(2N) sum ||y - label||^2): L2 regularise, history = momentum * history + lr * diff, w -= history.
+
+The replay memory, both networks (current + frozen target), the solver history and every batch stay resident on the device
+(torch tensors: PyTorch provides memory, autograd and the conv/GEMM calls); the host only keeps the index buffers. Rows arrive in
+the exact MACE replay layout the rollout engine emits ([r | s | a | s'], float32), so `dtrl_drain_tuples` output is appended as is.
+The only randomness is minibatch sampling (the reference uses its global RNG; a seeded numpy stream here).
+"""
+import re
+
+import numpy as np
+import torch
+
+FLAG_FAIL, FLAG_EXP_CRITIC, FLAG_EXP_ACTOR = 1, 2, 4   # tExpTuple flag bits as emitted by the rollout engine (include/dtrl.h)
+
+
+def _blocks(txt):
+    """Split a Caffe prototxt (or the fixture digest of one) into layer blocks with balanced braces."""
+    out = []
+    for m in re.finditer(r"\blayer\s*\{", txt):
+        depth, i = 1, m.end()
+        while depth and i < len(txt):
+            depth += {"{": 1, "}": -1}.get(txt[i], 0)
+            i += 1
+        out.append(txt[m.end():i - 1])
+    return out
+
+
+def parse_net(path):
+    """Topology + per-blob lr_mult / decay_mult of the MACE family (slice -> 3 conv1d -> terr_ip0 -> concat -> ip0 -> val / a* heads)."""
+    txt = open(path).read()
+    dims = [int(x) for x in re.findall(r"input_dim:\s*(\d+)", txt)]
+    layers = []
+    for blk in _blocks(txt):
+        g = lambda key, cast=int: (lambda m: cast(m.group(1)) if m else None)(re.search(key + r":\s*([-\d.eE]+)", blk))
+        mults = [(float((re.search(r"lr_mult:\s*([-\d.eE]+)", p) or [0, 1])[1]), float((re.search(r"decay_mult:\s*([-\d.eE]+)", p) or [0, 1])[1]))
+                 for p in re.findall(r"\bparam\s*\{([^}]*)\}", blk)]
+        layers.append({"name": re.search(r'name:\s*"([^"]+)"', blk).group(1), "type": re.search(r'type:\s*"([^"]+)"', blk).group(1),
+                       "num_output": g("num_output"), "kernel_w": g("kernel_w"), "slice_point": g("slice_point"),
+                       "batch_size": g("batch_size"), "width": g("width"), "mults": mults})
+    d = {"layers": layers}
+    data = [l for l in layers if l["type"] == "MemoryData"]
+    d["in_size"] = dims[-1] if dims else data[0]["width"]
+    d["batch_size"] = data[0]["batch_size"] if data else 1
+    d["n_terrain"] = [l for l in layers if l["type"] == "Slice"][0]["slice_point"]
+    d["convs"] = [l for l in layers if l["type"] == "Convolution"]
+    d["ips"] = {l["name"]: l for l in layers if l["type"] == "InnerProduct"}
+    d["n_frags"] = d["ips"]["val_ip1"]["num_output"]
+    d["frag_size"] = d["ips"]["a0_ip1"]["num_output"]
+    return d
+
+
+def parse_solver(path):
+    txt = open(path).read()
+    g = lambda key, dflt: (lambda m: float(m.group(1)) if m else dflt)(re.search(r"^\s*" + key + r":\s*([-\d.eE]+)", txt, re.M))
+    pol = re.search(r'lr_policy:\s*"([^"]+)"', txt)
+    return {"base_lr": g("base_lr", 0.01), "momentum": g("momentum", 0.0), "weight_decay": g("weight_decay", 0.0),
+            "lr_policy": pol.group(1) if pol else "fixed", "gamma": g("gamma", 0.1), "stepsize": g("stepsize", 1e18), "power": g("power", 0.75)}
+
+
+class MaceNet(torch.nn.Module):
+    """The dog/raptor *_mace3 net. Blob order (= the flat weight vector the rollout engine takes): conv0..2, terr_ip0, ip0,
+    val_ip0, val_ip1, a{f}_ip0, a{f}_ip1; weight then bias. Works in normalised input/output space like the Caffe net."""
+
+    def __init__(self, desc):
+        super().__init__()
+        self.n_terrain = desc["n_terrain"]
+        n_char = desc["in_size"] - self.n_terrain
+        mods, mults = [], []
+        cin, w = 1, self.n_terrain
+        for l in desc["convs"]:
+            mods.append(torch.nn.Conv1d(cin, l["num_output"], l["kernel_w"])); mults.append(l["mults"])
+            cin, w = l["num_output"], w - l["kernel_w"] + 1
+        ips = desc["ips"]
+        def lin(name, nin):
+            mods.append(torch.nn.Linear(nin, ips[name]["num_output"])); mults.append(ips[name]["mults"])
+            return ips[name]["num_output"]
+        n = lin("terr_ip0", cin * w)
+        n = lin("ip0", n + n_char)
+        nh = lin("val_ip0", n); lin("val_ip1", nh)
+        self.n_frags = desc["n_frags"]
+        for f in range(self.n_frags):
+            nh = lin("a%d_ip0" % f, n); lin("a%d_ip1" % f, nh)
+        self.mods = torch.nn.ModuleList(mods)
+        # (lr_mult, decay_mult) per blob, Caffe defaults 1 / 1 when a param block or a field is absent
+        self.blob_mults = []
+        for m in mults:
+            m = list(m) + [(1.0, 1.0)] * (2 - len(m))
+            self.blob_mults += [m[0], m[1]]
+
+    def blobs(self):
+        out = []
+        for m in self.mods:
+            out += [m.weight, m.bias]
+        return out
+
+    def forward(self, x):
+        relu = torch.nn.functional.relu
+        t = x[:, :self.n_terrain].unsqueeze(1)
+        for m in self.mods[:3]:
+            t = relu(m(t))
+        t = relu(self.mods[3](t.flatten(1)))
+        h = relu(self.mods[4](torch.cat([t, x[:, self.n_terrain:]], 1)))
+        outs = [self.mods[6](relu(self.mods[5](h)))]
+        for f in range(self.n_frags):
+            outs.append(self.mods[8 + 2 * f](relu(self.mods[7 + 2 * f](h))))
+        return torch.cat(outs, 1)
+
+    def get_flat(self):
+        return torch.cat([b.detach().reshape(-1) for b in self.blobs()]).to(torch.float32).cpu().numpy()
+
+    def set_flat(self, w):
+        w = torch.as_tensor(np.asarray(w), dtype=self.mods[0].weight.dtype, device=self.mods[0].weight.device)
+        off = 0
+        with torch.no_grad():
+            for b in self.blobs():
+                b.copy_(w[off:off + b.numel()].reshape(b.shape)); off += b.numel()
+        assert off == w.numel(), "weight count does not match the net"
+
+    def num_params(self):
+        return sum(b.numel() for b in self.blobs())
+
+
+class MACETrainer:
+    """cMACETrainer (pool size 1, synchronous mode)."""
+
+    def __init__(self, net_file, solver_file, state_size, action_size, mem_size=500000, num_init_samples=200, steps_per_iter=1,
+                 freeze_target_iters=0, discount=0.9, init_input_offset_scale=True, device=None, dtype=torch.float32, seed=0):
+        self.desc = parse_net(net_file)
+        self.solver = parse_solver(solver_file)
+        self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.dtype = dtype
+        self.S, self.A = state_size, action_size
+        self.num_frags, self.frag_size = self.desc["n_frags"], self.desc["frag_size"]
+        assert action_size == 1 + self.frag_size and self.desc["in_size"] == state_size
+        self.out_size = self.num_frags * (1 + self.frag_size)
+        self.batch = self.desc["batch_size"]
+        self.W = 1 + 2 * state_size + action_size                      # cMACETrainer::CalcBufferSize
+        self.mem_size, self.num_init_samples, self.steps_per_iter = mem_size, num_init_samples, steps_per_iter
+        self.freeze_target_iters, self.discount, self.init_input_offset_scale = freeze_target_iters, discount, init_input_offset_scale
+        self.net = MaceNet(self.desc).to(self.device, dtype)
+        self.target = MaceNet(self.desc).to(self.device, dtype)
+        self.history = [torch.zeros_like(b) for b in self.net.blobs()]
+        z = lambda n, v: torch.full((n,), v, device=self.device, dtype=dtype)
+        self.in_off, self.in_scale, self.out_off, self.out_scale = z(state_size, 0.0), z(state_size, 1.0), z(self.out_size, 0.0), z(self.out_size, 1.0)
+        self.mem = torch.zeros((mem_size, self.W), device=self.device, dtype=torch.float32)   # mPlaybackMem (float, as the reference)
+        self.flags = np.zeros(mem_size, np.int64)
+        self.rng = np.random.RandomState(seed)
+        self.Reset()
+        self.UpdateTargetNet()
+
+    # ---- cNeuralNetTrainer::ResetParams / cMACETrainer::Reset
+    def Reset(self):
+        self.total_tuples = self.num_tuples = self.head = self.iter = self.actor_iter = 0
+        self.stage_train = False
+        self.critic_buffer, self.critic_pos = [], {}
+        self.actor_buffer, self.actor_pos = [], {}
+        self.actor_batch_buffer = []
+        self.last_loss = self.last_actor_loss = None
+
+    # ---- weights / normalisers
+    def GetWeights(self): return self.net.get_flat()
+    def SetWeights(self, w):
+        self.net.set_flat(w); self.UpdateTargetNet()
+    def GetOffsetScale(self):
+        f = lambda t: t.detach().to(torch.float64).cpu().numpy()
+        return f(self.in_off), f(self.in_scale), f(self.out_off), f(self.out_scale)
+    def SetInputOffsetScale(self, off, scale):
+        self.in_off = torch.as_tensor(off, device=self.device, dtype=self.dtype); self.in_scale = torch.as_tensor(scale, device=self.device, dtype=self.dtype)
+    def SetOutputOffsetScale(self, off, scale):
+        self.out_off = torch.as_tensor(off, device=self.device, dtype=self.dtype); self.out_scale = torch.as_tensor(scale, device=self.device, dtype=self.dtype)
+    def GetIter(self): return self.iter
+    def GetNumTuples(self): return self.num_tuples
+    def EnableTargetNet(self): return self.freeze_target_iters > 0
+    def UpdateTargetNet(self):
+        """cMACETrainer::UpdateTargetNet; without freezing (freeze_target_iters == 0) the target IS the current net (GetTargetNetID)."""
+        self.target.load_state_dict(self.net.state_dict())
+
+    def _target_net(self):
+        return self.target if self.EnableTargetNet() else self.net
+
+    # ---- evaluation in unnormalised space (cNeuralNet::EvalBatch)
+    def _eval(self, net, X):
+        with torch.no_grad():
+            y = net((X.to(self.dtype) + self.in_off) * self.in_scale)
+            return y / self.out_scale - self.out_off
+    def Eval(self, X):
+        return self._eval(self.net, torch.as_tensor(np.atleast_2d(X), device=self.device)).to(torch.float64).cpu().numpy()
+
+    # ---- tuples
+    def AddTuples(self, rows, flags):
+        """rows [n, W] float in the MACE layout, flags [n] tExpTuple bits. Returns the slot of every row (-1 = rejected by CheckTuple)."""
+        rows = np.asarray(rows, np.float32).reshape(-1, self.W)
+        ok = np.all(np.isfinite(rows), axis=1)
+        slots = np.full(rows.shape[0], -1, np.int64)
+        keep = np.nonzero(ok)[0]
+        if keep.size:
+            slots[keep] = (self.head + np.arange(keep.size)) % self.mem_size
+            self.mem[torch.as_tensor(slots[keep], device=self.device)] = torch.as_tensor(rows[keep], device=self.device)
+            for i in keep:   # same order as the reference: write slot, advance head, then UpdateBuffers(slot)
+                t = int(slots[i])
+                self.flags[t] = int(flags[i])
+                self.head = (self.head + 1) % self.mem_size
+                self.num_tuples = min(self.mem_size, self.num_tuples + 1)
+                self.total_tuples += 1
+                self._update_buffers(t)
+        return slots
+
+    @staticmethod
+    def _buf_add(buf, pos, t):
+        if t not in pos:
+            pos[t] = len(buf); buf.append(t)
+
+    @staticmethod
+    def _buf_del(buf, pos, t):
+        if t in pos:   # move the last element into the hole (learning/MACETrainer.cpp:752-757, 774-779)
+            i = pos.pop(t); last = buf.pop()
+            if last != t:
+                buf[i] = last; pos[last] = i
+
+    def _update_buffers(self, t):
+        exp_actor = bool(self.flags[t] & FLAG_EXP_ACTOR)
+        if exp_actor:
+            self._buf_add(self.actor_buffer, self.actor_pos, t); self._buf_del(self.critic_buffer, self.critic_pos, t)
+        else:
+            self._buf_del(self.actor_buffer, self.actor_pos, t); self._buf_add(self.critic_buffer, self.critic_pos, t)
+        while t in self.actor_batch_buffer:
+            i = self.actor_batch_buffer.index(t); last = self.actor_batch_buffer.pop()
+            if i < len(self.actor_batch_buffer):
+                self.actor_batch_buffer[i] = last
+
+    # ---- stages
+    def UpdateOffsetScale(self):
+        """cNeuralNet::CalcOffsetScale over the stored begin states: offset = -mean, scale = 1 / population std (0 where std == 0)."""
+        X = self.mem[:self.num_tuples, 1:1 + self.S].to(torch.float64)
+        mean = X.mean(0)
+        std = ((X - mean) ** 2).mean(0).sqrt()
+        scale = torch.where(std == 0, torch.zeros_like(std), 1.0 / std)
+        self.SetInputOffsetScale(-mean, scale)
+
+    def Train(self):
+        if not self.stage_train and self.num_tuples >= self.num_init_samples and self.num_tuples > 0:
+            if self.num_init_samples > 1 and self.init_input_offset_scale:
+                self.UpdateOffsetScale()
+            self.stage_train = True
+        if self.stage_train:
+            self.ApplySteps(self.steps_per_iter)
+
+    def ApplySteps(self, n):
+        succ = False
+        for _ in range(n):
+            succ = self.Step()
+        if succ:
+            self.iter += 1
+
+    def Step(self):
+        ids = self.FetchMinibatch(self.batch)
+        succ = len(ids) >= self.batch
+        if succ:
+            X, Y = self._critic_problem(ids)
+            self.last_loss = self._solver_step(X, Y)
+        self.UpdateActor()
+        if self.EnableTargetNet() and self.iter > 0 and self.iter % self.freeze_target_iters == 0:
+            self.target.load_state_dict(self.net.state_dict())
+        return succ
+
+    # ---- critic
+    def FetchMinibatch(self, size):
+        n = len(self.critic_buffer)
+        if n < size:
+            return []
+        return [self.critic_buffer[int(self.rng.randint(0, n))] for _ in range(size)]
+
+    def _rows(self, ids):
+        return self.mem[torch.as_tensor(np.asarray(ids, np.int64), device=self.device)]
+
+    def _new_q(self, rows, ids):
+        """CalcNewCumulativeRewardBatch: r (1 - discount) + discount max_frag Q_target(s'), or r (1 - discount) on failure."""
+        r = rows[:, 0].to(self.dtype) * (1.0 - self.discount)
+        q_end = self._eval(self._target_net(), rows[:, 1 + self.S + self.A:])[:, :self.num_frags].max(1).values
+        fail = torch.as_tensor((self.flags[np.asarray(ids)] & FLAG_FAIL) != 0, device=self.device)
+        return torch.where(fail, r, r + self.discount * q_end)
+
+    def _critic_problem(self, ids):
+        rows = self._rows(ids)
+        X = rows[:, 1:1 + self.S]
+        Y = self._eval(self.net, X)
+        a = rows[:, 1 + self.S].to(torch.int64)
+        Y[torch.arange(len(ids), device=self.device), a] = self._new_q(rows, ids)
+        return X, Y
+
+    # ---- actor
+    def FetchActorMinibatch(self, size):
+        n = len(self.actor_buffer)
+        out = []
+        for _ in range(min(size, n)):
+            t = self.actor_buffer[int(self.rng.randint(0, n))]
+            if t not in self.actor_batch_buffer and t not in out:
+                out.append(t)
+        return out
+
+    def UpdateActorBatchBuffer(self):
+        ids = self.FetchActorMinibatch(self.batch)
+        if not ids:
+            return
+        rows = self._rows(ids)
+        curr = self._eval(self._target_net(), rows[:, 1:1 + self.S])[:, :self.num_frags].max(1).values
+        new = self._new_q(rows, ids)
+        better = (new > curr).cpu().numpy()
+        self.actor_batch_buffer += [t for t, b in zip(ids, better) if b]
+
+    def UpdateActor(self):
+        if self.stage_train:
+            self.UpdateActorBatchBuffer()
+        for _ in range(len(self.actor_batch_buffer) // self.batch):
+            ids = self.actor_batch_buffer[:self.batch]
+            rows = self._rows(ids)
+            X = rows[:, 1:1 + self.S]
+            Y = self._eval(self.net, X)
+            a = rows[:, 1 + self.S].to(torch.int64)
+            frag = rows[:, 2 + self.S:1 + self.S + self.A].to(self.dtype)
+            cols = self.num_frags + a[:, None] * self.frag_size + torch.arange(self.frag_size, device=self.device)[None, :]
+            Y.scatter_(1, cols, frag)
+            self.last_actor_loss = self._solver_step(X, Y)
+            self.actor_iter += 1
+            del self.actor_batch_buffer[:self.batch]
+
+    # ---- cNeuralNet::Train -> one Caffe SGD iteration on one batch
+    def _lr(self):
+        s = self.solver
+        if s["lr_policy"] == "step":
+            return s["base_lr"] * s["gamma"] ** int(self.solver_iter // s["stepsize"])
+        if s["lr_policy"] == "inv":
+            return s["base_lr"] * (1 + s["gamma"] * self.solver_iter) ** (-s["power"])
+        return s["base_lr"]
+
+    solver_iter = 0
+
+    def _solver_step(self, X, Y):
+        x = (X.to(self.dtype) + self.in_off) * self.in_scale                  # LoadTrainData: data and labels go in normalised
+        label = (Y + self.out_off) * self.out_scale
+        self.net.zero_grad(set_to_none=True)
+        out = self.net(x)
+        loss = 0.5 * ((out - label) ** 2).sum() / x.shape[0]                   # EuclideanLoss
+        loss.backward()
+        rate, mom, wd = self._lr(), self.solver["momentum"], self.solver["weight_decay"]
+        with torch.no_grad():
+            for b, h, (lr_mult, decay_mult) in zip(self.net.blobs(), self.history, self.net.blob_mults):
+                diff = b.grad + (wd * decay_mult) * b                          # Regularize (L2)
+                h.mul_(mom).add_(diff, alpha=rate * lr_mult)                   # ComputeUpdateValue
+                b.sub_(h)                                                      # Net::Update
+        self.solver_iter += 1
+        return float(loss.detach())
+
+
+def anneal(it, n_iters, v0, v1):
+    """cScenarioTrain::CalcExpRate / CalcExpTemp / CalcExpBaseRate: linear interpolation over the anneal window."""
+    lerp = min(max(float(it) / n_iters, 0.0), 1.0) if n_iters > 0 else 1.0
+    return (1 - lerp) * v0 + lerp * v1

@@ -1,0 +1,206 @@
+"""MACE trainer: product = deepterrainrl_amd/trainer.py (torch tensors on the device), checker = oracle/trainer_ref.py
+(plain numpy restatement of the reference's bookkeeping and update rule) + the C++ oracle's network forward."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REFDATA, dog_policy
+
+NETS = os.path.join(REFDATA, "data/policies/dog/nets")
+TRAIN, SOLVER, DEPLOY = (os.path.join(NETS, "dog_mace3_%s.prototxt" % k) for k in ("train", "solver", "deploy"))
+S, A, NF, FS = 283, 30, 3, 29
+
+
+def make_trainer(**kw):
+    from deepterrainrl_amd import trainer as tr
+    args = dict(mem_size=64, num_init_samples=40, freeze_target_iters=0, device="cpu", dtype=torch.float64, seed=3)
+    args.update(kw)
+    return tr.MACETrainer(TRAIN, SOLVER, S, A, **args)
+
+
+def random_rows(rng, n, p_actor=0.4, p_fail=0.2):
+    rows = rng.normal(0, 1, size=(n, 1 + 2 * S + A)).astype(np.float32)
+    rows[:, 0] = rng.uniform(0, 1, n)
+    rows[:, 1 + S] = rng.randint(0, NF, n)
+    flags = (rng.uniform(size=n) < p_actor) * 4 + (rng.uniform(size=n) < p_fail) * 1 + (rng.uniform(size=n) < 0.3) * 2
+    return rows, flags.astype(np.int64)
+
+
+def test_prototxt_parsing_and_blob_order_vs_oracle_forward(om):
+    from deepterrainrl_amd import trainer as tr
+    d = tr.parse_net(TRAIN)
+    assert d["batch_size"] == 32 and d["in_size"] == S and d["n_terrain"] == 200 and (d["n_frags"], d["frag_size"]) == (NF, FS)
+    assert tr.parse_net(DEPLOY)["in_size"] == S
+    s = tr.parse_solver(SOLVER)
+    assert (s["base_lr"], s["momentum"], s["weight_decay"], s["lr_policy"]) == (0.001, 0.9, 0.0005, "fixed")
+    t = make_trainer()
+    assert t.net.num_params() == 570474 and len(t.net.blob_mults) == 2 * 13
+    assert t.net.blob_mults[0] == (1.0, 1.0) and t.net.blob_mults[1] == (2.0, 1.0)          # conv: lr_mult only -> decay_mult defaults to 1
+    assert t.net.blob_mults[6] == (1.0, 1.0) and t.net.blob_mults[7] == (2.0, 0.0)          # terr_ip0: bias not decayed
+    # flat weights in the rollout engine's blob order: the torch net must reproduce the oracle's (C++, fp64) forward
+    desc, w, io, isc, oo, osc = dog_policy(om)
+    t.SetWeights(w); t.SetInputOffsetScale(io, isc); t.SetOutputOffsetScale(oo, osc)
+    assert np.array_equal(t.GetWeights(), w)
+    m, _ = om.build_model("args/dog_slopes_mixed_args.txt", REFDATA)
+    e = om.OracleEnv(m, terrain_seed=1, policy=(desc, w, io, isc, oo, osc))
+    rng = np.random.RandomState(0)
+    for _ in range(3):
+        x = rng.normal(0, 1, S) / np.where(isc == 0, 1, isc) - io
+        y_ref = e.nn_eval(x)
+        y = t.Eval(x)[0]
+        assert np.abs(y - y_ref).max() < 1e-9 * max(1.0, np.abs(y_ref).max())
+
+
+def test_bookkeeping_targets_and_labels_vs_oracle():
+    from oracle import trainer_ref as ref
+    t = make_trainer(mem_size=48, num_init_samples=10 ** 9)       # stays in the init stage: pure bookkeeping
+    book = ref.RefTrainerBook(S, A, NF, FS, 48, t.batch, t.discount)
+    rng = np.random.RandomState(11)
+    rows, flags = random_rows(rng, 130)                            # wraps the 48-slot ring almost three times
+    rows[17, 5] = np.nan; rows[40, 0] = np.inf                     # CheckTuple rejects these
+    t.actor_batch_buffer = [3, 9, 3, 20]                           # stale candidates must be purged when their slot is overwritten
+    book.actor_batch = [3, 9, 3, 20]
+    for k in range(0, 130, 7):
+        slots = t.AddTuples(rows[k:k + 7], flags[k:k + 7])
+        exp = [book.add(rows[i], flags[i]) for i in range(k, min(k + 7, 130))]
+        assert list(slots) == exp
+        assert t.critic_buffer == book.critic and t.actor_buffer == book.actor and t.actor_batch_buffer == book.actor_batch
+        assert (t.head, t.num_tuples) == (book.head, book.num)
+    assert np.array_equal(t.mem.cpu().numpy(), book.mem) and np.array_equal(t.flags, book.flags)
+    net_eval = lambda x: t.Eval(x)[0]
+    ids = t.critic_buffer[:6] + t.actor_buffer[:6]
+    X, Y = t._critic_problem(ids)
+    for i, tid in enumerate(ids):
+        assert np.abs(Y[i].numpy() - book.critic_label(tid, net_eval, net_eval)).max() < 1e-12
+    newq = t._new_q(t._rows(ids), ids).numpy()
+    assert np.allclose(newq, [book.new_q(tid, net_eval) for tid in ids], rtol=0, atol=1e-12)
+    fails = [tid for tid in ids if book.flags[tid] & 1]
+    assert fails and all(abs(book.new_q(tid, net_eval) - float(book.mem[tid][0]) * (1 - t.discount)) < 1e-15 for tid in fails)
+    # actor: candidate filter and labels
+    t.stage_train = True; t.actor_batch_buffer = []; book.actor_batch = []
+    st = t.rng.get_state()
+    t.UpdateActorBatchBuffer()
+    t.rng.set_state(st)
+    drawn = []
+    n = len(t.actor_buffer)
+    for _ in range(min(t.batch, n)):
+        c = t.actor_buffer[int(t.rng.randint(0, n))]
+        if c not in drawn: drawn.append(c)
+    assert t.actor_batch_buffer == [c for c in drawn if book.actor_accepts(c, net_eval)]
+    off, sc = book.offset_scale()
+    t.UpdateOffsetScale()
+    io, isc, _, _ = t.GetOffsetScale()
+    assert np.allclose(io, off, atol=1e-12) and np.allclose(isc, sc, rtol=1e-10)
+
+
+def test_solver_step_is_the_caffe_sgd_rule():
+    from oracle import trainer_ref as ref
+    t = make_trainer()
+    rng = np.random.RandomState(5)
+    rows, flags = random_rows(rng, 40)
+    t.AddTuples(rows, flags)
+    t.SetInputOffsetScale(rng.normal(0, 0.1, S), rng.uniform(0.5, 2, S)); t.SetOutputOffsetScale(rng.normal(0, 0.1, 90), rng.uniform(0.5, 2, 90))
+    ids = list(range(32))
+    X, Y = t._critic_problem(ids)
+    io, isc, oo, osc = [torch.as_tensor(v) for v in t.GetOffsetScale()]
+    for step in range(2):                                          # second step exercises the momentum history
+        w0 = [b.detach().clone() for b in t.net.blobs()]; h0 = [h.clone() for h in t.history]
+        out = t.net((X.double() + io) * isc)
+        label = (Y + oo) * osc
+        loss = 0.5 * ((out - label) ** 2).sum() / 32
+        grads = torch.autograd.grad(loss, t.net.blobs())
+        got = t._solver_step(X, Y)
+        assert abs(got - float(loss)) < 1e-12
+        for b, w, g, h, hn, (lm, dm) in zip(t.net.blobs(), w0, grads, h0, t.history, t.net.blob_mults):
+            w_ref, h_ref = ref.caffe_sgd_step(w.numpy(), g.numpy(), h.numpy(), 0.001, 0.9, 0.0005, lm, dm)
+            assert np.abs(b.detach().numpy() - w_ref).max() < 1e-15 and np.abs(hn.numpy() - h_ref).max() < 1e-15
+    # loss scaling: central finite difference of a few weights against autograd (EuclideanLoss = 1/(2N) sum ||.||^2)
+    blob = t.net.blobs()[8]                                        # ip0 weights
+    out = t.net((X.double() + io) * isc); label = (Y + oo) * osc
+    g = torch.autograd.grad(0.5 * ((out - label) ** 2).sum() / 32, blob)[0]
+    with torch.no_grad():
+        for idx in [(0, 0), (5, 70), (200, 146)]:
+            old = float(blob[idx]); eps = 1e-6
+            blob[idx] = old + eps; lp = float(0.5 * ((t.net((X.double() + io) * isc) - label) ** 2).sum() / 32)
+            blob[idx] = old - eps; lm_ = float(0.5 * ((t.net((X.double() + io) * isc) - label) ** 2).sum() / 32)
+            blob[idx] = old
+            assert abs((lp - lm_) / (2 * eps) - float(g[idx])) < 1e-6 * max(1.0, abs(float(g[idx])))
+
+
+def test_stages_iterations_and_target_freeze():
+    t = make_trainer(mem_size=256, num_init_samples=64, freeze_target_iters=3, dtype=torch.float32)
+    rng = np.random.RandomState(2)
+    rows, flags = random_rows(rng, 63, p_actor=0.5)
+    t.AddTuples(rows, flags); t.Train()
+    assert not t.stage_train and t.GetIter() == 0                  # below trainer_num_init_samples: nothing happens
+    rows, flags = random_rows(rng, 150, p_actor=0.5)
+    t.AddTuples(rows, flags)
+    w_before = t.GetWeights().copy()
+    t.Train()
+    io, isc, _, _ = t.GetOffsetScale()
+    assert t.stage_train and t.GetIter() == 1 and not np.allclose(io, 0) and not np.array_equal(t.GetWeights(), w_before)
+    tgt0 = t.target.get_flat().copy()
+    losses = []
+    for _ in range(8):
+        t.Train(); losses.append(t.last_loss)
+    assert t.GetIter() == 9 and np.all(np.isfinite(losses))
+    assert not np.array_equal(t.target.get_flat(), tgt0)           # refreshed at iterations 3 and 6 ...
+    assert not np.array_equal(t.target.get_flat(), t.GetWeights()) # ... and frozen in between
+    assert t.actor_iter >= 1                                       # advantage-filtered actor batches were trained
+    from deepterrainrl_amd import trainer as tr
+    assert tr.anneal(0, 100, 0.9, 0.2) == 0.9 and tr.anneal(250, 100, 0.9, 0.2) == 0.2 and abs(tr.anneal(50, 100, 0.9, 0.2) - 0.55) < 1e-15
+
+
+def test_train_loop_end_to_end_on_cpu(da):
+    """cScenarioTrain loop wiring (rollout -> drain -> AddTuples/Train -> SetPolicy/SetExplore) on the lane-loop test backend."""
+    from deepterrainrl_amd import train_loop
+    from conftest import EMUL_LIB
+    a = train_loop.parse_arg_file(os.path.join(REFDATA, "args/opt_args_train_mace.txt"))
+    assert a["trainer_replay_mem_size"] == "500000" and a["tuple_buffer_size"] == "32" and a["init_exp_temp"] == "20"
+    st = train_loop.train("args/opt_args_train_mace.txt", REFDATA, num_envs=48, max_frames=60, trainer_device="cpu", _lib_path=EMUL_LIB,
+                          extra_args={"terrain_seed": 3, "trainer_num_init_samples": 30, "trainer_replay_mem_size": 512, "trainer_freeze_target_iters": 4, "init_exp_rate": 0.3, "init_exp_base_rate": 0.1})   # (with the file's 0.9 / 0.9 nearly every early tuple is an actor-exploration tuple and the critic buffer fills slowly, as in the reference)
+    assert st["frames"] == 60 and st["tuples"] >= 40 and st["iters"] >= 1
+    assert np.all(np.isfinite(st["weights"])) and st["weights"].size == 570474
+    io, isc, oo, osc = st["offset_scale"]
+    assert not np.allclose(io, 0) and np.all(np.isfinite(isc))       # trainer_init_input_offset_scale = true
+
+
+@pytest.mark.gpu
+def test_gpu_trainer_matches_cpu_fp64():
+    rng = np.random.RandomState(9)
+    rows, flags = random_rows(rng, 200, p_actor=0.5)
+    ts = [make_trainer(mem_size=256, num_init_samples=100, device=dev, dtype=dt, seed=21) for dev, dt in (("cpu", torch.float64), ("cuda", torch.float32))]
+    w0 = ts[0].GetWeights()
+    for t in ts:
+        t.SetWeights(w0); t.AddTuples(rows, flags)
+        for _ in range(6):
+            t.Train()
+    assert ts[0].GetIter() == ts[1].GetIter() == 6 and ts[0].actor_iter == ts[1].actor_iter
+    a, b = ts[0].GetWeights(), ts[1].GetWeights()
+    assert np.abs(a - b).max() < 2e-4 * np.abs(a).max() and np.abs(a - w0).max() > 1e-4
+    assert ts[1].mem.is_cuda and ts[1].net.mods[0].weight.is_cuda
+
+
+@pytest.mark.gpu
+def test_gpu_rollout_to_trainer_loop(da, om):
+    """End to end on the GPU: exploration rollouts -> drained MACE rows -> trainer -> weights back into the rollout engine."""
+    from deepterrainrl_amd import trainer as tr
+    pol = dog_policy(om)
+    b = da.BatchScenario("args/opt_args_train_mace.txt", 256, data_root=REFDATA, extra_args={"terrain_seed": 5})
+    t = tr.MACETrainer(TRAIN, SOLVER, b.S, b.A, mem_size=4096, num_init_samples=200, freeze_target_iters=50, seed=1)
+    off, sc = b.BuildNNOutputOffsetScale()
+    t.SetOutputOffsetScale(off, sc)                                 # cScenarioTrain::SetupTrainerOutputOffsetScale
+    b.SetExplore(1, 0.3, 20.0, 0.1)                                 # (the file's init 0.9 / 0.9 makes nearly every early tuple an actor tuple)
+    b.SetPolicy(t.GetWeights(), *t.GetOffsetScale())
+    for f in range(60):
+        b.Update()
+        rows, flags, ids = b.DrainTuples()
+        if len(rows):
+            t.AddTuples(rows, flags)
+            for _ in range(len(rows) // 32 + 1):
+                t.Train()
+            b.SetPolicy(t.GetWeights(), *t.GetOffsetScale())
+    assert t.GetNumTuples() > 200 and t.GetIter() > 5 and np.isfinite(t.last_loss)
+    assert np.all(np.isfinite(t.GetWeights())) and np.all(np.isfinite(b.PoseVel()[0]))
