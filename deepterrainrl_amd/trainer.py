@@ -97,6 +97,23 @@ class MaceNet(torch.nn.Module):
         for m in mults:
             m = list(m) + [(1.0, 1.0)] * (2 - len(m))
             self.blob_mults += [m[0], m[1]]
+        self.flat = self.gflat = None
+
+    def flatten_storage(self):
+        """Re-home every blob (and its gradient) as a view into ONE flat buffer in the engine's blob order: the solver update, the
+        target-net copy and the weight hand-over to the rollout engine become single tensor ops instead of 26 small ones."""
+        blobs = self.blobs()
+        n = sum(b.numel() for b in blobs)
+        self.flat = torch.empty(n, dtype=blobs[0].dtype, device=blobs[0].device)
+        self.gflat = torch.zeros_like(self.flat)
+        off = 0
+        for b in blobs:
+            k = b.numel()
+            self.flat[off:off + k].copy_(b.detach().reshape(-1))
+            b.data = self.flat[off:off + k].view(b.shape)
+            b.grad = self.gflat[off:off + k].view(b.shape)
+            off += k
+        return self
 
     def blobs(self):
         out = []
@@ -117,7 +134,8 @@ class MaceNet(torch.nn.Module):
         return torch.cat(outs, 1)
 
     def get_flat(self):
-        return torch.cat([b.detach().reshape(-1) for b in self.blobs()]).to(torch.float32).cpu().numpy()
+        src = self.flat if self.flat is not None else torch.cat([b.detach().reshape(-1) for b in self.blobs()])
+        return src.detach().to(torch.float32).cpu().numpy()
 
     def set_flat(self, w):
         w = torch.as_tensor(np.asarray(w), dtype=self.mods[0].weight.dtype, device=self.mods[0].weight.device)
@@ -148,9 +166,17 @@ class MACETrainer:
         self.W = 1 + 2 * state_size + action_size                      # cMACETrainer::CalcBufferSize
         self.mem_size, self.num_init_samples, self.steps_per_iter = mem_size, num_init_samples, steps_per_iter
         self.freeze_target_iters, self.discount, self.init_input_offset_scale = freeze_target_iters, discount, init_input_offset_scale
-        self.net = MaceNet(self.desc).to(self.device, dtype)
-        self.target = MaceNet(self.desc).to(self.device, dtype)
-        self.history = [torch.zeros_like(b) for b in self.net.blobs()]
+        self.net = MaceNet(self.desc).to(self.device, dtype).flatten_storage()
+        self.target = MaceNet(self.desc).to(self.device, dtype).flatten_storage()
+        for p_ in self.target.parameters():
+            p_.requires_grad_(False)
+        self.hflat = torch.zeros_like(self.net.flat)
+        self.history, self.rate_mult, self.decay_mult = [], torch.empty_like(self.hflat), torch.empty_like(self.hflat)   # per-element lr_mult / decay_mult
+        off = 0
+        for b, (lm, dm) in zip(self.net.blobs(), self.net.blob_mults):
+            k = b.numel()
+            self.history.append(self.hflat[off:off + k].view(b.shape)); self.rate_mult[off:off + k] = lm; self.decay_mult[off:off + k] = dm
+            off += k
         z = lambda n, v: torch.full((n,), v, device=self.device, dtype=dtype)
         self.in_off, self.in_scale, self.out_off, self.out_scale = z(state_size, 0.0), z(state_size, 1.0), z(self.out_size, 0.0), z(self.out_size, 1.0)
         self.mem = torch.zeros((mem_size, self.W), device=self.device, dtype=torch.float32)   # mPlaybackMem (float, as the reference)
@@ -184,7 +210,7 @@ class MACETrainer:
     def EnableTargetNet(self): return self.freeze_target_iters > 0
     def UpdateTargetNet(self):
         """cMACETrainer::UpdateTargetNet; without freezing (freeze_target_iters == 0) the target IS the current net (GetTargetNetID)."""
-        self.target.load_state_dict(self.net.state_dict())
+        self.target.flat.copy_(self.net.flat)
 
     def _target_net(self):
         return self.target if self.EnableTargetNet() else self.net
@@ -271,7 +297,7 @@ class MACETrainer:
             self.last_loss = self._solver_step(X, Y)
         self.UpdateActor()
         if self.EnableTargetNet() and self.iter > 0 and self.iter % self.freeze_target_iters == 0:
-            self.target.load_state_dict(self.net.state_dict())
+            self.target.flat.copy_(self.net.flat)
         return succ
 
     # ---- critic
@@ -349,16 +375,15 @@ class MACETrainer:
     def _solver_step(self, X, Y):
         x = (X.to(self.dtype) + self.in_off) * self.in_scale                  # LoadTrainData: data and labels go in normalised
         label = (Y + self.out_off) * self.out_scale
-        self.net.zero_grad(set_to_none=True)
+        self.net.gflat.zero_()
         out = self.net(x)
         loss = 0.5 * ((out - label) ** 2).sum() / x.shape[0]                   # EuclideanLoss
         loss.backward()
         rate, mom, wd = self._lr(), self.solver["momentum"], self.solver["weight_decay"]
         with torch.no_grad():
-            for b, h, (lr_mult, decay_mult) in zip(self.net.blobs(), self.history, self.net.blob_mults):
-                diff = b.grad + (wd * decay_mult) * b                          # Regularize (L2)
-                h.mul_(mom).add_(diff, alpha=rate * lr_mult)                   # ComputeUpdateValue
-                b.sub_(h)                                                      # Net::Update
+            diff = torch.addcmul(self.net.gflat, self.decay_mult, self.net.flat, value=wd)   # Regularize (L2): diff + wd * decay_mult * w
+            self.hflat.mul_(mom).addcmul_(self.rate_mult, diff, value=rate)                    # ComputeUpdateValue
+            self.net.flat.sub_(self.hflat)                                                     # Net::Update
         self.solver_iter += 1
         return float(loss.detach())
 
