@@ -153,7 +153,7 @@ class MACETrainer:
     """cMACETrainer (pool size 1, synchronous mode)."""
 
     def __init__(self, net_file, solver_file, state_size, action_size, mem_size=500000, num_init_samples=200, steps_per_iter=1,
-                 freeze_target_iters=0, discount=0.9, init_input_offset_scale=True, device=None, dtype=torch.float32, seed=0):
+                 freeze_target_iters=0, discount=0.9, init_input_offset_scale=True, device=None, dtype=torch.float32, seed=0, use_graphs=None):
         self.desc = parse_net(net_file)
         self.solver = parse_solver(solver_file)
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
@@ -184,6 +184,10 @@ class MACETrainer:
         self.rng = np.random.RandomState(seed)
         self.Reset()
         self.UpdateTargetNet()
+        # batch-32 steps are launch-latency bound in eager mode: on the GPU the evaluation and the solver step are captured once as
+        # HIP graphs (static input / output buffers) and replayed; any capture problem falls back to eager execution
+        self.use_graphs = (self.device.type == "cuda") if use_graphs is None else bool(use_graphs)
+        self._g_eval, self._g_step = {}, None
 
     # ---- cNeuralNetTrainer::ResetParams / cMACETrainer::Reset
     def Reset(self):
@@ -192,7 +196,12 @@ class MACETrainer:
         self.critic_buffer, self.critic_pos = [], {}
         self.actor_buffer, self.actor_pos = [], {}
         self.actor_batch_buffer = []
-        self.last_loss = self.last_actor_loss = None
+        self._last_loss = self._last_actor_loss = None
+
+    @property
+    def last_loss(self): return None if self._last_loss is None else float(self._last_loss)
+    @property
+    def last_actor_loss(self): return None if self._last_actor_loss is None else float(self._last_actor_loss)
 
     # ---- weights / normalisers
     def GetWeights(self): return self.net.get_flat()
@@ -201,10 +210,10 @@ class MACETrainer:
     def GetOffsetScale(self):
         f = lambda t: t.detach().to(torch.float64).cpu().numpy()
         return f(self.in_off), f(self.in_scale), f(self.out_off), f(self.out_scale)
-    def SetInputOffsetScale(self, off, scale):
-        self.in_off = torch.as_tensor(off, device=self.device, dtype=self.dtype); self.in_scale = torch.as_tensor(scale, device=self.device, dtype=self.dtype)
+    def SetInputOffsetScale(self, off, scale):   # in place: captured graphs keep pointing at these buffers
+        self.in_off.copy_(torch.as_tensor(off, device=self.device, dtype=self.dtype)); self.in_scale.copy_(torch.as_tensor(scale, device=self.device, dtype=self.dtype))
     def SetOutputOffsetScale(self, off, scale):
-        self.out_off = torch.as_tensor(off, device=self.device, dtype=self.dtype); self.out_scale = torch.as_tensor(scale, device=self.device, dtype=self.dtype)
+        self.out_off.copy_(torch.as_tensor(off, device=self.device, dtype=self.dtype)); self.out_scale.copy_(torch.as_tensor(scale, device=self.device, dtype=self.dtype))
     def GetIter(self): return self.iter
     def GetNumTuples(self): return self.num_tuples
     def EnableTargetNet(self): return self.freeze_target_iters > 0
@@ -216,10 +225,36 @@ class MACETrainer:
         return self.target if self.EnableTargetNet() else self.net
 
     # ---- evaluation in unnormalised space (cNeuralNet::EvalBatch)
-    def _eval(self, net, X):
+    def _eval_eager(self, net, X):
         with torch.no_grad():
             y = net((X.to(self.dtype) + self.in_off) * self.in_scale)
             return y / self.out_scale - self.out_off
+
+    def _eval(self, net, X):
+        n = X.shape[0]
+        if not self.use_graphs or n > self.batch:
+            return self._eval_eager(net, X)
+        key = id(net)
+        try:
+            if key not in self._g_eval:
+                xin = torch.zeros((self.batch, self.S), device=self.device, dtype=torch.float32)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._eval_eager(net, xin)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    yout = self._eval_eager(net, xin)
+                self._g_eval[key] = (g, xin, yout)
+            g, xin, yout = self._g_eval[key]
+            xin[:n].copy_(X)
+            g.replay()
+            return yout[:n].clone()
+        except Exception:   # capture not available: stay eager from now on
+            self.use_graphs = False
+            return self._eval_eager(net, X)
     def Eval(self, X):
         return self._eval(self.net, torch.as_tensor(np.atleast_2d(X), device=self.device)).to(torch.float64).cpu().numpy()
 
@@ -294,7 +329,7 @@ class MACETrainer:
         succ = len(ids) >= self.batch
         if succ:
             X, Y = self._critic_problem(ids)
-            self.last_loss = self._solver_step(X, Y)
+            self._last_loss = self._solver_step(X, Y)
         self.UpdateActor()
         if self.EnableTargetNet() and self.iter > 0 and self.iter % self.freeze_target_iters == 0:
             self.target.flat.copy_(self.net.flat)
@@ -357,7 +392,7 @@ class MACETrainer:
             frag = rows[:, 2 + self.S:1 + self.S + self.A].to(self.dtype)
             cols = self.num_frags + a[:, None] * self.frag_size + torch.arange(self.frag_size, device=self.device)[None, :]
             Y.scatter_(1, cols, frag)
-            self.last_actor_loss = self._solver_step(X, Y)
+            self._last_actor_loss = self._solver_step(X, Y)
             self.actor_iter += 1
             del self.actor_batch_buffer[:self.batch]
 
@@ -372,7 +407,7 @@ class MACETrainer:
 
     solver_iter = 0
 
-    def _solver_step(self, X, Y):
+    def _solver_step_body(self, X, Y):
         x = (X.to(self.dtype) + self.in_off) * self.in_scale                  # LoadTrainData: data and labels go in normalised
         label = (Y + self.out_off) * self.out_scale
         self.net.gflat.zero_()
@@ -384,8 +419,36 @@ class MACETrainer:
             diff = torch.addcmul(self.net.gflat, self.decay_mult, self.net.flat, value=wd)   # Regularize (L2): diff + wd * decay_mult * w
             self.hflat.mul_(mom).addcmul_(self.rate_mult, diff, value=rate)                    # ComputeUpdateValue
             self.net.flat.sub_(self.hflat)                                                     # Net::Update
+        return loss.detach()
+
+    def _solver_step(self, X, Y):
+        if self.use_graphs and self.solver["lr_policy"] == "fixed" and X.shape[0] == self.batch:
+            try:
+                if self._g_step is None:
+                    xs = torch.zeros((self.batch, self.S), device=self.device, dtype=torch.float32)
+                    ys = torch.zeros((self.batch, self.out_size), device=self.device, dtype=self.dtype)
+                    keep = (self.net.flat.clone(), self.hflat.clone())
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        for _ in range(2):
+                            self._solver_step_body(xs, ys)
+                    torch.cuda.current_stream().wait_stream(side)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        lo = self._solver_step_body(xs, ys)
+                    self.net.flat.copy_(keep[0]); self.hflat.copy_(keep[1])     # undo the warm-up / capture updates
+                    self._g_step = (g, xs, ys, lo)
+                g, xs, ys, lo = self._g_step
+                xs.copy_(X); ys.copy_(Y)
+                g.replay()
+                self.solver_iter += 1
+                return lo.clone()
+            except Exception:
+                self.use_graphs = False; self._g_step = None
+        loss = self._solver_step_body(X, Y)
         self.solver_iter += 1
-        return float(loss.detach())
+        return loss
 
 
 def anneal(it, n_iters, v0, v1):
