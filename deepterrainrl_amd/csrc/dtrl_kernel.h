@@ -245,11 +245,12 @@ DTRL_HD_INLINE real sample_ground(const GroundRec& g, real x, real* slope, int* 
 //       (one LDS read per quantity and path element, fixed-trip predicated loops so the loads pipeline); COM, inertial force
 //   P4  per link: subtree sums (mass, first moments, inertia about the root origin, force, moment) with one masked loop
 // then b_d (planar RNEA in world coordinates) falls out without further loops.
-// quirk=true reproduces cRBDUtil::BuildCjPlanar as shipped (sim/RBDUtil.cpp:809-836: theta read from q_dot and
-// s = cos(theta)) as an extra base acceleration -- that is the bias the reference's implicit-PD controller sees;
-// quirk=false is the textbook bias used by the integrator.
+// The bias computed here is the textbook one (what the integrator needs). The reference's implicit-PD controller sees the bias of
+// cRBDUtil::BuildCjPlanar as shipped (sim/RBDUtil.cpp:809-836: theta read from q_dot and s = cos(theta)), which differs from the
+// textbook bias by a uniform extra base acceleration (dax, day); with subtree sums that is a closed-form correction per DoF
+// (quirk_bias() below), so ONE evaluation at the post-step configuration serves the controller AND the next substep.
 template <class W>
-DTRL_HD inline void kin_dyn_terms(W& ws, bool quirk)
+DTRL_HD inline void kin_dyn_terms(W& ws)
 {
 	PROF_T0();
 	LANES_BEGIN
@@ -290,16 +291,7 @@ DTRL_HD inline void kin_dyn_terms(W& ws, bool quirk)
 	if (lane < ws.M.L) {
 		const int j = lane;
 		const int dep = ws.M.depth[j];
-		real ax0 = 0, ay0 = -kGravityY;
-		if (quirk) {
-			const real vx0 = ws.st.qd[0], vy0 = ws.st.qd[1], om = ws.st.qd[2];
-			const real c = ws.cs[0], s = ws.sn[0];
-			const real cq = cos(om);
-			const real tx = (-s * vx0 + c * vy0) * om, ty = (-c * vx0 - s * vy0) * om;     // textbook cj (body frame)
-			const real qx = (-cq * vx0 + cq * vy0) * om, qy = (-cq * vx0 - cq * vy0) * om; // shipped cj
-			const real dx = qx - tx, dy = qy - ty;
-			ax0 += c * dx - s * dy; ay0 += s * dx + c * dy;                                 // back to world frame
-		}
+		const real ax0 = 0, ay0 = -kGravityY;
 		real px = 0, py = 0, vx = ws.st.qd[0], vy = ws.st.qd[1], ax = 0, ay = 0;
 #pragma unroll 4
 		for (int k = 1; k < kMaxDepth; ++k) {
@@ -345,7 +337,25 @@ DTRL_HD inline void kin_dyn_terms(W& ws, bool quirk)
 	PROF_ADD(ws, kProfP4);
 }
 template <class W>
-DTRL_HD inline void forward_kinematics(W& ws) { kin_dyn_terms(ws, false); }
+DTRL_HD inline void forward_kinematics(W& ws) { kin_dyn_terms(ws); }
+
+// bias of DoF i as the reference's controller sees it: textbook bias + the BuildCjPlanar discrepancy as a base acceleration
+// (dax, day) acting on the subtree: translations M (dax, day); hinge l: day (smx_l - sm_l px_l) - dax (smy_l - sm_l py_l)
+template <class W>
+DTRL_HD inline real quirk_bias(const W& ws, int i)
+{
+	const real vx0 = ws.st.qd[0], vy0 = ws.st.qd[1], om = ws.st.qd[2];
+	const real c = ws.cs[0], s = ws.sn[0];
+	const real cq = cos(om);
+	const real tx = (-s * vx0 + c * vy0) * om, ty = (-c * vx0 - s * vy0) * om;     // textbook cj (body frame)
+	const real qx = (-cq * vx0 + cq * vy0) * om, qy = (-cq * vx0 - cq * vy0) * om; // shipped cj
+	const real dx = qx - tx, dy = qy - ty;
+	const real dax = c * dx - s * dy, day = s * dx + c * dy;                        // back to world frame
+	if (i == 0) return ws.b[0] + ws.sm[0] * dax;
+	if (i == 1) return ws.b[1] + ws.sm[0] * day;
+	const int l = i - 2;
+	return ws.b[i] + (day * (ws.smx[l] - ws.sm[l] * ws.px[l]) - dax * (ws.smy[l] - ws.sm[l] * ws.py[l]));
+}
 
 // joint-space inertia matrix in closed form from the composite quantities (LDS copy, reference path)
 template <class W>
@@ -589,9 +599,9 @@ DTRL_HD inline void finish_substep(W& ws, real h)
 
 // one physics substep (stand-in for one Bullet internal step of sim/World.cpp:101-102)
 template <class W>
-DTRL_HD inline void substep_ref(W& ws, const DevModel& gm, const GroundRec& g, real h)
+DTRL_HD inline void substep_ref(W& ws, const DevModel& gm, const GroundRec& g, real h, bool kin_valid)
 {
-	{ PROF_T0(); kin_dyn_terms(ws, false); PROF_ADD(ws, kProfFK); }
+	if (!kin_valid) { PROF_T0(); kin_dyn_terms(ws); PROF_ADD(ws, kProfFK); }
 	{ PROF_T0(); mass_matrix(ws); PROF_ADD(ws, kProfMass); }
 	{ PROF_T0(); factorize(ws); PROF_ADD(ws, kProfFact); }
 	{ PROF_T0(); detect_contacts(ws, gm, g); PROF_ADD(ws, kProfDetect); }
@@ -1088,7 +1098,7 @@ DTRL_HD inline void pd_solve_ref(W& ws, real dt)
 	}
 }
 struct RefPath {
-	template <class W> static DTRL_HD void substep(W& ws, const DevModel& gm, const GroundRec& g, real h) { substep_ref(ws, gm, g, h); }
+	template <class W> static DTRL_HD void substep(W& ws, const DevModel& gm, const GroundRec& g, real h, bool kin_valid) { substep_ref(ws, gm, g, h, kin_valid); }
 	template <class W> static DTRL_HD void pd_solve(W& ws, real dt) { pd_solve_ref(ws, dt); }
 	template <class W> static DTRL_HD void contacts(W& ws, const DevModel& gm, const GroundRec& g) { detect_contacts(ws, gm, g); }
 };
@@ -1117,8 +1127,8 @@ DTRL_HD inline void controller_update(W& ws, const DevModel& gm, const RunParams
 	const int D = ws.M.D, L = ws.M.L;
 	const bool raptor = gm.char_type == 1;
 	unsigned long long pc_t = PROF_NOW();
-	// UpdateRBDModel: kinematics, composite inertias and the (quirk) bias at the post-step configuration were produced by
-	// kin_dyn_terms(ws, true) in env_step; H itself is assembled inside the PD solve
+	// UpdateRBDModel: kinematics, composite inertias and the textbook bias at the post-step configuration were produced by
+	// kin_dyn_terms() in env_step (quirk_bias() turns it into the reference's C); H itself is assembled inside the PD solve
 	LANES_BEGIN
 	if (lane == 0) {
 		ws.st.curr_cycle_time += dt;
@@ -1202,7 +1212,7 @@ DTRL_HD inline void controller_update(W& ws, const DevModel& gm, const RunParams
 			ve = 0 - ws.st.qd[i];
 		}
 		ws.kpv[i] = kp; ws.kdv[i] = kd; ws.kdm[i] = kdm; ws.perr[i] = pe; ws.verr[i] = ve;
-		ws.u[i] = kp * (pe - dt * ws.st.qd[i]) + kd * ve - ws.b[i];
+		ws.u[i] = kp * (pe - dt * ws.st.qd[i]) + kd * ve - quirk_bias(ws, i);
 	}
 	LANES_END
 	PROF_ADD_SINCE(ws, kProfC_PdSetup, pc_t); pc_t = PROF_NOW();
@@ -1391,8 +1401,10 @@ template <class Path, class W>
 DTRL_HD inline void env_step(W& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, real dt)
 {
 	const real h = dt / gm.num_sim_substeps;
-	for (int s = 0; s < gm.num_sim_substeps; ++s) Path::substep(ws, gm, g, h);   // UpdateWorld
-	kin_dyn_terms(ws, true);                                                // post-step kinematics + the controller's RBD terms
+	// UpdateWorld. The kinematics / composites / bias of the configuration at entry are already in the workspace (frame start, reset,
+	// or the post-step evaluation of the previous env-step), so the first substep does not recompute them
+	for (int s = 0; s < gm.num_sim_substeps; ++s) Path::substep(ws, gm, g, h, s == 0);
+	kin_dyn_terms(ws);                                                      // post-step kinematics: controller's RBD terms AND the next substep's
 	Path::contacts(ws, gm, g);                                                  // cContactManager::Update
 	// UpdateGround is host-side at frame boundaries (the 1 m look-ahead margin makes that equivalent; DESIGN.md "Ground")
 	{ PROF_T0(); controller_update<Path>(ws, gm, rp, buf, g, env, dt); PROF_ADD(ws, kProfCtrl); }   // UpdateCharacter

@@ -320,13 +320,13 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 
 template <int D>
 struct FastPath {
-	static __device__ void substep(WSFast& ws, const DevModel& gm, const GroundRec& g, real h)
+	static __device__ void substep(WSFast& ws, const DevModel& gm, const GroundRec& g, real h, bool kin_valid)
 	{
 		const int lane = static_cast<int>(threadIdx.x);
 #if defined(DTRL_PROFILE)
 		const unsigned long long prof_sub_t0 = __builtin_readcyclecounter();
 #endif
-		{ PROF_T0(); kin_dyn_terms(ws, false); PROF_ADD(ws, kProfFK); }
+		if (!kin_valid) { PROF_T0(); kin_dyn_terms(ws); PROF_ADD(ws, kProfFK); }
 		real hrow[D];
 		{ PROF_T0(); mass_row<D>(ws, hrow); PROF_ADD(ws, kProfMass); }
 		real dinv;
@@ -402,7 +402,7 @@ struct FastPath {
 	{
 		const int lane = static_cast<int>(threadIdx.x);
 		real hrow[D];
-		mass_row<D>(ws, hrow);   // composite inertias come from kin_dyn_terms(ws, true) in env_step
+		mass_row<D>(ws, hrow);   // composite inertias come from kin_dyn_terms() in env_step
 		const real add = (lane < D) ? dt * ws.kdm[lane] : 0.0;
 #pragma unroll
 		for (int k = 0; k < D; ++k) if (lane == k) hrow[k] += add;
