@@ -599,6 +599,7 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		m.sub_mask[j] = 0;
 	}
 	for (int k = 0; k < L; ++k) { m.anc_mask[k] = 0; for (int c = k; c >= 0; c = m.parent[c]) { m.sub_mask[c] |= (1u << k); m.anc_mask[k] |= (1u << c); } }
+	for (int j = 0; j < L; ++j) { double sm = 0; for (int k = 0; k < L; ++k) if ((m.sub_mask[j] >> k) & 1u) sm += m.mass[k]; m.sub_mass[j] = sm; }
 	m.n_pairs = 0;
 	for (int l = 0; l < L; ++l) for (int k = 0; k <= m.depth[l]; ++k) { m.pair_l[m.n_pairs] = static_cast<int8_t>(l); m.pair_k[m.n_pairs] = static_cast<int8_t>(k); ++m.n_pairs; }
 

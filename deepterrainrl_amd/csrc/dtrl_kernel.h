@@ -78,7 +78,7 @@ struct HotModel {
 	uint32_t anc_mask[kMaxL];   // bit a set <=> link a is an ancestor of j or j itself
 	real attach[kMaxL][2], lim_lo[kMaxL], lim_hi[kMaxL];
 	real body_attach[kMaxL][2];
-	real mass[kMaxL], inertia[kMaxL];
+	real mass[kMaxL], inertia[kMaxL], sub_mass[kMaxL];
 };
 
 struct DevBuffers {
@@ -317,14 +317,15 @@ DTRL_HD inline void kin_dyn_terms(W& ws)
 	if (lane < ws.M.L) {
 		const int j = lane;
 		const uint32_t mask = ws.M.sub_mask[j];
-		real m = 0, mx = 0, my = 0, I = 0, sfx = 0, sfy = 0, sfn = 0;
+		const real m = ws.M.sub_mass[j];   // subtree mass is a model constant (summed on the host in the same order)
+		real mx = 0, my = 0, I = 0, sfx = 0, sfy = 0, sfn = 0;
 		const int nL = ws.M.L;
 		for (int k0 = 0; k0 < nL; k0 += 7) {   // chunks of 7 (3 chunks cover the 19- and 21-link characters) so the loads of a chunk pipeline
 #pragma unroll
 			for (int kk = 0; kk < 7; ++kk) {
 				const int k = (k0 + kk < kMaxL) ? k0 + kk : 0;
-				const real mk = ws.M.mass[k], a1 = ws.mcx[k], a2 = ws.mcy[k], a3 = ws.Io[k], a4 = ws.fx[k], a5 = ws.fy[k], a6 = ws.fn[k];
-				if (k0 + kk < nL && ((mask >> k) & 1u)) { m += mk; mx += a1; my += a2; I += a3; sfx += a4; sfy += a5; sfn += a6; }
+				const real a1 = ws.mcx[k], a2 = ws.mcy[k], a3 = ws.Io[k], a4 = ws.fx[k], a5 = ws.fy[k], a6 = ws.fn[k];
+				if (k0 + kk < nL && ((mask >> k) & 1u)) { mx += a1; my += a2; I += a3; sfx += a4; sfy += a5; sfn += a6; }
 			}
 		}
 		ws.sm[j] = m; ws.smx[j] = mx; ws.smy[j] = my; ws.sI[j] = I;
@@ -1512,7 +1513,7 @@ DTRL_HD inline void load_hot_model(W& ws, const DevModel& gm)
 		ws.M.attach[j][0] = gm.attach[j][0]; ws.M.attach[j][1] = gm.attach[j][1];
 		ws.M.lim_lo[j] = gm.lim_lo[j]; ws.M.lim_hi[j] = gm.lim_hi[j];
 		ws.M.body_attach[j][0] = gm.body_attach[j][0]; ws.M.body_attach[j][1] = gm.body_attach[j][1];
-		ws.M.mass[j] = gm.mass[j]; ws.M.inertia[j] = gm.inertia[j];
+		ws.M.mass[j] = gm.mass[j]; ws.M.inertia[j] = gm.inertia[j]; ws.M.sub_mass[j] = gm.sub_mass[j];
 	}
 	LANES_END
 }

@@ -63,6 +63,7 @@ struct DevModel {
 	real body_theta[kMaxL];
 	real body_half[kMaxL][2];        // half extents
 	real mass[kMaxL];
+	real sub_mass[kMaxL];            // mass of the subtree rooted at j (summed in link order, as the kernel's subtree loop would)
 	real inertia[kMaxL];             // Izz about the COM: m/12 (sx^2 + sy^2)
 	real kp[kMaxL], kd[kMaxL], torque_lim[kMaxL], target_theta[kMaxL];
 	real act_blend[kMaxAct];
