@@ -47,6 +47,8 @@ class ShardedRollout:
         Layout of a row: MACE replay row [r | s | a | s'] (learning/MACETrainer.cpp:373-401)."""
         import torch
         rows, flags, ids = self.batch.DrainTuples(self.cap)
+        o = np.argsort(ids, kind="stable")   # ring order = completion order; sort by env id so the gathered stream does not depend on the sharding
+        rows, flags, ids = rows[o], flags[o], ids[o]
         ids = ids.astype(np.int64) + self.offset
         if self.dist is None or self.world == 1:
             return rows, flags, ids

@@ -66,7 +66,9 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     while t.GetIter() < max_iters and (max_frames is None or frames < max_frames):
         b.Update(1.0 / 30.0)
         frames += 1
-        rows, flags, _ = b.DrainTuples()
+        rows, flags, ids = b.DrainTuples()
+        o = np.argsort(ids, kind="stable")   # the device ring is filled in completion order; env-id order makes the run reproducible and shard-invariant
+        rows, flags = rows[o], flags[o]
         for k in range(0, len(rows), chunk):
             t.AddTuples(rows[k:k + chunk], flags[k:k + chunk])
             t.Train()
@@ -82,3 +84,74 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     stats.update(frames=frames, iters=t.GetIter(), tuples=tuples, seconds=dt, env_steps_per_s=frames * 20.0 * num_envs / dt,
                  trainer_iters_per_s=t.GetIter() / dt, weights=t.GetWeights(), offset_scale=t.GetOffsetScale())
     return stats
+
+
+def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, max_frames=None, extra_args=None, seed=0, device=None,
+                      trainer_device=None, local_device_id=-1, _lib_path=None):
+    """cScenarioTrain over several GPUs: one process per GPU (torch.distributed already initialised; backend "nccl" = RCCL on GPUs).
+    Every rank rolls out its contiguous range of global env ids; each outer frame the ranks' drained MACE rows are gathered on rank 0
+    (the only exchange on the experience side), rank 0 runs the trainer, then one broadcast carries [iteration, weights, normalisers]
+    back (the only exchange on the policy side). Trajectories do not depend on the sharding, so the run equals train() on one process."""
+    import torch
+    from .sharding import ShardedRollout
+    args = parse_arg_file(os.path.join(data_root, arg_file))
+    args.update({k: str(v) for k, v in (extra_args or {}).items()})
+    geti = lambda k, d: int(args.get(k, d)); getf = lambda k, d: float(args.get(k, d))
+    rank = dist.get_rank()
+
+    def make(n, off):
+        ea = dict(extra_args or {}); ea["global_env_offset"] = off
+        return BatchScenario(arg_file, n, data_root=data_root, device_id=local_device_id, extra_args=ea, _lib_path=_lib_path)
+    sr = ShardedRollout(make, global_envs, dist=dist, device=device)
+    b = sr.batch
+    t = None
+    if rank == 0:
+        solver = os.path.join(data_root, args["policy_solver"])
+        m = re.search(r'net:\s*"([^"]+)"', open(solver).read())
+        train_net = os.path.join(data_root, m.group(1)) if m else os.path.join(data_root, args["policy_net"].replace("_deploy", "_train"))
+        t = MACETrainer(train_net, solver, b.S, b.A, mem_size=geti("trainer_replay_mem_size", 500000), num_init_samples=geti("trainer_num_init_samples", 200),
+                        steps_per_iter=geti("trainer_num_steps_per_iters", 1), freeze_target_iters=geti("trainer_freeze_target_iters", 0),
+                        init_input_offset_scale=args.get("trainer_init_input_offset_scale", "false").lower() == "true", seed=seed, device=trainer_device)
+        t.SetOutputOffsetScale(*b.BuildNNOutputOffsetScale())
+    exp = dict(rate=getf("exp_rate", 0.2), temp=getf("exp_temp", 0.025), base=getf("exp_base_rate", 0.002))
+    init = dict(rate=getf("init_exp_rate", 1.0), temp=getf("init_exp_temp", 20.0), base=getf("init_exp_base_rate", 1.0))
+    n_anneal, n_base_anneal, n_curr = geti("trainer_num_anneal_iters", 1), geti("exp_base_anneal_iters", 1), geti("trainer_curriculum_iters", 0)
+    chunk = max(1, geti("tuple_buffer_size", 32))
+    max_iters = max_iters if max_iters is not None else geti("trainer_max_iter", 10 ** 9)
+
+    def sync(push):
+        # header [push?, iteration] from the trainer rank, then (if push) the policy itself
+        hdr = np.array([1 if push else 0, t.GetIter() if t is not None else 0], np.int64)
+        th = sr._t(hdr)
+        dist.broadcast(th, src=0)
+        push, it = int(th[0].item()), int(th[1].item())
+        if push:
+            if rank == 0:
+                sr.broadcast_policy(t.GetWeights(), *t.GetOffsetScale(), src=0)
+            else:
+                sr.broadcast_policy(src=0)
+        b.SetExplore(1, anneal(it, n_anneal, init["rate"], exp["rate"]), anneal(it, n_anneal, init["temp"], exp["temp"]), anneal(it, n_base_anneal, init["base"], exp["base"]))
+        phase = 1.0 if n_curr < 1 else min(max(it / float(n_curr), 0.0), 1.0)
+        b.SetTerrainParamsLerp(phase if it > 0 or n_curr < 1 else 0.0)
+        return it
+
+    it = sync(True)
+    frames = tuples = 0
+    t0 = time.time()
+    while it < max_iters and (max_frames is None or frames < max_frames):
+        sr.Update(1.0 / 30.0)
+        frames += 1
+        g = sr.gather_tuples(dst=0)
+        got = False
+        if rank == 0:
+            rows, flags, _ = g
+            for k in range(0, len(rows), chunk):
+                t.AddTuples(rows[k:k + chunk], flags[k:k + chunk])
+                t.Train()
+            tuples += len(rows); got = len(rows) > 0
+        it = sync(got)
+    dt = time.time() - t0
+    out = dict(frames=frames, iters=it, seconds=dt, env_steps_per_s=frames * 20.0 * global_envs / dt, rank=rank, batch=b)
+    if rank == 0:
+        out.update(tuples=tuples, weights=t.GetWeights(), offset_scale=t.GetOffsetScale())
+    return out

@@ -115,6 +115,18 @@ class MaceNet(torch.nn.Module):
             off += k
         return self
 
+    def init_fillers(self, seed):
+        """Caffe fillers of the train prototxt: weights "xavier" (uniform +-sqrt(3 / fan_in)), biases "constant" 0; seeded, so two
+        trainers built with the same seed start from the same policy (the reference draws from Caffe's RNG)."""
+        g = torch.Generator().manual_seed(int(seed))
+        with torch.no_grad():
+            for m in self.mods:
+                fan_in = m.weight[0].numel()
+                s = (3.0 / fan_in) ** 0.5
+                m.weight.copy_(((torch.rand(m.weight.shape, generator=g, dtype=torch.float64) * 2 - 1) * s).to(m.weight.dtype))
+                m.bias.zero_()
+        return self
+
     def blobs(self):
         out = []
         for m in self.mods:
@@ -166,7 +178,7 @@ class MACETrainer:
         self.W = 1 + 2 * state_size + action_size                      # cMACETrainer::CalcBufferSize
         self.mem_size, self.num_init_samples, self.steps_per_iter = mem_size, num_init_samples, steps_per_iter
         self.freeze_target_iters, self.discount, self.init_input_offset_scale = freeze_target_iters, discount, init_input_offset_scale
-        self.net = MaceNet(self.desc).to(self.device, dtype).flatten_storage()
+        self.net = MaceNet(self.desc).init_fillers(seed).to(self.device, dtype).flatten_storage()
         self.target = MaceNet(self.desc).to(self.device, dtype).flatten_storage()
         for p_ in self.target.parameters():
             p_.requires_grad_(False)

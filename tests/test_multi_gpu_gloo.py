@@ -67,6 +67,45 @@ def test_two_rank_gloo_matches_single_process(tmp_path, da, om):
         assert np.array_equal(t["rows"][t["ids"] == e], rows[ids == e]) and np.array_equal(t["flags"][t["ids"] == e], flags[ids == e])
 
 
+TRAIN_WORKER = r'''
+import os, sys, numpy as np
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import torch, torch.distributed as dist
+from conftest import REFDATA, EMUL_LIB
+from deepterrainrl_amd import train_loop
+dist.init_process_group(backend="gloo")
+st = train_loop.train_distributed("args/opt_args_train_mace.txt", REFDATA, 64, dist, max_frames=90, trainer_device="cpu", _lib_path=EMUL_LIB, extra_args={extra!r})
+if dist.get_rank() == 0:
+    np.savez(os.path.join({out!r}, "dist_train.npz"), weights=st["weights"], iters=st["iters"], tuples=st["tuples"], in_off=st["offset_scale"][0])
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_rank_training_equals_single_process(tmp_path, da):
+    """Rollout shards + tuple gather + trainer on rank 0 + policy broadcast (gloo, world size 2) == train() in one process, bit for bit."""
+    extra = {"terrain_seed": 3, "trainer_num_init_samples": 30, "trainer_replay_mem_size": 512, "trainer_freeze_target_iters": 4,
+             "init_exp_rate": 0.3, "init_exp_base_rate": 0.1}
+    script = tmp_path / "train_worker.py"
+    script.write_text(TRAIN_WORKER.format(repo=REPO, out=str(tmp_path), extra=extra))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29613", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = np.load(tmp_path / "dist_train.npz")
+    # the same run in ONE process (also with a single OpenMP thread: float32 GEMM/conv reductions depend on the thread count)
+    single = tmp_path / "train_single.py"
+    single.write_text("import os, sys, numpy as np\nsys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+                      "from conftest import REFDATA, EMUL_LIB\nfrom deepterrainrl_amd import train_loop\n"
+                      "st = train_loop.train('args/opt_args_train_mace.txt', REFDATA, num_envs=64, max_frames=90, trainer_device='cpu', _lib_path=EMUL_LIB, extra_args=%r)\n"
+                      "np.savez(os.path.join(%r, 'single_train.npz'), weights=st['weights'], iters=st['iters'], tuples=st['tuples'], in_off=st['offset_scale'][0])\n"
+                      % (REPO, REPO, extra, str(tmp_path)))
+    r = subprocess.run([sys.executable, str(single)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    s1 = np.load(tmp_path / "single_train.npz")
+    assert int(d["iters"]) == int(s1["iters"]) >= 1 and int(d["tuples"]) == int(s1["tuples"])
+    assert np.array_equal(d["weights"], s1["weights"]) and np.array_equal(d["in_off"], s1["in_off"])
+
+
 def test_shard_range():
     from deepterrainrl_amd.sharding import shard_range
     assert [shard_range(32768, 8, r) for r in (0, 7)] == [(0, 4096), (28672, 4096)]
