@@ -72,6 +72,11 @@ def test_scale_file_roundtrip(da, om, tmp_path):
     T.test_scale_file_roundtrip(da, om, tmp_path)
 
 
+def test_terrain_param_lerp_curriculum(da, om, tmp_path, monkeypatch):
+    monkeypatch.setattr(T, "EMUL_LIB", HIP_LIB)
+    T.test_terrain_param_lerp_curriculum(da, om, tmp_path)
+
+
 def test_raptor_flat_and_narrow_gaps(da, om):
     """BASELINE config 2 (raptor, different KinTree topology, D = 21 kernel instantiation)."""
     T.test_raptor_flat_1200_substeps_vs_oracle(da, om)

@@ -128,6 +128,45 @@ def test_ground_bit_exact_vs_oracle(da, om, arg, seed):
     assert sweeps >= 8 and e.stats()["terrain_builds"] > 2
 
 
+def test_terrain_param_lerp_curriculum(da, om, tmp_path):
+    """cScenarioSimChar::SetTerrainParamsLerp / -terrain_blend= (scenarios/ScenarioSimChar.cpp:255-272): a terrain file with two
+    parameter sets (the shipped files carry one, so the curriculum is synthetic here); creation-time blend and run-time lerp
+    followed by a seeded reset must give the oracle's ground bit for bit."""
+    import json, shutil
+    root = tmp_path / "data_root"
+    shutil.copytree(REFDATA, root)
+    tf = root / "data" / "terrain" / "mixed.txt"
+    d = json.load(open(tf))
+    easy = dict(d["Params"][0])
+    for k in easy:
+        if isinstance(easy[k], (int, float)) and ("Height" in k or "Delta" in k or "Gap" in k and "Spacing" not in k):
+            easy[k] = 0.25 * easy[k]
+    d["Params"] = [easy, d["Params"][0]]
+    json.dump(d, open(tf, "w"))
+
+    def grounds_equal(b, e):
+        s0, a0, _, _ = e.ground_segment(0); s1, a1, _, _ = e.ground_segment(1)
+        xs = np.concatenate([a0 + 0.1 * np.arange(len(s0)), a1 + 0.1 * np.arange(len(s1))])
+        h, seg, i, j = b.SampleGround(0, xs)
+        ho = np.array([e.sample_ground(x)[0] for x in xs])
+        return np.array_equal(h, ho)
+
+    heights = {}
+    for blend in (0.0, 0.35, 1.0):
+        m, _ = om.build_model("args/opt_args_train_mace.txt", str(root), overrides={"terrain_blend": blend})
+        e = om.OracleEnv(m, terrain_seed=21)
+        b = da.BatchScenario("args/opt_args_train_mace.txt", 1, data_root=str(root), extra_args={"terrain_seed": 21, "terrain_blend": blend}, _lib_path=EMUL_LIB)
+        assert grounds_equal(b, e)
+        heights[blend] = np.array(e.ground_segment(1)[0])
+    assert not np.array_equal(heights[0.0], heights[1.0]) and not np.array_equal(heights[0.35], heights[1.0])
+    # run-time lerp: takes effect at the next segment build; a seeded reset rebuilds the window from scratch
+    b = da.BatchScenario("args/opt_args_train_mace.txt", 1, data_root=str(root), extra_args={"terrain_seed": 5, "terrain_blend": 0.0}, _lib_path=EMUL_LIB)
+    b.SetTerrainParamsLerp(0.35)
+    b.Reset([0], terrain_seeds=[21])
+    m, _ = om.build_model("args/opt_args_train_mace.txt", str(root), overrides={"terrain_blend": 0.35})
+    assert grounds_equal(b, om.OracleEnv(m, terrain_seed=21))
+
+
 def test_kernel_math_vs_oracle_flat_1200_substeps(da, om):
     """BASELINE config 0 (args/sim_dog_args.txt, flat, 1 env, 1200 substeps): lane-phase planar math vs the oracle's
     6-D spatial algebra, per env-step: pose/vel, controller torque before/after the clamp, contact flags, FSM state."""
