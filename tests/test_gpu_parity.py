@@ -72,6 +72,11 @@ def test_scale_file_roundtrip(da, om, tmp_path):
     T.test_scale_file_roundtrip(da, om, tmp_path)
 
 
+@pytest.mark.parametrize("terrain", ["gaps", "mixed", "narrow_gaps", "cliffs_rugged"])
+def test_shipped_terrain_types(da, om, terrain):
+    T.test_every_shipped_terrain_type_vs_oracle(da, om, terrain)
+
+
 def test_terrain_param_lerp_curriculum(da, om, tmp_path, monkeypatch):
     monkeypatch.setattr(T, "EMUL_LIB", HIP_LIB)
     T.test_terrain_param_lerp_curriculum(da, om, tmp_path)

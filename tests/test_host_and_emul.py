@@ -128,6 +128,30 @@ def test_ground_bit_exact_vs_oracle(da, om, arg, seed):
     assert sweeps >= 8 and e.stats()["terrain_builds"] > 2
 
 
+@pytest.mark.parametrize("terrain", ["flat", "gaps", "steps", "walls", "mixed", "mixed_raptor", "narrow_gaps", "slopes", "slopes_mixed", "cliffs_rugged"])
+def test_every_shipped_terrain_type_vs_oracle(da, om, terrain):
+    """Each data/terrain/*.txt the reference ships: the product's generator (C++) and the oracle's give the same window, bit for bit,
+    at creation and after several slides (the character is teleported forward so the window has to rebuild)."""
+    tfile = "data/terrain/%s.txt" % terrain
+    m, _ = om.build_model("args/sim_dog_args.txt", REFDATA, overrides={"terrain_file": tfile})
+    e = om.OracleEnv(m, terrain_seed=77)
+    b = batch(da, "args/sim_dog_args.txt", 1, terrain_seed=77, terrain_file=tfile)
+    for hop in range(6):
+        s0, a0, _, _ = e.ground_segment(0); s1, a1, _, _ = e.ground_segment(1)
+        xs = np.concatenate([a0 + 0.1 * np.arange(len(s0)), a1 + 0.1 * np.arange(len(s1))])
+        h, seg, i, j = b.SampleGround(0, xs)
+        ref = [e.sample_ground(x) for x in xs]
+        assert np.array_equal(h, [r[0] for r in ref]) and list(seg) == [r[2] for r in ref] and list(i) == [r[3] for r in ref]
+        # move both characters 9 m ahead (above the terrain) and step once: the frame-boundary ground update slides the window.
+        # (Stays within the incremental-slide regime: a jump past the whole window re-centres it on the root x of the moment of the
+        # update, which is the frame end here and the env-step in the reference -- DESIGN.md 5.)
+        q, qd = b.PoseVel()
+        q[0][0] += 9.0; q[0][1] = 4.0 + max(h); qd[:] = 0
+        b.SetPoseVel(q, qd); e.set_pose_vel(q[0], qd[0])
+        b.Update(); e.update()
+    assert e.stats()["terrain_builds"] >= 3
+
+
 def test_terrain_param_lerp_curriculum(da, om, tmp_path):
     """cScenarioSimChar::SetTerrainParamsLerp / -terrain_blend= (scenarios/ScenarioSimChar.cpp:255-272): a terrain file with two
     parameter sets (the shipped files carry one, so the curriculum is synthetic here); creation-time blend and run-time lerp
