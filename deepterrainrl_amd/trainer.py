@@ -193,6 +193,9 @@ class MACETrainer:
         self.in_off, self.in_scale, self.out_off, self.out_scale = z(state_size, 0.0), z(state_size, 1.0), z(self.out_size, 0.0), z(self.out_size, 1.0)
         self.mem = torch.zeros((mem_size, self.W), device=self.device, dtype=torch.float32)   # mPlaybackMem (float, as the reference)
         self.flags = np.zeros(mem_size, np.int64)
+        self.flags_dev = torch.zeros(mem_size, device=self.device, dtype=torch.int64)     # device mirror (no host round trip when a batch is built)
+        self._idx_pin = torch.zeros((64, 256), dtype=torch.int64).pin_memory() if self.device.type == "cuda" else None   # ring of staging slots
+        self._idx_slot = 0
         self.rng = np.random.RandomState(seed)
         self.Reset()
         self.UpdateTargetNet()
@@ -279,7 +282,9 @@ class MACETrainer:
         keep = np.nonzero(ok)[0]
         if keep.size:
             slots[keep] = (self.head + np.arange(keep.size)) % self.mem_size
-            self.mem[torch.as_tensor(slots[keep], device=self.device)] = torch.as_tensor(rows[keep], device=self.device)
+            didx = self._idx(slots[keep])
+            self.mem[didx] = torch.as_tensor(rows[keep], device=self.device)
+            self.flags_dev[didx] = torch.as_tensor(np.asarray(flags, np.int64)[keep], device=self.device)
             for i in keep:   # same order as the reference: write slot, advance head, then UpdateBuffers(slot)
                 t = int(slots[i])
                 self.flags[t] = int(flags[i])
@@ -354,22 +359,34 @@ class MACETrainer:
             return []
         return [self.critic_buffer[int(self.rng.randint(0, n))] for _ in range(size)]
 
-    def _rows(self, ids):
-        return self.mem[torch.as_tensor(np.asarray(ids, np.int64), device=self.device)]
+    def _idx(self, ids):
+        """Index list -> device tensor; on the GPU through page-locked staging so the copy is queued, not synchronous."""
+        a = np.asarray(ids, np.int64)
+        if self._idx_pin is None or a.size > self._idx_pin.shape[1]:
+            return torch.as_tensor(a, device=self.device)
+        # a slot is rewritten only 64 calls later, long after its queued copy has run (every iteration ends in a host read-back)
+        self._idx_slot = (self._idx_slot + 1) % self._idx_pin.shape[0]
+        buf = self._idx_pin[self._idx_slot, :a.size]
+        buf.copy_(torch.from_numpy(a))
+        return buf.to(self.device, non_blocking=True)
 
-    def _new_q(self, rows, ids):
+    def _rows(self, ids):
+        return self.mem[self._idx(ids)]
+
+    def _new_q(self, rows, idx):
         """CalcNewCumulativeRewardBatch: r (1 - discount) + discount max_frag Q_target(s'), or r (1 - discount) on failure."""
         r = rows[:, 0].to(self.dtype) * (1.0 - self.discount)
         q_end = self._eval(self._target_net(), rows[:, 1 + self.S + self.A:])[:, :self.num_frags].max(1).values
-        fail = torch.as_tensor((self.flags[np.asarray(ids)] & FLAG_FAIL) != 0, device=self.device)
+        fail = (self.flags_dev[idx] & FLAG_FAIL) != 0
         return torch.where(fail, r, r + self.discount * q_end)
 
     def _critic_problem(self, ids):
-        rows = self._rows(ids)
+        idx = self._idx(ids)
+        rows = self.mem[idx]
         X = rows[:, 1:1 + self.S]
         Y = self._eval(self.net, X)
         a = rows[:, 1 + self.S].to(torch.int64)
-        Y[torch.arange(len(ids), device=self.device), a] = self._new_q(rows, ids)
+        Y.scatter_(1, a[:, None], self._new_q(rows, idx)[:, None].to(Y.dtype))
         return X, Y
 
     # ---- actor
@@ -386,9 +403,10 @@ class MACETrainer:
         ids = self.FetchActorMinibatch(self.batch)
         if not ids:
             return
-        rows = self._rows(ids)
+        idx = self._idx(ids)
+        rows = self.mem[idx]
         curr = self._eval(self._target_net(), rows[:, 1:1 + self.S])[:, :self.num_frags].max(1).values
-        new = self._new_q(rows, ids)
+        new = self._new_q(rows, idx)
         better = (new > curr).cpu().numpy()
         self.actor_batch_buffer += [t for t, b in zip(ids, better) if b]
 

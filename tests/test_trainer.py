@@ -74,7 +74,7 @@ def test_bookkeeping_targets_and_labels_vs_oracle():
     X, Y = t._critic_problem(ids)
     for i, tid in enumerate(ids):
         assert np.abs(Y[i].numpy() - book.critic_label(tid, net_eval, net_eval)).max() < 1e-12
-    newq = t._new_q(t._rows(ids), ids).numpy()
+    newq = t._new_q(t._rows(ids), t._idx(ids)).numpy()
     assert np.allclose(newq, [book.new_q(tid, net_eval) for tid in ids], rtol=0, atol=1e-12)
     fails = [tid for tid in ids if book.flags[tid] & 1]
     assert fails and all(abs(book.new_q(tid, net_eval) - float(book.mem[tid][0]) * (1 - t.discount)) < 1e-15 for tid in fails)
