@@ -31,7 +31,7 @@ TUPLE_FAIL, TUPLE_EXP_CRITIC, TUPLE_EXP_ACTOR = 1, 2, 4
 
 # every symbol include/dtrl.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = [
-    "dtrl_create", "dtrl_destroy", "dtrl_reset", "dtrl_step", "dtrl_step_updates", "dtrl_run_frames", "dtrl_set_policy",
+    "dtrl_create", "dtrl_destroy", "dtrl_reset", "dtrl_step", "dtrl_step_begin", "dtrl_step_end", "dtrl_step_updates", "dtrl_run_frames", "dtrl_set_policy",
     "dtrl_policy_num_params", "dtrl_build_output_offset_scale", "dtrl_load_scale_file", "dtrl_write_scale_file", "dtrl_set_explore", "dtrl_set_terrain_lerp", "dtrl_drain_tuples",
     "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
@@ -51,6 +51,8 @@ def _bind(path):
     L.dtrl_destroy.argtypes = [vp]
     L.dtrl_reset.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_step.argtypes = [vp, C.c_double]
+    L.dtrl_step_begin.argtypes = [vp, C.c_double]
+    L.dtrl_step_end.argtypes = [vp]
     L.dtrl_step_updates.argtypes = [vp, C.c_int]
     L.dtrl_run_frames.argtypes = [vp, C.c_int, C.c_double]
     L.dtrl_set_policy.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, vp]
@@ -131,6 +133,13 @@ class BatchScenario:
     # ---- cScenario interface ----
     def Update(self, dt=1.0 / 30.0):
         self._chk(self._lib.dtrl_step(self._h, float(dt)))
+
+    def UpdateBegin(self, dt=1.0 / 30.0):
+        """Queue one outer frame on the engine's stream and return (dtrl_step_begin); pair with UpdateEnd()."""
+        self._chk(self._lib.dtrl_step_begin(self._h, dt))
+
+    def UpdateEnd(self):
+        self._chk(self._lib.dtrl_step_end(self._h))
 
     def StepUpdates(self, n):
         self._chk(self._lib.dtrl_step_updates(self._h, int(n)))

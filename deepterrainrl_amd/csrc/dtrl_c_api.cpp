@@ -33,6 +33,8 @@ dtrl_status dtrl_destroy(dtrl_batch* b) { delete b; return DTRL_OK; }
 
 dtrl_status dtrl_reset(dtrl_batch* b, const int32_t* env_ids, int n, const uint64_t* seeds) { CHECK_B(); return static_cast<dtrl_status>(b->eng.Reset(env_ids, n, seeds)); }
 dtrl_status dtrl_step(dtrl_batch* b, double dt) { CHECK_B(); return static_cast<dtrl_status>(b->eng.Step(dt)); }
+dtrl_status dtrl_step_begin(dtrl_batch* b, double dt) { CHECK_B(); return static_cast<dtrl_status>(b->eng.StepBegin(dt)); }
+dtrl_status dtrl_step_end(dtrl_batch* b) { CHECK_B(); return static_cast<dtrl_status>(b->eng.StepEnd()); }
 dtrl_status dtrl_step_updates(dtrl_batch* b, int n) { CHECK_B(); return static_cast<dtrl_status>(b->eng.StepUpdates(n)); }
 dtrl_status dtrl_run_frames(dtrl_batch* b, int frames, double dt) { CHECK_B(); return static_cast<dtrl_status>(b->eng.RunFrames(frames, dt)); }
 dtrl_status dtrl_set_policy(dtrl_batch* b, const float* w, size_t n, const double* io, const double* is, const double* oo, const double* os)

@@ -197,15 +197,30 @@ int Engine::HostFrameWork()
 	return ApplyResets(reset_ids_);
 }
 
-int Engine::Step(double dt)
+int Engine::StepBegin(double dt)
 {
+	if (step_pending_) return Fail(DTRL_ERR_ARG, "dtrl_step_begin called twice without dtrl_step_end");
 	if (dt <= 0) return DTRL_OK;   // cScenarioSimChar::Update returns early (scenarios/ScenarioSimChar.cpp:148-151)
 	if (cfg_.model.has_net && !policy_set_) return Fail(DTRL_ERR_ARG, "policy_net was given but dtrl_set_policy has not been called");
 	const int steps = cfg_.model.num_update_steps;
 	DevBuffers b = buf_;
 	if (order_valid_) b.env_list = d_order_;
 	if (!be_->Launch(d_model_, cfg_.run, b, n_, steps, dt / steps, true)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	step_pending_ = true;
+	return DTRL_OK;
+}
+
+int Engine::StepEnd()
+{
+	if (!step_pending_) return DTRL_OK;
+	step_pending_ = false;
 	return HostFrameWork();
+}
+
+int Engine::Step(double dt)
+{
+	int rc = StepBegin(dt);
+	return rc != DTRL_OK ? rc : StepEnd();
 }
 
 int Engine::StepUpdates(int n)

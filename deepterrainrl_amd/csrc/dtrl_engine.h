@@ -38,6 +38,8 @@ public:
 	int Create(const char* const* argv, int argc, int num_envs, int device_id);
 	int Reset(const int32_t* env_ids, int n, const uint64_t* seeds);
 	int Step(double dt);
+	int StepBegin(double dt);
+	int StepEnd();
 	int StepUpdates(int n);
 	int RunFrames(int frames, double dt);
 	int SetPolicy(const float* w, size_t n, const double* io, const double* is, const double* oo, const double* os);
@@ -77,6 +79,7 @@ private:
 	Backend* be_ = nullptr;
 	int n_ = 0, S_ = 0, A_ = 0, W_ = 0;
 	bool policy_set_ = false;
+	bool step_pending_ = false;
 	DevModel* d_model_ = nullptr;
 	DevBuffers buf_{};
 	std::vector<void*> allocs_;

@@ -33,8 +33,11 @@ def parse_arg_file(path):
 
 
 def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, device_id=-1, extra_args=None, seed=0, log_every=0, out_scale_file=None,
-          trainer_device=None, _lib_path=None):
-    """extra_args override / extend the arg file (both for the engine and for the -trainer_* keys read here)."""
+          trainer_device=None, overlap=False, _lib_path=None):
+    """extra_args override / extend the arg file (both for the engine and for the -trainer_* keys read here).
+    overlap=True trains on frame f's tuples while the GPU already rolls out frame f+1 (dtrl_step_begin / dtrl_step_end): the policy
+    each frame runs with is one frame staler, as with the reference's concurrent env threads; overlap=False is the strictly
+    sequential, reproducible schedule."""
     args = parse_arg_file(os.path.join(data_root, arg_file))
     args.update({k: str(v) for k, v in (extra_args or {}).items()})
     geti = lambda k, d: int(args.get(k, d)); getf = lambda k, d: float(args.get(k, d))
@@ -63,21 +66,45 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     frames = tuples = 0
     t0 = time.time()
     stats = {"log": []}
-    while t.GetIter() < max_iters and (max_frames is None or frames < max_frames):
-        b.Update(1.0 / 30.0)
-        frames += 1
-        rows, flags, ids = b.DrainTuples()
+    def feed(rows, flags, ids):
         o = np.argsort(ids, kind="stable")   # the device ring is filled in completion order; env-id order makes the run reproducible and shard-invariant
         rows, flags = rows[o], flags[o]
         for k in range(0, len(rows), chunk):
             t.AddTuples(rows[k:k + chunk], flags[k:k + chunk])
             t.Train()
-        tuples += len(rows)
-        if len(rows):
-            sync(t.GetIter())
+        return len(rows)
+
+    def log():
         if log_every and frames % log_every == 0:
             stats["log"].append((frames, t.GetIter(), t.GetNumTuples(), t.last_loss, b.EvalStats()))
             print("frame %d iter %d tuples %d critic-loss %s actor-iters %d" % (frames, t.GetIter(), t.GetNumTuples(), t.last_loss, t.actor_iter), flush=True)
+
+    if not overlap:
+        while t.GetIter() < max_iters and (max_frames is None or frames < max_frames):
+            b.Update(1.0 / 30.0)
+            frames += 1
+            n = feed(*b.DrainTuples())
+            tuples += n
+            if n:
+                sync(t.GetIter())
+            log()
+    else:
+        pending = None
+        b.UpdateBegin(1.0 / 30.0)
+        while True:
+            b.UpdateEnd()                                   # frame f is complete (host work done)
+            frames += 1
+            drained = b.DrainTuples()
+            if pending is not None and pending[0].shape[0]:
+                sync(t.GetIter())                           # weights trained on frames <= f-1 go in before frame f+1 starts
+            more = t.GetIter() < max_iters and (max_frames is None or frames < max_frames)
+            if more:
+                b.UpdateBegin(1.0 / 30.0)                   # frame f+1 runs on the engine's stream ...
+            tuples += feed(*drained)                        # ... while the trainer works through frame f's tuples
+            pending = drained
+            log()
+            if not more:
+                break
     dt = time.time() - t0
     if out_scale_file:
         b.WriteOffsetScale(out_scale_file)

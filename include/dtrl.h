@@ -66,6 +66,13 @@ dtrl_status dtrl_reset(dtrl_batch* b, const int32_t* env_ids, int n, const uint6
  * scenarios/ScenarioSimChar.cpp:162-173, then fall handling (tuple + reset). dt is normally 1/30. */
 dtrl_status dtrl_step(dtrl_batch* b, double dt);
 
+/* dtrl_step split in two, so the caller can overlap its own GPU work (e.g. the trainer: the reference's env threads and trainer
+ * run concurrently, scenarios/ScenarioTrain.cpp:100-115) with the frame kernel: dtrl_step_begin queues the frame launch on the
+ * engine's stream and returns; dtrl_step_end waits for it and performs the frame-boundary host work (terrain windows, resets).
+ * dtrl_step(dt) == dtrl_step_begin(dt); dtrl_step_end(). No other call on the batch is allowed between the two. */
+dtrl_status dtrl_step_begin(dtrl_batch* b, double dt);
+dtrl_status dtrl_step_end(dtrl_batch* b);
+
 /* Finer grain: n iterations of the loop body only (no end-of-frame fall handling); used by parity tests and to count in
  * env-steps. The step length is (1/30)/num_update_steps. */
 dtrl_status dtrl_step_updates(dtrl_batch* b, int n);

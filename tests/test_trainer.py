@@ -165,6 +165,10 @@ def test_train_loop_end_to_end_on_cpu(da):
     assert np.all(np.isfinite(st["weights"])) and st["weights"].size == 570474
     io, isc, oo, osc = st["offset_scale"]
     assert not np.allclose(io, 0) and np.all(np.isfinite(isc))       # trainer_init_input_offset_scale = true
+    # overlapped schedule (dtrl_step_begin / dtrl_step_end): same data path, policy one frame staler
+    st2 = train_loop.train("args/opt_args_train_mace.txt", REFDATA, num_envs=64, max_frames=90, trainer_device="cpu", _lib_path=EMUL_LIB, overlap=True,
+                           extra_args={"terrain_seed": 3, "trainer_num_init_samples": 30, "trainer_replay_mem_size": 512, "trainer_freeze_target_iters": 4, "init_exp_rate": 0.3, "init_exp_base_rate": 0.1})
+    assert st2["frames"] == 90 and st2["tuples"] >= 40 and st2["iters"] >= 1 and np.all(np.isfinite(st2["weights"]))
 
 
 @pytest.mark.gpu
