@@ -18,7 +18,7 @@
 //   * per-env working set (kinematics, H, constraint rows, Delassus matrix) is staged in LDS; lanes map to links / DoFs /
 //     constraint rows / contact sample points; tree sweeps become path walks and subtree-mask sums with no level barriers;
 //   * the contact solve is projected Gauss-Seidel in lambda space on the dense Delassus matrix so a row update is one
-//     broadcast + one FMA per lane (see pgs_solve; the register/readlane form is in dtrl_engine.hip);
+//     broadcast + one FMA per lane (see pgs_solve; the register/readlane form is pgs_solve_fast in dtrl_kernel_fast.h);
 //   * one kernel launch advances a whole outer frame (20 env-steps); state touches HBM only at frame boundaries.
 //
 // The code is written once in "lane-phase" form: LANES_BEGIN/LANES_END delimit a phase executed by every lane, with a
