@@ -55,7 +55,7 @@ def load_scale():
     return [np.asarray(d[k], np.float64) for k in ("InputOffset", "InputScale", "OutputOffset", "OutputScale")]
 
 
-def cpu_baseline():
+def cpu_baseline(frames=100):
     """The oracle restatement (NOT Bullet -- the reference cannot be built here) timed on the host cores, bounded sample."""
     from oracle import model as om
     m, info = om.build_model(ARG_FILE, ROOT)
@@ -63,7 +63,7 @@ def cpu_baseline():
     w = om.xavier_weights(desc, 1234)
     io, isc, oo, osc = load_scale()
     cores = os.cpu_count() or 1
-    envs_per_thread, frames = 8, 100
+    envs_per_thread = 8
     n_envs = cores * envs_per_thread
     t0 = time.time()
     rate, resets, cycles = om.batch_run(m, n_envs, cores, frames, terrain_seed0=0, rng_seed=0, policy=(desc, w, io, isc, oo, osc))
@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=100, help="outer frames of the bounded CPU-baseline sample (default: about 30 s of CPU work)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,7 +146,7 @@ def main():
             "substeps_per_sec": value * 5, "stats": b.EvalStats(),
         }
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(a.cpu_frames)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -167,3 +167,22 @@ def test_fast_kernel_equals_reference_kernel_bitwise(da, om, monkeypatch):
     (qr, qdr), (tcr, tar), sr, cr = run("ref")
     assert np.array_equal(qf, qr) and np.array_equal(qdf, qdr) and np.array_equal(tcf, tcr) and np.array_equal(taf, tar)
     assert sf == sr and all(np.array_equal(a, b) for a, b in zip(cf, cr))
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the driver's contract keys, the roofline object and (unless skipped) the CPU baseline."""
+    import json, subprocess, sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "2", "--envs-per-gpu", "512", "--cpu-frames", "8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"] and d["value"] > 1e5
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel_launches"] == 3 and rf["kernel_avg_ms"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
