@@ -121,7 +121,9 @@ def main():
     total_env_steps = float(world) * n * a.steps * steps_per_frame
     value = total_env_steps / dt
     if rank == 0:
-        env_steps_per_launch = n * steps_per_frame
+        # the engine splits the batch into env groups (own stream each, no frame barrier between them): a launch covers one group
+        env_steps_per_launch = n * a.steps * steps_per_frame / max(launches, 1)
+        concurrent = max(1, int(round(launches / float(a.steps))))
         ach = B_ALG * env_steps_per_launch / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure comes from the latest committed
         # rocprofv3 --pmc passes of this same command (tools/gpu_profile.sh -> tools/rocpd_summary.py -> profiles/hbm_traffic.json)
@@ -139,8 +141,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": float(traffic) if traffic else None,
                          "kernel": "dtrl_frame_kernel", "kernel_avg_ms": kern_ms, "kernel_launches": launches,
-                         "algorithmic_bytes_per_env_step": B_ALG, "env_steps_per_launch": env_steps_per_launch,
-                         "note": "the fused path is latency/VALU/LDS-bound, not HBM-bound (SURVEY 8d); companion figure below",
+                         "algorithmic_bytes_per_env_step": B_ALG, "env_steps_per_launch": env_steps_per_launch, "concurrent_launches": concurrent,
+                         "aggregate_achieved": B_ALG * n * a.steps * steps_per_frame / dt / 1e9,
+                         "note": "per-launch figure (launches of the env groups overlap; aggregate_achieved = all bytes / wall time); the fused path is latency/VALU/LDS-bound, not HBM-bound (SURVEY 8d); companion figure below",
                          "valu": {"achieved": F_ALG * env_steps_per_launch / (kern_ms * 1e-3) / 1e12, "peak": FP64_VEC_PEAK_TF, "unit": "TFLOP/s (fp64 vector)",
                                   "frac": F_ALG * env_steps_per_launch / (kern_ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TF, "algorithmic_flops_per_env_step": F_ALG}},
             "substeps_per_sec": value * 5, "stats": b.EvalStats(),

@@ -39,7 +39,7 @@ public:
 	~HipBackend() override
 	{
 		for (auto& ev : events_) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-		if (stream_) hipStreamDestroy(stream_);
+		for (hipStream_t st : streams_) if (st) hipStreamDestroy(st);
 	}
 	bool Init(int device_id, std::string& err) override
 	{
@@ -47,8 +47,12 @@ public:
 		hipError_t e = hipGetDeviceCount(&count);
 		if (e != hipSuccess || count <= 0) { err = std::string("no usable HIP device (") + hipGetErrorString(e) + "); the engine has no CPU fallback"; return false; }
 		if (device_id >= 0) { e = hipSetDevice(device_id); if (e != hipSuccess) { err = std::string("hipSetDevice: ") + hipGetErrorString(e); return false; } }
-		e = hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
-		if (e != hipSuccess) { err = std::string("hipStreamCreate: ") + hipGetErrorString(e); return false; }
+		streams_.assign(kNumStreams, nullptr);
+		for (int i = 0; i < kNumStreams; ++i) {
+			e = hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking);
+			if (e != hipSuccess) { err = std::string("hipStreamCreate: ") + hipGetErrorString(e); return false; }
+		}
+		stream_ = streams_[0];
 		return true;
 	}
 	void* Alloc(size_t bytes) override
@@ -86,10 +90,12 @@ public:
 		if (timed) { hipEventRecord(ev.second, stream_); pending_.push_back(ev); }
 		return Check(hipGetLastError(), "kernel launch");
 	}
-	bool Sync() override { return Check(hipStreamSynchronize(stream_), "hipStreamSynchronize"); }
+	bool Sync() override { bool ok = true; for (hipStream_t st : streams_) ok = Check(hipStreamSynchronize(st), "hipStreamSynchronize") && ok; return ok; }
+	int NumStreams() const override { return kNumStreams; }
+	void SelectStream(int sid) override { stream_ = streams_[(sid >= 0 && sid < kNumStreams) ? sid : 0]; }
 	void KernelTime(double* avg_ms, int64_t* launches) override
 	{
-		hipStreamSynchronize(stream_);
+		for (hipStream_t st : streams_) hipStreamSynchronize(st);
 		double sum = 0; int64_t n = 0;
 		for (auto& ev : pending_) { float ms = 0; if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { sum += ms; ++n; } free_events_.push_back(ev); }
 		pending_.clear();
@@ -99,7 +105,9 @@ public:
 	const char* Name() const override { return "hip"; }
 private:
 	bool Check(hipError_t e, const char* what) { if (e == hipSuccess) return true; err_ = std::string(what) + ": " + hipGetErrorString(e); return false; }
-	hipStream_t stream_ = nullptr;
+	static constexpr int kNumStreams = 8;
+	std::vector<hipStream_t> streams_;
+	hipStream_t stream_ = nullptr;   // the selected one
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events_, free_events_, pending_;
 };
 

@@ -22,7 +22,10 @@ public:
 	virtual void FreeHostStaging(void* p) = 0;
 	virtual bool D2H(void* dst, const void* src, size_t n) = 0;
 	virtual bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) = 0;
-	virtual bool Sync() = 0;
+	virtual bool Sync() = 0;                 // all streams
+	// work queues: H2D / H2DAsync / D2H / Launch act on the selected stream (0 by default); D2H and H2D synchronise only that stream
+	virtual int NumStreams() const = 0;
+	virtual void SelectStream(int sid) = 0;
 	virtual void KernelTime(double* avg_ms, int64_t* launches) = 0;
 	virtual const char* Name() const = 0;
 	const std::string& error() const { return err_; }
@@ -65,14 +68,17 @@ public:
 
 private:
 	int Fail(int code, const std::string& msg) { err_ = msg; return code; }
-	int HostFrameWork();
-	int ApplyResets(const std::vector<int32_t>& ids);
+	int HostFrameWork(int group);
+	int ApplyResets(const std::vector<int32_t>& ids, int group);
+	int LaunchGroup(int group, int n_steps, double dt_step, bool frame_end);
+	// env groups: contiguous env ranges, each with its own stream, launch order and staging slices. Envs are independent, so a group
+	// starts its next frame as soon as ITS host work is done instead of waiting for the slowest wavefront of the whole batch
+	struct Group { int e0 = 0, n = 0; };
+	std::vector<Group> groups_;
 	int32_t* d_env_list_ = nullptr;
 	int32_t* d_order_ = nullptr;         // launch order of the full-batch frame launches (costliest env first)
-	bool order_valid_ = false;
 	std::vector<int32_t> reset_ids_;
 	bool UploadGround(int env);
-	bool UploadGroundAsync(int env);
 	int EnvIndex(const int32_t* env_ids, int i) const { return env_ids ? env_ids[i] : i; }
 
 	ScenarioConfig cfg_;
@@ -90,7 +96,7 @@ private:
 	int UploadNormalizers();
 	// page-locked staging for the per-frame uploads (terrain records, launch order, reset list): the copies are queued on the
 	// stream without a host sync; the arena is recycled after the next frame's status read-back (a stream sync)
-	GroundRec* pin_recs_ = nullptr; int pin_recs_used_ = 0;
+	GroundRec* pin_recs_ = nullptr;
 	int32_t* pin_order_ = nullptr; int32_t* pin_ids_ = nullptr;
 	std::vector<int32_t> bucket_;
 	std::string err_;

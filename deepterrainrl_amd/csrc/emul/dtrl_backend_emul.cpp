@@ -35,6 +35,8 @@ public:
 		return true;
 	}
 	bool Sync() override { return true; }
+	int NumStreams() const override { return 8; }
+	void SelectStream(int) override {}
 	void KernelTime(double* avg_ms, int64_t* launches) override { if (avg_ms) *avg_ms = 0; if (launches) *launches = launches_; launches_ = 0; }
 	const char* Name() const override { return "emul"; }
 private:

@@ -169,6 +169,10 @@ def test_fast_kernel_equals_reference_kernel_bitwise(da, om, monkeypatch):
     assert sf == sr and all(np.array_equal(a, b) for a, b in zip(cf, cr))
 
 
+def test_env_groups_pipelined_run_frames(da, om, monkeypatch):
+    T.test_env_groups_pipelined_run_frames_equals_stepwise(da, om, monkeypatch)
+
+
 def test_bench_contract_line():
     """bench.py prints ONE JSON line with the driver's contract keys, the roofline object and (unless skipped) the CPU baseline."""
     import json, subprocess, sys

@@ -348,6 +348,31 @@ def test_shard_invariance(da, om):
     assert np.array_equal(qf[2:], qp) and np.array_equal(qdf[2:], qdp)
 
 
+def test_env_groups_pipelined_run_frames_equals_stepwise(da, om, monkeypatch):
+    """RunFrames(k) lets every env group (own stream, own launch order, own frame-boundary host work) run ahead without a frame
+    barrier across groups; the envs are independent, so the result must equal k calls of Update() and must not depend on the
+    number of groups -- including resets, terrain slides and the tuple stream per env."""
+    pol = dog_policy(om)
+    res = []
+    for groups, stepwise in ((1, True), (3, False), (4, True), (2, False)):
+        monkeypatch.setenv("DTRL_GROUPS", str(groups))
+        b = batch(da, "args/opt_args_train_mace.txt", 7, terrain_seed=31, rand_seed=4, exp_base_rate=0.3, exp_rate=0.5)
+        b.SetPolicy(pol[1], *pol[2:])
+        if stepwise:
+            for _ in range(140):
+                b.Update()
+        else:
+            b.RunFrames(25); b.RunFrames(115)
+        rows, flags, ids = b.DrainTuples()
+        o = np.lexsort((np.arange(len(ids)), ids))
+        res.append((b.PoseVel(), b.EvalStats(), rows[o], flags[o], ids[o], b.SampleGround(3, np.linspace(-5, 25, 50))[0]))
+    q0, st0 = res[0][0], res[0][1]
+    assert st0["resets"] >= 1 and len(res[0][2]) >= 7
+    for r in res[1:]:
+        assert np.array_equal(r[0][0], q0[0]) and np.array_equal(r[0][1], q0[1]) and r[1] == st0
+        assert np.array_equal(r[2], res[0][2]) and np.array_equal(r[3], res[0][3]) and np.array_equal(r[4], res[0][4]) and np.array_equal(r[5], res[0][5])
+
+
 def test_set_pose_vel_and_reset_roundtrip(da, om):
     m, _ = om.build_model("args/sim_dog_args.txt", REFDATA)
     b = batch(da, "args/sim_dog_args.txt", 3, terrain_seed=1)
