@@ -29,18 +29,20 @@ def main(src, dst):
         out.append("\n%s dispatches by grid size (threads): grid, n, avg_ms, min_ms, max_ms, vgpr, sgpr, lds_bytes, scratch_bytes" % KERNEL)
         for r in rows:
             out.append("  %8d %4d %10.3f %10.3f %10.3f %5s %5s %7s %7s" % (r[0], r[1], r[2] / 1e6, r[3] / 1e6, r[4] / 1e6, r[5], r[6], r[7], r[8]))
-        last = [r[0] for r in cur.execute("select duration from kernels where name like '%" + KERNEL + "%' and grid_x = (select max(grid_x) from kernels where name like '%" + KERNEL + "%') order by start desc limit 60")]
-        if last:
-            out.append("  timed region = last %d full-batch launches: avg %.3f ms (compare roofline.kernel_avg_ms of the bench line)" % (len(last), sum(last) / len(last) / 1e6))
+        dom = list(cur.execute("select grid_x from kernels where name like '%" + KERNEL + "%' group by grid_x order by sum(duration) desc limit 1"))
+        if dom:
+            per_step = max(1, round(sum(1 for _ in cur.execute("select 1 from kernels where name like '%" + KERNEL + "%' and grid_x = ?", (dom[0][0],))) / 80.0))
+            last = [r[0] for r in cur.execute("select duration from kernels where name like '%" + KERNEL + "%' and grid_x = ? order by start desc limit ?", (dom[0][0], 60 * per_step))]
+            out.append("  timed region = last %d frame launches (grid %d, %d env-group launches per bench step): avg %.3f ms (compare roofline.kernel_avg_ms of the bench line)" % (len(last), dom[0][0], per_step, sum(last) / len(last) / 1e6))
         out.append("")
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_ic"):
         db = os.path.join(src, sub, "pmc_results.db")
         if not os.path.exists(db):
             continue
         cur = sqlite3.connect(db).cursor()
-        out.append("## rocprofv3 --pmc (%s pass) -- per-dispatch averages for %s (grid = full batch launches only; bench.py --steps 20 --warmup 10)" % (sub, KERNEL))
+        out.append("## rocprofv3 --pmc (%s pass) -- per-dispatch averages for %s (frame launches of the env groups only; bench.py --steps 20 --warmup 10)" % (sub, KERNEL))
         q = ("select counter_name, count(*), avg(value), max(grid_size) from counters_collection where kernel_name like '%" + KERNEL + "%' "
-             "and grid_size = (select max(grid_size) from counters_collection where kernel_name like '%" + KERNEL + "%') group by counter_name order by counter_name")
+             "and grid_size = (select grid_size from counters_collection where kernel_name like '%" + KERNEL + "%' group by grid_size order by count(*) desc limit 1) group by counter_name order by counter_name")
         for r in cur.execute(q):
             extra = ""
             if r[0] in ("FETCH_SIZE", "WRITE_SIZE"):
