@@ -33,11 +33,12 @@ def parse_arg_file(path):
 
 
 def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, device_id=-1, extra_args=None, seed=0, log_every=0, out_scale_file=None,
-          trainer_device=None, overlap=False, _lib_path=None):
+          trainer_device=None, overlap=False, frames_per_drain=1, _lib_path=None):
     """extra_args override / extend the arg file (both for the engine and for the -trainer_* keys read here).
     overlap=True trains on frame f's tuples while the GPU already rolls out frame f+1 (dtrl_step_begin / dtrl_step_end): the policy
     each frame runs with is one frame staler, as with the reference's concurrent env threads; overlap=False is the strictly
-    sequential, reproducible schedule."""
+    sequential, reproducible schedule. frames_per_drain > 1 rolls out several outer frames per drain / policy sync (RunFrames: the env
+    groups then run without a frame barrier between them, which is where the rollout engine is fastest)."""
     args = parse_arg_file(os.path.join(data_root, arg_file))
     args.update({k: str(v) for k, v in (extra_args or {}).items()})
     geti = lambda k, d: int(args.get(k, d)); getf = lambda k, d: float(args.get(k, d))
@@ -81,8 +82,11 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
 
     if not overlap:
         while t.GetIter() < max_iters and (max_frames is None or frames < max_frames):
-            b.Update(1.0 / 30.0)
-            frames += 1
+            if frames_per_drain > 1:
+                b.RunFrames(frames_per_drain)
+            else:
+                b.Update(1.0 / 30.0)
+            frames += frames_per_drain
             n = feed(*b.DrainTuples())
             tuples += n
             if n:

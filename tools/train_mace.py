@@ -12,10 +12,11 @@ ap.add_argument("--data-root", default=os.path.join(REPO, "tests", "golden", "re
 ap.add_argument("--envs", type=int, default=4096)
 ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--iters", type=int, default=None)
+ap.add_argument("--frames-per-drain", type=int, default=1)
 ap.add_argument("--overlap", action="store_true", help="train on frame f while frame f+1 rolls out (only pays off when the trainer has its own GPU: on one GPU the frame kernel fills every CU and the trainer's small kernels queue behind it -- measured 4.0 vs 4.7 M env-steps/s)")
 ap.add_argument("--out", default=None, help="write weights (.npy) and <out>_scale.txt")
 a = ap.parse_args()
-st = train_loop.train(a.arg_file, a.data_root, a.envs, max_iters=a.iters, max_frames=a.frames, log_every=50, overlap=a.overlap,
+st = train_loop.train(a.arg_file, a.data_root, a.envs, max_iters=a.iters, max_frames=a.frames, log_every=50, overlap=a.overlap, frames_per_drain=a.frames_per_drain,
                       out_scale_file=(a.out + "_scale.txt") if a.out else None)
 if a.out:
     np.save(a.out + ".npy", st["weights"])
