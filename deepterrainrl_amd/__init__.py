@@ -167,6 +167,19 @@ class BatchScenario:
         self._chk(self._lib.dtrl_build_output_offset_scale(self._h, _p(off), _p(sc)))
         return off, sc
 
+    def LoadModel(self, model_file):
+        """cNeuralNet::LoadModel (learning/NeuralNet.cpp:110-135): Caffe HDF5 weights by layer name, then the normalisers from
+        '<model>_scale.txt' next to it when that file exists (GetOffsetScaleFile)."""
+        from . import caffe_hdf5
+        w = caffe_hdf5.load_mace_weights(model_file, self.num_frags)
+        if w.size != self.PolicyNumParams():
+            raise DtrlError("%s holds %d parameters, the deploy net needs %d" % (model_file, w.size, self.PolicyNumParams()))
+        self.SetPolicy(w)
+        scale = os.path.splitext(model_file)[0] + "_scale.txt"
+        if os.path.exists(scale):
+            self.LoadScale(scale)
+        return w
+
     def LoadScale(self, path):
         """cNeuralNet::LoadScale: install the normaliser vectors of a '<model>_scale.txt' file (weights untouched)."""
         self._chk(self._lib.dtrl_load_scale_file(self._h, os.fsencode(path)))

@@ -16,6 +16,7 @@ The replay memory, both networks (current + frozen target), the solver history a
 the exact MACE replay layout the rollout engine emits ([r | s | a | s'], float32), so `dtrl_drain_tuples` output is appended as is.
 The only randomness is minibatch sampling (the reference uses its global RNG; a seeded numpy stream here).
 """
+import os
 import re
 
 import numpy as np
@@ -229,6 +230,27 @@ class MACETrainer:
         self.in_off.copy_(torch.as_tensor(off, device=self.device, dtype=self.dtype)); self.in_scale.copy_(torch.as_tensor(scale, device=self.device, dtype=self.dtype))
     def SetOutputOffsetScale(self, off, scale):
         self.out_off.copy_(torch.as_tensor(off, device=self.device, dtype=self.dtype)); self.out_scale.copy_(torch.as_tensor(scale, device=self.device, dtype=self.dtype))
+    def OutputModel(self, model_file):
+        """cNeuralNetTrainer::OutputModel -> cNeuralNet::OutputModel (learning/NeuralNet.cpp:1139-1180): the net as a Caffe HDF5 model
+        (/data/<layer>/<blob>, Caffe blob shapes) plus '<model>_scale.txt' with the normalisers, both readable by the reference."""
+        from . import caffe_hdf5
+        names = caffe_hdf5.mace_layer_names(self.num_frags)
+        layers = {}
+        for name, m in zip(names, self.net.mods):
+            w = m.weight.detach().to(torch.float32).cpu().numpy()
+            if w.ndim == 3:
+                w = w[:, :, None, :]                       # Caffe convolution blob: [out, in, kernel_h = 1, kernel_w]
+            layers[name] = [w, m.bias.detach().to(torch.float32).cpu().numpy()]
+        caffe_hdf5.write_caffe_model(model_file, layers)
+        io, isc, oo, osc = self.GetOffsetScale()
+        vec = lambda v: "[" + ", ".join("%f" % x for x in v) + "]"
+        with open(os.path.splitext(model_file)[0] + "_scale.txt", "w") as f:
+            f.write('{\n"InputOffset": %s,\n"InputScale": %s,\n"OutputOffset": %s,\n"OutputScale": %s\n}' % (vec(io), vec(isc), vec(oo), vec(osc)))
+
+    def LoadModel(self, model_file):
+        from . import caffe_hdf5
+        self.SetWeights(caffe_hdf5.load_mace_weights(model_file, self.num_frags))
+
     def GetIter(self): return self.iter
     def GetNumTuples(self): return self.num_tuples
     def EnableTargetNet(self): return self.freeze_target_iters > 0

@@ -1,0 +1,76 @@
+"""Caffe .h5 model import / export without an HDF5 library. Pin: tests/golden/caffe_model_small.h5 was written by the
+real HDF5 library (h5py, tests/golden/make_hdf5_fixture.py); its contents as read by that library are in *_expected.npz."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REFDATA, EMUL_LIB
+
+H5PY_PYTHON = "/opt/conda/bin/python3.9"   # optional cross-check against libhdf5 where this interpreter (with h5py) exists
+
+
+def test_reader_against_file_written_by_libhdf5():
+    from deepterrainrl_amd import caffe_hdf5 as h
+    m = h.read_caffe_model(os.path.join(GOLDEN, "caffe_model_small.h5"))
+    exp = np.load(os.path.join(GOLDEN, "caffe_model_small_expected.npz"))
+    assert len(exp.files) == 26 and sorted(m) == sorted({k.split("/")[0] for k in exp.files})      # parameter-less layers are skipped
+    for k in exp.files:
+        layer, idx = k.split("/")
+        got = m[layer][int(idx)]
+        assert got.dtype == np.float32 and got.shape == exp[k].shape and np.array_equal(got, exp[k])
+    assert m["terr_conv0"][0].shape == (4, 1, 1, 8)
+    w = h.load_mace_weights(os.path.join(GOLDEN, "caffe_model_small.h5"), 3)
+    assert w.size == sum(exp[k].size for k in exp.files) and np.array_equal(w[:32], exp["terr_conv0/0"].reshape(-1))
+
+
+def test_reader_rejects_what_it_does_not_understand(tmp_path):
+    from deepterrainrl_amd import caffe_hdf5 as h
+    p = tmp_path / "junk.h5"
+    p.write_bytes(b"not an hdf5 file at all" * 10)
+    with pytest.raises(h.H5Error):
+        h.read_caffe_model(str(p))
+    raw = bytearray(open(os.path.join(GOLDEN, "caffe_model_small.h5"), "rb").read())
+    raw[8] = 2                                           # superblock version 2 (new-style files)
+    p.write_bytes(bytes(raw))
+    with pytest.raises(h.H5Error):
+        h.read_caffe_model(str(p))
+    h.write_caffe_model(str(p), {"ip0": [np.ones((3, 2), np.float32)]})   # a layer without its bias
+    with pytest.raises(h.H5Error):
+        h.load_mace_weights(str(p), 3)
+
+
+def test_trainer_output_model_roundtrip_into_the_engine(da, tmp_path):
+    """MACETrainer.OutputModel -> .h5 + _scale.txt -> BatchScenario.LoadModel (weights by layer name + normalisers) -> same rollout
+    as pushing the trainer's weights directly; trainer.LoadModel restores them too."""
+    from deepterrainrl_amd import caffe_hdf5 as h
+    from deepterrainrl_amd import trainer as tr
+    nets = os.path.join(REFDATA, "data/policies/dog/nets")
+    t = tr.MACETrainer(os.path.join(nets, "dog_mace3_train.prototxt"), os.path.join(nets, "dog_mace3_solver.prototxt"), 283, 30, mem_size=64, device="cpu", dtype=torch.float64, seed=5)   # fp64: the 6-decimal normalisers survive the text file exactly
+    rng = np.random.RandomState(1)
+    t.SetInputOffsetScale(np.round(rng.normal(0, 0.1, 283), 6), np.round(rng.uniform(0.5, 2, 283), 6))
+    t.SetOutputOffsetScale(np.round(rng.normal(0, 0.1, 90), 6), np.round(rng.uniform(0.5, 2, 90), 6))
+    model = str(tmp_path / "dog_mace3_model.h5")
+    t.OutputModel(model)
+    m = h.read_caffe_model(model)
+    assert m["terr_conv1"][0].shape == (32, 16, 1, 4) and m["terr_ip0"][0].shape == (64, 5984) and m["a2_ip1"][1].shape == (29,)
+    assert np.array_equal(h.load_mace_weights(model, 3), t.GetWeights())
+    a = da.BatchScenario("args/dog_slopes_mixed_args.txt", 2, data_root=REFDATA, extra_args={"terrain_seed": 8}, _lib_path=EMUL_LIB)
+    b = da.BatchScenario("args/dog_slopes_mixed_args.txt", 2, data_root=REFDATA, extra_args={"terrain_seed": 8}, _lib_path=EMUL_LIB)
+    a.SetPolicy(t.GetWeights(), *t.GetOffsetScale())
+    assert np.array_equal(b.LoadModel(model), t.GetWeights())
+    a.RunFrames(30); b.RunFrames(30)
+    assert np.array_equal(a.PoseVel()[0], b.PoseVel()[0]) and a.EvalStats() == b.EvalStats() and a.EvalStats()["cycles"] > 2
+    t2 = tr.MACETrainer(os.path.join(nets, "dog_mace3_train.prototxt"), os.path.join(nets, "dog_mace3_solver.prototxt"), 283, 30, mem_size=64, device="cpu", seed=6)
+    assert not np.array_equal(t2.GetWeights(), t.GetWeights())
+    t2.LoadModel(model)
+    assert np.array_equal(t2.GetWeights(), t.GetWeights()) and np.array_equal(t2.target.get_flat(), t.GetWeights())
+    # where libhdf5 is around, let it judge the writer
+    if os.path.exists(H5PY_PYTHON) and subprocess.run([H5PY_PYTHON, "-c", "import h5py"], capture_output=True).returncode == 0:
+        code = ("import h5py, numpy as np, sys\nf = h5py.File(sys.argv[1], 'r')\nassert len(f['data']) == 13\n"
+                "w = np.concatenate([f['data'][l][k][...].reshape(-1) for l in %r for k in ('0', '1')])\nnp.save(sys.argv[2], w)\n" % (h.mace_layer_names(3),))
+        r = subprocess.run([H5PY_PYTHON, "-c", code, model, str(tmp_path / "via_libhdf5.npy")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert np.array_equal(np.load(tmp_path / "via_libhdf5.npy"), t.GetWeights())
