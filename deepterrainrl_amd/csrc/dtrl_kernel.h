@@ -1484,9 +1484,11 @@ DTRL_HD inline void frame_end(W& ws, const DevModel& gm, const DevBuffers& buf, 
 		if (gm.scenario == kScnExp) { if (!is_new_cycle(ws) && has_fallen(ws)) mode = 1; }
 		else if (gm.scenario == kScnPoliEval) {
 			if (has_fallen(ws)) {
-				real dist = ws.st.q[0] - ws.st.pos_start_x;
-				ws.st.avg_dist = (ws.st.num_episodes * ws.st.avg_dist + dist) / (ws.st.num_episodes + 1.0);
-				ws.st.num_episodes += 1;
+				if (ws.st.num_cycles >= 1) {   // IsValidCycle(): mCycleCount >= gNumWarmupCycles (= 1), scenarios/ScenarioPoliEval.cpp:7, 406-410
+					real dist = ws.st.q[0] - ws.st.pos_start_x;
+					ws.st.avg_dist = (ws.st.num_episodes * ws.st.avg_dist + dist) / (ws.st.num_episodes + 1.0);
+					ws.st.num_episodes += 1;
+				}
 				mode = 2;
 			}
 		}

@@ -770,9 +770,11 @@ struct Env {
 			if (!IsNewCycle() && HasFallen()) { ScenarioNewCycleUpdate(); Reset(); }
 		} else if (M.scenario == 2) {
 			if (HasFallen()) {
-				double dist = q[0] - pos_start_x;
-				avg_dist = (num_episodes * avg_dist + dist) / (num_episodes + 1.0);
-				++num_episodes; dist_log.push_back(dist);
+				if (num_cycles >= 1) {   // IsValidCycle(): mCycleCount >= gNumWarmupCycles (= 1), scenarios/ScenarioPoliEval.cpp:7, 406-410
+					double dist = q[0] - pos_start_x;
+					avg_dist = (num_episodes * avg_dist + dist) / (num_episodes + 1.0);
+					++num_episodes; dist_log.push_back(dist);
+				}
 				Reset();
 			}
 		}
