@@ -93,6 +93,7 @@ public:
 	bool Sync() override { bool ok = true; for (hipStream_t st : streams_) ok = Check(hipStreamSynchronize(st), "hipStreamSynchronize") && ok; return ok; }
 	int NumStreams() const override { return kNumStreams; }
 	void SelectStream(int sid) override { stream_ = streams_[(sid >= 0 && sid < kNumStreams) ? sid : 0]; }
+	bool StreamIdle(int sid) override { return hipStreamQuery(streams_[(sid >= 0 && sid < kNumStreams) ? sid : 0]) == hipSuccess; }
 	void KernelTime(double* avg_ms, int64_t* launches) override
 	{
 		for (hipStream_t st : streams_) hipStreamSynchronize(st);

@@ -269,14 +269,17 @@ int Engine::RunFrames(int frames, double dt)
 	const int steps = cfg_.model.num_update_steps;
 	std::vector<int> done(G, 0);
 	for (int g = 0; g < G; ++g) { int rc = LaunchGroup(g, steps, dt / steps, true); if (rc != DTRL_OK) return rc; }
+	int next = 0;   // oldest outstanding launch (launch order is round-robin)
 	for (int remaining = G * frames; remaining > 0;) {
-		for (int g = 0; g < G; ++g) {
-			if (done[g] >= frames) continue;
-			int rc = HostFrameWork(g);
-			if (rc != DTRL_OK) return rc;
-			--remaining;
-			if (++done[g] < frames) { rc = LaunchGroup(g, steps, dt / steps, true); if (rc != DTRL_OK) return rc; }
-		}
+		// serve whichever group has finished its frame; if none has, block on the oldest launch
+		int g = -1;
+		for (int k = 0; k < G; ++k) { const int c = (next + k) % G; if (done[c] < frames && be_->StreamIdle(c)) { g = c; break; } }
+		if (g < 0) { for (int k = 0; k < G; ++k) { const int c = (next + k) % G; if (done[c] < frames) { g = c; break; } } }
+		int rc = HostFrameWork(g);
+		if (rc != DTRL_OK) return rc;
+		--remaining;
+		if (++done[g] < frames) { rc = LaunchGroup(g, steps, dt / steps, true); if (rc != DTRL_OK) return rc; }
+		if (g == next) next = (next + 1) % G;
 	}
 	return DTRL_OK;
 }

@@ -26,6 +26,7 @@ public:
 	// work queues: H2D / H2DAsync / D2H / Launch act on the selected stream (0 by default); D2H and H2D synchronise only that stream
 	virtual int NumStreams() const = 0;
 	virtual void SelectStream(int sid) = 0;
+	virtual bool StreamIdle(int sid) = 0;    // everything queued on the stream has completed
 	virtual void KernelTime(double* avg_ms, int64_t* launches) = 0;
 	virtual const char* Name() const = 0;
 	const std::string& error() const { return err_; }

@@ -37,6 +37,7 @@ public:
 	bool Sync() override { return true; }
 	int NumStreams() const override { return 8; }
 	void SelectStream(int) override {}
+	bool StreamIdle(int) override { return true; }
 	void KernelTime(double* avg_ms, int64_t* launches) override { if (avg_ms) *avg_ms = 0; if (launches) *launches = launches_; launches_ = 0; }
 	const char* Name() const override { return "emul"; }
 private:
