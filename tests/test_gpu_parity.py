@@ -150,23 +150,32 @@ def test_full_size_4096_properties(da, om):
     assert n >= frames and ms > 0
 
 
-def test_fast_kernel_equals_reference_kernel_bitwise(da, om, monkeypatch):
-    """The register-resident gfx950 kernel (default) and the LDS-phase reference kernel (DTRL_KERNEL=ref) perform the same
-    arithmetic in the same order: 256 envs x 30 frames (falls, resets, policy forwards included) must agree bit for bit."""
-    pol = dog_policy(om)
+@pytest.mark.parametrize("arg,n,frames", [("args/dog_slopes_mixed_args.txt", 256, 30), ("args/raptor_narrow_gaps_args.txt", 192, 40),
+                                          ("args/opt_args_train_mace.txt", 128, 40), ("args/goat_cliffs_args.txt", 128, 40)])
+def test_fast_kernel_equals_reference_kernel_bitwise(da, om, monkeypatch, arg, n, frames):
+    """The register-resident gfx950 kernels (fast<23> dog/goat, fast<21> raptor) and the LDS-phase reference kernel (DTRL_KERNEL=ref)
+    perform the same arithmetic in the same order: falls, resets, policy forwards, exploration and tuples included, everything must
+    agree bit for bit."""
+    raptor = "raptor" in arg
+    pol = T.raptor_policy(om) if raptor else dog_policy(om)
     def run(kernel):
         if kernel:
             monkeypatch.setenv("DTRL_KERNEL", kernel)
         else:
             monkeypatch.delenv("DTRL_KERNEL", raising=False)
-        b = T.batch(da, "args/dog_slopes_mixed_args.txt", 256, terrain_seed=77)
+        b = T.batch(da, arg, n, terrain_seed=77)
         b.SetPolicy(pol[1], *pol[2:])
-        b.RunFrames(30)
-        return b.PoseVel(), b.Torques(), b.EvalStats(), b.Ctrl()
-    (qf, qdf), (tcf, taf), sf, cf = run(None)
-    (qr, qdr), (tcr, tar), sr, cr = run("ref")
+        b.RunFrames(frames)
+        rows, flags, ids = b.DrainTuples()
+        o = np.lexsort((np.arange(len(ids)), ids))
+        return b.PoseVel(), b.Torques(), b.EvalStats(), b.Ctrl(), rows[o], flags[o]
+    (qf, qdf), (tcf, taf), sf, cf, rf, ff = run(None)
+    (qr, qdr), (tcr, tar), sr, cr, rr, fr = run("ref")
     assert np.array_equal(qf, qr) and np.array_equal(qdf, qdr) and np.array_equal(tcf, tcr) and np.array_equal(taf, tar)
-    assert sf == sr and all(np.array_equal(a, b) for a, b in zip(cf, cr))
+    assert sf == sr and all(np.array_equal(a, b) for a, b in zip(cf, cr)) and sf["cycles"] > n
+    assert np.array_equal(rf, rr) and np.array_equal(ff, fr)
+    if "train" in arg:
+        assert len(rf) > n // 2
 
 
 def test_env_groups_pipelined_run_frames(da, om, monkeypatch):
