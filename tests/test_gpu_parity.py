@@ -199,3 +199,16 @@ def test_bench_contract_line():
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel_launches"] == 3 and rf["kernel_avg_ms"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_fsm_controllers_locomote_at_scale(da, om):
+    """Behavioural sanity at batch scale (no network, shipped FSM parameters): the bounding dog and the running raptor make steady
+    forward progress on flat ground in every env -- the same check tests/test_oracle_kat.py applies to the oracle's single env."""
+    for arg, min_speed in (("args/sim_dog_args.txt", 3.0), ("args/sim_raptor_args.txt", 2.5)):
+        b = T.batch(da, arg, 512, terrain_seed=1)
+        b.RunFrames(300)                                   # 10 s of simulated time
+        q, qd = b.PoseVel()
+        assert np.all(np.isfinite(q)) and np.all(np.isfinite(qd))
+        speed = q[:, 0] / 10.0
+        assert speed.min() > min_speed, (arg, speed.min(), speed.mean())
+        assert np.abs(speed - speed.mean()).max() < 1e-9   # flat ground, identical envs: identical trajectories in all 512 lanes of work
