@@ -33,7 +33,7 @@ TUPLE_FAIL, TUPLE_EXP_CRITIC, TUPLE_EXP_ACTOR = 1, 2, 4
 ABI_SYMBOLS = [
     "dtrl_create", "dtrl_destroy", "dtrl_reset", "dtrl_step", "dtrl_step_begin", "dtrl_step_end", "dtrl_step_updates", "dtrl_run_frames", "dtrl_set_policy",
     "dtrl_policy_num_params", "dtrl_build_output_offset_scale", "dtrl_load_scale_file", "dtrl_write_scale_file", "dtrl_set_explore", "dtrl_set_terrain_lerp", "dtrl_drain_tuples",
-    "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
+    "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
 ]
 
@@ -66,6 +66,7 @@ def _bind(path):
     for name in ("dtrl_get_pose_vel", "dtrl_get_torques"):
         getattr(L, name).argtypes = [vp, vp, C.c_int, vp, vp]
     L.dtrl_set_pose_vel.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.dtrl_get_link_states.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.dtrl_get_poli_state.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_flags.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_contacts.argtypes = [vp, vp, C.c_int, vp]
@@ -212,6 +213,13 @@ class BatchScenario:
 
     def BuildVel(self, env_ids=None):
         return self.PoseVel(env_ids)[1]
+
+    def LinkStates(self, env_ids=None):
+        """World COM position [n, L, 2], COM velocity [n, L, 2] and body angle [n, L] of every link (GetBodyPart(i)->GetPos() ...)."""
+        ids, n = self._ids(env_ids)
+        c = np.zeros((n, self.L, 2)); v = np.zeros((n, self.L, 2)); a = np.zeros((n, self.L))
+        self._chk(self._lib.dtrl_get_link_states(self._h, _p(ids), n, _p(c), _p(v), _p(a)))
+        return c, v, a
 
     def SetPoseVel(self, q, qd, env_ids=None):
         ids, n = self._ids(env_ids)

@@ -1,6 +1,7 @@
 // dtrl_c_api.cpp -- extern "C" surface declared in include/dtrl.h; thin wrappers over dtrl::Engine.
 #include "../../include/dtrl.h"
 #include "dtrl_engine.h"
+#include <cmath>
 #include <new>
 
 using dtrl::Engine;
@@ -102,6 +103,36 @@ dtrl_status dtrl_get_torques(dtrl_batch* b, const int32_t* env_ids, int n, doubl
 	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
 	const int D = b->eng.cfg().model.D;
 	for (int i = 0; i < n; ++i) for (int k = 0; k < D; ++k) { if (tau_ctrl) tau_ctrl[i * D + k] = st[i].tau_ctrl[k]; if (tau_applied) tau_applied[i * D + k] = st[i].tau[k]; }
+	return DTRL_OK;
+}
+dtrl_status dtrl_get_link_states(dtrl_batch* b, const int32_t* env_ids, int n, double* com_xy, double* com_vel_xy, double* angle)
+{
+	CHECK_B();
+	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
+	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
+	const dtrl::DevModel& m = b->eng.cfg().model;
+	const int L = m.L;
+	for (int e = 0; e < n; ++e) {
+		const EnvState& s = st[e];
+		double phi[dtrl::kMaxL], w[dtrl::kMaxL], px[dtrl::kMaxL], py[dtrl::kMaxL], vx[dtrl::kMaxL], vy[dtrl::kMaxL];
+		for (int j = 0; j < L; ++j) {   // parents precede children (cKinTree joint order)
+			const int pa = m.parent[j];
+			if (pa < 0) { phi[j] = s.q[2]; w[j] = s.qd[2]; px[j] = s.q[0]; py[j] = s.q[1]; vx[j] = s.qd[0]; vy[j] = s.qd[1]; }
+			else {
+				const double c = std::cos(phi[pa]), sn = std::sin(phi[pa]);
+				const double rx = c * m.attach[j][0] - sn * m.attach[j][1], ry = sn * m.attach[j][0] + c * m.attach[j][1];
+				phi[j] = phi[pa] + s.q[j + 2]; w[j] = w[pa] + s.qd[j + 2];
+				px[j] = px[pa] + rx; py[j] = py[pa] + ry;
+				vx[j] = vx[pa] - w[pa] * ry; vy[j] = vy[pa] + w[pa] * rx;
+			}
+			const double c = std::cos(phi[j]), sn = std::sin(phi[j]);
+			const double bx = c * m.body_attach[j][0] - sn * m.body_attach[j][1], by = sn * m.body_attach[j][0] + c * m.body_attach[j][1];
+			const size_t o = static_cast<size_t>(e) * L + j;
+			if (com_xy) { com_xy[2 * o] = px[j] + bx; com_xy[2 * o + 1] = py[j] + by; }
+			if (com_vel_xy) { com_vel_xy[2 * o] = vx[j] - w[j] * by; com_vel_xy[2 * o + 1] = vy[j] + w[j] * bx; }
+			if (angle) angle[o] = phi[j] + m.body_theta[j];
+		}
+	}
 	return DTRL_OK;
 }
 dtrl_status dtrl_get_contacts(dtrl_batch* b, const int32_t* env_ids, int n, int32_t* flags)

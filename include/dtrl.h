@@ -118,6 +118,12 @@ dtrl_status dtrl_set_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, cons
 dtrl_status dtrl_get_poli_state(dtrl_batch* b, const int32_t* env_ids, int n, double* s);
 /* fallen | stumbled<<1 | new_cycle<<2 | fsm_state<<8: cSimCharacter::HasFallen/HasStumbled, cCharController::IsNewCycle/GetState. */
 dtrl_status dtrl_get_flags(dtrl_batch* b, const int32_t* env_ids, int n, uint32_t* bits);
+/* Replaces: cSimCharacter::GetBodyPart(i)->GetPos() / GetLinearVelocity() / GetRotation() (sim/SimCharacter.cpp:317-352, sim/SimObj.cpp:
+ * 60-130), what the reference's features, recorders and draw code read per link: world position and velocity of every link's body
+ * COM ([n][L][2] each) and the body's world angle ([n][L]); derived from (q, qd) with the same planar kinematics the kernel uses.
+ * Any output may be NULL. */
+dtrl_status dtrl_get_link_states(dtrl_batch* b, const int32_t* env_ids, int n, double* com_xy, double* com_vel_xy, double* angle);
+
 /* observability for parity tests: controller torque before / after the cJoint clamp (sim/Joint.cpp:171-201), per-link contact flags */
 dtrl_status dtrl_get_torques(dtrl_batch* b, const int32_t* env_ids, int n, double* tau_ctrl, double* tau_applied);
 dtrl_status dtrl_get_contacts(dtrl_batch* b, const int32_t* env_ids, int n, int32_t* flags);

@@ -208,6 +208,9 @@ def test_kernel_math_vs_oracle_flat_1200_substeps(da, om):
         st, ph, aid, prm, tg = b.Ctrl(); so, pho, aido, prmo, tgo = e.ctrl()
         assert st[0] == so and aid[0] == aido and abs(ph[0] - pho) < 1e-12 and np.abs(tg[0] - tgo).max() < 1e-9
         assert b.Flags()[0] == e.flags()
+        if k % 40 == 7:
+            c, v, a = b.LinkStates(); co, vo, ao = e.bodies()
+            assert np.abs(c[0] - co).max() < 1e-10 and np.abs(v[0] - vo).max() < 1e-8 and np.abs(a[0] - ao).max() < 1e-10
         if (k + 1) % 20 == 0:
             assert np.abs(q[0] - g["q"][k // 20]).max() < 1e-9   # committed golden trace
 
