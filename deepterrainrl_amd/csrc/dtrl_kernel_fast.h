@@ -12,6 +12,7 @@
 // (the transpose copy, so back substitution also only needs the lane's own registers).
 #pragma once
 #include "dtrl_kernel.h"
+#include <type_traits>
 
 #if defined(__HIP_DEVICE_COMPILE__)
 
@@ -78,6 +79,66 @@ __device__ __forceinline__ void mass_row(WSFast& ws, real (&h)[D])
 	__syncthreads();   // T is dead; the storage may be reused
 }
 
+// ---- lane-predicated updates through EXEC ----
+// The elimination steps below update "the lanes below the pivot". Written as `if (lane > k) x = fma(...)` the compiler emits the FMA
+// for every lane plus two v_cndmask per double (and keeps 23 lane masks alive in SGPRs that spill to VGPR lanes and come back by
+// v_readlane): 5+ VALU instructions per step for one useful FMA. The frame kernel is VALU-issue-bound, while the SALU
+// port is nearly idle, so these helpers narrow EXEC with three SALU instructions around the FMA instead. The lane mask is built from an
+// inline constant (no SGPR pressure). EXEC is restored inside the same asm block, so the compiler never sees a changed EXEC.
+// Same operation, same operands, same rounding as the predicated C++ form: the bits do not change (fast-vs-ref parity tests).
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+	if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_down(F&& f)   // E-1, E-2, ..., B
+{
+	if constexpr (B < E) { f(std::integral_constant<int, E - 1>{}); static_for_down<B, E - 1>(f); }
+}
+// acc = fma(-a, b, acc) on lanes >= J; b is wave-uniform (SGPR pair)
+template <int J>
+__device__ __forceinline__ void fnma_lanes_ge(real& acc, real a, real b)
+{
+	unsigned long long sv, m;
+	asm("s_lshl_b64 %2, -1, %5\n\ts_and_saveexec_b64 %1, %2\n\tv_fma_f64 %0, -%3, %4, %0\n\ts_mov_b64 exec, %1"
+	    : "+v"(acc), "=&s"(sv), "=&s"(m) : "v"(a), "s"(b), "n"(J) : "scc");
+}
+template <int J>
+__device__ __forceinline__ void fnma_lanes_ge(real (&acc)[1], real a, const real (&b)[1]) { fnma_lanes_ge<J>(acc[0], a, b[0]); }
+template <int J>
+__device__ __forceinline__ void fnma_lanes_ge(real (&acc)[2], real a, const real (&b)[2])
+{
+	unsigned long long sv, m;
+	asm("s_lshl_b64 %3, -1, %7\n\ts_and_saveexec_b64 %2, %3\n\tv_fma_f64 %0, -%4, %5, %0\n\tv_fma_f64 %1, -%4, %6, %1\n\ts_mov_b64 exec, %2"
+	    : "+v"(acc[0]), "+v"(acc[1]), "=&s"(sv), "=&s"(m) : "v"(a), "s"(b[0]), "s"(b[1]), "n"(J) : "scc");
+}
+template <int J>
+__device__ __forceinline__ void fnma_lanes_ge(real (&acc)[4], real a, const real (&b)[4])
+{
+	unsigned long long sv, m;
+	asm("s_lshl_b64 %5, -1, %11\n\ts_and_saveexec_b64 %4, %5\n\tv_fma_f64 %0, -%6, %7, %0\n\tv_fma_f64 %1, -%6, %8, %1\n\t"
+	    "v_fma_f64 %2, -%6, %9, %2\n\tv_fma_f64 %3, -%6, %10, %3\n\ts_mov_b64 exec, %4"
+	    : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "=&s"(sv), "=&s"(m)
+	    : "v"(a), "s"(b[0]), "s"(b[1]), "s"(b[2]), "s"(b[3]), "n"(J) : "scc");
+}
+// acc = fma(-a, b, acc) on lanes < I
+template <int I>
+__device__ __forceinline__ void fnma_lanes_lt(real& acc, real a, real b)
+{
+	unsigned long long sv, m;
+	asm("s_bfm_b64 %2, %5, 0\n\ts_and_saveexec_b64 %1, %2\n\tv_fma_f64 %0, -%3, %4, %0\n\ts_mov_b64 exec, %1"
+	    : "+v"(acc), "=&s"(sv), "=&s"(m) : "v"(a), "s"(b), "n"(I) : "scc");
+}
+// dst = src on lanes >= J
+template <int J>
+__device__ __forceinline__ void mov_lanes_ge(real& dst, real src)
+{
+	unsigned long long sv, m;
+	asm("s_lshl_b64 %2, -1, %4\n\ts_and_saveexec_b64 %1, %2\n\tv_mov_b64 %0, %3\n\ts_mov_b64 exec, %1"
+	    : "+v"(dst), "=&s"(sv), "=&s"(m) : "v"(src), "n"(J) : "scc");
+}
+
 // in-register LDL^T; returns 1/d_lane. Same elimination order and operations as factorize(). The transposed copy of L
 // (needed by bsub_regs) is produced with one pass through LDS (packed lower triangle in the Apk storage, which is dead
 // between mass_row() and the Delassus build) instead of per-entry lane selects.
@@ -85,16 +146,16 @@ template <int D>
 __device__ __forceinline__ real factorize_regs(WSFast& ws, real (&h)[D])
 {
 	const int lane = static_cast<int>(threadIdx.x);
+	// Only the lower triangle (lane >= column) is ever read back, so the per-entry predicate `lane >= j` of the textbook form is dropped:
+	// lanes above the diagonal update entries nobody reads (they are overwritten by the transposed copy below), the lanes that matter
+	// execute exactly the same operations. One predicated move per pivot keeps the diagonal.
 #pragma unroll
 	for (int k = 0; k < D - 1; ++k) {
 		const real dk = bcast(h[k], k);
 		const real ak = h[k];
 		const real lik = ak / dk;
 #pragma unroll
-		for (int j = k + 1; j < D; ++j) {
-			const real ajk = bcast(ak, j);
-			if (lane >= j) h[j] = fmadd(-lik, ajk, h[j]);
-		}
+		for (int j = k + 1; j < D; ++j) h[j] = fmadd(-lik, bcast(ak, j), h[j]);
 		if (lane > k) h[k] = lik;
 	}
 	real dinv = 0;
@@ -114,41 +175,35 @@ __device__ __forceinline__ real factorize_regs(WSFast& ws, real (&h)[D])
 template <int D>
 __device__ __forceinline__ real fsub_regs(const real (&h)[D], real z)
 {
-	const int lane = static_cast<int>(threadIdx.x);
-#pragma unroll
-	for (int k = 0; k < D - 1; ++k) {
+	static_for<0, D - 1>([&](auto kc) {
+		constexpr int k = decltype(kc)::value;
 		const real zk = bcast(z, k);
-		if (lane > k) z = fmadd(-h[k], zk, z);
-	}
+		fnma_lanes_ge<k + 1>(z, h[k], zk);              // if (lane > k) z = fma(-h[k], zk, z)
+	});
 	return z;
 }
 // NR right-hand sides at once: the substitution is a 22-step dependent chain per right-hand side, so interleaving independent
-// chains divides the exposed latency at the same instruction count
+// chains divides the exposed latency at the same instruction count (and the NR updates of a step share one EXEC window)
 template <int D, int NR>
 __device__ __forceinline__ void fsub_regs_n(const real (&h)[D], real (&z)[NR])
 {
-	const int lane = static_cast<int>(threadIdx.x);
-#pragma unroll
-	for (int k = 0; k < D - 1; ++k) {
+	static_for<0, D - 1>([&](auto kc) {
+		constexpr int k = decltype(kc)::value;
 		real zk[NR];
 #pragma unroll
 		for (int j = 0; j < NR; ++j) zk[j] = bcast(z[j], k);
-		if (lane > k) {
-#pragma unroll
-			for (int j = 0; j < NR; ++j) z[j] = fmadd(-h[k], zk[j], z[j]);
-		}
-	}
+		fnma_lanes_ge<k + 1>(z, h[k], zk);
+	});
 }
 // x = L^-T u
 template <int D>
 __device__ __forceinline__ real bsub_regs(const real (&h)[D], real u)
 {
-	const int lane = static_cast<int>(threadIdx.x);
-#pragma unroll
-	for (int i = D - 1; i >= 1; --i) {
+	static_for_down<1, D>([&](auto ic) {
+		constexpr int i = decltype(ic)::value;
 		const real ui = bcast(u, i);
-		if (lane < i) u = fmadd(-h[i], ui, u);
-	}
+		fnma_lanes_lt<i>(u, h[i], ui);                  // if (lane < i) u = fma(-h[i], ui, u)
+	});
 	return u;
 }
 
