@@ -262,7 +262,8 @@ DTRL_HD inline void kin_dyn_terms(W& ws)
 		for (int k = 0; k < kMaxDepth; ++k) {
 			const int a = ws.M.path[j][k <= dep ? k : 0];
 			const real qa = ws.st.q[a + 2], wa = ws.st.qd[a + 2];
-			if (k <= dep) { phi += qa; w += wa; }
+			const real on = (k <= dep) ? 1.0 : 0.0;   // predicated accumulation as fma(x, 1|0, acc): same sum (x*1 is exact), but branch-free, so the LDS loads of the whole loop pipeline
+			phi = fmadd(qa, on, phi); w = fmadd(wa, on, w);
 		}
 		ws.phi[j] = phi; ws.w[j] = w;
 		real s, c; sincos(phi, &s, &c);
@@ -297,7 +298,8 @@ DTRL_HD inline void kin_dyn_terms(W& ws)
 		for (int k = 1; k < kMaxDepth; ++k) {
 			const int a = ws.M.path[j][k <= dep ? k : 0];
 			const real rx = ws.bx[a], ry = ws.by[a], dux = ws.ux[a], duy = ws.uy[a], dgx = ws.gx[a], dgy = ws.gy[a];
-			if (k <= dep) { px += rx; py += ry; vx += dux; vy += duy; ax += dgx; ay += dgy; }
+			const real on = (k <= dep) ? 1.0 : 0.0;
+			px = fmadd(rx, on, px); py = fmadd(ry, on, py); vx = fmadd(dux, on, vx); vy = fmadd(duy, on, vy); ax = fmadd(dgx, on, ax); ay = fmadd(dgy, on, ay);
 		}
 		ws.px[j] = px; ws.py[j] = py; ws.vpx[j] = vx; ws.vpy[j] = vy;
 		const real c = ws.cs[j], s = ws.sn[j], wj = ws.w[j];
@@ -325,7 +327,8 @@ DTRL_HD inline void kin_dyn_terms(W& ws)
 			for (int kk = 0; kk < 7; ++kk) {
 				const int k = (k0 + kk < kMaxL) ? k0 + kk : 0;
 				const real a1 = ws.mcx[k], a2 = ws.mcy[k], a3 = ws.Io[k], a4 = ws.fx[k], a5 = ws.fy[k], a6 = ws.fn[k];
-				if (k0 + kk < nL && ((mask >> k) & 1u)) { mx += a1; my += a2; I += a3; sfx += a4; sfy += a5; sfn += a6; }
+				const real on = (k0 + kk < nL && ((mask >> k) & 1u)) ? 1.0 : 0.0;
+				mx = fmadd(a1, on, mx); my = fmadd(a2, on, my); I = fmadd(a3, on, I); sfx = fmadd(a4, on, sfx); sfy = fmadd(a5, on, sfy); sfn = fmadd(a6, on, sfn);
 			}
 		}
 		ws.sm[j] = m; ws.smx[j] = mx; ws.smy[j] = my; ws.sI[j] = I;
