@@ -325,7 +325,7 @@ DTRL_HD inline void kin_dyn_terms(W& ws)
 		for (int k0 = 0; k0 < nL; k0 += 7) {   // chunks of 7 (3 chunks cover the 19- and 21-link characters) so the loads of a chunk pipeline
 #pragma unroll
 			for (int kk = 0; kk < 7; ++kk) {
-				const int k = (k0 + kk < kMaxL) ? k0 + kk : 0;
+				const int k = (k0 + kk < nL) ? k0 + kk : 0;   // clamped to a live link: the 0|1 multiplier below needs finite operands (LDS beyond link L-1 is never written)
 				const real a1 = ws.mcx[k], a2 = ws.mcy[k], a3 = ws.Io[k], a4 = ws.fx[k], a5 = ws.fy[k], a6 = ws.fn[k];
 				const real on = (k0 + kk < nL && ((mask >> k) & 1u)) ? 1.0 : 0.0;
 				mx = fmadd(a1, on, mx); my = fmadd(a2, on, my); I = fmadd(a3, on, I); sfx = fmadd(a4, on, sfx); sfy = fmadd(a5, on, sfy); sfn = fmadd(a6, on, sfn);

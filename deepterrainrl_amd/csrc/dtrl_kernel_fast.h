@@ -27,23 +27,36 @@ __device__ __forceinline__ real bcast(real v, int src)   // src must be wave-uni
 }
 
 // row `lane` of the joint-space inertia matrix from the composite quantities in LDS (same formulas and operand order as
-// mass_matrix()). Each hinge lane evaluates the closed form once per ancestor and parks the values in LDS (in the storage of
-// the Delassus matrix, which is dead at that point); every lane then assembles its row with one LDS read per column: the entry (d, c) lives in
-// the table row of the DEEPER link at the path position of the shallower one.
+// mass_matrix()). Only the lower triangle (column <= lane) is produced: the factorisation never reads the rest (factorize_regs()).
+// The (link, ancestor) pairs are dealt round-robin to all 64 lanes, each evaluates the closed form once and parks the value in a
+// packed table in LDS (the storage of the Delassus matrix, dead at that point) laid out as the rows themselves:
+//   row of link l (DoF l + 2) at base_l = l (l + 5) / 2: [hx, hy, H(l, link 0), ..., H(l, link l)], non-ancestor slots = 0
+// so a lane assembles its row with D loads at compile-time offsets from one base (no per-column index arithmetic, no branches: the
+// loads pipeline). Lanes without a hinge row (translations, lanes >= D) read a block of zeros behind the table.
 template <int D>
 __device__ __forceinline__ void mass_row(WSFast& ws, real (&h)[D])
 {
+	constexpr int Lk = D - 2;                                  // links of the character this kernel is instantiated for
+	constexpr int kTab = Lk * (Lk + 5) / 2;                    // packed rows
+	constexpr int kFill = (kTab + D + 1) & ~1;                 // + one block of D zeros, even count (16-byte stores)
+	static_assert(kFill <= static_cast<int>(sizeof(ws.Apk) / sizeof(real)), "mass table does not fit the packed-matrix storage");
 	const int d = static_cast<int>(threadIdx.x);
 	const int l = d >= 2 ? d - 2 : 0;
-	const bool valid = d < D;
-	real (*T)[kMaxDepth + 2] = reinterpret_cast<real (*)[kMaxDepth + 2]>(&ws.Apk[0]);   // T[link][0..depth] + hx, hy at [kMaxDepth], [kMaxDepth+1]; the Delassus storage is dead here
-	if (valid && d >= 2) {
-		const real m = ws.sm[l], mx = ws.smx[l], my = ws.smy[l];
-		T[l][kMaxDepth] = -(my - m * ws.py[l]);
-		T[l][kMaxDepth + 1] = (mx - m * ws.px[l]);
+	const bool hinge = d >= 2 && d < D;
+	real* T = ws.Apk;
+	{
+		double2* T2 = reinterpret_cast<double2*>(T);
+		const double2 z2 = {0.0, 0.0};
+#pragma unroll
+		for (int e = 0; e < (kFill / 2 + kGroup - 1) / kGroup; ++e) if (d + e * kGroup < kFill / 2) T2[d + e * kGroup] = z2;
 	}
-	// hinge-hinge entries: the (link, ancestor) pairs are dealt round-robin to all 64 lanes (a deep link has up to 12 ancestors;
-	// one lane per link would leave most of the wave idle behind the deepest chains)
+	__syncthreads();
+	const int base = hinge ? l * (l + 5) / 2 : kTab;
+	if (hinge) {
+		const real m = ws.sm[l], mx = ws.smx[l], my = ws.smy[l];
+		T[base] = -(my - m * ws.py[l]);
+		T[base + 1] = (mx - m * ws.px[l]);
+	}
 	const int n_pairs = ws.M.n_pairs;
 #pragma unroll 2
 	for (int e = lane_id(); e < n_pairs; e += kGroup) {
@@ -52,30 +65,14 @@ __device__ __forceinline__ void mass_row(WSFast& ws, real (&h)[D])
 		const real m = ws.sm[pl], mx = ws.smx[pl], my = ws.smy[pl], I = ws.sI[pl];
 		const real plx = ws.px[pl], ply = ws.py[pl];
 		const real pax = ws.px[a], pay = ws.py[a];
-		T[pl][pk] = I - ((plx + pax) * mx + (ply + pay) * my) + m * (plx * pax + ply * pay);
+		T[pl * (pl + 5) / 2 + 2 + a] = I - ((plx + pax) * mx + (ply + pay) * my) + m * (plx * pax + ply * pay);
 	}
 	__syncthreads();
 	const real M0 = ws.sm[0];
-	const uint32_t my_sub = valid ? ws.M.sub_mask[l] : 0u, my_anc = valid ? ws.M.anc_mask[l] : 0u;
-	const int my_depth = ws.M.depth[l];
 #pragma unroll
-	for (int c = 0; c < D; ++c) {
-		real v = 0;
-		if (valid) {
-			if (d < 2) {
-				if (c == d) v = M0;
-				else if (c >= 2) v = T[c - 2][kMaxDepth + d];
-			} else if (c < 2) {
-				v = T[l][kMaxDepth + c];
-			} else {
-				const int lc = c - 2;
-				const int dc = __builtin_amdgcn_readlane(my_depth, c);          // depth of link lc (lane c = lc + 2 holds it)
-				if ((my_anc >> lc) & 1u) v = T[l][dc];                           // lc is an ancestor of (or is) my link
-				else if ((my_sub >> lc) & 1u) v = T[lc][my_depth];               // lc is a descendant
-			}
-		}
-		h[c] = v;
-	}
+	for (int c = 0; c < D; ++c) h[c] = T[base + c];
+	if (d == 0) h[0] = M0;
+	if (d == 1) h[1] = M0;
 	__syncthreads();   // T is dead; the storage may be reused
 }
 

@@ -5,6 +5,7 @@
 #include "../dtrl_engine.h"
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -26,9 +27,15 @@ public:
 		if (buf.tuple_count && nt > 1 && gm->scenario == kScnExp) nt = 1;   // the tuple cursor is a plain int on the host
 		std::vector<std::thread> th;
 		for (int t = 0; t < nt; ++t) th.emplace_back([=]() {
-			WSRef* ws = new WSRef();
-			for (int e = t; e < n_envs; e += nt) env_frame<RefPath>(*ws, *gm, rp, buf, buf.env_list ? buf.env_list[e] : e, n_steps, dt, frame_end);
-			delete ws;
+			// LDS is not cleared between workgroups on the device: poison the workspace before every env (all-ones bytes = NaN doubles,
+			// -1 ints) so that a read of a never-written slot shows up in the CPU tests instead of as a flaky GPU result
+			void* mem = ::operator new(sizeof(WSRef));
+			for (int e = t; e < n_envs; e += nt) {
+				std::memset(mem, 0xFF, sizeof(WSRef));
+				WSRef* ws = new (mem) WSRef;
+				env_frame<RefPath>(*ws, *gm, rp, buf, buf.env_list ? buf.env_list[e] : e, n_steps, dt, frame_end);
+			}
+			::operator delete(mem);
 		});
 		for (auto& x : th) x.join();
 		++launches_;
