@@ -22,15 +22,15 @@ __global__ void __launch_bounds__(kGroup) dtrl_frame_kernel(const DevModel* __re
 	env_frame<RefPath>(ws, *gm, rp, buf, env, n_steps, dt, frame_end != 0);
 }
 
-// register-resident fast path (dtrl_kernel_fast.h), one instantiation per DoF count of the shipped characters
-template <int D>
+// register-resident fast path (dtrl_kernel_fast.h), one instantiation per skeleton of the shipped characters (dtrl_topo.h)
+template <class Topo>
 __global__ void __launch_bounds__(kGroup, 2) dtrl_frame_kernel_fast(const DevModel* __restrict__ gm, RunParams rp, DevBuffers buf, int n_envs, int n_steps, real dt, int frame_end)
 {
 	__shared__ WSFast ws;
 	if (static_cast<int>(blockIdx.x) >= n_envs) return;
 	const int env = buf.env_list ? buf.env_list[blockIdx.x] : static_cast<int>(blockIdx.x);
 #if defined(__HIP_DEVICE_COMPILE__)
-	env_frame<FastPath<D>>(ws, *gm, rp, buf, env, n_steps, dt, frame_end != 0);
+	env_frame<FastPath<Topo>>(ws, *gm, rp, buf, env, n_steps, dt, frame_end != 0);
 #endif
 }
 
@@ -81,10 +81,10 @@ public:
 		// DTRL_KERNEL=ref selects the LDS-phase reference kernel (A/B and bitwise cross-check); default is the fast path
 		const char* sel = std::getenv("DTRL_KERNEL");
 		const bool use_ref = sel && std::strcmp(sel, "ref") == 0;
-		if (!use_ref && buf.model_D == 23)
-			hipLaunchKernelGGL(dtrl_frame_kernel_fast<23>, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
-		else if (!use_ref && buf.model_D == 21)
-			hipLaunchKernelGGL(dtrl_frame_kernel_fast<21>, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
+		if (!use_ref && buf.model_topo == TopoDog::kId)
+			hipLaunchKernelGGL(dtrl_frame_kernel_fast<TopoDog>, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
+		else if (!use_ref && buf.model_topo == TopoRaptor::kId)
+			hipLaunchKernelGGL(dtrl_frame_kernel_fast<TopoRaptor>, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
 		else
 			hipLaunchKernelGGL(dtrl_frame_kernel, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
 		if (timed) { hipEventRecord(ev.second, stream_); pending_.push_back(ev); }

@@ -10,6 +10,7 @@
 //      (cScenarioSimChar::UpdateGround, :564-572). Doing this at frame boundaries instead of every env-step is
 //      equivalent because the window is rebuilt 1 m before any sample can reach its end (DESIGN.md "Ground").
 #include "dtrl_engine.h"
+#include "dtrl_topo.h"
 #include <algorithm>
 #include <cstdlib>
 #include <cstdio>
@@ -76,7 +77,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	buf_.poli_state = static_cast<real*>(alloc(sizeof(real) * S_ * n_));
 	buf_.tup_s0 = static_cast<real*>(alloc(sizeof(real) * S_ * n_));
 	buf_.tup_a = static_cast<real*>(alloc(sizeof(real) * A_ * n_));
-	buf_.S = S_; buf_.A = A_; buf_.W = W_; buf_.model_D = m.D;
+	buf_.S = S_; buf_.A = A_; buf_.W = W_; buf_.model_D = m.D; buf_.model_topo = match_topology(m.parent, m.L);
 	// a tuple per env per cycle (~13 frames) at most; room for 2 per env between drains, at least the reference's ring size
 	buf_.tuple_cap = std::max(2 * n_, cfg_.tuple_buffer_size);
 	buf_.tuple_rows = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(W_) * buf_.tuple_cap));

@@ -97,7 +97,8 @@ struct DevBuffers {
 	int32_t tuple_cap;
 	int32_t S, A, W;
 	int32_t nn_scratch_stride;
-	int32_t model_D;           // host-known DoF count (selects the register-resident kernel instantiation)
+	int32_t model_D;           // host-known DoF count
+	int32_t model_topo;        // compiled-in skeleton id (dtrl_topo.h; selects the register-resident kernel instantiation), 0 = none
 	unsigned long long* prof;  // [N][kProfMax] cycle counters (DTRL_PROFILE builds), else null
 	const int32_t* env_list;   // optional indirection: workgroup b handles env_list[b] (launch order, compact reset launches)
 	int32_t reset_listed;      // 1: every env of this launch performs the device half of a reset (compact reset launches)
@@ -390,17 +391,21 @@ DTRL_HD inline void mass_matrix(W& ws)
 	LANES_END
 }
 
-// in-place LDL^T of ws.H (right-looking; lane i owns row i). Afterwards: diag = d_k, H[k][i] (i > k) = L_ik, dinv = 1/d.
+// in-place H = U D U^T of ws.H (U unit upper triangular; lane i owns row i), eliminating the LAST DoF first. Joints are numbered
+// parents-first, so this is the leaf-to-root order of Featherstone's LTDL: a pivot only couples to its ancestors and the
+// factorisation creates no fill-in -- U(i,k) != 0 only if DoF i is an ancestor of DoF k. This path runs the dense loops (the skipped
+// updates are exact no-ops: fma(-0, x, h) = h); the register fast path compiles the sparsity of the shipped skeletons in.
+// Afterwards: diag = d_k, H[k][i] (i < k) = U_ik (stored transposed, in the lower triangle), dinv = 1/d.
 template <class W>
 DTRL_HD inline void factorize(W& ws)
 {
 	const int D = ws.M.D;
-	for (int k = 0; k < D - 1; ++k) {
+	for (int k = D - 1; k >= 1; --k) {
 		LANES_BEGIN
-		if (lane > k && lane < D) {
+		if (lane < k) {
 			const int i = lane;
 			real lik = ws.H[i][k] / ws.H[k][k];
-			for (int j = k + 1; j <= i; ++j) ws.H[i][j] = fmadd(-lik, ws.H[j][k], ws.H[i][j]);
+			for (int j = k - 1; j >= i; --j) ws.H[i][j] = fmadd(-lik, ws.H[j][k], ws.H[i][j]);
 			ws.H[k][i] = lik;
 		}
 		LANES_END
@@ -497,7 +502,7 @@ DTRL_HD inline void build_rows(W& ws, real h)
 	LANES_END
 }
 
-// Z_r = L^-1 J_r^T for every row (lane r) and z_0 = L^-1 rhs (lane R), forward substitution per lane
+// Z_r = U^-1 J_r^T for every row (lane r) and z_0 = U^-1 rhs (lane R): substitution from the last DoF up, per lane
 template <class W>
 DTRL_HD inline void forward_subst_rows(W& ws, const real* rhs)
 {
@@ -506,9 +511,9 @@ DTRL_HD inline void forward_subst_rows(W& ws, const real* rhs)
 	if (lane <= R) {
 		const int r = lane;
 		real* z = ws.Z[r];
-		for (int i = 0; i < D; ++i) {
+		for (int i = D - 1; i >= 0; --i) {
 			real s = (r < R) ? row_jac(ws, r, i) : rhs[i];
-			for (int k = 0; k < i; ++k) s = fmadd(-ws.H[k][i], z[k], s);
+			for (int k = D - 1; k > i; --k) s = fmadd(-ws.H[k][i], z[k], s);
 			z[i] = s;
 		}
 	}
@@ -578,7 +583,7 @@ DTRL_HD inline void pgs_solve(W& ws)
 	}
 }
 
-// v+ = qd + L^-T D^-1 (h z_0 + sum_r Z_r lambda_r); q+ = q + h v+
+// v+ = qd + U^-T D^-1 (h z_0 + sum_r Z_r lambda_r); q+ = q + h v+
 template <class W>
 DTRL_HD inline void finish_substep(W& ws, real h)
 {
@@ -591,9 +596,9 @@ DTRL_HD inline void finish_substep(W& ws, real h)
 		ws.u[i] = s * ws.dinv[i];
 	}
 	LANES_END
-	for (int i = D - 1; i >= 1; --i) {
+	for (int k = 0; k < D - 1; ++k) {   // U^-T: x_i -= U_ki x_k for i > k (U_ki sits at H[i][k])
 		LANES_BEGIN
-		if (lane < i) ws.u[lane] = fmadd(-ws.H[lane][i], ws.u[i], ws.u[lane]);
+		if (lane > k && lane < D) ws.u[lane] = fmadd(-ws.H[lane][k], ws.u[k], ws.u[lane]);
 		LANES_END
 	}
 	LANES_BEGIN
@@ -1091,13 +1096,13 @@ DTRL_HD inline void pd_solve_ref(W& ws, real dt)
 	if (lane == 0) { ws.R = 0; }
 	LANES_END
 	factorize(ws);
-	forward_subst_rows(ws, ws.u);   // R = 0: only z_0 = L^-1 rhs (lane 0)
+	forward_subst_rows(ws, ws.u);   // R = 0: only z_0 = U^-1 rhs (lane 0)
 	LANES_BEGIN
 	if (lane < D) ws.u[lane] = ws.Z[0][lane] * ws.dinv[lane];
 	LANES_END
-	for (int i = D - 1; i >= 1; --i) {
+	for (int k = 0; k < D - 1; ++k) {   // U^-T: x_i -= U_ki x_k for i > k (U_ki sits at H[i][k])
 		LANES_BEGIN
-		if (lane < i) ws.u[lane] = fmadd(-ws.H[lane][i], ws.u[i], ws.u[lane]);
+		if (lane > k && lane < D) ws.u[lane] = fmadd(-ws.H[lane][k], ws.u[k], ws.u[lane]);
 		LANES_END
 	}
 }

@@ -8,10 +8,13 @@
 // The arithmetic (operation order included) is IDENTICAL to the reference path, so both produce the same bits; the
 // reference kernel stays in the library (DTRL_KERNEL=ref) and tests/test_gpu_parity.py compares the two.
 //
-// Row layout after factorize_regs(): h[k] for k < lane = L_{lane,k}; h[lane] = d_lane; h[k] for k > lane = L_{k,lane}
-// (the transpose copy, so back substitution also only needs the lane's own registers).
+// The factorisation is H = U D U^T, eliminating the last DoF first (leaf-to-root: no fill-in, factorize() in dtrl_kernel.h); the
+// kernel is instantiated per skeleton (dtrl_topo.h) and emits only the structurally non-zero updates.
+// Row layout after factorize_regs(): h[k] for k > lane = U_{lane,k}; h[lane] = d_lane; h[k] for k < lane = U_{k,lane}
+// (the transpose copy, so the second substitution also only needs the lane's own registers).
 #pragma once
 #include "dtrl_kernel.h"
+#include "dtrl_topo.h"
 #include <type_traits>
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -27,18 +30,18 @@ __device__ __forceinline__ real bcast(real v, int src)   // src must be wave-uni
 }
 
 // row `lane` of the joint-space inertia matrix from the composite quantities in LDS (same formulas and operand order as
-// mass_matrix()). Only the lower triangle (column <= lane) is produced: the factorisation never reads the rest (factorize_regs()).
+// mass_matrix()). Only the upper triangle (column >= lane) is produced: the leaf-first factorisation never reads the rest.
 // The (link, ancestor) pairs are dealt round-robin to all 64 lanes, each evaluates the closed form once and parks the value in a
-// packed table in LDS (the storage of the Delassus matrix, dead at that point) laid out as the rows themselves:
-//   row of link l (DoF l + 2) at base_l = l (l + 5) / 2: [hx, hy, H(l, link 0), ..., H(l, link l)], non-ancestor slots = 0
-// so a lane assembles its row with D loads at compile-time offsets from one base (no per-column index arithmetic, no branches: the
-// loads pipeline). Lanes without a hinge row (translations, lanes >= D) read a block of zeros behind the table.
+// packed table in LDS (the storage of the Delassus matrix, dead at that point):
+//   entries of link l (DoF l + 2) at base_l = l (l + 5) / 2: [hx, hy, H(l, link 0), ..., H(l, link l)], non-ancestor slots = 0
+// i.e. the slot of DoF pair (c, d), d <= c, is base_{c-2} + d: a lane assembles its row with D loads at compile-time offsets from its
+// own lane id (no per-column index arithmetic, no branches: the loads pipeline). Lanes >= D copy row 0 (finite, never read).
 template <int D>
 __device__ __forceinline__ void mass_row(WSFast& ws, real (&h)[D])
 {
 	constexpr int Lk = D - 2;                                  // links of the character this kernel is instantiated for
-	constexpr int kTab = Lk * (Lk + 5) / 2;                    // packed rows
-	constexpr int kFill = (kTab + D + 1) & ~1;                 // + one block of D zeros, even count (16-byte stores)
+	constexpr int kTab = Lk * (Lk + 5) / 2;
+	constexpr int kFill = (kTab + 1) & ~1;                     // even count (16-byte stores)
 	static_assert(kFill <= static_cast<int>(sizeof(ws.Apk) / sizeof(real)), "mass table does not fit the packed-matrix storage");
 	const int d = static_cast<int>(threadIdx.x);
 	const int l = d >= 2 ? d - 2 : 0;
@@ -51,8 +54,8 @@ __device__ __forceinline__ void mass_row(WSFast& ws, real (&h)[D])
 		for (int e = 0; e < (kFill / 2 + kGroup - 1) / kGroup; ++e) if (d + e * kGroup < kFill / 2) T2[d + e * kGroup] = z2;
 	}
 	__syncthreads();
-	const int base = hinge ? l * (l + 5) / 2 : kTab;
 	if (hinge) {
+		const int base = l * (l + 5) / 2;
 		const real m = ws.sm[l], mx = ws.smx[l], my = ws.smy[l];
 		T[base] = -(my - m * ws.py[l]);
 		T[base + 1] = (mx - m * ws.px[l]);
@@ -69,10 +72,11 @@ __device__ __forceinline__ void mass_row(WSFast& ws, real (&h)[D])
 	}
 	__syncthreads();
 	const real M0 = ws.sm[0];
+	const real* Tl = T + (d < D ? d : 0);
+	h[0] = (d == 0) ? M0 : 0.0;
+	h[1] = (d == 1) ? M0 : 0.0;
 #pragma unroll
-	for (int c = 0; c < D; ++c) h[c] = T[base + c];
-	if (d == 0) h[0] = M0;
-	if (d == 1) h[1] = M0;
+	for (int c = 2; c < D; ++c) h[c] = Tl[(c - 2) * (c + 3) / 2];   // base_{c-2} + lane
 	__syncthreads();   // T is dead; the storage may be reused
 }
 
@@ -136,70 +140,93 @@ __device__ __forceinline__ void mov_lanes_ge(real& dst, real src)
 	    : "+v"(dst), "=&s"(sv), "=&s"(m) : "v"(src), "n"(J) : "scc");
 }
 
-// in-register LDL^T; returns 1/d_lane. Same elimination order and operations as factorize(). The transposed copy of L
-// (needed by bsub_regs) is produced with one pass through LDS (packed lower triangle in the Apk storage, which is dead
-// between mass_row() and the Delassus build) instead of per-entry lane selects.
-template <int D>
-__device__ __forceinline__ real factorize_regs(WSFast& ws, real (&h)[D])
+template <int I>
+__device__ __forceinline__ void fnma_lanes_lt(real (&acc)[1], real a, const real (&b)[1]) { fnma_lanes_lt<I>(acc[0], a, b[0]); }
+template <int I>
+__device__ __forceinline__ void fnma_lanes_lt(real (&acc)[2], real a, const real (&b)[2])
 {
+	unsigned long long sv, m;
+	asm("s_bfm_b64 %3, %7, 0\n\ts_and_saveexec_b64 %2, %3\n\tv_fma_f64 %0, -%4, %5, %0\n\tv_fma_f64 %1, -%4, %6, %1\n\ts_mov_b64 exec, %2"
+	    : "+v"(acc[0]), "+v"(acc[1]), "=&s"(sv), "=&s"(m) : "v"(a), "s"(b[0]), "s"(b[1]), "n"(I) : "scc");
+}
+template <int I>
+__device__ __forceinline__ void fnma_lanes_lt(real (&acc)[4], real a, const real (&b)[4])
+{
+	unsigned long long sv, m;
+	asm("s_bfm_b64 %5, %11, 0\n\ts_and_saveexec_b64 %4, %5\n\tv_fma_f64 %0, -%6, %7, %0\n\tv_fma_f64 %1, -%6, %8, %1\n\t"
+	    "v_fma_f64 %2, -%6, %9, %2\n\tv_fma_f64 %3, -%6, %10, %3\n\ts_mov_b64 exec, %4"
+	    : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "=&s"(sv), "=&s"(m)
+	    : "v"(a), "s"(b[0]), "s"(b[1]), "s"(b[2]), "s"(b[3]), "n"(I) : "scc");
+}
+
+// in-register H = U D U^T, last DoF first; returns 1/d_lane. Same elimination order and operations as factorize(), minus the
+// updates that are structurally zero for the skeleton Topo (exact no-ops in the dense form). The transposed copy of U (needed by
+// utsolve_regs) is produced with one pass through LDS (packed triangle in the Apk storage, which is dead between mass_row() and the
+// Delassus build) instead of per-entry lane selects.
+// Only the upper triangle (column >= lane) is live, so the per-entry predicate of the textbook form is dropped: the other lanes
+// update entries nobody reads (they are overwritten by the transposed copy), the lanes that matter execute exactly the same
+// operations. One predicated move per pivot keeps the diagonal.
+template <class Topo>
+__device__ __forceinline__ real factorize_regs(WSFast& ws, real (&h)[Topo::L + 2])
+{
+	constexpr int D = Topo::L + 2;
 	const int lane = static_cast<int>(threadIdx.x);
-	// Only the lower triangle (lane >= column) is ever read back, so the per-entry predicate `lane >= j` of the textbook form is dropped:
-	// lanes above the diagonal update entries nobody reads (they are overwritten by the transposed copy below), the lanes that matter
-	// execute exactly the same operations. One predicated move per pivot keeps the diagonal.
-#pragma unroll
-	for (int k = 0; k < D - 1; ++k) {
+	static_for_down<1, D>([&](auto kc) {             // k = D-1 ... 1
+		constexpr int k = decltype(kc)::value;
 		const real dk = bcast(h[k], k);
 		const real ak = h[k];
 		const real lik = ak / dk;
-#pragma unroll
-		for (int j = k + 1; j < D; ++j) h[j] = fmadd(-lik, bcast(ak, j), h[j]);
-		if (lane > k) h[k] = lik;
-	}
+		static_for_down<0, k>([&](auto jc) {
+			constexpr int j = decltype(jc)::value;
+			if constexpr (dof_coupled<Topo>(j, k)) h[j] = fmadd(-lik, bcast(ak, j), h[j]);
+		});
+		if (lane < k) h[k] = lik;
+	});
 	real dinv = 0;
 #pragma unroll
 	for (int k = 0; k < D; ++k) if (lane == k) dinv = 1.0 / h[k];
 	real* S = ws.Apk;
+#pragma unroll
+	for (int k = 1; k < D; ++k) if (lane < k) S[k * (k - 1) / 2 + lane] = h[k];
+	__syncthreads();
 	const int base = lane * (lane - 1) / 2;
 #pragma unroll
-	for (int k = 0; k < D - 1; ++k) if (lane > k && lane < D) S[base + k] = h[k];
-	__syncthreads();
-#pragma unroll
-	for (int k = 1; k < D; ++k) if (lane < k) h[k] = S[k * (k - 1) / 2 + lane];
+	for (int k = 0; k < D - 1; ++k) if (lane > k && lane < D) h[k] = S[base + k];
 	__syncthreads();
 	return dinv;
 }
-// z = L^-1 rhs (lane i holds component i)
+// z = U^-1 rhs (lane i holds component i): from the last DoF up
 template <int D>
-__device__ __forceinline__ real fsub_regs(const real (&h)[D], real z)
+__device__ __forceinline__ real usolve_regs(const real (&h)[D], real z)
 {
-	static_for<0, D - 1>([&](auto kc) {
+	static_for_down<1, D>([&](auto kc) {
 		constexpr int k = decltype(kc)::value;
 		const real zk = bcast(z, k);
-		fnma_lanes_ge<k + 1>(z, h[k], zk);              // if (lane > k) z = fma(-h[k], zk, z)
+		fnma_lanes_lt<k>(z, h[k], zk);                  // if (lane < k) z = fma(-h[k], zk, z)
 	});
 	return z;
 }
 // NR right-hand sides at once: the substitution is a 22-step dependent chain per right-hand side, so interleaving independent
 // chains divides the exposed latency at the same instruction count (and the NR updates of a step share one EXEC window)
 template <int D, int NR>
-__device__ __forceinline__ void fsub_regs_n(const real (&h)[D], real (&z)[NR])
+__device__ __forceinline__ void usolve_regs_n(const real (&h)[D], real (&z)[NR])
 {
-	static_for<0, D - 1>([&](auto kc) {
+	static_for_down<1, D>([&](auto kc) {
 		constexpr int k = decltype(kc)::value;
 		real zk[NR];
 #pragma unroll
 		for (int j = 0; j < NR; ++j) zk[j] = bcast(z[j], k);
-		fnma_lanes_ge<k + 1>(z, h[k], zk);
+		fnma_lanes_lt<k>(z, h[k], zk);
 	});
 }
-// x = L^-T u
+// x = U^-T u: from DoF 0 down
 template <int D>
-__device__ __forceinline__ real bsub_regs(const real (&h)[D], real u)
+__device__ __forceinline__ real utsolve_regs(const real (&h)[D], real u)
 {
-	static_for_down<1, D>([&](auto ic) {
-		constexpr int i = decltype(ic)::value;
-		const real ui = bcast(u, i);
-		fnma_lanes_lt<i>(u, h[i], ui);                  // if (lane < i) u = fma(-h[i], ui, u)
+	static_for<0, D - 1>([&](auto kc) {
+		constexpr int k = decltype(kc)::value;
+		const real uk = bcast(u, k);
+		fnma_lanes_ge<k + 1>(u, h[k], uk);              // if (lane > k) u = fma(-h[k], uk, u)
 	});
 	return u;
 }
@@ -370,8 +397,9 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 	__syncthreads();
 }
 
-template <int D>
+template <class Topo>
 struct FastPath {
+	static constexpr int D = Topo::L + 2;
 	static __device__ void substep(WSFast& ws, const DevModel& gm, const GroundRec& g, real h, bool kin_valid)
 	{
 		const int lane = static_cast<int>(threadIdx.x);
@@ -382,7 +410,7 @@ struct FastPath {
 		real hrow[D];
 		{ PROF_T0(); mass_row<D>(ws, hrow); PROF_ADD(ws, kProfMass); }
 		real dinv;
-		{ PROF_T0(); dinv = factorize_regs<D>(ws, hrow); PROF_ADD(ws, kProfFact); }
+		{ PROF_T0(); dinv = factorize_regs<Topo>(ws, hrow); PROF_ADD(ws, kProfFact); }
 		{
 			ContactPts cp;
 			{ PROF_T0(); cp = eval_points(ws, gm, g); contact_bits_fast(ws, cp.m0, cp.m1, cp.m2); PROF_ADD(ws, kProfDetect); }
@@ -411,19 +439,19 @@ struct FastPath {
 			int r0 = 0;
 			for (; r0 + 4 <= R + 1; r0 += 4) {
 				real z[4] = {rhs_of(r0), rhs_of(r0 + 1), rhs_of(r0 + 2), rhs_of(r0 + 3)};
-				fsub_regs_n<D, 4>(hrow, z);
+				usolve_regs_n<D, 4>(hrow, z);
 #pragma unroll
 				for (int j = 0; j < 4; ++j) if (lane < D) ws.Z[r0 + j][lane] = z[j];
 			}
 			if (r0 + 2 <= R + 1) {
 				real z[2] = {rhs_of(r0), rhs_of(r0 + 1)};
-				fsub_regs_n<D, 2>(hrow, z);
+				usolve_regs_n<D, 2>(hrow, z);
 				if (lane < D) { ws.Z[r0][lane] = z[0]; ws.Z[r0 + 1][lane] = z[1]; }
 				r0 += 2;
 			}
 			if (r0 <= R) {
 				real z[1] = {rhs_of(r0)};
-				fsub_regs_n<D, 1>(hrow, z);
+				usolve_regs_n<D, 1>(hrow, z);
 				if (lane < D) ws.Z[r0][lane] = z[0];
 			}
 			__syncthreads();
@@ -441,7 +469,7 @@ struct FastPath {
 				for (int r = 0; r < R; ++r) s = fmadd(ws.Z[r][lane], ws.lam[r], s);
 				u = s * dinv;
 			}
-			u = bsub_regs<D>(hrow, u);
+			u = utsolve_regs<D>(hrow, u);
 			if (lane < D) { const real v = ws.st.qd[lane] + u; ws.st.qd[lane] = v; ws.st.q[lane] += h * v; }
 			__syncthreads();
 			PROF_ADD(ws, kProfFinish);
@@ -458,11 +486,11 @@ struct FastPath {
 		const real add = (lane < D) ? dt * ws.kdm[lane] : 0.0;
 #pragma unroll
 		for (int k = 0; k < D; ++k) if (lane == k) hrow[k] += add;
-		const real dinv = factorize_regs<D>(ws, hrow);
+		const real dinv = factorize_regs<Topo>(ws, hrow);
 		real z = (lane < D) ? ws.u[lane] : 0.0;
-		z = fsub_regs<D>(hrow, z);
+		z = usolve_regs<D>(hrow, z);
 		real u = z * dinv;
-		u = bsub_regs<D>(hrow, u);
+		u = utsolve_regs<D>(hrow, u);
 		__syncthreads();
 		if (lane < D) ws.u[lane] = u;
 		if (lane == 0) ws.R = 0;

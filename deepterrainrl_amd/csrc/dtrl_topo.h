@@ -1,0 +1,53 @@
+// dtrl_topo.h -- skeleton topologies the register fast path is compiled for (dtrl_kernel_fast.h).
+// The fast path eliminates the joint-space inertia matrix leaf-to-root; with the parent table known at compile time the updates that
+// are structurally zero (DoF pairs that are not on one root->leaf path) are simply not emitted. A character whose parent table
+// matches none of these runs on the generic LDS-phase kernel (same results, slower).
+// Parent tables: data/characters/dog.txt and goat.txt (same skeleton), raptor.txt of the reference.
+#pragma once
+#include <cstdint>
+
+namespace dtrl {
+
+struct TopoDog {
+	static constexpr int kId = 1;
+	static constexpr int L = 21;
+	static constexpr int parent(int l) { constexpr int p[L] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 0, 9, 10, 11, 5, 13, 14, 15, 0, 17, 18, 19}; return p[l]; }
+};
+struct TopoRaptor {
+	static constexpr int kId = 2;
+	static constexpr int L = 19;
+	static constexpr int parent(int l) { constexpr int p[L] = {-1, 0, 1, 2, 3, 4, 0, 6, 7, 8, 9, 0, 11, 12, 13, 0, 15, 16, 17}; return p[l]; }
+};
+
+// link a is l or an ancestor of l
+template <class T>
+constexpr bool link_on_path(int a, int l)
+{
+	while (l >= 0) { if (l == a) return true; l = T::parent(l); }
+	return false;
+}
+// entry (j, k), j < k, of the joint-space inertia matrix is structurally non-zero during the leaf-first elimination. DoFs 0, 1 are the
+// root translations: every hinge hangs below them (H(0,1) itself starts at zero but fills in as the hinges are eliminated);
+// DoF d >= 2 is the hinge of link d - 2
+template <class T>
+constexpr bool dof_coupled(int j, int k)
+{
+	if (j < 2) return true;
+	return link_on_path<T>(j - 2, k - 2);
+}
+template <class T>
+inline bool topology_matches(const int32_t* parent, int L)
+{
+	if (L != T::L) return false;
+	for (int l = 0; l < L; ++l) if (parent[l] != T::parent(l)) return false;
+	return true;
+}
+// 0 = no compiled-in topology (generic kernel)
+inline int match_topology(const int32_t* parent, int L)
+{
+	if (topology_matches<TopoDog>(parent, L)) return TopoDog::kId;
+	if (topology_matches<TopoRaptor>(parent, L)) return TopoRaptor::kId;
+	return 0;
+}
+
+}  // namespace dtrl
