@@ -177,6 +177,34 @@ struct WSFast : WSBase {
 // fused multiply-add a*b + c, spelled out (the build runs with -ffp-contract=off): the SAME fused operations in the lane-loop,
 // reference and register-resident builds keep the three bit-identical, and the solver's dependent chains are one op shorter per step
 DTRL_HD_INLINE real fmadd(real a, real b, real c) { return __builtin_fma(a, b, c); }
+// 1/x and 1/sqrt(x) for the solver's pivots and the contact normals. An IEEE fp64 division on gfx950 is a 14-instruction VALU sequence
+// (div_scale x2, rcp, Newton, div_fmas, div_fixup) and the frame kernel is bound by VALU issue; the hardware seed + two Newton steps
+// (5 / 9 instructions) is within an ulp or two for the normal, positive arguments that occur here (inertias, 1 + slope^2).
+// Both device kernels use these, so they stay bit-identical to each other; the CPU builds keep the exact division (tests compare
+// against the oracle with a tolerance, not bitwise).
+DTRL_HD_INLINE real fast_recip(real x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	real r = __builtin_amdgcn_rcp(x);
+	r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+	r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+	return r;
+#else
+	return 1.0 / x;
+#endif
+}
+DTRL_HD_INLINE real fast_rsqrt(real x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	real r = __builtin_amdgcn_rsq(x);
+	const real hx = 0.5 * x;
+	r = __builtin_fma(__builtin_fma(-hx * r, r, 0.5), r, r);   // r += r (1/2 - x r^2 / 2)
+	r = __builtin_fma(__builtin_fma(-hx * r, r, 0.5), r, r);
+	return r;
+#else
+	return 1.0 / sqrt(x);
+#endif
+}
 
 DTRL_HD inline real wrap_pi(real a)
 {
@@ -404,14 +432,14 @@ DTRL_HD inline void factorize(W& ws)
 		LANES_BEGIN
 		if (lane < k) {
 			const int i = lane;
-			real lik = ws.H[i][k] / ws.H[k][k];
+			real lik = ws.H[i][k] * fast_recip(ws.H[k][k]);
 			for (int j = k - 1; j >= i; --j) ws.H[i][j] = fmadd(-lik, ws.H[j][k], ws.H[i][j]);
 			ws.H[k][i] = lik;
 		}
 		LANES_END
 	}
 	LANES_BEGIN
-	if (lane < D) ws.dinv[lane] = 1.0 / ws.H[lane][lane];
+	if (lane < D) ws.dinv[lane] = fast_recip(ws.H[lane][lane]);
 	LANES_END
 }
 
@@ -443,7 +471,7 @@ DTRL_HD_INLINE PtVal contact_point_eval(const W& ws, const DevModel& gm, const G
 	const real h = sample_ground(g, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
 	const real gap = h - (ws.st.q[1] + y);
 	if (!(gap > 0)) return r;   // depth = gap * ny with ny > 0: the normal is only needed for penetrating points
-	const real inv = 1.0 / sqrt(1.0 + slope * slope);
+	const real inv = fast_rsqrt(1.0 + slope * slope);
 	r.nx = -slope * inv; r.ny = inv;
 	r.depth = gap * r.ny;
 	r.x = x; r.y = y;

@@ -171,20 +171,21 @@ __device__ __forceinline__ real factorize_regs(WSFast& ws, real (&h)[Topo::L + 2
 {
 	constexpr int D = Topo::L + 2;
 	const int lane = static_cast<int>(threadIdx.x);
+	real dinv = 0;
 	static_for_down<1, D>([&](auto kc) {             // k = D-1 ... 1
 		constexpr int k = decltype(kc)::value;
 		const real dk = bcast(h[k], k);
 		const real ak = h[k];
-		const real lik = ak / dk;
+		const real rk = fast_recip(dk);
+		if (lane == k) dinv = rk;
+		const real lik = ak * rk;
 		static_for_down<0, k>([&](auto jc) {
 			constexpr int j = decltype(jc)::value;
 			if constexpr (dof_coupled<Topo>(j, k)) h[j] = fmadd(-lik, bcast(ak, j), h[j]);
 		});
 		if (lane < k) h[k] = lik;
 	});
-	real dinv = 0;
-#pragma unroll
-	for (int k = 0; k < D; ++k) if (lane == k) dinv = 1.0 / h[k];
+	{ const real r0 = fast_recip(h[0]); if (lane == 0) dinv = r0; }
 	real* S = ws.Apk;
 #pragma unroll
 	for (int k = 1; k < D; ++k) if (lane < k) S[k * (k - 1) / 2 + lane] = h[k];

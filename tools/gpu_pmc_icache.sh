@@ -14,6 +14,6 @@ for sub in ("pmc_ic", "pmc_ic2"):
     for db in glob.glob("$OUT/%s/*.db" % sub):
         cur = sqlite3.connect(db).cursor()
         q = ("select counter_name, count(*), avg(value) from counters_collection where kernel_name like '%dtrl_frame_kernel%' "
-             "and grid_size = (select max(grid_size) from counters_collection where kernel_name like '%dtrl_frame_kernel%') group by counter_name order by counter_name")
+             "and grid_size = (select grid_size from counters_collection where kernel_name like '%dtrl_frame_kernel%' group by grid_size order by count(*) desc limit 1) group by counter_name order by counter_name")
         for r in cur.execute(q): print("%-30s n=%3d avg=%.6g" % r)
 PY
