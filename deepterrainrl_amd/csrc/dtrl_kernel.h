@@ -73,7 +73,7 @@ struct HotModel {
 	int32_t L, D, char_type, n_pairs;
 	int32_t parent[kMaxL], depth[kMaxL], col[kMaxL];
 	int8_t pair_l[kMaxPairs], pair_k[kMaxPairs];
-	int8_t path[kMaxL][kMaxDepth];
+	alignas(4) int8_t path[kMaxL][kMaxDepth];   // read four entries at a time (path_word())
 	uint32_t sub_mask[kMaxL];
 	uint32_t anc_mask[kMaxL];   // bit a set <=> link a is an ancestor of j or j itself
 	real attach[kMaxL][2], lim_lo[kMaxL], lim_hi[kMaxL];
@@ -278,6 +278,18 @@ DTRL_HD_INLINE real sample_ground(const GroundRec& g, real x, real* slope, int* 
 // cRBDUtil::BuildCjPlanar as shipped (sim/RBDUtil.cpp:809-836: theta read from q_dot and s = cos(theta)), which differs from the
 // textbook bias by a uniform extra base acceleration (dax, day); with subtree sums that is a closed-form correction per DoF
 // (quirk_bias() below), so ONE evaluation at the post-step configuration serves the controller AND the next substep.
+// four consecutive entries of link j's root->j path in one 32-bit LDS read. The path loops below fetch the whole index list of a lane
+// up front (three independent loads) instead of one dependent byte load per path element in front of every data load
+static_assert(kMaxDepth % 4 == 0, "path rows are read as 32-bit words");
+template <class W>
+DTRL_HD_INLINE uint32_t path_word(const W& ws, int j, int t)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return reinterpret_cast<const uint32_t*>(&ws.M.path[j][0])[t];
+#else
+	uint32_t w; __builtin_memcpy(&w, &ws.M.path[j][4 * t], 4); return w;
+#endif
+}
 template <class W>
 DTRL_HD inline void kin_dyn_terms(W& ws)
 {
@@ -287,9 +299,10 @@ DTRL_HD inline void kin_dyn_terms(W& ws)
 		const int j = lane;
 		const int dep = ws.M.depth[j];
 		real phi = 0, w = 0;
-#pragma unroll 6
+		const uint32_t pw[kMaxDepth / 4] = {path_word(ws, j, 0), path_word(ws, j, 1), path_word(ws, j, 2)};
+#pragma unroll
 		for (int k = 0; k < kMaxDepth; ++k) {
-			const int a = ws.M.path[j][k <= dep ? k : 0];
+			const int a = (k <= dep) ? static_cast<int>((pw[k / 4] >> (8 * (k % 4))) & 0xffu) : 0;
 			const real qa = ws.st.q[a + 2], wa = ws.st.qd[a + 2];
 			const real on = (k <= dep) ? 1.0 : 0.0;   // predicated accumulation as fma(x, 1|0, acc): same sum (x*1 is exact), but branch-free, so the LDS loads of the whole loop pipeline
 			phi = fmadd(qa, on, phi); w = fmadd(wa, on, w);
@@ -323,9 +336,10 @@ DTRL_HD inline void kin_dyn_terms(W& ws)
 		const int dep = ws.M.depth[j];
 		const real ax0 = 0, ay0 = -kGravityY;
 		real px = 0, py = 0, vx = ws.st.qd[0], vy = ws.st.qd[1], ax = 0, ay = 0;
-#pragma unroll 4
+		const uint32_t pw[kMaxDepth / 4] = {path_word(ws, j, 0), path_word(ws, j, 1), path_word(ws, j, 2)};
+#pragma unroll
 		for (int k = 1; k < kMaxDepth; ++k) {
-			const int a = ws.M.path[j][k <= dep ? k : 0];
+			const int a = (k <= dep) ? static_cast<int>((pw[k / 4] >> (8 * (k % 4))) & 0xffu) : 0;
 			const real rx = ws.bx[a], ry = ws.by[a], dux = ws.ux[a], duy = ws.uy[a], dgx = ws.gx[a], dgy = ws.gy[a];
 			const real on = (k <= dep) ? 1.0 : 0.0;
 			px = fmadd(rx, on, px); py = fmadd(ry, on, py); vx = fmadd(dux, on, vx); vy = fmadd(duy, on, vy); ax = fmadd(dgx, on, ax); ay = fmadd(dgy, on, ay);
