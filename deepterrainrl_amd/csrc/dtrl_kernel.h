@@ -244,13 +244,27 @@ DTRL_HD inline Rng make_rng(const RunParams& rp, int env, uint64_t* ctr)
 // heightfield sampling: /root/reference/sim/GroundVar2D.cpp:98-114 (segment pick) + :559-619 (grid coord, clamp, lerp).
 // Grid coordinates are computed in double with the float-rounded Bullet origin / scaling the host stored in GroundRec,
 // so the cell indices i, j are bit-exact with the reference's arithmetic.
-DTRL_HD_INLINE real sample_ground(const GroundRec& g, real x, real* slope, int* oi, int* oj, int* oseg)
+struct GroundHdr { real mx0, o0, o1, sc0, sc1; int w0, w1; };
+// both segment headers, fetched up front (independent of the sample position, so the loads travel with the caller's other loads)
+// and selected afterwards: loads indexed by the segment would be a second dependent round trip to memory in front of the heights
+DTRL_HD_INLINE GroundHdr ground_header(const GroundRec& g)
 {
-	int seg = (x >= g.max_x[0]) ? 1 : 0;
-	const int w = g.w[seg];
+	GroundHdr h;
+	h.mx0 = g.max_x[0]; h.w0 = g.w[0]; h.w1 = g.w[1];
+	h.o0 = g.origin_x[0]; h.o1 = g.origin_x[1]; h.sc0 = g.scale_x[0]; h.sc1 = g.scale_x[1];
+	return h;
+}
+DTRL_HD_INLINE real sample_ground(const GroundRec& g, const GroundHdr& gh, real x, real* slope, int* oi, int* oj, int* oseg)
+{
+	const real mx0 = gh.mx0;
+	const int w0 = gh.w0, w1 = gh.w1;
+	const real o0 = gh.o0, o1 = gh.o1, sc0 = gh.sc0, sc1 = gh.sc1;
+	const int seg = (x >= mx0) ? 1 : 0;
+	const int w = seg ? w1 : w0;
+	const real scale = seg ? sc1 : sc0;
 	const real tol = 0.0001;
-	real c = x - g.origin_x[seg];
-	c /= g.scale_x[seg];
+	real c = x - (seg ? o1 : o0);
+	c /= scale;
 	c += ((w - 1) * 0.5);
 	if (c > -tol && c < w - 1 + tol) { c = c < 0.0 ? 0.0 : (c > w - 1.0 ? w - 1.0 : c); }
 	c = c < 0.0 ? 0.0 : (c > w - 1.0 ? w - 1.0 : c);
@@ -259,11 +273,16 @@ DTRL_HD_INLINE real sample_ground(const GroundRec& g, real x, real* slope, int* 
 	real lerp = c - i;
 	real a = g.data[seg][i];
 	real b = g.data[seg][j];
-	if (slope) *slope = (j == i) ? 0.0 : (b - a) / (g.scale_x[seg] * (j - i));
+	if (slope) *slope = (j == i) ? 0.0 : (b - a) / (scale * (j - i));
 	if (oi) *oi = i;
 	if (oj) *oj = j;
 	if (oseg) *oseg = seg;
 	return (1 - lerp) * a + lerp * b;
+}
+DTRL_HD_INLINE real sample_ground(const GroundRec& g, real x, real* slope, int* oi, int* oj, int* oseg)
+{
+	const GroundHdr gh = ground_header(g);
+	return sample_ground(g, gh, x, slope, oi, oj, oseg);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -476,13 +495,14 @@ DTRL_HD_INLINE PtVal contact_point_eval(const W& ws, const DevModel& gm, const G
 {
 	PtVal r; r.x = 0; r.y = 0; r.depth = 0; r.nx = 0; r.ny = 0; r.active = 0;
 	const int j = pt / kPtsPerLink, k = pt - j * kPtsPerLink;
+	const GroundHdr gh = ground_header(g);   // issued with the sample point's local coordinates below: one trip to memory for both
 	if (ws.M.col[j] == 0) return r;
 	const real lx = gm.pt_joint[j][k][0], ly = gm.pt_joint[j][k][1];
 	const real c = ws.cs[j], s = ws.sn[j];
 	const real x = ws.px[j] + c * lx - s * ly;
 	const real y = ws.py[j] + s * lx + c * ly;
 	real slope;
-	const real h = sample_ground(g, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
+	const real h = sample_ground(g, gh, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
 	const real gap = h - (ws.st.q[1] + y);
 	if (!(gap > 0)) return r;   // depth = gap * ny with ny > 0: the normal is only needed for penetrating points
 	const real inv = fast_rsqrt(1.0 + slope * slope);
