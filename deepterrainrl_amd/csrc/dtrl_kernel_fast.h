@@ -323,34 +323,47 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 	real di[D];
 #pragma unroll
 	for (int i = 0; i < D; ++i) di[i] = bcast(dinv_mine, i);   // wave-uniform (SGPR pairs)
-	for (int e = lane; e < n_ent; e += kGroup) {
-		int s = static_cast<int>((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+	auto entry_rows = [](int e, int& s, int& r) {
+		s = static_cast<int>((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
 		while (s * (s + 1) / 2 > e) --s;
 		while ((s + 1) * (s + 2) / 2 <= e) ++s;
-		const int r = e - s * (s + 1) / 2;
+		r = e - s * (s + 1) / 2;
+	};
+	// first pass: the lane's matrix entry (all of them for R <= 10) and, on lanes < R, the row's initial residual w = J v_free - target.
+	// The two 23-term dot products are independent dependent chains; evaluated in one loop they cost the latency of one
+	{
+		const bool has_e = lane < n_ent, has_w = lane < R;
+		int s = 0, r = 0;
+		if (has_e) entry_rows(lane, s, r);
+		const int sw = has_w ? lane : 0;
+		real jv = 0;
+		if (has_w) {
+			if (ws.row_kind[sw] == 0) jv = ws.row_dx[sw] * ws.st.qd[ws.row_link[sw] + 2];
+			else {
+				const int l = ws.row_link[sw];
+				const real vx = ws.vpx[l] - ws.w[l] * (ws.row_y[sw] - ws.py[l]);
+				const real vy = ws.vpy[l] + ws.w[l] * (ws.row_x[sw] - ws.px[l]);
+				jv = ws.row_dx[sw] * vx + ws.row_dy[sw] * vy;
+			}
+		}
+		const real* zs = ws.Z[s];
+		const real* zr = ws.Z[r];
+		const real* zw = ws.Z[sw];
+		const real* z0 = ws.Z[R];
+		real a = 0, zz = 0;
+#pragma unroll
+		for (int i = 0; i < D; ++i) { a = fmadd(zs[i] * zr[i], di[i], a); zz = fmadd(zw[i] * di[i], z0[i], zz); }
+		if (has_e) ws.Apk[lane] = a;
+		if (has_w) ws.wv[lane] = jv + h * zz - ws.row_tgt[lane];
+	}
+	for (int e = lane + kGroup; e < n_ent; e += kGroup) {
+		int s, r; entry_rows(e, s, r);
 		const real* zs = ws.Z[s];
 		const real* zr = ws.Z[r];
 		real a = 0;
 #pragma unroll
 		for (int i = 0; i < D; ++i) a = fmadd(zs[i] * zr[i], di[i], a);
 		ws.Apk[e] = a;
-	}
-	if (lane < R) {
-		const int s = lane;
-		real jv;
-		if (ws.row_kind[s] == 0) jv = ws.row_dx[s] * ws.st.qd[ws.row_link[s] + 2];
-		else {
-			const int l = ws.row_link[s];
-			const real vx = ws.vpx[l] - ws.w[l] * (ws.row_y[s] - ws.py[l]);
-			const real vy = ws.vpy[l] + ws.w[l] * (ws.row_x[s] - ws.px[l]);
-			jv = ws.row_dx[s] * vx + ws.row_dy[s] * vy;
-		}
-		const real* zs = ws.Z[s];
-		const real* z0 = ws.Z[R];
-		real zz = 0;
-#pragma unroll
-		for (int i = 0; i < D; ++i) zz = fmadd(zs[i] * di[i], z0[i], zz);
-		ws.wv[s] = jv + h * zz - ws.row_tgt[s];
 	}
 	__syncthreads();
 }
