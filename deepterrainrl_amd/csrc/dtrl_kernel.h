@@ -1178,17 +1178,40 @@ struct RefPath {
 DTRL_HD inline void solve_ls4(const real (*basis)[4], const real* tau_g, const real* W, real* x)
 {
 	real M4[4][5];
+#pragma unroll
 	for (int a = 0; a < 4; ++a) {
+#pragma unroll
 		for (int c = 0; c < 4; ++c) { real s = 0; for (int r = 0; r < 3; ++r) s += basis[r][a] * W[r] * basis[r][c]; M4[a][c] = s; }
 		real s = 0; for (int r = 0; r < 3; ++r) s += basis[r][a] * W[r] * tau_g[r];
 		M4[a][4] = s; M4[a][a] += 0.0001;
 	}
+	// every index below is a compile-time constant after unrolling (the pivot row is applied as predicated swaps against each candidate
+	// row, not as M4[p]): a dynamically indexed private array would live in scratch memory and cost a write-back to HBM per env-step
+#pragma unroll
 	for (int c = 0; c < 4; ++c) {
-		int p = c; for (int r = c + 1; r < 4; ++r) if (fabs(M4[r][c]) > fabs(M4[p][c])) p = r;
-		if (p != c) for (int k = 0; k < 5; ++k) { real t = M4[c][k]; M4[c][k] = M4[p][k]; M4[p][k] = t; }
-		for (int r = c + 1; r < 4; ++r) { real f = M4[r][c] / M4[c][c]; for (int k = c; k < 5; ++k) M4[r][k] -= f * M4[c][k]; }
+		int p = c; real best = fabs(M4[c][c]);
+#pragma unroll
+		for (int r = c + 1; r < 4; ++r) { const real v = fabs(M4[r][c]); if (v > best) { best = v; p = r; } }
+#pragma unroll
+		for (int r = c + 1; r < 4; ++r) {
+			const bool sw = (p == r);
+#pragma unroll
+			for (int k = 0; k < 5; ++k) { const real a = M4[c][k], b = M4[r][k]; M4[c][k] = sw ? b : a; M4[r][k] = sw ? a : b; }
+		}
+#pragma unroll
+		for (int r = c + 1; r < 4; ++r) {
+			const real f = M4[r][c] / M4[c][c];
+#pragma unroll
+			for (int k = c; k < 5; ++k) M4[r][k] -= f * M4[c][k];
+		}
 	}
-	for (int i = 3; i >= 0; --i) { real s = M4[i][4]; for (int k = i + 1; k < 4; ++k) s -= M4[i][k] * x[k]; x[i] = s / M4[i][i]; }
+#pragma unroll
+	for (int i = 3; i >= 0; --i) {
+		real s = M4[i][4];
+#pragma unroll
+		for (int k = i + 1; k < 4; ++k) s -= M4[i][k] * x[k];
+		x[i] = s / M4[i][i];
+	}
 }
 
 // cDogController::Update (sim/DogController.cpp:229-268) / cRaptorController::Update (sim/RaptorController.cpp:195-233)
