@@ -271,9 +271,10 @@ DTRL_HD_INLINE real sample_ground(const GroundRec& g, const GroundHdr& gh, real 
 	int i = static_cast<int>(c);
 	int j = (i + 1 < w - 1) ? i + 1 : w - 1;
 	real lerp = c - i;
+	const real inv_run = fast_recip(scale * ((j - i) > 0 ? (j - i) : 1));   // ready before the height samples arrive
 	real a = g.data[seg][i];
 	real b = g.data[seg][j];
-	if (slope) *slope = (j == i) ? 0.0 : (b - a) / (scale * (j - i));
+	if (slope) *slope = (j == i) ? 0.0 : (b - a) * inv_run;
 	if (oi) *oi = i;
 	if (oj) *oj = j;
 	if (oseg) *oseg = seg;
@@ -542,17 +543,18 @@ DTRL_HD inline void build_rows(W& ws, real h)
 {
 	LANES_BEGIN
 	if (lane == 0) {
+		const real inv_h = 1.0 / h;   // one division per call instead of one per row (same value in both kernels)
 		int R = 0;
 		for (int j = 1; j < ws.M.L; ++j) {
 			if (ws.M.lim_lo[j] > ws.M.lim_hi[j]) continue;
 			real th = ws.st.q[j + 2];
-			if (th <= ws.M.lim_lo[j] + kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_dx[R] = 1; ws.row_tgt[R] = kLimitErp * fmax(ws.M.lim_lo[j] - th, 0.0) / h; ++R; }
-			else if (th >= ws.M.lim_hi[j] - kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_dx[R] = -1; ws.row_tgt[R] = kLimitErp * fmax(th - ws.M.lim_hi[j], 0.0) / h; ++R; }
+			if (th <= ws.M.lim_lo[j] + kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_dx[R] = 1; ws.row_tgt[R] = kLimitErp * fmax(ws.M.lim_lo[j] - th, 0.0) * inv_h; ++R; }
+			else if (th >= ws.M.lim_hi[j] - kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_dx[R] = -1; ws.row_tgt[R] = kLimitErp * fmax(th - ws.M.lim_hi[j], 0.0) * inv_h; ++R; }
 		}
 		int cap = (kMaxRows - R) / 2, nc = 0;
 		for (int pt = 0; pt < ws.M.L * kPtsPerLink && nc < cap; ++pt) if (ws.pt_active[pt]) {
 			const int j = pt / kPtsPerLink;
-			real t = kErp * fmax(ws.pt_depth[pt] - kSlop, 0.0) / h;
+			real t = kErp * fmax(ws.pt_depth[pt] - kSlop, 0.0) * inv_h;
 			ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_x[R] = ws.pt_x[pt]; ws.row_y[R] = ws.pt_y[pt];
 			ws.row_dx[R] = ws.pt_nx[pt]; ws.row_dy[R] = ws.pt_ny[pt]; ws.row_tgt[R] = fmin(t, kVDepenMax); ++R;
 			ws.row_kind[R] = 2; ws.row_link[R] = j; ws.row_x[R] = ws.pt_x[pt]; ws.row_y[R] = ws.pt_y[pt];
@@ -1177,7 +1179,7 @@ struct RefPath {
 // 4x4 ridge solve of the contact-basis least squares (partial-pivot elimination), shared by both characters
 DTRL_HD inline void solve_ls4(const real (*basis)[4], const real* tau_g, const real* W, real* x)
 {
-	real M4[4][5];
+	real M4[4][5], ipiv[4];
 #pragma unroll
 	for (int a = 0; a < 4; ++a) {
 #pragma unroll
@@ -1198,9 +1200,10 @@ DTRL_HD inline void solve_ls4(const real (*basis)[4], const real* tau_g, const r
 #pragma unroll
 			for (int k = 0; k < 5; ++k) { const real a = M4[c][k], b = M4[r][k]; M4[c][k] = sw ? b : a; M4[r][k] = sw ? a : b; }
 		}
+		ipiv[c] = fast_recip(M4[c][c]);   // one reciprocal per pivot, reused by the back substitution (10 divisions -> 4 reciprocals)
 #pragma unroll
 		for (int r = c + 1; r < 4; ++r) {
-			const real f = M4[r][c] / M4[c][c];
+			const real f = M4[r][c] * ipiv[c];
 #pragma unroll
 			for (int k = c; k < 5; ++k) M4[r][k] -= f * M4[c][k];
 		}
@@ -1210,7 +1213,7 @@ DTRL_HD inline void solve_ls4(const real (*basis)[4], const real* tau_g, const r
 		real s = M4[i][4];
 #pragma unroll
 		for (int k = i + 1; k < 4; ++k) s -= M4[i][k] * x[k];
-		x[i] = s / M4[i][i];
+		x[i] = s * ipiv[i];
 	}
 }
 

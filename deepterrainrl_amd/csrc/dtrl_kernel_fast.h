@@ -272,12 +272,12 @@ __device__ __forceinline__ void detect_contacts_fast(WSFast& ws, const DevModel&
 	contact_bits_fast(ws, c.m0, c.m1, c.m2);
 	__syncthreads();
 }
-__device__ __forceinline__ void emit_contact_rows(WSFast& ws, const PtVal& p, int pt, int rank, int cap, int R0, real h)
+__device__ __forceinline__ void emit_contact_rows(WSFast& ws, const PtVal& p, int pt, int rank, int cap, int R0, real inv_h)
 {
 	if (p.active && rank < cap) {
 		const int R = R0 + 2 * rank;
 		const int j = pt / kPtsPerLink;
-		const real t = kErp * fmax(p.depth - kSlop, 0.0) / h;
+		const real t = kErp * fmax(p.depth - kSlop, 0.0) * inv_h;
 		ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_x[R] = p.x; ws.row_y[R] = p.y;
 		ws.row_dx[R] = p.nx; ws.row_dy[R] = p.ny; ws.row_tgt[R] = fmin(t, kVDepenMax);
 		ws.row_kind[R + 1] = 2; ws.row_link[R + 1] = j; ws.row_x[R + 1] = p.x; ws.row_y[R + 1] = p.y;
@@ -288,12 +288,13 @@ __device__ __forceinline__ void build_rows_fast(WSFast& ws, const ContactPts& c,
 {
 	const int lane = static_cast<int>(threadIdx.x);
 	const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+	const real inv_h = 1.0 / h;
 	// joint limits, ordered by joint id
 	int lim = 0; real tgt = 0;
 	if (lane >= 1 && lane < ws.M.L && !(ws.M.lim_lo[lane] > ws.M.lim_hi[lane])) {
 		const real th = ws.st.q[lane + 2];
-		if (th <= ws.M.lim_lo[lane] + kLimitSlop) { lim = 1; tgt = kLimitErp * fmax(ws.M.lim_lo[lane] - th, 0.0) / h; }
-		else if (th >= ws.M.lim_hi[lane] - kLimitSlop) { lim = -1; tgt = kLimitErp * fmax(th - ws.M.lim_hi[lane], 0.0) / h; }
+		if (th <= ws.M.lim_lo[lane] + kLimitSlop) { lim = 1; tgt = kLimitErp * fmax(ws.M.lim_lo[lane] - th, 0.0) * inv_h; }
+		else if (th >= ws.M.lim_hi[lane] - kLimitSlop) { lim = -1; tgt = kLimitErp * fmax(th - ws.M.lim_hi[lane], 0.0) * inv_h; }
 	}
 	const unsigned long long ml = __ballot(lim != 0);
 	const int rl = __popcll(ml & below);
@@ -302,9 +303,9 @@ __device__ __forceinline__ void build_rows_fast(WSFast& ws, const ContactPts& c,
 	// contacts, ordered by sample-point index
 	const int cap = (kMaxRows - R0) / 2;
 	const int n0 = __popcll(c.m0), n1 = __popcll(c.m1), n2 = __popcll(c.m2);
-	emit_contact_rows(ws, c.p0, lane, __popcll(c.m0 & below), cap, R0, h);
-	emit_contact_rows(ws, c.p1, lane + kGroup, n0 + __popcll(c.m1 & below), cap, R0, h);
-	emit_contact_rows(ws, c.p2, lane + 2 * kGroup, n0 + n1 + __popcll(c.m2 & below), cap, R0, h);
+	emit_contact_rows(ws, c.p0, lane, __popcll(c.m0 & below), cap, R0, inv_h);
+	emit_contact_rows(ws, c.p1, lane + kGroup, n0 + __popcll(c.m1 & below), cap, R0, inv_h);
+	emit_contact_rows(ws, c.p2, lane + 2 * kGroup, n0 + n1 + __popcll(c.m2 & below), cap, R0, inv_h);
 	int nc = n0 + n1 + n2; if (nc > cap) nc = cap;
 	if (lane == 0) ws.R = R0 + 2 * nc;
 	__syncthreads();
