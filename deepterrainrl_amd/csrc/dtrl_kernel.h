@@ -118,8 +118,9 @@ struct WSBase {
 	real phi[kMaxL], cs[kMaxL], sn[kMaxL], w[kMaxL];
 	real px[kMaxL], py[kMaxL], cx[kMaxL], cy[kMaxL];
 	real vpx[kMaxL], vpy[kMaxL], vcx[kMaxL], vcy[kMaxL];
-	real fx[kMaxL], fy[kMaxL], fn[kMaxL];
-	real mcx[kMaxL], mcy[kMaxL], Io[kMaxL];
+	real fx[kMaxL], fy[kMaxL], fn[kMaxL];       // per-link inertial force / moment and first moments / inertia about the root origin:
+	real mcx[kMaxL], mcy[kMaxL], Io[kMaxL];     // six contiguous arrays = the [6][kMaxL] right-hand matrix of the subtree-sum product
+	real sfs[3][kMaxL];                         // subtree sums of fx, fy, fn
 	// time-multiplexed: the bone vectors (kin_dyn_terms P2 -> P3) are dead when P4 writes the composite (subtree) sums
 	union {
 		struct { real bx[kMaxL], by[kMaxL], ux[kMaxL], uy[kMaxL], gx[kMaxL], gy[kMaxL]; };   // bone vectors, their velocity / centripetal terms
@@ -378,23 +379,63 @@ DTRL_HD inline void kin_dyn_terms(W& ws)
 	}
 	LANES_END
 	PROF_ADD(ws, kProfP3);
+	// P4: subtree sums S[j][q] = sum_k sub(j, k) V[k][q] of the six per-link quantities. This is a (0/1 matrix) x (matrix) product, and
+	// on the device it runs on the fp64 matrix pipe: two 16-row tiles x six k-steps of v_mfma_f64_16x16x4_f64 (12 instructions and
+	// 6 LDS reads per lane instead of 126 FMAs and 126 LDS reads). The MFMA accumulates in k order with fused multiply-adds, i.e. exactly
+	// the sequence of the lane loop below (verified bit for bit by tools/microbench/mfma_f64_check.hip), so the CPU builds agree.
+	// Operand layout (same check): A[i = lane % 16][k = lane / 16], B[k = lane / 16][n = lane % 16], D register r = D[4 r + lane / 16][lane % 16].
+#if defined(__HIP_DEVICE_COMPILE__)
+	{
+		typedef double v4d_t __attribute__((ext_vector_type(4)));
+		const int l = static_cast<int>(threadIdx.x), g = l >> 4, c = l & 15;
+		const int nL = ws.M.L;
+		const real* V = &ws.fx[0];                                              // [6][kMaxL]: fx, fy, fn, mcx, mcy, Io
+		const uint32_t m0 = (c < nL) ? ws.M.sub_mask[c < nL ? c : 0] : 0u;      // rows c and 16 + c of the mask matrix
+		const uint32_t m1 = (16 + c < nL) ? ws.M.sub_mask[16 + c < nL ? 16 + c : 0] : 0u;
+		v4d_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+		for (int s4 = 0; s4 < kMaxL / 4; ++s4) {
+			const int k = 4 * s4 + g;
+			const bool live = c < 6 && k < nL;                                   // never multiply an unwritten LDS slot, not even by zero
+			const real bv = V[live ? c * kMaxL + k : 0];
+			const real b = live ? bv : 0.0;
+			const real a0 = ((m0 >> k) & 1u) ? 1.0 : 0.0, a1 = ((m1 >> k) & 1u) ? 1.0 : 0.0;
+			acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc0, 0, 0, 0);
+			acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc1, 0, 0, 0);
+		}
+		if (c < 6) {
+			real* out = (c < 3) ? &ws.sfs[c][0] : (&ws.smx[0] + (c - 3) * kMaxL);   // smx, smy, sI are contiguous
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int j0 = 4 * r + g, j1 = 16 + 4 * r + g;
+				if (j0 < nL) out[j0] = acc0[r];
+				if (j1 < nL) out[j1] = acc1[r];
+			}
+		}
+	}
+	__syncthreads();
+#else
 	LANES_BEGIN
 	if (lane < ws.M.L) {
 		const int j = lane;
 		const uint32_t mask = ws.M.sub_mask[j];
-		const real m = ws.M.sub_mass[j];   // subtree mass is a model constant (summed on the host in the same order)
 		real mx = 0, my = 0, I = 0, sfx = 0, sfy = 0, sfn = 0;
 		const int nL = ws.M.L;
-		for (int k0 = 0; k0 < nL; k0 += 7) {   // chunks of 7 (3 chunks cover the 19- and 21-link characters) so the loads of a chunk pipeline
-#pragma unroll
-			for (int kk = 0; kk < 7; ++kk) {
-				const int k = (k0 + kk < nL) ? k0 + kk : 0;   // clamped to a live link: the 0|1 multiplier below needs finite operands (LDS beyond link L-1 is never written)
-				const real a1 = ws.mcx[k], a2 = ws.mcy[k], a3 = ws.Io[k], a4 = ws.fx[k], a5 = ws.fy[k], a6 = ws.fn[k];
-				const real on = (k0 + kk < nL && ((mask >> k) & 1u)) ? 1.0 : 0.0;
-				mx = fmadd(a1, on, mx); my = fmadd(a2, on, my); I = fmadd(a3, on, I); sfx = fmadd(a4, on, sfx); sfy = fmadd(a5, on, sfy); sfn = fmadd(a6, on, sfn);
-			}
+		for (int k = 0; k < nL; ++k) {
+			const real on = ((mask >> k) & 1u) ? 1.0 : 0.0;
+			sfx = fmadd(ws.fx[k], on, sfx); sfy = fmadd(ws.fy[k], on, sfy); sfn = fmadd(ws.fn[k], on, sfn);
+			mx = fmadd(ws.mcx[k], on, mx); my = fmadd(ws.mcy[k], on, my); I = fmadd(ws.Io[k], on, I);
 		}
-		ws.sm[j] = m; ws.smx[j] = mx; ws.smy[j] = my; ws.sI[j] = I;
+		ws.sfs[0][j] = sfx; ws.sfs[1][j] = sfy; ws.sfs[2][j] = sfn;
+		ws.smx[j] = mx; ws.smy[j] = my; ws.sI[j] = I;
+	}
+	LANES_END
+#endif
+	LANES_BEGIN
+	if (lane < ws.M.L) {
+		const int j = lane;
+		ws.sm[j] = ws.M.sub_mass[j];   // subtree mass is a model constant (summed on the host in the same order)
+		const real sfx = ws.sfs[0][j], sfy = ws.sfs[1][j], sfn = ws.sfs[2][j];
 		// generalised bias: translations see the total force (root subtree = everything), hinge l the subtree moment about p_l
 		const real bl = sfn - ws.px[j] * sfy + ws.py[j] * sfx;
 		ws.b[j + 2] = bl;

@@ -237,9 +237,17 @@ __device__ __forceinline__ real utsolve_regs(const real (&h)[D], real u)
 // (three named values, not an array: the struct must stay in VGPRs, never in scratch)
 static_assert((kMaxPts + kGroup - 1) / kGroup == 3, "written for 3 sample points per lane");
 struct ContactPts { PtVal p0, p1, p2; unsigned long long m0, m1, m2; };
+// lane id the optimiser cannot see through: address / index arithmetic derived from it is recomputed where it is used instead of being
+// hoisted out of the 4000-instruction physics loop as a loop invariant and spilled to scratch across it
+__device__ __forceinline__ int opaque_lane()
+{
+	int lane = static_cast<int>(threadIdx.x);
+	asm volatile("" : "+v"(lane));
+	return lane;
+}
 __device__ __forceinline__ ContactPts eval_points(const WSFast& ws, const DevModel& gm, const GroundRec& g)
 {
-	const int lane = static_cast<int>(threadIdx.x);
+	const int lane = opaque_lane();
 	const int npts = ws.M.L * kPtsPerLink;
 	ContactPts c;
 	PtVal z; z.x = 0; z.y = 0; z.depth = 0; z.nx = 0; z.ny = 0; z.active = 0;
@@ -384,7 +392,7 @@ __device__ __forceinline__ real wave_shr1(real v)
 constexpr int kPgsRegRows = 8;
 __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 {
-	const int lane = static_cast<int>(threadIdx.x);
+	const int lane = opaque_lane();
 	const int R = ws.R;
 	const bool mine = lane < R;
 	real w = mine ? ws.wv[lane] : 0.0, lam = 0.0;
