@@ -636,7 +636,7 @@ DTRL_HD inline void build_delassus(W& ws, real h)
 		for (int r = 0; r <= s; ++r) {
 			real a = 0;
 #pragma unroll 13
-			for (int i = 0; i < kMaxD; ++i) { const real zs = ws.Z[s][i], zr = ws.Z[r][i], di = ws.dinv[i]; if (i < D) a = fmadd(zs * zr, di, a); }
+			for (int i = 0; i < kMaxD; ++i) { const real zs = ws.Z[s][i], zr = ws.Z[r][i], di = ws.dinv[i]; if (i < D) a = fmadd(zs * di, zr, a); }   // (Z_s D^-1) Z_r^T: the left factor is scaled first, as the matrix-pipe form of the fast path does
 			ws.A[s][r] = a;
 		}
 		real jv;

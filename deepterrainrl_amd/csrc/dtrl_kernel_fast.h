@@ -329,9 +329,48 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 	const int lane = static_cast<int>(threadIdx.x);
 	const int R = ws.R;
 	const int n_ent = R * (R + 1) / 2;
-	real di[D];
+	if (R < 16) {
+		// up to 15 rows (all but 0.2 % of the substeps): [A | zz] = (Z D^-1) Z^T for the R constraint rows plus the free right-hand side as
+		// column R is ONE 16x16 tile of the fp64 matrix pipe, six k-steps of v_mfma_f64_16x16x4_f64 (k = DoF, padded to 24). The MFMA
+		// accumulates in k order with fused multiply-adds, i.e. the sequence of the scalar loops (tools/microbench/mfma_f64_check.hip).
+		// Operand layout: A[i = lane % 16][k = lane / 16], B[k = lane / 16][n = lane % 16], D register r = D[4 r + lane / 16][lane % 16].
+		typedef double v4d_t __attribute__((ext_vector_type(4)));
+		const int g = lane >> 4, c = lane & 15;
+		// row residual's velocity term, on the lanes that finish wv below (independent of the product: overlaps it)
+		real jv = 0;
+		if (lane < R) {
+			const int sw = lane;
+			if (ws.row_kind[sw] == 0) jv = ws.row_dx[sw] * ws.st.qd[ws.row_link[sw] + 2];
+			else {
+				const int l = ws.row_link[sw];
+				const real vx = ws.vpx[l] - ws.w[l] * (ws.row_y[sw] - ws.py[l]);
+				const real vy = ws.vpy[l] + ws.w[l] * (ws.row_x[sw] - ws.px[l]);
+				jv = ws.row_dx[sw] * vx + ws.row_dy[sw] * vy;
+			}
+		}
+		const int zrow = c <= R ? c : 0;                        // rows above R are never stored; any finite-or-not value will do
+		v4d_t acc = {0, 0, 0, 0};
 #pragma unroll
-	for (int i = 0; i < D; ++i) di[i] = bcast(dinv_mine, i);   // wave-uniform (SGPR pairs)
+		for (int s4 = 0; s4 < (D + 3) / 4; ++s4) {
+			const int k = 4 * s4 + g;
+			const bool live = k < D;
+			const real z = ws.Z[zrow][live ? k : 0], dk = ws.dinv[live ? k : 0];
+			const real b = live ? z : 0.0;
+			const real a = live ? z * dk : 0.0;
+			acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+		}
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int i = 4 * r + g;                               // D[i][c]
+			if (i < R && c <= i) ws.Apk[i * (i + 1) / 2 + c] = acc[r];
+			if (i < R && c == R) ws.wv[i] = acc[r];               // zz_i, finished below
+		}
+		__syncthreads();
+		if (lane < R) ws.wv[lane] = jv + h * ws.wv[lane] - ws.row_tgt[lane];
+		__syncthreads();
+		return;
+	}
+	const real* di = ws.dinv;   // general path (16+ rows, 0.2 % of the substeps): entry-parallel dot products
 	auto entry_rows = [](int e, int& s, int& r) {
 		s = static_cast<int>((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
 		while (s * (s + 1) / 2 > e) --s;
@@ -360,8 +399,8 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 		const real* zw = ws.Z[sw];
 		const real* z0 = ws.Z[R];
 		real a = 0, zz = 0;
-#pragma unroll
-		for (int i = 0; i < D; ++i) { a = fmadd(zs[i] * zr[i], di[i], a); zz = fmadd(zw[i] * di[i], z0[i], zz); }
+#pragma unroll 4
+		for (int i = 0; i < D; ++i) { a = fmadd(zs[i] * di[i], zr[i], a); zz = fmadd(zw[i] * di[i], z0[i], zz); }
 		if (has_e) ws.Apk[lane] = a;
 		if (has_w) ws.wv[lane] = jv + h * zz - ws.row_tgt[lane];
 	}
@@ -370,8 +409,8 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 		const real* zs = ws.Z[s];
 		const real* zr = ws.Z[r];
 		real a = 0;
-#pragma unroll
-		for (int i = 0; i < D; ++i) a = fmadd(zs[i] * zr[i], di[i], a);
+#pragma unroll 4
+		for (int i = 0; i < D; ++i) a = fmadd(zs[i] * di[i], zr[i], a);
 		ws.Apk[e] = a;
 	}
 	__syncthreads();
@@ -501,6 +540,7 @@ struct FastPath {
 				usolve_regs_n<D, 1>(hrow, z);
 				if (lane < D) ws.Z[r0][lane] = z[0];
 			}
+			if (lane < D) ws.dinv[lane] = dinv;   // the Delassus product reads 1/d per DoF from LDS
 			__syncthreads();
 			PROF_ADD(ws, kProfFsub);
 		}
