@@ -361,12 +361,18 @@ def test_env_groups_pipelined_run_frames_equals_stepwise(da, om, monkeypatch):
         monkeypatch.setenv("DTRL_GROUPS", str(groups))
         b = batch(da, "args/opt_args_train_mace.txt", 7, terrain_seed=31, rand_seed=4, exp_base_rate=0.3, exp_rate=0.5)
         b.SetPolicy(pol[1], *pol[2:])
-        if stepwise:
-            for _ in range(140):
-                b.Update()
-        else:
-            b.RunFrames(25); b.RunFrames(115)
-        rows, flags, ids = b.DrainTuples()
+        # the tuple ring is drained every 10 frames: once it is full, WHICH tuples are dropped depends on the arrival order across envs
+        # (i.e. on group timing), so an overflowing ring would make the comparison below meaningless
+        parts = []
+        for _ in range(14):
+            if stepwise:
+                for _ in range(10):
+                    b.Update()
+            else:
+                b.RunFrames(10)
+            parts.append(b.DrainTuples())
+        rows = np.concatenate([p[0] for p in parts]); flags = np.concatenate([p[1] for p in parts]); ids = np.concatenate([p[2] for p in parts])
+        assert max(len(p[2]) for p in parts) < 32
         o = np.lexsort((np.arange(len(ids)), ids))
         res.append((b.PoseVel(), b.EvalStats(), rows[o], flags[o], ids[o], b.SampleGround(3, np.linspace(-5, 25, 50))[0]))
     q0, st0 = res[0][0], res[0][1]
