@@ -33,7 +33,7 @@ TUPLE_FAIL, TUPLE_EXP_CRITIC, TUPLE_EXP_ACTOR = 1, 2, 4
 ABI_SYMBOLS = [
     "dtrl_create", "dtrl_destroy", "dtrl_reset", "dtrl_step", "dtrl_step_begin", "dtrl_step_end", "dtrl_step_updates", "dtrl_run_frames", "dtrl_set_policy",
     "dtrl_policy_num_params", "dtrl_build_output_offset_scale", "dtrl_load_scale_file", "dtrl_write_scale_file", "dtrl_set_explore", "dtrl_set_terrain_lerp", "dtrl_drain_tuples",
-    "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
+    "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
 ]
 
@@ -67,6 +67,8 @@ def _bind(path):
         getattr(L, name).argtypes = [vp, vp, C.c_int, vp, vp]
     L.dtrl_set_pose_vel.argtypes = [vp, vp, C.c_int, vp, vp]
     L.dtrl_get_link_states.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    L.dtrl_add_perturb.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
+    L.dtrl_apply_rand_force.argtypes = [vp, vp, C.c_int, C.c_uint64]
     L.dtrl_get_poli_state.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_flags.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_contacts.argtypes = [vp, vp, C.c_int, vp]
@@ -220,6 +222,20 @@ class BatchScenario:
         c = np.zeros((n, self.L, 2)); v = np.zeros((n, self.L, 2)); a = np.zeros((n, self.L))
         self._chk(self._lib.dtrl_get_link_states(self._h, _p(ids), n, _p(c), _p(v), _p(a)))
         return c, v, a
+
+    def AddPerturb(self, link, force, duration, local_pos=None, env_ids=None):
+        """cScenarioSimChar::AddPerturb with an ePerturbForce: world-frame force [n, 2] on body part link [n] for duration [n] seconds."""
+        ids, n = self._ids(env_ids)
+        link = np.ascontiguousarray(np.broadcast_to(np.asarray(link, np.int32), (n,)))
+        force = np.ascontiguousarray(np.broadcast_to(np.asarray(force, np.float64), (n, 2)))
+        duration = np.ascontiguousarray(np.broadcast_to(np.asarray(duration, np.float64), (n,)))
+        lp = None if local_pos is None else np.ascontiguousarray(np.broadcast_to(np.asarray(local_pos, np.float64), (n, 2)))
+        self._chk(self._lib.dtrl_add_perturb(self._h, _p(ids), n, _p(link), _p(lp) if lp is not None else None, _p(force), _p(duration)))
+
+    def ApplyRandForce(self, seed=0, env_ids=None):
+        """cScenarioSimChar::ApplyRandForce(): random body part / direction / magnitude / duration per env."""
+        ids, n = self._ids(env_ids)
+        self._chk(self._lib.dtrl_apply_rand_force(self._h, _p(ids), n, int(seed)))
 
     def SetPoseVel(self, q, qd, env_ids=None):
         ids, n = self._ids(env_ids)

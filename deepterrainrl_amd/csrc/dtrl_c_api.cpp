@@ -75,6 +75,13 @@ dtrl_status dtrl_get_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, doub
 	return DTRL_OK;
 }
 dtrl_status dtrl_set_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, const double* q, const double* qd) { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetPoseVel(env_ids, n, q, qd)); }
+dtrl_status dtrl_add_perturb(dtrl_batch* b, const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration)
+{
+	CHECK_B();
+	if (!link || !force || !duration) { b->eng.set_error("dtrl_add_perturb: link, force and duration are required"); return DTRL_ERR_ARG; }
+	return static_cast<dtrl_status>(b->eng.AddPerturb(env_ids, n, link, local_pos, force, duration));
+}
+dtrl_status dtrl_apply_rand_force(dtrl_batch* b, const int32_t* env_ids, int n, uint64_t seed) { CHECK_B(); return static_cast<dtrl_status>(b->eng.ApplyRandForce(env_ids, n, seed)); }
 dtrl_status dtrl_get_poli_state(dtrl_batch* b, const int32_t* env_ids, int n, double* s) { CHECK_B(); return static_cast<dtrl_status>(b->eng.GetPoliState(env_ids, n, s)); }
 
 dtrl_status dtrl_get_flags(dtrl_batch* b, const int32_t* env_ids, int n, uint32_t* bits)

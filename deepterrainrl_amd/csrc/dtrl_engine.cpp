@@ -12,6 +12,7 @@
 #include "dtrl_engine.h"
 #include "dtrl_topo.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstdio>
 #include "../../include/dtrl.h"
@@ -139,7 +140,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	if (!be_->H2D(buf_.gr, recs.data(), sizeof(GroundRec) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	std::vector<EnvState> st(n_);
 	std::memset(st.data(), 0, sizeof(EnvState) * n_);
-	for (int e = 0; e < n_; ++e) { st[e].do_init = 1; st[e].cmd_action = -1; }
+	for (int e = 0; e < n_; ++e) { st[e].do_init = 1; st[e].cmd_action = -1; st[e].pert_link = -1; }
 	if (!be_->H2D(buf_.st, st.data(), sizeof(EnvState) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	// cScenarioSimChar::Init on every env now (a 0-step launch), so getters and dtrl_set_pose_vel see / act on the initial state
 	// before the first step, as with the reference's Init()
@@ -464,6 +465,58 @@ int Engine::SetPoseVel(const int32_t* env_ids, int n, const double* q, const dou
 		if (!be_->H2D(&buf_.st[e], &st, sizeof(EnvState))) return Fail(DTRL_ERR_DEVICE, be_->error());
 	}
 	return DTRL_OK;
+}
+
+// cScenarioSimChar::AddPerturb -> cWorld::AddPerturb (scenarios/ScenarioSimChar.cpp:204-207): a world-frame force on a body part at a
+// body-local offset for `duration` seconds of simulated time. Planar characters: the in-plane components. One slot per env.
+int Engine::AddPerturb(const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration)
+{
+	be_->Sync();
+	const DevModel& m = cfg_.model;
+	EnvState st;
+	const int cnt = env_ids ? n : n_;
+	for (int i = 0; i < cnt; ++i) {
+		const int e = EnvIndex(env_ids, i);
+		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
+		const int l = link[i];
+		if (l < 0 || l >= m.L) return Fail(DTRL_ERR_ARG, "perturbation link out of range");
+		if (!(duration[i] >= 0)) return Fail(DTRL_ERR_ARG, "perturbation duration must be non-negative");
+		if (!be_->D2H(&st, &buf_.st[e], sizeof(EnvState))) return Fail(DTRL_ERR_DEVICE, be_->error());
+		// the body frame is the joint frame turned by the body's attach angle: store the offset in the joint frame (the kernel has cos/sin of that)
+		const double c = std::cos(m.body_theta[l]), sn = std::sin(m.body_theta[l]);
+		const double lx = local_pos ? local_pos[2 * i] : 0.0, ly = local_pos ? local_pos[2 * i + 1] : 0.0;
+		st.pert_link = l; st.pert_on = 0;
+		st.pert_lp[0] = c * lx - sn * ly; st.pert_lp[1] = sn * lx + c * ly;
+		st.pert_f[0] = force[2 * i]; st.pert_f[1] = force[2 * i + 1];
+		st.pert_torque = 0; st.pert_time = 0; st.pert_dur = duration[i];
+		if (!be_->H2D(&buf_.st[e], &st, sizeof(EnvState))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	}
+	return DTRL_OK;
+}
+
+// cScenarioSimChar::ApplyRandForce (scenarios/ScenarioSimChar.cpp:209-235): a random body part, a random 3-D direction scaled to a random
+// magnitude in [min_perturb, max_perturb] (the planar character keeps x, y), a random duration. The reference draws from its racy,
+// time-seeded global RNG; here the stream is a counter-based hash of (seed, global env id), so a run is reproducible.
+int Engine::ApplyRandForce(const int32_t* env_ids, int n, uint64_t seed)
+{
+	const DevModel& m = cfg_.model;
+	const int cnt = env_ids ? n : n_;
+	std::vector<int32_t> link(cnt); std::vector<double> f(2 * static_cast<size_t>(cnt)), dur(cnt);
+	for (int i = 0; i < cnt; ++i) {
+		const int e = EnvIndex(env_ids, i);
+		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
+		uint64_t ctr = 0;
+		const uint64_t key = rng_mix(seed ^ rng_mix(static_cast<uint64_t>(cfg_.run.env_id_base + e) + 0x5851F42D4C957F2DULL));
+		auto uni = [&]() { const uint64_t z = rng_mix(key + (ctr++) * 0xD1342543DE82EF95ULL); return static_cast<double>(z >> 11) * (1.0 / 9007199254740992.0); };
+		int part = static_cast<int>(uni() * m.L); if (part >= m.L) part = m.L - 1;        // every link of the shipped characters has a body
+		double d[3];
+		for (int k = 0; k < 3; ++k) { const double sgn = uni() < 0.5 ? -1.0 : 1.0; d[k] = sgn * uni(); }
+		double nrm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); if (nrm == 0) { d[0] = 1; nrm = 1; }
+		const double mag = cfg_.min_perturb + uni() * (cfg_.max_perturb - cfg_.min_perturb);
+		link[i] = part; f[2 * i] = mag * d[0] / nrm; f[2 * i + 1] = mag * d[1] / nrm;
+		dur[i] = cfg_.min_perturb_duration + uni() * (cfg_.max_perturb_duration - cfg_.min_perturb_duration);
+	}
+	return AddPerturb(env_ids, cnt, link.data(), nullptr, f.data(), dur.data());
 }
 
 int Engine::GetPoliState(const int32_t* env_ids, int n, double* s)

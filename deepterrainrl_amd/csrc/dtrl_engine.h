@@ -54,6 +54,8 @@ public:
 	int DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n);
 	int GetStates(const int32_t* env_ids, int n, std::vector<EnvState>& out);
 	int SetPoseVel(const int32_t* env_ids, int n, const double* q, const double* qd);
+	int AddPerturb(const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration);
+	int ApplyRandForce(const int32_t* env_ids, int n, uint64_t seed);
 	int GetPoliState(const int32_t* env_ids, int n, double* s);
 	int SampleGround(int env, int n, const double* x, double* h, int32_t* seg, int32_t* oi, int32_t* oj);
 	int EvalStats(double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets);

@@ -670,6 +670,8 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		}
 	}
 	args.ParseDouble("terrain_blend", cfg.terrain_blend);
+	args.ParseDouble("min_perturb", cfg.min_perturb); args.ParseDouble("max_perturb", cfg.max_perturb);
+	args.ParseDouble("min_pertrub_duration", cfg.min_perturb_duration); args.ParseDouble("max_perturb_duration", cfg.max_perturb_duration);
 	int seed = 0; if (args.ParseInt("terrain_seed", seed)) cfg.terrain_seed = static_cast<uint64_t>(seed);
 
 	// exploration (scenarios/ScenarioExp.cpp:16-45)

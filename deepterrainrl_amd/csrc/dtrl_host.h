@@ -106,6 +106,8 @@ struct ScenarioConfig {
 	double terrain_blend = 0;
 	uint64_t terrain_seed = 0;
 	int tuple_buffer_size = 16;
+	// cScenarioSimChar::ApplyRandForce ranges (scenarios/ScenarioSimChar.cpp:60-63, 88-91; the duration key's typo is the reference's)
+	double min_perturb = 50, max_perturb = 100, min_perturb_duration = 0.1, max_perturb_duration = 0.5;
 	std::string data_root;
 	std::string policy_net_file, policy_model_file;
 };

@@ -711,6 +711,36 @@ DTRL_HD inline void finish_substep(W& ws, real h)
 	LANES_END
 }
 
+// generalised force of the env's active perturbation on DoF d (tPerturb::ApplyForce -> cWorld::ApplyForce, sim/World.cpp:445-470: Bullet
+// accumulates the force at the body's COM plus the torque rel_pos x force evaluated when it is applied, once per cWorld::Update)
+template <class W>
+DTRL_HD_INLINE real perturb_gen_force(const W& ws, int d)
+{
+	const int l = ws.st.pert_link;
+	if (d == 0) return ws.st.pert_f[0];
+	if (d == 1) return ws.st.pert_f[1];
+	const int a = d - 2;
+	if (!((ws.M.sub_mask[a] >> l) & 1u)) return 0.0;
+	return (ws.cx[l] - ws.px[a]) * ws.st.pert_f[1] - (ws.cy[l] - ws.py[a]) * ws.st.pert_f[0] + ws.st.pert_torque;
+}
+// start of cWorld::Update: cPerturbManager::UpdatePerturbs (sim/PerturbManager.cpp:41-56) -- expired perturbations are dropped, the others
+// advance their clock and are applied for this env-step. Needs the kinematics of the current configuration (cs, sn)
+template <class W>
+DTRL_HD inline void perturb_begin_step(W& ws, real dt)
+{
+	LANES_BEGIN
+	if (lane == 0 && ws.st.pert_link >= 0) {
+		if (ws.st.pert_time >= ws.st.pert_dur) { ws.st.pert_link = -1; ws.st.pert_on = 0; }
+		else {
+			ws.st.pert_time += dt; ws.st.pert_on = 1;
+			const int l = ws.st.pert_link;
+			const real rx = ws.cs[l] * ws.st.pert_lp[0] - ws.sn[l] * ws.st.pert_lp[1], ry = ws.sn[l] * ws.st.pert_lp[0] + ws.cs[l] * ws.st.pert_lp[1];
+			ws.st.pert_torque = rx * ws.st.pert_f[1] - ry * ws.st.pert_f[0];
+		}
+	}
+	LANES_END
+}
+
 // one physics substep (stand-in for one Bullet internal step of sim/World.cpp:101-102)
 template <class W>
 DTRL_HD inline void substep_ref(W& ws, const DevModel& gm, const GroundRec& g, real h, bool kin_valid)
@@ -721,7 +751,7 @@ DTRL_HD inline void substep_ref(W& ws, const DevModel& gm, const GroundRec& g, r
 	{ PROF_T0(); detect_contacts(ws, gm, g); PROF_ADD(ws, kProfDetect); }
 	{ PROF_T0(); build_rows(ws, h);
 	LANES_BEGIN
-	if (lane < ws.M.D) ws.u[lane] = ws.st.tau[lane] - ws.b[lane];
+	if (lane < ws.M.D) { ws.u[lane] = ws.st.tau[lane] - ws.b[lane]; if (__builtin_expect(ws.st.pert_on != 0, 0)) ws.u[lane] += perturb_gen_force(ws, lane); }
 	if (lane == 0) ws.cost += 8 + ws.R;
 	LANES_END
 	PROF_ADD(ws, kProfRows); }
@@ -1539,6 +1569,7 @@ template <class Path, class W>
 DTRL_HD inline void env_step(W& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, const GroundRec& g, int env, real dt)
 {
 	const real h = dt / gm.num_sim_substeps;
+	if (__builtin_expect(ws.st.pert_link >= 0, 0)) perturb_begin_step(ws, dt);   // wave-uniform (LDS)
 	// UpdateWorld. The kinematics / composites / bias of the configuration at entry are already in the workspace (frame start, reset,
 	// or the post-step evaluation of the previous env-step), so the first substep does not recompute them
 	for (int s = 0; s < gm.num_sim_substeps; ++s) Path::substep(ws, gm, g, h, s == 0);
@@ -1598,6 +1629,7 @@ DTRL_HD inline void reset_env(W& ws, const DevModel& gm, const RunParams& rp, co
 		ws.st.fall_contact_counter = 0.1; ws.st.sum_fall_contact = 0;
 		ws.st.contact_bits = 0;
 		ws.st.time = 0;
+		ws.st.pert_link = -1; ws.st.pert_on = 0;   // cWorld::Reset clears the perturbation manager (sim/World.cpp:76-82)
 		// cScenarioSimChar::InitCharacterPos
 		if (gm.valid_init_pos_x) ws.st.q[0] = gm.init_pos_x;
 		ws.st.q[1] += sample_ground(g, ws.st.q[0], nullptr, nullptr, nullptr, nullptr);

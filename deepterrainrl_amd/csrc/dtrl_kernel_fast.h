@@ -510,7 +510,8 @@ struct FastPath {
 			const bool hinge = lane >= 2 && lane < D;
 			const real mypx = hinge ? ws.px[lane - 2] : 0.0, mypy = hinge ? ws.py[lane - 2] : 0.0;
 			const uint32_t mysub = hinge ? ws.M.sub_mask[lane - 2] : 0u;
-			const real rhs0 = (lane < D) ? (ws.st.tau[lane] - ws.b[lane]) : 0.0;
+			real rhs0 = (lane < D) ? (ws.st.tau[lane] - ws.b[lane]) : 0.0;
+			if (__builtin_expect(ws.st.pert_on != 0, 0)) { if (lane < D) rhs0 += perturb_gen_force(ws, lane); }
 			// J_r^T for row r (r < R), the free right-hand side for r == R
 			auto rhs_of = [&](int r) -> real {
 				if (r >= R) return rhs0;

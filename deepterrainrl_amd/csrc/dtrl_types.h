@@ -106,7 +106,12 @@ struct EnvState {
 	int32_t need_reset;      // set by the kernel at frame end (fall); host regenerates terrain, then sets do_reset
 	int32_t do_reset;        // consumed by the kernel at frame start
 	int32_t do_init;         // first launch: full cScenario::Init ordering
-	int32_t pad_[3];
+	// external perturbation (sim/Perturb.cpp, sim/PerturbManager.cpp; one slot per env, a new one replaces the old): a world-frame force
+	// on link pert_link at its COM plus the constant torque of its application offset, while pert_time < pert_dur
+	int32_t pert_link;       // -1 = none
+	int32_t pert_on;         // applied during the current env-step (set at the env-step's start)
+	int32_t pad_;
+	real pert_f[2], pert_lp[2], pert_torque, pert_time, pert_dur;   // pert_lp: application point relative to the COM, in the link's joint frame
 };
 
 struct GroundRec {

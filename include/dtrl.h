@@ -114,6 +114,16 @@ dtrl_status dtrl_drain_tuples(dtrl_batch* b, float* rows, uint32_t* flags, int32
 dtrl_status dtrl_get_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, double* q, double* qd);
 /* Replaces: cSimCharacter::SetPose / SetVel (sim/SimCharacter.cpp:665-683, 227-315). */
 dtrl_status dtrl_set_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, const double* q, const double* qd);
+
+/* Replaces: cScenarioSimChar::AddPerturb -> cWorld::AddPerturb (scenarios/ScenarioSimChar.cpp:204-207, sim/World.cpp:256-259) with a
+ * tPerturb of type ePerturbForce (sim/Perturb.cpp:52-79, sim/World.cpp:445-470): a world-frame force[n][2] on body part link[n] at the
+ * body-local offset local_pos[n][2] (NULL = the COM) for duration[n] seconds of simulated time, advanced and applied at the start of
+ * every env-step like cPerturbManager::UpdatePerturbs. One slot per env (a new perturbation replaces the old one); reset clears it. */
+dtrl_status dtrl_add_perturb(dtrl_batch* b, const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration);
+/* Replaces: cScenarioSimChar::ApplyRandForce() (scenarios/ScenarioSimChar.cpp:209-235; ranges -min_perturb= -max_perturb=
+ * -min_pertrub_duration= -max_perturb_duration= as the reference spells them): a random body part, direction, magnitude and duration per
+ * env. The reference draws from its time-seeded global RNG; here the draw is a function of (seed, global env id). */
+dtrl_status dtrl_apply_rand_force(dtrl_batch* b, const int32_t* env_ids, int n, uint64_t seed);
 /* Replaces: cNNController::RecordPoliState (sim/TerrainRLCharController.cpp:120-123). */
 dtrl_status dtrl_get_poli_state(dtrl_batch* b, const int32_t* env_ids, int n, double* s);
 /* fallen | stumbled<<1 | new_cycle<<2 | fsm_state<<8: cSimCharacter::HasFallen/HasStumbled, cCharController::IsNewCycle/GetState. */

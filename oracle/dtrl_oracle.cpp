@@ -74,6 +74,7 @@ void orc_set_pose_vel(void* p, const double* q, const double* qd)
 	for (int i = 0; i < e.D; ++i) { e.q[i] = q[i]; e.qd[i] = qd[i]; }
 	ForwardKin(e.M, e.q, e.qd, e.B);
 }
+void orc_add_perturb(void* p, int link, double lx, double ly, double fx, double fy, double dur) { static_cast<OrcHandle*>(p)->env.AddPerturb(link, lx, ly, fx, fy, dur); }
 void orc_get_tau(void* p, double* tau_ctrl, double* tau_applied)
 {
 	Env& e = static_cast<OrcHandle*>(p)->env;

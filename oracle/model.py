@@ -361,6 +361,7 @@ def lib():
         L.orc_dims.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 5
         L.orc_get_pose_vel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_set_pose_vel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_add_perturb.argtypes = [C.c_void_p, C.c_int] + [C.c_double] * 5
         L.orc_get_tau.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_get_contacts.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_get_flags.restype = C.c_uint32
@@ -429,6 +430,9 @@ class OracleEnv:
     def set_pose_vel(self, q, qd):
         q = np.ascontiguousarray(q, np.float64); qd = np.ascontiguousarray(qd, np.float64)
         self.L_.orc_set_pose_vel(self.h, _p(q), _p(qd))
+
+    def add_perturb(self, link, local_pos, force, duration):
+        self.L_.orc_add_perturb(self.h, int(link), float(local_pos[0]), float(local_pos[1]), float(force[0]), float(force[1]), float(duration))
 
     def tau(self):
         a = np.zeros(self.D); b = np.zeros(self.D)

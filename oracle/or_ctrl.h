@@ -280,6 +280,7 @@ struct Env {
 	void Reset()
 	{
 		time = 0;
+		pert.link = -1; pert.on = false;   // cWorld::Reset clears the perturbation manager
 		ResetCharacter();
 		ground.Clear();
 		ground.Update(-10 + -1.0, 10 + -1.0);
@@ -732,10 +733,26 @@ struct Env {
 	}
 
 	// ---- one iteration of the loop at scenarios/ScenarioSimChar.cpp:162-173 ---------------------------------
+	// cWorld::AddPerturb with one slot per env; local position in the body frame
+	Integrator::PerturbForce pert; double pert_lp[2] = {0, 0}, pert_time = 0, pert_dur = 0;
+	void AddPerturb(int link, double lx, double ly, double fx, double fy, double dur)
+	{
+		pert.link = link; pert.fx = fx; pert.fy = fy; pert.torque = 0; pert.on = false;
+		pert_lp[0] = lx; pert_lp[1] = ly; pert_time = 0; pert_dur = dur;
+	}
 	void EnvStep(double dt)
 	{
 		double h = dt / M.num_sim_substeps;
-		for (int s = 0; s < M.num_sim_substeps; ++s) integ.Substep(M, rbd, ground, h, q, qd, tau_applied);  // UpdateWorld
+		if (pert.link >= 0) {   // cPerturbManager::UpdatePerturbs at the start of cWorld::Update (sim/PerturbManager.cpp:41-56)
+			if (pert_time >= pert_dur) { pert.link = -1; pert.on = false; }
+			else {
+				pert_time += dt; pert.on = true;
+				const double c = std::cos(B.psi[pert.link]), sn = std::sin(B.psi[pert.link]);
+				const double rx = c * pert_lp[0] - sn * pert_lp[1], ry = sn * pert_lp[0] + c * pert_lp[1];
+				pert.torque = rx * pert.fy - ry * pert.fx;
+			}
+		}
+		for (int s = 0; s < M.num_sim_substeps; ++s) integ.Substep(M, rbd, ground, h, q, qd, tau_applied, &pert);  // UpdateWorld
 		ForwardKin(M, q, qd, B);
 		{   // cContactManager::Update at the post-step configuration
 			ContactPoint tmp[1];

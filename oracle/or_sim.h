@@ -131,7 +131,11 @@ struct Integrator {
 		}
 	}
 
-	void Substep(const OrcModel& M, RBDModel& rbd, const Ground& ground, double h, double* q, double* qd, const double* tau)
+	// external perturbation applied during the env-step (sim/Perturb.cpp:52-79, sim/World.cpp:445-470): Bullet accumulates the force at
+	// the body's COM plus the torque rel_pos x force evaluated when cWorld::Update applies it, and holds both over the substeps
+	struct PerturbForce { int link = -1; double fx = 0, fy = 0, torque = 0; bool on = false; };
+
+	void Substep(const OrcModel& M, RBDModel& rbd, const Ground& ground, double h, double* q, double* qd, const double* tau, const PerturbForce* pf = nullptr)
 	{
 		const int D = rbd.D;
 		rbd.Update(q, qd, /*fix_cj=*/true);
@@ -140,6 +144,15 @@ struct Integrator {
 		for (int i = 0; i < D; ++i) for (int k = 0; k < D; ++k) Hm[i * D + k] = rbd.H[i][k];
 		double rhs[ORC_MAXD], dv[ORC_MAXD], v[ORC_MAXD];
 		for (int i = 0; i < D; ++i) rhs[i] = tau[i] - rbd.C[i];
+		if (pf && pf->on) {
+			double jx[ORC_MAXD], jy[ORC_MAXD];
+			PointJacobian(M, B, pf->link, B.cx[pf->link], B.cy[pf->link], 1, 0, jx, D);
+			PointJacobian(M, B, pf->link, B.cx[pf->link], B.cy[pf->link], 0, 1, jy, D);
+			double add[ORC_MAXD];
+			for (int i = 0; i < D; ++i) add[i] = jx[i] * pf->fx + jy[i] * pf->fy;
+			for (int j = pf->link; j >= 0; j = M.parent[j]) add[j + 2] += pf->torque;
+			for (int i = 0; i < D; ++i) rhs[i] += add[i];
+		}
 		SolveLDLT(D, Hm, D, rhs, dv);
 		for (int i = 0; i < D; ++i) v[i] = qd[i] + h * dv[i];
 

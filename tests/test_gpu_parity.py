@@ -56,6 +56,11 @@ def test_shard_invariance_small(da, om):
     T.test_shard_invariance(da, om)
 
 
+def test_perturbation_force(da, om):
+    T.test_perturbation_force_vs_oracle(da, om)
+    T.test_apply_rand_force_is_seeded_and_bounded(da, om)
+
+
 def test_set_pose_reset(da, om):
     T.test_set_pose_vel_and_reset_roundtrip(da, om)
 

@@ -382,6 +382,47 @@ def test_env_groups_pipelined_run_frames_equals_stepwise(da, om, monkeypatch):
         assert np.array_equal(r[2], res[0][2]) and np.array_equal(r[3], res[0][3]) and np.array_equal(r[4], res[0][4]) and np.array_equal(r[5], res[0][5])
 
 
+def test_perturbation_force_vs_oracle(da, om):
+    """tPerturb (ePerturbForce) through cWorld::AddPerturb: a world-frame force on a body part at a body-local offset for a duration,
+    advanced at the start of every env-step and dropped when expired (sim/Perturb.cpp, sim/PerturbManager.cpp:41-56); reset clears it."""
+    m, _ = om.build_model("args/sim_dog_args.txt", REFDATA)
+    e = om.OracleEnv(m, terrain_seed=5); e0 = om.OracleEnv(m, terrain_seed=5)
+    b = batch(da, "args/sim_dog_args.txt", 2, terrain_seed=5)
+    b.StepUpdates(30); e.step(30); e0.step(30)
+    link, force, lp, dur = 5, (60.0, 45.0), (0.1, -0.05), 0.05          # torso, 30 env-steps of 1/600 s
+    b.AddPerturb(link, force, dur, local_pos=lp, env_ids=[1]); e.add_perturb(link, lp, force, dur)
+    for k in range(80):
+        b.StepUpdates(1); e.step(1); e0.step(1)
+        q, qd = b.PoseVel(); qo, qdo = e.pose_vel(); qu, _ = e0.pose_vel()
+        assert np.abs(q[1] - qo).max() < 1e-9 and np.abs(qd[1] - qdo).max() < 1e-7, k     # perturbed env follows the perturbed oracle
+        assert np.abs(q[0] - qu).max() < 1e-9                                              # the other env is untouched
+    assert np.abs(q[1] - qu).max() > 1e-3                                                  # and the push did something
+    # COM perturbation (local_pos omitted) on a leg, then a reset: the slot is cleared with the world
+    b.AddPerturb(19, (0.0, 80.0), 10.0, env_ids=[0]); e0.add_perturb(19, (0.0, 0.0), (0.0, 80.0), 10.0)
+    b.StepUpdates(10); e0.step(10)
+    assert np.abs(b.PoseVel()[0][0] - e0.pose_vel()[0]).max() < 1e-9
+    b.Reset(); e0.reset(); b.StepUpdates(20); e0.step(20)
+    assert np.abs(b.PoseVel()[0][0] - e0.pose_vel()[0]).max() < 1e-9
+    with pytest.raises(Exception):
+        b.AddPerturb(99, (1.0, 0.0), 1.0)
+
+
+def test_apply_rand_force_is_seeded_and_bounded(da, om):
+    """cScenarioSimChar::ApplyRandForce: per-env random pushes, reproducible given (seed, env id), different across envs and seeds."""
+    def run(seed, n=6):
+        b = batch(da, "args/sim_dog_args.txt", n, terrain_seed=2, min_perturb=200, max_perturb=300, min_pertrub_duration=0.05, max_perturb_duration=0.1)
+        b.StepUpdates(5)
+        if seed is not None:
+            b.ApplyRandForce(seed)
+        b.StepUpdates(40)
+        return b.PoseVel()[0]
+    base, a, a2, c = run(None), run(11), run(11), run(12)
+    assert np.array_equal(a, a2) and not np.array_equal(a, c)
+    d = np.abs(a - base).max(axis=1)
+    assert (d > 1e-5).all() and len(set(np.round(d, 9))) == len(d)          # every env was pushed, each differently
+    assert np.isfinite(a).all() and d.max() < 1.0                            # 200-300 N for <= 0.1 s moves a 34 kg dog by centimetres
+
+
 def test_set_pose_vel_and_reset_roundtrip(da, om):
     m, _ = om.build_model("args/sim_dog_args.txt", REFDATA)
     b = batch(da, "args/sim_dog_args.txt", 3, terrain_seed=1)
