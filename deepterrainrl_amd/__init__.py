@@ -33,7 +33,7 @@ TUPLE_FAIL, TUPLE_EXP_CRITIC, TUPLE_EXP_ACTOR = 1, 2, 4
 ABI_SYMBOLS = [
     "dtrl_create", "dtrl_destroy", "dtrl_reset", "dtrl_step", "dtrl_step_begin", "dtrl_step_end", "dtrl_step_updates", "dtrl_run_frames", "dtrl_set_policy",
     "dtrl_policy_num_params", "dtrl_build_output_offset_scale", "dtrl_load_scale_file", "dtrl_write_scale_file", "dtrl_set_explore", "dtrl_set_terrain_lerp", "dtrl_drain_tuples",
-    "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
+    "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_cycle_info", "dtrl_get_action_table", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
 ]
 
@@ -69,6 +69,8 @@ def _bind(path):
     L.dtrl_get_link_states.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.dtrl_add_perturb.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
     L.dtrl_apply_rand_force.argtypes = [vp, vp, C.c_int, C.c_uint64]
+    L.dtrl_get_cycle_info.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.dtrl_get_action_table.argtypes = [vp, C.POINTER(C.c_int), vp]
     L.dtrl_get_poli_state.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_flags.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_contacts.argtypes = [vp, vp, C.c_int, vp]
@@ -271,6 +273,21 @@ class BatchScenario:
         st = np.zeros(n, np.int32); ph = np.zeros(n); aid = np.zeros(n, np.int32); prm = np.zeros((n, self.P)); tg = np.zeros((n, self.L))
         self._chk(self._lib.dtrl_get_ctrl(self._h, _p(ids), n, _p(st), _p(ph), _p(aid), _p(prm), _p(tg)))
         return st, ph, aid, prm, tg
+
+    def CycleInfo(self, env_ids=None):
+        """Per env: cycle counter, reset counter, COM [n, 2] and simulated time at the start of the current cycle, optimisable params of the current action [n, A - 1]."""
+        ids, n = self._ids(env_ids)
+        nc = np.zeros(n, np.int64); nr = np.zeros(n, np.int64); com = np.zeros((n, 2)); t = np.zeros(n); prm = np.zeros((n, self.A - 1))
+        self._chk(self._lib.dtrl_get_cycle_info(self._h, _p(ids), n, _p(nc), _p(nr), _p(com), _p(t), _p(prm)))
+        return nc, nr, com, t, prm
+
+    def ActionTable(self):
+        """cTerrainRLCharController::BuildActionOptParams for every action: [n_actions, A - 1]."""
+        na = C.c_int(0)
+        self._chk(self._lib.dtrl_get_action_table(self._h, C.byref(na), None))
+        tab = np.zeros((na.value, self.A - 1))
+        self._chk(self._lib.dtrl_get_action_table(self._h, C.byref(na), _p(tab)))
+        return tab
 
     def SampleGround(self, env, xs):
         xs = np.ascontiguousarray(xs, np.float64); n = len(xs)

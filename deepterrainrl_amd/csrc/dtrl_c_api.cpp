@@ -166,6 +166,32 @@ dtrl_status dtrl_get_ctrl(dtrl_batch* b, const int32_t* env_ids, int n, int32_t*
 	}
 	return DTRL_OK;
 }
+dtrl_status dtrl_get_cycle_info(dtrl_batch* b, const int32_t* env_ids, int n, int64_t* num_cycles, int64_t* num_resets, double* cycle_start_com, double* cycle_start_time, double* opt_params)
+{
+	CHECK_B();
+	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
+	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
+	const dtrl::DevModel& m = b->eng.cfg().model;
+	for (int i = 0; i < n; ++i) {
+		if (num_cycles) num_cycles[i] = st[i].num_cycles;
+		if (num_resets) num_resets[i] = st[i].num_resets;
+		if (cycle_start_com) { cycle_start_com[2 * i] = st[i].prev_com[0]; cycle_start_com[2 * i + 1] = st[i].prev_com[1]; }
+		if (cycle_start_time) cycle_start_time[i] = st[i].time - st[i].curr_cycle_time;
+		if (opt_params) for (int k = 0; k < m.n_opt; ++k) opt_params[static_cast<size_t>(i) * m.n_opt + k] = st[i].params[m.opt_index[k]];
+	}
+	return DTRL_OK;
+}
+dtrl_status dtrl_get_action_table(dtrl_batch* b, int* n_actions, double* table)
+{
+	CHECK_B();
+	const dtrl::DevModel& m = b->eng.cfg().model;
+	if (n_actions) *n_actions = m.n_actions;
+	if (table) for (int a = 0; a < m.n_actions; ++a) {
+		const dtrl::real* p0 = m.ctrl_params[m.act_idx0[a]]; const dtrl::real* p1 = m.ctrl_params[m.act_idx1[a]]; const double bl = m.act_blend[a];
+		for (int k = 0; k < m.n_opt; ++k) { const int i = m.opt_index[k]; table[static_cast<size_t>(a) * m.n_opt + k] = (1 - bl) * p0[i] + bl * p1[i]; }
+	}
+	return DTRL_OK;
+}
 dtrl_status dtrl_sample_ground(dtrl_batch* b, int env, int n, const double* x, double* h, int32_t* seg, int32_t* i, int32_t* j)
 {
 	CHECK_B(); return static_cast<dtrl_status>(b->eng.SampleGround(env, n, x, h, seg, i, j));

@@ -61,6 +61,11 @@ def test_perturbation_force(da, om):
     T.test_apply_rand_force_is_seeded_and_bounded(da, om)
 
 
+def test_poli_eval_recorders(da, om, tmp_path):
+    T.test_poli_eval_recorders_frame_polling_equals_env_step_polling(da, om, tmp_path)
+    T.test_poli_eval_recorders_across_resets(da, om, tmp_path)
+
+
 def test_set_pose_reset(da, om):
     T.test_set_pose_vel_and_reset_roundtrip(da, om)
 

@@ -423,6 +423,73 @@ def test_apply_rand_force_is_seeded_and_bounded(da, om):
     assert np.isfinite(a).all() and d.max() < 1.0                            # 200-300 N for <= 0.1 s moves a 34 kg dog by centimetres
 
 
+def test_poli_eval_recorders_frame_polling_equals_env_step_polling(da, om, tmp_path):
+    """cScenarioPoliEval's per-cycle recorders (RecordAction / RecordVel / RecordActionIDState, scenarios/ScenarioPoliEval.cpp:234-404) written
+    by PoliEvalRecorder from frame-boundary polls must be what an observer sitting at every env-step would have written: the COM velocity between
+    cycle starts computed independently from link states and masses, the action of every valid cycle, in the reference's text formats."""
+    from deepterrainrl_amd.recorders import PoliEvalRecorder
+    m, _ = om.build_model("args/sim_dog_args.txt", REFDATA)
+    mass = np.array([m.body_mass[j] for j in range(m.L)])
+    # observer at env-step granularity
+    a = batch(da, "args/sim_dog_args.txt", 2, terrain_seed=5)
+    def com_x(bb):
+        c, _, _ = bb.LinkStates(); return (c[:, :, 0] * mass).sum(1) / mass.sum()
+    nc0 = a.CycleInfo()[0].copy(); prev_x = com_x(a); prev_t = np.zeros(2); expect = [[], []]
+    for k in range(900):
+        a.StepUpdates(1)
+        nc, _, com, t, prm = a.CycleInfo()
+        x = com_x(a)
+        for e in range(2):
+            if nc[e] != nc0[e]:
+                assert abs(com[e, 0] - x[e]) < 1e-9 and abs(t[e] - (k + 1) / 600.0) < 1e-9          # cycle-start COM / time = this instant
+                if nc0[e] >= 1:
+                    m_time = (k // 20 + 1) / 30.0            # the reference's mTime is advanced by the whole frame before its env-steps run
+                    expect[e].append(((x[e] - prev_x[e]) / (m_time - prev_t[e]), int(a.Ctrl()[2][e]), prm[e].copy()))
+                    prev_x[e] = x[e]; prev_t[e] = m_time
+                nc0[e] = nc[e]
+    assert a.EvalStats()["resets"] == 0 and min(len(x) for x in expect) >= 3
+    # the recorder, polled once per outer frame
+    b = batch(da, "args/sim_dog_args.txt", 2, terrain_seed=5)
+    rec = PoliEvalRecorder(b, [0, 1], action_file=str(tmp_path / "act_{env}.txt"), vel_file=str(tmp_path / "vel_{env}.txt"), action_id_state_file=str(tmp_path / "ids_{env}.txt"))
+    for _ in range(45):
+        b.Update(); rec.Poll()
+    tab = b.ActionTable()
+    for e in range(2):
+        vel = [float(l) for l in open(tmp_path / ("vel_%d.txt" % e))]
+        act = open(tmp_path / ("act_%d.txt" % e)).read().splitlines()
+        ids = open(tmp_path / ("ids_%d.txt" % e)).read().splitlines()
+        assert len(vel) == len(expect[e]) == len(act) - len(tab) == len(ids)
+        assert np.allclose(vel, [v for v, _, _ in expect[e]], atol=1e-6, rtol=0)                      # "%f" keeps 6 decimals
+        for a_id, row in enumerate(tab):                                                               # InitActionRecord header
+            assert act[a_id] == "%i" % a_id + "".join(", %.5f" % v for v in row)
+        for line, (_, aid, prm) in zip(act[len(tab):], expect[e]):
+            f = line.split(",\t")
+            assert int(f[0]) == aid and len(f) == 1 + b.A - 1 and np.allclose([float(v) for v in f[1:]], prm, atol=1e-6)
+        for line, (_, aid, _) in zip(ids, expect[e]):
+            f = line.split(",\t"); assert int(f[0]) == aid and len(f) == 1 + b.S
+    assert rec.lines == sum(len(x) for x in expect)
+
+
+def test_poli_eval_recorders_across_resets(da, om, tmp_path):
+    """Falls and resets: the cycle counter survives them (mCycleCount is only cleared by Init/Clear), the velocity span restarts at the reset."""
+    from deepterrainrl_amd.recorders import PoliEvalRecorder
+    pol = dog_policy(om)
+    b = batch(da, "args/dog_slopes_mixed_args.txt", 4, terrain_seed=3, rand_seed=2)
+    b.SetPolicy(pol[1], *pol[2:])
+    rec = PoliEvalRecorder(b, np.arange(4), action_file=str(tmp_path / "a{env}.txt"), vel_file=str(tmp_path / "v{env}.txt"), action_id_state_file=str(tmp_path / "s{env}.txt"))
+    for _ in range(150):
+        b.Update(); rec.Poll()
+    nc, nr, _, _, _ = b.CycleInfo()
+    assert nr.sum() >= 2 and (nc >= 3).all() and rec.lines + rec.lost == (nc - 1).sum()
+    n_tab = len(b.ActionTable())
+    for e in range(4):
+        vel = [float(l) for l in open(tmp_path / ("v%d.txt" % e))]
+        assert len(vel) == len(open(tmp_path / ("a%d.txt" % e)).read().splitlines()) - n_tab and nc[e] - 1 - rec.lost <= len(vel) <= nc[e] - 1
+        assert np.isfinite(vel).all() and np.abs(vel).max() < 50
+        first = open(tmp_path / ("s%d.txt" % e)).readline().split(",\t")
+        assert len(first) == 1 + b.S and 0 <= int(first[0]) < n_tab
+
+
 def test_set_pose_vel_and_reset_roundtrip(da, om):
     m, _ = om.build_model("args/sim_dog_args.txt", REFDATA)
     b = batch(da, "args/sim_dog_args.txt", 3, terrain_seed=1)
