@@ -130,7 +130,7 @@ struct WSBase {
 	real b[kMaxD];
 	real u[kMaxD];
 	// constraint rows
-	int32_t R, n_pts_active;
+	int32_t R, n_pts_active;   // n_pts_active (fast path): row count of the list built by the post-step contact pass for the next substep, -1 = none
 	int32_t row_kind[kMaxRows], row_link[kMaxRows];
 	real row_x[kMaxRows], row_y[kMaxRows], row_dx[kMaxRows], row_dy[kMaxRows], row_tgt[kMaxRows];
 	real wv[kMaxRows], lam[kMaxRows], rinv[kMaxRows];
@@ -1244,7 +1244,7 @@ DTRL_HD inline void pd_solve_ref(W& ws, real dt)
 struct RefPath {
 	template <class W> static DTRL_HD void substep(W& ws, const DevModel& gm, const GroundRec& g, real h, bool kin_valid) { substep_ref(ws, gm, g, h, kin_valid); }
 	template <class W> static DTRL_HD void pd_solve(W& ws, real dt) { pd_solve_ref(ws, dt); }
-	template <class W> static DTRL_HD void contacts(W& ws, const DevModel& gm, const GroundRec& g) { detect_contacts(ws, gm, g); }
+	template <class W> static DTRL_HD void contacts(W& ws, const DevModel& gm, const GroundRec& g, real) { detect_contacts(ws, gm, g); }
 };
 
 // 4x4 ridge solve of the contact-basis least squares (partial-pivot elimination), shared by both characters
@@ -1574,7 +1574,7 @@ DTRL_HD inline void env_step(W& ws, const DevModel& gm, const RunParams& rp, con
 	// or the post-step evaluation of the previous env-step), so the first substep does not recompute them
 	for (int s = 0; s < gm.num_sim_substeps; ++s) Path::substep(ws, gm, g, h, s == 0);
 	kin_dyn_terms(ws);                                                      // post-step kinematics: controller's RBD terms AND the next substep's
-	Path::contacts(ws, gm, g);                                                  // cContactManager::Update
+	Path::contacts(ws, gm, g, h);                                               // cContactManager::Update
 	// UpdateGround is host-side at frame boundaries (the 1 m look-ahead margin makes that equivalent; DESIGN.md "Ground")
 	{ PROF_T0(); controller_update<Path>(ws, gm, rp, buf, g, env, dt); PROF_ADD(ws, kProfCtrl); }   // UpdateCharacter
 	LANES_BEGIN
@@ -1700,7 +1700,7 @@ DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, co
 #endif
 	load_hot_model(ws, gm);
 	LANES_BEGIN
-	if (lane == 0) ws.cost = 0;
+	if (lane == 0) { ws.cost = 0; ws.n_pts_active = -1; }
 	LANES_END
 	{
 		const uint64_t* src = reinterpret_cast<const uint64_t*>(&buf.st[env]);

@@ -497,7 +497,13 @@ struct FastPath {
 		{ PROF_T0(); mass_row<D>(ws, hrow); PROF_ADD(ws, kProfMass); }
 		real dinv;
 		{ PROF_T0(); dinv = factorize_regs<Topo>(ws, hrow); PROF_ADD(ws, kProfFact); }
-		{
+		// the post-step contact pass of the previous env-step (contacts() below) ran at this very configuration and left its constraint
+		// row list in LDS: the first substep of an env-step takes it over instead of sampling the heightfield again
+		const int rows_ready = kin_valid ? ws.n_pts_active : -1;   // wave-uniform
+		if (rows_ready >= 0) {
+			if (lane == 0) { ws.R = rows_ready; ws.n_pts_active = -1; }
+			__syncthreads();
+		} else {
 			ContactPts cp;
 			{ PROF_T0(); cp = eval_points(ws, gm, g); contact_bits_fast(ws, cp.m0, cp.m1, cp.m2); PROF_ADD(ws, kProfDetect); }
 			{ PROF_T0(); build_rows_fast(ws, cp, h); PROF_ADD(ws, kProfRows); }
@@ -584,7 +590,16 @@ struct FastPath {
 		if (lane == 0) ws.R = 0;
 		__syncthreads();
 	}
-	static __device__ void contacts(WSFast& ws, const DevModel& gm, const GroundRec& g) { detect_contacts_fast(ws, gm, g); }
+	// cContactManager::Update at the post-step configuration: the controller needs the per-link flags; the same pass builds the row list of
+	// the next env-step's first substep (same q, same heightfield window within a launch)
+	static __device__ void contacts(WSFast& ws, const DevModel& gm, const GroundRec& g, real h)
+	{
+		const ContactPts cp = eval_points(ws, gm, g);
+		contact_bits_fast(ws, cp.m0, cp.m1, cp.m2);
+		build_rows_fast(ws, cp, h);
+		if (threadIdx.x == 0) ws.n_pts_active = ws.R;
+		__syncthreads();
+	}
 };
 
 }  // namespace dtrl
