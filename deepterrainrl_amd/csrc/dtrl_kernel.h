@@ -1100,7 +1100,7 @@ DTRL_HD inline void nn_eval(W& ws, const DevBuffers& buf, int env)
 	PROF_ADD_SINCE(ws, kProfNNRest, prof_rest_t0);
 	PROF_COUNT(ws, kProfNNEvals);
 	LANES_BEGIN
-	if (lane == 0) ws.cost += 280;
+	(void)0;   // the forward's cost enters the work estimate as a PREDICTION for the next frame (env_frame), not as history
 	LANES_END
 }
 
@@ -1720,7 +1720,13 @@ DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, co
 		const uint64_t* src = reinterpret_cast<const uint64_t*>(&ws.st);
 		LANES_BEGIN
 		for (int i = lane; i < static_cast<int>(sizeof(EnvState) / 8); i += kGroup) dst[i] = src[i];
-		if (lane == 0) { buf.status[env].root_x = ws.st.q[0]; buf.status[env].need_reset = ws.st.need_reset; buf.status[env].cost = ws.cost; }
+		if (lane == 0) { buf.status[env].root_x = ws.st.q[0]; buf.status[env].need_reset = ws.st.need_reset; 
+			// work estimate for the NEXT frame (the host launches the costliest envs first): the constraint-row part is persistent (a stumbling
+			// character stays expensive), a policy forward is not -- it is predicted from the gait clock: the running cycle will reach the
+			// length of the previous one within the next frame (one forward ~ 400 row-substep units, tools/gpu_sections.py)
+			const real frame_t = n_steps * dt;
+			const bool forward_due = gm.has_net != 0 && (ws.st.first_cycle != 0 || ws.st.curr_cycle_time + frame_t >= 0.9 * ws.st.prev_cycle_time);
+			buf.status[env].cost = ws.cost + (forward_due ? 400 : 0); }
 		LANES_END
 	}
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DTRL_PROFILE)
