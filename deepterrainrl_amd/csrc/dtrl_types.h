@@ -126,7 +126,7 @@ struct GroundRec {
 struct EnvStatus {
 	double root_x;
 	int32_t need_reset;
-	int32_t cost;   // work estimate of the env's last frame: sum over substeps of (8 + constraint rows) + 280 per policy forward
+	int32_t cost;   // work estimate for the env's next frame: sum over the last frame's substeps of (8 + constraint rows) + 400 if a policy forward is due
 };
 
 // MACE network family (data/policies/*/nets/*_mace3_deploy.prototxt)
