@@ -32,7 +32,7 @@ Engine::~Engine()
 	if (be_) {
 		be_->Sync();
 		for (void* p : allocs_) be_->Free(p);
-		be_->FreeHostStaging(pin_recs_); be_->FreeHostStaging(pin_order_); be_->FreeHostStaging(pin_ids_);
+		be_->FreeHostStaging(pin_recs_); be_->FreeHostStaging(pin_order_); be_->FreeHostStaging(pin_ids_); be_->FreeHostStaging(status_);
 		delete be_;
 	}
 }
@@ -126,7 +126,8 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 
 	// per-env grounds: cGroundVar2D seeded per env (terrain_seed + global env id) so a trajectory is shard-invariant
 	grounds_.resize(n_);
-	status_.resize(n_);
+	status_ = static_cast<EnvStatus*>(be_->HostStaging(sizeof(EnvStatus) * n_));
+	if (!status_) return Fail(DTRL_ERR_DEVICE, "host staging allocation failed: " + be_->error());
 	double params[kNumTerrainParams];
 	LerpTerrainParams(cfg_, cfg_.terrain_blend, params);
 	std::vector<GroundRec> recs(n_);
@@ -190,7 +191,7 @@ int Engine::HostFrameWork(int group)
 	struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
 	// the status read-back synchronises the group's stream: its frame kernel and every upload queued during its previous frame
 	// have completed, so its slice of the staging arena can be reused from the start
-	if (!be_->D2H(status_.data() + e0, buf_.status + e0, sizeof(EnvStatus) * grp.n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!be_->D2H(status_ + e0, buf_.status + e0, sizeof(EnvStatus) * grp.n)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	int used = 0;
 	reset_ids_.clear();
 	auto upload = [&](int e) {

@@ -93,7 +93,7 @@ private:
 	DevBuffers buf_{};
 	std::vector<void*> allocs_;
 	std::vector<GroundWindow> grounds_;
-	std::vector<EnvStatus> status_;
+	EnvStatus* status_ = nullptr;   // page-locked: the per-frame read-back lands here without a staging copy
 	GroundRec tmp_rec_;
 	std::vector<double> in_off_, in_scale_, out_off_, out_scale_;   // host copies of the policy normalisers (identity until set)
 	int UploadNormalizers();
