@@ -12,6 +12,7 @@
 #include "dtrl_engine.h"
 #include "dtrl_topo.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -171,13 +172,24 @@ int Engine::ApplyResets(const std::vector<int32_t>& ids, int group)
 	return DTRL_OK;
 }
 
+// DTRL_HOST_TIMING=1: print where the frame-boundary host work goes when the engine is destroyed (diagnosis only)
+namespace {
+struct HostTiming {
+	bool on = std::getenv("DTRL_HOST_TIMING") != nullptr;
+	double t_sync = 0, t_loop = 0, t_sort = 0, t_reset = 0, t_launch = 0; long n = 0, regen = 0;
+	~HostTiming() { if (on && n) std::fprintf(stderr, "[dtrl host] per group-frame: status read-back %.1f us, env loop %.1f us (%.2f regen), order %.1f us, resets %.1f us, launch %.1f us (n=%ld)\n", 1e6 * t_sync / n, 1e6 * t_loop / n, double(regen) / n, 1e6 * t_sort / n, 1e6 * t_reset / n, 1e6 * t_launch / n, n); }
+} g_ht;
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}
 int Engine::LaunchGroup(int group, int n_steps, double dt_step, bool frame_end)
 {
 	const Group& g = groups_[group];
 	be_->SelectStream(group);
 	DevBuffers b = buf_;
 	b.env_list = d_order_ + g.e0;   // the group's launch order (global env ids), costliest first
+	const double lt0 = g_ht.on ? now_s() : 0;
 	bool ok = be_->Launch(d_model_, cfg_.run, b, g.n, n_steps, dt_step, frame_end);
+	if (g_ht.on) g_ht.t_launch += now_s() - lt0;
 	be_->SelectStream(0);
 	return ok ? DTRL_OK : Fail(DTRL_ERR_DEVICE, be_->error());
 }
@@ -185,6 +197,7 @@ int Engine::LaunchGroup(int group, int n_steps, double dt_step, bool frame_end)
 // frame-boundary host work of one env group, on the group's stream
 int Engine::HostFrameWork(int group)
 {
+	const double ht0 = g_ht.on ? now_s() : 0;
 	const Group& grp = groups_[group];
 	const int e0 = grp.e0, e1 = grp.e0 + grp.n;
 	be_->SelectStream(group);
@@ -192,6 +205,7 @@ int Engine::HostFrameWork(int group)
 	// the status read-back synchronises the group's stream: its frame kernel and every upload queued during its previous frame
 	// have completed, so its slice of the staging arena can be reused from the start
 	if (!be_->D2H(status_ + e0, buf_.status + e0, sizeof(EnvStatus) * grp.n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	const double ht1 = g_ht.on ? now_s() : 0;
 	int used = 0;
 	reset_ids_.clear();
 	auto upload = [&](int e) {
@@ -213,6 +227,7 @@ int Engine::HostFrameWork(int group)
 			if (!upload(e)) return DTRL_ERR_CAPACITY;
 		}
 	}
+	const double ht2 = g_ht.on ? now_s() : 0;
 	// longest-processing-time-first: a launch is as long as its slowest wavefront (a stumbling character with ~20 constraint
 	// rows per substep costs 3x a running one), so the envs that were costliest last frame are dispatched first.
 	// Counting sort on cost / 16 (stable, O(n)).
@@ -223,7 +238,10 @@ int Engine::HostFrameWork(int group)
 	for (int k = 0; k < kBuckets; ++k) bucket_[k + 1] += bucket_[k];
 	for (int e = e0; e < e1; ++e) pin_order_[e0 + bucket_[key(e)]++] = e;
 	if (!be_->H2DAsync(d_order_ + e0, pin_order_ + e0, sizeof(int32_t) * grp.n)) return Fail(DTRL_ERR_DEVICE, be_->error());
-	return ApplyResets(reset_ids_, group);
+	const double ht3 = g_ht.on ? now_s() : 0;
+	const int rc = ApplyResets(reset_ids_, group);
+	if (g_ht.on) { const double ht4 = now_s(); g_ht.t_sync += ht1 - ht0; g_ht.t_loop += ht2 - ht1; g_ht.t_sort += ht3 - ht2; g_ht.t_reset += ht4 - ht3; g_ht.regen += used; ++g_ht.n; }
+	return rc;
 }
 
 int Engine::StepBegin(double dt)
