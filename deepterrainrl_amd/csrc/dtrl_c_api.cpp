@@ -45,7 +45,7 @@ dtrl_status dtrl_set_policy(dtrl_batch* b, const float* w, size_t n, const doubl
 dtrl_status dtrl_policy_num_params(const dtrl_batch* b, size_t* n)
 {
 	CHECK_B(); if (!b->eng.cfg().has_policy_net) { *n = 0; return DTRL_OK; }
-	*n = static_cast<size_t>(b->eng.cfg().net.num_params); return DTRL_OK;
+	*n = static_cast<size_t>(b->eng.cfg().user_num_params); return DTRL_OK;
 }
 dtrl_status dtrl_build_output_offset_scale(const dtrl_batch* b, double* out_off, double* out_scale)
 {
@@ -206,8 +206,8 @@ dtrl_status dtrl_dims(const dtrl_batch* b, int* L, int* D, int* S, int* A, int* 
 	if (S) *S = b->eng.S();
 	if (A) *A = b->eng.A();
 	if (P) *P = c.model.P;
-	if (nn_out) *nn_out = c.has_policy_net ? c.net.out_size : 0;
-	if (num_frags) *num_frags = c.has_policy_net ? c.net.n_frags : 0;
+	if (nn_out) *nn_out = c.has_policy_net ? c.user_out_size : 0;
+	if (num_frags) *num_frags = (c.has_policy_net && !c.actor_only) ? c.net.n_frags : 0;
 	if (frag_size) *frag_size = c.model.n_opt;
 	return DTRL_OK;
 }

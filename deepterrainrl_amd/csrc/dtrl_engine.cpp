@@ -65,7 +65,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	n_ = num_envs;
 	const DevModel& m = cfg_.model;
 	S_ = kNumGroundSamples + (2 * m.L - 1) + 2 * m.L;   // sim/TerrainRLCharController.cpp:308-342
-	A_ = 1 + m.n_opt;                                   // sim/BaseControllerMACE.cpp:28-31
+	A_ = (m.ctrl_type == 2) ? m.n_opt : 1 + m.n_opt;    // sim/BaseControllerMACE.cpp:28-31; sim/BaseControllerCacla.cpp:13-16 (the parameters alone)
 	W_ = 1 + 2 * S_ + A_;                               // learning/MACETrainer.cpp:373-376
 
 	be_ = MakeBackend();
@@ -330,8 +330,19 @@ int Engine::SetPolicy(const float* w, size_t n, const double* io, const double* 
 {
 	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
 	const NetDesc& d = cfg_.net;
-	if (n != static_cast<size_t>(d.num_params)) return Fail(DTRL_ERR_ARG, "weight count does not match the deploy prototxt");
+	if (n != static_cast<size_t>(cfg_.user_num_params)) return Fail(DTRL_ERR_ARG, "weight count does not match the deploy prototxt");
 	be_->Sync();
+	// CACLA actor: insert the all-zero critic head (val_ip0, val_ip1) behind the trunk and a neutral critic slot in front of the output
+	// normalisers, so that the device sees a one-fragment MACE net; the boundary keeps the actor's blob order and sizes
+	std::vector<float> w_pad; std::vector<double> oo_pad, os_pad;
+	if (cfg_.actor_only) {
+		const size_t head = static_cast<size_t>(d.fc_head) * d.fc_trunk + d.fc_head + d.fc_head + 1;
+		const size_t tail = static_cast<size_t>(d.fc_head) * d.fc_trunk + d.fc_head + static_cast<size_t>(d.frag_size) * d.fc_head + d.frag_size;   // ip2, output
+		w_pad.assign(w, w + (n - tail)); w_pad.insert(w_pad.end(), head, 0.0f); w_pad.insert(w_pad.end(), w + (n - tail), w + n);
+		w = w_pad.data(); n = w_pad.size();
+		if (oo) { oo_pad.assign(1, 0.0); oo_pad.insert(oo_pad.end(), oo, oo + d.frag_size); oo = oo_pad.data(); }
+		if (os) { os_pad.assign(1, 1.0); os_pad.insert(os_pad.end(), os, os + d.frag_size); os = os_pad.data(); }
+	}
 	// device layout (dtrl_kernel.h conv_layer/fc_layer): conv blobs [cout][cin][k] -> [cin][k][cout]; InnerProduct blobs
 	// [nout][nin] -> [ceil(nin/4)][nout][4] (zero padded); biases unchanged; same blob order.
 	std::vector<float> dev_w(static_cast<size_t>(DevNumParams(d)), 0.0f);
@@ -383,6 +394,7 @@ int Engine::UploadNormalizers()
 // cNeuralNet::LoadScale, learning/NeuralNet.cpp:137-215
 int Engine::LoadScaleFile(const char* path)
 {
+	if (cfg_.actor_only) return Fail(DTRL_ERR_ARG, "scale files of the CACLA actor are not handled by the engine yet: pass the normalisers to dtrl_set_policy");
 	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
 	if (!path) return Fail(DTRL_ERR_ARG, "null path");
 	const NetDesc& d = cfg_.net;
@@ -409,6 +421,7 @@ int Engine::LoadScaleFile(const char* path)
 // cNeuralNet::WriteOffsetScale, learning/NeuralNet.cpp:1182-1205 (cJsonUtil::BuildVectorJson: std::to_string per element)
 int Engine::WriteScaleFile(const char* path)
 {
+	if (cfg_.actor_only) return Fail(DTRL_ERR_ARG, "scale files of the CACLA actor are not handled by the engine yet: pass the normalisers to dtrl_set_policy");
 	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
 	const NetDesc& d = cfg_.net;
 	if (in_off_.empty()) { in_off_.assign(d.in_size, 0.0); in_scale_.assign(d.in_size, 1.0); out_off_.assign(d.out_size, 0.0); out_scale_.assign(d.out_size, 1.0); }

@@ -420,7 +420,7 @@ const int kRaptorOptMask[37] = {0, 1, 1, 0, 0, 1, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 
 const int kRaptorCol[19] = {2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 4, 4, 4, 4, 4, 4, 4, 4};
 }  // namespace
 
-bool ParseDeployPrototxt(const std::string& path, NetDesc& d, std::string& err)
+bool ParseDeployPrototxt(const std::string& path, NetDesc& d, std::string& err, bool* actor_only)
 {
 	std::ifstream f(path);
 	if (!f.is_open()) { err = "cannot open " + path; return false; }
@@ -456,11 +456,15 @@ bool ParseDeployPrototxt(const std::string& path, NetDesc& d, std::string& err)
 		else if (l.type == "Convolution") { if (nconv < 3) { d.conv_ch[nconv] = l.num_output; d.conv_k[nconv] = l.kernel_w; } ++nconv; }
 		else if (l.type == "InnerProduct") ips[l.name] = l.num_output;
 	}
-	if (d.n_terrain < 0 || nconv != 3 || !ips.count("terr_ip0") || !ips.count("ip0") || !ips.count("val_ip0") || !ips.count("val_ip1") || !ips.count("a0_ip1")) {
-		err = path + ": not a MACE (slice/3 conv/terr_ip0/ip0/val/a*) deploy net"; return false;
+	// the CACLA actor (data/policies/dog/nets/dog_actor_deploy.prototxt): same trunk, ONE head ip1 -> ip2 -> output and no critic outputs
+	const bool actor = d.n_terrain >= 0 && nconv == 3 && ips.count("terr_ip0") && ips.count("ip1") && ips.count("ip2") && ips.count("output") && !ips.count("ip0");
+	if (actor_only) *actor_only = actor;
+	if (!actor && (d.n_terrain < 0 || nconv != 3 || !ips.count("terr_ip0") || !ips.count("ip0") || !ips.count("val_ip0") || !ips.count("val_ip1") || !ips.count("a0_ip1"))) {
+		err = path + ": not a MACE (slice/3 conv/terr_ip0/ip0/val/a*) or actor (slice/3 conv/terr_ip0/ip1/ip2/output) deploy net"; return false;
 	}
 	d.n_char = dims.back() - d.n_terrain;
-	d.fc_terr = ips["terr_ip0"]; d.fc_trunk = ips["ip0"]; d.fc_head = ips["val_ip0"]; d.n_frags = ips["val_ip1"]; d.frag_size = ips["a0_ip1"];
+	if (actor) { d.fc_terr = ips["terr_ip0"]; d.fc_trunk = ips["ip1"]; d.fc_head = ips["ip2"]; d.n_frags = 1; d.frag_size = ips["output"]; }
+	else { d.fc_terr = ips["terr_ip0"]; d.fc_trunk = ips["ip0"]; d.fc_head = ips["val_ip0"]; d.n_frags = ips["val_ip1"]; d.frag_size = ips["a0_ip1"]; }
 	if (d.n_frags > kMaxFrags) { err = "too many actor fragments"; return false; }
 	for (int l = 0; l < 3; ++l) if (d.conv_ch[l] % 16 != 0 || d.conv_ch[l] > 32 || d.conv_k[l] > 8 || d.conv_ch[l] * d.conv_k[l] > 128) { err = path + ": conv layer outside the supported family (channels 16 or 32, kernel <= 8, channels*kernel <= 128)"; return false; }
 	d.in_size = d.n_terrain + d.n_char; d.out_size = d.n_frags + d.n_frags * d.frag_size;
@@ -503,6 +507,9 @@ void BuildOutputOffsetScale(const DevModel& m, const NetDesc& d, std::vector<dou
 		for (int a = 0; a < m.n_actions; ++a) if (a != da) { action_opt(a, tmp); for (int k = 0; k < frag; ++k) f_scale[k] = std::max(f_scale[k], std::fabs(tmp[k] + f_off[k])); }
 		for (double& v : f_scale) v = 1.0 / v;
 	}
+	if (m.ctrl_type == 2) {   // cBaseControllerCacla::BuildNNOutputOffsetScale (sim/BaseControllerCacla.cpp:88-122): the parameter block alone
+		off = f_off; scale = f_scale; return;
+	}
 	off.assign(nf + nf * frag, 0.0); scale.assign(nf + nf * frag, 1.0);
 	for (int f = 0; f < nf; ++f) {
 		off[f] = -0.5; scale[f] = 2;
@@ -529,10 +536,11 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	else if (char_ctrl == "dog_mace" || char_ctrl == "goat_mace") { m.char_type = 0; m.ctrl_type = 1; }
 	else if (char_ctrl == "raptor") { m.char_type = 1; m.ctrl_type = 0; }
 	else if (char_ctrl == "raptor_mace") { m.char_type = 1; m.ctrl_type = 1; }
-	else { err = "char_ctrl '" + char_ctrl + "' is not supported by this build (dog, dog_mace, goat_mace, raptor, raptor_mace; Q/CACLA heads are out of scope)"; return false; }
+	else if (char_ctrl == "dog_cacla") { m.char_type = 0; m.ctrl_type = 2; }   // cDogControllerCacla (sim/DogControllerCacla.cpp)
+	else { err = "char_ctrl '" + char_ctrl + "' is not supported by this build (dog, dog_mace, dog_cacla, goat_mace, raptor, raptor_mace; the Q head is out of scope)"; return false; }
 	if (!char_type.empty() && char_type != (m.char_type == 0 ? "dog" : "raptor")) { err = "char_type '" + char_type + "' does not match the controller"; return false; }
 	m.target_vel_x = (char_ctrl == "goat_mace") ? 2.0 : 4.0;   // sim/GoatControllerMACE.cpp:11-14, sim/DogController.cpp:625-628
-	if (scenario == "train_mace" || scenario == "exp" || scenario == "exp_mace") m.scenario = kScnExp;
+	if (scenario == "train_mace" || scenario == "exp" || scenario == "exp_mace" || scenario == "train_cacla" || scenario == "exp_cacla") m.scenario = kScnExp;
 	else if (scenario == "poli_eval") m.scenario = kScnPoliEval;
 	else m.scenario = kScnSimChar;
 
@@ -685,8 +693,14 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 
 	// policy net topology (weights arrive through dtrl_set_policy: the shipped *.h5 blobs are not in the reference checkout)
 	cfg.has_policy_net = false; m.has_net = 0;
-	if (args.ParseString("policy_net", cfg.policy_net_file) && m.ctrl_type == 1) {
-		if (!ParseDeployPrototxt(JoinPath(root, cfg.policy_net_file), cfg.net, err)) return false;
+	if (args.ParseString("policy_net", cfg.policy_net_file) && m.ctrl_type >= 1) {
+		if (!ParseDeployPrototxt(JoinPath(root, cfg.policy_net_file), cfg.net, err, &cfg.actor_only)) return false;
+		if (cfg.actor_only != (m.ctrl_type == 2)) { err = "policy_net topology does not match char_ctrl (MACE nets for *_mace, the actor net for dog_cacla)"; return false; }
+		cfg.user_num_params = cfg.net.num_params; cfg.user_out_size = cfg.net.out_size;
+		if (cfg.actor_only) {   // minus the (zero) critic head val_ip0 / val_ip1 that only exists on the device
+			cfg.user_num_params -= static_cast<int64_t>(cfg.net.fc_head) * cfg.net.fc_trunk + cfg.net.fc_head + cfg.net.fc_head + 1;
+			cfg.user_out_size = cfg.net.frag_size;
+		}
 		const int S = kNumGroundSamples + (2 * L - 1) + 2 * L;
 		if (cfg.net.in_size != S) { err = "Network input dimension does not match expected input size"; return false; }      // sim/NNController.cpp:58-75
 		if (cfg.net.frag_size != m.n_opt) { err = "Network output dimension does not match expected output size"; return false; }

@@ -101,6 +101,11 @@ struct ScenarioConfig {
 	RunParams run{};
 	NetDesc net{};
 	bool has_policy_net = false;
+	// CACLA (sim/BaseControllerCacla.cpp): the policy net is the ACTOR alone (slice / 3 conv / terr_ip0 / ip1 / ip2 / output). It runs on the
+	// device as a MACE-family net with one fragment whose critic head is all zeros; the boundary keeps the actor's own sizes and blob order
+	bool actor_only = false;
+	int64_t user_num_params = 0;   // what dtrl_set_policy expects (== net.num_params unless actor_only)
+	int user_out_size = 0;         // normaliser length at the boundary (== net.out_size unless actor_only)
 	int terrain_type = 0;
 	std::vector<std::vector<double>> terrain_param_sets;
 	double terrain_blend = 0;
@@ -113,7 +118,7 @@ struct ScenarioConfig {
 };
 
 bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err);
-bool ParseDeployPrototxt(const std::string& path, NetDesc& d, std::string& err);
+bool ParseDeployPrototxt(const std::string& path, NetDesc& d, std::string& err, bool* actor_only = nullptr);
 // cBaseControllerMACE::BuildNNOutputOffsetScale + cDogControllerMACE::BuildActorBias
 void BuildOutputOffsetScale(const DevModel& m, const NetDesc& d, std::vector<double>& off, std::vector<double>& scale);
 void LerpTerrainParams(const ScenarioConfig& cfg, double lerp, double* out);

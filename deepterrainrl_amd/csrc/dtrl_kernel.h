@@ -1143,6 +1143,16 @@ DTRL_HD inline void update_action(W& ws, const DevModel& gm, const RunParams& rp
 		ws.st.is_off_policy = 1;
 		int mode = 0;  // 0: keep / default action, 1: command, 2: net, 3: random base action (exploration)
 		if (ws.st.cmd_action >= 0) mode = 1;
+		else if (gm.has_net && gm.ctrl_type == 2) {
+			// cBaseControllerCacla::DecideAction / ShouldExplore / ExploreAction (sim/BaseControllerCacla.cpp:124-151, 219-234): explore with
+			// probability exp_rate; an exploring step is a random base action with probability exp_base_rate, the actor's output plus noise otherwise
+			Rng rng = make_rng(rp, env, &ws.st.rng_ctr);
+			const bool explore = rp.enable_exp && rng.uniform() < rp.exp_rate;
+			ws.st.is_off_policy = explore ? 1 : 0;
+			ws.st.exp_actor = 0;
+			mode = 2;
+			if (explore) { if (rng.uniform() < rp.exp_base_rate) mode = 3; else ws.st.exp_actor = 1; }   // exp_actor: add parameter noise below
+		}
 		else if (gm.has_net) {
 			Rng rng = make_rng(rp, env, &ws.st.rng_ctr);
 			ws.st.is_off_policy = 0;
@@ -1169,6 +1179,14 @@ DTRL_HD inline void update_action(W& ws, const DevModel& gm, const RunParams& rp
 			int a = rng.rand_int(0, gm.n_actions);
 			build_base_action(gm, num_frags, a, rng, &id, prm);
 			ws.st.is_off_policy = 1; ws.st.exp_actor = 1; ws.st.exp_critic = 1;
+		} else if (mode == 2 && gm.ctrl_type == 2) {
+			// cBaseControllerCacla::ExploitPolicy (:205-217) + ApplyExpNoiseAction (:262-296). The device net carries a (zero) critic slot in
+			// front of the actor's outputs (dtrl_engine.cpp SetPolicy), hence the offset of one
+			const real* y = buf.nn_out + static_cast<int64_t>(env) * buf.net.out_size;
+			id = -1;                                                                     // gInvalidIdx
+			for (int k = 0; k < gm.n_opt; ++k) prm[gm.opt_index[k]] = y[1 + k];
+			post_process_params(prm, gm.char_type);
+			if (ws.st.exp_actor) for (int k = 0; k < gm.n_opt; ++k) { real noise = rng.normal(0, rp.exp_noise); prm[gm.opt_index[k]] += noise * (1.0 / buf.out_scale[1 + k]); }
 		} else if (mode == 2) {
 			// sim/BaseControllerMACE.cpp:267-296
 			const real* y = buf.nn_out + static_cast<int64_t>(env) * buf.net.out_size;
@@ -1194,7 +1212,7 @@ DTRL_HD inline void update_action(W& ws, const DevModel& gm, const RunParams& rp
 				ws.st.is_off_policy = (ws.st.exp_actor || ws.st.exp_critic) ? 1 : 0;
 			}
 		} else {
-			bool cyclic = (gm.ctrl_type == 1) ? false : (gm.act_cyclic[ws.st.action_id] != 0);
+			bool cyclic = (gm.ctrl_type >= 1) ? false : (gm.act_cyclic[ws.st.action_id] != 0);
 			if (!cyclic) build_base_action(gm, num_frags, gm.default_action, rng, &id, prm);
 		}
 		apply_action(ws, id, prm, P);
@@ -1554,10 +1572,14 @@ DTRL_HD inline void scenario_new_cycle(W& ws, const DevModel& gm, const DevBuffe
 	LANES_BEGIN
 	for (int i = lane; i < buf.S; i += kGroup) s0[i] = ps[i];
 	if (lane == 0) {
-		ta[0] = ws.st.action_id;
-		for (int k = 0; k < gm.n_opt; ++k) ta[1 + k] = ws.st.params[gm.opt_index[k]];
+		if (gm.ctrl_type == 2) { for (int k = 0; k < gm.n_opt; ++k) ta[k] = ws.st.params[gm.opt_index[k]]; }   // cBaseControllerCacla::RecordPoliAction: the parameters alone
+		else {
+			ta[0] = ws.st.action_id;
+			for (int k = 0; k < gm.n_opt; ++k) ta[1 + k] = ws.st.params[gm.opt_index[k]];
+		}
 		int flags = 0;
 		if (gm.ctrl_type == 1) flags |= (ws.st.exp_critic ? 2 : 0) | (ws.st.exp_actor ? 4 : 0);
+		if (gm.ctrl_type == 2) flags |= ws.st.is_off_policy ? 2 : 0;   // cScenarioExpCacla::RecordFlagsBeg: cCaclaTrainer::eFlagOffPolicy
 		ws.st.tuple_flags = flags;
 		ws.st.cycle_count += 1;
 	}

@@ -85,7 +85,8 @@ dtrl_status dtrl_run_frames(dtrl_batch* b, int frames, double dt);
 /* Replaces: cNNController::LoadNet + LoadModel + LoadScale (sim/NNController.cpp:49-91; learning/NeuralNet.cpp:81-215)
  * and cNeuralNet::CopyModel pushes from the trainer (learning/NeuralNetLearner.cpp:85-89). weights: flat float32 in Caffe
  * blob order of the deploy prototxt named by -policy_net= (W then b per layer). Offsets/scales follow
- * learning/NeuralNet.cpp:977-986,1027-1036. n must equal dtrl_policy_num_params(). */
+ * learning/NeuralNet.cpp:977-986,1027-1036. n must equal dtrl_policy_num_params().  * With -char_ctrl= dog_cacla the net is the CACLA ACTOR (cBaseControllerCacla::CopyActorNet, sim/BaseControllerCacla.cpp:67-75): weights in the actor
+ * deploy net's blob order, output normalisers of its 29 outputs. */
 dtrl_status dtrl_set_policy(dtrl_batch* b, const float* weights, size_t n, const double* in_off, const double* in_scale, const double* out_off, const double* out_scale);
 dtrl_status dtrl_policy_num_params(const dtrl_batch* b, size_t* n);
 

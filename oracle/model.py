@@ -114,8 +114,8 @@ RAPTOR_STATES = ["Contact", "Down", "Passing", "Up"]
 RAPTOR_STATE_PARAMS = ["RootPitch", "SpineCurve", "StanceHip", "StanceKnee", "StanceAnkle", "SwingHip", "SwingKnee", "SwingAnkle"]
 # sim/RaptorController.cpp:71-114 gOptParamsMasks
 RAPTOR_OPT_MASK = [0, 1, 1, 0, 0] + [1, 0, 1, 1, 1, 1, 1, 1] * 2 + [0, 0, 1, 1, 1, 1, 1, 1] * 2
-CTRL_NAMES = {"dog": ("dog", 0), "dog_mace": ("dog", 1), "goat_mace": ("dog", 1), "raptor": ("raptor", 0), "raptor_mace": ("raptor", 1)}
-SCENARIOS = {"sim_char": 0, "train_mace": 1, "exp": 1, "exp_mace": 1, "poli_eval": 2}
+CTRL_NAMES = {"dog": ("dog", 0), "dog_mace": ("dog", 1), "goat_mace": ("dog", 1), "raptor": ("raptor", 0), "raptor_mace": ("raptor", 1), "dog_cacla": ("dog", 2)}
+SCENARIOS = {"sim_char": 0, "train_mace": 1, "exp": 1, "exp_mace": 1, "train_cacla": 1, "exp_cacla": 1, "poli_eval": 2}
 
 
 def load_json(path):
@@ -277,10 +277,39 @@ def parse_deploy_prototxt(path):
     for i, l in enumerate(convs):
         d.conv_ch[i] = l["num_output"]; d.conv_k[i] = l["kernel_w"]
     ips = {l["name"]: l["num_output"] for l in layers if l["type"] == "InnerProduct"}
+    if "ip0" not in ips and {"ip1", "ip2", "output"} <= set(ips):
+        # the CACLA actor (dog_actor_deploy.prototxt): one head ip1 -> ip2 -> output; held as a one-fragment MACE-family net whose critic head is zero
+        d.fc_terr = ips["terr_ip0"]; d.fc_trunk = ips["ip1"]; d.fc_head = ips["ip2"]; d.n_frags = 1; d.frag_size = ips["output"]
+        d.actor_only = True
+        return d
     d.fc_terr = ips["terr_ip0"]; d.fc_trunk = ips["ip0"]; d.fc_head = ips["val_ip0"]
     d.n_frags = ips["val_ip1"]; d.frag_size = ips["a0_ip1"]
     assert all(ips["a%d_ip0" % f] == d.fc_head and ips["a%d_ip1" % f] == d.frag_size for f in range(d.n_frags))
     return d
+
+
+def actor_policy_to_mace(desc, w_actor, out_off, out_scale):
+    """Actor blobs (conv0..2, terr_ip0, ip1, ip2, output) and its output normalisers -> the one-fragment MACE-family form the oracle's
+    PolicyNet evaluates: an all-zero critic head (val_ip0, val_ip1) behind the trunk, one neutral critic slot in front of the outputs."""
+    head = desc.fc_head * desc.fc_trunk + desc.fc_head + desc.fc_head + 1
+    tail = desc.fc_head * desc.fc_trunk + desc.fc_head + desc.frag_size * desc.fc_head + desc.frag_size
+    w = np.concatenate([w_actor[:len(w_actor) - tail], np.zeros(head, np.float32), w_actor[len(w_actor) - tail:]]).astype(np.float32)
+    return w, np.concatenate([[0.0], out_off]), np.concatenate([[1.0], out_scale])
+
+
+def actor_xavier_weights(desc, seed=1234):
+    """Synthetic actor weights in the actor's own blob order (conv0..2, terr_ip0, ip1, ip2, output)."""
+    rng = np.random.RandomState(seed)
+    out = []
+
+    def blob(nout, fan_in):
+        s = np.sqrt(3.0 / fan_in)
+        out.append(rng.uniform(-s, s, size=nout * fan_in).astype(np.float32)); out.append(np.zeros(nout, np.float32))
+    cin, w = 1, desc.n_terrain
+    for l in range(3):
+        blob(desc.conv_ch[l], cin * desc.conv_k[l]); cin = desc.conv_ch[l]; w = w - desc.conv_k[l] + 1
+    blob(desc.fc_terr, cin * w); blob(desc.fc_trunk, desc.fc_terr + desc.n_char); blob(desc.fc_head, desc.fc_trunk); blob(desc.frag_size, desc.fc_head)
+    return np.concatenate(out)
 
 
 def xavier_weights(desc, seed=1234):

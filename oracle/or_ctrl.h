@@ -241,7 +241,7 @@ struct Env {
 	}
 
 	int PoliStateSize() const { return 200 + (L * 2 - 1) + L * 2; }  // sim/TerrainRLCharController.cpp:308-342
-	int PoliActionSize() const { return 1 + nOpt; }                    // sim/BaseControllerMACE.cpp:28-31
+	int PoliActionSize() const { return M.ctrl_type == 2 ? nOpt : 1 + nOpt; }   // sim/BaseControllerMACE.cpp:28-31; sim/BaseControllerCacla.cpp:13-16
 
 	// ---- character reset: cSimCharacter::Reset + cScenarioSimChar::InitCharacterPos -----------------
 	void ResetCharacter()
@@ -468,6 +468,31 @@ struct Env {
 			is_off_policy = exp_actor || exp_critic;
 		}
 	}
+	// ---- CACLA action selection: sim/BaseControllerCacla.cpp:124-151 (ShouldExplore / DecideAction), 205-234 (ExploitPolicy / ExploreAction),
+	// 262-296 (ApplyExpNoiseAction). The actor is held as a one-fragment net of the MACE family with an all-zero critic head, so its
+	// parameter outputs sit behind one (unused) critic slot
+	void DecideActionCacla(Action& out)
+	{
+		bool explore = false;
+		if (enable_exp) explore = rng.RandDouble() < exp_rate;
+		is_off_policy = explore;
+		if (explore && rng.RandDouble() < exp_base_rate) {
+			int a = rng.RandInt(0, M.n_actions);  // BuildRandBaseAction
+			BuildBaseAction(a, out);
+			return;
+		}
+		nn_out.assign(net->OutSize(), 0.0);
+		net->Eval(poli_state.data(), nn_out.data());
+		BuildActorAction(nn_out.data(), 0, out);
+		out.id = -1;   // gInvalidIdx
+		if (explore) {
+			int k = 0;
+			for (int i = 0; i < P; ++i) if (IsOptParam(i)) {
+				double noise = rng.RandNorm(0, exp_noise);
+				out.params[i] += noise * (1.0 / net->out_scale[1 + k]); ++k;
+			}
+		}
+	}
 	void UpdateAction()  // sim/DogControllerMACE.cpp:26-30 + sim/DogController.cpp:847-868
 	{
 		if (M.ctrl_type == 1) { exp_actor = false; exp_critic = false; }
@@ -480,9 +505,9 @@ struct Env {
 			if (M.ctrl_type == 1) { exp_actor = true; exp_critic = true; }
 			BuildBaseAction(cmd, a);
 		} else if (net && net->valid) {
-			DecideActionBoltzmann(a);
+			if (M.ctrl_type == 2) DecideActionCacla(a); else DecideActionBoltzmann(a);
 		} else {
-			bool cyclic = (M.ctrl_type == 1) ? false : (M.act_cyclic[curr.id] != 0);  // MACE: IsCurrActionCyclic() == false
+			bool cyclic = (M.ctrl_type >= 1) ? false : (M.act_cyclic[curr.id] != 0);  // MACE / CACLA: IsCurrActionCyclic() == false
 			if (!cyclic) BuildBaseAction(M.default_action, a);
 		}
 		ApplyAction(a);
@@ -725,10 +750,11 @@ struct Env {
 		if (cycle_count > 1) tuples.push_back(cur_tuple);  // gNumWarmupCycles = 1
 		cur_tuple.s0 = cur_tuple.s1;
 		cur_tuple.a.assign(PoliActionSize(), 0.0);
-		cur_tuple.a[0] = curr.id;
-		GetOptParams(curr.params, cur_tuple.a.data() + 1);
+		if (M.ctrl_type == 2) GetOptParams(curr.params, cur_tuple.a.data());   // cBaseControllerCacla::RecordPoliAction
+		else { cur_tuple.a[0] = curr.id; GetOptParams(curr.params, cur_tuple.a.data() + 1); }
 		cur_tuple.flags = 0;
 		if (M.ctrl_type == 1) cur_tuple.flags |= (exp_critic ? 2u : 0u) | (exp_actor ? 4u : 0u);
+		if (M.ctrl_type == 2) cur_tuple.flags |= is_off_policy ? 2u : 0u;       // cScenarioExpCacla::RecordFlagsBeg (cCaclaTrainer::eFlagOffPolicy)
 		++cycle_count;
 	}
 

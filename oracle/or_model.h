@@ -17,7 +17,7 @@ extern "C" {
 
 struct OrcModel {
 	int32_t char_type;   // 0 = dog (also goat), 1 = raptor
-	int32_t ctrl_type;   // 0 = FSM without net ("dog"/"raptor": cDogControllerQ w/o net), 1 = MACE
+	int32_t ctrl_type;   // 0 = FSM without net ("dog"/"raptor": cDogControllerQ w/o net), 1 = MACE, 2 = CACLA (actor as a one-fragment MACE-family net with a zero critic head)
 	int32_t L, D;
 	int32_t parent[ORC_MAXL];
 	int32_t joint_type[ORC_MAXL];          // cKinTree::eJointType (0 revolute, 1 planar)

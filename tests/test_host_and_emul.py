@@ -382,6 +382,51 @@ def test_env_groups_pipelined_run_frames_equals_stepwise(da, om, monkeypatch):
         assert np.array_equal(r[2], res[0][2]) and np.array_equal(r[3], res[0][3]) and np.array_equal(r[4], res[0][4]) and np.array_equal(r[5], res[0][5])
 
 
+def test_cacla_action_selection_and_tuples_vs_oracle(da, om):
+    """cDogControllerCacla (args/opt_args_train_cacla.txt): explore with probability exp_rate -- a random base action with probability
+    exp_base_rate, the actor's parameters plus noise otherwise --, exploit = the actor's parameters with action id gInvalidIdx
+    (sim/BaseControllerCacla.cpp:124-151, 205-296); tuples [r | s | a | s'] with a = the optimisable parameters alone and flags fail /
+    off-policy (scenarios/ScenarioExpCacla.cpp). The engine takes the actor net in its own blob order and sizes; the oracle the padded form."""
+    over = dict(exp_rate=0.5, exp_base_rate=0.3)
+    m, _ = om.build_model("args/opt_args_train_cacla.txt", REFDATA, over)
+    desc = om.parse_deploy_prototxt(os.path.join(REFDATA, "data/policies/dog/nets/dog_actor_deploy.prototxt"))
+    w = om.actor_xavier_weights(desc, 77)
+    n = 2
+    b = batch(da, "args/opt_args_train_cacla.txt", n, terrain_seed=40, rand_seed=5, **over)
+    assert b.A == 29 and b.nn_out == 29 and b.PolicyNumParams() == len(w) and b.num_frags == 0
+    oo, osc = b.BuildNNOutputOffsetScale()
+    assert len(oo) == 29 and np.all(osc > 0)
+    io, isc = np.zeros(283), np.ones(283)
+    b.SetPolicy(w, io, isc, oo, osc)
+    wm, oom, osm = om.actor_policy_to_mace(desc, w, oo, osc)
+    es = [om.OracleEnv(m, terrain_seed=40 + i, rng_seed=5, env_id=i, policy=(desc, wm, io, isc, oom, osm)) for i in range(n)]
+    rows, flags, ids = [], [], []
+    for f in range(120):
+        b.Update()
+        for e in es:
+            e.update()
+        r, fl, ei = b.DrainTuples()
+        rows.append(r); flags.append(fl); ids.append(ei)
+        if f == 30:
+            st, ph, aid, prm, tg = b.Ctrl()
+            for i, e in enumerate(es):
+                so, pho, aido, prmo, tgo = e.ctrl()
+                assert aid[i] == aido and np.abs(prm[i] - prmo).max() < 1e-6
+    rows = np.concatenate(rows); flags = np.concatenate(flags); ids = np.concatenate(ids)
+    assert rows.shape[1] == 1 + 2 * 283 + 29
+    seen_ids = set()
+    for i, e in enumerate(es):
+        ro, fo = e.drain_tuples(1024)
+        mine = rows[ids == i]; mf = flags[ids == i]
+        k = min(len(ro), len(mine), 4)
+        assert k >= 3
+        assert np.array_equal(mf[:k], fo[:k]) and np.all((mf.astype(np.int64) >> 2) == 0)               # only fail (1) and off-policy (2)
+        assert np.abs(mine[:k] - ro[:k]).max() < 2e-4 * max(1.0, np.abs(ro[:k]).max())
+        seen_ids.update(mf.tolist())
+    assert any(f & 2 for f in seen_ids) and any(not (f & 2) for f in seen_ids)            # both explored and exploited cycles occurred
+    assert set(b.Ctrl()[2].tolist()) <= set(range(-1, 8))                                  # gInvalidIdx after the actor, a table id after a base action
+
+
 def test_perturbation_force_vs_oracle(da, om):
     """tPerturb (ePerturbForce) through cWorld::AddPerturb: a world-frame force on a body part at a body-local offset for a duration,
     advanced at the start of every env-step and dropped when expired (sim/Perturb.cpp, sim/PerturbManager.cpp:41-56); reset clears it."""
