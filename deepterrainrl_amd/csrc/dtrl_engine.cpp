@@ -394,7 +394,6 @@ int Engine::UploadNormalizers()
 // cNeuralNet::LoadScale, learning/NeuralNet.cpp:137-215
 int Engine::LoadScaleFile(const char* path)
 {
-	if (cfg_.actor_only) return Fail(DTRL_ERR_ARG, "scale files of the CACLA actor are not handled by the engine yet: pass the normalisers to dtrl_set_policy");
 	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
 	if (!path) return Fail(DTRL_ERR_ARG, "null path");
 	const NetDesc& d = cfg_.net;
@@ -403,7 +402,8 @@ int Engine::LoadScaleFile(const char* path)
 	if (in_off_.empty()) { in_off_.assign(d.in_size, 0.0); in_scale_.assign(d.in_size, 1.0); out_off_.assign(d.out_size, 0.0); out_scale_.assign(d.out_size, 1.0); }
 	struct Slot { const char* key; std::vector<double>* vec; int size; const char* what; };
 	const Slot slots[4] = {{"InputOffset", &in_off_, d.in_size, "input offset"}, {"InputScale", &in_scale_, d.in_size, "input scale"},
-		{"OutputOffset", &out_off_, d.out_size, "output offset"}, {"OutputScale", &out_scale_, d.out_size, "output scale"}};
+		{"OutputOffset", &out_off_, cfg_.user_out_size, "output offset"}, {"OutputScale", &out_scale_, cfg_.user_out_size, "output scale"}};
+	const int pad = d.out_size - cfg_.user_out_size;   // CACLA actor: 1 (the unused critic slot of the device net), else 0
 	std::vector<double> tmp[4];
 	for (int k = 0; k < 4; ++k) {
 		const Json* j = root.find(slots[k].key);
@@ -413,7 +413,7 @@ int Engine::LoadScaleFile(const char* path)
 			return Fail(DTRL_ERR_IO, std::string("Invalid ") + slots[k].what + " size, expecting " + std::to_string(slots[k].size) + ", but got " + std::to_string(j->arr.size()));
 		for (const Json& v : j->arr) tmp[k].push_back(v.num);
 	}
-	for (int k = 0; k < 4; ++k) if (!tmp[k].empty()) *slots[k].vec = tmp[k];
+	for (int k = 0; k < 4; ++k) if (!tmp[k].empty()) { if (k >= 2 && pad) tmp[k].insert(tmp[k].begin(), pad, k == 2 ? 0.0 : 1.0); *slots[k].vec = tmp[k]; }
 	be_->Sync();
 	return UploadNormalizers();
 }
@@ -421,7 +421,6 @@ int Engine::LoadScaleFile(const char* path)
 // cNeuralNet::WriteOffsetScale, learning/NeuralNet.cpp:1182-1205 (cJsonUtil::BuildVectorJson: std::to_string per element)
 int Engine::WriteScaleFile(const char* path)
 {
-	if (cfg_.actor_only) return Fail(DTRL_ERR_ARG, "scale files of the CACLA actor are not handled by the engine yet: pass the normalisers to dtrl_set_policy");
 	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
 	const NetDesc& d = cfg_.net;
 	if (in_off_.empty()) { in_off_.assign(d.in_size, 0.0); in_scale_.assign(d.in_size, 1.0); out_off_.assign(d.out_size, 0.0); out_scale_.assign(d.out_size, 1.0); }
@@ -429,7 +428,9 @@ int Engine::WriteScaleFile(const char* path)
 	if (!f) return Fail(DTRL_ERR_IO, std::string("Failed to write offset and scale to ") + (path ? path : "(null)"));
 	auto vec_json = [](const std::vector<double>& v) { std::string s = "["; for (size_t i = 0; i < v.size(); ++i) { if (i) s += ", "; s += std::to_string(v[i]); } return s + "]"; };
 	std::fprintf(f, "{\n\"InputOffset\": %s,\n\"InputScale\": %s,\n\"OutputOffset\": %s,\n\"OutputScale\": %s\n}",
-		vec_json(in_off_).c_str(), vec_json(in_scale_).c_str(), vec_json(out_off_).c_str(), vec_json(out_scale_).c_str());
+		vec_json(in_off_).c_str(), vec_json(in_scale_).c_str(),
+		vec_json(std::vector<double>(out_off_.begin() + (d.out_size - cfg_.user_out_size), out_off_.end())).c_str(),
+		vec_json(std::vector<double>(out_scale_.begin() + (d.out_size - cfg_.user_out_size), out_scale_.end())).c_str());
 	std::fclose(f);
 	return DTRL_OK;
 }

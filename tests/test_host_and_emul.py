@@ -4,6 +4,7 @@ The kernel source (deepterrainrl_amd/csrc/dtrl_kernel.h) is written in lane-phas
 with the lane loop expanded on the host (tests only -- the product never loads it). These tests pin (a) the C++ loader and
 terrain generator against the independent Python/oracle implementations and (b) the planar wave-cooperative math against the
 oracle's 6-D restatement, so a GPU run only has to confirm what already holds here."""
+import json
 import os
 
 import numpy as np
@@ -424,6 +425,12 @@ def test_cacla_action_selection_and_tuples_vs_oracle(da, om):
         assert np.abs(mine[:k] - ro[:k]).max() < 2e-4 * max(1.0, np.abs(ro[:k]).max())
         seen_ids.update(mf.tolist())
     assert any(f & 2 for f in seen_ids) and any(not (f & 2) for f in seen_ids)            # both explored and exploited cycles occurred
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:                                              # the actor's scale file keeps the actor's own 29 outputs
+        p = os.path.join(td, "actor_scale.txt"); b.WriteOffsetScale(p)
+        d = json.load(open(p))
+        assert len(d["OutputOffset"]) == 29 and len(d["InputScale"]) == 283 and np.allclose(d["OutputScale"], osc, atol=1e-5)
+        b.LoadScale(p)
     assert set(b.Ctrl()[2].tolist()) <= set(range(-1, 8))                                  # gInvalidIdx after the actor, a table id after a base action
 
 
