@@ -131,6 +131,21 @@ __device__ __forceinline__ void fnma_lanes_lt(real& acc, real a, real b)
 	asm("s_bfm_b64 %2, %5, 0\n\ts_and_saveexec_b64 %1, %2\n\tv_fma_f64 %0, -%3, %4, %0\n\ts_mov_b64 exec, %1"
 	    : "+v"(acc), "=&s"(sv), "=&s"(m) : "v"(a), "s"(b), "n"(I) : "scc");
 }
+// dst = src on lane K only / on lanes < I
+template <int K>
+__device__ __forceinline__ void mov_lane_eq(real& dst, real src)
+{
+	unsigned long long sv, m;
+	asm("s_lshl_b64 %2, 1, %4\n\ts_and_saveexec_b64 %1, %2\n\tv_mov_b64 %0, %3\n\ts_mov_b64 exec, %1"
+	    : "+v"(dst), "=&s"(sv), "=&s"(m) : "v"(src), "n"(K) : "scc");
+}
+template <int I>
+__device__ __forceinline__ void mov_lanes_lt(real& dst, real src)
+{
+	unsigned long long sv, m;
+	asm("s_bfm_b64 %2, %4, 0\n\ts_and_saveexec_b64 %1, %2\n\tv_mov_b64 %0, %3\n\ts_mov_b64 exec, %1"
+	    : "+v"(dst), "=&s"(sv), "=&s"(m) : "v"(src), "n"(I) : "scc");
+}
 // dst = src on lanes >= J
 template <int J>
 __device__ __forceinline__ void mov_lanes_ge(real& dst, real src)
@@ -177,13 +192,13 @@ __device__ __forceinline__ real factorize_regs(WSFast& ws, real (&h)[Topo::L + 2
 		const real dk = bcast(h[k], k);
 		const real ak = h[k];
 		const real rk = fast_recip(dk);
-		if (lane == k) dinv = rk;
+		mov_lane_eq<k>(dinv, rk);                       // if (lane == k) dinv = rk
 		const real lik = ak * rk;
 		static_for_down<0, k>([&](auto jc) {
 			constexpr int j = decltype(jc)::value;
 			if constexpr (dof_coupled<Topo>(j, k)) h[j] = fmadd(-lik, bcast(ak, j), h[j]);
 		});
-		if (lane < k) h[k] = lik;
+		mov_lanes_lt<k>(h[k], lik);                     // if (lane < k) h[k] = lik
 	});
 	{ const real r0 = fast_recip(h[0]); if (lane == 0) dinv = r0; }
 	real* S = ws.Apk;
