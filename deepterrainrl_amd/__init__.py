@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "dtrl_policy_num_params", "dtrl_build_output_offset_scale", "dtrl_load_scale_file", "dtrl_write_scale_file", "dtrl_set_explore", "dtrl_set_terrain_lerp", "dtrl_drain_tuples",
     "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_cycle_info", "dtrl_get_action_table", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
+    "dtrl_terrain_build", "dtrl_terrain_load_file", "dtrl_args_parse_string",
 ]
 
 
@@ -79,6 +80,9 @@ def _bind(path):
     L.dtrl_eval_stats.argtypes = [vp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.dtrl_dims.argtypes = [vp] + [C.POINTER(C.c_int)] * 8
     L.dtrl_kernel_time_ms.argtypes = [vp, dp, C.POINTER(C.c_int64)]
+    L.dtrl_terrain_build.argtypes = [C.c_char_p, vp, C.c_uint64, C.c_double, vp, C.c_int, C.POINTER(C.c_int), dp]
+    L.dtrl_terrain_load_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
+    L.dtrl_args_parse_string.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.dtrl_last_error.restype = C.c_char_p
     L.dtrl_last_error.argtypes = [vp]
     L.dtrl_version.restype = C.c_char_p
@@ -308,3 +312,35 @@ class BatchScenario:
 
 def version():
     return _bind(LIB_PATH).dtrl_version().decode()
+
+
+# ---- host-side utility entry points (no batch, no device) ----
+def terrain_build(type_name, params40, seed, width, _lib_path=None):
+    """cTerrainGen2D::GetTerrainFunc(type)(width, params, cRand(seed), data): (float32 heights, width added)."""
+    L = _bind(_lib_path or LIB_PATH)
+    p = np.ascontiguousarray(params40, np.float64); buf = np.zeros(8192, np.float32); n = C.c_int(); w = C.c_double()
+    rc = L.dtrl_terrain_build(type_name.encode(), _p(p), int(seed), float(width), _p(buf), 8192, C.byref(n), C.byref(w))
+    if rc != DTRL_OK:
+        raise DtrlError("dtrl_terrain_build failed (%d): %s" % (rc, L.dtrl_last_error(None).decode()))
+    return buf[:n.value].copy(), w.value
+
+
+def terrain_load_file(path, max_sets=8, _lib_path=None):
+    """Terrain file -> (type name, [n_sets, 40] parameter vectors in cTerrainGen2D::eParams order)."""
+    L = _bind(_lib_path or LIB_PATH)
+    buf = C.create_string_buffer(64); prm = np.zeros((max_sets, 40)); n = C.c_int()
+    rc = L.dtrl_terrain_load_file(os.fsencode(path), buf, 64, _p(prm), max_sets, C.byref(n))
+    if rc != DTRL_OK:
+        raise DtrlError("dtrl_terrain_load_file failed (%d): %s" % (rc, L.dtrl_last_error(None).decode()))
+    return buf.value.decode(), prm[:n.value].copy()
+
+
+def args_parse_string(argv, key, _lib_path=None):
+    """cArgParser(argv) + AppendArgs(-arg_file=) + ParseString(key): (value or None, number of tokens)."""
+    L = _bind(_lib_path or LIB_PATH)
+    arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+    buf = C.create_string_buffer(4096); found = C.c_int(); nt = C.c_int()
+    rc = L.dtrl_args_parse_string(arr, len(argv), key.encode(), buf, 4096, C.byref(found), C.byref(nt))
+    if rc != DTRL_OK:
+        raise DtrlError("dtrl_args_parse_string failed (%d): %s" % (rc, L.dtrl_last_error(None).decode()))
+    return (buf.value.decode() if found.value else None), nt.value

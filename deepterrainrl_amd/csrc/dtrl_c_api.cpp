@@ -2,6 +2,7 @@
 #include "../../include/dtrl.h"
 #include "dtrl_engine.h"
 #include <cmath>
+#include <cstdio>
 #include <new>
 
 using dtrl::Engine;
@@ -212,6 +213,57 @@ dtrl_status dtrl_dims(const dtrl_batch* b, int* L, int* D, int* S, int* A, int* 
 	return DTRL_OK;
 }
 dtrl_status dtrl_kernel_time_ms(dtrl_batch* b, double* avg_ms, int64_t* launches) { CHECK_B(); return static_cast<dtrl_status>(b->eng.KernelTime(avg_ms, launches)); }
+
+dtrl_status dtrl_terrain_build(const char* type_name, const double* params40, uint64_t seed, double width, float* out, int cap, int* out_n, double* out_width)
+{
+	if (!type_name || !params40 || !out_n || cap < 0 || (cap > 0 && !out)) return DTRL_ERR_ARG;
+	std::string name = type_name;
+	if (name.empty()) name = "flat";   // cTerrainGen2D::ParseType: "" == flat
+	int type = -1;
+	for (int i = 0; i < dtrl::kTerrTypeMax; ++i) if (name == dtrl::kTerrainTypeNames[i]) type = i;
+	if (type < 0) { g_create_error = "unsupported terrain type " + name; return DTRL_ERR_ARG; }
+	dtrl::TerrainRand rnd; rnd.Seed(static_cast<unsigned long>(seed));
+	std::vector<float> data;
+	const double w = dtrl::BuildTerrain(type, width, params40, rnd, data);
+	*out_n = static_cast<int>(data.size());
+	if (out_width) *out_width = w;
+	for (int i = 0; i < *out_n && i < cap; ++i) out[i] = data[i];
+	return *out_n <= cap ? DTRL_OK : DTRL_ERR_CAPACITY;
+}
+dtrl_status dtrl_terrain_load_file(const char* path, char* type_out, int type_cap, double* params_out, int max_sets, int* out_sets)
+{
+	if (!path || !out_sets) return DTRL_ERR_ARG;
+	dtrl::Json tf; std::string err;
+	if (!dtrl::Json::parse_file(path, tf, err)) { g_create_error = err; return DTRL_ERR_IO; }
+	const dtrl::Json* ty = tf.find("Type");
+	const std::string tname = ty ? ty->str : "";
+	if (type_out && type_cap > 0) { std::snprintf(type_out, static_cast<size_t>(type_cap), "%s", tname.c_str()); }
+	int n = 0;
+	const dtrl::Json* ps = tf.find("Params");
+	if (ps) for (const dtrl::Json& obj : ps->arr) {
+		if (n >= max_sets) break;
+		for (int k = 0; k < dtrl::kNumTerrainParams; ++k) params_out[n * dtrl::kNumTerrainParams + k] = obj.get_num(dtrl::kTerrainParamNames[k], dtrl::kTerrainParamDefaults[k]);
+		++n;
+	}
+	*out_sets = n;
+	return DTRL_OK;
+}
+dtrl_status dtrl_args_parse_string(const char* const* argv, int argc, const char* key, char* out, int cap, int* found, int* n_tokens)
+{
+	if (!key || !found || argc < 0 || (argc > 0 && !argv)) return DTRL_ERR_ARG;
+	dtrl::ArgParser args(argv, argc);
+	std::string arg_file;
+	if (args.ParseString("arg_file", arg_file)) {
+		std::string root; args.ParseString("data_root", root);
+		const std::string path = (arg_file.empty() || arg_file[0] == '/' || root.empty()) ? arg_file : root + "/" + arg_file;
+		if (!args.AppendArgs(path)) { g_create_error = "Failed to load args from: " + path; return DTRL_ERR_IO; }
+	}
+	std::string v;
+	*found = args.ParseString(key, v) ? 1 : 0;
+	if (out && cap > 0) std::snprintf(out, static_cast<size_t>(cap), "%s", *found ? v.c_str() : "");
+	if (n_tokens) *n_tokens = args.GetNumArgs();
+	return DTRL_OK;
+}
 
 // not part of include/dtrl.h: developer hook used by tools/gpu_sections.py with the DTRL_PROFILE build
 int dtrlx_profile_sections(dtrl_batch* b, unsigned long long* out, int cap) { return b ? b->eng.ProfileSections(out, cap) : 1; }

@@ -162,6 +162,22 @@ dtrl_status dtrl_dims(const dtrl_batch* b, int* L, int* D, int* S, int* A, int* 
  * average duration in ms of the frame kernel over the launches since the previous call, measured with hipEvents on that stream. */
 dtrl_status dtrl_kernel_time_ms(dtrl_batch* b, double* avg_ms, int64_t* launches);
 
+/* ---- host-side pieces of the path that need no batch and no device (the reference's static / utility entry points) ---- */
+
+/* Replaces: cTerrainGen2D::ParseType + GetTerrainFunc(type) (sim/TerrainGen2D.cpp:90-181) called as func(width, params, rand, data) on a
+ * cRand seeded with `seed` (util/Rand.cpp:89-92), i.e. what cGroundVar2D::BuildSegment runs per segment (sim/GroundVar2D.cpp:312-342).
+ * params40 in cTerrainGen2D::eParams order (sim/TerrainGen2D.h:31-81). The strip (float heights, 0.1 m vertex spacing) is written to
+ * out[0..min(n, cap)); *out_n = vertex count, *out_width = the function's return value (metres added). Bit-identical to the reference
+ * on the same libstdc++. */
+dtrl_status dtrl_terrain_build(const char* type_name, const double* params40, uint64_t seed, double width, float* out, int cap, int* out_n, double* out_width);
+/* Replaces: the terrain-file reader of cScenarioSimChar::ParseTerrainParams (scenarios/ScenarioSimChar.cpp:670-706) + cTerrainGen2D::LoadParams
+ * (sim/TerrainGen2D.cpp:69-81): "Type" string and every 40-vector of the "Params" array (defaults sim/TerrainGen2D.cpp:8-56). */
+dtrl_status dtrl_terrain_load_file(const char* path, char* type_out, int type_cap, double* params_out, int max_sets, int* out_sets);
+/* Replaces: cArgParser(argv, argc) + AppendArgs(-arg_file) + ParseString(key) (optimizer/Main.cpp:19-32, util/ArgParser.cpp:42-108, 131-150) exactly as
+ * dtrl_create resolves its arguments (-data_root= prefixes a relative -arg_file=). *found = 0 when the key is absent or followed by another key.
+ * Returns the number of tokens through n_tokens (may be NULL). */
+dtrl_status dtrl_args_parse_string(const char* const* argv, int argc, const char* key, char* out, int cap, int* found, int* n_tokens);
+
 const char* dtrl_last_error(const dtrl_batch* b);
 const char* dtrl_version(void);
 
