@@ -36,6 +36,7 @@ ABI_SYMBOLS = [
     "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_cycle_info", "dtrl_get_action_table", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
     "dtrl_terrain_build", "dtrl_terrain_load_file", "dtrl_args_parse_string",
+    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log",
 ]
 
 
@@ -83,6 +84,12 @@ def _bind(path):
     L.dtrl_terrain_build.argtypes = [C.c_char_p, vp, C.c_uint64, C.c_double, vp, C.c_int, C.POINTER(C.c_int), dp]
     L.dtrl_terrain_load_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     L.dtrl_args_parse_string.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.dtrl_drain_tuples_device.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.dtrl_tuple_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    L.dtrl_set_policy_device.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, vp]
+    L.dtrl_get_dist_log.argtypes = [vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.dtrl_reset_avg_dist.argtypes = [vp]
+    L.dtrl_write_dist_log.argtypes = [vp, C.c_char_p]
     L.dtrl_last_error.restype = C.c_char_p
     L.dtrl_last_error.argtypes = [vp]
     L.dtrl_version.restype = C.c_char_p
@@ -96,8 +103,12 @@ def _p(a):
 class BatchScenario:
     """N reference-shaped scenarios (cScenarioExp / cScenarioPoliEval / cScenarioSimChar) stepped as one batch on one GPU."""
 
-    def __init__(self, arg_file=None, num_envs=1, data_root=None, device_id=-1, extra_args=None, _lib_path=None):
-        self._lib = _bind(_lib_path or LIB_PATH)
+    def _library(self):
+        """The HIP library; there is no other backend in the product (tests of the host logic subclass this from tests/conftest.py)."""
+        return _bind(LIB_PATH)
+
+    def __init__(self, arg_file=None, num_envs=1, data_root=None, device_id=-1, extra_args=None):
+        self._lib = self._library()
         argv = []
         if extra_args:
             for k, v in extra_args.items():
@@ -209,6 +220,38 @@ class BatchScenario:
         self._chk(self._lib.dtrl_drain_tuples(self._h, _p(rows), _p(fl), _p(ids), cap, C.byref(n)))
         return rows[:n.value], fl[:n.value], ids[:n.value]
 
+    def DrainTuplesDevice(self, rows_ptr, flags_ptr, ids_ptr, cap):
+        """dtrl_drain_tuples_device: raw DEVICE pointers (e.g. tensor.data_ptr()) of float32 [cap, W] / uint32 [cap] / int32 [cap]; returns n."""
+        n = C.c_int()
+        self._chk(self._lib.dtrl_drain_tuples_device(self._h, C.c_void_p(rows_ptr), C.c_void_p(flags_ptr) if flags_ptr else None, C.c_void_p(ids_ptr) if ids_ptr else None, int(cap), C.byref(n)))
+        return n.value
+
+    def TupleStats(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64(); cap = C.c_int32()
+        self._chk(self._lib.dtrl_tuple_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(cap)))
+        return {"pending": a.value, "drained": b.value, "dropped": c.value, "capacity": cap.value}
+
+    def SetPolicyDevice(self, weights_ptr, n, in_off_ptr=None, in_scale_ptr=None, out_off_ptr=None, out_scale_ptr=None):
+        """dtrl_set_policy_device: raw DEVICE pointers (float32 weights in Caffe blob order, float64 normalisers or None)."""
+        q = [C.c_void_p(x) if x else None for x in (in_off_ptr, in_scale_ptr, out_off_ptr, out_scale_ptr)]
+        self._chk(self._lib.dtrl_set_policy_device(self._h, C.c_void_p(weights_ptr), int(n), *q))
+
+    def GetDistLog(self):
+        """cScenarioPoliEval::GetDistLog over the batch: (distances, env ids), grouped by env, episodes in time order."""
+        n = C.c_int()
+        self._chk(self._lib.dtrl_get_dist_log(self._h, None, None, 0, C.byref(n)))
+        d = np.zeros(n.value); ids = np.zeros(n.value, np.int32)
+        if n.value:
+            self._chk(self._lib.dtrl_get_dist_log(self._h, _p(d), _p(ids), n.value, C.byref(n)))
+        return d, ids
+
+    def ResetAvgDist(self):
+        self._chk(self._lib.dtrl_reset_avg_dist(self._h))
+
+    def OutputResults(self, out_file):
+        """cOptScenarioPoliEval::OutputResults: append the dist log as one line to out_file."""
+        self._chk(self._lib.dtrl_write_dist_log(self._h, os.fsencode(out_file)))
+
     # ---- character / controller observability ----
     def PoseVel(self, env_ids=None):
         ids, n = self._ids(env_ids)
@@ -315,9 +358,9 @@ def version():
 
 
 # ---- host-side utility entry points (no batch, no device) ----
-def terrain_build(type_name, params40, seed, width, _lib_path=None):
+def terrain_build(type_name, params40, seed, width):
     """cTerrainGen2D::GetTerrainFunc(type)(width, params, cRand(seed), data): (float32 heights, width added)."""
-    L = _bind(_lib_path or LIB_PATH)
+    L = _bind(LIB_PATH)
     p = np.ascontiguousarray(params40, np.float64); buf = np.zeros(8192, np.float32); n = C.c_int(); w = C.c_double()
     rc = L.dtrl_terrain_build(type_name.encode(), _p(p), int(seed), float(width), _p(buf), 8192, C.byref(n), C.byref(w))
     if rc != DTRL_OK:
@@ -325,9 +368,9 @@ def terrain_build(type_name, params40, seed, width, _lib_path=None):
     return buf[:n.value].copy(), w.value
 
 
-def terrain_load_file(path, max_sets=8, _lib_path=None):
+def terrain_load_file(path, max_sets=8):
     """Terrain file -> (type name, [n_sets, 40] parameter vectors in cTerrainGen2D::eParams order)."""
-    L = _bind(_lib_path or LIB_PATH)
+    L = _bind(LIB_PATH)
     buf = C.create_string_buffer(64); prm = np.zeros((max_sets, 40)); n = C.c_int()
     rc = L.dtrl_terrain_load_file(os.fsencode(path), buf, 64, _p(prm), max_sets, C.byref(n))
     if rc != DTRL_OK:
@@ -335,9 +378,9 @@ def terrain_load_file(path, max_sets=8, _lib_path=None):
     return buf.value.decode(), prm[:n.value].copy()
 
 
-def args_parse_string(argv, key, _lib_path=None):
+def args_parse_string(argv, key):
     """cArgParser(argv) + AppendArgs(-arg_file=) + ParseString(key): (value or None, number of tokens)."""
-    L = _bind(_lib_path or LIB_PATH)
+    L = _bind(LIB_PATH)
     arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
     buf = C.create_string_buffer(4096); found = C.c_int(); nt = C.c_int()
     rc = L.dtrl_args_parse_string(arr, len(argv), key.encode(), buf, 4096, C.byref(found), C.byref(nt))

@@ -34,6 +34,15 @@ __global__ void __launch_bounds__(kGroup, 2) dtrl_frame_kernel_fast(const DevMod
 #endif
 }
 
+// dst[i] = idx[i] >= 0 ? src[idx[i]] : 0: re-lays a policy blob handed over in device memory into the kernel's weight layout
+__global__ void dtrl_gather_f32(float* __restrict__ dst, const float* __restrict__ src, const int32_t* __restrict__ idx, size_t n)
+{
+	for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+		const int32_t k = idx[i];
+		dst[i] = k >= 0 ? src[k] : 0.0f;
+	}
+}
+
 class HipBackend : public Backend {
 public:
 	~HipBackend() override
@@ -68,6 +77,12 @@ public:
 	void* HostStaging(size_t bytes) override { void* p = nullptr; return Check(hipHostMalloc(&p, bytes, hipHostMallocDefault), "hipHostMalloc") ? p : nullptr; }
 	void FreeHostStaging(void* p) override { if (p) hipHostFree(p); }
 	bool D2H(void* dst, const void* src, size_t n) override { return Check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream_), "hipMemcpy D2H") && Check(hipStreamSynchronize(stream_), "sync"); }
+	bool D2D(void* dst, const void* src, size_t n) override { return Check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, stream_), "hipMemcpy D2D") && Check(hipStreamSynchronize(stream_), "sync"); }
+	bool GatherF32(float* dst, const float* src, const int32_t* idx, size_t n) override
+	{
+		hipLaunchKernelGGL(dtrl_gather_f32, dim3(1024), dim3(256), 0, stream_, dst, src, idx, n);
+		return Check(hipGetLastError(), "gather launch") && Check(hipStreamSynchronize(stream_), "sync");
+	}
 	bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) override
 	{
 		// only stepping launches are timed (the compact 0-step reset launches would skew the per-frame average)
@@ -87,7 +102,11 @@ public:
 			hipLaunchKernelGGL(dtrl_frame_kernel_fast<TopoRaptor>, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
 		else
 			hipLaunchKernelGGL(dtrl_frame_kernel, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
-		if (timed) { hipEventRecord(ev.second, stream_); pending_.push_back(ev); }
+		if (timed) {
+			hipEventRecord(ev.second, stream_); pending_.push_back(ev);
+			// a long run never asks for the timing: fold finished pairs into the running sum so the event pool stays bounded
+			if (pending_.size() > kMaxPendingEvents) FoldFinished(false);
+		}
 		return Check(hipGetLastError(), "kernel launch");
 	}
 	bool Sync() override { bool ok = true; for (hipStream_t st : streams_) ok = Check(hipStreamSynchronize(st), "hipStreamSynchronize") && ok; return ok; }
@@ -97,14 +116,29 @@ public:
 	void KernelTime(double* avg_ms, int64_t* launches) override
 	{
 		for (hipStream_t st : streams_) hipStreamSynchronize(st);
-		double sum = 0; int64_t n = 0;
-		for (auto& ev : pending_) { float ms = 0; if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { sum += ms; ++n; } free_events_.push_back(ev); }
-		pending_.clear();
-		if (avg_ms) *avg_ms = n > 0 ? sum / n : 0.0;
-		if (launches) *launches = n;
+		FoldFinished(true);
+		if (avg_ms) *avg_ms = time_n_ > 0 ? time_sum_ms_ / time_n_ : 0.0;
+		if (launches) *launches = time_n_;
+		time_sum_ms_ = 0; time_n_ = 0;
 	}
 	const char* Name() const override { return "hip"; }
 private:
+	// move the event pairs whose launch has completed (all of them when `all`: the streams were synchronised) into the running sum
+	void FoldFinished(bool all)
+	{
+		size_t keep = 0;
+		for (size_t i = 0; i < pending_.size(); ++i) {
+			auto& ev = pending_[i];
+			if (all || hipEventQuery(ev.second) == hipSuccess) {
+				float ms = 0;
+				if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { time_sum_ms_ += ms; ++time_n_; }
+				free_events_.push_back(ev);
+			} else pending_[keep++] = ev;
+		}
+		pending_.resize(keep);
+	}
+	static constexpr size_t kMaxPendingEvents = 64;
+	double time_sum_ms_ = 0; int64_t time_n_ = 0;
 	bool Check(hipError_t e, const char* what) { if (e == hipSuccess) return true; err_ = std::string(what) + ": " + hipGetErrorString(e); return false; }
 	static constexpr int kNumStreams = 8;
 	std::vector<hipStream_t> streams_;

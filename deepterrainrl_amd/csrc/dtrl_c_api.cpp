@@ -4,6 +4,9 @@
 #include <cmath>
 #include <cstdio>
 #include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
 
 using dtrl::Engine;
 using dtrl::EnvState;
@@ -12,14 +15,29 @@ struct dtrl_batch { Engine eng; };
 
 static thread_local std::string g_create_error;
 
+// nothing may propagate across the C boundary (the reference's convention is bool + message, no exceptions): allocation failures and
+// anything else thrown below the ABI become a status code and a message
+static int dtrl_on_exception(const dtrl_batch* b)
+{
+	std::string msg = "internal error";
+	int code = DTRL_ERR_DEVICE;
+	try { throw; }
+	catch (const std::bad_alloc&) { msg = "out of host memory"; code = DTRL_ERR_CAPACITY; }
+	catch (const std::length_error& e) { msg = std::string("invalid size: ") + e.what(); code = DTRL_ERR_ARG; }
+	catch (const std::exception& e) { msg = std::string("internal error: ") + e.what(); }
+	catch (...) {}
+	if (b) const_cast<dtrl_batch*>(b)->eng.set_error(msg); else g_create_error = msg;
+	return code;
+}
+
 extern "C" {
 
-const char* dtrl_version(void) { return "dtrl-mi355x 0.1 (round 1)"; }
+const char* dtrl_version(void) { return "dtrl-mi355x 0.2 (round 2)"; }
 
 const char* dtrl_last_error(const dtrl_batch* b) { return b ? b->eng.error().c_str() : g_create_error.c_str(); }
 
 dtrl_status dtrl_create(const char* const* argv, int argc, int num_envs, int device_id, dtrl_batch** out)
-{
+try {
 	if (!out) return DTRL_ERR_ARG;
 	*out = nullptr;
 	dtrl_batch* b = new (std::nothrow) dtrl_batch();
@@ -28,65 +46,65 @@ dtrl_status dtrl_create(const char* const* argv, int argc, int num_envs, int dev
 	if (rc != DTRL_OK) { g_create_error = b->eng.error(); delete b; return static_cast<dtrl_status>(rc); }
 	*out = b;
 	return DTRL_OK;
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(nullptr)); }
 dtrl_status dtrl_destroy(dtrl_batch* b) { delete b; return DTRL_OK; }
 
 #define CHECK_B() do { if (!b) return DTRL_ERR_ARG; } while (0)
 
-dtrl_status dtrl_reset(dtrl_batch* b, const int32_t* env_ids, int n, const uint64_t* seeds) { CHECK_B(); return static_cast<dtrl_status>(b->eng.Reset(env_ids, n, seeds)); }
-dtrl_status dtrl_step(dtrl_batch* b, double dt) { CHECK_B(); return static_cast<dtrl_status>(b->eng.Step(dt)); }
-dtrl_status dtrl_step_begin(dtrl_batch* b, double dt) { CHECK_B(); return static_cast<dtrl_status>(b->eng.StepBegin(dt)); }
-dtrl_status dtrl_step_end(dtrl_batch* b) { CHECK_B(); return static_cast<dtrl_status>(b->eng.StepEnd()); }
-dtrl_status dtrl_step_updates(dtrl_batch* b, int n) { CHECK_B(); return static_cast<dtrl_status>(b->eng.StepUpdates(n)); }
-dtrl_status dtrl_run_frames(dtrl_batch* b, int frames, double dt) { CHECK_B(); return static_cast<dtrl_status>(b->eng.RunFrames(frames, dt)); }
+dtrl_status dtrl_reset(dtrl_batch* b, const int32_t* env_ids, int n, const uint64_t* seeds) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.Reset(env_ids, n, seeds)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_step(dtrl_batch* b, double dt) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.Step(dt)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_step_begin(dtrl_batch* b, double dt) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.StepBegin(dt)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_step_end(dtrl_batch* b) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.StepEnd()); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_step_updates(dtrl_batch* b, int n) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.StepUpdates(n)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_run_frames(dtrl_batch* b, int frames, double dt) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.RunFrames(frames, dt)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_set_policy(dtrl_batch* b, const float* w, size_t n, const double* io, const double* is, const double* oo, const double* os)
-{
+try {
 	CHECK_B(); return static_cast<dtrl_status>(b->eng.SetPolicy(w, n, io, is, oo, os));
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_policy_num_params(const dtrl_batch* b, size_t* n)
-{
+try {
 	CHECK_B(); if (!b->eng.cfg().has_policy_net) { *n = 0; return DTRL_OK; }
 	*n = static_cast<size_t>(b->eng.cfg().user_num_params); return DTRL_OK;
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_build_output_offset_scale(const dtrl_batch* b, double* out_off, double* out_scale)
-{
+try {
 	CHECK_B();
 	if (!b->eng.cfg().has_policy_net) return DTRL_ERR_ARG;
 	std::vector<double> off, sc;
 	dtrl::BuildOutputOffsetScale(b->eng.cfg().model, b->eng.cfg().net, off, sc);
 	for (size_t i = 0; i < off.size(); ++i) { out_off[i] = off[i]; out_scale[i] = sc[i]; }
 	return DTRL_OK;
-}
-dtrl_status dtrl_load_scale_file(dtrl_batch* b, const char* path) { CHECK_B(); return static_cast<dtrl_status>(b->eng.LoadScaleFile(path)); }
-dtrl_status dtrl_write_scale_file(dtrl_batch* b, const char* path) { CHECK_B(); return static_cast<dtrl_status>(b->eng.WriteScaleFile(path)); }
-dtrl_status dtrl_set_explore(dtrl_batch* b, int enable, double rate, double temp, double base_rate) { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetExplore(enable, rate, temp, base_rate)); }
-dtrl_status dtrl_set_terrain_lerp(dtrl_batch* b, double lerp) { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetTerrainLerp(lerp)); }
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_load_scale_file(dtrl_batch* b, const char* path) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.LoadScaleFile(path)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_write_scale_file(dtrl_batch* b, const char* path) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.WriteScaleFile(path)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_set_explore(dtrl_batch* b, int enable, double rate, double temp, double base_rate) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetExplore(enable, rate, temp, base_rate)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_set_terrain_lerp(dtrl_batch* b, double lerp) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetTerrainLerp(lerp)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_drain_tuples(dtrl_batch* b, float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n)
-{
+try {
 	CHECK_B(); return static_cast<dtrl_status>(b->eng.DrainTuples(rows, flags, env_ids, cap, out_n));
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 
 dtrl_status dtrl_get_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, double* q, double* qd)
-{
+try {
 	CHECK_B();
 	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
 	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
 	const int D = b->eng.cfg().model.D;
 	for (int i = 0; i < n; ++i) for (int k = 0; k < D; ++k) { if (q) q[i * D + k] = st[i].q[k]; if (qd) qd[i * D + k] = st[i].qd[k]; }
 	return DTRL_OK;
-}
-dtrl_status dtrl_set_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, const double* q, const double* qd) { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetPoseVel(env_ids, n, q, qd)); }
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_set_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, const double* q, const double* qd) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetPoseVel(env_ids, n, q, qd)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_add_perturb(dtrl_batch* b, const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration)
-{
+try {
 	CHECK_B();
 	if (!link || !force || !duration) { b->eng.set_error("dtrl_add_perturb: link, force and duration are required"); return DTRL_ERR_ARG; }
 	return static_cast<dtrl_status>(b->eng.AddPerturb(env_ids, n, link, local_pos, force, duration));
-}
-dtrl_status dtrl_apply_rand_force(dtrl_batch* b, const int32_t* env_ids, int n, uint64_t seed) { CHECK_B(); return static_cast<dtrl_status>(b->eng.ApplyRandForce(env_ids, n, seed)); }
-dtrl_status dtrl_get_poli_state(dtrl_batch* b, const int32_t* env_ids, int n, double* s) { CHECK_B(); return static_cast<dtrl_status>(b->eng.GetPoliState(env_ids, n, s)); }
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_apply_rand_force(dtrl_batch* b, const int32_t* env_ids, int n, uint64_t seed) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.ApplyRandForce(env_ids, n, seed)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_get_poli_state(dtrl_batch* b, const int32_t* env_ids, int n, double* s) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.GetPoliState(env_ids, n, s)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 
 dtrl_status dtrl_get_flags(dtrl_batch* b, const int32_t* env_ids, int n, uint32_t* bits)
-{
+try {
 	CHECK_B();
 	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
 	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
@@ -103,18 +121,18 @@ dtrl_status dtrl_get_flags(dtrl_batch* b, const int32_t* env_ids, int n, uint32_
 		bits[i] = (fallen ? DTRL_FLAG_FALLEN : 0u) | (stumbled ? DTRL_FLAG_STUMBLED : 0u) | (new_cycle ? DTRL_FLAG_NEW_CYCLE : 0u) | (static_cast<uint32_t>(s.state) << DTRL_FLAG_STATE_SHIFT);
 	}
 	return DTRL_OK;
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_get_torques(dtrl_batch* b, const int32_t* env_ids, int n, double* tau_ctrl, double* tau_applied)
-{
+try {
 	CHECK_B();
 	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
 	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
 	const int D = b->eng.cfg().model.D;
 	for (int i = 0; i < n; ++i) for (int k = 0; k < D; ++k) { if (tau_ctrl) tau_ctrl[i * D + k] = st[i].tau_ctrl[k]; if (tau_applied) tau_applied[i * D + k] = st[i].tau[k]; }
 	return DTRL_OK;
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_get_link_states(dtrl_batch* b, const int32_t* env_ids, int n, double* com_xy, double* com_vel_xy, double* angle)
-{
+try {
 	CHECK_B();
 	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
 	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
@@ -142,18 +160,18 @@ dtrl_status dtrl_get_link_states(dtrl_batch* b, const int32_t* env_ids, int n, d
 		}
 	}
 	return DTRL_OK;
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_get_contacts(dtrl_batch* b, const int32_t* env_ids, int n, int32_t* flags)
-{
+try {
 	CHECK_B();
 	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
 	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
 	const int L = b->eng.cfg().model.L;
 	for (int i = 0; i < n; ++i) for (int j = 0; j < L; ++j) flags[i * L + j] = (st[i].contact_bits >> j) & 1u;
 	return DTRL_OK;
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_get_ctrl(dtrl_batch* b, const int32_t* env_ids, int n, int32_t* state, double* phase, int32_t* action_id, double* params, double* pd_targets)
-{
+try {
 	CHECK_B();
 	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
 	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
@@ -166,9 +184,9 @@ dtrl_status dtrl_get_ctrl(dtrl_batch* b, const int32_t* env_ids, int n, int32_t*
 		if (pd_targets) for (int j = 0; j < L; ++j) pd_targets[i * L + j] = st[i].pd_target[j];
 	}
 	return DTRL_OK;
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_get_cycle_info(dtrl_batch* b, const int32_t* env_ids, int n, int64_t* num_cycles, int64_t* num_resets, double* cycle_start_com, double* cycle_start_time, double* opt_params)
-{
+try {
 	CHECK_B();
 	std::vector<EnvState> st; int rc = b->eng.GetStates(env_ids, n, st);
 	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
@@ -181,9 +199,9 @@ dtrl_status dtrl_get_cycle_info(dtrl_batch* b, const int32_t* env_ids, int n, in
 		if (opt_params) for (int k = 0; k < m.n_opt; ++k) opt_params[static_cast<size_t>(i) * m.n_opt + k] = st[i].params[m.opt_index[k]];
 	}
 	return DTRL_OK;
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_get_action_table(dtrl_batch* b, int* n_actions, double* table)
-{
+try {
 	CHECK_B();
 	const dtrl::DevModel& m = b->eng.cfg().model;
 	if (n_actions) *n_actions = m.n_actions;
@@ -192,14 +210,14 @@ dtrl_status dtrl_get_action_table(dtrl_batch* b, int* n_actions, double* table)
 		for (int k = 0; k < m.n_opt; ++k) { const int i = m.opt_index[k]; table[static_cast<size_t>(a) * m.n_opt + k] = (1 - bl) * p0[i] + bl * p1[i]; }
 	}
 	return DTRL_OK;
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_sample_ground(dtrl_batch* b, int env, int n, const double* x, double* h, int32_t* seg, int32_t* i, int32_t* j)
-{
+try {
 	CHECK_B(); return static_cast<dtrl_status>(b->eng.SampleGround(env, n, x, h, seg, i, j));
-}
-dtrl_status dtrl_eval_stats(dtrl_batch* b, double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets) { CHECK_B(); return static_cast<dtrl_status>(b->eng.EvalStats(avg_dist, episodes, cycles, resets)); }
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_eval_stats(dtrl_batch* b, double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.EvalStats(avg_dist, episodes, cycles, resets)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_dims(const dtrl_batch* b, int* L, int* D, int* S, int* A, int* P, int* nn_out, int* num_frags, int* frag_size)
-{
+try {
 	CHECK_B();
 	const dtrl::ScenarioConfig& c = b->eng.cfg();
 	if (L) *L = c.model.L;
@@ -211,11 +229,43 @@ dtrl_status dtrl_dims(const dtrl_batch* b, int* L, int* D, int* S, int* A, int* 
 	if (num_frags) *num_frags = (c.has_policy_net && !c.actor_only) ? c.net.n_frags : 0;
 	if (frag_size) *frag_size = c.model.n_opt;
 	return DTRL_OK;
-}
-dtrl_status dtrl_kernel_time_ms(dtrl_batch* b, double* avg_ms, int64_t* launches) { CHECK_B(); return static_cast<dtrl_status>(b->eng.KernelTime(avg_ms, launches)); }
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_kernel_time_ms(dtrl_batch* b, double* avg_ms, int64_t* launches) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.KernelTime(avg_ms, launches)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+
+dtrl_status dtrl_drain_tuples_device(dtrl_batch* b, float* rows_dev, uint32_t* flags_dev, int32_t* env_ids_dev, int cap, int* out_n)
+try {
+	CHECK_B(); return static_cast<dtrl_status>(b->eng.DrainTuples(rows_dev, flags_dev, env_ids_dev, cap, out_n, true));
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_tuple_stats(dtrl_batch* b, int64_t* pending, int64_t* drained, int64_t* dropped, int32_t* capacity) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.TupleStats(pending, drained, dropped, capacity)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_set_policy_device(dtrl_batch* b, const float* w_dev, size_t n, const double* io_dev, const double* is_dev, const double* oo_dev, const double* os_dev)
+try {
+	CHECK_B(); return static_cast<dtrl_status>(b->eng.SetPolicyDevice(w_dev, n, io_dev, is_dev, oo_dev, os_dev));
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_get_dist_log(dtrl_batch* b, double* dist, int32_t* env_ids, int cap, int* out_n) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.GetDistLog(dist, env_ids, cap, out_n)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_reset_avg_dist(dtrl_batch* b) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.ResetAvgDist()); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+// cOptScenarioPoliEval::OutputResults (optimizer/scenarios/OptScenarioPoliEval.cpp:213-239): one line appended to `path`, the distances of every
+// recorded episode pool member by pool member, std::to_string formatting, ", " separated
+dtrl_status dtrl_write_dist_log(dtrl_batch* b, const char* path)
+try {
+	CHECK_B();
+	if (!path) { b->eng.set_error("null path"); return DTRL_ERR_ARG; }
+	int n = 0;
+	int rc = b->eng.GetDistLog(nullptr, nullptr, 0, &n);
+	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
+	std::vector<double> d(static_cast<size_t>(n));
+	rc = b->eng.GetDistLog(d.data(), nullptr, n, &n);
+	if (rc != DTRL_OK) return static_cast<dtrl_status>(rc);
+	std::string str;
+	for (int i = 0; i < n; ++i) { if (!str.empty()) str += ", "; str += std::to_string(d[i]); }
+	str += "\n";
+	FILE* f = std::fopen(path, "a");   // cFileUtil::AppendText
+	if (!f) { b->eng.set_error(std::string("Failed to output results to ") + path); return DTRL_ERR_IO; }
+	std::fputs(str.c_str(), f); std::fclose(f);
+	return DTRL_OK;
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 
 dtrl_status dtrl_terrain_build(const char* type_name, const double* params40, uint64_t seed, double width, float* out, int cap, int* out_n, double* out_width)
-{
+try {
 	if (!type_name || !params40 || !out_n || cap < 0 || (cap > 0 && !out)) return DTRL_ERR_ARG;
 	std::string name = type_name;
 	if (name.empty()) name = "flat";   // cTerrainGen2D::ParseType: "" == flat
@@ -229,9 +279,9 @@ dtrl_status dtrl_terrain_build(const char* type_name, const double* params40, ui
 	if (out_width) *out_width = w;
 	for (int i = 0; i < *out_n && i < cap; ++i) out[i] = data[i];
 	return *out_n <= cap ? DTRL_OK : DTRL_ERR_CAPACITY;
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(nullptr)); }
 dtrl_status dtrl_terrain_load_file(const char* path, char* type_out, int type_cap, double* params_out, int max_sets, int* out_sets)
-{
+try {
 	if (!path || !out_sets) return DTRL_ERR_ARG;
 	dtrl::Json tf; std::string err;
 	if (!dtrl::Json::parse_file(path, tf, err)) { g_create_error = err; return DTRL_ERR_IO; }
@@ -247,9 +297,9 @@ dtrl_status dtrl_terrain_load_file(const char* path, char* type_out, int type_ca
 	}
 	*out_sets = n;
 	return DTRL_OK;
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(nullptr)); }
 dtrl_status dtrl_args_parse_string(const char* const* argv, int argc, const char* key, char* out, int cap, int* found, int* n_tokens)
-{
+try {
 	if (!key || !found || argc < 0 || (argc > 0 && !argv)) return DTRL_ERR_ARG;
 	dtrl::ArgParser args(argv, argc);
 	std::string arg_file;
@@ -263,9 +313,9 @@ dtrl_status dtrl_args_parse_string(const char* const* argv, int argc, const char
 	if (out && cap > 0) std::snprintf(out, static_cast<size_t>(cap), "%s", *found ? v.c_str() : "");
 	if (n_tokens) *n_tokens = args.GetNumArgs();
 	return DTRL_OK;
-}
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(nullptr)); }
 
 // not part of include/dtrl.h: developer hook used by tools/gpu_sections.py with the DTRL_PROFILE build
-int dtrlx_profile_sections(dtrl_batch* b, unsigned long long* out, int cap) { return b ? b->eng.ProfileSections(out, cap) : 1; }
+int dtrlx_profile_sections(dtrl_batch* b, unsigned long long* out, int cap) try { return b ? b->eng.ProfileSections(out, cap) : 1; } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 
 }  // extern "C"

@@ -81,7 +81,9 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	buf_.tup_a = static_cast<real*>(alloc(sizeof(real) * A_ * n_));
 	buf_.S = S_; buf_.A = A_; buf_.W = W_; buf_.model_D = m.D; buf_.model_topo = match_topology(m.parent, m.L);
 	// a tuple per env per cycle (~13 frames) at most; room for 2 per env between drains, at least the reference's ring size
+	// (-tuple_ring_capacity= overrides; dtrl_tuple_stats reports how many rows were dropped because the ring was full)
 	buf_.tuple_cap = std::max(2 * n_, cfg_.tuple_buffer_size);
+	if (cfg_.tuple_ring_capacity > 0) buf_.tuple_cap = cfg_.tuple_ring_capacity;
 	buf_.tuple_rows = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(W_) * buf_.tuple_cap));
 	buf_.tuple_flags = static_cast<uint32_t*>(alloc(sizeof(uint32_t) * buf_.tuple_cap));
 	buf_.tuple_env = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
@@ -122,6 +124,9 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 		if (!buf_.nn_scratch || !buf_.nn_out || !w_dev || !io || !is || !oo || !os) return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
 		buf_.weights = w_dev; buf_.in_off = io; buf_.in_scale = is; buf_.out_off = oo; buf_.out_scale = os;
 		cfg_.model.has_net = 1;
+		BuildRelayoutMap(relayout_);
+		d_relayout_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * relayout_.size()));
+		if (!d_relayout_ || !be_->H2D(d_relayout_, relayout_.data(), sizeof(int32_t) * relayout_.size())) return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
 	}
 	if (!be_->H2D(d_model_, &cfg_.model, sizeof(DevModel))) return Fail(DTRL_ERR_DEVICE, be_->error());
 
@@ -217,6 +222,7 @@ int Engine::HostFrameWork(int group)
 	for (int e = e0; e < e1; ++e) {
 		const EnvStatus& s = status_[e];
 		GroundWindow& g = grounds_[e];
+		if (s.need_reset & 2) dist_log_.emplace_back(e, s.episode_dist);   // cScenarioPoliEval::RecordDistTraveled -> mDistLog
 		if (s.need_reset) {
 			// cScenarioSimChar::ResetGround: Clear + Update around the spawn point -> InitSegments with the SAME rng stream
 			g.Clear();
@@ -307,12 +313,17 @@ int Engine::RunFrames(int frames, double dt)
 
 int Engine::Reset(const int32_t* env_ids, int n, const uint64_t* seeds)
 {
+	if (env_ids && n < 0) return Fail(DTRL_ERR_ARG, "negative env count");
 	be_->Sync();
 	const int cnt = env_ids ? n : n_;
 	reset_ids_.clear();
+	// an env listed twice is reset once (its first seed wins): the reset list feeds buffers sized for num_envs entries
+	std::vector<char> seen(static_cast<size_t>(n_), 0);
 	for (int i = 0; i < cnt; ++i) {
 		int e = EnvIndex(env_ids, i);
 		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
+		if (seen[e]) continue;
+		seen[e] = 1;
 		GroundWindow& g = grounds_[e];
 		if (seeds) g.SeedRand(static_cast<unsigned long>(seeds[i]));
 		g.Clear();
@@ -326,57 +337,86 @@ int Engine::Reset(const int32_t* env_ids, int n, const uint64_t* seeds)
 	return DTRL_OK;
 }
 
+// device weight layout (dtrl_kernel.h conv_layer / fc_layer) as an index map into the caller's blob (Caffe blob order of the deploy net, W then b
+// per layer): conv blobs [cout][cin][k] -> [cin][k][cout]; InnerProduct blobs [nout][nin] -> [ceil(nin/4)][nout][4] (zero padded); biases
+// unchanged; same blob order. -1 = a padding / zero entry. CACLA actor: the all-zero critic head (val_ip0, val_ip1) is inserted behind the
+// trunk so that the device sees a one-fragment MACE net; the boundary keeps the actor's blob order and sizes.
+void Engine::BuildRelayoutMap(std::vector<int32_t>& map) const
+{
+	const NetDesc& d = cfg_.net;
+	map.assign(static_cast<size_t>(DevNumParams(d)), -1);
+	const size_t n_user = static_cast<size_t>(cfg_.user_num_params);
+	const size_t head = static_cast<size_t>(d.fc_head) * d.fc_trunk + d.fc_head + d.fc_head + 1;
+	const size_t tail = static_cast<size_t>(d.fc_head) * d.fc_trunk + d.fc_head + static_cast<size_t>(d.frag_size) * d.fc_head + d.frag_size;   // ip2, output
+	// index into the MACE-ordered (padded) blob -> index into the caller's blob
+	auto user = [&](size_t p) -> int32_t {
+		if (!cfg_.actor_only) return static_cast<int32_t>(p);
+		if (p < n_user - tail) return static_cast<int32_t>(p);
+		if (p < n_user - tail + head) return -1;
+		return static_cast<int32_t>(p - head);
+	};
+	size_t src = 0, dst = 0; int cin = 1, wdt = d.n_terrain;
+	for (int l = 0; l < 3; ++l) {
+		const int co = d.conv_ch[l], k = d.conv_k[l];
+		for (int o = 0; o < co; ++o) for (int c = 0; c < cin; ++c) for (int u = 0; u < k; ++u)
+			map[dst + (static_cast<size_t>(c) * k + u) * co + o] = user(src + (static_cast<size_t>(o) * cin + c) * k + u);
+		src += static_cast<size_t>(co) * cin * k; dst += static_cast<size_t>(pad4(static_cast<int64_t>(co) * cin * k));
+		for (int o = 0; o < co; ++o) map[dst + o] = user(src + o);
+		src += co; dst += static_cast<size_t>(pad4(co)); cin = co; wdt = wdt - k + 1;
+	}
+	auto block = [&](int nout, int nin) {
+		for (int o = 0; o < nout; ++o) for (int i = 0; i < nin; ++i)
+			map[dst + (static_cast<size_t>(i / 4) * nout + o) * 4 + (i % 4)] = user(src + static_cast<size_t>(o) * nin + i);
+		src += static_cast<size_t>(nout) * nin; dst += static_cast<size_t>(fc_dev_size(nout, nin));
+		for (int o = 0; o < nout; ++o) map[dst + o] = user(src + o);
+		src += nout; dst += static_cast<size_t>(pad4(nout));
+	};
+	block(d.fc_terr, cin * wdt);
+	block(d.fc_trunk, d.fc_terr + d.n_char);
+	block(d.fc_head, d.fc_trunk); block(d.n_frags, d.fc_head);
+	for (int f = 0; f < d.n_frags; ++f) { block(d.fc_head, d.fc_trunk); block(d.frag_size, d.fc_head); }
+}
+
 int Engine::SetPolicy(const float* w, size_t n, const double* io, const double* is, const double* oo, const double* os)
 {
 	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
 	const NetDesc& d = cfg_.net;
-	if (n != static_cast<size_t>(cfg_.user_num_params)) return Fail(DTRL_ERR_ARG, "weight count does not match the deploy prototxt");
+	if (!w || n != static_cast<size_t>(cfg_.user_num_params)) return Fail(DTRL_ERR_ARG, "weight count does not match the deploy prototxt");
 	be_->Sync();
-	// CACLA actor: insert the all-zero critic head (val_ip0, val_ip1) behind the trunk and a neutral critic slot in front of the output
-	// normalisers, so that the device sees a one-fragment MACE net; the boundary keeps the actor's blob order and sizes
-	std::vector<float> w_pad; std::vector<double> oo_pad, os_pad;
-	if (cfg_.actor_only) {
-		const size_t head = static_cast<size_t>(d.fc_head) * d.fc_trunk + d.fc_head + d.fc_head + 1;
-		const size_t tail = static_cast<size_t>(d.fc_head) * d.fc_trunk + d.fc_head + static_cast<size_t>(d.frag_size) * d.fc_head + d.frag_size;   // ip2, output
-		w_pad.assign(w, w + (n - tail)); w_pad.insert(w_pad.end(), head, 0.0f); w_pad.insert(w_pad.end(), w + (n - tail), w + n);
-		w = w_pad.data(); n = w_pad.size();
-		if (oo) { oo_pad.assign(1, 0.0); oo_pad.insert(oo_pad.end(), oo, oo + d.frag_size); oo = oo_pad.data(); }
-		if (os) { os_pad.assign(1, 1.0); os_pad.insert(os_pad.end(), os, os + d.frag_size); os = os_pad.data(); }
-	}
-	// device layout (dtrl_kernel.h conv_layer/fc_layer): conv blobs [cout][cin][k] -> [cin][k][cout]; InnerProduct blobs
-	// [nout][nin] -> [ceil(nin/4)][nout][4] (zero padded); biases unchanged; same blob order.
-	std::vector<float> dev_w(static_cast<size_t>(DevNumParams(d)), 0.0f);
-	{
-		size_t src = 0, dst = 0; int cin = 1, wdt = d.n_terrain;
-		for (int l = 0; l < 3; ++l) {
-			const int co = d.conv_ch[l], k = d.conv_k[l];
-			for (int o = 0; o < co; ++o) for (int c = 0; c < cin; ++c) for (int u = 0; u < k; ++u)
-				dev_w[dst + (static_cast<size_t>(c) * k + u) * co + o] = w[src + (static_cast<size_t>(o) * cin + c) * k + u];
-			src += static_cast<size_t>(co) * cin * k; dst += static_cast<size_t>(pad4(static_cast<int64_t>(co) * cin * k));
-			for (int o = 0; o < co; ++o) dev_w[dst + o] = w[src + o];
-			src += co; dst += static_cast<size_t>(pad4(co)); cin = co; wdt = wdt - k + 1;
-		}
-		auto block = [&](int nout, int nin) {
-			for (int o = 0; o < nout; ++o) for (int i = 0; i < nin; ++i)
-				dev_w[dst + (static_cast<size_t>(i / 4) * nout + o) * 4 + (i % 4)] = w[src + static_cast<size_t>(o) * nin + i];
-			src += static_cast<size_t>(nout) * nin; dst += static_cast<size_t>(fc_dev_size(nout, nin));
-			for (int o = 0; o < nout; ++o) dev_w[dst + o] = w[src + o];
-			src += nout; dst += static_cast<size_t>(pad4(nout));
-		};
-		block(d.fc_terr, cin * wdt);
-		block(d.fc_trunk, d.fc_terr + d.n_char);
-		block(d.fc_head, d.fc_trunk); block(d.n_frags, d.fc_head);
-		for (int f = 0; f < d.n_frags; ++f) { block(d.fc_head, d.fc_trunk); block(d.frag_size, d.fc_head); }
-	}
-	w = dev_w.data();
+	std::vector<float> dev_w(relayout_.size());
+	for (size_t i = 0; i < relayout_.size(); ++i) dev_w[i] = relayout_[i] >= 0 ? w[relayout_[i]] : 0.0f;
+	// CACLA actor: a neutral critic slot in front of the output normalisers (the device net's one zero critic output)
+	const int pad = d.out_size - cfg_.user_out_size;
 	// cNeuralNet without a scale file: identity normalisation (learning/NeuralNet.cpp:925-933) for every vector passed as NULL
 	if (io) in_off_.assign(io, io + d.in_size); else in_off_.assign(d.in_size, 0.0);
 	if (is) in_scale_.assign(is, is + d.in_size); else in_scale_.assign(d.in_size, 1.0);
-	if (oo) out_off_.assign(oo, oo + d.out_size); else out_off_.assign(d.out_size, 0.0);
-	if (os) out_scale_.assign(os, os + d.out_size); else out_scale_.assign(d.out_size, 1.0);
-	if (!be_->H2D(const_cast<float*>(buf_.weights), w, sizeof(float) * dev_w.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
+	out_off_.assign(d.out_size, 0.0); out_scale_.assign(d.out_size, 1.0);
+	if (oo) std::copy(oo, oo + cfg_.user_out_size, out_off_.begin() + pad);
+	if (os) std::copy(os, os + cfg_.user_out_size, out_scale_.begin() + pad);
+	if (!be_->H2D(const_cast<float*>(buf_.weights), dev_w.data(), sizeof(float) * dev_w.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
 	int rc = UploadNormalizers();
 	if (rc != DTRL_OK) return rc;
+	policy_set_ = true;
+	return DTRL_OK;
+}
+
+// dtrl_set_policy with every pointer in DEVICE memory (the trainer's own tensors): no host round trip. Weights are gathered into the
+// device layout by a kernel; NULL normalisers keep their current values.
+int Engine::SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, const double* is_dev, const double* oo_dev, const double* os_dev)
+{
+	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
+	const NetDesc& d = cfg_.net;
+	if (!w_dev || n != static_cast<size_t>(cfg_.user_num_params)) return Fail(DTRL_ERR_ARG, "weight count does not match the deploy prototxt");
+	be_->Sync();
+	if (!be_->GatherF32(const_cast<float*>(buf_.weights), w_dev, d_relayout_, relayout_.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (in_off_.empty()) { in_off_.assign(d.in_size, 0.0); in_scale_.assign(d.in_size, 1.0); out_off_.assign(d.out_size, 0.0); out_scale_.assign(d.out_size, 1.0); int rc = UploadNormalizers(); if (rc != DTRL_OK) return rc; }
+	const int pad = d.out_size - cfg_.user_out_size;
+	bool ok = true;
+	if (io_dev) ok = ok && be_->D2D(const_cast<real*>(buf_.in_off), io_dev, sizeof(real) * d.in_size) && be_->D2H(in_off_.data(), buf_.in_off, sizeof(real) * d.in_size);
+	if (is_dev) ok = ok && be_->D2D(const_cast<real*>(buf_.in_scale), is_dev, sizeof(real) * d.in_size) && be_->D2H(in_scale_.data(), buf_.in_scale, sizeof(real) * d.in_size);
+	if (oo_dev) ok = ok && be_->D2D(const_cast<real*>(buf_.out_off) + pad, oo_dev, sizeof(real) * cfg_.user_out_size) && be_->D2H(out_off_.data(), buf_.out_off, sizeof(real) * d.out_size);
+	if (os_dev) ok = ok && be_->D2D(const_cast<real*>(buf_.out_scale) + pad, os_dev, sizeof(real) * cfg_.user_out_size) && be_->D2H(out_scale_.data(), buf_.out_scale, sizeof(real) * d.out_size);
+	if (!ok) return Fail(DTRL_ERR_DEVICE, be_->error());
 	policy_set_ = true;
 	return DTRL_OK;
 }
@@ -449,27 +489,73 @@ int Engine::SetTerrainLerp(double lerp)
 	return DTRL_OK;
 }
 
-int Engine::DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n)
+// rows the kernel could not store because the ring was full are counted, never silently lost: the cursor keeps counting past the capacity
+int Engine::PendingTuples(int32_t* stored, int32_t* overflow)
 {
 	int32_t cnt = 0;
 	be_->Sync();
 	if (!be_->D2H(&cnt, buf_.tuple_count, sizeof(cnt))) return Fail(DTRL_ERR_DEVICE, be_->error());
-	if (cnt > buf_.tuple_cap) cnt = buf_.tuple_cap;   // overflowed tuples were dropped by the kernel
+	*overflow = cnt > buf_.tuple_cap ? cnt - buf_.tuple_cap : 0;
+	*stored = cnt - *overflow;
+	return DTRL_OK;
+}
+int Engine::DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n, bool device_dst)
+{
+	if (cap < 0 || !out_n || (cap > 0 && !rows)) return Fail(DTRL_ERR_ARG, "bad arguments");
+	int32_t cnt = 0, over = 0;
+	int rc = PendingTuples(&cnt, &over);
+	if (rc != DTRL_OK) return rc;
 	int n = std::min<int>(cnt, cap);
-	if (n > 0) {
-		if (!be_->D2H(rows, buf_.tuple_rows, sizeof(float) * static_cast<size_t>(W_) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
-		if (flags && !be_->D2H(flags, buf_.tuple_flags, sizeof(uint32_t) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
-		if (env_ids && !be_->D2H(env_ids, buf_.tuple_env, sizeof(int32_t) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
-	}
 	if (n < cnt) return Fail(DTRL_ERR_CAPACITY, "caller buffer smaller than the number of pending tuples");
+	if (n > 0) {
+		auto copy = [&](void* dst, const void* src, size_t bytes) { return device_dst ? be_->D2D(dst, src, bytes) : be_->D2H(dst, src, bytes); };
+		if (!copy(rows, buf_.tuple_rows, sizeof(float) * static_cast<size_t>(W_) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (flags && !copy(flags, buf_.tuple_flags, sizeof(uint32_t) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (env_ids && !copy(env_ids, buf_.tuple_env, sizeof(int32_t) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	}
 	const int32_t zero = 0;
 	if (!be_->H2D(buf_.tuple_count, &zero, sizeof(zero))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	tuples_drained_ += n; tuples_dropped_ += over;
 	*out_n = n;
+	return DTRL_OK;
+}
+int Engine::TupleStats(int64_t* pending, int64_t* drained, int64_t* dropped, int32_t* capacity)
+{
+	int32_t cnt = 0, over = 0;
+	int rc = PendingTuples(&cnt, &over);
+	if (rc != DTRL_OK) return rc;
+	if (pending) *pending = cnt;
+	if (drained) *drained = tuples_drained_;
+	if (dropped) *dropped = tuples_dropped_ + over;
+	if (capacity) *capacity = buf_.tuple_cap;
+	return DTRL_OK;
+}
+
+// cScenarioPoliEval::GetDistLog for the batch: every recorded episode distance since Init / Clear, grouped by env (the order in which
+// cOptScenarioPoliEval::OutputResults walks its pool, optimizer/scenarios/OptScenarioPoliEval.cpp:213-239), episodes of one env in time order
+int Engine::GetDistLog(double* dist, int32_t* env_ids, int cap, int* out_n)
+{
+	if (!out_n || cap < 0) return Fail(DTRL_ERR_ARG, "bad arguments");
+	std::vector<std::pair<int32_t, double>> v = dist_log_;
+	std::stable_sort(v.begin(), v.end(), [](const std::pair<int32_t, double>& a, const std::pair<int32_t, double>& b) { return a.first < b.first; });
+	*out_n = static_cast<int>(v.size());
+	for (int i = 0; i < *out_n && i < cap; ++i) { if (dist) dist[i] = v[i].second; if (env_ids) env_ids[i] = v[i].first; }
+	return *out_n <= cap || (!dist && !env_ids) ? DTRL_OK : Fail(DTRL_ERR_CAPACITY, "caller buffer smaller than the dist log");
+}
+// cScenarioPoliEval::ResetAvgDist on every env: mAvgDist = 0, mEpisodeCount = 0 (the dist log and the cycle counters stay)
+int Engine::ResetAvgDist()
+{
+	std::vector<EnvState> st;
+	int rc = GetStates(nullptr, n_, st);
+	if (rc != DTRL_OK) return rc;
+	for (EnvState& s : st) { s.avg_dist = 0; s.num_episodes = 0; }
+	if (!be_->H2D(buf_.st, st.data(), sizeof(EnvState) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	return DTRL_OK;
 }
 
 int Engine::GetStates(const int32_t* env_ids, int n, std::vector<EnvState>& out)
 {
+	if (n < 0) return Fail(DTRL_ERR_ARG, "negative env count");
 	be_->Sync();
 	out.resize(n);
 	if (!env_ids) {
@@ -487,6 +573,7 @@ int Engine::GetStates(const int32_t* env_ids, int n, std::vector<EnvState>& out)
 
 int Engine::SetPoseVel(const int32_t* env_ids, int n, const double* q, const double* qd)
 {
+	if (n < 0 || !q || !qd) return Fail(DTRL_ERR_ARG, "bad arguments");
 	be_->Sync();
 	const int D = cfg_.model.D;
 	EnvState st;
@@ -504,6 +591,7 @@ int Engine::SetPoseVel(const int32_t* env_ids, int n, const double* q, const dou
 // body-local offset for `duration` seconds of simulated time. Planar characters: the in-plane components. One slot per env.
 int Engine::AddPerturb(const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration)
 {
+	if (env_ids && n < 0) return Fail(DTRL_ERR_ARG, "negative env count");
 	be_->Sync();
 	const DevModel& m = cfg_.model;
 	EnvState st;
@@ -532,6 +620,7 @@ int Engine::AddPerturb(const int32_t* env_ids, int n, const int32_t* link, const
 // time-seeded global RNG; here the stream is a counter-based hash of (seed, global env id), so a run is reproducible.
 int Engine::ApplyRandForce(const int32_t* env_ids, int n, uint64_t seed)
 {
+	if (env_ids && n < 0) return Fail(DTRL_ERR_ARG, "negative env count");
 	const DevModel& m = cfg_.model;
 	const int cnt = env_ids ? n : n_;
 	std::vector<int32_t> link(cnt); std::vector<double> f(2 * static_cast<size_t>(cnt)), dur(cnt);
@@ -554,6 +643,7 @@ int Engine::ApplyRandForce(const int32_t* env_ids, int n, uint64_t seed)
 
 int Engine::GetPoliState(const int32_t* env_ids, int n, double* s)
 {
+	if (n < 0 || !s) return Fail(DTRL_ERR_ARG, "bad arguments");
 	be_->Sync();
 	for (int i = 0; i < n; ++i) {
 		int e = EnvIndex(env_ids, i);

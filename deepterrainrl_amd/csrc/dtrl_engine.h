@@ -1,6 +1,6 @@
 // dtrl_engine.h -- batch engine: owns the device slabs, the per-env ground windows and the frame loop.
 // The backend interface isolates the HIP runtime (dtrl_backend_hip.hip) from the engine logic so that the same logic can
-// be unit-tested on a CPU-only box against the lane-loop build of the kernel math (csrc/emul/, tests only).
+// be unit-tested on a CPU-only box against the lane-loop build of the kernel math (tests/emul/, tests only).
 #pragma once
 #include "dtrl_host.h"
 #include "dtrl_kernel.h"
@@ -21,6 +21,9 @@ public:
 	virtual void* HostStaging(size_t bytes) = 0;   // page-locked host memory (plain malloc in the test backend)
 	virtual void FreeHostStaging(void* p) = 0;
 	virtual bool D2H(void* dst, const void* src, size_t n) = 0;
+	virtual bool D2D(void* dst, const void* src, size_t n) = 0;   // device-to-device on the selected stream, synchronised before returning
+	// dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 for i < n, all device pointers (policy hand-over without a host round trip); synchronised
+	virtual bool GatherF32(float* dst, const float* src, const int32_t* idx, size_t n) = 0;
 	virtual bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) = 0;
 	virtual bool Sync() = 0;                 // all streams
 	// work queues: H2D / H2DAsync / D2H / Launch act on the selected stream (0 by default); D2H and H2D synchronise only that stream
@@ -33,7 +36,7 @@ public:
 protected:
 	std::string err_;
 };
-Backend* MakeBackend();   // resolved at link time: HIP in libdtrl.so, lane-loop in the test-only libdtrl_emul.so
+Backend* MakeBackend();   // resolved at link time: HIP in libdtrl.so, the lane-loop test backend under tests/emul/
 
 class Engine {
 public:
@@ -51,7 +54,11 @@ public:
 	int WriteScaleFile(const char* path);
 	int SetExplore(int enable, double rate, double temp, double base_rate);
 	int SetTerrainLerp(double lerp);
-	int DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n);
+	int DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n, bool device_dst = false);
+	int TupleStats(int64_t* pending, int64_t* drained, int64_t* dropped, int32_t* capacity);
+	int GetDistLog(double* dist, int32_t* env_ids, int cap, int* out_n);
+	int ResetAvgDist();
+	int SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, const double* is_dev, const double* oo_dev, const double* os_dev);
 	int GetStates(const int32_t* env_ids, int n, std::vector<EnvState>& out);
 	int SetPoseVel(const int32_t* env_ids, int n, const double* q, const double* qd);
 	int AddPerturb(const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration);
@@ -97,11 +104,17 @@ private:
 	GroundRec tmp_rec_;
 	std::vector<double> in_off_, in_scale_, out_off_, out_scale_;   // host copies of the policy normalisers (identity until set)
 	int UploadNormalizers();
+	void BuildRelayoutMap(std::vector<int32_t>& map) const;
+	std::vector<int32_t> relayout_;
 	// page-locked staging for the per-frame uploads (terrain records, launch order, reset list): the copies are queued on the
 	// stream without a host sync; the arena is recycled after the next frame's status read-back (a stream sync)
 	GroundRec* pin_recs_ = nullptr;
 	int32_t* pin_order_ = nullptr; int32_t* pin_ids_ = nullptr;
 	std::vector<int32_t> bucket_;
+	std::vector<std::pair<int32_t, double>> dist_log_;   // (env, distance) of every recorded poli_eval episode, in completion order
+	int64_t tuples_drained_ = 0, tuples_dropped_ = 0;
+	int PendingTuples(int32_t* stored, int32_t* overflow);
+	int32_t* d_relayout_ = nullptr;   // device weight index -> index into the caller's Caffe-order blob (-1 = padding), built at Create
 	std::string err_;
 };
 

@@ -684,6 +684,7 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 
 	// exploration (scenarios/ScenarioExp.cpp:16-45)
 	cfg.tuple_buffer_size = 16; args.ParseInt("tuple_buffer_size", cfg.tuple_buffer_size);
+	cfg.tuple_ring_capacity = 0; args.ParseInt("tuple_ring_capacity", cfg.tuple_ring_capacity);
 	double exp_rate = 0.1, exp_temp = 1, exp_base = 0.01;   // cScenarioExp ctor defaults; mExpTemp is uninitialised there -> controller default 1
 	args.ParseDouble("exp_rate", exp_rate); args.ParseDouble("exp_temp", exp_temp); args.ParseDouble("exp_base_rate", exp_base);
 	cfg.run.enable_exp = (m.scenario == kScnExp) ? 1 : 0;

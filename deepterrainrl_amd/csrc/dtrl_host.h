@@ -111,6 +111,7 @@ struct ScenarioConfig {
 	double terrain_blend = 0;
 	uint64_t terrain_seed = 0;
 	int tuple_buffer_size = 16;
+	int tuple_ring_capacity = 0;   // -tuple_ring_capacity=: rows of the device tuple ring (0 = max(2 num_envs, tuple_buffer_size))
 	// cScenarioSimChar::ApplyRandForce ranges (scenarios/ScenarioSimChar.cpp:60-63, 88-91; the duration key's typo is the reference's)
 	double min_perturb = 50, max_perturb = 100, min_perturb_duration = 0.1, max_perturb_duration = 0.5;
 	std::string data_root;

@@ -23,7 +23,7 @@
 //
 // The code is written once in "lane-phase" form: LANES_BEGIN/LANES_END delimit a phase executed by every lane, with a
 // workgroup barrier at the end. Under hipcc a phase body runs once per thread; under g++ (tests only, see
-// csrc/emul/README) the same body runs in a for-loop over lanes so the math can be checked on a CPU-only box. The
+// tests/emul/README) the same body runs in a for-loop over lanes so the math can be checked on a CPU-only box. The
 // C-ABI never dispatches to the lane-loop build: the product path is the HIP kernel or an error.
 #pragma once
 #include "dtrl_types.h"
@@ -1679,8 +1679,9 @@ DTRL_HD inline void frame_end(W& ws, const DevModel& gm, const DevBuffers& buf, 
 					real dist = ws.st.q[0] - ws.st.pos_start_x;
 					ws.st.avg_dist = (ws.st.num_episodes * ws.st.avg_dist + dist) / (ws.st.num_episodes + 1.0);
 					ws.st.num_episodes += 1;
+					ws.red[7] = dist; mode = 3;   // episode recorded: the host appends dist to the batch's dist log (mDistLog)
 				}
-				mode = 2;
+				else mode = 2;
 			}
 		}
 		ws.flag_misc = mode;
@@ -1688,7 +1689,7 @@ DTRL_HD inline void frame_end(W& ws, const DevModel& gm, const DevBuffers& buf, 
 	LANES_END
 	if (ws.flag_misc == 1) scenario_new_cycle(ws, gm, buf, env);
 	LANES_BEGIN
-	if (lane == 0 && ws.flag_misc != 0) ws.st.need_reset = 1;
+	if (lane == 0 && ws.flag_misc != 0) ws.st.need_reset = (ws.flag_misc == 3) ? 3 : 1;
 	LANES_END
 }
 
@@ -1742,7 +1743,7 @@ DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, co
 		const uint64_t* src = reinterpret_cast<const uint64_t*>(&ws.st);
 		LANES_BEGIN
 		for (int i = lane; i < static_cast<int>(sizeof(EnvState) / 8); i += kGroup) dst[i] = src[i];
-		if (lane == 0) { buf.status[env].root_x = ws.st.q[0]; buf.status[env].need_reset = ws.st.need_reset; 
+		if (lane == 0) { buf.status[env].root_x = ws.st.q[0]; buf.status[env].need_reset = ws.st.need_reset; buf.status[env].episode_dist = (ws.st.need_reset & 2) ? ws.red[7] : 0.0;
 			// work estimate for the NEXT frame (the host launches the costliest envs first): the constraint-row part is persistent (a stumbling
 			// character stays expensive), a policy forward is not -- it is predicted from the gait clock: the running cycle will reach the
 			// length of the previous one within the next frame (one forward ~ 400 row-substep units, tools/gpu_sections.py)

@@ -122,11 +122,12 @@ struct GroundRec {
 	float data[2][kSegCap];
 };
 
-// per-env status the host reads back after each frame (16 B, coalesced)
+// per-env status the host reads back after each frame (24 B, coalesced)
 struct EnvStatus {
 	double root_x;
-	int32_t need_reset;
+	int32_t need_reset;   // bit 0: the env fell, the host regenerates its terrain; bit 1: a poli_eval episode ended with a valid cycle, episode_dist holds its distance
 	int32_t cost;   // work estimate for the env's next frame: sum over the last frame's substeps of (8 + constraint rows) + 400 if a policy forward is due
+	double episode_dist;  // cScenarioPoliEval::RecordDistTraveled's dist (scenarios/ScenarioPoliEval.cpp:202-217) when need_reset & 2
 };
 
 // MACE network family (data/policies/*/nets/*_mace3_deploy.prototxt)

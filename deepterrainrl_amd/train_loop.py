@@ -33,7 +33,7 @@ def parse_arg_file(path):
 
 
 def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, device_id=-1, extra_args=None, seed=0, log_every=0, out_scale_file=None,
-          trainer_device=None, overlap=False, frames_per_drain=1, _lib_path=None):
+          trainer_device=None, overlap=False, frames_per_drain=1, scenario_cls=BatchScenario):
     """extra_args override / extend the arg file (both for the engine and for the -trainer_* keys read here).
     overlap=True trains on frame f's tuples while the GPU already rolls out frame f+1 (dtrl_step_begin / dtrl_step_end): the policy
     each frame runs with is one frame staler, as with the reference's concurrent env threads; overlap=False is the strictly
@@ -42,7 +42,7 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     args = parse_arg_file(os.path.join(data_root, arg_file))
     args.update({k: str(v) for k, v in (extra_args or {}).items()})
     geti = lambda k, d: int(args.get(k, d)); getf = lambda k, d: float(args.get(k, d))
-    b = BatchScenario(arg_file, num_envs, data_root=data_root, device_id=device_id, extra_args=extra_args, _lib_path=_lib_path)
+    b = scenario_cls(arg_file, num_envs, data_root=data_root, device_id=device_id, extra_args=extra_args)
     solver = os.path.join(data_root, args["policy_solver"])
     train_net = os.path.join(data_root, re.search(r'net:\s*"([^"]+)"', open(solver).read()).group(1)) if re.search(r'net:\s*"', open(solver).read()) \
         else os.path.join(data_root, args["policy_net"].replace("_deploy", "_train"))
@@ -118,7 +118,7 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
 
 
 def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, max_frames=None, extra_args=None, seed=0, device=None,
-                      trainer_device=None, local_device_id=-1, _lib_path=None):
+                      trainer_device=None, local_device_id=-1, scenario_cls=BatchScenario):
     """cScenarioTrain over several GPUs: one process per GPU (torch.distributed already initialised; backend "nccl" = RCCL on GPUs).
     Every rank rolls out its contiguous range of global env ids; each outer frame the ranks' drained MACE rows are gathered on rank 0
     (the only exchange on the experience side), rank 0 runs the trainer, then one broadcast carries [iteration, weights, normalisers]
@@ -132,7 +132,7 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
 
     def make(n, off):
         ea = dict(extra_args or {}); ea["global_env_offset"] = off
-        return BatchScenario(arg_file, n, data_root=data_root, device_id=local_device_id, extra_args=ea, _lib_path=_lib_path)
+        return scenario_cls(arg_file, n, data_root=data_root, device_id=local_device_id, extra_args=ea)
     sr = ShardedRollout(make, global_envs, dist=dist, device=device)
     b = sr.batch
     t = None

@@ -111,6 +111,20 @@ dtrl_status dtrl_set_terrain_lerp(dtrl_batch* b, double lerp);
  * rows: [cap][1 + 2S + A] float32 in the MACE replay row layout [r | s | a | s'] (learning/MACETrainer.cpp:373-401). */
 dtrl_status dtrl_drain_tuples(dtrl_batch* b, float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n);
 
+/* dtrl_drain_tuples with DEVICE destination buffers (e.g. the trainer's replay tensors on the same GPU, or the send buffer of the RCCL tuple
+ * gather): device-to-device copies on the batch's stream, completed on return; no host staging. The reference hands tuples to the trainer by
+ * reference under its lock (learning/NeuralNetLearner.cpp:33-46). flags_dev / env_ids_dev may be NULL. */
+dtrl_status dtrl_drain_tuples_device(dtrl_batch* b, float* rows_dev, uint32_t* flags_dev, int32_t* env_ids_dev, int cap, int* out_n);
+/* The reference never drops a tuple (scenarios/ScenarioTrain.cpp:376-410 trains whenever a scene's buffer is full). Here the ring holds
+ * max(2 num_envs, -tuple_buffer_size=) rows (-tuple_ring_capacity= overrides); rows completed while it is full are COUNTED, not stored:
+ * pending = rows waiting in the ring, drained = rows handed out so far, dropped = rows lost to a full ring since creation (stays 0 when
+ * the caller drains at least every ~2 gait cycles), capacity = ring size. Any output may be NULL. */
+dtrl_status dtrl_tuple_stats(dtrl_batch* b, int64_t* pending, int64_t* drained, int64_t* dropped, int32_t* capacity);
+/* dtrl_set_policy with every pointer in DEVICE memory (cNeuralNet::CopyModel is a memcpy per blob between two nets of one process,
+ * learning/NeuralNet.cpp:636-658): the trainer's weight blob -- same Caffe blob order -- is re-laid into the kernel's layout by a gather kernel;
+ * NULL normaliser pointers keep the current vectors. */
+dtrl_status dtrl_set_policy_device(dtrl_batch* b, const float* weights_dev, size_t n, const double* in_off_dev, const double* in_scale_dev, const double* out_off_dev, const double* out_scale_dev);
+
 /* Replaces: cSimCharacter::BuildPose / BuildVel (sim/SimCharacter.cpp:166-225). env_ids == NULL -> envs 0..n-1. */
 dtrl_status dtrl_get_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, double* q, double* qd);
 /* Replaces: cSimCharacter::SetPose / SetVel (sim/SimCharacter.cpp:665-683, 227-315). */
@@ -154,6 +168,18 @@ dtrl_status dtrl_sample_ground(dtrl_batch* b, int env, int n, const double* x, d
 
 /* Replaces: cScenarioPoliEval::GetAvgDist / GetNumEpisodes / GetNumCycles (scenarios/ScenarioPoliEval.h:20-26), batch aggregate. */
 dtrl_status dtrl_eval_stats(dtrl_batch* b, double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets);
+
+/* Replaces: cScenarioPoliEval::GetDistLog (scenarios/ScenarioPoliEval.cpp:147-150, filled by RecordDistTraveled :202-217) for the batch: the distance of
+ * every recorded episode since creation, grouped by env id (= pool member, the order cOptScenarioPoliEval::OutputResults walks,
+ * optimizer/scenarios/OptScenarioPoliEval.cpp:213-239), each env's episodes in time order. *out_n = number of entries (call with cap 0 and
+ * NULL buffers to size them). */
+dtrl_status dtrl_get_dist_log(dtrl_batch* b, double* dist, int32_t* env_ids, int cap, int* out_n);
+/* Replaces: cScenarioPoliEval::ResetAvgDist (scenarios/ScenarioPoliEval.cpp:132-136) on every env: average distance and episode count restart,
+ * cycle counters and the dist log stay (cOptScenarioPoliEval::EvalHelper calls it after folding a batch of episodes into its record, :184-196). */
+dtrl_status dtrl_reset_avg_dist(dtrl_batch* b);
+/* Replaces: cOptScenarioPoliEval::OutputResults (optimizer/scenarios/OptScenarioPoliEval.cpp:213-239): appends ONE line to `path`, every logged
+ * distance in dtrl_get_dist_log order, printed with std::to_string and separated by ", ". */
+dtrl_status dtrl_write_dist_log(dtrl_batch* b, const char* path);
 
 /* sizes: L links, D dofs, S policy-state, A policy-action (1 + frag), P controller params, nn_out, num_frags, frag_size */
 dtrl_status dtrl_dims(const dtrl_batch* b, int* L, int* D, int* S, int* A, int* P, int* nn_out, int* num_frags, int* frag_size);

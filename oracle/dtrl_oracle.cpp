@@ -113,6 +113,14 @@ void orc_stats(void* p, int64_t* resets, int64_t* cycles, int64_t* episodes, dou
 	Env& e = static_cast<OrcHandle*>(p)->env;
 	*resets = e.num_resets; *cycles = e.num_cycles; *episodes = e.num_episodes; *avg_dist = e.avg_dist; *terrain_builds = e.ground.num_builds;
 }
+// cScenarioPoliEval::GetDistLog (scenarios/ScenarioPoliEval.cpp:147-150)
+int orc_dist_log(void* p, double* out, int cap)
+{
+	Env& e = static_cast<OrcHandle*>(p)->env;
+	const int n = static_cast<int>(e.dist_log.size());
+	for (int i = 0; i < n && i < cap; ++i) out[i] = e.dist_log[i];
+	return n;
+}
 // rows in the MACE replay layout [r | s | a | s'] (learning/MACETrainer.cpp:373-401)
 int orc_drain_tuples(void* p, float* rows, uint32_t* flags, int cap)
 {
@@ -236,6 +244,31 @@ double orc_batch_run(const OrcModel* m, int n_envs, int n_threads, int n_frames,
 	if (out_resets) *out_resets = resets;
 	if (out_cycles) *out_cycles = cycles;
 	return static_cast<double>(n_envs) * n_frames * m->num_update_steps / sec;
+}
+
+// distribution-level statistics of a poli_eval / exp run on n_envs oracle envs (n_threads host threads): out[0] resets, [1] cycles, [2] episodes,
+// [3] sum of episode distances, [4] sum of squared episode distances, [5] env-steps; returns wall seconds
+double orc_batch_eval(const OrcModel* m, int n_envs, int n_threads, int n_frames, uint64_t terrain_seed0, uint64_t rng_seed, uint64_t env_id0,
+					  const OrcNetDesc* d, const float* weights, const double* in_off, const double* in_scale, const double* out_off, const double* out_scale, double* out)
+{
+	std::vector<OrcHandle*> hs(n_envs);
+	for (int i = 0; i < n_envs; ++i)
+		hs[i] = static_cast<OrcHandle*>(d ? orc_create_with_policy(m, terrain_seed0 + i, rng_seed, env_id0 + i, d, weights, in_off, in_scale, out_off, out_scale)
+										  : orc_create(m, terrain_seed0 + i, rng_seed, env_id0 + i));
+	auto t0 = std::chrono::steady_clock::now();
+	std::vector<std::thread> th;
+	for (int t = 0; t < n_threads; ++t) th.emplace_back([&, t]() { for (int i = t; i < n_envs; i += n_threads) for (int f = 0; f < n_frames; ++f) hs[i]->env.Update(1.0 / 30.0); });
+	for (auto& x : th) x.join();
+	const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	for (int k = 0; k < 6; ++k) out[k] = 0;
+	for (int i = 0; i < n_envs; ++i) {
+		const Env& e = hs[i]->env;
+		out[0] += e.num_resets; out[1] += e.num_cycles; out[2] += e.num_episodes;
+		for (double x : e.dist_log) { out[3] += x; out[4] += x * x; }
+		delete hs[i];
+	}
+	out[5] = static_cast<double>(n_envs) * n_frames * m->num_update_steps;
+	return sec;
 }
 
 }  // extern "C"

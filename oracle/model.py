@@ -399,6 +399,8 @@ def lib():
         L.orc_get_poli_state.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_get_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.orc_dist_log.restype = C.c_int
+        L.orc_dist_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_drain_tuples.restype = C.c_int
         L.orc_drain_tuples.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_drain_tuples_f64.restype = C.c_int
@@ -415,6 +417,8 @@ def lib():
         L.orc_rng_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
         L.orc_batch_run.restype = C.c_double
         L.orc_batch_run.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(OrcNetDesc)] + [C.c_void_p] * 5 + [C.POINTER(C.c_int64)] * 2
+        L.orc_batch_eval.restype = C.c_double
+        L.orc_batch_eval.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(OrcNetDesc)] + [C.c_void_p] * 6
         _lib = L
     return _lib
 
@@ -489,6 +493,9 @@ class OracleEnv:
         self.L_.orc_stats(self.h, C.byref(r), C.byref(c), C.byref(e), C.byref(a), C.byref(t))
         return {"resets": r.value, "cycles": c.value, "episodes": e.value, "avg_dist": a.value, "terrain_builds": t.value}
 
+    def dist_log(self):
+        buf = np.zeros(4096); n = self.L_.orc_dist_log(self.h, _p(buf), 4096); return buf[:n].copy()
+
     def drain_tuples(self, cap=1024, f64=False):
         W = 1 + 2 * self.S + self.A
         rows = np.zeros((cap, W), np.float64 if f64 else np.float32); fl = np.zeros(cap, np.uint32)
@@ -541,3 +548,13 @@ def batch_run(model, n_envs, n_threads, n_frames, terrain_seed0=0, rng_seed=0, p
         io, isc, oo, osc = (np.ascontiguousarray(x, np.float64) for x in (io, isc, oo, osc))
         v = lib().orc_batch_run(C.byref(model), n_envs, n_threads, n_frames, terrain_seed0, rng_seed, C.byref(desc), _p(w), _p(io), _p(isc), _p(oo), _p(osc), C.byref(r), C.byref(c))
     return v, r.value, c.value
+
+
+def batch_eval(model, n_envs, n_threads, n_frames, terrain_seed0=0, rng_seed=0, env_id0=0, policy=None):
+    """Distribution-level statistics of n_envs oracle envs: dict(resets, cycles, episodes, dist_sum, dist_sq_sum, env_steps, seconds)."""
+    out = np.zeros(6)
+    desc, w, io, isc, oo, osc = policy
+    w = np.ascontiguousarray(w, np.float32)
+    io, isc, oo, osc = (np.ascontiguousarray(x, np.float64) for x in (io, isc, oo, osc))
+    sec = lib().orc_batch_eval(C.byref(model), n_envs, n_threads, n_frames, terrain_seed0, rng_seed, env_id0, C.byref(desc), _p(w), _p(io), _p(isc), _p(oo), _p(osc), _p(out))
+    return dict(resets=out[0], cycles=out[1], episodes=out[2], dist_sum=out[3], dist_sq_sum=out[4], env_steps=out[5], seconds=sec)

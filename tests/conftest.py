@@ -9,7 +9,7 @@ if REPO not in sys.path:
 
 REFDATA = os.path.join(REPO, "tests", "golden", "refdata")
 GOLDEN = os.path.join(REPO, "tests", "golden")
-EMUL_LIB = os.path.join(REPO, "deepterrainrl_amd", "lib", "libdtrl_emul.so")
+EMUL_LIB = os.path.join(REPO, "tests", "emul", "libdtrl_emul.so")   # lane-loop build of the kernel source: TESTS ONLY, lives outside the product package
 HIP_LIB = os.path.join(REPO, "deepterrainrl_amd", "lib", "libdtrl.so")
 REFERENCE = "/root/reference"
 
@@ -30,6 +30,39 @@ def _ensure_built():
 @pytest.fixture(scope="session", autouse=True)
 def built():
     _ensure_built()
+
+
+def _emul_scenario_cls():
+    import deepterrainrl_amd
+
+    class EmulScenario(deepterrainrl_amd.BatchScenario):
+        """BatchScenario bound to the lane-loop CPU build of the kernel source (tests/emul/): checks host logic and kernel math without a GPU."""
+        def _library(self):
+            return deepterrainrl_amd._bind(EMUL_LIB)
+    return EmulScenario
+
+
+class _Lazy:
+    def __call__(self, *a, **k):
+        return _emul_scenario_cls()(*a, **k)
+
+
+EmulScenario = _Lazy()   # callable like the class; resolved lazily so that importing conftest does not import the package
+
+
+def pytest_collection_modifyitems(config, items):
+    """gpu-marked tests need a HIP device: skip them (instead of failing in dtrl_create) when none is visible."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = os.path.exists("/dev/kfd")
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs a HIP device (run with -m gpu on an MI355X box)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

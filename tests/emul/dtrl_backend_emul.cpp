@@ -2,7 +2,7 @@
 // loop expanded on the host, so tests can check the kernel math and the engine's host logic on a box without a GPU.
 // It is linked ONLY into libdtrl_emul.so, which nothing in the product loads (deepterrainrl_amd/__init__.py loads
 // libdtrl.so and raises if the HIP library or device is missing). It is not a CPU fallback and is never benchmarked.
-#include "../dtrl_engine.h"
+#include "dtrl_engine.h"
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -21,6 +21,8 @@ public:
 	void* HostStaging(size_t bytes) override { return std::calloc(1, bytes ? bytes : 1); }
 	void FreeHostStaging(void* p) override { std::free(p); }
 	bool D2H(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
+	bool D2D(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
+	bool GatherF32(float* dst, const float* src, const int32_t* idx, size_t n) override { for (size_t i = 0; i < n; ++i) dst[i] = idx[i] >= 0 ? src[idx[i]] : 0.0f; return true; }
 	bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) override
 	{
 		int nt = std::min<int>(n_envs, std::max(1u, std::thread::hardware_concurrency()));

@@ -58,5 +58,5 @@ def test_product_does_not_reference_the_oracle():
                 assert "oracle/" not in src.replace("oracle/or_", "ORC_DOC").replace("oracle/model.py", "ORC_DOC") or f.endswith((".h", ".cpp", ".hip")), f
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "libdtrl_oracle" not in src, f
-                if f.endswith(".py"):
-                    assert "libdtrl_emul" not in src, f
+                assert "libdtrl_emul" not in src and "_lib_path" not in src, f
+    assert not os.path.exists(os.path.join(pkg, "lib", "libdtrl_emul.so")) and not os.path.isdir(os.path.join(pkg, "csrc", "emul")), "the lane-loop test backend must live under tests/, not in the product package"

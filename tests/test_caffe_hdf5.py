@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, REFDATA, EMUL_LIB
+from conftest import GOLDEN, REFDATA, EmulScenario as Scenario
 
 H5PY_PYTHON = "/opt/conda/bin/python3.9"   # optional cross-check against libhdf5 where this interpreter (with h5py) exists
 
@@ -57,8 +57,8 @@ def test_trainer_output_model_roundtrip_into_the_engine(da, tmp_path):
     m = h.read_caffe_model(model)
     assert m["terr_conv1"][0].shape == (32, 16, 1, 4) and m["terr_ip0"][0].shape == (64, 5984) and m["a2_ip1"][1].shape == (29,)
     assert np.array_equal(h.load_mace_weights(model, 3), t.GetWeights())
-    a = da.BatchScenario("args/dog_slopes_mixed_args.txt", 2, data_root=REFDATA, extra_args={"terrain_seed": 8}, _lib_path=EMUL_LIB)
-    b = da.BatchScenario("args/dog_slopes_mixed_args.txt", 2, data_root=REFDATA, extra_args={"terrain_seed": 8}, _lib_path=EMUL_LIB)
+    a = Scenario("args/dog_slopes_mixed_args.txt", 2, data_root=REFDATA, extra_args={"terrain_seed": 8})
+    b = Scenario("args/dog_slopes_mixed_args.txt", 2, data_root=REFDATA, extra_args={"terrain_seed": 8})
     a.SetPolicy(t.GetWeights(), *t.GetOffsetScale())
     assert np.array_equal(b.LoadModel(model), t.GetWeights())
     a.RunFrames(30); b.RunFrames(30)

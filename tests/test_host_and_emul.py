@@ -10,11 +10,13 @@ import os
 import numpy as np
 import pytest
 
-from conftest import REFDATA, EMUL_LIB, GOLDEN, dog_policy
+from conftest import REFDATA, EmulScenario, GOLDEN, dog_policy
+
+Scenario = EmulScenario   # the GPU twin (tests/test_gpu_parity.py) points this at the product class
 
 
 def batch(da, arg, n, **extra):
-    return da.BatchScenario(arg, n, data_root=REFDATA, extra_args=extra, _lib_path=EMUL_LIB)
+    return Scenario(arg, n, data_root=REFDATA, extra_args=extra)
 
 
 def test_loader_dims_and_offset_scale(da, om):
@@ -33,7 +35,7 @@ def test_arg_errors(da):
     with pytest.raises(da.DtrlError):
         batch(da, "args/does_not_exist.txt", 1)
     with pytest.raises(da.DtrlError):
-        da.BatchScenario(None, 1, data_root=REFDATA, extra_args={"char_ctrl": "dog"}, _lib_path=EMUL_LIB)   # "No character file specified."
+        Scenario(None, 1, data_root=REFDATA, extra_args={"char_ctrl": "dog"})   # "No character file specified."
     b = batch(da, "args/dog_slopes_mixed_args.txt", 1)
     with pytest.raises(da.DtrlError):
         b.Update()      # -policy_net= given but no weights pushed yet
@@ -180,12 +182,12 @@ def test_terrain_param_lerp_curriculum(da, om, tmp_path):
     for blend in (0.0, 0.35, 1.0):
         m, _ = om.build_model("args/opt_args_train_mace.txt", str(root), overrides={"terrain_blend": blend})
         e = om.OracleEnv(m, terrain_seed=21)
-        b = da.BatchScenario("args/opt_args_train_mace.txt", 1, data_root=str(root), extra_args={"terrain_seed": 21, "terrain_blend": blend}, _lib_path=EMUL_LIB)
+        b = Scenario("args/opt_args_train_mace.txt", 1, data_root=str(root), extra_args={"terrain_seed": 21, "terrain_blend": blend})
         assert grounds_equal(b, e)
         heights[blend] = np.array(e.ground_segment(1)[0])
     assert not np.array_equal(heights[0.0], heights[1.0]) and not np.array_equal(heights[0.35], heights[1.0])
     # run-time lerp: takes effect at the next segment build; a seeded reset rebuilds the window from scratch
-    b = da.BatchScenario("args/opt_args_train_mace.txt", 1, data_root=str(root), extra_args={"terrain_seed": 5, "terrain_blend": 0.0}, _lib_path=EMUL_LIB)
+    b = Scenario("args/opt_args_train_mace.txt", 1, data_root=str(root), extra_args={"terrain_seed": 5, "terrain_blend": 0.0})
     b.SetTerrainParamsLerp(0.35)
     b.Reset([0], terrain_seeds=[21])
     m, _ = om.build_model("args/opt_args_train_mace.txt", str(root), overrides={"terrain_blend": 0.35})
@@ -649,7 +651,7 @@ def test_raptor_gravity_comp_and_virtual_forces_paths(da, om, tmp_path):
     m, _ = om.build_model("args/sim_raptor_args.txt", str(root))
     assert m.enable_grav_comp == 1 and m.enable_virtual_forces == 1
     e = om.OracleEnv(m, terrain_seed=2)
-    b = da.BatchScenario("args/sim_raptor_args.txt", 1, data_root=str(root), extra_args={"terrain_seed": 2}, _lib_path=EMUL_LIB)
+    b = Scenario("args/sim_raptor_args.txt", 1, data_root=str(root), extra_args={"terrain_seed": 2})
     for k in range(120):
         b.StepUpdates(1); e.step(1)
         q, qd = b.PoseVel(); qo, qdo = e.pose_vel()

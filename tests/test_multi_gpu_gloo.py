@@ -6,20 +6,23 @@ import sys
 
 import numpy as np
 
-from conftest import REPO, REFDATA, EMUL_LIB
+from conftest import REPO, REFDATA, EmulScenario
+
+Scenario = EmulScenario
 
 WORKER = r'''
 import os, sys, numpy as np
 sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
 import torch, torch.distributed as dist
-from conftest import REFDATA, EMUL_LIB, dog_policy
+from conftest import REFDATA, EmulScenario, dog_policy
+Scenario = EmulScenario
 from oracle import model as om
 import deepterrainrl_amd as da
 from deepterrainrl_amd.sharding import ShardedRollout
 dist.init_process_group(backend="gloo")
 rank = dist.get_rank()
 def make(n, off):
-    return da.BatchScenario("args/opt_args_train_mace.txt", n, data_root=REFDATA, extra_args=dict(terrain_seed=300, rand_seed=9, global_env_offset=off), _lib_path=EMUL_LIB)
+    return Scenario("args/opt_args_train_mace.txt", n, data_root=REFDATA, extra_args=dict(terrain_seed=300, rand_seed=9, global_env_offset=off))
 sr = ShardedRollout(make, 4, dist=dist)
 pol = dog_policy(om)
 if rank == 0:
@@ -50,7 +53,7 @@ def test_two_rank_gloo_matches_single_process(tmp_path, da, om):
     assert r.returncode == 0, r.stderr[-3000:]
     # single process over the same 4 global envs
     pol = dog_policy(om)
-    b = da.BatchScenario("args/opt_args_train_mace.txt", 4, data_root=REFDATA, extra_args=dict(terrain_seed=300, rand_seed=9), _lib_path=EMUL_LIB)
+    b = Scenario("args/opt_args_train_mace.txt", 4, data_root=REFDATA, extra_args=dict(terrain_seed=300, rand_seed=9))
     b.SetPolicy(pol[1], *pol[2:])
     rows, flags, ids = [], [], []
     for f in range(70):
@@ -71,10 +74,10 @@ TRAIN_WORKER = r'''
 import os, sys, numpy as np
 sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
 import torch, torch.distributed as dist
-from conftest import REFDATA, EMUL_LIB
+from conftest import REFDATA, EmulScenario
 from deepterrainrl_amd import train_loop
 dist.init_process_group(backend="gloo")
-st = train_loop.train_distributed("args/opt_args_train_mace.txt", REFDATA, 64, dist, max_frames=90, trainer_device="cpu", _lib_path=EMUL_LIB, extra_args={extra!r})
+st = train_loop.train_distributed("args/opt_args_train_mace.txt", REFDATA, 64, dist, max_frames=90, trainer_device="cpu", scenario_cls=EmulScenario, extra_args={extra!r})
 if dist.get_rank() == 0:
     np.savez(os.path.join({out!r}, "dist_train.npz"), weights=st["weights"], iters=st["iters"], tuples=st["tuples"], in_off=st["offset_scale"][0])
 dist.barrier(); dist.destroy_process_group()
@@ -95,8 +98,8 @@ def test_two_rank_training_equals_single_process(tmp_path, da):
     # the same run in ONE process (also with a single OpenMP thread: float32 GEMM/conv reductions depend on the thread count)
     single = tmp_path / "train_single.py"
     single.write_text("import os, sys, numpy as np\nsys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
-                      "from conftest import REFDATA, EMUL_LIB\nfrom deepterrainrl_amd import train_loop\n"
-                      "st = train_loop.train('args/opt_args_train_mace.txt', REFDATA, num_envs=64, max_frames=90, trainer_device='cpu', _lib_path=EMUL_LIB, extra_args=%r)\n"
+                      "from conftest import REFDATA, EmulScenario\nfrom deepterrainrl_amd import train_loop\n"
+                      "st = train_loop.train('args/opt_args_train_mace.txt', REFDATA, num_envs=64, max_frames=90, trainer_device='cpu', scenario_cls=EmulScenario, extra_args=%r)\n"
                       "np.savez(os.path.join(%r, 'single_train.npz'), weights=st['weights'], iters=st['iters'], tuples=st['tuples'], in_off=st['offset_scale'][0])\n"
                       % (REPO, REPO, extra, str(tmp_path)))
     r = subprocess.run([sys.executable, str(single)], env=env, capture_output=True, text=True, timeout=900)
