@@ -13,6 +13,12 @@ loop at scenarios/ScenarioSimChar.cpp:162-173 = 1 controller update + 5 physics 
 Envs shard across ranks by global env id (weak scaling, no data-path collective: envs are independent); the timed region is
 bracketed by barrier + torch.cuda.synchronize() on both sides and the max over ranks is taken.
 Inputs (state, terrain windows, weights) are resident in HBM when the timed region starts.
+
+`value` is always the pure rollout (weak scaling of BASELINE configs[1] across N). The line also carries an "exchange" object: a second, shorter
+timed leg on the BASELINE configs[3] workload (args/opt_args_train_mace.txt: exploration on, rates 0.2 / 0.025 / 0.002) in which every outer
+frame's experience tuples are drained device-to-device, all-gathered over RCCL on a side stream while the next frame's kernel runs, appended
+to a device replay ring on rank 0, and the policy is re-broadcast (one packed buffer) every --bcast-every frames -- the two exchange steps of
+the north star, measured with the same barrier / synchronize / max-over-ranks bracket. --exchange-steps 0 skips it.
 """
 import argparse
 import json
@@ -32,6 +38,10 @@ B_ALG = 1053.0          # algorithmic bytes per env-step, dog (SURVEY 8d / BASEL
 F_ALG = 0.6e6           # algorithmic flops per env-step, dog
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s
 FP64_VEC_PEAK_TF = 78.6 # the engine computes in fp64 (reference controller/net precision); fp32 vector peak is 157.3
+SIMDS = 256 * 4         # MI355X: 256 CUs x 4 SIMD16
+CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md peak engine clock
+VALU_CYCLES = 4         # one wave64 VALU instruction occupies a SIMD16 for 4 cycles (fp64 FMA is full rate: 78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 x 2.4 GHz)
+EXCHANGE_ARG_FILE = "args/opt_args_train_mace.txt"
 
 
 def xavier_weights(num_params_check, seed=1234):
@@ -71,6 +81,74 @@ def cpu_baseline(frames=100):
             "sample": "%d envs (%d per thread) x %d frames x 20 env-steps of the same workload on the fp64 oracle restatement (not Bullet), %.1f s wall" % (n_envs, envs_per_thread, frames, time.time() - t0)}
 
 
+def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bcast_every, w, scale):
+    """BASELINE configs[3] at this world size: exploration rollouts + the two exchange steps, overlapped with stepping."""
+    from deepterrainrl_amd.sharding import ShardedRollout
+    dev = torch.device("cuda", local_rank)
+
+    def make(n_local, off):
+        b = da.BatchScenario(EXCHANGE_ARG_FILE, n_local, data_root=ROOT, device_id=local_rank,
+                             extra_args={"terrain_seed": 20260925, "rand_seed": 1, "global_env_offset": off})
+        return b
+    sr = ShardedRollout(make, n * world, dist=dist if world > 1 else None, device=dev)
+    b = sr.batch
+    if rank == 0:
+        sr.broadcast_policy(w, *scale, src=0)
+    else:
+        sr.broadcast_policy(src=0)
+    b.SetExplore(True, 0.2, 0.025, 0.002)        # args/opt_args_train_mace.txt:25-27
+    W = b.W
+    replay_cap = 1 << 18
+    replay = torch.zeros((replay_cap, W), dtype=torch.float32, device=dev) if rank == 0 else None   # device replay ring on the trainer rank
+    cursor = 0; tuples = 0
+    pol = [v.clone() for v in sr._pol_views()]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def frame(k):
+        nonlocal cursor, tuples
+        # frame k is running (UpdateBegin was called); finish it, hand its tuples to the collective, start frame k + 1, then consume
+        sr.UpdateEnd()
+        sr.gather_tuples_begin()
+        sr.UpdateBegin()
+        g = sr.gather_tuples_end(dst=0)
+        if rank == 0:
+            rows = g[0]; m = int(rows.shape[0])
+            if m:
+                idx = (torch.arange(m, device=dev) + cursor) % replay_cap
+                replay[idx] = rows
+                cursor = (cursor + m) % replay_cap; tuples += m
+        if bcast_every > 0 and (k + 1) % bcast_every == 0:
+            if rank == 0:
+                sr.broadcast_policy(*pol, src=0)
+            else:
+                sr.broadcast_policy(src=0)
+    sr.UpdateBegin()
+    for k in range(warmup):
+        frame(k)
+    b.KernelTimeMs(); sr.exchange_wait_s = 0.0; tuples = 0
+    drop0 = b.TupleStats()["dropped"]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        frame(k)
+    fence()
+    dt = time.perf_counter() - t0
+    sr.UpdateEnd()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms, launches = b.KernelTimeMs()
+    return {"workload": "BASELINE configs[3] shape: dog slopes_mixed, exploration on (0.2 / 0.025 / 0.002), %d envs per GPU x %d GPUs; per outer frame: device tuple drain -> one all-gather (RCCL) on a side stream overlapped with the next frame kernel -> device replay ring on rank 0; one packed policy broadcast every %d frames" % (n, world, bcast_every),
+            "env_steps_per_s": float(world) * n * steps * 20 / dt, "tuples_per_s": tuples / dt, "tuples": tuples, "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "exchange_wait_ms_per_step": sr.exchange_wait_s / steps * 1e3, "tuple_block_bytes": int(sr.block.numel() * 4), "policy_bytes": int(sr.pol_bytes),
+            "bcast_every": bcast_every, "dropped_tuples": b.TupleStats()["dropped"] - drop0, "kernel_avg_ms": kern_ms, "collective": "all_gather (RCCL)" if world > 1 else "none (1 rank: device drain + replay append only)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +157,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=100, help="outer frames of the bounded CPU-baseline sample (default: about 30 s of CPU work)")
+    ap.add_argument("--exchange-steps", type=int, default=-1, help="timed frames of the exchange leg (default: half of --steps; 0 = skip)")
+    ap.add_argument("--bcast-every", type=int, default=10, help="exchange leg: policy broadcast every K frames")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,6 +187,7 @@ def main():
 
     b.RunFrames(a.warmup)
     b.KernelTimeMs()   # drop warm-up launches from the kernel-time average
+    stats0 = b.EvalStats()
     fence()
     t0 = time.perf_counter()
     b.RunFrames(a.steps)
@@ -127,10 +208,13 @@ def main():
         ach = B_ALG * env_steps_per_launch / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure comes from the latest committed
         # rocprofv3 --pmc passes of this same command (tools/gpu_profile.sh -> tools/rocpd_summary.py -> profiles/hbm_traffic.json)
-        traffic = None
+        traffic = None; valu_insts = None; traffic_source = None
         tj = os.path.join(REPO, "profiles", "hbm_traffic.json")
         if os.path.exists(tj) and n == ENVS_PER_GPU:
-            traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+            rec = json.load(open(tj))
+            traffic = rec.get("hbm_bytes_per_launch"); valu_insts = rec.get("sq_insts_valu_per_launch")
+            traffic_source = "profiles/hbm_traffic.json <- profiles/%s (rocprofv3 --pmc passes of this command at the same batch size; NOT counters of this run)" % rec.get("source")
+        stats1 = b.EvalStats()
         line = {
             "metric": "env-steps/sec (batched rollout) dog/slopes_mixed", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -139,15 +223,30 @@ def main():
                        "envs_per_gpu": n, "global_envs": n * world, "env_steps_per_step": n * world * steps_per_frame,
                        "substeps_per_env_step": 5, "parallelism": "env-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": float(traffic) if traffic else None,
+                         "traffic": float(traffic) if traffic else None, "traffic_source": traffic_source,
                          "kernel": "dtrl_frame_kernel", "kernel_avg_ms": kern_ms, "kernel_launches": launches,
                          "algorithmic_bytes_per_env_step": B_ALG, "env_steps_per_launch": env_steps_per_launch, "concurrent_launches": concurrent,
                          "aggregate_achieved": B_ALG * n * a.steps * steps_per_frame / dt / 1e9,
                          "note": "per-launch figure (launches of the env groups overlap; aggregate_achieved = all bytes / wall time); the fused path is latency/VALU/LDS-bound, not HBM-bound (SURVEY 8d); companion figure below",
                          "valu": {"achieved": F_ALG * env_steps_per_launch / (kern_ms * 1e-3) / 1e12, "peak": FP64_VEC_PEAK_TF, "unit": "TFLOP/s (fp64 vector)",
-                                  "frac": F_ALG * env_steps_per_launch / (kern_ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TF, "algorithmic_flops_per_env_step": F_ALG}},
-            "substeps_per_sec": value * 5, "stats": b.EvalStats(),
+                                  "frac": F_ALG * env_steps_per_launch / (kern_ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TF, "algorithmic_flops_per_env_step": F_ALG,
+                                  "note": "frac is on the survey's reference-shaped F_alg (comparable across implementations), not on executed instructions; 'executed' below is the utilisation figure",
+                                  "executed": None if not valu_insts else {
+                                      "sq_insts_valu_per_launch": valu_insts, "per_env_step_per_wave": valu_insts / env_steps_per_launch,
+                                      "issue_utilisation_per_launch": valu_insts * VALU_CYCLES / (kern_ms * 1e-3 * CLOCK_GHZ * 1e9 * SIMDS),
+                                      "issue_utilisation_wall": valu_insts * VALU_CYCLES * launches / (dt * CLOCK_GHZ * 1e9 * SIMDS),
+                                      "assumes": "%d cycles per wave64 VALU instruction on a SIMD16, %d SIMDs, %.1f GHz; counter from the committed PMC pass" % (VALU_CYCLES, SIMDS, CLOCK_GHZ)}}},
+            "substeps_per_sec": value * 5, "stats": stats1,
+            "timed_window": {"resets": stats1["resets"] - stats0["resets"], "cycles": stats1["cycles"] - stats0["cycles"], "seconds": dt,
+                             "note": "characters driven by the synthetic seeded policy fall; falls (terrain regeneration + reset launches) are part of the timed work"},
         }
+    ex_steps = a.exchange_steps if a.exchange_steps >= 0 else max(a.steps // 2, 1)
+    ex = None
+    if ex_steps > 0:
+        b.close()
+        ex = exchange_leg(da, dist, torch, world, rank, local_rank, n, ex_steps, max(a.warmup // 2, 2), a.bcast_every, w, load_scale())
+    if rank == 0:
+        line["exchange"] = ex
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_frames)
         print(json.dumps(line), flush=True)

@@ -3,12 +3,22 @@
 The rollout itself needs no collective (envs are independent; each reference scene owns its world, ground, character,
 controller and RNG: scenarios/ScenarioTrain.cpp:201-221). The only exchange steps of the path are the two the reference
 performs between env threads and the trainer:
-  (a) experience tuples env -> trainer   (learning/NeuralNetLearner.cpp:33-46)   -> gather_tuples(): counts all-gather +
-      gather of fixed-capacity row blocks to the trainer rank (RCCL when the process group backend is "nccl")
-  (b) policy weights trainer -> envs     (learning/NeuralNet.cpp:636-658)        -> broadcast_policy(): one broadcast of the
-      flat float32 blob (2.28 MB for dog_mace3) + the four normaliser vectors
-Both are latency-bound (<= ~10 MB/s at 1 M env-steps/s), so a single collective per outer frame is used instead of bucketing.
-Trajectories are shard-invariant: terrain seeds and exploration streams are keyed by the global env id (-global_env_offset=).
+  (a) experience tuples env -> trainer   (learning/NeuralNetLearner.cpp:33-46)
+  (b) policy weights trainer -> envs     (learning/NeuralNet.cpp:636-658)
+Both are latency-bound on xGMI (<= ~10 MB/s of tuples at 1 M env-steps/s; 2.3 MB of weights per push), so each is ONE collective on ONE
+preallocated device buffer, issued on a side stream so that it overlaps the next frame kernel:
+
+  (a) gather_tuples_begin(): dtrl_drain_tuples_device copies the frame's rows device-to-device into this rank's slot of a fixed-capacity
+      block [cap + 1, W + 2] float32 (row 0 = header carrying the count; the two extra columns carry the flag word and the GLOBAL env id
+      as raw int32 bits), sorts the rows by env id on the device (so the gathered stream does not depend on how envs are sharded) and
+      starts one all_gather of the block (RCCL: ncclAllGather over xGMI) on the comm stream. gather_tuples_end() waits and hands the
+      trainer rank the concatenated DEVICE tensors (rows, flags, ids) -- nothing visits the host. gather_tuples() = begin + end.
+  (b) broadcast_policy(): weights (float32) and the four normaliser vectors (float64) travel as ONE byte buffer (one ncclBroadcast), and
+      every rank installs them with dtrl_set_policy_device (a gather kernel re-lays the blob; no host round trip).
+
+With a CPU process group (gloo, tests/test_multi_gpu_gloo.py, lane-loop test backend) the same code runs on CPU tensors: "device" pointers
+are host pointers there. Trajectories are shard-invariant: terrain seeds and exploration streams are keyed by the global env id
+(-global_env_offset=).
 """
 import numpy as np
 
@@ -22,73 +32,143 @@ def shard_range(global_envs, world_size, rank):
 
 
 class ShardedRollout:
-    """One rank's shard of a global batch + the two exchange steps. `dist` is torch.distributed (already initialised)."""
+    """One rank's shard of a global batch + the two exchange steps. `dist` is torch.distributed (already initialised) or None.
+    `device`: torch device of the exchange buffers -- the GPU the batch runs on (RCCL), or None / "cpu" with a gloo group."""
 
     def __init__(self, make_batch, global_envs, dist=None, device=None):
+        import torch
+        self.torch = torch
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
         self.offset, self.n_local = shard_range(global_envs, self.world, self.rank)
         self.global_envs = int(global_envs)
         self.batch = make_batch(self.n_local, self.offset)
-        self.device = device
-        self.cap = max(2 * max(shard_range(global_envs, self.world, r)[1] for r in range(self.world)), 64)
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.on_gpu = self.device.type == "cuda"
+        b = self.batch
+        self.cap = int(b.TupleStats()["capacity"])
+        caps = [self.cap]
+        if self.world > 1:
+            t = torch.tensor([self.cap], dtype=torch.int64, device=self.device)
+            lst = [torch.zeros_like(t) for _ in range(self.world)]
+            dist.all_gather(lst, t)
+            caps = [int(x.item()) for x in lst]
+        self.cap = max(caps)           # one block size for every rank (a fixed-size collective)
+        W = b.W
+        # this rank's block: header row + cap tuple rows, W floats + [flags, global env id] as int32 bit patterns
+        self.block = torch.zeros((self.cap + 1, W + 2), dtype=torch.float32, device=self.device)
+        self.stage_rows = torch.zeros((self.cap, W), dtype=torch.float32, device=self.device)
+        self.stage_flags = torch.zeros(self.cap, dtype=torch.int32, device=self.device)
+        self.stage_ids = torch.zeros(self.cap, dtype=torch.int32, device=self.device)
+        self.gathered = [torch.zeros_like(self.block) for _ in range(self.world)] if self.world > 1 else None
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self._pending = None
+        # policy buffer: [weights f32 | in_off | in_scale | out_off | out_scale f64], 8-byte aligned sections
+        self.n_w = b.PolicyNumParams()
+        self.w_bytes = (4 * self.n_w + 7) // 8 * 8
+        self.pol_bytes = self.w_bytes + 8 * (2 * b.S + 2 * b.nn_out)
+        self.pol_buf = torch.zeros(self.pol_bytes, dtype=torch.uint8, device=self.device) if self.n_w else None
+        self.exchange_wait_s = 0.0
 
-    def _t(self, a):
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(a))
-        return t.to(self.device) if self.device is not None else t
-
+    # ---- rollout ----
     def Update(self, dt=1.0 / 30.0):
         self.batch.Update(dt)
 
-    def gather_tuples(self, dst=0):
-        """Drain this rank's tuples and gather everybody's on `dst`. Returns (rows, flags, global_env_ids) on dst, else None.
-        Layout of a row: MACE replay row [r | s | a | s'] (learning/MACETrainer.cpp:373-401)."""
-        import torch
-        rows, flags, ids = self.batch.DrainTuples(self.cap)
-        o = np.argsort(ids, kind="stable")   # ring order = completion order; sort by env id so the gathered stream does not depend on the sharding
-        rows, flags, ids = rows[o], flags[o], ids[o]
-        ids = ids.astype(np.int64) + self.offset
-        if self.dist is None or self.world == 1:
-            return rows, flags, ids
+    def UpdateBegin(self, dt=1.0 / 30.0):
+        self.batch.UpdateBegin(dt)
+
+    def UpdateEnd(self):
+        self.batch.UpdateEnd()
+
+    # ---- (a) experience tuples ----
+    def gather_tuples_begin(self):
+        """Drain this rank's finished tuples into its block and start the all-gather (asynchronous on the GPU). Call between UpdateEnd() of
+        frame f and UpdateBegin() of frame f + 1; the collective then overlaps frame f + 1's kernel."""
+        torch = self.torch
+        assert self._pending is None, "gather_tuples_begin called twice without gather_tuples_end"
+        b = self.batch
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).synchronize()     # the staging tensors are free (previous packing kernels done)
+        n = b.DrainTuplesDevice(self.stage_rows.data_ptr(), self.stage_flags.data_ptr(), self.stage_ids.data_ptr(), self.cap)
+        W = b.W
+        blk = self.block
+        hdr = blk[0].view(torch.int32)
+        hdr.zero_()
+        hdr[0] = n
+        if n > 0:
+            ids = self.stage_ids[:n]
+            order = torch.argsort(ids, stable=True)                  # ring order = completion order; sort by env id: shard-invariant stream
+            blk[1:n + 1, :W] = self.stage_rows[:n][order]
+            meta = blk[1:n + 1, W:].view(torch.int32)
+            meta[:, 0] = self.stage_flags[:n][order]
+            meta[:, 1] = ids[order] + int(self.offset)
+        work = None
+        if self.world > 1:
+            if self.on_gpu:
+                self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self.comm_stream):
+                    work = self.dist.all_gather(self.gathered, blk, async_op=True)
+            else:
+                work = self.dist.all_gather(self.gathered, blk, async_op=True)
+        self._pending = (work, n)
+        return n
+
+    def gather_tuples_end(self, dst=0):
+        """Wait for the all-gather. Returns (rows [n, W] float32, flags [n] int32, global env ids [n] int32) as tensors on self.device on rank
+        `dst`, None elsewhere."""
+        import time
+        torch = self.torch
+        work, n = self._pending
+        self._pending = None
         W = self.batch.W
-        n = len(rows)
-        # one fixed-capacity block per rank: [count | flags | ids | rows] packed as float64 would waste bandwidth; use 3 small tensors
-        cnt = self._t(np.array([n], np.int64))
-        counts = [torch.zeros_like(cnt) for _ in range(self.world)]
-        self.dist.all_gather(counts, cnt)
-        blk_rows = np.zeros((self.cap, W), np.float32); blk_rows[:n] = rows
-        blk_meta = np.zeros((self.cap, 2), np.int64); blk_meta[:n, 0] = flags; blk_meta[:n, 1] = ids
-        tr, tm = self._t(blk_rows), self._t(blk_meta)
-        if self.rank == dst:
-            gr = [torch.zeros_like(tr) for _ in range(self.world)]
-            gm = [torch.zeros_like(tm) for _ in range(self.world)]
-        else:
-            gr = gm = None
-        self.dist.gather(tr, gr, dst=dst)
-        self.dist.gather(tm, gm, dst=dst)
+        t0 = time.perf_counter()
+        if work is not None:
+            work.wait()
+            if self.on_gpu:
+                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        self.exchange_wait_s += time.perf_counter() - t0
         if self.rank != dst:
             return None
-        out_r, out_f, out_i = [], [], []
-        for r in range(self.world):
-            c = int(counts[r].item())
-            out_r.append(gr[r][:c].cpu().numpy()); m = gm[r][:c].cpu().numpy()
-            out_f.append(m[:, 0].astype(np.uint32)); out_i.append(m[:, 1])
-        return np.concatenate(out_r), np.concatenate(out_f), np.concatenate(out_i)
+        blocks = self.gathered if self.world > 1 else [self.block]
+        counts = [int(x) for x in torch.stack([g[0].view(torch.int32)[0] for g in blocks]).tolist()]
+        rows = torch.cat([g[1:c + 1, :W] for g, c in zip(blocks, counts)])
+        meta = torch.cat([g[1:c + 1, W:].view(torch.int32) for g, c in zip(blocks, counts)])
+        return rows, meta[:, 0].contiguous(), meta[:, 1].contiguous()
+
+    def gather_tuples(self, dst=0):
+        """Synchronous form. Returns numpy (rows, flags uint32, global env ids int64) on dst, else None (the host-side trainer loop's interface)."""
+        self.gather_tuples_begin()
+        g = self.gather_tuples_end(dst)
+        if g is None:
+            return None
+        rows, flags, ids = g
+        return rows.cpu().numpy(), flags.cpu().numpy().astype(np.uint32), ids.cpu().numpy().astype(np.int64)
+
+    # ---- (b) policy ----
+    def _pol_views(self):
+        torch = self.torch
+        b = self.batch
+        buf = self.pol_buf
+        w = buf[:4 * self.n_w].view(torch.float32)
+        o = self.w_bytes
+        secs = []
+        for n in (b.S, b.S, b.nn_out, b.nn_out):
+            secs.append(buf[o:o + 8 * n].view(torch.float64)); o += 8 * n
+        return [w] + secs
 
     def broadcast_policy(self, weights=None, in_off=None, in_scale=None, out_off=None, out_scale=None, src=0):
-        """Trainer rank pushes the policy; every rank installs it (cNeuralNetLearner::SyncNet over RCCL)."""
-        b = self.batch
-        n = b.PolicyNumParams()
+        """Trainer rank pushes the policy (numpy arrays or tensors); every rank installs it from the device buffer
+        (cNeuralNetLearner::SyncNet over one RCCL broadcast). Returns the five arrays as numpy (host copies for callers that log them)."""
+        torch = self.torch
+        views = self._pol_views()
         if self.rank == src:
-            packed = [np.ascontiguousarray(weights, np.float32)] + [np.ascontiguousarray(a, np.float64) for a in (in_off, in_scale, out_off, out_scale)]
-        else:
-            packed = [np.zeros(n, np.float32), np.zeros(b.S), np.zeros(b.S), np.zeros(b.nn_out), np.zeros(b.nn_out)]
+            for v, a in zip(views, (weights, in_off, in_scale, out_off, out_scale)):
+                t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a, np.float32 if v.dtype == torch.float32 else np.float64))
+                v.copy_(t.to(self.device, dtype=v.dtype).reshape(-1))
         if self.dist is not None and self.world > 1:
-            ts = [self._t(a) for a in packed]
-            for t in ts:
-                self.dist.broadcast(t, src=src)
-            packed = [t.cpu().numpy() for t in ts]
-        b.SetPolicy(*packed)
-        return packed
+            self.dist.broadcast(self.pol_buf, src=src)
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).synchronize()
+        self.batch.SetPolicyDevice(views[0].data_ptr(), self.n_w, *[v.data_ptr() for v in views[1:]])
+        return [v.cpu().numpy().copy() for v in views]

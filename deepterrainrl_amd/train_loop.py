@@ -153,7 +153,7 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
     def sync(push):
         # header [push?, iteration] from the trainer rank, then (if push) the policy itself
         hdr = np.array([1 if push else 0, t.GetIter() if t is not None else 0], np.int64)
-        th = sr._t(hdr)
+        th = torch.from_numpy(hdr).to(sr.device)
         dist.broadcast(th, src=0)
         push, it = int(th[0].item()), int(th[1].item())
         if push:

@@ -197,6 +197,7 @@ class MACETrainer:
         self.flags_dev = torch.zeros(mem_size, device=self.device, dtype=torch.int64)     # device mirror (no host round trip when a batch is built)
         self._idx_pin = torch.zeros((64, 256), dtype=torch.int64).pin_memory() if self.device.type == "cuda" else None   # ring of staging slots
         self._idx_slot = 0
+        self._idx_events = [None] * 64   # one event per staging slot: a slot is rewritten only after its queued copy has executed
         self.rng = np.random.RandomState(seed)
         self.Reset()
         self.UpdateTargetNet()
@@ -386,11 +387,17 @@ class MACETrainer:
         a = np.asarray(ids, np.int64)
         if self._idx_pin is None or a.size > self._idx_pin.shape[1]:
             return torch.as_tensor(a, device=self.device)
-        # a slot is rewritten only 64 calls later, long after its queued copy has run (every iteration ends in a host read-back)
         self._idx_slot = (self._idx_slot + 1) % self._idx_pin.shape[0]
+        ev = self._idx_events[self._idx_slot]
+        if ev is not None:
+            ev.synchronize()   # the copy queued from this slot 64 calls ago has executed (AddTuples in the init stage queues ~1500 copies without a read-back)
         buf = self._idx_pin[self._idx_slot, :a.size]
         buf.copy_(torch.from_numpy(a))
-        return buf.to(self.device, non_blocking=True)
+        out = buf.to(self.device, non_blocking=True)
+        if ev is None:
+            ev = self._idx_events[self._idx_slot] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return out
 
     def _rows(self, ids):
         return self.mem[self._idx(ids)]

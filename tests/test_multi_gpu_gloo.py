@@ -113,3 +113,35 @@ def test_shard_range():
     from deepterrainrl_amd.sharding import shard_range
     assert [shard_range(32768, 8, r) for r in (0, 7)] == [(0, 4096), (28672, 4096)]
     assert [shard_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
+
+
+def test_overlapped_exchange_equals_the_synchronous_one(om):
+    """gather_tuples_begin / UpdateBegin / gather_tuples_end / UpdateEnd (the bench's exchange leg: the collective overlaps the next frame) hands the
+    trainer the same rows, in the same order, as the synchronous Update + gather_tuples loop; one packed policy broadcast installs the same policy."""
+    import torch
+    from deepterrainrl_amd.sharding import ShardedRollout
+    pol = dog_policy_()
+    def make(n, off):
+        return Scenario("args/opt_args_train_mace.txt", n, data_root=REFDATA, extra_args=dict(terrain_seed=300, rand_seed=9, global_env_offset=off))
+    a = ShardedRollout(make, 6); b = ShardedRollout(make, 6)
+    a.broadcast_policy(pol[1], *pol[2:]); b.broadcast_policy(pol[1], *pol[2:])
+    rows_a, rows_b = [], []
+    b.UpdateBegin()
+    for f in range(80):
+        a.Update()
+        g = a.gather_tuples()
+        rows_a.append(np.concatenate([g[0], g[1][:, None].astype(np.float32), g[2][:, None].astype(np.float32)], axis=1))
+        b.UpdateEnd(); b.gather_tuples_begin(); b.UpdateBegin()
+        r, fl, ids = b.gather_tuples_end()
+        rows_b.append(np.concatenate([r.numpy(), fl.numpy()[:, None].astype(np.float32), ids.numpy()[:, None].astype(np.float32)], axis=1))
+    b.UpdateEnd()
+    ra, rb = np.concatenate(rows_a), np.concatenate(rows_b)
+    assert len(ra) >= 6 and np.array_equal(ra, rb)
+    a.Update()   # b is one frame ahead (its frame 81 has run)
+    assert np.array_equal(a.batch.PoseVel()[0], b.batch.PoseVel()[0])
+
+
+def dog_policy_():
+    from conftest import dog_policy
+    from oracle import model as om
+    return dog_policy(om)

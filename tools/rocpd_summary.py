@@ -50,6 +50,8 @@ def main(src, dst):
             out.append("  %-24s n=%3d avg=%.6g%s" % (r[0], r[1], r[2], extra))
             if r[0] in ("FETCH_SIZE", "WRITE_SIZE"):
                 traffic[r[0]] = r[2] * 1024.0
+            if r[0] == "SQ_INSTS_VALU":
+                traffic[r[0]] = r[2]
         out.append("")
     open(dst, "w").write("\n".join(out) + "\n")
     if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
@@ -57,6 +59,7 @@ def main(src, dst):
         rec = {"source": os.path.basename(dst), "fetch_size_bytes_per_launch_raw": traffic["FETCH_SIZE"], "write_size_bytes_per_launch_raw": traffic["WRITE_SIZE"],
                "hbm_bytes_per_launch": 2.0 * traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"],
                "correction": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 read-request correction of MI355X_MICROARCH.md; separate --pmc passes)",
+               "sq_insts_valu_per_launch": traffic.get("SQ_INSTS_VALU"),
                "workload": "python bench.py --steps 20 --warmup 10 (4096 envs, full-batch frame launches only)"}
         json.dump(rec, open(os.path.join(os.path.dirname(dst), "hbm_traffic.json"), "w"), indent=1)
     print("\n".join(out))
