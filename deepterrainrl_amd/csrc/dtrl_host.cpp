@@ -563,7 +563,7 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		m.parent[j] = parent;
 		bool is_root = parent < 0;
 		m.attach[j][0] = is_root ? 0 : jd.get_num("AttachX", 0); m.attach[j][1] = is_root ? 0 : jd.get_num("AttachY", 0);
-		m.lim_lo[j] = jd.get_num("LimLow", 1); m.lim_hi[j] = jd.get_num("LimHigh", 0);                // anim/KinTree.cpp:990-1006
+		m.lim_lo[j] = jd.get_num("LimLow", 1); m.lim_hi[j] = jd.get_num("LimHigh", 0);                // anim/KinTree.cpp:990-1006 (shifted by ref_theta below)
 		D += (type == 1) ? 3 : 1;
 	}
 	m.D = D;
@@ -584,6 +584,16 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		m.kp[j] = pd.get_num("Kp", 0); m.kd[j] = pd.get_num("Kd", 0); m.torque_lim[j] = pd.get_num("TorqueLim", 0);
 		m.target_theta[j] = pd.get_num("TargetTheta", 0); m.use_world[j] = pd.get_num("UseWorldCoord", 0) != 0;
 	}
+	// hinge limits act on theta + ref_theta (sim/World.cpp:543-553: theta = -getHingeAngle() - ref_theta; :624-626 setLimit(-LimHigh, -LimLow)) with
+	// ref_theta = -angle(BodyJointTrans(parent) * ParentChildTrans(zero pose) * BodyJointTrans(child)) as cSimCharacter::BuildConstraints computes it
+	// (sim/SimCharacter.cpp:846-865; RotMatToAxisAngle returns acos of the cosine, util/MathUtil.cpp:128-149): the device tables hold the limits on theta itself
+	for (int j = 1; j < L; ++j) {
+		if (m.lim_lo[j] > m.lim_hi[j]) continue;   // free joint
+		const double cth = std::cos(m.body_theta[m.parent[j]] + m.body_theta[j]);
+		const double ref_theta = -std::acos(std::min(1.0, std::max(-1.0, cth)));
+		m.lim_lo[j] -= ref_theta; m.lim_hi[j] -= ref_theta;
+	}
+	m.contact_tol = 0.001 / world_scale;   // sim/ContactManager.cpp:74-75, dist_tol in world-scaled units
 	// contact sample points (4 corners + long-edge midpoints, DESIGN.md "Integrator v1") and end-effector points, joint frame
 	for (int j = 0; j < L; ++j) {
 		const double hx = m.body_half[j][0], hy = m.body_half[j][1];

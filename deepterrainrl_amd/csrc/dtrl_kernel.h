@@ -159,7 +159,7 @@ struct WSRef : WSBase {
 		real A[kMaxRows][kMaxRows + 1];
 		struct {
 			real pt_x[kMaxPts], pt_y[kMaxPts], pt_depth[kMaxPts], pt_nx[kMaxPts], pt_ny[kMaxPts];
-			int32_t pt_active[kMaxPts];
+			int32_t pt_active[kMaxPts];   // bit 0: gets constraint rows, bit 1: near the surface (contact flag), bit 2: scratch (dropped by a rank filter)
 		};
 	};
 };
@@ -531,11 +531,11 @@ DTRL_HD inline real row_jac(const W& ws, int r, int i)
 }
 
 // world position of contact sample point pt (relative to the root origin) + ground test; shared by both kernel paths
-struct PtVal { real x, y, depth, nx, ny; int active; };
-template <class W>
+struct PtVal { real x, y, depth, nx, ny; int active; int near; };   // active: penetrating (gets constraint rows); near: within contact_tol of the surface (sets the link's contact flag)
+template <bool kNear = true, class W>
 DTRL_HD_INLINE PtVal contact_point_eval(const W& ws, const DevModel& gm, const GroundRec& g, int pt)
 {
-	PtVal r; r.x = 0; r.y = 0; r.depth = 0; r.nx = 0; r.ny = 0; r.active = 0;
+	PtVal r; r.x = 0; r.y = 0; r.depth = 0; r.nx = 0; r.ny = 0; r.active = 0; r.near = 0;
 	const int j = pt / kPtsPerLink, k = pt - j * kPtsPerLink;
 	const GroundHdr gh = ground_header(g);   // issued with the sample point's local coordinates below: one trip to memory for both
 	if (ws.M.col[j] == 0) return r;
@@ -546,12 +546,15 @@ DTRL_HD_INLINE PtVal contact_point_eval(const W& ws, const DevModel& gm, const G
 	real slope;
 	const real h = sample_ground(g, gh, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
 	const real gap = h - (ws.st.q[1] + y);
-	if (!(gap > 0)) return r;   // depth = gap * ny with ny > 0: the normal is only needed for penetrating points
+	if (!kNear && !(gap > 0)) return r;                 // inside a substep only penetrating points matter (depth = gap * ny, ny > 0): skip the normal
 	const real inv = fast_rsqrt(1.0 + slope * slope);
+	const real depth = gap * inv;                       // along the cell normal (ny = inv > 0)
+	if (kNear) r.near = depth >= -gm.contact_tol ? 1 : 0;   // cContactManager::Update: getDistance() <= dist_tol
+	if (!(depth > 0)) return r;
 	r.nx = -slope * inv; r.ny = inv;
-	r.depth = gap * r.ny;
+	r.depth = depth;
 	r.x = x; r.y = y;
-	r.active = r.depth > 0 ? 1 : 0;
+	r.active = 1;
 	return r;
 }
 template <class W>
@@ -559,7 +562,7 @@ DTRL_HD inline int sample_contact_point(W& ws, const DevModel& gm, const GroundR
 {
 	const PtVal v = contact_point_eval(ws, gm, g, pt);
 	if (v.active) { ws.pt_x[pt] = v.x; ws.pt_y[pt] = v.y; ws.pt_depth[pt] = v.depth; ws.pt_nx[pt] = v.nx; ws.pt_ny[pt] = v.ny; }
-	ws.pt_active[pt] = v.active;
+	ws.pt_active[pt] = v.active | (v.near << 1);
 	return v.active;
 }
 // contact sample points of every colliding link against the env's heightfield (2 points per lane)
@@ -572,9 +575,27 @@ DTRL_HD inline void detect_contacts(W& ws, const DevModel& gm, const GroundRec& 
 	LANES_BEGIN
 	if (lane == 0) {
 		uint32_t bits = 0;
-		for (int j = 0; j < ws.M.L; ++j) { int any = 0; for (int k = 0; k < kPtsPerLink; ++k) any |= ws.pt_active[j * kPtsPerLink + k]; if (any) bits |= (1u << j); }
+		for (int j = 0; j < ws.M.L; ++j) { int any = 0; for (int k = 0; k < kPtsPerLink; ++k) any |= ws.pt_active[j * kPtsPerLink + k] & 2; if (any) bits |= (1u << j); }
 		ws.st.contact_bits = bits;
 	}
+	LANES_END
+	// at most kMaxPtsPerLink constraint-carrying points per link: the deepest ones (ties: lower sample-point index). Two phases: every lane ranks
+	// its points against the unfiltered flags, then the flags are rewritten
+	LANES_BEGIN
+	for (int pt = lane; pt < ws.M.L * kPtsPerLink; pt += kGroup) {
+		int drop = 0;
+		if (ws.pt_active[pt] & 1) {
+			const int base = (pt / kPtsPerLink) * kPtsPerLink;
+			const real d = ws.pt_depth[pt];
+			int rank = 0;
+			for (int k = 0; k < kPtsPerLink; ++k) { const int o = base + k; if (o != pt && (ws.pt_active[o] & 1)) { const real od = ws.pt_depth[o]; rank += (od > d || (od == d && o < pt)) ? 1 : 0; } }
+			drop = rank >= kMaxPtsPerLink;
+		}
+		if (drop) ws.pt_active[pt] |= 4;
+	}
+	LANES_END
+	LANES_BEGIN
+	for (int pt = lane; pt < ws.M.L * kPtsPerLink; pt += kGroup) { const int f = ws.pt_active[pt]; ws.pt_active[pt] = (f & 4) ? (f & 2) : (f & 3); }
 	LANES_END
 }
 
@@ -593,7 +614,19 @@ DTRL_HD inline void build_rows(W& ws, real h)
 			else if (th >= ws.M.lim_hi[j] - kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_dx[R] = -1; ws.row_tgt[R] = kLimitErp * fmax(th - ws.M.lim_hi[j], 0.0) * inv_h; ++R; }
 		}
 		int cap = (kMaxRows - R) / 2, nc = 0;
-		for (int pt = 0; pt < ws.M.L * kPtsPerLink && nc < cap; ++pt) if (ws.pt_active[pt]) {
+		// more penetrating points than rows: the deepest `cap` points overall get rows (ties: lower sample-point index)
+		int n_act = 0;
+		for (int pt = 0; pt < ws.M.L * kPtsPerLink; ++pt) n_act += ws.pt_active[pt] & 1;
+		if (n_act > cap) {
+			for (int pt = 0; pt < ws.M.L * kPtsPerLink; ++pt) if (ws.pt_active[pt] & 1) {
+				const real d = ws.pt_depth[pt];
+				int rank = 0;
+				for (int o = 0; o < ws.M.L * kPtsPerLink; ++o) if (o != pt && (ws.pt_active[o] & 1)) { const real od = ws.pt_depth[o]; rank += (od > d || (od == d && o < pt)) ? 1 : 0; }
+				if (rank >= cap) ws.pt_active[pt] |= 4;
+			}
+			for (int pt = 0; pt < ws.M.L * kPtsPerLink; ++pt) if (ws.pt_active[pt] & 4) ws.pt_active[pt] &= 2;
+		}
+		for (int pt = 0; pt < ws.M.L * kPtsPerLink && nc < cap; ++pt) if (ws.pt_active[pt] & 1) {
 			const int j = pt / kPtsPerLink;
 			real t = kErp * fmax(ws.pt_depth[pt] - kSlop, 0.0) * inv_h;
 			ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_x[R] = ws.pt_x[pt]; ws.row_y[R] = ws.pt_y[pt];

@@ -251,7 +251,7 @@ __device__ __forceinline__ real utsolve_regs(const real (&h)[D], real u)
 // flags and the ordered constraint-row list (same order as detect_contacts()/build_rows()) without touching LDS.
 // (three named values, not an array: the struct must stay in VGPRs, never in scratch)
 static_assert((kMaxPts + kGroup - 1) / kGroup == 3, "written for 3 sample points per lane");
-struct ContactPts { PtVal p0, p1, p2; unsigned long long m0, m1, m2; };
+struct ContactPts { PtVal p0, p1, p2; unsigned long long m0, m1, m2; /* constraint-carrying points */ unsigned long long f0, f1, f2; /* points near the surface: contact flags */ };
 // lane id the optimiser cannot see through: address / index arithmetic derived from it is recomputed where it is used instead of being
 // hoisted out of the 4000-instruction physics loop as a loop invariant and spilled to scratch across it
 __device__ __forceinline__ int opaque_lane()
@@ -260,39 +260,102 @@ __device__ __forceinline__ int opaque_lane()
 	asm volatile("" : "+v"(lane));
 	return lane;
 }
-__device__ __forceinline__ ContactPts eval_points(const WSFast& ws, const DevModel& gm, const GroundRec& g)
+// the kPtsPerLink ballot bits of link `link`'s sample points (points link * 6 .. link * 6 + 5 of the three 64-point ballots)
+__device__ __forceinline__ unsigned link_field(unsigned long long m0, unsigned long long m1, unsigned long long m2, int link)
+{
+	const int b = link * kPtsPerLink, word = b >> 6, off = b & 63;
+	unsigned long long lo = m0, hi = m1;   // (plain selects on by-value scalars: an indexable aggregate here would be demoted to scratch)
+	if (word == 1) { lo = m1; hi = m2; }
+	if (word == 2) { lo = m2; hi = 0ull; }
+	unsigned long long bits = lo >> off;
+	if (off + kPtsPerLink > 64) bits |= hi << (64 - off);
+	return static_cast<unsigned>(bits & ((1ull << kPtsPerLink) - 1ull));
+}
+// at most kMaxPtsPerLink constraint-carrying points per link, the deepest ones (ties: lower sample-point index). Cold path (a box lying in the
+// ground with five or six of its sample points below the surface): the depths go once through LDS (the packed-matrix storage is dead between
+// the factorisation and the Delassus build, and before the controller's mass rows) so that a point sees the other sample points of its link
+// Takes and returns scalars only (an aggregate passed by reference to a non-inlined function would live in scratch memory on the hot path):
+// d0..d2 = depth of the lane's three sample points or -1 when not penetrating; returns bit k set when point k is dropped
+__device__ __noinline__ unsigned link_cap_drop_mask(WSFast& ws, real d0, real d1, real d2)
+{
+	const int lane = opaque_lane();
+	const int npts = ws.M.L * kPtsPerLink;
+	real* S = ws.Apk;
+	if (lane < npts) S[lane] = d0;
+	if (lane + kGroup < npts) S[lane + kGroup] = d1;
+	if (lane + 2 * kGroup < npts) S[lane + 2 * kGroup] = d2;
+	__syncthreads();
+	auto over = [&](real d, int pt) -> unsigned {
+		if (!(d > 0)) return 0u;
+		const int base = (pt / kPtsPerLink) * kPtsPerLink;
+		int rank = 0;
+		for (int k = 0; k < kPtsPerLink; ++k) { const int o = base + k; const real od = S[o]; rank += (o != pt && (od > d || (od == d && o < pt))) ? 1 : 0; }
+		return rank >= kMaxPtsPerLink ? 1u : 0u;
+	};
+	const unsigned m = over(d0, lane) | (over(d1, lane + kGroup) << 1) | (over(d2, lane + 2 * kGroup) << 2);
+	__syncthreads();
+	return m;
+}
+// kFlags: also find the points within contact_tol of the surface (the per-link contact flags the controller reads: only the post-step pass needs them)
+template <bool kFlags>
+__device__ __forceinline__ ContactPts eval_points(WSFast& ws, const DevModel& gm, const GroundRec& g)
 {
 	const int lane = opaque_lane();
 	const int npts = ws.M.L * kPtsPerLink;
 	ContactPts c;
-	PtVal z; z.x = 0; z.y = 0; z.depth = 0; z.nx = 0; z.ny = 0; z.active = 0;
+	PtVal z; z.x = 0; z.y = 0; z.depth = 0; z.nx = 0; z.ny = 0; z.active = 0; z.near = 0;
 	c.p0 = z; c.p1 = z; c.p2 = z;
-	if (lane < npts) c.p0 = contact_point_eval(ws, gm, g, lane);
-	if (lane + kGroup < npts) c.p1 = contact_point_eval(ws, gm, g, lane + kGroup);
-	if (lane + 2 * kGroup < npts) c.p2 = contact_point_eval(ws, gm, g, lane + 2 * kGroup);
+	if (lane < npts) c.p0 = contact_point_eval<kFlags>(ws, gm, g, lane);
+	if (lane + kGroup < npts) c.p1 = contact_point_eval<kFlags>(ws, gm, g, lane + kGroup);
+	if (lane + 2 * kGroup < npts) c.p2 = contact_point_eval<kFlags>(ws, gm, g, lane + 2 * kGroup);
+	c.f0 = 0; c.f1 = 0; c.f2 = 0;
+	if (kFlags) { c.f0 = __ballot(c.p0.near); c.f1 = __ballot(c.p1.near); c.f2 = __ballot(c.p2.near); }
 	c.m0 = __ballot(c.p0.active); c.m1 = __ballot(c.p1.active); c.m2 = __ballot(c.p2.active);
+	if ((c.m0 | c.m1 | c.m2) != 0ull) {   // wave-uniform: somebody penetrates; does any link have more than kMaxPtsPerLink such points?
+		const int many = (lane < ws.M.L) && __popc(link_field(c.m0, c.m1, c.m2, lane)) > kMaxPtsPerLink;
+		if (__builtin_expect(__ballot(many) != 0ull, 0)) {
+			const unsigned drop = link_cap_drop_mask(ws, c.p0.active ? c.p0.depth : -1.0, c.p1.active ? c.p1.depth : -1.0, c.p2.active ? c.p2.depth : -1.0);
+			if (drop & 1u) c.p0.active = 0;
+			if (drop & 2u) c.p1.active = 0;
+			if (drop & 4u) c.p2.active = 0;
+			c.m0 = __ballot(c.p0.active); c.m1 = __ballot(c.p1.active); c.m2 = __ballot(c.p2.active);
+		}
+	}
 	return c;
+}
+// more penetrating points than constraint rows: the deepest `cap` points overall keep theirs (ties: lower sample-point index). Cold path
+// (a character lying on the ground with a dozen points in it)
+__device__ __noinline__ unsigned row_cap_drop_mask(WSFast& ws, real d0, real d1, real d2, int cap)
+{
+	const int lane = opaque_lane();
+	const int npts = ws.M.L * kPtsPerLink;
+	real* S = ws.Apk;
+	if (lane < npts) S[lane] = d0;
+	if (lane + kGroup < npts) S[lane + kGroup] = d1;
+	if (lane + 2 * kGroup < npts) S[lane + 2 * kGroup] = d2;
+	__syncthreads();
+	auto over = [&](real d, int pt) -> unsigned {
+		if (!(d > 0)) return 0u;
+		int rank = 0;
+		for (int o = 0; o < npts; ++o) { const real od = S[o]; rank += (o != pt && (od > d || (od == d && o < pt))) ? 1 : 0; }
+		return rank >= cap ? 1u : 0u;
+	};
+	const unsigned m = over(d0, lane) | (over(d1, lane + kGroup) << 1) | (over(d2, lane + 2 * kGroup) << 2);
+	__syncthreads();
+	return m;
 }
 __device__ __forceinline__ void contact_bits_fast(WSFast& ws, unsigned long long m0, unsigned long long m1, unsigned long long m2)
 {
 	const int lane = static_cast<int>(threadIdx.x);
 	int any = 0;
-	if (lane < ws.M.L) {
-		const int b = lane * kPtsPerLink, word = b >> 6, off = b & 63;
-		unsigned long long lo = m0, hi = m1;   // (plain selects on by-value scalars: an indexable aggregate here would be demoted to scratch)
-		if (word == 1) { lo = m1; hi = m2; }
-		if (word == 2) { lo = m2; hi = 0ull; }
-		unsigned long long bits = lo >> off;
-		if (off + kPtsPerLink > 64) bits |= hi << (64 - off);
-		any = (bits & ((1ull << kPtsPerLink) - 1ull)) != 0;
-	}
+	if (lane < ws.M.L) any = link_field(m0, m1, m2, lane) != 0u;
 	const unsigned long long lm = __ballot(any);
 	if (lane == 0) ws.st.contact_bits = static_cast<uint32_t>(lm);
 }
 __device__ __forceinline__ void detect_contacts_fast(WSFast& ws, const DevModel& gm, const GroundRec& g)
 {
-	const ContactPts c = eval_points(ws, gm, g);
-	contact_bits_fast(ws, c.m0, c.m1, c.m2);
+	const ContactPts c = eval_points<true>(ws, gm, g);
+	contact_bits_fast(ws, c.f0, c.f1, c.f2);
 	__syncthreads();
 }
 __device__ __forceinline__ void emit_contact_rows(WSFast& ws, const PtVal& p, int pt, int rank, int cap, int R0, real inv_h)
@@ -307,8 +370,9 @@ __device__ __forceinline__ void emit_contact_rows(WSFast& ws, const PtVal& p, in
 		ws.row_dx[R + 1] = p.ny; ws.row_dy[R + 1] = -p.nx; ws.row_tgt[R + 1] = 0;
 	}
 }
-__device__ __forceinline__ void build_rows_fast(WSFast& ws, const ContactPts& c, real h)
+__device__ __forceinline__ void build_rows_fast(WSFast& ws, const ContactPts& c_in, real h)
 {
+	ContactPts c = c_in;
 	const int lane = static_cast<int>(threadIdx.x);
 	const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 	const real inv_h = 1.0 / h;
@@ -325,6 +389,13 @@ __device__ __forceinline__ void build_rows_fast(WSFast& ws, const ContactPts& c,
 	if (lim != 0 && rl < kMaxRows) { ws.row_kind[rl] = 0; ws.row_link[rl] = lane; ws.row_dx[rl] = lim; ws.row_tgt[rl] = tgt; }
 	// contacts, ordered by sample-point index
 	const int cap = (kMaxRows - R0) / 2;
+	if (__builtin_expect(__popcll(c.m0) + __popcll(c.m1) + __popcll(c.m2) > cap, 0)) {   // wave-uniform
+		const unsigned drop = row_cap_drop_mask(ws, c.p0.active ? c.p0.depth : -1.0, c.p1.active ? c.p1.depth : -1.0, c.p2.active ? c.p2.depth : -1.0, cap);
+		if (drop & 1u) c.p0.active = 0;
+		if (drop & 2u) c.p1.active = 0;
+		if (drop & 4u) c.p2.active = 0;
+		c.m0 = __ballot(c.p0.active); c.m1 = __ballot(c.p1.active); c.m2 = __ballot(c.p2.active);
+	}
 	const int n0 = __popcll(c.m0), n1 = __popcll(c.m1), n2 = __popcll(c.m2);
 	emit_contact_rows(ws, c.p0, lane, __popcll(c.m0 & below), cap, R0, inv_h);
 	emit_contact_rows(ws, c.p1, lane + kGroup, n0 + __popcll(c.m1 & below), cap, R0, inv_h);
@@ -520,7 +591,7 @@ struct FastPath {
 			__syncthreads();
 		} else {
 			ContactPts cp;
-			{ PROF_T0(); cp = eval_points(ws, gm, g); contact_bits_fast(ws, cp.m0, cp.m1, cp.m2); PROF_ADD(ws, kProfDetect); }
+			{ PROF_T0(); cp = eval_points<false>(ws, gm, g); PROF_ADD(ws, kProfDetect); }   // the per-link contact flags are the post-step pass's business (contacts() below)
 			{ PROF_T0(); build_rows_fast(ws, cp, h); PROF_ADD(ws, kProfRows); }
 		}
 		const int R = ws.R;
@@ -609,8 +680,8 @@ struct FastPath {
 	// the next env-step's first substep (same q, same heightfield window within a launch)
 	static __device__ void contacts(WSFast& ws, const DevModel& gm, const GroundRec& g, real h)
 	{
-		const ContactPts cp = eval_points(ws, gm, g);
-		contact_bits_fast(ws, cp.m0, cp.m1, cp.m2);
+		const ContactPts cp = eval_points<true>(ws, gm, g);
+		contact_bits_fast(ws, cp.f0, cp.f1, cp.f2);
 		build_rows_fast(ws, cp, h);
 		if (threadIdx.x == 0) ws.n_pts_active = ws.R;
 		__syncthreads();

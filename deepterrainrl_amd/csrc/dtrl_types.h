@@ -22,6 +22,7 @@ constexpr int kMaxAct = 16;
 constexpr int kMaxDepth = 12;    // longest root->link path (dog: 10)
 constexpr int kMaxRows = 24;     // constraint rows per substep (joint limits + 2 per contact point)
 constexpr int kPtsPerLink = 6;   // contact sample points per box link (4 corners + 2 long-edge midpoints)
+constexpr int kMaxPtsPerLink = 4;  // constraint-carrying points of one link--ground pair (Bullet's persistent manifold holds 4): the deepest ones
 constexpr int kMaxPts = kMaxL * kPtsPerLink;
 constexpr int kSegCap = 512;     // floats per heightfield segment slot (51 m at 0.1 m spacing)
 constexpr int kNumGroundSamples = 200;
@@ -73,6 +74,7 @@ struct DevModel {
 	real eff_joint[kMaxL][2];               // body-local (0, -size_y/2) in the joint frame (end-effector contact position)
 	real init_pos_x, target_vel_x, total_mass;
 	real world_scale;
+	real contact_tol;                       // cContactManager::Update: a link is in contact when a point is within 0.001 (world-scaled units) of the surface = 0.001 / world_scale
 };
 
 // exploration knobs + seeds: may change between launches (dtrl_set_explore)

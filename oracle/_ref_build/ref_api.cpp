@@ -186,6 +186,26 @@ void ref_rbd(void* h, const double* q, const double* qd, double* H, double* C, d
 	}
 	if (joint_pos) for (int j = 0; j < L; ++j) { tVector p = c->model.CalcJointWorldPos(j); for (int k = 0; k < 3; ++k) joint_pos[3 * j + k] = p[k]; }
 }
+// cWorld::tJointParams::mRefTheta of every joint, evaluated with the reference's own primitives in the order cSimCharacter::BuildConstraints uses them
+// (sim/SimCharacter.cpp:838-853; that translation unit itself needs Bullet): BodyJointTrans, ParentChildTrans at the zero pose, InvRigidMat, RotMatToAxisAngle
+void ref_char_ref_theta(void* h, double* out)
+{
+	RefChar* c = static_cast<RefChar*>(h);
+	const int L = cKinTree::GetNumJoints(c->joint_mat);
+	Eigen::VectorXd default_pose = Eigen::VectorXd::Zero(cKinTree::GetNumDof(c->joint_mat));
+	for (int j = 0; j < L; ++j) {
+		out[j] = 0;
+		const int parent_id = cKinTree::GetParent(c->joint_mat, j);
+		if (parent_id == cKinTree::gInvalidJointID) continue;
+		tMatrix curr_body_mat = cKinTree::BodyJointTrans(c->body_defs, j);
+		tMatrix child_parent_mat = cKinTree::ParentChildTrans(c->joint_mat, default_pose, j);
+		tMatrix parent_body_mat = cMathUtil::InvRigidMat(cKinTree::BodyJointTrans(c->body_defs, parent_id));
+		tMatrix child_parent_body_mat = cMathUtil::InvRigidMat(parent_body_mat) * child_parent_mat * curr_body_mat;
+		tVector ref_axis; double ref_theta;
+		cMathUtil::RotMatToAxisAngle(child_parent_body_mat, ref_axis, ref_theta);
+		out[j] = -ref_theta;
+	}
+}
 // inverse dynamics for a given acceleration: cRBDUtil::SolveInvDyna (sim/RBDUtil.cpp:4-84) after Update(pose, vel)
 void ref_inv_dyna(void* h, const double* q, const double* qd, const double* acc, double* tau)
 {

@@ -20,6 +20,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 """
 import ctypes as C
 import json
+import math
 import os
 import re
 
@@ -36,7 +37,7 @@ class OrcModel(C.Structure):
         ("char_type", C.c_int32), ("ctrl_type", C.c_int32), ("L", C.c_int32), ("D", C.c_int32),
         ("parent", C.c_int32 * MAXL), ("joint_type", C.c_int32 * MAXL),
         ("attach", (C.c_double * 3) * MAXL),
-        ("lim_lo", C.c_double * MAXL), ("lim_hi", C.c_double * MAXL),
+        ("lim_lo", C.c_double * MAXL), ("lim_hi", C.c_double * MAXL), ("ref_theta", C.c_double * MAXL),
         ("body_attach", (C.c_double * 3) * MAXL), ("body_theta", C.c_double * MAXL),
         ("body_size", (C.c_double * 3) * MAXL), ("body_mass", C.c_double * MAXL),
         ("col_group", C.c_int32 * MAXL),
@@ -184,6 +185,17 @@ def build_model(arg_file, root, overrides=None):
             m.body_attach[j][k] = float(bd.get(key, 0))
         for k, key in enumerate(("Param0", "Param1", "Param2")):
             m.body_size[j][k] = float(bd.get(key, 0))
+    # cSimCharacter::BuildConstraints (sim/SimCharacter.cpp:846-853): ref_theta = -angle(RotMatToAxisAngle(BodyJointTrans(parent) * ParentChildTrans(zero pose)
+    # * BodyJointTrans(child))): the rotation parts multiply to R_z(theta_parent + theta_child), RotMatToAxisAngle returns acos((trace - 1) / 2) in [0, pi]
+    # (util/MathUtil.cpp:128-149). The hinge limits apply to theta + ref_theta (sim/World.cpp:543-553, 624-626): only the dog's / goat's root body is rotated (0.61),
+    # so spine0, tail0 and hip carry ref_theta = -0.61 and everything else 0
+    for j in range(L):
+        p = m.parent[j]
+        if p < 0:
+            m.ref_theta[j] = 0.0
+        else:
+            c = math.cos(m.body_theta[p] + m.body_theta[j])
+            m.ref_theta[j] = -math.acos(max(-1.0, min(1.0, c)))
     pds = char["PDControllers"]
     assert len(pds) == L
     for j, pd in enumerate(pds):

@@ -23,6 +23,7 @@ struct OrcModel {
 	int32_t joint_type[ORC_MAXL];          // cKinTree::eJointType (0 revolute, 1 planar)
 	double attach[ORC_MAXL][3];            // joint attach point in parent joint frame
 	double lim_lo[ORC_MAXL], lim_hi[ORC_MAXL];
+	double ref_theta[ORC_MAXL];            // cWorld::tJointParams::mRefTheta as cSimCharacter::BuildConstraints computes it (sim/SimCharacter.cpp:846-865)
 	double body_attach[ORC_MAXL][3];       // body COM in joint frame
 	double body_theta[ORC_MAXL];
 	double body_size[ORC_MAXL][3];

@@ -15,6 +15,13 @@
 //   normal target velocity = min(ERP * max(depth - slop, 0) / h, v_depen_max); friction box |lt| <= mu * ln.
 //   Contact sample points per box link: 4 corners + midpoints of the two long edges, tested against the
 //   heightfield polyline; depth measured along the cell normal.
+// Reference-visible semantics carried by the model (round 2):
+//   * hinge limits act on theta + ref_theta (sim/World.cpp:543-553: theta = -getHingeAngle() - ref_theta; :624-626 setLimit(-LimHigh, -LimLow)),
+//     ref_theta as cSimCharacter::BuildConstraints computes it (sim/SimCharacter.cpp:846-865): LimLow - ref_theta <= theta <= LimHigh - ref_theta;
+//   * a link is "in contact" when a manifold point is within dist_tol = 0.001 in WORLD-SCALED units of the surface
+//     (sim/ContactManager.cpp:74-75: pt.getDistance() <= 0.001f), i.e. separation <= 0.001 / world_scale, not only when it penetrates;
+//   * at most 4 contact points per link and ground (Bullet's persistent manifold holds 4 points per pair): the deepest four of the link's
+//     penetrating sample points; when the row budget is exceeded the DEEPEST points overall get rows (not the lowest link ids).
 #pragma once
 #include "or_rbd.h"
 #include "or_terrain.h"
@@ -31,6 +38,8 @@ struct SimConst {
 	static constexpr int pgs_iters = 10;
 	static constexpr int max_rows = 24;
 	static constexpr int pts_per_link = 6;
+	static constexpr int max_pts_per_link = 4;      // points of one link--ground manifold
+	static constexpr double contact_dist_tol = 0.001;   // world-scaled units (sim/ContactManager.cpp:74)
 };
 
 struct Bodies {
@@ -85,12 +94,17 @@ inline void LinkSamplePoint(const OrcModel& M, int j, int k, double& sx, double&
 
 struct ContactPoint { int link; double x, y, depth, nx, ny; };
 
-// contact detection at the current configuration; fills in-contact flags per link
+// contact detection at the current configuration; fills in-contact flags per link and the list of points that get constraint rows
+// (ordered by link, then sample point): per link the deepest max_pts_per_link penetrating points; overall the deepest `cap`
 inline int DetectContacts(const OrcModel& M, const Bodies& B, const Ground& g, ContactPoint* out, int cap, bool* flags)
 {
-	int n = 0;
+	const int npts = M.L * SimConst::pts_per_link;
+	ContactPoint all[ORC_MAXL * SimConst::pts_per_link];
+	bool active[ORC_MAXL * SimConst::pts_per_link];
+	const double tol = SimConst::contact_dist_tol / M.world_scale;
 	for (int j = 0; j < M.L; ++j) {
 		flags[j] = false;
+		for (int k = 0; k < SimConst::pts_per_link; ++k) active[j * SimConst::pts_per_link + k] = false;
 		if (M.col_group[j] == 0) continue;
 		double c = std::cos(B.psi[j]), s = std::sin(B.psi[j]);
 		for (int k = 0; k < SimConst::pts_per_link; ++k) {
@@ -102,12 +116,38 @@ inline int DetectContacts(const OrcModel& M, const Bodies& B, const Ground& g, C
 			double inv = 1.0 / std::sqrt(1.0 + slope * slope);
 			double nx = -slope * inv, ny = inv;
 			double depth = (h - y) * ny;
-			if (depth > 0) {
-				flags[j] = true;
-				if (n < cap) { out[n].link = j; out[n].x = x; out[n].y = y; out[n].depth = depth; out[n].nx = nx; out[n].ny = ny; ++n; }
-			}
+			if (depth >= -tol) flags[j] = true;                 // cContactManager::Update: distance <= dist_tol
+			ContactPoint& p = all[j * SimConst::pts_per_link + k];
+			p.link = j; p.x = x; p.y = y; p.depth = depth; p.nx = nx; p.ny = ny;
+			active[j * SimConst::pts_per_link + k] = depth > 0;
 		}
 	}
+	// a point outranks another when it is deeper (ties: lower sample-point index)
+	auto outranks = [&](int a, int b) { return all[a].depth > all[b].depth || (all[a].depth == all[b].depth && a < b); };
+	bool keep[ORC_MAXL * SimConst::pts_per_link];
+	int n_keep = 0;
+	for (int pt = 0; pt < npts; ++pt) {
+		keep[pt] = false;
+		if (!active[pt]) continue;
+		const int j = pt / SimConst::pts_per_link;
+		int rank = 0;
+		for (int k = 0; k < SimConst::pts_per_link; ++k) { const int o = j * SimConst::pts_per_link + k; if (o != pt && active[o] && outranks(o, pt)) ++rank; }
+		keep[pt] = rank < SimConst::max_pts_per_link;
+		n_keep += keep[pt];
+	}
+	if (n_keep > cap) {
+		bool keep2[ORC_MAXL * SimConst::pts_per_link];
+		for (int pt = 0; pt < npts; ++pt) {
+			keep2[pt] = false;
+			if (!keep[pt]) continue;
+			int rank = 0;
+			for (int o = 0; o < npts; ++o) if (o != pt && keep[o] && outranks(o, pt)) ++rank;
+			keep2[pt] = rank < cap;
+		}
+		for (int pt = 0; pt < npts; ++pt) keep[pt] = keep2[pt];
+	}
+	int n = 0;
+	for (int pt = 0; pt < npts; ++pt) if (keep[pt] && n < cap) out[n++] = all[pt];
 	return n;
 }
 
@@ -160,12 +200,13 @@ struct Integrator {
 		for (int j = 1; j < M.L; ++j) {
 			if (M.lim_lo[j] > M.lim_hi[j]) continue;
 			double th = q[j + 2];
-			if (th <= M.lim_lo[j] + SimConst::limit_slop && R < SimConst::max_rows) {
+			const double lo = M.lim_lo[j] - M.ref_theta[j], hi = M.lim_hi[j] - M.ref_theta[j];   // limits act on theta + ref_theta
+			if (th <= lo + SimConst::limit_slop && R < SimConst::max_rows) {
 				for (int i = 0; i < D; ++i) Jr[R][i] = 0;
-				Jr[R][j + 2] = 1; kind[R] = 0; tgt[R] = SimConst::limit_erp * std::max(M.lim_lo[j] - th, 0.0) / h; ++R;
-			} else if (th >= M.lim_hi[j] - SimConst::limit_slop && R < SimConst::max_rows) {
+				Jr[R][j + 2] = 1; kind[R] = 0; tgt[R] = SimConst::limit_erp * std::max(lo - th, 0.0) / h; ++R;
+			} else if (th >= hi - SimConst::limit_slop && R < SimConst::max_rows) {
 				for (int i = 0; i < D; ++i) Jr[R][i] = 0;
-				Jr[R][j + 2] = -1; kind[R] = 0; tgt[R] = SimConst::limit_erp * std::max(th - M.lim_hi[j], 0.0) / h; ++R;
+				Jr[R][j + 2] = -1; kind[R] = 0; tgt[R] = SimConst::limit_erp * std::max(th - hi, 0.0) / h; ++R;
 			}
 		}
 		ContactPoint cps[SimConst::max_rows / 2];

@@ -45,6 +45,7 @@ def lib():
         L.ref_char_dims.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.ref_char_tables.argtypes = [vp, vp, vp]
         L.ref_rbd.argtypes = [vp] * 10
+        L.ref_char_ref_theta.argtypes = [vp, vp]
         L.ref_inv_dyna.argtypes = [vp] * 5
         L.ref_kin_bodies.argtypes = [vp] * 6
         L.ref_kin_world_vel.argtypes = [vp, vp, vp, C.c_int, vp, vp]
@@ -149,6 +150,9 @@ class RefChar:
     def tables(self):
         j = np.zeros((self.L, 9)); b = np.zeros((self.L, 8))
         lib().ref_char_tables(self.h, _p(j), _p(b)); return j, b
+
+    def ref_theta(self):
+        out = np.zeros(self.L); lib().ref_char_ref_theta(self.h, _p(out)); return out
 
     def rbd(self, q, qd):
         """dict(H, C, grav, J, com, com_vel, joint_pos) after cRBDModel::Update(q, qd)."""

@@ -211,6 +211,22 @@ def test_kin_tree_tables_match_the_reference_loader(om, name, arg):
 
 @needs_ref
 @pytest.mark.parametrize("name,arg", CHARS)
+def test_hinge_limit_reference_angles(om, da, name, arg):
+    """mRefTheta (sim/SimCharacter.cpp:838-865) from the reference's own BodyJointTrans / ParentChildTrans / InvRigidMat / RotMatToAxisAngle == the oracle
+    loader's closed form; the hinge limits then act on theta + ref_theta (sim/World.cpp:543-553, 624-626). Only the children of the dog's / goat's
+    rotated root body (spine0, tail0, hip) carry a non-zero one."""
+    m, info = om.build_model(arg, REFERENCE)
+    r = rc.RefChar(os.path.join(REFERENCE, info["args"]["character_file"]))
+    got = r.ref_theta()
+    assert np.abs(got - np.array(m.ref_theta[:m.L])).max() < 1e-12
+    nz = [j for j in range(m.L) if abs(got[j]) > 1e-9]
+    assert nz == ([1, 9, 17] if name != "raptor" else [])
+    if name != "raptor":
+        assert abs(got[17] + 0.61) < 1e-12
+
+
+@needs_ref
+@pytest.mark.parametrize("name,arg", CHARS)
 def test_rbd_model_matches_the_reference(om, name, arg):
     """cRBDModel::Update -> BuildMassMat (CRBA), BuildBiasForce (RNEA with BuildCjPlanar as shipped), CalcGravityForce, CalcCoM."""
     m, info = om.build_model(arg, REFERENCE)
