@@ -110,22 +110,25 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
 
     def frame(k):
         nonlocal cursor, tuples
-        # frame k is running (UpdateBegin was called); finish it, hand its tuples to the collective, start frame k + 1, then consume
-        sr.UpdateEnd()
-        sr.gather_tuples_begin()
-        sr.UpdateBegin()
-        g = sr.gather_tuples_end(dst=0)
-        if rank == 0:
-            rows = g[0]; m = int(rows.shape[0])
-            if m:
-                idx = (torch.arange(m, device=dev) + cursor) % replay_cap
-                replay[idx] = rows
-                cursor = (cursor + m) % replay_cap; tuples += m
+        # Frame k is running (UpdateBegin was called). Everything below happens in the gap between two frame kernels, when the GPU is idle: a
+        # frame kernel fills every CU for ~4 ms, so small kernels or host syncs issued WHILE it runs wait for it (measured: 5 ms per frame lost
+        # that way). Only the collective itself overlaps the next frame; its result is consumed one frame later.
+        sr.UpdateEnd()                                   # frame k finished (status read-back, terrain windows, resets)
+        if sr._pending is not None:
+            g = sr.gather_tuples_end(dst=0)              # all-gather of frame k - 1's tuples: started a whole frame ago
+            if rank == 0:
+                rows = g[0]; m = int(rows.shape[0])
+                if m:
+                    idx = (torch.arange(m, device=dev) + cursor) % replay_cap
+                    replay[idx] = rows
+                    cursor = (cursor + m) % replay_cap; tuples += m
         if bcast_every > 0 and (k + 1) % bcast_every == 0:
             if rank == 0:
                 sr.broadcast_policy(*pol, src=0)
             else:
                 sr.broadcast_policy(src=0)
+        sr.gather_tuples_begin()                         # drain frame k's tuples device-to-device, pack, start the all-gather on the comm stream
+        sr.UpdateBegin()                                 # frame k + 1
     sr.UpdateBegin()
     for k in range(warmup):
         frame(k)
@@ -138,6 +141,8 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
     fence()
     dt = time.perf_counter() - t0
     sr.UpdateEnd()
+    if sr._pending is not None:
+        sr.gather_tuples_end(dst=0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

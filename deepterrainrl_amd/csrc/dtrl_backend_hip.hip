@@ -43,6 +43,17 @@ __global__ void dtrl_gather_f32(float* __restrict__ dst, const float* __restrict
 	}
 }
 
+// gr[ids[b]] = staged[b]: one workgroup per record (4 176 B as 16-byte words)
+__global__ void dtrl_scatter_ground(GroundRec* __restrict__ gr, const GroundRec* __restrict__ staged, const int32_t* __restrict__ ids, int n)
+{
+	const int b = static_cast<int>(blockIdx.x);
+	if (b >= n) return;
+	static_assert(sizeof(GroundRec) % 16 == 0, "GroundRec is copied as 16-byte words");
+	const uint4* src = reinterpret_cast<const uint4*>(&staged[b]);
+	uint4* dst = reinterpret_cast<uint4*>(&gr[ids[b]]);
+	for (int i = static_cast<int>(threadIdx.x); i < static_cast<int>(sizeof(GroundRec) / 16); i += static_cast<int>(blockDim.x)) dst[i] = src[i];
+}
+
 class HipBackend : public Backend {
 public:
 	~HipBackend() override
@@ -82,6 +93,12 @@ public:
 	{
 		hipLaunchKernelGGL(dtrl_gather_f32, dim3(1024), dim3(256), 0, stream_, dst, src, idx, n);
 		return Check(hipGetLastError(), "gather launch") && Check(hipStreamSynchronize(stream_), "sync");
+	}
+	bool ScatterGround(GroundRec* gr, const GroundRec* staged, const int32_t* ids, int n) override
+	{
+		if (n <= 0) return true;
+		hipLaunchKernelGGL(dtrl_scatter_ground, dim3(n), dim3(256), 0, stream_, gr, staged, ids, n);
+		return Check(hipGetLastError(), "scatter launch");
 	}
 	bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) override
 	{

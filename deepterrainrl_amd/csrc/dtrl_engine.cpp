@@ -17,8 +17,13 @@
 #include <cstdlib>
 #include <cstdio>
 #include "../../include/dtrl.h"
+#include <atomic>
+#include <condition_variable>
 #include <cstddef>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 namespace dtrl {
 
@@ -28,12 +33,80 @@ constexpr double kGroundSpawnOffset = -1.0; // scenarios/ScenarioSimChar.cpp:19
 constexpr double kViewPad = 1.0;            // gCharViewDistPad, scenarios/ScenarioSimChar.cpp:18
 }
 
+// Persistent host workers for the frame-boundary terrain regeneration: every env owns its RNG stream and its window, so the rebuilds of one
+// frame are independent (the reference runs one OS thread per scene, scenarios/ScenarioTrain.cpp:100-115). The pool is process-wide and
+// created on first use; a frame with fewer than kMinParallel rebuilds stays on the calling thread.
+namespace {
+class WorkerPool {
+public:
+	static WorkerPool& Get() { static WorkerPool p; return p; }
+	void ParallelFor(int count, const std::function<void(int)>& fn)
+	{
+		if (count <= 0) return;
+		if (count < kMinParallel || threads_.empty()) { for (int i = 0; i < count; ++i) fn(i); return; }
+		std::lock_guard<std::mutex> one_caller(call_m_);   // batches driven from different host threads take turns
+		{
+			std::lock_guard<std::mutex> lk(m_);
+			fn_ = &fn; count_ = count; next_.store(0); done_ = 0; ++epoch_;
+		}
+		cv_.notify_all();
+		Run();   // the caller works too
+		std::unique_lock<std::mutex> lk(m_);
+		cv_done_.wait(lk, [&] { return done_ == count_; });
+		fn_ = nullptr;
+	}
+private:
+	static constexpr int kMinParallel = 8;
+	WorkerPool()
+	{
+		int n = 0;
+		if (const char* env = std::getenv("DTRL_HOST_THREADS")) n = std::atoi(env);
+		else n = std::min(16, static_cast<int>(std::thread::hardware_concurrency()) / 2);
+		for (int t = 1; t < n; ++t) threads_.emplace_back([this] { Loop(); });
+	}
+	~WorkerPool()
+	{
+		{ std::lock_guard<std::mutex> lk(m_); stop_ = true; ++epoch_; }
+		cv_.notify_all();
+		for (auto& t : threads_) t.join();
+	}
+	void Run()
+	{
+		int finished = 0;
+		for (;;) {
+			const int i = next_.fetch_add(1);
+			if (i >= count_) break;
+			(*fn_)(i); ++finished;
+		}
+		if (finished) { std::lock_guard<std::mutex> lk(m_); done_ += finished; if (done_ == count_) cv_done_.notify_all(); }
+	}
+	void Loop()
+	{
+		long seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> lk(m_);
+				cv_.wait(lk, [&] { return epoch_ != seen; });
+				seen = epoch_;
+				if (stop_) return;
+			}
+			Run();
+		}
+	}
+	std::vector<std::thread> threads_;
+	std::mutex m_, call_m_; std::condition_variable cv_, cv_done_;
+	const std::function<void(int)>* fn_ = nullptr;
+	int count_ = 0, done_ = 0; std::atomic<int> next_{0};
+	long epoch_ = 0; bool stop_ = false;
+};
+}  // namespace
+
 Engine::~Engine()
 {
 	if (be_) {
 		be_->Sync();
 		for (void* p : allocs_) be_->Free(p);
-		be_->FreeHostStaging(pin_recs_); be_->FreeHostStaging(pin_order_); be_->FreeHostStaging(pin_ids_); be_->FreeHostStaging(status_);
+		be_->FreeHostStaging(pin_recs_); be_->FreeHostStaging(pin_order_); be_->FreeHostStaging(pin_ids_); be_->FreeHostStaging(pin_stage_ids_); be_->FreeHostStaging(status_);
 		delete be_;
 	}
 }
@@ -93,7 +166,10 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	pin_recs_ = static_cast<GroundRec*>(be_->HostStaging(sizeof(GroundRec) * n_));
 	pin_order_ = static_cast<int32_t*>(be_->HostStaging(sizeof(int32_t) * n_));
 	pin_ids_ = static_cast<int32_t*>(be_->HostStaging(sizeof(int32_t) * n_));
-	if (!pin_recs_ || !pin_order_ || !pin_ids_) return Fail(DTRL_ERR_DEVICE, "host staging allocation failed: " + be_->error());
+	pin_stage_ids_ = static_cast<int32_t*>(be_->HostStaging(sizeof(int32_t) * n_));
+	d_stage_recs_ = static_cast<GroundRec*>(alloc(sizeof(GroundRec) * n_));
+	d_stage_ids_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
+	if (!pin_recs_ || !pin_order_ || !pin_ids_ || !pin_stage_ids_ || !d_stage_recs_ || !d_stage_ids_) return Fail(DTRL_ERR_DEVICE, "host staging allocation failed: " + be_->error());
 	// env groups (one stream each). Two halves is the measured optimum (4096 envs on one MI355X: 1 group 10.1 M env-steps/s, 2 groups
 	// 13.7 M, 3: 10.9 M, 4: 12.6 M, 8: 6.3 M): one half fills the 2048 resident-wavefront slots while the other half's frame-boundary host
 	// work runs; more groups only add host work and launches. DTRL_GROUPS overrides.
@@ -211,27 +287,35 @@ int Engine::HostFrameWork(int group)
 	// have completed, so its slice of the staging arena can be reused from the start
 	if (!be_->D2H(status_ + e0, buf_.status + e0, sizeof(EnvStatus) * grp.n)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	const double ht1 = g_ht.on ? now_s() : 0;
-	int used = 0;
 	reset_ids_.clear();
-	auto upload = [&](int e) {
-		GroundRec* slot = &pin_recs_[e0 + used++];
-		if (!grounds_[e].FillRecord(*slot, err_)) return false;
-		if (!be_->H2DAsync(&buf_.gr[e], slot, sizeof(GroundRec))) { err_ = be_->error(); return false; }
-		return true;
-	};
+	work_.clear();
 	for (int e = e0; e < e1; ++e) {
 		const EnvStatus& s = status_[e];
-		GroundWindow& g = grounds_[e];
 		if (s.need_reset & 2) dist_log_.emplace_back(e, s.episode_dist);   // cScenarioPoliEval::RecordDistTraveled -> mDistLog
-		if (s.need_reset) {
-			// cScenarioSimChar::ResetGround: Clear + Update around the spawn point -> InitSegments with the SAME rng stream
-			g.Clear();
-			g.Update(-kViewDist + kGroundSpawnOffset, kViewDist + kGroundSpawnOffset);
-			if (!upload(e)) return DTRL_ERR_CAPACITY;
-			reset_ids_.push_back(e);
-		} else if (g.Update(s.root_x - 2, s.root_x + kViewDist + kViewPad)) {
-			if (!upload(e)) return DTRL_ERR_CAPACITY;
-		}
+		if (s.need_reset) { reset_ids_.push_back(e); work_.push_back(e); }
+		else if (grounds_[e].NeedsUpdate(s.root_x - 2, s.root_x + kViewDist + kViewPad)) work_.push_back(e);
+	}
+	const int used = static_cast<int>(work_.size());
+	if (used > 0) {
+		// the rebuilds of one frame are independent (own RNG stream, own window per env): host workers share them; every rebuilt record goes into
+		// its slot of the group's page-locked slice, then ONE upload + one scatter launch replace a hipMemcpyAsync per env
+		std::atomic<int> failed{0};
+		WorkerPool::Get().ParallelFor(used, [&](int k) {
+			const int e = work_[k];
+			GroundWindow& g = grounds_[e];
+			const EnvStatus& s = status_[e];
+			if (s.need_reset) {
+				// cScenarioSimChar::ResetGround: Clear + Update around the spawn point -> InitSegments with the SAME rng stream
+				g.Clear();
+				g.Update(-kViewDist + kGroundSpawnOffset, kViewDist + kGroundSpawnOffset);
+			} else g.Update(s.root_x - 2, s.root_x + kViewDist + kViewPad);
+			std::string err;
+			if (!g.FillRecord(pin_recs_[e0 + k], err)) failed.store(1);
+			pin_stage_ids_[e0 + k] = e;
+		});
+		if (failed.load()) return Fail(DTRL_ERR_CAPACITY, "terrain segment exceeds kSegCap vertices");
+		if (!be_->H2DAsync(d_stage_recs_ + e0, pin_recs_ + e0, sizeof(GroundRec) * used) || !be_->H2DAsync(d_stage_ids_ + e0, pin_stage_ids_ + e0, sizeof(int32_t) * used)
+			|| !be_->ScatterGround(buf_.gr, d_stage_recs_ + e0, d_stage_ids_ + e0, used)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	}
 	const double ht2 = g_ht.on ? now_s() : 0;
 	// longest-processing-time-first: a launch is as long as its slowest wavefront (a stumbling character with ~20 constraint

@@ -24,6 +24,9 @@ public:
 	virtual bool D2D(void* dst, const void* src, size_t n) = 0;   // device-to-device on the selected stream, synchronised before returning
 	// dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 for i < n, all device pointers (policy hand-over without a host round trip); synchronised
 	virtual bool GatherF32(float* dst, const float* src, const int32_t* idx, size_t n) = 0;
+	// gr[ids[k]] = staged[k] for k < n (device pointers), queued on the selected stream: the frame's regenerated terrain windows arrive as ONE upload
+	// of a packed array + this scatter instead of one hipMemcpyAsync per env
+	virtual bool ScatterGround(GroundRec* gr, const GroundRec* staged, const int32_t* ids, int n) = 0;
 	virtual bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) = 0;
 	virtual bool Sync() = 0;                 // all streams
 	// work queues: H2D / H2DAsync / D2H / Launch act on the selected stream (0 by default); D2H and H2D synchronise only that stream
@@ -114,6 +117,9 @@ private:
 	std::vector<std::pair<int32_t, double>> dist_log_;   // (env, distance) of every recorded poli_eval episode, in completion order
 	int64_t tuples_drained_ = 0, tuples_dropped_ = 0;
 	int PendingTuples(int32_t* stored, int32_t* overflow);
+	GroundRec* d_stage_recs_ = nullptr;   // device staging for the frame's regenerated terrain records (per-group slices)
+	int32_t* d_stage_ids_ = nullptr; int32_t* pin_stage_ids_ = nullptr;
+	std::vector<int32_t> work_;
 	int32_t* d_relayout_ = nullptr;   // device weight index -> index into the caller's Caffe-order blob (-1 = padding), built at Create
 	std::string err_;
 };

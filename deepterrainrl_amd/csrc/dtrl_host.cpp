@@ -375,6 +375,11 @@ void GroundWindow::InitSegments(double bound_min_x, double bound_max_x)
 		BuildSegment(SegID(i), (align_min ? 0 : -w) + mid, (align_min ? w : 0) + mid, align_min, 0.0);
 	}
 }
+bool GroundWindow::NeedsUpdate(double bmin, double bmax) const
+{
+	const Seg& lo = segs_[SegID(0)]; const Seg& hi = segs_[SegID(1)];
+	return !(bmax < hi.MaxX() && bmin > lo.MinX());
+}
 bool GroundWindow::Update(double bmin, double bmax)
 {
 	const Seg& lo = segs_[SegID(0)]; const Seg& hi = segs_[SegID(1)];

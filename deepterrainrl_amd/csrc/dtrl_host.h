@@ -81,6 +81,7 @@ public:
 	void Clear();
 	// returns true when a segment was (re)built, i.e. the device record must be refreshed
 	bool Update(double bound_min_x, double bound_max_x);   // sim/GroundVar2D.cpp:43-91
+	bool NeedsUpdate(double bound_min_x, double bound_max_x) const;   // Update() would (re)build a segment
 	void InitSegments(double bound_min_x, double bound_max_x);
 	bool FillRecord(GroundRec& rec, std::string& err) const;
 	long num_builds() const { return builds_; }

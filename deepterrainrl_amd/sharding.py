@@ -84,7 +84,9 @@ class ShardedRollout:
     # ---- (a) experience tuples ----
     def gather_tuples_begin(self):
         """Drain this rank's finished tuples into its block and start the all-gather (asynchronous on the GPU). Call between UpdateEnd() of
-        frame f and UpdateBegin() of frame f + 1; the collective then overlaps frame f + 1's kernel."""
+        frame f and UpdateBegin() of frame f + 1; the collective then overlaps frame f + 1's kernel. Collect it with gather_tuples_end() in the
+        NEXT gap (after UpdateEnd() of frame f + 1): a frame kernel fills every CU, so small kernels and host syncs issued while it runs stall
+        until it ends (bench.py's exchange leg: UpdateEnd -> gather_tuples_end (previous frame) -> consume -> gather_tuples_begin -> UpdateBegin)."""
         torch = self.torch
         assert self._pending is None, "gather_tuples_begin called twice without gather_tuples_end"
         b = self.batch
