@@ -592,10 +592,12 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	// hinge limits act on theta + ref_theta (sim/World.cpp:543-553: theta = -getHingeAngle() - ref_theta; :624-626 setLimit(-LimHigh, -LimLow)) with
 	// ref_theta = -angle(BodyJointTrans(parent) * ParentChildTrans(zero pose) * BodyJointTrans(child)) as cSimCharacter::BuildConstraints computes it
 	// (sim/SimCharacter.cpp:846-865; RotMatToAxisAngle returns acos of the cosine, util/MathUtil.cpp:128-149): the device tables hold the limits on theta itself
+	m.ref_theta[0] = 0;
 	for (int j = 1; j < L; ++j) {
-		if (m.lim_lo[j] > m.lim_hi[j]) continue;   // free joint
 		const double cth = std::cos(m.body_theta[m.parent[j]] + m.body_theta[j]);
 		const double ref_theta = -std::acos(std::min(1.0, std::max(-1.0, cth)));
+		m.ref_theta[j] = ref_theta;                // also the window the controller reads the angle in (dtrl_kernel.h, PD error)
+		if (m.lim_lo[j] > m.lim_hi[j]) continue;   // free joint
 		m.lim_lo[j] -= ref_theta; m.lim_hi[j] -= ref_theta;
 	}
 	m.contact_tol = 0.001 / world_scale;   // sim/ContactManager.cpp:74-75, dist_tol in world-scaled units

@@ -1426,7 +1426,16 @@ DTRL_HD inline void controller_update(W& ws, const DevModel& gm, const RunParams
 			const int j = i - 2;
 			kdm = gm.kd[j];
 			if ((ws.st.pd_active_bits >> j) & 1u) { kp = gm.kp[j]; kd = kdm; }
-			real theta = gm.use_world[j] ? wrap_pi(ws.phi[j] + gm.body_theta[j]) : wrap_pi(ws.st.q[i]);
+			// relative joint: -getHingeAngle() - ref_theta, an atan2 window (sim/World.cpp:543-553). World-coordinate joint (dog shoulder / hip):
+			// btQuaternion::getAngle() * (axis . z) of the quaternion btMatrix3x3::getRotation extracts from the link's world basis (sim/World.cpp:374-384):
+			// phi while 1 + 2 cos(phi) > 0 or phi > 0, phi + 2 pi for phi in (-pi, -2 pi / 3] (w < 0 in the largest-diagonal branch)
+			real theta;
+			if (gm.use_world[j]) {
+				theta = wrap_pi(ws.phi[j] + gm.body_theta[j]);
+				if (theta <= real(-2.0943951023931954923084289221863)) theta += real(6.283185307179586476925286766559);
+			} else {
+				theta = wrap_pi(ws.st.q[i] + gm.ref_theta[j]) - gm.ref_theta[j];
+			}
 			pe = ws.st.pd_target[j] - theta;
 			ve = 0 - ws.st.qd[i];
 		}

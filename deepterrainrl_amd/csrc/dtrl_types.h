@@ -60,6 +60,7 @@ struct DevModel {
 	int32_t opt_index[kMaxP];        // opt_index[k] = param index of the k-th optimisable param
 	real attach[kMaxL][2];
 	real lim_lo[kMaxL], lim_hi[kMaxL];
+	real ref_theta[kMaxL];           // hinge reference angle: the controller reads theta through atan2(theta + ref_theta) - ref_theta (sim/World.cpp:543-553)
 	real body_attach[kMaxL][2];
 	real body_theta[kMaxL];
 	real body_half[kMaxL][2];        // half extents

@@ -411,6 +411,10 @@ def lib():
         L.orc_get_poli_state.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_get_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.orc_frame_end.argtypes = [C.c_void_p]
+        L.orc_command_action.argtypes = [C.c_void_p, C.c_int]
+        L.orc_contact_distances.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_time.restype = C.c_double; L.orc_time.argtypes = [C.c_void_p]
         L.orc_dist_log.restype = C.c_int
         L.orc_dist_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_drain_tuples.restype = C.c_int
@@ -504,6 +508,12 @@ class OracleEnv:
         r, c, e, t = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(); a = C.c_double()
         self.L_.orc_stats(self.h, C.byref(r), C.byref(c), C.byref(e), C.byref(a), C.byref(t))
         return {"resets": r.value, "cycles": c.value, "episodes": e.value, "avg_dist": a.value, "terrain_builds": t.value}
+
+    def frame_end(self): self.L_.orc_frame_end(self.h)
+    def command_action(self, a): self.L_.orc_command_action(self.h, int(a))
+
+    def contact_distances(self):
+        d = np.zeros((self.L, 6)); self.L_.orc_contact_distances(self.h, _p(d)); return d
 
     def dist_log(self):
         buf = np.zeros(4096); n = self.L_.orc_dist_log(self.h, _p(buf), 4096); return buf[:n].copy()

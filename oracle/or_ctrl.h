@@ -514,7 +514,18 @@ struct Env {
 	}
 
 	// ---- PD error terms: sim/PDController.cpp:181-224 ---------------------------------------------------
-	double CalcTheta(int j) const { return M.use_world[j] ? WrapPi(B.psi[j]) : WrapPi(q[j + 2]); }
+	// relative joint: theta = -btHingeConstraint::getHingeAngle() - ref_theta (sim/World.cpp:543-553), the hinge angle an atan2: the value the controller
+	// reads lives in [-pi - ref_theta, pi - ref_theta). World-coordinate joint (dog shoulder / hip): cJoint::GetChildRotation -> cWorld::GetRotation
+	// (sim/World.cpp:374-384) = btQuaternion::getAngle() * (axis . z) of the quaternion btMatrix3x3::getRotation extracts from the child's world basis:
+	// for a rotation phi about z that is phi itself while trace = 1 + 2 cos(phi) > 0, and otherwise (largest-diagonal branch, z kept positive,
+	// w = sin(phi) * s) phi for phi in [2 pi / 3, pi] but phi + 2 pi for phi in (-pi, -2 pi / 3]: 2 acos(w) with w < 0. The PD error of a shoulder or hip
+	// whose link points more than 120 degrees clockwise is therefore off by a full turn in the reference, and here.
+	double CalcTheta(int j) const
+	{
+		if (!M.use_world[j]) return WrapPi(q[j + 2] + M.ref_theta[j]) - M.ref_theta[j];
+		const double phi = WrapPi(B.psi[j]);
+		return phi <= -2.0943951023931954923084289221863 ? phi + 6.283185307179586476925286766559 : phi;
+	}
 
 	// ---- cDogController::Update, sim/DogController.cpp:229-268 -------------------------------------------
 	void ImpPD(double dt, double* tau)  // cImpPDController::CalcControlForces, sim/ImpPDController.cpp:234-278
@@ -809,6 +820,11 @@ struct Env {
 		if (time_elapsed <= 0) return;
 		double step = time_elapsed / M.num_update_steps;
 		for (int i = 0; i < M.num_update_steps; ++i) EnvStep(step);
+		FrameEnd();
+	}
+	// the scenario logic behind the step loop of one outer frame (fall -> tuple / distance record -> Reset)
+	void FrameEnd()
+	{
 		if (M.scenario == 1) {
 			if (!IsNewCycle() && HasFallen()) { ScenarioNewCycleUpdate(); Reset(); }
 		} else if (M.scenario == 2) {

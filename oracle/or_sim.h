@@ -94,6 +94,23 @@ inline void LinkSamplePoint(const OrcModel& M, int j, int k, double& sx, double&
 
 struct ContactPoint { int link; double x, y, depth, nx, ny; };
 
+// signed separation (negative = penetration) of every contact sample point from the heightfield, along the cell normal; +inf for links that collide with nothing
+inline void ContactDistances(const OrcModel& M, const Bodies& B, const Ground& g, double* out)
+{
+	for (int j = 0; j < M.L; ++j) {
+		double c = std::cos(B.psi[j]), s = std::sin(B.psi[j]);
+		for (int k = 0; k < SimConst::pts_per_link; ++k) {
+			double& d = out[j * SimConst::pts_per_link + k];
+			d = 1e30;
+			if (M.col_group[j] == 0) continue;
+			double sx, sy; LinkSamplePoint(M, j, k, sx, sy);
+			double x = B.cx[j] + c * sx - s * sy, y = B.cy[j] + s * sx + c * sy;
+			double slope = g.SampleSlope(x);
+			d = -(g.SampleHeight(x) - y) / std::sqrt(1.0 + slope * slope);
+		}
+	}
+}
+
 // contact detection at the current configuration; fills in-contact flags per link and the list of points that get constraint rows
 // (ordered by link, then sample point): per link the deepest max_pts_per_link penetrating points; overall the deepest `cap`
 inline int DetectContacts(const OrcModel& M, const Bodies& B, const Ground& g, ContactPoint* out, int cap, bool* flags)

@@ -1,0 +1,239 @@
+"""The oracle pinned against the reference's OWN rollout code, env-step by env-step.
+
+oracle/_ref/libref_sim.so holds the reference's scenario / character / controller / ground translation units compiled UNCHANGED from
+/root/reference (oracle/_ref_build/Makefile): scenarios/ScenarioSimChar, ScenarioExpMACE, ScenarioPoliEval; sim/World, SimCharacter, Joint,
+ContactManager, GroundVar2D, the Dog / Raptor / Goat controllers, ImpPDController, RBDModel / RBDUtil, ... Only Bullet (a state container with a
+step HOOK instead of a solver), Caffe (a forward callback) and Eigen / jsoncpp (stand-in headers) are not the reference's.
+
+LockStep (oracle/refsim.py) hands the oracle's post-physics state to the reference through cSimCharacter::SetPose / SetVel every env-step and
+then lets the REFERENCE run the rest of the step: contact flags from manifold distances (cContactManager::Update), ground window update
+(cGroundVar2D::Update), cDogController / cRaptorController::Update (FSM, feedback, implicit PD on the reference's RBD model, gravity compensation,
+virtual forces), cJoint torque clamp, soft-fall logic, cycle bookkeeping, policy state and action selection. What it computes is compared with
+the oracle's output for the same step -- rows a1, a3-a17, a20-a27 of SURVEY 8 checked against the reference itself; only a2 (Bullet's solver)
+stays a documented model. Needs the reference checkout (data files) and the compiled library: skipped without them.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REFERENCE, dog_policy
+
+from oracle import refsim as rs
+
+pytestmark = pytest.mark.skipif(not (rs.available() and os.path.isdir(os.path.join(REFERENCE, "data"))), reason="needs /root/reference and oracle/_ref/libref_sim.so")
+
+
+def wrap(a):
+    return (a + np.pi) % (2 * np.pi) - np.pi
+
+
+def check_records(records, D, n_min, tau_tol=1e-8, prm_tol=1e-9, ctx="", action_id_from=0):
+    """every env-step: the reference, given the oracle's state, must reproduce the oracle's controller"""
+    assert len(records) >= n_min
+    worst_tau = worst_q = 0.0
+    n_contact = n_new_cycle = n_loose = 0
+    states = set()
+    for k, (o, r) in enumerate(records):
+        if r.get("after_reset"):                                                # (LockStep.update: the reference already reset; the loop's own checks cover the reset)
+            continue
+        dq = np.abs(np.concatenate([o["q"][:2] - r["q"][:2], wrap(o["q"][2:] - r["q"][2:])])).max()   # BuildPose reports angles in (-pi, pi]
+        dqd = np.abs(o["qd"] - r["qd"]).max()
+        # SetPose/SetVel -> rigid bodies -> BuildPose/BuildVel round trip: exact to rounding, except where a link's WORLD angle is within ~1e-7 of pi
+        # (btMatrix3x3 <-> btQuaternion loses digits there: sqrt(trace + 1) with trace -> -1; one step in several hundred, 1e-7 .. 1e-5 rad in the double build)
+        assert dq < 1e-4 and dqd < 1e-9, (ctx, k, dq, dqd)
+        n_loose += dq > 1e-9
+        assert np.array_equal(o["contacts"], r["contacts"]), (ctx, k, o["contacts"], r["contacts"])   # cContactManager::Update (distance <= 0.001 scaled)
+        assert o["state"] == r["state"] and abs(o["phase"] - r["phase"]) < 1e-12, (ctx, k, o["state"], r["state"], o["phase"], r["phase"])
+        assert o["flags"] == r["flags"], (ctx, k, hex(o["flags"]), hex(r["flags"]))   # fallen | stumbled | new cycle | FSM state
+        assert k < action_id_from or o["action_id"] == r["action_id"], (ctx, k)
+        P = len(o["params"])
+        assert np.abs(o["params"] - r["params"][:P]).max() < prm_tol * max(1.0, np.abs(o["params"]).max()), (ctx, k)
+        assert np.abs(o["pd_targets"][1:] - r["pd_targets"][1:]).max() < prm_tol * 10, (ctx, k, o["pd_targets"], r["pd_targets"])
+        dt = np.abs(o["tau"][3:] - r["tau"][1:]).max()                          # joint j > 0 drives DoF j + 2; the reference's clamp has run
+        assert dt < tau_tol * max(1.0, np.abs(o["tau"]).max()) + 400 * dq, (ctx, k, dt, dq)   # (gains up to 300 N m / rad turn a pose rounding into a torque one)
+        worst_tau = max(worst_tau, dt); worst_q = max(worst_q, dq)
+        n_contact += int(o["contacts"].any()); n_new_cycle += (o["flags"] >> 2) & 1; states.add(o["state"])
+    assert n_loose <= max(2, len(records) // 100), (ctx, n_loose)
+    return dict(worst_tau=worst_tau, worst_q=worst_q, n_contact=n_contact, n_new_cycle=n_new_cycle, states=states, n_loose=n_loose)
+
+
+@pytest.mark.parametrize("arg,frames", [("args/sim_dog_args.txt", 30), ("args/sim_raptor_args.txt", 30), ("args/sim_goat_args.txt", 20)])
+def test_fsm_controllers_on_flat_ground_match_the_reference_every_env_step(om, arg, frames):
+    """cScenarioSimChar + cDogController / cRaptorController without a net, 600 env-steps (BASELINE configs[0] is the first 240 of the dog run)."""
+    m, _ = om.build_model(arg, REFERENCE)
+    e = om.OracleEnv(m, terrain_seed=5)
+    r = rs.RefScenario("sim_char", arg, REFERENCE, global_seed=3)
+    assert (r.L, r.D) == (e.L, e.D)
+    r.seed_ground_and_reset(5)
+    q0, qd0 = e.pose_vel(); qr, qdr = r.pose_vel()
+    assert np.abs(q0 - qr).max() < 1e-9 and np.abs(qd0 - qdr).max() < 1e-9      # cScenarioSimChar::Init + Reset == the oracle's initial state
+    ls = rs.LockStep(r, e)
+    for f in range(frames):
+        ls.update()
+    st = check_records(ls.records, e.D, frames * 20, ctx=arg)
+    assert st["n_contact"] > 100 and st["n_new_cycle"] >= 1 and len(st["states"]) >= (3 if "goat" in arg else 4), st   # a gait cycle with contact-triggered transitions
+    assert abs(r.time() - frames / 30.0) < 1e-9
+    print(arg, st)
+
+
+def _policy_raw_forward(e, pol):
+    desc, w, io, isc, oo, osc = pol
+    def raw(x_norm):
+        x_raw = np.where(isc != 0, x_norm / np.where(isc != 0, isc, 1.0), 0.0) - io
+        y = e.nn_eval(x_raw)
+        return (y + oo) * osc
+    return raw
+
+
+@pytest.mark.parametrize("seed", [17, 40])
+def test_poli_eval_slopes_mixed_with_policy_matches_the_reference(om, seed):
+    """cScenarioPoliEval on dog + slopes_mixed with the MACE net (BASELINE configs[1], one env): ground windows and grid cells, terrain features,
+    policy state, argmax action selection, action parameters, and the fall -> distance record -> reset logic of the REFERENCE vs the oracle."""
+    arg = "args/dog_slopes_mixed_args.txt"
+    m, _ = om.build_model(arg, REFERENCE)
+    pol = dog_policy(om)
+    e = om.OracleEnv(m, terrain_seed=seed, policy=pol)
+    rs.nn_config(283, 90, _policy_raw_forward(e, pol))
+    r = rs.RefScenario("poli_eval", arg, REFERENCE, global_seed=9)
+    assert (r.S, r.A, r.P) == (283, 30, 30)
+    r.set_net_scale(*pol[2:])
+    off, sc = r.build_output_offset_scale(90)                                    # cBaseControllerMACE::BuildNNOutputOffsetScale, the reference's own
+    o2, s2 = om.build_output_offset_scale(m, 3)
+    assert np.abs(off - o2).max() < 1e-12 and np.abs(sc / s2 - 1).max() < 1e-12
+    r.seed_ground_and_reset(seed)
+    ls = rs.LockStep(r, e)
+    n_states = n_ground = resets_seen = 0
+    prev_cycles = 0
+    for f in range(150):
+        ls.update()
+        e.frame_end()                                                            # the oracle's end-of-frame logic; the reference ran its own inside Update
+        # ground: both windows hold the same two segments, sample for sample, and pick the same cells
+        q, _ = e.pose_vel()
+        for slot in (0, 1):
+            ho, mn_o, _, _ = e.ground_segment(slot)
+            hr, mn_r, mx_r = r.ground_segment(slot)
+            hr = (hr / np.float32(m.world_scale)).astype(np.float32)                  # tSegment stores Bullet-scaled heights (x 4: exact in float)
+            # (the reference reads a segment's x range back from Bullet's AABB, which is padded by the collision margin: 0.04 scaled = 0.01 m in the stand-in;
+            # the oracle keeps the construction values)
+            assert len(ho) == len(hr) and np.array_equal(ho.view(np.uint32), hr.view(np.uint32)) and abs(mn_o - mn_r) < 0.011, (f, slot)
+        for x in np.linspace(q[0] - 1.5, q[0] + 10.5, 25):
+            h_o, valid_o, seg_o, i_o, j_o = e.sample_ground(x)
+            h_r, valid_r, coord_r = r.sample_ground(x)
+            # (this library keeps Bullet's transforms in double: origins and scalings are not float-rounded, so heights agree to (float ulp of x ~ 1e-6) x slope here;
+            # the float build is held to bit-equality in test_ground_window_bit_exact_in_the_float_build)
+            assert valid_o == valid_r and (not valid_o or abs(h_o - h_r) < 5e-5), (f, x, h_o, h_r)
+            n_ground += valid_o
+        st_r = r.eval_stats(); st_o = e.stats()
+        assert st_r["cycles"] == st_o["cycles"] and st_r["episodes"] == st_o["episodes"], (f, st_r, st_o)
+        if st_o["cycles"] != prev_cycles:                                        # a new cycle began this frame: the policy state the action was chosen from
+            prev_cycles = st_o["cycles"]
+            ps_r, ps_o = r.poli_state(), e.poli_state()
+            assert np.abs(ps_r[201:] - ps_o[201:]).max() < 1e-9 * max(1.0, np.abs(ps_o).max()), (f, np.abs(ps_r - ps_o).max())   # pose / velocity features
+            assert np.abs(ps_r[:201] - ps_o[:201]).max() < 5e-5, (f, np.abs(ps_r[:201] - ps_o[:201]).max())                       # 200 terrain samples + root height above ground (double-transform build, see above)
+            n_states += 1
+        if st_o["episodes"] > resets_seen:
+            resets_seen = st_o["episodes"]
+            assert np.abs(st_r["dist_log"] - e.dist_log()).max() < 1e-9 and abs(st_r["avg_dist"] - st_o["avg_dist"]) < 1e-9
+            qo, _ = e.pose_vel(); qr, _ = r.pose_vel()
+            assert np.abs(qo - qr).max() < 1e-9                                  # both reset to the same pose on fresh terrain
+    # (action parameters come out of the network: its terrain inputs differ by up to 1e-5 in this build (float ulp of x times the slope), the output normaliser scales by up to 500)
+    info = check_records(ls.records, e.D, 150 * 20, tau_tol=1e-4, prm_tol=1e-5, ctx="poli_eval seed %d" % seed)
+    assert n_states >= 8 and n_ground > 2000 and info["n_new_cycle"] >= 8, (n_states, n_ground, info)
+    print("poli_eval seed", seed, info, "cycles", prev_cycles, "episodes", resets_seen)
+
+
+def test_raptor_poli_eval_stance_mirrored_state(om):
+    """raptor + narrow_gaps (BASELINE configs[2] scene): stance flip, swing / stance feedback, stance-mirrored policy state."""
+    import test_host_and_emul as T
+    arg = "args/raptor_narrow_gaps_args.txt"
+    m, _ = om.build_model(arg, REFERENCE)
+    pol = T.raptor_policy(om)
+    e = om.OracleEnv(m, terrain_seed=11, policy=pol)
+    rs.nn_config(275, 87, _policy_raw_forward(e, pol))
+    r = rs.RefScenario("poli_eval", arg, REFERENCE, global_seed=2)
+    assert (r.S, r.A, r.P) == (275, 29, 37)
+    r.set_net_scale(*pol[2:])
+    r.seed_ground_and_reset(11)
+    ls = rs.LockStep(r, e)
+    n_states = 0; prev = 0
+    for f in range(90):
+        ls.update(); e.frame_end()
+        c = e.stats()["cycles"]
+        if c != prev:
+            prev = c
+            ps_r, ps_o = r.poli_state(), e.poli_state()
+            d = np.abs(ps_r - ps_o)
+            assert d[201:].max() < 1e-9 * max(1.0, np.abs(ps_o).max()) and d[:201].max() < 5e-5, (f, d[201:].max(), d[:201].max())   # terrain part: see the dog test
+            n_states += 1
+    info = check_records(ls.records, e.D, 90 * 20, tau_tol=1e-4, prm_tol=1e-5, ctx="raptor")
+    assert n_states >= 6, n_states
+    print("raptor", info)
+
+
+def test_exp_mace_tuples_match_the_reference(om):
+    """cScenarioExpMACE with exploration switched off on both sides (the reference's exploration draws from a clock-seeded global RNG)
+    and the same commanded first action: reward, state / action / next-state and the flag word of every tuple the REFERENCE records vs the oracle's."""
+    arg = "args/opt_args_train_mace.txt"
+    m, _ = om.build_model(arg, REFERENCE, overrides={"policy_model": ""})
+    m.enable_explore = 0
+    pol = dog_policy(om)
+    e = om.OracleEnv(m, terrain_seed=21, policy=pol)
+    rs.nn_config(283, 90, _policy_raw_forward(e, pol))
+    r = rs.RefScenario("exp_mace", arg, REFERENCE, global_seed=4)
+    r.set_net_scale(*pol[2:])
+    r.seed_ground_and_reset(21)
+    r.enable_explore(0)
+    r.command_action(2); e.command_action(2)
+    ls = rs.LockStep(r, e)
+    rows_r, rows_o = [], []
+    for f in range(120):
+        ls.update(); e.frame_end()
+        a, fa = r.drain_tuples()
+        b, fb = e.drain_tuples(f64=True)
+        assert len(a) == len(b), (f, len(a), len(b))
+        for x, y, p, q_ in zip(a, b, fa, fb):
+            assert p == q_ and np.abs(x - y).max() < 5e-5 * max(1.0, np.abs(y).max()), (f, p, q_, np.abs(x - y).max())   # (terrain features / action parameters: double-transform build)
+            rows_r.append(x)
+        if e.stats()["resets"] > 0 and len(rows_r) >= 4:
+            break
+    # (the fragment a COMMANDED base action is booked under is drawn at random, sim/DogControllerMACE.cpp:44-91: ids compared from the second cycle on)
+    second = next(k for k, (o, _) in enumerate(ls.records) if k > 0 and (o["flags"] & 4))
+    check_records(ls.records, e.D, 100, tau_tol=1e-4, prm_tol=1e-5, ctx="exp", action_id_from=second)
+    assert len(rows_r) >= 4
+
+
+@pytest.mark.parametrize("arg,seed", [("args/dog_slopes_mixed_args.txt", 17), ("args/dog_narrow_gaps_args.txt", 9), ("args/goat_cliffs_args.txt", 3)])
+def test_ground_window_bit_exact_in_the_float_build(om, arg, seed):
+    """'terrain indices bit-exact' against the reference's OWN cGroundVar2D (sim/GroundVar2D.cpp: Update / BuildSegment / tSegment::Init / SampleHeight /
+    CalcGridCoord) in its real configuration (btScalar = float: origins and x scaling pass through float Bullet transforms): as the character travels
+    150 frames, both windows hold bit-identical segments and every sample picks the same cell and returns the same double."""
+    m, _ = om.build_model(arg, REFERENCE)
+    pol = dog_policy(om)
+    e = om.OracleEnv(m, terrain_seed=seed, policy=pol)
+    rs.nn_config(283, 90, _policy_raw_forward(e, pol), variant="f32")
+    r = rs.RefScenario("poli_eval", arg, REFERENCE, global_seed=9, variant="f32")
+    r.set_net_scale(*pol[2:])
+    r.seed_ground_and_reset(seed)
+    ls = rs.LockStep(r, e)
+    n = n_slides = 0
+    builds0 = e.stats()["terrain_builds"]
+    rng = np.random.RandomState(seed)
+    for f in range(150):
+        ls.update(); e.frame_end()
+        q, _ = e.pose_vel()
+        for slot in (0, 1):
+            ho = e.ground_segment(slot)[0]
+            hr = (r.ground_segment(slot)[0] / np.float32(m.world_scale)).astype(np.float32)
+            assert len(ho) == len(hr) and np.array_equal(ho.view(np.uint32), hr.view(np.uint32)), (f, slot)
+        w_min = len(e.ground_segment(0)[0])
+        xs = np.concatenate([np.linspace(q[0] - 1.9, q[0] + 10.9, 40), q[0] + rng.uniform(-1.9, 10.9, 20)])
+        for x in xs:
+            h_o, valid_o, seg_o, i_o, j_o = e.sample_ground(x)
+            h_r, valid_r, coord_r = r.sample_ground(x)
+            assert valid_o == valid_r, (f, x)
+            if valid_o:
+                # cGroundVar2D::CalcGridCoord (sim/GroundVar2D.cpp:171-190) counts cells across the window: the second segment's start at w_min - 1
+                assert h_o == h_r and int(coord_r) == i_o + seg_o * (w_min - 1), (f, x, h_o, h_r, coord_r, seg_o, i_o)
+                n += 1
+    assert n > 8000 and e.stats()["terrain_builds"] >= builds0 + 2
