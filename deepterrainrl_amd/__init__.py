@@ -322,17 +322,17 @@ class BatchScenario:
         return st, ph, aid, prm, tg
 
     def CycleInfo(self, env_ids=None):
-        """Per env: cycle counter, reset counter, COM [n, 2] and simulated time at the start of the current cycle, optimisable params of the current action [n, A - 1]."""
+        """Per env: cycle counter, reset counter, COM [n, 2] and simulated time at the start of the current cycle, optimisable params of the current action [n, frag_size]."""
         ids, n = self._ids(env_ids)
-        nc = np.zeros(n, np.int64); nr = np.zeros(n, np.int64); com = np.zeros((n, 2)); t = np.zeros(n); prm = np.zeros((n, self.A - 1))
+        nc = np.zeros(n, np.int64); nr = np.zeros(n, np.int64); com = np.zeros((n, 2)); t = np.zeros(n); prm = np.zeros((n, self.frag_size))
         self._chk(self._lib.dtrl_get_cycle_info(self._h, _p(ids), n, _p(nc), _p(nr), _p(com), _p(t), _p(prm)))
         return nc, nr, com, t, prm
 
     def ActionTable(self):
-        """cTerrainRLCharController::BuildActionOptParams for every action: [n_actions, A - 1]."""
+        """cTerrainRLCharController::BuildActionOptParams for every action: [n_actions, frag_size]."""
         na = C.c_int(0)
         self._chk(self._lib.dtrl_get_action_table(self._h, C.byref(na), None))
-        tab = np.zeros((na.value, self.A - 1))
+        tab = np.zeros((na.value, self.frag_size))
         self._chk(self._lib.dtrl_get_action_table(self._h, C.byref(na), _p(tab)))
         return tab
 

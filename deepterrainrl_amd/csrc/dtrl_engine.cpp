@@ -138,7 +138,8 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	n_ = num_envs;
 	const DevModel& m = cfg_.model;
 	S_ = kNumGroundSamples + (2 * m.L - 1) + 2 * m.L;   // sim/TerrainRLCharController.cpp:308-342
-	A_ = (m.ctrl_type == 2) ? m.n_opt : 1 + m.n_opt;    // sim/BaseControllerMACE.cpp:28-31; sim/BaseControllerCacla.cpp:13-16 (the parameters alone)
+	// sim/BaseControllerMACE.cpp:28-31; sim/BaseControllerCacla.cpp:13-16 (the parameters alone); sim/BaseControllerQ.cpp:12-23 (one-hot over the base actions)
+	A_ = (m.ctrl_type == 2) ? m.n_opt : (m.ctrl_type == 0 ? m.n_actions : 1 + m.n_opt);
 	W_ = 1 + 2 * S_ + A_;                               // learning/MACETrainer.cpp:373-376
 
 	be_ = MakeBackend();

@@ -515,6 +515,9 @@ void BuildOutputOffsetScale(const DevModel& m, const NetDesc& d, std::vector<dou
 	if (m.ctrl_type == 2) {   // cBaseControllerCacla::BuildNNOutputOffsetScale (sim/BaseControllerCacla.cpp:88-122): the parameter block alone
 		off = f_off; scale = f_scale; return;
 	}
+	if (m.ctrl_type == 0) {   // cBaseControllerQ::BuildNNOutputOffsetScale (sim/BaseControllerQ.cpp:25-30): one value per base action
+		off.assign(m.n_actions, -0.5); scale.assign(m.n_actions, 2.0); return;
+	}
 	off.assign(nf + nf * frag, 0.0); scale.assign(nf + nf * frag, 1.0);
 	for (int f = 0; f < nf; ++f) {
 		off[f] = -0.5; scale[f] = 2;
@@ -537,15 +540,17 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	m.world_scale = world_scale; m.num_update_steps = num_update_steps; m.num_sim_substeps = num_sim_substeps;
 
 	// scenarios/ScenarioSimChar.cpp:19-36 controller names
+	// "dog" / "raptor" build cDogControllerQ / cRaptorControllerQ (scenarios/ScenarioSimChar.cpp:421-430, 469-478): the plain FSM without a net,
+	// the Q head (sim/BaseControllerQ.cpp) once -policy_net= names a net with one output per base action
 	if (char_ctrl == "dog") { m.char_type = 0; m.ctrl_type = 0; }
 	else if (char_ctrl == "dog_mace" || char_ctrl == "goat_mace") { m.char_type = 0; m.ctrl_type = 1; }
 	else if (char_ctrl == "raptor") { m.char_type = 1; m.ctrl_type = 0; }
 	else if (char_ctrl == "raptor_mace") { m.char_type = 1; m.ctrl_type = 1; }
 	else if (char_ctrl == "dog_cacla") { m.char_type = 0; m.ctrl_type = 2; }   // cDogControllerCacla (sim/DogControllerCacla.cpp)
-	else { err = "char_ctrl '" + char_ctrl + "' is not supported by this build (dog, dog_mace, dog_cacla, goat_mace, raptor, raptor_mace; the Q head is out of scope)"; return false; }
+	else { err = "char_ctrl '" + char_ctrl + "' is not supported by this build (dog, dog_mace, dog_cacla, goat_mace, raptor, raptor_mace)"; return false; }
 	if (!char_type.empty() && char_type != (m.char_type == 0 ? "dog" : "raptor")) { err = "char_type '" + char_type + "' does not match the controller"; return false; }
 	m.target_vel_x = (char_ctrl == "goat_mace") ? 2.0 : 4.0;   // sim/GoatControllerMACE.cpp:11-14, sim/DogController.cpp:625-628
-	if (scenario == "train_mace" || scenario == "exp" || scenario == "exp_mace" || scenario == "train_cacla" || scenario == "exp_cacla") m.scenario = kScnExp;
+	if (scenario == "train" || scenario == "train_mace" || scenario == "exp" || scenario == "exp_mace" || scenario == "train_cacla" || scenario == "exp_cacla") m.scenario = kScnExp;
 	else if (scenario == "poli_eval") m.scenario = kScnPoliEval;
 	else m.scenario = kScnSimChar;
 
@@ -711,9 +716,9 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 
 	// policy net topology (weights arrive through dtrl_set_policy: the shipped *.h5 blobs are not in the reference checkout)
 	cfg.has_policy_net = false; m.has_net = 0;
-	if (args.ParseString("policy_net", cfg.policy_net_file) && m.ctrl_type >= 1) {
+	if (args.ParseString("policy_net", cfg.policy_net_file)) {
 		if (!ParseDeployPrototxt(JoinPath(root, cfg.policy_net_file), cfg.net, err, &cfg.actor_only)) return false;
-		if (cfg.actor_only != (m.ctrl_type == 2)) { err = "policy_net topology does not match char_ctrl (MACE nets for *_mace, the actor net for dog_cacla)"; return false; }
+		if (cfg.actor_only != (m.ctrl_type != 1)) { err = "policy_net topology does not match char_ctrl (MACE nets for *_mace, the single-head actor / Q net for dog_cacla, dog, raptor)"; return false; }
 		cfg.user_num_params = cfg.net.num_params; cfg.user_out_size = cfg.net.out_size;
 		if (cfg.actor_only) {   // minus the (zero) critic head val_ip0 / val_ip1 that only exists on the device
 			cfg.user_num_params -= static_cast<int64_t>(cfg.net.fc_head) * cfg.net.fc_trunk + cfg.net.fc_head + cfg.net.fc_head + 1;
@@ -721,7 +726,7 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		}
 		const int S = kNumGroundSamples + (2 * L - 1) + 2 * L;
 		if (cfg.net.in_size != S) { err = "Network input dimension does not match expected input size"; return false; }      // sim/NNController.cpp:58-75
-		if (cfg.net.frag_size != m.n_opt) { err = "Network output dimension does not match expected output size"; return false; }
+		if (cfg.net.frag_size != (m.ctrl_type == 0 ? m.n_actions : m.n_opt)) { err = "Network output dimension does not match expected output size"; return false; }
 		cfg.has_policy_net = true;
 	}
 	args.ParseString("policy_model", cfg.policy_model_file);

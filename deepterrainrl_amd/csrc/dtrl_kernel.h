@@ -1174,7 +1174,7 @@ DTRL_HD inline void update_action(W& ws, const DevModel& gm, const RunParams& rp
 	if (lane == 0) {
 		if (gm.ctrl_type == 1) { ws.st.exp_actor = 0; ws.st.exp_critic = 0; }
 		ws.st.is_off_policy = 1;
-		int mode = 0;  // 0: keep / default action, 1: command, 2: net, 3: random base action (exploration)
+		int mode = 0;  // 0: keep / default action, 1: command, 2: net, 3: random base action (MACE / CACLA exploration), 4: random base action (Q exploration)
 		if (ws.st.cmd_action >= 0) mode = 1;
 		else if (gm.has_net && gm.ctrl_type == 2) {
 			// cBaseControllerCacla::DecideAction / ShouldExplore / ExploreAction (sim/BaseControllerCacla.cpp:124-151, 219-234): explore with
@@ -1185,6 +1185,13 @@ DTRL_HD inline void update_action(W& ws, const DevModel& gm, const RunParams& rp
 			ws.st.exp_actor = 0;
 			mode = 2;
 			if (explore) { if (rng.uniform() < rp.exp_base_rate) mode = 3; else ws.st.exp_actor = 1; }   // exp_actor: add parameter noise below
+		}
+		else if (gm.has_net && gm.ctrl_type == 0) {
+			// cBaseControllerQ::DecideAction / ShouldExplore (sim/BaseControllerQ.cpp:32-57): a random base action with probability exp_rate
+			Rng rng = make_rng(rp, env, &ws.st.rng_ctr);
+			const bool explore = rp.enable_exp && rng.uniform() < rp.exp_rate;
+			ws.st.is_off_policy = explore ? 1 : 0;
+			mode = explore ? 4 : 2;
 		}
 		else if (gm.has_net) {
 			Rng rng = make_rng(rp, env, &ws.st.rng_ctr);
@@ -1212,6 +1219,14 @@ DTRL_HD inline void update_action(W& ws, const DevModel& gm, const RunParams& rp
 			int a = rng.rand_int(0, gm.n_actions);
 			build_base_action(gm, num_frags, a, rng, &id, prm);
 			ws.st.is_off_policy = 1; ws.st.exp_actor = 1; ws.st.exp_critic = 1;
+		} else if (mode == 4) {
+			build_base_action(gm, num_frags, rng.rand_int(0, gm.n_actions), rng, &id, prm);   // cBaseControllerQ::ExploreAction
+		} else if (mode == 2 && gm.ctrl_type == 0) {
+			// cBaseControllerQ::ExploitPolicy (sim/BaseControllerQ.cpp:59-82): the base action with the largest value (Eigen maxCoeff: the first one);
+			// like the CACLA actor, the device net carries an unused critic slot in front of its outputs
+			const real* y = buf.nn_out + static_cast<int64_t>(env) * buf.net.out_size + 1;
+			int a = 0; for (int i = 1; i < gm.n_actions; ++i) if (y[i] > y[a]) a = i;
+			build_base_action(gm, num_frags, a, rng, &id, prm);
 		} else if (mode == 2 && gm.ctrl_type == 2) {
 			// cBaseControllerCacla::ExploitPolicy (:205-217) + ApplyExpNoiseAction (:262-296). The device net carries a (zero) critic slot in
 			// front of the actor's outputs (dtrl_engine.cpp SetPolicy), hence the offset of one
@@ -1615,6 +1630,7 @@ DTRL_HD inline void scenario_new_cycle(W& ws, const DevModel& gm, const DevBuffe
 	for (int i = lane; i < buf.S; i += kGroup) s0[i] = ps[i];
 	if (lane == 0) {
 		if (gm.ctrl_type == 2) { for (int k = 0; k < gm.n_opt; ++k) ta[k] = ws.st.params[gm.opt_index[k]]; }   // cBaseControllerCacla::RecordPoliAction: the parameters alone
+		else if (gm.ctrl_type == 0) { for (int k = 0; k < gm.n_actions; ++k) ta[k] = (k == ws.st.action_id) ? 1 : 0; }   // cBaseControllerQ::RecordPoliAction: one-hot
 		else {
 			ta[0] = ws.st.action_id;
 			for (int k = 0; k < gm.n_opt; ++k) ta[1 + k] = ws.st.params[gm.opt_index[k]];

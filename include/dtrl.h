@@ -156,11 +156,11 @@ dtrl_status dtrl_get_contacts(dtrl_batch* b, const int32_t* env_ids, int n, int3
 dtrl_status dtrl_get_ctrl(dtrl_batch* b, const int32_t* env_ids, int n, int32_t* state, double* phase, int32_t* action_id, double* params, double* pd_targets);
 /* What cScenarioPoliEval's per-cycle recorders read (scenarios/ScenarioPoliEval.cpp:234-404: RecordAction, RecordVel, RecordActionIDState): the
  * env's cycle counter (mCycleCount; like the reference's it survives resets) and reset counter, the COM and simulated time at the start of the current cycle (what mChar->CalcCOM() / mTime returned when
- * the cycle began), and the optimisable parameters of the current action (cTerrainRLCharController::BuildOptParams, [n][A - 1]). The action id is in
+ * the cycle began), and the optimisable parameters of the current action (cTerrainRLCharController::BuildOptParams, [n][frag_size] as dtrl_dims reports it). The action id is in
  * dtrl_get_ctrl, the policy state of the current action in dtrl_get_poli_state. deepterrainrl_amd.recorders.PoliEvalRecorder writes the
  * reference's files from these at frame boundaries (all of them are constant over a cycle, so nothing is lost). Any output may be NULL. */
 dtrl_status dtrl_get_cycle_info(dtrl_batch* b, const int32_t* env_ids, int n, int64_t* num_cycles, int64_t* num_resets, double* cycle_start_com, double* cycle_start_time, double* opt_params);
-/* Replaces: cTerrainRLCharController::BuildActionOptParams(a) for every action a (what cScenarioPoliEval::InitActionRecord writes): table[n_actions][A - 1];
+/* Replaces: cTerrainRLCharController::BuildActionOptParams(a) for every action a (what cScenarioPoliEval::InitActionRecord writes): table[n_actions][frag_size];
  * returns the number of actions through n_actions (table may be NULL to query it). */
 dtrl_status dtrl_get_action_table(dtrl_batch* b, int* n_actions, double* table);
 /* ground observability: cGround::SampleHeight (sim/GroundVar2D.cpp:98-114) with the grid cell it used (terrain-index parity) */

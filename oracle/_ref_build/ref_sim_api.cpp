@@ -80,7 +80,7 @@ void ref_nn_config(int in_size, int out_size, nn_forward_fn fwd)
 	h.mForward = [fwd, out_size](const Eigen::VectorXd& x, Eigen::VectorXd& y) { y.resize(out_size); fwd(x.data(), y.data()); };
 }
 
-// kind: 0 cScenarioSimChar, 1 cScenarioExpMACE, 2 cScenarioPoliEval. argv = "-key= value" tokens (command line first, then -arg_file= is appended like
+// kind: 0 cScenarioSimChar, 1 cScenarioExpMACE, 2 cScenarioPoliEval, 3 cScenarioExp (what -scenario= train builds its pool from: the Q controllers). argv = "-key= value" tokens (command line first, then -arg_file= is appended like
 // optimizer/Main.cpp:19-32 does); cwd = the directory relative data paths resolve against (the reference is run from its repo root).
 // global_seed seeds cMathUtil's global RNG before Init (the reference seeds it from the clock, util/Rand.cpp:8).
 void* ref_scn_create(int kind, char** argv, int argc, const char* cwd, unsigned long global_seed)
@@ -94,6 +94,7 @@ void* ref_scn_create(int kind, char** argv, int argc, const char* cwd, unsigned 
 	RefScn* s = new RefScn(); s->kind = kind;
 	if (kind == 1) s->scn = std::shared_ptr<cScenarioSimChar>(new cScenarioExpMACE());
 	else if (kind == 2) s->scn = std::shared_ptr<cScenarioSimChar>(new cScenarioPoliEval());
+	else if (kind == 3) s->scn = std::shared_ptr<cScenarioSimChar>(new cScenarioExp());
 	else s->scn = std::shared_ptr<cScenarioSimChar>(new cScenarioSimChar());
 	s->scn->ParseArgs(parser);
 	s->scn->Init();

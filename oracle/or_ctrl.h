@@ -241,7 +241,9 @@ struct Env {
 	}
 
 	int PoliStateSize() const { return 200 + (L * 2 - 1) + L * 2; }  // sim/TerrainRLCharController.cpp:308-342
-	int PoliActionSize() const { return M.ctrl_type == 2 ? nOpt : 1 + nOpt; }   // sim/BaseControllerMACE.cpp:28-31; sim/BaseControllerCacla.cpp:13-16
+	// sim/BaseControllerMACE.cpp:28-31; sim/BaseControllerCacla.cpp:13-16; sim/BaseControllerQ.cpp:12-15 ("dog" / "raptor" ARE the Q controllers,
+	// scenarios/ScenarioSimChar.cpp:421-430, 469-478)
+	int PoliActionSize() const { return M.ctrl_type == 2 ? nOpt : (M.ctrl_type == 0 ? M.n_actions : 1 + nOpt); }
 
 	// ---- character reset: cSimCharacter::Reset + cScenarioSimChar::InitCharacterPos -----------------
 	void ResetCharacter()
@@ -468,6 +470,21 @@ struct Env {
 			is_off_policy = exp_actor || exp_critic;
 		}
 	}
+	// ---- Q action selection: sim/BaseControllerQ.cpp:32-87 (ShouldExplore / DecideAction / ExploitPolicy / ExploreAction). The net (trunk -> ip1 -> ip2
+	// -> one output per base action, data/policies/dog/nets/dog_q_deploy.prototxt) is held like the CACLA actor: one fragment of n_actions outputs
+	// behind an unused critic slot. Eigen's maxCoeff(&a) returns the FIRST maximum
+	void DecideActionQ(Action& out)
+	{
+		bool explore = false;
+		if (enable_exp) explore = rng.RandDouble() < exp_rate;
+		is_off_policy = explore;
+		if (explore) { BuildBaseAction(rng.RandInt(0, M.n_actions), out); return; }   // BuildRandBaseAction
+		nn_out.assign(net->OutSize(), 0.0);
+		net->Eval(poli_state.data(), nn_out.data());
+		const double* y = nn_out.data() + 1;
+		int a = 0; for (int i = 1; i < M.n_actions; ++i) if (y[i] > y[a]) a = i;
+		BuildBaseAction(a, out);
+	}
 	// ---- CACLA action selection: sim/BaseControllerCacla.cpp:124-151 (ShouldExplore / DecideAction), 205-234 (ExploitPolicy / ExploreAction),
 	// 262-296 (ApplyExpNoiseAction). The actor is held as a one-fragment net of the MACE family with an all-zero critic head, so its
 	// parameter outputs sit behind one (unused) critic slot
@@ -505,7 +522,7 @@ struct Env {
 			if (M.ctrl_type == 1) { exp_actor = true; exp_critic = true; }
 			BuildBaseAction(cmd, a);
 		} else if (net && net->valid) {
-			if (M.ctrl_type == 2) DecideActionCacla(a); else DecideActionBoltzmann(a);
+			if (M.ctrl_type == 2) DecideActionCacla(a); else if (M.ctrl_type == 0) DecideActionQ(a); else DecideActionBoltzmann(a);
 		} else {
 			bool cyclic = (M.ctrl_type >= 1) ? false : (M.act_cyclic[curr.id] != 0);  // MACE / CACLA: IsCurrActionCyclic() == false
 			if (!cyclic) BuildBaseAction(M.default_action, a);
@@ -762,6 +779,7 @@ struct Env {
 		cur_tuple.s0 = cur_tuple.s1;
 		cur_tuple.a.assign(PoliActionSize(), 0.0);
 		if (M.ctrl_type == 2) GetOptParams(curr.params, cur_tuple.a.data());   // cBaseControllerCacla::RecordPoliAction
+		else if (M.ctrl_type == 0) { if (curr.id >= 0 && curr.id < M.n_actions) cur_tuple.a[curr.id] = 1; }   // cBaseControllerQ::RecordPoliAction: one-hot
 		else { cur_tuple.a[0] = curr.id; GetOptParams(curr.params, cur_tuple.a.data() + 1); }
 		cur_tuple.flags = 0;
 		if (M.ctrl_type == 1) cur_tuple.flags |= (exp_critic ? 2u : 0u) | (exp_actor ? 4u : 0u);

@@ -85,7 +85,7 @@ def nn_config(in_size, out_size, raw_forward, variant="f64"):
 
 
 class RefScenario:
-    KINDS = {"sim_char": 0, "exp_mace": 1, "poli_eval": 2}
+    KINDS = {"sim_char": 0, "exp_mace": 1, "poli_eval": 2, "exp": 3}
 
     def __init__(self, kind, arg_file, cwd, extra_args=None, global_seed=1, variant="f64"):
         self.variant = variant

@@ -62,6 +62,10 @@ def test_cacla_action_selection(da, om):
     T.test_cacla_action_selection_and_tuples_vs_oracle(da, om)
 
 
+def test_q_head_action_selection(da, om):
+    T.test_q_head_action_selection_and_tuples_vs_oracle(da, om)
+
+
 def test_perturbation_force(da, om):
     T.test_perturbation_force_vs_oracle(da, om)
     T.test_apply_rand_force_is_seeded_and_bounded(da, om)

@@ -436,6 +436,55 @@ def test_cacla_action_selection_and_tuples_vs_oracle(da, om):
     assert set(b.Ctrl()[2].tolist()) <= set(range(-1, 8))                                  # gInvalidIdx after the actor, a table id after a base action
 
 
+def test_q_head_action_selection_and_tuples_vs_oracle(da, om):
+    """cDogControllerQ (args/opt_args_train_q.txt: -char_ctrl= dog with dog_q_deploy.prototxt, one output per base action): a random base action with
+    probability exp_rate, else the base action with the largest value (sim/BaseControllerQ.cpp:32-87); tuples [r | s | a | s'] with a = one-hot over the
+    8 base actions (:17-23) and only the fail flag (scenarios/ScenarioExp.cpp:286-294); output normaliser -0.5 / 2 (:25-30)."""
+    over = dict(exp_rate=0.4)
+    m, _ = om.build_model("args/opt_args_train_q.txt", REFDATA, over)
+    assert m.ctrl_type == 0 and m.scenario == 1
+    desc = om.parse_deploy_prototxt(os.path.join(REFDATA, "data/policies/dog/nets/dog_q_deploy.prototxt"))
+    assert desc.frag_size == m.n_actions == 8
+    w = om.actor_xavier_weights(desc, 31)
+    n = 3
+    b = batch(da, "args/opt_args_train_q.txt", n, terrain_seed=60, rand_seed=8, **over)
+    assert b.A == 8 and b.nn_out == 8 and b.PolicyNumParams() == len(w) and b.num_frags == 0
+    oo, osc = b.BuildNNOutputOffsetScale()
+    assert np.array_equal(oo, -0.5 * np.ones(8)) and np.array_equal(osc, 2 * np.ones(8))
+    io, isc = np.zeros(283), np.ones(283)
+    b.SetPolicy(w, io, isc, oo, osc)
+    wm, oom, osm = om.actor_policy_to_mace(desc, w, oo, osc)
+    es = [om.OracleEnv(m, terrain_seed=60 + i, rng_seed=8, env_id=i, policy=(desc, wm, io, isc, oom, osm)) for i in range(n)]
+    rows, flags, ids = [], [], []
+    acts = set()
+    for f in range(150):
+        b.Update()
+        for e in es:
+            e.update()
+        r, fl, ei = b.DrainTuples()
+        rows.append(r); flags.append(fl); ids.append(ei)
+        if f % 10 == 5:
+            st, ph, aid, prm, tg = b.Ctrl()
+            for i, e in enumerate(es):
+                so, pho, aido, prmo, tgo = e.ctrl()
+                if e.stats()["resets"] == 0:
+                    assert aid[i] == aido and np.abs(prm[i] - prmo).max() < 1e-9, (f, i)
+                acts.add(int(aid[i]))
+    rows = np.concatenate(rows); flags = np.concatenate(flags); ids = np.concatenate(ids)
+    assert rows.shape[1] == 1 + 2 * 283 + 8
+    a_blk = rows[:, 1 + 283: 1 + 283 + 8]
+    assert np.all((a_blk == 0) | (a_blk == 1)) and np.all(a_blk.sum(axis=1) == 1)          # one-hot
+    assert np.all((flags.astype(np.int64) >> 1) == 0)                                       # cQNetTrainer::eFlagFail only
+    for i, e in enumerate(es):
+        ro, fo = e.drain_tuples(1024)
+        mine = rows[ids == i]; mf = flags[ids == i]
+        k = min(len(ro), len(mine), 4)
+        assert k >= 3
+        assert np.array_equal(mf[:k], fo[:k]) and np.array_equal(mine[:k, 284:292], ro[:k, 284:292].astype(np.float32))
+        assert np.abs(mine[:k] - ro[:k]).max() < 2e-4 * max(1.0, np.abs(ro[:k]).max())
+    assert len(acts) >= 3 and acts <= set(range(8))                                          # exploration visited several base actions
+
+
 def test_perturbation_force_vs_oracle(da, om):
     """tPerturb (ePerturbForce) through cWorld::AddPerturb: a world-frame force on a body part at a body-local offset for a duration,
     advanced at the start of every env-step and dropped when expired (sim/Perturb.cpp, sim/PerturbManager.cpp:41-56); reset clears it."""
@@ -518,7 +567,7 @@ def test_poli_eval_recorders_frame_polling_equals_env_step_polling(da, om, tmp_p
             assert act[a_id] == "%i" % a_id + "".join(", %.5f" % v for v in row)
         for line, (_, aid, prm) in zip(act[len(tab):], expect[e]):
             f = line.split(",\t")
-            assert int(f[0]) == aid and len(f) == 1 + b.A - 1 and np.allclose([float(v) for v in f[1:]], prm, atol=1e-6)
+            assert int(f[0]) == aid and len(f) == 1 + b.frag_size and np.allclose([float(v) for v in f[1:]], prm, atol=1e-6)
         for line, (_, aid, _) in zip(ids, expect[e]):
             f = line.split(",\t"); assert int(f[0]) == aid and len(f) == 1 + b.S
     assert rec.lines == sum(len(x) for x in expect)

@@ -203,6 +203,48 @@ def test_exp_mace_tuples_match_the_reference(om):
     assert len(rows_r) >= 4
 
 
+def test_exp_q_head_tuples_match_the_reference(om):
+    """cScenarioExp + cDogControllerQ (args/opt_args_train_q.txt: -char_ctrl= dog, one network output per base action): greedy action = the first maximum
+    (sim/BaseControllerQ.cpp:59-82), tuple action = one-hot (:17-23), fail flag only; exploration off on both sides (global clock-seeded RNG)."""
+    arg = "args/opt_args_train_q.txt"
+    m, _ = om.build_model(arg, REFERENCE)
+    m.enable_explore = 0
+    desc = om.parse_deploy_prototxt(os.path.join(REFERENCE, "data/policies/dog/nets/dog_q_deploy.prototxt"))
+    w = om.actor_xavier_weights(desc, 5)
+    io, isc = np.zeros(283), np.ones(283)
+    oo, osc = -0.5 * np.ones(8), 2 * np.ones(8)
+    wm, oom, osm = om.actor_policy_to_mace(desc, w, oo, osc)
+    pol = (desc, wm, io, isc, oom, osm)
+    e = om.OracleEnv(m, terrain_seed=33, policy=pol)
+    fwd9 = _policy_raw_forward(e, pol)                                         # the oracle's padded form: [unused critic slot | 8 values], normalised space
+    rs.nn_config(283, 8, lambda x: fwd9(x)[1:9])
+    r = rs.RefScenario("exp", arg, REFERENCE, global_seed=6)
+    assert (r.S, r.A) == (283, 8)
+    off, sc = r.build_output_offset_scale(8)
+    assert np.array_equal(off, oo) and np.array_equal(sc, osc)                  # cBaseControllerQ::BuildNNOutputOffsetScale
+    r.set_net_scale(io, isc, oo, osc)
+    r.seed_ground_and_reset(33)
+    r.enable_explore(0)
+    r.command_action(1); e.command_action(1)
+    ls = rs.LockStep(r, e)
+    n_t = 0; acts = set()
+    for f in range(150):
+        ls.update(); e.frame_end()
+        a, fa = r.drain_tuples()
+        b, fb = e.drain_tuples(f64=True)
+        assert len(a) == len(b), (f, len(a), len(b))
+        for x, y, p, q_ in zip(a, b, fa, fb):
+            assert p == q_ and p in (0, 1)
+            assert np.array_equal(x[284:292], y[284:292]) and x[284:292].sum() == 1 and set(x[284:292]) <= {0.0, 1.0}   # one-hot, same action
+            assert np.abs(x - y).max() < 5e-5 * max(1.0, np.abs(y).max()), (f, np.abs(x - y).max())
+            acts.add(int(np.argmax(x[284:292]))); n_t += 1
+        if e.stats()["resets"] > 0 and n_t >= 4:
+            break
+    check_records(ls.records, e.D, 100, tau_tol=1e-4, prm_tol=1e-9, ctx="exp q")
+    assert n_t >= 4, n_t
+    print("q head: tuples", n_t, "actions", sorted(acts))
+
+
 @pytest.mark.parametrize("arg,seed", [("args/dog_slopes_mixed_args.txt", 17), ("args/dog_narrow_gaps_args.txt", 9), ("args/goat_cliffs_args.txt", 3)])
 def test_ground_window_bit_exact_in_the_float_build(om, arg, seed):
     """'terrain indices bit-exact' against the reference's OWN cGroundVar2D (sim/GroundVar2D.cpp: Update / BuildSegment / tSegment::Init / SampleHeight /
