@@ -87,3 +87,187 @@ def caffe_sgd_step(w, grad, hist, base_lr, momentum, weight_decay, lr_mult, deca
     diff = grad + weight_decay * decay_mult * w
     hist_new = momentum * hist + base_lr * lr_mult * diff
     return w - hist_new, hist_new
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# A whole trainer in numpy fp64: the net (forward + hand-derived backward), the solver and the iteration order of cMACETrainer.
+# ---------------------------------------------------------------------------------------------------------------------------------
+class RefMaceNet:
+    """The *_mace3 topology (3 valid 1-D convolutions over the terrain slice -> terr_ip0 -> concat with the character slice -> ip0 -> value head
+    val_ip0/val_ip1 + n_frags actor heads a{f}_ip0/a{f}_ip1; ReLU after every layer but the head outputs), Caffe conventions: cross-correlation,
+    channel-major flatten, blob order conv0..2, terr_ip0, ip0, val_ip0, val_ip1, a{f}_ip0, a{f}_ip1, weight then bias. All arithmetic fp64."""
+
+    def __init__(self, n_terrain, n_char, convs, fc_terr, fc_trunk, fc_head, n_frags, frag_size):
+        self.n_terrain, self.n_char, self.n_frags, self.frag_size = n_terrain, n_char, n_frags, frag_size
+        self.shapes = []
+        cin, w = 1, n_terrain
+        for cout, k in convs:
+            self.shapes += [(cout, cin, k), (cout,)]; cin, w = cout, w - k + 1
+        self.conv_out = (cin, w)
+        for nout, nin in [(fc_terr, cin * w), (fc_trunk, fc_terr + n_char), (fc_head, fc_trunk), (n_frags, fc_head)]:
+            self.shapes += [(nout, nin), (nout,)]
+        for _ in range(n_frags):
+            self.shapes += [(fc_head, fc_trunk), (fc_head,), (frag_size, fc_head), (frag_size,)]
+        self.sizes = [int(np.prod(s)) for s in self.shapes]
+        self.num_params = sum(self.sizes)
+
+    def split(self, flat):
+        out, off = [], 0
+        for s, n in zip(self.shapes, self.sizes):
+            out.append(np.asarray(flat[off:off + n], np.float64).reshape(s)); off += n
+        assert off == len(flat)
+        return out
+
+    @staticmethod
+    def _im2col(x, k):   # x [B, cin, W] -> [B, Wout, cin * k] (column index = channel * k + tap)
+        B, cin, W = x.shape
+        wout = W - k + 1
+        cols = np.empty((B, wout, cin, k))
+        for t in range(k):
+            cols[:, :, :, t] = x[:, :, t:t + wout].transpose(0, 2, 1)
+        return cols.reshape(B, wout, cin * k)
+
+    def forward(self, flat, x, keep=False):
+        P = self.split(flat)
+        B = x.shape[0]
+        t = x[:, :self.n_terrain].reshape(B, 1, self.n_terrain)
+        tape = []
+        for l in range(3):
+            Wc, bc = P[2 * l], P[2 * l + 1]
+            cols = self._im2col(t, Wc.shape[2])
+            z = cols @ Wc.reshape(Wc.shape[0], -1).T + bc          # [B, Wout, cout]
+            tape.append((cols, z, t.shape))
+            t = np.maximum(z, 0).transpose(0, 2, 1)
+        f_in = t.reshape(B, -1)
+        z3 = f_in @ P[6].T + P[7]; a3 = np.maximum(z3, 0)
+        c_in = np.concatenate([a3, x[:, self.n_terrain:]], 1)
+        z4 = c_in @ P[8].T + P[9]; h = np.maximum(z4, 0)
+        heads, outs = [], []
+        zv = h @ P[10].T + P[11]; av = np.maximum(zv, 0); outs.append(av @ P[12].T + P[13]); heads.append((zv, av))
+        for f in range(self.n_frags):
+            b0 = 14 + 4 * f
+            zf = h @ P[b0].T + P[b0 + 1]; af = np.maximum(zf, 0); outs.append(af @ P[b0 + 2].T + P[b0 + 3]); heads.append((zf, af))
+        y = np.concatenate(outs, 1)
+        if keep:
+            self._tape = (P, x, tape, f_in, z3, c_in, z4, h, heads)
+        return y
+
+    def backward(self, dy):
+        """Gradient of sum(dy * y) wrt every blob, flat, in blob order (call after forward(..., keep=True))."""
+        P, x, tape, f_in, z3, c_in, z4, h, heads = self._tape
+        G = [None] * len(P)
+        B = dy.shape[0]
+        dh = np.zeros_like(h)
+        col = 0
+        for i, (zf, af) in enumerate(heads):
+            b0 = 10 if i == 0 else 14 + 4 * (i - 1)
+            nout = P[b0 + 2].shape[0]
+            d_out = dy[:, col:col + nout]; col += nout
+            G[b0 + 2] = d_out.T @ af; G[b0 + 3] = d_out.sum(0)
+            dz = (d_out @ P[b0 + 2]) * (zf > 0)
+            G[b0] = dz.T @ h; G[b0 + 1] = dz.sum(0)
+            dh += dz @ P[b0]
+        dz4 = dh * (z4 > 0)
+        G[8] = dz4.T @ c_in; G[9] = dz4.sum(0)
+        da3 = (dz4 @ P[8])[:, :z3.shape[1]]
+        dz3 = da3 * (z3 > 0)
+        G[6] = dz3.T @ f_in; G[7] = dz3.sum(0)
+        dt = (dz3 @ P[6]).reshape(B, *self.conv_out)                 # [B, cout, Wout]
+        for l in (2, 1, 0):
+            cols, z, in_shape = tape[l]
+            Wc = P[2 * l]
+            dz = dt.transpose(0, 2, 1) * (z > 0)                     # [B, Wout, cout]
+            G[2 * l] = np.einsum("bwo,bwc->oc", dz, cols).reshape(Wc.shape); G[2 * l + 1] = dz.sum((0, 1))
+            if l > 0:
+                dcols = (dz @ Wc.reshape(Wc.shape[0], -1)).reshape(B, dz.shape[1], in_shape[1], Wc.shape[2])
+                dt = np.zeros(in_shape)
+                for t in range(Wc.shape[2]):
+                    dt[:, :, t:t + dz.shape[1]] += dcols[:, :, :, t].transpose(0, 2, 1)
+        return np.concatenate([g.reshape(-1) for g in G])
+
+
+class RefMaceTrainer:
+    """cMACETrainer, pool size 1, synchronous mode, fp64 numpy: the iteration order of cNeuralNetTrainer::Train / ApplySteps / Step
+    (learning/NeuralNetTrainer.cpp:96-141, 392-455) and cMACETrainer::Step / UpdateActor (learning/MACETrainer.cpp:252-283, 517-600) on top of the
+    bookkeeping above. Index draws come from numpy's RandomState(seed).randint (the reference draws from its clock-seeded cRand): the product
+    trainer is run with the same stream so that batches coincide."""
+
+    def __init__(self, net, blob_mults, S, A, mem_size, batch, discount, num_init_samples, solver, seed, freeze_target_iters=0, init_input_offset_scale=True):
+        self.net, self.S, self.A, self.batch, self.discount = net, S, A, batch, discount
+        self.nf, self.fs = net.n_frags, net.frag_size
+        self.book = RefTrainerBook(S, A, self.nf, self.fs, mem_size, batch, discount)
+        self.num_init_samples, self.solver, self.freeze, self.init_os = num_init_samples, solver, freeze_target_iters, init_input_offset_scale
+        self.lr_mult = np.concatenate([np.full(n, m[0]) for n, m in zip(net.sizes, blob_mults)])
+        self.decay_mult = np.concatenate([np.full(n, m[1]) for n, m in zip(net.sizes, blob_mults)])
+        self.w = np.zeros(net.num_params); self.w_target = self.w.copy(); self.hist = np.zeros(net.num_params)
+        out = self.nf * (1 + self.fs)
+        self.in_off, self.in_scale, self.out_off, self.out_scale = np.zeros(S), np.ones(S), np.zeros(out), np.ones(out)
+        self.rng = np.random.RandomState(seed)
+        self.iter = self.actor_iter = 0
+        self.stage_train = False
+        self.last_loss = None
+
+    def set_weights(self, w):
+        self.w = np.asarray(w, np.float64).copy(); self.w_target = self.w.copy()
+
+    def eval(self, w, X):
+        X = np.atleast_2d(np.asarray(X, np.float64))
+        return self.net.forward(w, (X + self.in_off) * self.in_scale) / self.out_scale - self.out_off
+
+    def _target(self):
+        return self.w_target if self.freeze > 0 else self.w
+
+    def add_tuples(self, rows, flags):
+        return [self.book.add(np.asarray(r, np.float32), int(f)) for r, f in zip(rows, flags)]
+
+    def _sgd(self, X, Y):
+        x = (np.asarray(X, np.float64) + self.in_off) * self.in_scale
+        label = (Y + self.out_off) * self.out_scale
+        out = self.net.forward(self.w, x, keep=True)
+        loss = 0.5 * ((out - label) ** 2).sum() / x.shape[0]
+        grad = self.net.backward((out - label) / x.shape[0])
+        s = self.solver
+        self.w, self.hist = caffe_sgd_step(self.w, grad, self.hist, s["base_lr"], s["momentum"], s["weight_decay"], self.lr_mult, self.decay_mult)
+        return loss
+
+    def train(self):
+        b = self.book
+        if not self.stage_train and b.num >= self.num_init_samples and b.num > 0:
+            if self.num_init_samples > 1 and self.init_os:
+                self.in_off, self.in_scale = b.offset_scale()
+            self.stage_train = True
+        if self.stage_train and self.step():
+            self.iter += 1
+
+    def step(self):
+        b = self.book
+        n = len(b.critic)
+        ids = [b.critic[int(self.rng.randint(0, n))] for _ in range(self.batch)] if n >= self.batch else []
+        succ = len(ids) >= self.batch
+        net_eval = lambda x: self.eval(self.w, x)[0]
+        tgt_eval = lambda x: self.eval(self._target(), x)[0]
+        if succ:
+            X = np.stack([b.mem[t, 1:1 + self.S] for t in ids]).astype(np.float64)
+            Y = np.stack([b.critic_label(t, net_eval, tgt_eval) for t in ids])
+            self.last_loss = self._sgd(X, Y)
+            net_eval = lambda x: self.eval(self.w, x)[0]
+        # UpdateActor
+        if self.stage_train:
+            na = len(b.actor)
+            drawn = []
+            for _ in range(min(self.batch, na)):
+                t = b.actor[int(self.rng.randint(0, na))]
+                if t not in b.actor_batch and t not in drawn:
+                    drawn.append(t)
+            b.actor_batch += [t for t in drawn if b.actor_accepts(t, tgt_eval)]
+        for _ in range(len(b.actor_batch) // self.batch):
+            ids = b.actor_batch[:self.batch]
+            X = np.stack([b.mem[t, 1:1 + self.S] for t in ids]).astype(np.float64)
+            Y = np.stack([b.actor_label(t, net_eval) for t in ids])
+            self._sgd(X, Y)
+            net_eval = lambda x: self.eval(self.w, x)[0]
+            self.actor_iter += 1
+            del b.actor_batch[:self.batch]
+        if self.freeze > 0 and self.iter > 0 and self.iter % self.freeze == 0:
+            self.w_target = self.w.copy()
+        return succ
