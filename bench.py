@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--terrain-gen", choices=["host", "device"], default="host",
+                    help="host: the reference's terrain generator streams (bit-exact windows), regenerated by host workers at the frame boundary (default, the parity-tested mode); "
+                         "device: counter-based streams, windows generated and slid by the GPU, no host sync per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=100, help="outer frames of the bounded CPU-baseline sample (default: about 30 s of CPU work)")
     ap.add_argument("--exchange-steps", type=int, default=-1, help="timed frames of the exchange leg (default: half of --steps; 0 = skip)")
@@ -181,7 +184,7 @@ def main():
     import deepterrainrl_amd as da
     n = a.envs_per_gpu
     b = da.BatchScenario(ARG_FILE, n, data_root=ROOT, device_id=local_rank,
-                         extra_args={"terrain_seed": 20260925, "rand_seed": 1, "global_env_offset": rank * n})
+                         extra_args={"terrain_seed": 20260925, "rand_seed": 1, "global_env_offset": rank * n, "terrain_gen": a.terrain_gen})
     w = xavier_weights(b.PolicyNumParams())
     b.SetPolicy(w, *load_scale())
 
@@ -226,7 +229,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: dog + GroundVar2D slopes_mixed, %d envs per MI355X, ImpPD + MACE actor/critic forward, poli_eval (args/dog_slopes_mixed_args.txt)" % n,
                        "envs_per_gpu": n, "global_envs": n * world, "env_steps_per_step": n * world * steps_per_frame,
-                       "substeps_per_env_step": 5, "parallelism": "env-sharded x%d, no data-path collective" % world},
+                       "substeps_per_env_step": 5, "parallelism": "env-sharded x%d, no data-path collective" % world, "terrain_gen": a.terrain_gen},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": float(traffic) if traffic else None, "traffic_source": traffic_source,
                          "kernel": "dtrl_frame_kernel", "kernel_avg_ms": kern_ms, "kernel_launches": launches,

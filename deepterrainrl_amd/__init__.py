@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_cycle_info", "dtrl_get_action_table", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
     "dtrl_terrain_build", "dtrl_terrain_load_file", "dtrl_args_parse_string",
-    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log",
+    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window",
 ]
 
 
@@ -78,6 +78,7 @@ def _bind(path):
     L.dtrl_get_contacts.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_ctrl.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
     L.dtrl_sample_ground.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.dtrl_get_ground_window.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int64)]
     L.dtrl_eval_stats.argtypes = [vp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.dtrl_dims.argtypes = [vp] + [C.POINTER(C.c_int)] * 8
     L.dtrl_kernel_time_ms.argtypes = [vp, dp, C.POINTER(C.c_int64)]
@@ -341,6 +342,14 @@ class BatchScenario:
         h = np.zeros(n); seg = np.zeros(n, np.int32); i = np.zeros(n, np.int32); j = np.zeros(n, np.int32)
         self._chk(self._lib.dtrl_sample_ground(self._h, int(env), n, _p(xs), _p(h), _p(seg), _p(i), _p(j)))
         return h, seg, i, j
+
+    def GroundWindow(self, env):
+        """One env's two-segment ground window in logical order: [(min_x, max_x, heights float32[w])] * 2 and the number of segments built so far
+        (-1 unless -terrain_gen= device)."""
+        w = (C.c_int32 * 2)(); mn = (C.c_double * 2)(); mx = (C.c_double * 2)(); nb = C.c_int64(0)
+        h0 = np.zeros(512, np.float32); h1 = np.zeros(512, np.float32)
+        self._chk(self._lib.dtrl_get_ground_window(self._h, int(env), w, mn, mx, _p(h0), _p(h1), 512, C.byref(nb)))
+        return [(mn[0], mx[0], h0[:w[0]].copy()), (mn[1], mx[1], h1[:w[1]].copy())], nb.value
 
     def EvalStats(self):
         a = C.c_double(); e, c, r = C.c_int64(), C.c_int64(), C.c_int64()

@@ -7,6 +7,7 @@
 // except the read-only model and policy weights.
 #include "dtrl_engine.h"
 #include "dtrl_kernel_fast.h"
+#include "dtrl_terrain_dev.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +45,39 @@ __global__ void dtrl_gather_f32(float* __restrict__ dst, const float* __restrict
 }
 
 // gr[ids[b]] = staged[b]: one workgroup per record (4 176 B as 16-byte words)
+// -terrain_gen= device: one thread per env; only the few envs whose window must move (or that fell) do any work
+__global__ void dtrl_terrain_boundary(DevBuffers buf, int e0, int n, int mode, const int32_t* __restrict__ env_list)
+{
+	const int k = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+	if (k >= n) return;
+	const int e = env_list ? env_list[k] : e0 + k;
+	tg_env_boundary(buf.gr[e], buf.gen[e], buf.status[e], *buf.tcfg, mode, e, buf.dist_ring, buf.dist_count, buf.dist_cap);
+}
+// launch order of a group's next frame: counting sort on cost / 16, costliest first (one workgroup; the order inside a bucket is whatever the
+// atomics produce -- it only decides which wavefront starts first)
+constexpr int kOrderBuckets = 1024;
+__global__ void __launch_bounds__(1024) dtrl_order_by_cost(const EnvStatus* __restrict__ status, int e0, int n, int32_t* __restrict__ order)
+{
+	__shared__ int hist[kOrderBuckets];
+	__shared__ int part[kOrderBuckets / 64];
+	const int t = static_cast<int>(threadIdx.x);
+	hist[t] = 0;
+	__syncthreads();
+	auto key = [&](int e) { int k = status[e].cost >> 4; k = k < 0 ? 0 : (k >= kOrderBuckets ? kOrderBuckets - 1 : k); return kOrderBuckets - 1 - k; };
+	for (int i = t; i < n; i += kOrderBuckets) atomicAdd(&hist[key(e0 + i)], 1);
+	__syncthreads();
+	// exclusive scan of 1024 counters: per-wave serial prefix over 64 entries by lane 0 of each wave would idle; a two-level scan instead
+	int v = hist[t];
+	int incl = v;
+	for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if ((t & 63) >= d) incl += o; }
+	if ((t & 63) == 63) part[t >> 6] = incl;
+	__syncthreads();
+	if (t == 0) { int run = 0; for (int w = 0; w < kOrderBuckets / 64; ++w) { const int c = part[w]; part[w] = run; run += c; } }
+	__syncthreads();
+	hist[t] = part[t >> 6] + incl - v;
+	__syncthreads();
+	for (int i = t; i < n; i += kOrderBuckets) { const int e = e0 + i; order[e0 + atomicAdd(&hist[key(e)], 1)] = e; }
+}
 __global__ void dtrl_scatter_ground(GroundRec* __restrict__ gr, const GroundRec* __restrict__ staged, const int32_t* __restrict__ ids, int n)
 {
 	const int b = static_cast<int>(blockIdx.x);
@@ -99,6 +133,18 @@ public:
 		if (n <= 0) return true;
 		hipLaunchKernelGGL(dtrl_scatter_ground, dim3(n), dim3(256), 0, stream_, gr, staged, ids, n);
 		return Check(hipGetLastError(), "scatter launch");
+	}
+	bool TerrainBoundary(const DevBuffers& buf, int e0, int n, int mode, const int32_t* env_list) override
+	{
+		if (n <= 0) return true;
+		hipLaunchKernelGGL(dtrl_terrain_boundary, dim3((n + 63) / 64), dim3(64), 0, stream_, buf, e0, n, mode, env_list);
+		return Check(hipGetLastError(), "terrain boundary launch");
+	}
+	bool OrderByCost(const EnvStatus* status, int e0, int n, int32_t* order) override
+	{
+		if (n <= 0) return true;
+		hipLaunchKernelGGL(dtrl_order_by_cost, dim3(1), dim3(kOrderBuckets), 0, stream_, status, e0, n, order);
+		return Check(hipGetLastError(), "order launch");
 	}
 	bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) override
 	{

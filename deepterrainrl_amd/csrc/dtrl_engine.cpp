@@ -10,6 +10,7 @@
 //      (cScenarioSimChar::UpdateGround, :564-572). Doing this at frame boundaries instead of every env-step is
 //      equivalent because the window is rebuilt 1 m before any sample can reach its end (DESIGN.md "Ground").
 #include "dtrl_engine.h"
+#include "dtrl_terrain_dev.h"
 #include "dtrl_topo.h"
 #include <algorithm>
 #include <chrono>
@@ -164,6 +165,15 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	buf_.tuple_count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));
 	d_env_list_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
 	d_order_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
+	if (cfg_.device_terrain) {
+		buf_.gen = static_cast<GroundGen*>(alloc(sizeof(GroundGen) * n_));
+		d_tcfg_ = static_cast<TerrainCfg*>(alloc(sizeof(TerrainCfg)));
+		buf_.tcfg = d_tcfg_;
+		buf_.dist_cap = kDistRingCap;
+		buf_.dist_ring = static_cast<DistRec*>(alloc(sizeof(DistRec) * buf_.dist_cap));
+		buf_.dist_count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));
+		if (!buf_.gen || !d_tcfg_ || !buf_.dist_ring || !buf_.dist_count) return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
+	}
 	pin_recs_ = static_cast<GroundRec*>(be_->HostStaging(sizeof(GroundRec) * n_));
 	pin_order_ = static_cast<int32_t*>(be_->HostStaging(sizeof(int32_t) * n_));
 	pin_ids_ = static_cast<int32_t*>(be_->HostStaging(sizeof(int32_t) * n_));
@@ -213,6 +223,16 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	if (!status_) return Fail(DTRL_ERR_DEVICE, "host staging allocation failed: " + be_->error());
 	double params[kNumTerrainParams];
 	LerpTerrainParams(cfg_, cfg_.terrain_blend, params);
+	if (cfg_.device_terrain) {
+		// every env's window is built by the GPU from its own counter stream (key: terrain seed + global env id)
+		grounds_.clear();
+		int rc = UploadTerrainCfg(params);
+		if (rc != DTRL_OK) return rc;
+		std::vector<GroundGen> gen(n_);
+		for (int e = 0; e < n_; ++e) { gen[e].key = terrain_stream_key(cfg_.terrain_seed, cfg_.run.env_id_base + e); gen[e].ctr = 0; gen[e].builds = 0; gen[e].overflow = 0; }
+		if (!be_->H2D(buf_.gen, gen.data(), sizeof(GroundGen) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (!be_->TerrainBoundary(buf_, 0, n_, 1, nullptr) || !be_->Sync()) return Fail(DTRL_ERR_DEVICE, be_->error());
+	} else {
 	std::vector<GroundRec> recs(n_);
 	for (int e = 0; e < n_; ++e) {
 		GroundWindow& g = grounds_[e];
@@ -222,6 +242,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 		if (!g.FillRecord(recs[e], err_)) return DTRL_ERR_CAPACITY;
 	}
 	if (!be_->H2D(buf_.gr, recs.data(), sizeof(GroundRec) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	}
 	std::vector<EnvState> st(n_);
 	std::memset(st.data(), 0, sizeof(EnvState) * n_);
 	for (int e = 0; e < n_; ++e) { st[e].do_init = 1; st[e].cmd_action = -1; st[e].pert_link = -1; }
@@ -276,9 +297,59 @@ int Engine::LaunchGroup(int group, int n_steps, double dt_step, bool frame_end)
 	return ok ? DTRL_OK : Fail(DTRL_ERR_DEVICE, be_->error());
 }
 
+int Engine::UploadTerrainCfg(const double* params)
+{
+	TerrainCfg c{};
+	c.type = cfg_.terrain_type;
+	std::memcpy(c.params, params, sizeof(c.params));
+	c.world_scale = cfg_.model.world_scale; c.segment_width = 2 * kViewDist;
+	c.view_min = -2; c.view_max = kViewDist + kViewPad;
+	c.spawn_min = -kViewDist + kGroundSpawnOffset; c.spawn_max = kViewDist + kGroundSpawnOffset;
+	be_->Sync();
+	if (!be_->H2D(d_tcfg_, &c, sizeof(c))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	return DTRL_OK;
+}
+
+// -terrain_gen= device: the frame boundary of one env group as three launches on the group's stream, behind its frame kernel and in front of its next
+// one -- the host neither waits nor loops over envs:
+//   dtrl_terrain_boundary  fresh windows for the envs that fell, slid windows where the character got close to an edge, episode distances logged
+//   dtrl_order_by_cost     launch order of the next frame (costliest wavefronts first)
+//   0-step frame launch    the device half of the reset, taken by the envs that fell, skipped by the others (reset_listed = 2)
+int Engine::DeviceFrameWork(int group)
+{
+	const Group& grp = groups_[group];
+	be_->SelectStream(group);
+	struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
+	DevBuffers b = buf_;
+	b.env_list = nullptr; b.reset_listed = 2;
+	if (!be_->TerrainBoundary(buf_, grp.e0, grp.n, 0, nullptr) || !be_->OrderByCost(buf_.status, grp.e0, grp.n, d_order_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	b.env_list = d_order_ + grp.e0;
+	if (!be_->Launch(d_model_, cfg_.run, b, grp.n, 0, 0.0, false)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	return DTRL_OK;
+}
+// device distance ring -> dist_log_ (completion order inside the ring is whatever the atomics produced; GetDistLog groups by env, and one env
+// finishes at most one episode per frame, so the per-env time order is kept by draining between frames or by the ring order of separate launches)
+int Engine::DrainDeviceDistLog()
+{
+	if (!cfg_.device_terrain) return DTRL_OK;
+	be_->Sync();
+	int32_t cnt = 0;
+	if (!be_->D2H(&cnt, buf_.dist_count, sizeof(cnt))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (cnt > buf_.dist_cap) return Fail(DTRL_ERR_CAPACITY, "episode distance ring overflowed: call dtrl_get_dist_log more often");
+	if (cnt > 0) {
+		std::vector<DistRec> tmp(cnt);
+		if (!be_->D2H(tmp.data(), buf_.dist_ring, sizeof(DistRec) * cnt)) return Fail(DTRL_ERR_DEVICE, be_->error());
+		for (const DistRec& r : tmp) dist_log_.emplace_back(r.env, r.dist);
+		const int32_t zero = 0;
+		if (!be_->H2D(buf_.dist_count, &zero, sizeof(zero))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	}
+	return DTRL_OK;
+}
+
 // frame-boundary host work of one env group, on the group's stream
 int Engine::HostFrameWork(int group)
 {
+	if (cfg_.device_terrain) return DeviceFrameWork(group);
 	const double ht0 = g_ht.on ? now_s() : 0;
 	const Group& grp = groups_[group];
 	const int e0 = grp.e0, e1 = grp.e0 + grp.n;
@@ -379,6 +450,15 @@ int Engine::RunFrames(int frames, double dt)
 	if (cfg_.model.has_net && !policy_set_) return Fail(DTRL_ERR_ARG, "policy_net was given but dtrl_set_policy has not been called");
 	const int G = static_cast<int>(groups_.size());
 	const int steps = cfg_.model.num_update_steps;
+	if (cfg_.device_terrain) {
+		// nothing on the host depends on a frame's outcome: queue everything; the streams run ahead of the host by as much as the HIP queues hold
+		for (int f = 0; f < frames; ++f) for (int g = 0; g < G; ++g) {
+			int rc = LaunchGroup(g, steps, dt / steps, true);
+			if (rc == DTRL_OK) rc = DeviceFrameWork(g);
+			if (rc != DTRL_OK) return rc;
+		}
+		return DTRL_OK;
+	}
 	std::vector<int> done(G, 0);
 	for (int g = 0; g < G; ++g) { int rc = LaunchGroup(g, steps, dt / steps, true); if (rc != DTRL_OK) return rc; }
 	int next = 0;   // oldest outstanding launch (launch order is round-robin)
@@ -409,12 +489,24 @@ int Engine::Reset(const int32_t* env_ids, int n, const uint64_t* seeds)
 		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
 		if (seen[e]) continue;
 		seen[e] = 1;
+		if (cfg_.device_terrain) {
+			if (seeds) {   // a fresh stream for this env (cGroundVar2D::SeedRand)
+				GroundGen gg; gg.key = terrain_stream_key(seeds[i], 0); gg.ctr = 0; gg.builds = 0; gg.overflow = 0;
+				if (!be_->H2D(&buf_.gen[e], &gg, sizeof(uint64_t) * 2)) return Fail(DTRL_ERR_DEVICE, be_->error());
+			}
+			reset_ids_.push_back(e);
+			continue;
+		}
 		GroundWindow& g = grounds_[e];
 		if (seeds) g.SeedRand(static_cast<unsigned long>(seeds[i]));
 		g.Clear();
 		g.Update(-kViewDist + kGroundSpawnOffset, kViewDist + kGroundSpawnOffset);
 		if (!UploadGround(e)) return DTRL_ERR_CAPACITY;
 		reset_ids_.push_back(e);
+	}
+	if (cfg_.device_terrain && !reset_ids_.empty()) {
+		std::memcpy(pin_ids_, reset_ids_.data(), sizeof(int32_t) * reset_ids_.size());
+		if (!be_->H2DAsync(d_env_list_, pin_ids_, sizeof(int32_t) * reset_ids_.size()) || !be_->TerrainBoundary(buf_, 0, static_cast<int>(reset_ids_.size()), 1, d_env_list_)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	}
 	int rc = ApplyResets(reset_ids_, -1);
 	if (rc != DTRL_OK) return rc;
@@ -570,6 +662,7 @@ int Engine::SetTerrainLerp(double lerp)
 {
 	double params[kNumTerrainParams];
 	LerpTerrainParams(cfg_, lerp, params);
+	if (cfg_.device_terrain) return UploadTerrainCfg(params);
 	for (GroundWindow& g : grounds_) g.SetParams(params);   // takes effect at the next segment build, as in the reference
 	return DTRL_OK;
 }
@@ -621,6 +714,7 @@ int Engine::TupleStats(int64_t* pending, int64_t* drained, int64_t* dropped, int
 int Engine::GetDistLog(double* dist, int32_t* env_ids, int cap, int* out_n)
 {
 	if (!out_n || cap < 0) return Fail(DTRL_ERR_ARG, "bad arguments");
+	{ int rc = DrainDeviceDistLog(); if (rc != DTRL_OK) return rc; }
 	std::vector<std::pair<int32_t, double>> v = dist_log_;
 	std::stable_sort(v.begin(), v.end(), [](const std::pair<int32_t, double>& a, const std::pair<int32_t, double>& b) { return a.first < b.first; });
 	*out_n = static_cast<int>(v.size());
@@ -750,6 +844,25 @@ int Engine::SampleGround(int env, int n, const double* x, double* h, int32_t* se
 		if (seg) seg[i] = s;
 		if (oi) oi[i] = a;
 		if (oj) oj[i] = b;
+	}
+	return DTRL_OK;
+}
+
+int Engine::GroundWindowRec(int env, int32_t* w2, double* min_x2, double* max_x2, float* h0, float* h1, int cap, int64_t* num_builds)
+{
+	if (env < 0 || env >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
+	be_->Sync();
+	if (!be_->D2H(&tmp_rec_, &buf_.gr[env], sizeof(GroundRec))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	float* dst[2] = {h0, h1};
+	for (int s = 0; s < 2; ++s) {
+		if (w2) w2[s] = tmp_rec_.w[s];
+		if (min_x2) min_x2[s] = tmp_rec_.min_x[s];
+		if (max_x2) max_x2[s] = tmp_rec_.max_x[s];
+		if (dst[s]) std::memcpy(dst[s], tmp_rec_.data[s], sizeof(float) * std::max(0, std::min<int>(cap, tmp_rec_.w[s])));
+	}
+	if (num_builds) {
+		*num_builds = -1;
+		if (cfg_.device_terrain) { GroundGen g; if (!be_->D2H(&g, &buf_.gen[env], sizeof(g))) return Fail(DTRL_ERR_DEVICE, be_->error()); *num_builds = g.builds; if (g.overflow) return Fail(DTRL_ERR_CAPACITY, "terrain segment exceeds kSegCap vertices"); }
 	}
 	return DTRL_OK;
 }

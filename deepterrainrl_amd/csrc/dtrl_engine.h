@@ -27,6 +27,11 @@ public:
 	// gr[ids[k]] = staged[k] for k < n (device pointers), queued on the selected stream: the frame's regenerated terrain windows arrive as ONE upload
 	// of a packed array + this scatter instead of one hipMemcpyAsync per env
 	virtual bool ScatterGround(GroundRec* gr, const GroundRec* staged, const int32_t* ids, int n) = 0;
+	// -terrain_gen= device: the frame-boundary terrain work of envs [e0, e0 + n) (or of env_list[0 .. n) when given), queued on the selected stream
+	// (tg_env_boundary, dtrl_terrain_dev.h); mode 0 = after a frame, 1 = (re)initialise
+	virtual bool TerrainBoundary(const DevBuffers& buf, int e0, int n, int mode, const int32_t* env_list) = 0;
+	// order[e0 .. e0 + n) = the envs e0 .. e0 + n - 1 sorted by status[].cost, costliest first (launch order of the group's next frame), on the selected stream
+	virtual bool OrderByCost(const EnvStatus* status, int e0, int n, int32_t* order) = 0;
 	virtual bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) = 0;
 	virtual bool Sync() = 0;                 // all streams
 	// work queues: H2D / H2DAsync / D2H / Launch act on the selected stream (0 by default); D2H and H2D synchronise only that stream
@@ -67,6 +72,7 @@ public:
 	int AddPerturb(const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration);
 	int ApplyRandForce(const int32_t* env_ids, int n, uint64_t seed);
 	int GetPoliState(const int32_t* env_ids, int n, double* s);
+	int GroundWindowRec(int env, int32_t* w2, double* min_x2, double* max_x2, float* h0, float* h1, int cap, int64_t* num_builds);
 	int SampleGround(int env, int n, const double* x, double* h, int32_t* seg, int32_t* oi, int32_t* oj);
 	int EvalStats(double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets);
 	int KernelTime(double* avg_ms, int64_t* launches);
@@ -82,6 +88,9 @@ public:
 private:
 	int Fail(int code, const std::string& msg) { err_ = msg; return code; }
 	int HostFrameWork(int group);
+	int DeviceFrameWork(int group);   // -terrain_gen= device: the same frame-boundary work queued as device kernels, no host sync
+	int DrainDeviceDistLog();
+	int UploadTerrainCfg(const double* params);
 	int ApplyResets(const std::vector<int32_t>& ids, int group);
 	int LaunchGroup(int group, int n_steps, double dt_step, bool frame_end);
 	// env groups: contiguous env ranges, each with its own stream, launch order and staging slices. Envs are independent, so a group
@@ -105,6 +114,8 @@ private:
 	std::vector<GroundWindow> grounds_;
 	EnvStatus* status_ = nullptr;   // page-locked: the per-frame read-back lands here without a staging copy
 	GroundRec tmp_rec_;
+	TerrainCfg* d_tcfg_ = nullptr;
+	static constexpr int kDistRingCap = 1 << 20;
 	std::vector<double> in_off_, in_scale_, out_off_, out_scale_;   // host copies of the policy normalisers (identity until set)
 	int UploadNormalizers();
 	void BuildRelayoutMap(std::vector<int32_t>& map) const;

@@ -1,5 +1,6 @@
 // dtrl_host.cpp -- see dtrl_host.h. Reference citations are file:line relative to the reference repo root.
 #include "dtrl_host.h"
+#include "dtrl_terrain_gen.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -162,181 +163,15 @@ const char* const kTerrainParamNames[kNumTerrainParams] = {
 const double kTerrainParamDefaults[kNumTerrainParams] = {4, 7, 0.5, 2, -2, -2, 6, 8, 0.2, 0.2, 0.25, 0.5, 5, 7, 0.1, 0.4, -0.4, -0.1, 0, 0.03,
 	3, 6, 0.1, 0.4, 0.15, 0.5, -2, -2, 1, 4, 5, 7, 0.1, 0.4, -0.4, -0.1, 0, 0.25, -0.35, 0.35};
 
-namespace {
-enum { GSmin, GSmax, GWmin, GWmax, GHmin, GHmax, WSmin, WSmax, WWmin, WWmax, WHmin, WHmax, SSmin, SSmax, SH0min, SH0max, SH1min, SH1max,
-	BHmin, BHmax, NSmin, NSmax, NDmin, NDmax, NWmin, NWmax, NDpmin, NDpmax, NCmin, NCmax, CSmin, CSmax, CH0min, CH0max, CH1min, CH1max, CMini,
-	SlRange, SlMin, SlMax };
-
-const float kSpacing = 0.1f;  // cTerrainGen2D::gVertSpacing (float)
-
-// a run of vertices appended to a height strip; knows whether the strip started empty (first vertex is shared otherwise)
-struct Strip {
-	std::vector<float>& h;
-	explicit Strip(std::vector<float>& v) : h(v) {}
-	static int verts_for(double w) { return static_cast<int>(std::ceil(w / kSpacing)) + 1; }
-	// common prologue of AddFlat/AddBox/AddStep: hold the current height for `w` metres; returns (n0, was_empty, base)
-	float hold(double w, size_t& n0, bool& empty)
-	{
-		int n = verts_for(w);
-		n0 = h.size(); empty = h.empty();
-		float base = 0;
-		if (!empty) { --n; base = h.back(); }
-		for (int i = 0; i < n; ++i) h.push_back(base);
-		return base;
-	}
-	double added(size_t n0, bool empty) const
-	{
-		int verts = static_cast<int>(h.size() - n0);
-		if (empty) --verts;
-		return verts * kSpacing;   // int * float -> float, widened on return (as in the reference)
-	}
-	double flat(double w) { size_t n0; bool e; hold(w, n0, e); return added(n0, e); }
-	double box(double spacing, double w, double depth)
-	{
-		size_t n0; bool e; float base = hold(spacing, n0, e);
-		int n = verts_for(w) - 1;
-		float lvl = static_cast<float>(base + depth);
-		for (int i = 0; i < n; ++i) h.push_back(lvl);
-		h.push_back(base);
-		return added(n0, e);
-	}
-	double step(double w, double dh)
-	{
-		size_t n0; bool e; float base = hold(w, n0, e);
-		h.push_back(static_cast<float>(base + dh));
-		return added(n0, e);
-	}
-};
-
-void overlay_slopes(const double* p, size_t beg, size_t end, TerrainRand& rnd, std::vector<float>& h)
-{
-	const double range = std::abs(p[SlRange]), mean = 0.5 * (p[SlMin] + p[SlMax]), half = 0.5 * (p[SlMax] - p[SlMin]);
-	double slope = 0, dh = 0;
-	for (size_t i = beg; i < end; ++i) {
-		double delta = rnd.RandDouble(0, range);
-		double sign_rand = rnd.RandDouble(-1, 1);
-		if (sign_rand < (slope - mean) / half) delta = -delta;
-		slope += delta;
-		dh += slope * kSpacing;
-		h[i] += static_cast<float>(dh);
-	}
-}
-void overlay_bumps(double mn, double mx, size_t beg, size_t end, TerrainRand& rnd, std::vector<float>& h)
-{
-	for (size_t i = beg; i + 1 < end; ++i) { double d = rnd.RandSign() * rnd.RandDouble(mn, mx); h[i] += static_cast<float>(d); }
-}
-void pick_range(double a0, double a1, double b0, double b1, TerrainRand& rnd, double& mn, double& mx)
-{
-	bool va = (a0 != 0 || a1 != 0), vb = (b0 != 0 || b1 != 0);
-	if (va && vb) { bool heads = rnd.FlipCoin(); mn = heads ? a0 : b0; mx = heads ? a1 : b1; }
-	else if (va) { mn = a0; mx = a1; }
-	else { mn = b0; mx = b1; }
-}
-double base_feature(int kind, double width, const double* p, TerrainRand& rnd, std::vector<float>& h);
-
-double gaps(double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
-{
-	Strip s(h); double tot = 0;
-	while (tot < width) { double sp = rnd.RandDouble(p[GSmin], p[GSmax]); double w = rnd.RandDouble(p[GWmin], p[GWmax]); double d = rnd.RandDouble(p[GHmin], p[GHmax]); tot += s.box(sp, w, d); }
-	return tot;
-}
-double walls(double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
-{
-	Strip s(h); double tot = 0;
-	while (tot < width) { double sp = rnd.RandDouble(p[WSmin], p[WSmax]); double w = rnd.RandDouble(p[WWmin], p[WWmax]); double d = rnd.RandDouble(p[WHmin], p[WHmax]); tot += s.box(sp, w, d); }
-	return tot;
-}
-double steps(double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
-{
-	Strip s(h); double tot = 0;
-	while (tot < width) {
-		double mn, mx; pick_range(p[SH0min], p[SH0max], p[SH1min], p[SH1max], rnd, mn, mx);
-		double w = rnd.RandDouble(p[SSmin], p[SSmax]); double dh = rnd.RandDouble(mn, mx);
-		tot += s.step(w, dh);
-	}
-	return tot;
-}
-double narrow_gaps(double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
-{
-	Strip s(h); double tot = 0;
-	int cmin = std::max(1, static_cast<int>(p[NCmin])), cmax = std::max(1, static_cast<int>(p[NCmax]));
-	while (tot < width) {
-		double sp = rnd.RandDouble(p[NSmin], p[NSmax]);
-		int count = rnd.RandInt(cmin, cmax + 1);
-		for (int i = 0; i < count; ++i) {
-			double w = rnd.RandDouble(p[NWmin], p[NWmax]); double d = rnd.RandDouble(p[NDpmin], p[NDpmax]);
-			tot += s.box(sp, w, d);
-			sp = rnd.RandDouble(p[NDmin], p[NDmax]);
-		}
-	}
-	return tot;
-}
-double mixed(double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
-{
-	double tot = 0; const double dummy = kSpacing;
-	while (tot < width) {
-		int t = rnd.RandInt(0, 3);
-		tot += (t == 0) ? gaps(dummy, p, rnd, h) : (t == 1) ? steps(dummy, p, rnd, h) : walls(dummy, p, rnd, h);
-	}
-	return tot;
-}
-double cliffs(double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
-{
-	Strip s(h); double tot = 0; size_t beg = h.size();
-	int mini_max = static_cast<int>(p[CMini]);
-	while (tot < width) {
-		double mn, mx; pick_range(p[CH0min], p[CH0max], p[CH1min], p[CH1max], rnd, mn, mx);
-		double w = rnd.RandDouble(p[CSmin], p[CSmax]); double dh = rnd.RandDouble(mn, mx);
-		double cur_w = 0, cur_dh = 0;
-		int n_mini = rnd.RandInt(0, mini_max + 1);
-		for (int i = 0; i < n_mini + 1; ++i) {
-			double mw = (i == 0) ? w : 0.1;
-			double mh = rnd.RandDouble(cur_dh, dh);
-			if (i == n_mini) mh = dh;
-			cur_w += s.step(mw, mh - cur_dh);
-			cur_dh = mh;
-		}
-		tot += cur_w;
-	}
-	size_t end = h.size();
-	overlay_slopes(p, beg, end, rnd, h);
-	overlay_bumps(p[BHmin], p[BHmax], beg, end, rnd, h);
-	return tot;
-}
-// kind: 0 flat 1 gaps 2 steps 3 walls 4 mixed 5 narrow gaps
-double base_feature(int kind, double width, const double* p, TerrainRand& rnd, std::vector<float>& h)
-{
-	switch (kind) {
-	case 1: return gaps(width, p, rnd, h);
-	case 2: return steps(width, p, rnd, h);
-	case 3: return walls(width, p, rnd, h);
-	case 4: return mixed(width, p, rnd, h);
-	case 5: return narrow_gaps(width, p, rnd, h);
-	default: { Strip s(h); return s.flat(width); }
-	}
-}
-}  // namespace
-
 double BuildTerrain(int type, double width, const double* p, TerrainRand& rnd, std::vector<float>& out)
 {
-	// (base feature, slopes overlay, bumps overlay) per terrain type: sim/TerrainGen2D.cpp:148-181 + the Build* bodies
-	static const struct { int base; bool slopes; bool bumps; } kRecipe[kTerrTypeMax] = {
-		{0, false, false}, {1, false, false}, {2, false, false}, {3, false, false}, {0, false, true}, {4, false, false}, {5, false, false},
-		{0, true, false}, {1, true, false}, {2, true, false}, {3, true, false}, {4, true, false}, {5, true, false}, {-1, false, false}};
-	if (type == kTerrCliffs) return cliffs(width, p, rnd, out);
-	if (type < 0 || type >= kTerrTypeMax) type = kTerrFlat;
-	size_t beg = out.size();
-	double tot = base_feature(kRecipe[type].base, width, p, rnd, out);
-	size_t end = out.size();
-	if (kRecipe[type].slopes) overlay_slopes(p, beg, end, rnd, out);
-	if (kRecipe[type].bumps) overlay_bumps(p[BHmin], p[BHmax], beg, end, rnd, out);
-	return tot;
+	return tgen::build_terrain(type, width, p, rnd, out);   // dtrl_terrain_gen.h: the generator shared with the on-device path
 }
 
 // =====================================================================================================================
 // cGroundVar2D window (sim/GroundVar2D.cpp)
 double GroundWindow::Seg::MinX() const { return data.empty() ? std::numeric_limits<double>::infinity() : min_x; }
-double GroundWindow::Seg::MaxX() const { return data.empty() ? -std::numeric_limits<double>::infinity() : min_x + (data.size() - 1) * static_cast<double>(kSpacing); }
+double GroundWindow::Seg::MaxX() const { return data.empty() ? -std::numeric_limits<double>::infinity() : min_x + (data.size() - 1) * static_cast<double>(tgen::kSpacing); }
 
 void GroundWindow::Configure(int type, const double* params, double world_scale, double segment_width)
 {
@@ -351,13 +186,13 @@ void GroundWindow::BuildSegment(int seg_id, double bmin, double bmax, bool align
 	// tSegment::Init (:392-455) whose Bullet round trips fix the float-rounded origin / x scaling used by CalcGridCoord.
 	Seg& seg = segs_[seg_id];
 	seg.data.clear();
-	if (bmin <= 0 && bmax >= 0) { Strip s(seg.data); s.flat(std::min(bmax - bmin, 1 - bmin)); }
+	if (bmin <= 0 && bmax >= 0) { tgen::Strip<std::vector<float>> s(seg.data); s.flat(std::min(bmax - bmin, 1 - bmin)); }
 	BuildTerrain(type_, bmax - bmin, params_, rand_, seg.data);
 	const int n = static_cast<int>(seg.data.size());
 	float end_h = n > 0 ? (align_min ? seg.data[0] : seg.data[n - 1]) : 0.f;
 	float off = static_cast<float>(fix_y - end_h);
 	for (float& v : seg.data) v += off;
-	const double sp = static_cast<double>(kSpacing);
+	const double sp = static_cast<double>(tgen::kSpacing);
 	seg.min_x = align_min ? bmin : (bmax - (n - 1) * sp);
 	double centre = 0.5 * (seg.min_x + (seg.min_x + (seg.data.size() - 1) * sp));
 	float bt_origin = static_cast<float>(world_scale_) * static_cast<float>(centre);
@@ -703,6 +538,11 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	args.ParseDouble("min_perturb", cfg.min_perturb); args.ParseDouble("max_perturb", cfg.max_perturb);
 	args.ParseDouble("min_pertrub_duration", cfg.min_perturb_duration); args.ParseDouble("max_perturb_duration", cfg.max_perturb_duration);
 	int seed = 0; if (args.ParseInt("terrain_seed", seed)) cfg.terrain_seed = static_cast<uint64_t>(seed);
+	{
+		std::string gen = "host"; args.ParseString("terrain_gen", gen);
+		if (gen != "host" && gen != "device") { err = "-terrain_gen= must be host (the reference's generator streams, bit-exact) or device (counter-based streams, generated on the GPU)"; return false; }
+		cfg.device_terrain = gen == "device";
+	}
 
 	// exploration (scenarios/ScenarioExp.cpp:16-45)
 	cfg.tuple_buffer_size = 16; args.ParseInt("tuple_buffer_size", cfg.tuple_buffer_size);

@@ -111,6 +111,7 @@ struct ScenarioConfig {
 	std::vector<std::vector<double>> terrain_param_sets;
 	double terrain_blend = 0;
 	uint64_t terrain_seed = 0;
+	bool device_terrain = false;   // -terrain_gen= device: windows are generated and slid by the GPU at the frame boundary (dtrl_terrain_dev.h)
 	int tuple_buffer_size = 16;
 	int tuple_ring_capacity = 0;   // -tuple_ring_capacity=: rows of the device tuple ring (0 = max(2 num_envs, tuple_buffer_size))
 	// cScenarioSimChar::ApplyRandForce ranges (scenarios/ScenarioSimChar.cpp:60-63, 88-91; the duration key's typo is the reference's)

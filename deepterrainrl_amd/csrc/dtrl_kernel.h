@@ -101,7 +101,12 @@ struct DevBuffers {
 	int32_t model_topo;        // compiled-in skeleton id (dtrl_topo.h; selects the register-resident kernel instantiation), 0 = none
 	unsigned long long* prof;  // [N][kProfMax] cycle counters (DTRL_PROFILE builds), else null
 	const int32_t* env_list;   // optional indirection: workgroup b handles env_list[b] (launch order, compact reset launches)
-	int32_t reset_listed;      // 1: every env of this launch performs the device half of a reset (compact reset launches)
+	int32_t reset_listed;      // 1: every env of this launch performs the device half of a reset (compact reset launches);
+	                           // 2: (-terrain_gen= device) a 0-step launch over a whole group in which the envs that fell (st.need_reset) do, the others return
+	// on-device terrain generation (dtrl_terrain_dev.h); null / 0 in the default (host generator) mode
+	GroundGen* gen;
+	const TerrainCfg* tcfg;
+	DistRec* dist_ring; int32_t* dist_count; int32_t dist_cap;
 	const float* weights;
 	const real* in_off; const real* in_scale; const real* out_off; const real* out_scale;
 	NetDesc net;
@@ -1791,6 +1796,7 @@ DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, co
 		LANES_END
 	}
 	const GroundRec& g = buf.gr[env];
+	if (buf.reset_listed == 2 && ws.st.need_reset == 0 && ws.st.do_init == 0) return;   // wave-uniform: this env did not fall, nothing to do (state, status untouched)
 	if (__builtin_expect(ws.st.do_init != 0, 0)) reset_env(ws, gm, rp, buf, g, env, true);
 	else if (__builtin_expect(ws.st.do_reset != 0 || buf.reset_listed != 0, 0)) reset_env(ws, gm, rp, buf, g, env, false);
 	else forward_kinematics(ws);

@@ -125,6 +125,25 @@ struct GroundRec {
 	float data[2][kSegCap];
 };
 
+// ---- on-device terrain generation (-terrain_gen= device; dtrl_terrain_dev.h) ----
+// generator state of one env: a counter-based random stream (key from terrain seed + GLOBAL env id, so windows do not depend on sharding or on
+// scheduling) and bookkeeping
+struct GroundGen {
+	uint64_t key, ctr;
+	int32_t builds;      // segments built so far
+	int32_t overflow;    // a segment did not fit kSegCap vertices (the host path reports DTRL_ERR_CAPACITY; here the strip is cut and this is counted)
+};
+// what cGroundVar2D / cTerrainGen2D are configured with (one record per batch; the curriculum rewrites params)
+struct TerrainCfg {
+	int32_t type, pad_;
+	double params[40];
+	double world_scale, segment_width;
+	double view_min, view_max;      // window the character must see: root_x + view_min .. root_x + view_max (scenarios/ScenarioSimChar.cpp:328-342)
+	double spawn_min, spawn_max;    // bounds cScenarioSimChar::ResetGround / BuildGround build around (:344-369)
+};
+// poli_eval episode distances recorded by the device-side frame boundary (cScenarioPoliEval::RecordDistTraveled -> mDistLog)
+struct DistRec { int32_t env, pad_; double dist; };
+
 // per-env status the host reads back after each frame (24 B, coalesced)
 struct EnvStatus {
 	double root_x;

@@ -165,6 +165,10 @@ dtrl_status dtrl_get_cycle_info(dtrl_batch* b, const int32_t* env_ids, int n, in
 dtrl_status dtrl_get_action_table(dtrl_batch* b, int* n_actions, double* table);
 /* ground observability: cGround::SampleHeight (sim/GroundVar2D.cpp:98-114) with the grid cell it used (terrain-index parity) */
 dtrl_status dtrl_sample_ground(dtrl_batch* b, int env, int n, const double* x, double* h, int32_t* seg, int32_t* i, int32_t* j);
+/* Replaces: cGroundVar2D::GetSegment(s) / tSegment::mData, GetMinX / GetMaxX (sim/GroundVar2D.cpp:279-290, 392-455, 504-520) of one env's two-segment
+ * window in logical order (slot 0 = min segment): vertex counts, x ranges, and the heights (metres, float) of each slot, heights0 / heights1 holding
+ * up to cap values each (may be NULL). num_builds = segments built for this env so far (-terrain_gen= device; -1 in host mode) */
+dtrl_status dtrl_get_ground_window(dtrl_batch* b, int env, int32_t* w2, double* min_x2, double* max_x2, float* heights0, float* heights1, int cap, int64_t* num_builds);
 
 /* Replaces: cScenarioPoliEval::GetAvgDist / GetNumEpisodes / GetNumCycles (scenarios/ScenarioPoliEval.h:20-26), batch aggregate. */
 dtrl_status dtrl_eval_stats(dtrl_batch* b, double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets);

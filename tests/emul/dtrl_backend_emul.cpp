@@ -3,6 +3,8 @@
 // It is linked ONLY into libdtrl_emul.so, which nothing in the product loads (deepterrainrl_amd/__init__.py loads
 // libdtrl.so and raises if the HIP library or device is missing). It is not a CPU fallback and is never benchmarked.
 #include "dtrl_engine.h"
+#include "dtrl_terrain_dev.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -24,6 +26,17 @@ public:
 	bool D2D(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
 	bool ScatterGround(GroundRec* gr, const GroundRec* staged, const int32_t* ids, int n) override { for (int k = 0; k < n; ++k) gr[ids[k]] = staged[k]; return true; }
 	bool GatherF32(float* dst, const float* src, const int32_t* idx, size_t n) override { for (size_t i = 0; i < n; ++i) dst[i] = idx[i] >= 0 ? src[idx[i]] : 0.0f; return true; }
+	bool TerrainBoundary(const DevBuffers& buf, int e0, int n, int mode, const int32_t* env_list) override
+	{
+		for (int k = 0; k < n; ++k) { const int e = env_list ? env_list[k] : e0 + k; tg_env_boundary(buf.gr[e], buf.gen[e], buf.status[e], *buf.tcfg, mode, e, buf.dist_ring, buf.dist_count, buf.dist_cap); }
+		return true;
+	}
+	bool OrderByCost(const EnvStatus* status, int e0, int n, int32_t* order) override
+	{
+		for (int k = 0; k < n; ++k) order[e0 + k] = e0 + k;
+		std::stable_sort(order + e0, order + e0 + n, [&](int a, int b) { return (status[a].cost >> 4) > (status[b].cost >> 4); });
+		return true;
+	}
 	bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) override
 	{
 		int nt = std::min<int>(n_envs, std::max(1u, std::thread::hardware_concurrency()));

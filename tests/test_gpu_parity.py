@@ -423,3 +423,48 @@ def test_same_group_nonadjacent_links_overlap_statistics(da, om):
         samples, rate.sum(), ", ".join("%d-%d: %.4f" % (p[0], p[1], r) for r, p in worst)))
     assert samples > 0.8 * n * frames
     assert rate.max() < 0.5
+
+
+# ---- on-device terrain generation (tests/test_device_terrain.py holds the CPU twins and the description) ----
+def test_device_terrain_rollout_windows_resets_and_dist_log(om):
+    import test_device_terrain as D
+    import deepterrainrl_amd as da_mod
+    b = D.run_device_terrain_rollout(da_mod.BatchScenario, om, n=256, frames=150)
+    assert b.EvalStats()["resets"] >= 20
+
+
+def test_device_terrain_determinism_and_shard_invariance(om):
+    import test_device_terrain as D
+    import deepterrainrl_amd as da_mod
+    D.run_determinism_and_shard_invariance(da_mod.BatchScenario, om)
+
+
+def test_device_terrain_equals_the_lane_loop_build(om):
+    """The GPU's windows against the same code run by the host compiler (tests/emul): identical records for the same global env ids."""
+    import test_device_terrain as D
+    import deepterrainrl_amd as da_mod
+    from conftest import EmulScenario
+    g = D.make(da_mod.BatchScenario, 16, terrain_seed=21, rand_seed=4); D.set_policy(g, om)
+    c = D.make(EmulScenario, 16, terrain_seed=21, rand_seed=4); D.set_policy(c, om)
+    for f in range(60):
+        g.Update(); c.Update()
+    qg, _ = g.PoseVel(); qc, _ = c.PoseVel()
+    n_same = 0
+    for e in range(16):
+        if abs(qg[e, 0] - qc[e, 0]) < 1e-6:                                  # trajectories that have not yet diverged in the last bits (fast vs reference kernel)
+            (wg, nbg), (wc, nbc) = g.GroundWindow(e), c.GroundWindow(e)
+            assert nbg == nbc and all(np.array_equal(wg[s][2], wc[s][2]) and wg[s][0] == wc[s][0] for s in range(2))
+            n_same += 1
+    assert n_same >= 8
+
+
+def test_device_generator_statistics_match_the_host_generator(om):
+    import test_device_terrain as D
+    import deepterrainrl_amd as da_mod
+    D.run_generator_statistics(da_mod.BatchScenario, om, terrains=("slopes_mixed", "narrow_gaps"))
+
+
+def test_device_terrain_user_reset_and_curriculum(om):
+    import test_device_terrain as D
+    import deepterrainrl_amd as da_mod
+    D.run_user_reset_and_curriculum(da_mod.BatchScenario, om)
