@@ -177,6 +177,7 @@ class BatchScenario:
         w = np.ascontiguousarray(weights, np.float32)
         arrs = [None if a is None else np.ascontiguousarray(a, np.float64) for a in (in_off, in_scale, out_off, out_scale)]
         self._chk(self._lib.dtrl_set_policy(self._h, _p(w), w.size, *[_p(a) for a in arrs]))
+        self._policy = (w.copy(), arrs[0], arrs[1])     # kept for the NN-activation recorder (recorders.py)
 
     def PolicyNumParams(self):
         n = C.c_size_t()

@@ -146,6 +146,30 @@ class MaceNet(torch.nn.Module):
             outs.append(self.mods[8 + 2 * f](relu(self.mods[7 + 2 * f](h))))
         return torch.cat(outs, 1)
 
+    def named_blobs(self, x):
+        """Forward pass that keeps every Caffe blob of the deploy net by name (cNeuralNet::GetLayerState reads mNet->blob_by_name): the ReLU layers
+        of these nets write to their own tops, so "terr_conv0" is the pre-activation and "terr_relu0" the rectified blob. x: normalised input [B, S]."""
+        relu = torch.nn.functional.relu
+        out = {"data": x, "data_terrain": x[:, :self.n_terrain], "data_char": x[:, self.n_terrain:]}
+        t = x[:, :self.n_terrain].unsqueeze(1)
+        for l in range(3):
+            t = self.mods[l](t); out["terr_conv%d" % l] = t.flatten(1)
+            t = relu(t); out["terr_relu%d" % l] = t.flatten(1)
+        t = self.mods[3](t.flatten(1)); out["terr_ip0"] = t
+        t = relu(t); out["terr_relu3"] = t
+        out["char_flatten0"] = x[:, self.n_terrain:]
+        c = torch.cat([t, x[:, self.n_terrain:]], 1); out["concat0"] = c
+        h = self.mods[4](c); out["ip0"] = h
+        h = relu(h); out["relu0"] = h
+        heads = []
+        for i, pre in enumerate(["val"] + ["a%d" % f for f in range(self.n_frags)]):
+            z = self.mods[5 + 2 * i](h); out[pre + "_ip0"] = z
+            z = relu(z); out[pre + "_relu0"] = z
+            y = self.mods[6 + 2 * i](z); out[pre + "_ip1"] = y
+            heads.append(y)
+        out["output"] = torch.cat(heads, 1)
+        return out
+
     def get_flat(self):
         src = self.flat if self.flat is not None else torch.cat([b.detach().reshape(-1) for b in self.blobs()])
         return src.detach().to(torch.float32).cpu().numpy()

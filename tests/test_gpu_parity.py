@@ -468,3 +468,7 @@ def test_device_terrain_user_reset_and_curriculum(om):
     import test_device_terrain as D
     import deepterrainrl_amd as da_mod
     D.run_user_reset_and_curriculum(da_mod.BatchScenario, om)
+
+
+def test_nn_activation_recorder(da, om, tmp_path):
+    T.test_nn_activation_recorder_vs_numpy_net_and_oracle_forward(da, om, tmp_path)

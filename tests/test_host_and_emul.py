@@ -573,6 +573,40 @@ def test_poli_eval_recorders_frame_polling_equals_env_step_polling(da, om, tmp_p
     assert rec.lines == sum(len(x) for x in expect)
 
 
+def test_nn_activation_recorder_vs_numpy_net_and_oracle_forward(da, om, tmp_path):
+    """cScenarioPoliEval::RecordNNActivation (scenarios/ScenarioPoliEval.cpp:271-296): one line per valid cycle, "<action id>,\\t<blob>..." with the named
+    blob of the policy net after the forward pass that chose the action. Checked against (a) the numpy restatement of the net (oracle/trainer_ref.py)
+    run on the oracle's policy state of the same cycle, for a hidden blob, and (b) the engine's own network output for the "output" blob."""
+    from deepterrainrl_amd.recorders import PoliEvalRecorder
+    from oracle import trainer_ref as ref
+    pol = dog_policy(om)
+    desc, w, io, isc, oo, osc = pol
+    arg = "args/dog_slopes_mixed_args.txt"
+    net_file = os.path.join(REFDATA, "data/policies/dog/nets/dog_mace3_deploy.prototxt")
+    rnet = ref.RefMaceNet(desc.n_terrain, desc.n_char, [(desc.conv_ch[i], desc.conv_k[i]) for i in range(3)], desc.fc_terr, desc.fc_trunk, desc.fc_head, desc.n_frags, desc.frag_size)
+    for layer in ("relu0", "output", "terr_relu2"):
+        b = batch(da, arg, 2, terrain_seed=3, rand_seed=2)
+        b.SetPolicy(w, io, isc, oo, osc)
+        rec = PoliEvalRecorder(b, [0, 1], nn_activation_file=str(tmp_path / ("nn_%s_{env}.txt" % layer)), nn_activation_layer=layer, policy_net=net_file,
+                               action_id_state_file=str(tmp_path / ("ids_%s_{env}.txt" % layer)))
+        for _ in range(60):
+            b.Update(); rec.Poll()
+        for e in range(2):
+            lines = open(tmp_path / ("nn_%s_%d.txt" % (layer, e))).read().splitlines()
+            ids = open(tmp_path / ("ids_%s_%d.txt" % (layer, e))).read().splitlines()
+            assert len(lines) == len(ids) >= 3
+            for ln, st in zip(lines, ids):
+                f = ln.split(",\t"); g = st.split(",\t")
+                assert f[0] == g[0]                                                  # same action id on both recorders' lines
+                x = np.array([float(v) for v in g[1:]])                             # the recorded policy state ("%f": 6 decimals)
+                y = rnet.forward(w.astype(np.float64), ((x + io) * isc)[None, :], keep=True)
+                P, xx, tape, f_in, z3, c_in, z4, h, heads = rnet._tape
+                want = {"relu0": h[0], "output": y[0], "terr_relu2": f_in[0]}[layer]
+                got = np.array([float(v) for v in f[1:]])
+                assert got.shape == want.shape
+                assert np.abs(got - want).max() < 2e-4 * max(1.0, np.abs(want).max())   # both sides print 6 decimals; the state feeds through the net
+
+
 def test_poli_eval_recorders_across_resets(da, om, tmp_path):
     """Falls and resets: the cycle counter survives them (mCycleCount is only cleared by Init/Clear), the velocity span restarts at the reset."""
     from deepterrainrl_amd.recorders import PoliEvalRecorder
