@@ -118,9 +118,11 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
             g = sr.gather_tuples_end(dst=0)              # all-gather of frame k - 1's tuples: started a whole frame ago
             if rank == 0:
                 rows = g[0]; m = int(rows.shape[0])
-                if m:
-                    idx = (torch.arange(m, device=dev) + cursor) % replay_cap
-                    replay[idx] = rows
+                if m:                                    # append to the device replay ring: one copy, two when the ring wraps
+                    first = min(m, replay_cap - cursor)
+                    replay[cursor:cursor + first].copy_(rows[:first])
+                    if first < m:
+                        replay[:m - first].copy_(rows[first:])
                     cursor = (cursor + m) % replay_cap; tuples += m
         if bcast_every > 0 and (k + 1) % bcast_every == 0:
             if rank == 0:

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_cycle_info", "dtrl_get_action_table", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
     "dtrl_terrain_build", "dtrl_terrain_load_file", "dtrl_args_parse_string",
-    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window",
+    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed",
 ]
 
 
@@ -78,6 +78,7 @@ def _bind(path):
     L.dtrl_get_contacts.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_ctrl.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
     L.dtrl_sample_ground.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.dtrl_drain_tuples_packed.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.dtrl_get_ground_window.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int64)]
     L.dtrl_eval_stats.argtypes = [vp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.dtrl_dims.argtypes = [vp] + [C.POINTER(C.c_int)] * 8
@@ -227,6 +228,13 @@ class BatchScenario:
         n = C.c_int()
         self._chk(self._lib.dtrl_drain_tuples_device(self._h, C.c_void_p(rows_ptr), C.c_void_p(flags_ptr) if flags_ptr else None, C.c_void_p(ids_ptr) if ids_ptr else None, int(cap), C.byref(n)))
         return n.value
+
+    def DrainTuplesPacked(self, block_ptr, block_rows, want_count=False):
+        """Pending tuples -> ONE device block [block_rows + 1, W + 2] float32 (header row, then rows sorted by env id with the flag word and the GLOBAL
+        env id as int32 bit patterns in the two extra columns); the ring is emptied. Returns the row count when want_count (a 4-byte read-back), else None."""
+        n = C.c_int(0)
+        self._chk(self._lib.dtrl_drain_tuples_packed(self._h, C.c_void_p(int(block_ptr)), int(block_rows), C.byref(n) if want_count else None))
+        return n.value if want_count else None
 
     def TupleStats(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64(); cap = C.c_int32()

@@ -9,6 +9,7 @@
 #include "dtrl_kernel_fast.h"
 #include "dtrl_terrain_dev.h"
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -78,6 +79,37 @@ __global__ void __launch_bounds__(1024) dtrl_order_by_cost(const EnvStatus* __re
 	__syncthreads();
 	for (int i = t; i < n; i += kOrderBuckets) { const int e = e0 + i; order[e0 + atomicAdd(&hist[key(e)], 1)] = e; }
 }
+// packed tuple drain (dtrl_drain_tuples_packed): rank of every pending row in (env id, ring position) order, scatter-copy into the block, header
+__device__ inline int pending_rows(const DevBuffers& buf, int block_rows) { int n = buf.tuple_count[0]; n = n < buf.tuple_cap ? n : buf.tuple_cap; return n < block_rows ? n : block_rows; }
+__global__ void dtrl_tuple_rank(DevBuffers buf, int block_rows, int32_t* __restrict__ rank)
+{
+	const int n = pending_rows(buf, block_rows);
+	const int k = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+	if (k >= n) return;
+	const int mine = buf.tuple_env[k];
+	int r = 0;
+	for (int j = 0; j < n; ++j) { const int e = buf.tuple_env[j]; r += (e < mine) || (e == mine && j < k); }   // every lane reads the same address: one broadcast load per step
+	rank[k] = r;
+}
+__global__ void dtrl_tuple_pack(DevBuffers buf, int block_rows, const int32_t* __restrict__ rank, float* __restrict__ block, int64_t env_id_base)
+{
+	const int n = pending_rows(buf, block_rows);
+	const int k = static_cast<int>(blockIdx.x);
+	if (k >= n) return;
+	const int W = buf.W;
+	float* dst = block + static_cast<size_t>(1 + rank[k]) * (W + 2);
+	const float* src = buf.tuple_rows + static_cast<size_t>(k) * W;
+	for (int i = static_cast<int>(threadIdx.x); i < W; i += static_cast<int>(blockDim.x)) dst[i] = src[i];
+	if (threadIdx.x == 0) { dst[W] = __int_as_float(static_cast<int>(buf.tuple_flags[k])); dst[W + 1] = __int_as_float(static_cast<int>(env_id_base + buf.tuple_env[k])); }
+}
+__global__ void dtrl_tuple_finish(DevBuffers buf, int block_rows, float* __restrict__ block)
+{
+	const int cnt = buf.tuple_count[0];
+	const int n = pending_rows(buf, block_rows);
+	const int t = static_cast<int>(threadIdx.x);
+	for (int i = t; i < buf.W + 2; i += static_cast<int>(blockDim.x)) block[i] = (i == 0) ? __int_as_float(n) : (i == 1) ? __int_as_float(cnt - n) : 0.0f;
+	if (t == 0) { buf.tuple_count[1] += n; buf.tuple_count[2] += cnt - n; buf.tuple_count[0] = 0; }
+}
 __global__ void dtrl_scatter_ground(GroundRec* __restrict__ gr, const GroundRec* __restrict__ staged, const int32_t* __restrict__ ids, int n)
 {
 	const int b = static_cast<int>(blockIdx.x);
@@ -133,6 +165,16 @@ public:
 		if (n <= 0) return true;
 		hipLaunchKernelGGL(dtrl_scatter_ground, dim3(n), dim3(256), 0, stream_, gr, staged, ids, n);
 		return Check(hipGetLastError(), "scatter launch");
+	}
+	bool PackTuples(const DevBuffers& buf, float* block, int block_rows, int64_t env_id_base, int32_t* rank) override
+	{
+		const int rows = std::min<int>(buf.tuple_cap, block_rows);
+		if (rows > 0) {
+			hipLaunchKernelGGL(dtrl_tuple_rank, dim3((rows + 255) / 256), dim3(256), 0, stream_, buf, block_rows, rank);
+			hipLaunchKernelGGL(dtrl_tuple_pack, dim3(rows), dim3(256), 0, stream_, buf, block_rows, rank, block, env_id_base);
+		}
+		hipLaunchKernelGGL(dtrl_tuple_finish, dim3(1), dim3(256), 0, stream_, buf, block_rows, block);
+		return Check(hipGetLastError(), "tuple pack launch") && Check(hipStreamSynchronize(stream_), "tuple pack");
 	}
 	bool TerrainBoundary(const DevBuffers& buf, int e0, int n, int mode, const int32_t* env_list) override
 	{

@@ -215,6 +215,10 @@ dtrl_status dtrl_sample_ground(dtrl_batch* b, int env, int n, const double* x, d
 try {
 	CHECK_B(); return static_cast<dtrl_status>(b->eng.SampleGround(env, n, x, h, seg, i, j));
 } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_drain_tuples_packed(dtrl_batch* b, float* block_dev, int block_rows, int* out_n)
+try {
+	CHECK_B(); return static_cast<dtrl_status>(b->eng.DrainTuplesPacked(block_dev, block_rows, out_n));
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_get_ground_window(dtrl_batch* b, int env, int32_t* w2, double* min_x2, double* max_x2, float* heights0, float* heights1, int cap, int64_t* num_builds)
 try {
 	CHECK_B(); return static_cast<dtrl_status>(b->eng.GroundWindowRec(env, w2, min_x2, max_x2, heights0, heights1, cap, num_builds));

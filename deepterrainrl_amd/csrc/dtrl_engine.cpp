@@ -162,7 +162,8 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	buf_.tuple_rows = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(W_) * buf_.tuple_cap));
 	buf_.tuple_flags = static_cast<uint32_t*>(alloc(sizeof(uint32_t) * buf_.tuple_cap));
 	buf_.tuple_env = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
-	buf_.tuple_count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));
+	buf_.tuple_count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));   // [0] ring cursor, [1] / [2] rows drained / dropped by packed drains since the last fold
+	d_tuple_rank_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
 	d_env_list_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
 	d_order_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
 	if (cfg_.device_terrain) {
@@ -697,10 +698,32 @@ int Engine::DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap,
 	*out_n = n;
 	return DTRL_OK;
 }
+// totals of the device-side (packed) drains -> host counters
+int Engine::FoldTupleTotals()
+{
+	int32_t c[4] = {0, 0, 0, 0};
+	be_->Sync();
+	if (!be_->D2H(c, buf_.tuple_count, sizeof(c))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (c[1] || c[2]) {
+		tuples_drained_ += c[1]; tuples_dropped_ += c[2];
+		const int32_t zero[2] = {0, 0};
+		if (!be_->H2D(buf_.tuple_count + 1, zero, sizeof(zero))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	}
+	return DTRL_OK;
+}
+int Engine::DrainTuplesPacked(float* block_dev, int block_rows, int* out_n)
+{
+	if (!block_dev || block_rows < 0) return Fail(DTRL_ERR_ARG, "bad arguments");
+	if (!be_->Sync()) return Fail(DTRL_ERR_DEVICE, be_->error());   // the frame kernels of every group have finished writing the ring
+	if (!be_->PackTuples(buf_, block_dev, block_rows, cfg_.run.env_id_base, d_tuple_rank_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (out_n) { int32_t n = 0; if (!be_->D2H(&n, block_dev, sizeof(n))) return Fail(DTRL_ERR_DEVICE, be_->error()); *out_n = n; }
+	return DTRL_OK;
+}
 int Engine::TupleStats(int64_t* pending, int64_t* drained, int64_t* dropped, int32_t* capacity)
 {
 	int32_t cnt = 0, over = 0;
-	int rc = PendingTuples(&cnt, &over);
+	int rc = FoldTupleTotals();
+	if (rc == DTRL_OK) rc = PendingTuples(&cnt, &over);
 	if (rc != DTRL_OK) return rc;
 	if (pending) *pending = cnt;
 	if (drained) *drained = tuples_drained_;

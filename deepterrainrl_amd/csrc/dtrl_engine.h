@@ -32,6 +32,9 @@ public:
 	virtual bool TerrainBoundary(const DevBuffers& buf, int e0, int n, int mode, const int32_t* env_list) = 0;
 	// order[e0 .. e0 + n) = the envs e0 .. e0 + n - 1 sorted by status[].cost, costliest first (launch order of the group's next frame), on the selected stream
 	virtual bool OrderByCost(const EnvStatus* status, int e0, int n, int32_t* order) = 0;
+	// pending tuples -> block [block_rows + 1][W + 2] (header row + rows sorted by env id, flag word and global env id as the two extra columns), ring
+	// emptied, drained / dropped totals accumulated in tuple_count[1], [2]; device pointers; queued on the selected stream and synchronised
+	virtual bool PackTuples(const DevBuffers& buf, float* block, int block_rows, int64_t env_id_base, int32_t* rank_scratch) = 0;
 	virtual bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) = 0;
 	virtual bool Sync() = 0;                 // all streams
 	// work queues: H2D / H2DAsync / D2H / Launch act on the selected stream (0 by default); D2H and H2D synchronise only that stream
@@ -73,6 +76,7 @@ public:
 	int ApplyRandForce(const int32_t* env_ids, int n, uint64_t seed);
 	int GetPoliState(const int32_t* env_ids, int n, double* s);
 	int GroundWindowRec(int env, int32_t* w2, double* min_x2, double* max_x2, float* h0, float* h1, int cap, int64_t* num_builds);
+	int DrainTuplesPacked(float* block_dev, int block_rows, int* out_n);
 	int SampleGround(int env, int n, const double* x, double* h, int32_t* seg, int32_t* oi, int32_t* oj);
 	int EvalStats(double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets);
 	int KernelTime(double* avg_ms, int64_t* launches);
@@ -88,6 +92,7 @@ public:
 private:
 	int Fail(int code, const std::string& msg) { err_ = msg; return code; }
 	int HostFrameWork(int group);
+	int FoldTupleTotals();
 	int DeviceFrameWork(int group);   // -terrain_gen= device: the same frame-boundary work queued as device kernels, no host sync
 	int DrainDeviceDistLog();
 	int UploadTerrainCfg(const double* params);
@@ -115,6 +120,7 @@ private:
 	EnvStatus* status_ = nullptr;   // page-locked: the per-frame read-back lands here without a staging copy
 	GroundRec tmp_rec_;
 	TerrainCfg* d_tcfg_ = nullptr;
+	int32_t* d_tuple_rank_ = nullptr;
 	static constexpr int kDistRingCap = 1 << 20;
 	std::vector<double> in_off_, in_scale_, out_off_, out_scale_;   // host copies of the policy normalisers (identity until set)
 	int UploadNormalizers();

@@ -8,9 +8,9 @@ performs between env threads and the trainer:
 Both are latency-bound on xGMI (<= ~10 MB/s of tuples at 1 M env-steps/s; 2.3 MB of weights per push), so each is ONE collective on ONE
 preallocated device buffer, issued on a side stream so that it overlaps the next frame kernel:
 
-  (a) gather_tuples_begin(): dtrl_drain_tuples_device copies the frame's rows device-to-device into this rank's slot of a fixed-capacity
-      block [cap + 1, W + 2] float32 (row 0 = header carrying the count; the two extra columns carry the flag word and the GLOBAL env id
-      as raw int32 bits), sorts the rows by env id on the device (so the gathered stream does not depend on how envs are sharded) and
+  (a) gather_tuples_begin(): dtrl_drain_tuples_packed moves the frame's rows inside the engine (rank / scatter-copy / header kernels) into this
+      rank's fixed-capacity block [cap + 1, W + 2] float32 (row 0 = header carrying the count; the two extra columns carry the flag word and the
+      GLOBAL env id as raw int32 bits), sorted by env id (so the gathered stream does not depend on how envs are sharded), and
       starts one all_gather of the block (RCCL: ncclAllGather over xGMI) on the comm stream. gather_tuples_end() waits and hands the
       trainer rank the concatenated DEVICE tensors (rows, flags, ids) -- nothing visits the host. gather_tuples() = begin + end.
   (b) broadcast_policy(): weights (float32) and the four normaliser vectors (float64) travel as ONE byte buffer (one ncclBroadcast), and
@@ -58,9 +58,6 @@ class ShardedRollout:
         W = b.W
         # this rank's block: header row + cap tuple rows, W floats + [flags, global env id] as int32 bit patterns
         self.block = torch.zeros((self.cap + 1, W + 2), dtype=torch.float32, device=self.device)
-        self.stage_rows = torch.zeros((self.cap, W), dtype=torch.float32, device=self.device)
-        self.stage_flags = torch.zeros(self.cap, dtype=torch.int32, device=self.device)
-        self.stage_ids = torch.zeros(self.cap, dtype=torch.int32, device=self.device)
         self.gathered = [torch.zeros_like(self.block) for _ in range(self.world)] if self.world > 1 else None
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self._pending = None
@@ -86,42 +83,27 @@ class ShardedRollout:
         """Drain this rank's finished tuples into its block and start the all-gather (asynchronous on the GPU). Call between UpdateEnd() of
         frame f and UpdateBegin() of frame f + 1; the collective then overlaps frame f + 1's kernel. Collect it with gather_tuples_end() in the
         NEXT gap (after UpdateEnd() of frame f + 1): a frame kernel fills every CU, so small kernels and host syncs issued while it runs stall
-        until it ends (bench.py's exchange leg: UpdateEnd -> gather_tuples_end (previous frame) -> consume -> gather_tuples_begin -> UpdateBegin)."""
+        until it ends (bench.py's exchange leg: UpdateEnd -> gather_tuples_end (previous frame) -> consume -> gather_tuples_begin -> UpdateBegin).
+        The packing (sort by env id so that the gathered stream does not depend on how envs are sharded, flag word and GLOBAL env id appended to every
+        row, header row with the count) is three small kernels inside the engine (dtrl_drain_tuples_packed): no framework op touches the rows."""
         torch = self.torch
         assert self._pending is None, "gather_tuples_begin called twice without gather_tuples_end"
-        b = self.batch
-        if self.on_gpu:
-            torch.cuda.current_stream(self.device).synchronize()     # the staging tensors are free (previous packing kernels done)
-        n = b.DrainTuplesDevice(self.stage_rows.data_ptr(), self.stage_flags.data_ptr(), self.stage_ids.data_ptr(), self.cap)
-        W = b.W
-        blk = self.block
-        hdr = blk[0].view(torch.int32)
-        hdr.zero_()
-        hdr[0] = n
-        if n > 0:
-            ids = self.stage_ids[:n]
-            order = torch.argsort(ids, stable=True)                  # ring order = completion order; sort by env id: shard-invariant stream
-            blk[1:n + 1, :W] = self.stage_rows[:n][order]
-            meta = blk[1:n + 1, W:].view(torch.int32)
-            meta[:, 0] = self.stage_flags[:n][order]
-            meta[:, 1] = ids[order] + int(self.offset)
+        self.batch.DrainTuplesPacked(self.block.data_ptr(), self.cap)        # synchronised: the block is complete when this returns
         work = None
         if self.world > 1:
             if self.on_gpu:
-                self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self.comm_stream):
-                    work = self.dist.all_gather(self.gathered, blk, async_op=True)
+                    work = self.dist.all_gather(self.gathered, self.block, async_op=True)
             else:
-                work = self.dist.all_gather(self.gathered, blk, async_op=True)
-        self._pending = (work, n)
-        return n
+                work = self.dist.all_gather(self.gathered, self.block, async_op=True)
+        self._pending = (work,)
 
     def gather_tuples_end(self, dst=0):
         """Wait for the all-gather. Returns (rows [n, W] float32, flags [n] int32, global env ids [n] int32) as tensors on self.device on rank
         `dst`, None elsewhere."""
         import time
         torch = self.torch
-        work, n = self._pending
+        work, = self._pending
         self._pending = None
         W = self.batch.W
         t0 = time.perf_counter()
@@ -133,7 +115,12 @@ class ShardedRollout:
         if self.rank != dst:
             return None
         blocks = self.gathered if self.world > 1 else [self.block]
-        counts = [int(x) for x in torch.stack([g[0].view(torch.int32)[0] for g in blocks]).tolist()]
+        if self.world == 1:
+            c = int(self.block[0, :1].view(torch.int32).item())       # one 4-byte read-back; the rows below are views into the block (valid until the next begin)
+            blk = self.block[1:c + 1]
+            meta = blk[:, W:].view(torch.int32)
+            return blk[:, :W], meta[:, 0], meta[:, 1]
+        counts = [int(x) for x in torch.stack([g[0, :1].view(torch.int32)[0] for g in blocks]).tolist()]
         rows = torch.cat([g[1:c + 1, :W] for g, c in zip(blocks, counts)])
         meta = torch.cat([g[1:c + 1, W:].view(torch.int32) for g, c in zip(blocks, counts)])
         return rows, meta[:, 0].contiguous(), meta[:, 1].contiguous()

@@ -115,6 +115,13 @@ dtrl_status dtrl_drain_tuples(dtrl_batch* b, float* rows, uint32_t* flags, int32
  * gather): device-to-device copies on the batch's stream, completed on return; no host staging. The reference hands tuples to the trainer by
  * reference under its lock (learning/NeuralNetLearner.cpp:33-46). flags_dev / env_ids_dev may be NULL. */
 dtrl_status dtrl_drain_tuples_device(dtrl_batch* b, float* rows_dev, uint32_t* flags_dev, int32_t* env_ids_dev, int cap, int* out_n);
+/* Replaces: the same three calls as dtrl_drain_tuples_device, plus the per-rank packing the reference's learner thread does before it hands tuples to
+ * the trainer (learning/NeuralNetLearner.cpp:33-46) -- for a consumer that wants ONE device block it can put on the wire as it is (one RCCL
+ * all-gather per frame). block_dev: [block_rows + 1][W + 2] float32 in DEVICE memory. Row 0 is a header (int32 bit patterns: [0] = number of rows that
+ * follow, [1] = rows that did not fit block_rows and were dropped -- counted in dtrl_tuple_stats); rows 1..n are the pending tuples sorted by env id
+ * (stable: an env's tuples stay in time order), each [r | s | a | s' | flag word | GLOBAL env id], the last two as int32 bit patterns. The ring is
+ * emptied. Everything runs on the device (rank, scatter-copy and header kernels); out_n, when not NULL, costs one 4-byte read-back. */
+dtrl_status dtrl_drain_tuples_packed(dtrl_batch* b, float* block_dev, int block_rows, int* out_n);
 /* The reference never drops a tuple (scenarios/ScenarioTrain.cpp:376-410 trains whenever a scene's buffer is full). Here the ring holds
  * max(2 num_envs, -tuple_buffer_size=) rows (-tuple_ring_capacity= overrides); rows completed while it is full are COUNTED, not stored:
  * pending = rows waiting in the ring, drained = rows handed out so far, dropped = rows lost to a full ring since creation (stays 0 when

@@ -37,6 +37,24 @@ public:
 		std::stable_sort(order + e0, order + e0 + n, [&](int a, int b) { return (status[a].cost >> 4) > (status[b].cost >> 4); });
 		return true;
 	}
+	bool PackTuples(const DevBuffers& buf, float* block, int block_rows, int64_t env_id_base, int32_t* rank) override
+	{
+		const int cnt = buf.tuple_count[0];
+		const int n = std::min(std::min(cnt, static_cast<int>(buf.tuple_cap)), block_rows);
+		const int stride = buf.W + 2;
+		for (int k = 0; k < n; ++k) { int r = 0; for (int j = 0; j < n; ++j) r += (buf.tuple_env[j] < buf.tuple_env[k]) || (buf.tuple_env[j] == buf.tuple_env[k] && j < k); rank[k] = r; }
+		for (int k = 0; k < n; ++k) {
+			float* dst = block + static_cast<size_t>(1 + rank[k]) * stride;
+			std::memcpy(dst, buf.tuple_rows + static_cast<size_t>(k) * buf.W, sizeof(float) * buf.W);
+			const int32_t fl = static_cast<int32_t>(buf.tuple_flags[k]), id = static_cast<int32_t>(env_id_base + buf.tuple_env[k]);
+			std::memcpy(dst + buf.W, &fl, 4); std::memcpy(dst + buf.W + 1, &id, 4);
+		}
+		std::memset(block, 0, sizeof(float) * stride);
+		const int32_t hdr[2] = {n, cnt - n};
+		std::memcpy(block, hdr, sizeof(hdr));
+		buf.tuple_count[1] += n; buf.tuple_count[2] += cnt - n; buf.tuple_count[0] = 0;
+		return true;
+	}
 	bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) override
 	{
 		int nt = std::min<int>(n_envs, std::max(1u, std::thread::hardware_concurrency()));

@@ -217,6 +217,54 @@ def test_device_destination_drain_and_policy_hand_over_equal_the_host_calls(da, 
     assert np.array_equal(a.PoseVel()[0], b.PoseVel()[0])
 
 
+def run_packed_drain_equals_plain_drain(scn, om, to_ptr=None, read=None):
+    """dtrl_drain_tuples_packed: the rows of dtrl_drain_tuples sorted by env id (stable), flag word and GLOBAL env id appended, a header row with the
+    count; rows that do not fit the caller's block are dropped AND counted."""
+    pol = dog_policy(om)
+    args = dict(terrain_seed=31, rand_seed=2, global_env_offset=100)
+    a = scn("args/opt_args_train_mace.txt", 10, data_root=REFDATA, extra_args=args)
+    b = scn("args/opt_args_train_mace.txt", 10, data_root=REFDATA, extra_args=args)
+    c = scn("args/opt_args_train_mace.txt", 10, data_root=REFDATA, extra_args=args)
+    for x in (a, b, c):
+        x.SetPolicy(pol[1], *pol[2:])
+    W = a.W
+    cap = 32
+    if to_ptr is None:
+        blk = np.zeros((cap + 1, W + 2), np.float32); blk_c = np.zeros((2 + 1, W + 2), np.float32)
+        to_ptr = lambda t: t.ctypes.data; read = lambda t: t
+    else:
+        import torch
+        blk = torch.zeros((cap + 1, W + 2), dtype=torch.float32, device="cuda"); blk_c = torch.zeros((2 + 1, W + 2), dtype=torch.float32, device="cuda")
+    n_tot = n_multi = dropped = 0
+    for f in range(120):
+        for x in (a, b, c):
+            x.Update()
+        if f % 3 != 2:
+            continue                                                   # drain every third frame: several tuples per drain, some envs twice over time
+        ra, fa, ia = a.DrainTuples()
+        n = b.DrainTuplesPacked(to_ptr(blk), cap, want_count=True)
+        h = read(blk)
+        assert n == len(ra) and h[0, :2].view(np.int32).tolist() == [n, 0]
+        order = np.argsort(ia, kind="stable")
+        assert np.array_equal(h[1:n + 1, :W], ra[order])
+        meta = h[1:n + 1, W:].view(np.int32)
+        assert np.array_equal(meta[:, 0], fa[order].astype(np.int32)) and np.array_equal(meta[:, 1], ia[order] + 100)
+        n_tot += n; n_multi += n >= 2
+        # a block with room for two rows only: the rest is dropped, and counted
+        m = c.DrainTuplesPacked(to_ptr(blk_c), 2, want_count=True)
+        hc = read(blk_c)
+        assert m == min(n, 2) and hc[0, :2].view(np.int32).tolist() == [m, n - m]
+        dropped += n - m
+    assert n_tot >= 12 and n_multi >= 3
+    sb, sc = b.TupleStats(), c.TupleStats()
+    assert sb["drained"] == n_tot and sb["dropped"] == 0 and sb["pending"] == 0
+    assert sc["drained"] == n_tot - dropped and sc["dropped"] == dropped > 0
+
+
+def test_packed_drain_equals_plain_drain(da, om):
+    run_packed_drain_equals_plain_drain(Scenario, om)
+
+
 def test_env_id_lists_are_validated(da):
     """dtrl_reset with more ids than envs / duplicates / negative counts must not overrun the engine's buffers."""
     b = Scenario("args/sim_dog_args.txt", 3, data_root=REFDATA, extra_args={"terrain_seed": 4})

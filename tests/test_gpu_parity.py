@@ -472,3 +472,9 @@ def test_device_terrain_user_reset_and_curriculum(om):
 
 def test_nn_activation_recorder(da, om, tmp_path):
     T.test_nn_activation_recorder_vs_numpy_net_and_oracle_forward(da, om, tmp_path)
+
+
+def test_packed_drain_equals_plain_drain(om):
+    import test_boundary as B
+    import deepterrainrl_amd as da_mod
+    B.run_packed_drain_equals_plain_drain(da_mod.BatchScenario, om, to_ptr=lambda t: t.data_ptr(), read=lambda t: t.cpu().numpy())
