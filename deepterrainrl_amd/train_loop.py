@@ -12,7 +12,7 @@ import time
 import numpy as np
 
 from . import BatchScenario
-from .trainer import MACETrainer, anneal
+from .trainer import MACETrainer, QNetTrainer, anneal
 
 
 def parse_arg_file(path):
@@ -46,7 +46,10 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     solver = os.path.join(data_root, args["policy_solver"])
     train_net = os.path.join(data_root, re.search(r'net:\s*"([^"]+)"', open(solver).read()).group(1)) if re.search(r'net:\s*"', open(solver).read()) \
         else os.path.join(data_root, args["policy_net"].replace("_deploy", "_train"))
-    t = MACETrainer(train_net, solver, b.S, b.A, mem_size=geti("trainer_replay_mem_size", 500000), num_init_samples=geti("trainer_num_init_samples", 200),
+    # -char_ctrl= dog / raptor are the Q controllers (scenarios/ScenarioSimChar.cpp:421-430): -scenario= train pairs them with cQNetTrainer
+    # (scenarios/ScenarioTrain.cpp BuildTrainer), the *_mace controllers with cMACETrainer
+    trainer_cls = QNetTrainer if args.get("char_ctrl", "") in ("dog", "raptor") else MACETrainer
+    t = trainer_cls(train_net, solver, b.S, b.A, mem_size=geti("trainer_replay_mem_size", 500000), num_init_samples=geti("trainer_num_init_samples", 200),
                     steps_per_iter=geti("trainer_num_steps_per_iters", 1), freeze_target_iters=geti("trainer_freeze_target_iters", 0),
                     init_input_offset_scale=args.get("trainer_init_input_offset_scale", "false").lower() == "true", seed=seed, device=trainer_device)
     t.SetOutputOffsetScale(*b.BuildNNOutputOffsetScale())

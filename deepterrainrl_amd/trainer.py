@@ -56,8 +56,12 @@ def parse_net(path):
     d["n_terrain"] = [l for l in layers if l["type"] == "Slice"][0]["slice_point"]
     d["convs"] = [l for l in layers if l["type"] == "Convolution"]
     d["ips"] = {l["name"]: l for l in layers if l["type"] == "InnerProduct"}
-    d["n_frags"] = d["ips"]["val_ip1"]["num_output"]
-    d["frag_size"] = d["ips"]["a0_ip1"]["num_output"]
+    if "val_ip1" in d["ips"]:                                  # MACE family: value head + n_frags actor heads
+        d["n_frags"] = d["ips"]["val_ip1"]["num_output"]
+        d["frag_size"] = d["ips"]["a0_ip1"]["num_output"]
+    else:                                                      # single-head family (Q net, CACLA actor): terr_ip0 -> ip1 -> ip2 -> output
+        d["n_frags"] = 0
+        d["frag_size"] = d["ips"]["output"]["num_output"]
     return d
 
 
@@ -186,6 +190,45 @@ class MaceNet(torch.nn.Module):
         return sum(b.numel() for b in self.blobs())
 
 
+class QNet(MaceNet):
+    """The single-head nets (data/policies/dog/nets/dog_q_*.prototxt; same layers as the CACLA actor): 3 conv1d over the terrain slice -> terr_ip0 ->
+    concat with the character slice -> ip1 -> ip2 -> output (one value per base action). Blob order conv0..2, terr_ip0, ip1, ip2, output."""
+
+    def __init__(self, desc):
+        torch.nn.Module.__init__(self)
+        self.n_terrain = desc["n_terrain"]
+        n_char = desc["in_size"] - self.n_terrain
+        mods, mults = [], []
+        cin, w = 1, self.n_terrain
+        for l in desc["convs"]:
+            mods.append(torch.nn.Conv1d(cin, l["num_output"], l["kernel_w"])); mults.append(l["mults"])
+            cin, w = l["num_output"], w - l["kernel_w"] + 1
+        ips = desc["ips"]
+        n = cin * w
+        for name, extra in (("terr_ip0", 0), ("ip1", n_char), ("ip2", 0), ("output", 0)):
+            mods.append(torch.nn.Linear(n + extra, ips[name]["num_output"])); mults.append(ips[name]["mults"])
+            n = ips[name]["num_output"]
+        self.n_frags = 0
+        self.mods = torch.nn.ModuleList(mods)
+        self.blob_mults = []
+        for m in mults:
+            m = list(m) + [(1.0, 1.0)] * (2 - len(m))
+            self.blob_mults += [m[0], m[1]]
+        self.flat = self.gflat = None
+
+    def forward(self, x):
+        relu = torch.nn.functional.relu
+        t = x[:, :self.n_terrain].unsqueeze(1)
+        for m in self.mods[:3]:
+            t = relu(m(t))
+        t = relu(self.mods[3](t.flatten(1)))
+        h = relu(self.mods[4](torch.cat([t, x[:, self.n_terrain:]], 1)))
+        return self.mods[6](relu(self.mods[5](h)))
+
+    def named_blobs(self, x):
+        raise NotImplementedError("blob names of the single-head nets are not mapped")
+
+
 class MACETrainer:
     """cMACETrainer (pool size 1, synchronous mode)."""
 
@@ -197,14 +240,13 @@ class MACETrainer:
         self.dtype = dtype
         self.S, self.A = state_size, action_size
         self.num_frags, self.frag_size = self.desc["n_frags"], self.desc["frag_size"]
-        assert action_size == 1 + self.frag_size and self.desc["in_size"] == state_size
-        self.out_size = self.num_frags * (1 + self.frag_size)
+        self._configure_sizes()
         self.batch = self.desc["batch_size"]
         self.W = 1 + 2 * state_size + action_size                      # cMACETrainer::CalcBufferSize
         self.mem_size, self.num_init_samples, self.steps_per_iter = mem_size, num_init_samples, steps_per_iter
         self.freeze_target_iters, self.discount, self.init_input_offset_scale = freeze_target_iters, discount, init_input_offset_scale
-        self.net = MaceNet(self.desc).init_fillers(seed).to(self.device, dtype).flatten_storage()
-        self.target = MaceNet(self.desc).to(self.device, dtype).flatten_storage()
+        self.net = self._new_net().init_fillers(seed).to(self.device, dtype).flatten_storage()
+        self.target = self._new_net().to(self.device, dtype).flatten_storage()
         for p_ in self.target.parameters():
             p_.requires_grad_(False)
         self.hflat = torch.zeros_like(self.net.flat)
@@ -229,6 +271,13 @@ class MACETrainer:
         # HIP graphs (static input / output buffers) and replayed; any capture problem falls back to eager execution
         self.use_graphs = (self.device.type == "cuda") if use_graphs is None else bool(use_graphs)
         self._g_eval, self._g_step = {}, None
+
+    def _configure_sizes(self):
+        assert self.A == 1 + self.frag_size and self.desc["in_size"] == self.S
+        self.out_size = self.num_frags * (1 + self.frag_size)
+
+    def _new_net(self):
+        return MaceNet(self.desc)
 
     # ---- cNeuralNetTrainer::ResetParams / cMACETrainer::Reset
     def Reset(self):
@@ -532,6 +581,59 @@ class MACETrainer:
         loss = self._solver_step_body(X, Y)
         self.solver_iter += 1
         return loss
+
+
+class QNetTrainer(MACETrainer):
+    """cQNetTrainer (learning/QNetTrainer.cpp; pool size 1, synchronous mode) for the Q head (-char_ctrl= dog / raptor, args/opt_args_train_q.txt): replay
+    rows [r | s | one-hot a | s'] exactly as the rollout engine emits them, uniform minibatches over the whole replay memory
+    (cNeuralNetTrainer::FetchMinibatch, learning/NeuralNetTrainer.cpp:508-524), targets y[a] = r (1 - discount) on failure, else
+    r (1 - discount) + discount * Q_ref(s')[argmax_a' Q(s')] with the reference net = the net itself for a pool of one (GetRandRefID, :183-192;
+    FREEZE_TARGET_NET is compiled out in the reference), Caffe SGD as in MACETrainer. Everything stays on the device."""
+
+    def _configure_sizes(self):
+        assert self.num_frags == 0 and self.A == self.frag_size and self.desc["in_size"] == self.S, "the Q net has one output per base action"
+        self.out_size = self.frag_size
+
+    def _new_net(self):
+        return QNet(self.desc)
+
+    def _update_buffers(self, t):
+        pass                                                            # no critic / actor index buffers: every stored tuple is a candidate
+
+    def EnableTargetNet(self):
+        return False
+
+    def FetchMinibatch(self, size):
+        n = self.num_tuples
+        return [int(self.rng.randint(0, n)) for _ in range(size)] if n > 0 else []
+
+    def _q_problem(self, ids):
+        idx = self._idx(ids)
+        rows = self.mem[idx]
+        X = rows[:, 1:1 + self.S]
+        Y = self._eval(self.net, X)
+        y_next = self._eval(self.net, rows[:, 1 + self.S + self.A:])     # curr_net and ref_net coincide for a pool of one
+        a_next = y_next.argmax(1, keepdim=True)
+        q_end = y_next.gather(1, a_next)[:, 0]
+        r = rows[:, 0].to(self.dtype) * (1.0 - self.discount)
+        fail = (self.flags_dev[idx] & FLAG_FAIL) != 0
+        new_q = torch.where(fail, r, r + self.discount * q_end)
+        a = rows[:, 1 + self.S:1 + self.S + self.A].argmax(1, keepdim=True)      # tuple.mAction.maxCoeff(&action_idx): the first maximum of the one-hot
+        Y.scatter_(1, a, new_q[:, None].to(Y.dtype))
+        return X, Y
+
+    def Step(self):
+        ids = self.FetchMinibatch(self.batch)
+        if len(ids) >= self.batch:
+            X, Y = self._q_problem(ids)
+            self._last_loss = self._solver_step(X, Y)
+        return True                                                     # cQNetTrainer::Step returns true unconditionally (learning/QNetTrainer.cpp:142-163)
+
+    def UpdateActor(self):
+        pass
+
+    def OutputModel(self, model_file):
+        raise NotImplementedError("HDF5 layer names of the Q net are not mapped; use GetWeights() / BatchScenario.WriteOffsetScale")
 
 
 def anneal(it, n_iters, v0, v1):

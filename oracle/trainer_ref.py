@@ -271,3 +271,128 @@ class RefMaceTrainer:
         if self.freeze > 0 and self.iter > 0 and self.iter % self.freeze == 0:
             self.w_target = self.w.copy()
         return succ
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The Q head's trainer (learning/QNetTrainer.cpp) in numpy fp64.
+# ---------------------------------------------------------------------------------------------------------------------------------
+class RefQNet:
+    """Single-head net of data/policies/dog/nets/dog_q_*.prototxt: the MACE trunk (3 valid conv1d -> terr_ip0 -> concat) -> ip1 -> ip2 -> output,
+    ReLU after every layer but the output. Blob order conv0..2, terr_ip0, ip1, ip2, output; weight then bias."""
+
+    def __init__(self, n_terrain, n_char, convs, fc_terr, fc1, fc2, n_out):
+        self.n_terrain, self.n_char = n_terrain, n_char
+        self.shapes = []
+        cin, w = 1, n_terrain
+        for cout, k in convs:
+            self.shapes += [(cout, cin, k), (cout,)]; cin, w = cout, w - k + 1
+        self.conv_out = (cin, w)
+        for nout, nin in [(fc_terr, cin * w), (fc1, fc_terr + n_char), (fc2, fc1), (n_out, fc2)]:
+            self.shapes += [(nout, nin), (nout,)]
+        self.sizes = [int(np.prod(s)) for s in self.shapes]
+        self.num_params = sum(self.sizes)
+
+    split = RefMaceNet.split
+    _im2col = staticmethod(RefMaceNet._im2col)
+
+    def forward(self, flat, x, keep=False):
+        P = self.split(flat)
+        B = x.shape[0]
+        t = x[:, :self.n_terrain].reshape(B, 1, self.n_terrain)
+        tape = []
+        for l in range(3):
+            Wc, bc = P[2 * l], P[2 * l + 1]
+            cols = self._im2col(t, Wc.shape[2])
+            z = cols @ Wc.reshape(Wc.shape[0], -1).T + bc
+            tape.append((cols, z, t.shape))
+            t = np.maximum(z, 0).transpose(0, 2, 1)
+        acts = [t.reshape(B, -1)]; zs = []
+        for i, b0 in enumerate((6, 8, 10, 12)):
+            a_in = acts[-1] if i != 1 else np.concatenate([acts[-1], x[:, self.n_terrain:]], 1)
+            if i == 1: acts[-1] = a_in
+            z = a_in @ P[b0].T + P[b0 + 1]; zs.append(z)
+            acts.append(np.maximum(z, 0) if i < 3 else z)
+        if keep:
+            self._tape = (P, tape, acts, zs)
+        return acts[-1]
+
+    def backward(self, dy):
+        P, tape, acts, zs = self._tape
+        G = [None] * len(P)
+        B = dy.shape[0]
+        d = dy
+        for i, b0 in reversed(list(enumerate((6, 8, 10, 12)))):
+            if i < 3: d = d * (zs[i] > 0)
+            G[b0] = d.T @ acts[i]; G[b0 + 1] = d.sum(0)
+            d = d @ P[b0]
+            if i == 1: d = d[:, :zs[0].shape[1]]
+        dt = d.reshape(B, *self.conv_out)
+        for l in (2, 1, 0):
+            cols, z, in_shape = tape[l]
+            Wc = P[2 * l]
+            dz = dt.transpose(0, 2, 1) * (z > 0)
+            G[2 * l] = np.einsum("bwo,bwc->oc", dz, cols).reshape(Wc.shape); G[2 * l + 1] = dz.sum((0, 1))
+            if l > 0:
+                dcols = (dz @ Wc.reshape(Wc.shape[0], -1)).reshape(B, dz.shape[1], in_shape[1], Wc.shape[2])
+                dt = np.zeros(in_shape)
+                for t in range(Wc.shape[2]):
+                    dt[:, :, t:t + dz.shape[1]] += dcols[:, :, :, t].transpose(0, 2, 1)
+        return np.concatenate([g.reshape(-1) for g in G])
+
+
+class RefQTrainer:
+    """cQNetTrainer with a pool of one (learning/QNetTrainer.cpp:27-83 BuildProblemY, :142-163 Step; cNeuralNetTrainer::AddTuple / FetchMinibatch /
+    Train, learning/NeuralNetTrainer.cpp:145-193, 508-524): ring of rows [r | s | one-hot a | s'], uniform minibatches over the stored tuples,
+    y[a] = r (1 - g) on failure else r (1 - g) + g Q(s')[argmax Q(s')] (reference net = the net itself), Caffe SGD."""
+
+    def __init__(self, net, blob_mults, S, A, mem_size, batch, discount, num_init_samples, solver, seed, init_input_offset_scale=True):
+        self.net, self.S, self.A, self.batch, self.discount = net, S, A, batch, discount
+        self.W = 1 + 2 * S + A
+        self.mem = np.zeros((mem_size, self.W), np.float32); self.flags = np.zeros(mem_size, np.int64)
+        self.mem_size, self.head, self.num = mem_size, 0, 0
+        self.num_init_samples, self.solver, self.init_os = num_init_samples, solver, init_input_offset_scale
+        self.lr_mult = np.concatenate([np.full(n, m[0]) for n, m in zip(net.sizes, blob_mults)])
+        self.decay_mult = np.concatenate([np.full(n, m[1]) for n, m in zip(net.sizes, blob_mults)])
+        self.w = np.zeros(net.num_params); self.hist = np.zeros(net.num_params)
+        self.in_off, self.in_scale, self.out_off, self.out_scale = np.zeros(S), np.ones(S), np.zeros(A), np.ones(A)
+        self.rng = np.random.RandomState(seed)
+        self.iter = 0; self.stage_train = False; self.last_loss = None
+
+    def add_tuples(self, rows, flags):
+        for r, f in zip(rows, flags):
+            r = np.asarray(r, np.float32)
+            if not np.all(np.isfinite(r)):
+                continue
+            self.mem[self.head] = r; self.flags[self.head] = int(f)
+            self.head = (self.head + 1) % self.mem_size; self.num = min(self.mem_size, self.num + 1)
+
+    def eval(self, X):
+        X = np.atleast_2d(np.asarray(X, np.float64))
+        return self.net.forward(self.w, (X + self.in_off) * self.in_scale) / self.out_scale - self.out_off
+
+    def train(self):
+        if not self.stage_train and self.num >= self.num_init_samples and self.num > 0:
+            if self.num_init_samples > 1 and self.init_os:
+                X = self.mem[:self.num, 1:1 + self.S].astype(np.float64)
+                mean = X.mean(0); std = np.sqrt(((X - mean) ** 2).mean(0))
+                self.in_off, self.in_scale = -mean, np.where(std == 0, 0.0, 1.0 / np.where(std == 0, 1.0, std))
+            self.stage_train = True
+        if not self.stage_train:
+            return
+        ids = [int(self.rng.randint(0, self.num)) for _ in range(self.batch)]
+        S, A, g = self.S, self.A, self.discount
+        X = self.mem[ids, 1:1 + S].astype(np.float64)
+        Y = self.eval(X).copy()
+        y_next = self.eval(self.mem[ids, 1 + S + A:].astype(np.float64))
+        for i, t in enumerate(ids):
+            r = float(self.mem[t, 0]) * (1.0 - g)
+            a = int(np.argmax(self.mem[t, 1 + S:1 + S + A]))
+            Y[i, a] = r if (self.flags[t] & 1) else r + g * y_next[i, int(np.argmax(y_next[i]))]
+        x = (X + self.in_off) * self.in_scale
+        label = (Y + self.out_off) * self.out_scale
+        out = self.net.forward(self.w, x, keep=True)
+        self.last_loss = 0.5 * ((out - label) ** 2).sum() / x.shape[0]
+        grad = self.net.backward((out - label) / x.shape[0])
+        s = self.solver
+        self.w, self.hist = caffe_sgd_step(self.w, grad, self.hist, s["base_lr"], s["momentum"], s["weight_decay"], self.lr_mult, self.decay_mult)
+        self.iter += 1
