@@ -12,7 +12,7 @@ import time
 import numpy as np
 
 from . import BatchScenario
-from .trainer import MACETrainer, QNetTrainer, anneal
+from .trainer import CaclaTrainer, MACETrainer, QNetTrainer, anneal
 
 
 def parse_arg_file(path):
@@ -48,10 +48,18 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
         else os.path.join(data_root, args["policy_net"].replace("_deploy", "_train"))
     # -char_ctrl= dog / raptor are the Q controllers (scenarios/ScenarioSimChar.cpp:421-430): -scenario= train pairs them with cQNetTrainer
     # (scenarios/ScenarioTrain.cpp BuildTrainer), the *_mace controllers with cMACETrainer
-    trainer_cls = QNetTrainer if args.get("char_ctrl", "") in ("dog", "raptor") else MACETrainer
-    t = trainer_cls(train_net, solver, b.S, b.A, mem_size=geti("trainer_replay_mem_size", 500000), num_init_samples=geti("trainer_num_init_samples", 200),
-                    steps_per_iter=geti("trainer_num_steps_per_iters", 1), freeze_target_iters=geti("trainer_freeze_target_iters", 0),
-                    init_input_offset_scale=args.get("trainer_init_input_offset_scale", "false").lower() == "true", seed=seed, device=trainer_device)
+    tkw = dict(mem_size=geti("trainer_replay_mem_size", 500000), num_init_samples=geti("trainer_num_init_samples", 200),
+               steps_per_iter=geti("trainer_num_steps_per_iters", 1), freeze_target_iters=geti("trainer_freeze_target_iters", 0),
+               init_input_offset_scale=args.get("trainer_init_input_offset_scale", "false").lower() == "true", seed=seed, device=trainer_device)
+    if args.get("char_ctrl", "").endswith("_cacla"):
+        # cScenarioTrainCacla::ParseArgs (scenarios/ScenarioTrainCacla.cpp:21-34): -policy_* name the ACTOR, -critic_* the critic the trainer steps first
+        c_solver = os.path.join(data_root, args["critic_solver"])
+        m = re.search(r'net:\s*"([^"]+)"', open(c_solver).read())
+        c_train = os.path.join(data_root, m.group(1)) if m else os.path.join(data_root, args["critic_net"].replace("_deploy", "_train"))
+        t = CaclaTrainer(c_train, c_solver, train_net, solver, b.S, b.A, **tkw)
+    else:
+        trainer_cls = QNetTrainer if args.get("char_ctrl", "") in ("dog", "raptor") else MACETrainer
+        t = trainer_cls(train_net, solver, b.S, b.A, **tkw)
     t.SetOutputOffsetScale(*b.BuildNNOutputOffsetScale())
     exp = dict(rate=getf("exp_rate", 0.2), temp=getf("exp_temp", 0.025), base=getf("exp_base_rate", 0.002))
     init = dict(rate=getf("init_exp_rate", 1.0), temp=getf("init_exp_temp", 20.0), base=getf("init_exp_base_rate", 1.0))

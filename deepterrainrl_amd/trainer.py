@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 FLAG_FAIL, FLAG_EXP_CRITIC, FLAG_EXP_ACTOR = 1, 2, 4   # tExpTuple flag bits as emitted by the rollout engine (include/dtrl.h)
+FLAG_OFF_POLICY = 2                                    # cCaclaTrainer::eFlagOffPolicy (the CACLA scenes use bit 1 for it)
 
 
 def _blocks(txt):
@@ -634,6 +635,114 @@ class QNetTrainer(MACETrainer):
 
     def OutputModel(self, model_file):
         raise NotImplementedError("HDF5 layer names of the Q net are not mapped; use GetWeights() / BatchScenario.WriteOffsetScale")
+
+
+class CaclaTrainer(QNetTrainer):
+    """cCaclaTrainer on top of cACTrainer (learning/CaclaTrainer.cpp, learning/ACTrainer.cpp; pool of one, synchronous, mode eModeCacla, reward mode
+    "start") for -char_ctrl= dog_cacla (args/opt_args_train_cacla.txt): a critic V(s) (dog_critic_*.prototxt, one output) and an actor
+    (dog_actor_*.prototxt, the optimisable action parameters), both single-head nets, one replay ring of rows [r | s | a | s'] with the flags
+    fail (1) / off-policy (2) as the rollout engine emits them.
+      critic step   uniform minibatch, target r (1 - g) on failure else r (1 - g) + g V_target(s')            (CaclaTrainer.cpp:149-157, 234-277)
+      actor step    candidates drawn from the OFF-POLICY tuples (exploration steps), kept when the critic's TD error
+                    new_v - V_target(s) is positive; per full actor batch one SGD step of the actor towards the explored
+                    actions themselves (CACLA)                                                            (:105-127, 342-387; ACTrainer.cpp:611-646, 271-284)
+      target net    refreshed every trainer_freeze_target_iters critic iterations when that is > 0, else the critic itself (:395-418)
+    GetWeights / GetOffsetScale / SetOutputOffsetScale speak for the ACTOR (what the rollout engine runs); the critic has its own accessors."""
+
+    def __init__(self, critic_net_file, critic_solver_file, actor_net_file, actor_solver_file, state_size, action_size, **kw):
+        actor_kw = dict(kw); actor_kw.update(mem_size=1, num_init_samples=1)
+        self._actor_args = (actor_net_file, actor_solver_file, state_size, action_size, actor_kw)
+        super().__init__(critic_net_file, critic_solver_file, state_size, action_size, **kw)
+        # cBaseControllerCacla::BuildCriticOutputOffsetScale (sim/BaseControllerCacla.cpp:197-202)
+        MACETrainer.SetOutputOffsetScale(self, np.full(1, -0.5), np.full(1, 2.0))
+
+    def _configure_sizes(self):
+        assert self.num_frags == 0 and self.frag_size == 1 and self.desc["in_size"] == self.S, "the critic has one output"
+        self.out_size = 1
+
+    def Reset(self):
+        super().Reset()
+        net_file, solver_file, S, A, kw = self._actor_args
+        self.actor = QNetTrainer(net_file, solver_file, S, A, **kw)          # the actor net with its own solver state, normalisers and captured graphs
+        self.actor_batch = self.actor.batch
+        self.off_policy_buffer, self.off_policy_pos = [], {}
+        self.actor_batch_buffer, self.actor_batch_td = [], []
+
+    # ---- the interface the training loop uses: the policy = the actor
+    def GetWeights(self): return self.actor.GetWeights()
+    def SetWeights(self, w): self.actor.SetWeights(w)
+    def GetOffsetScale(self): return self.actor.GetOffsetScale()
+    def SetOutputOffsetScale(self, off, scale): self.actor.SetOutputOffsetScale(off, scale)
+    def SetInputOffsetScale(self, off, scale):          # cACTrainer::SetInputOffsetScale: both nets
+        MACETrainer.SetInputOffsetScale(self, off, scale); self.actor.SetInputOffsetScale(off, scale)
+    def GetCriticWeights(self): return self.net.get_flat()
+    def SetCriticWeights(self, w):
+        self.net.set_flat(w); self.UpdateTargetNet()
+    def GetCriticOffsetScale(self): return MACETrainer.GetOffsetScale(self)
+    def EnableTargetNet(self): return self.freeze_target_iters > 0
+    @property
+    def last_actor_loss(self): return self.actor.last_loss
+
+    def _update_buffers(self, t):
+        if self.flags[t] & FLAG_OFF_POLICY:
+            self._buf_add(self.off_policy_buffer, self.off_policy_pos, t)
+        else:
+            self._buf_del(self.off_policy_buffer, self.off_policy_pos, t)
+        while t in self.actor_batch_buffer:              # a slot that is overwritten leaves the pending actor batch (move-last-into-hole, CaclaTrainer.cpp:445-460)
+            i = self.actor_batch_buffer.index(t)
+            last, last_td = self.actor_batch_buffer.pop(), self.actor_batch_td.pop()
+            if i < len(self.actor_batch_buffer):
+                self.actor_batch_buffer[i] = last; self.actor_batch_td[i] = last_td
+
+    def _new_v(self, rows, idx):
+        r = rows[:, 0].to(self.dtype) * (1.0 - self.discount)                 # NormalizeReward, eRewardModeStart
+        v_end = self._eval(self._target_net(), rows[:, 1 + self.S + self.A:])[:, 0]
+        fail = (self.flags_dev[idx] & FLAG_FAIL) != 0
+        return torch.where(fail, r, r + self.discount * v_end)
+
+    def Step(self):
+        ids = self.FetchMinibatch(self.batch)
+        if len(ids) >= self.batch:
+            idx = self._idx(ids)
+            rows = self.mem[idx]
+            self._last_loss = self._solver_step(rows[:, 1:1 + self.S], self._new_v(rows, idx)[:, None].to(self.dtype))
+        self.UpdateActor()
+        if self.EnableTargetNet() and self.iter > 0 and self.iter % self.freeze_target_iters == 0:      # cCaclaTrainer::Step: CheckUpdateTarget after cACTrainer::Step
+            self.UpdateTargetNet()
+        return True
+
+    def UpdateActorBatchBuffer(self):
+        n = len(self.off_policy_buffer)
+        ids = []
+        for _ in range(min(self.actor_batch, n)):
+            t = self.off_policy_buffer[int(self.rng.randint(0, n))]
+            if t not in self.actor_batch_buffer and t not in ids:
+                ids.append(t)
+        if not ids:
+            return
+        idx = self._idx(ids)
+        rows = self.mem[idx]
+        curr = self._eval(self._target_net(), rows[:, 1:1 + self.S])[:, 0]
+        td = (self._new_v(rows, idx) - curr).to(torch.float64).cpu().numpy()
+        for t, d in zip(ids, td):
+            if d > 0:
+                self.actor_batch_buffer.append(t); self.actor_batch_td.append(float(d))
+
+    def UpdateActor(self):
+        if self.stage_train:
+            self.UpdateActorBatchBuffer()
+        for _ in range(len(self.actor_batch_buffer) // self.actor_batch):
+            rows = self._rows(self.actor_batch_buffer[:self.actor_batch])
+            X = rows[:, 1:1 + self.S]
+            Y = rows[:, 1 + self.S:1 + self.S + self.A].to(self.dtype)          # BuildTupleActorY: the action that was taken
+            self.actor._last_loss = self.actor._solver_step(X, Y)
+            self.actor_iter += 1
+            del self.actor_batch_buffer[:self.actor_batch]; del self.actor_batch_td[:self.actor_batch]
+
+    def UpdateOffsetScale(self):
+        super().UpdateOffsetScale()                                            # UpdateCriticOffsetScale ...
+        io, isc, _, _ = MACETrainer.GetOffsetScale(self)
+        self.actor.SetInputOffsetScale(io, isc)                                 # ... and UpdateActorOffsetScale: the same statistics of the same states
 
 
 def anneal(it, n_iters, v0, v1):

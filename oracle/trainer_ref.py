@@ -396,3 +396,105 @@ class RefQTrainer:
         s = self.solver
         self.w, self.hist = caffe_sgd_step(self.w, grad, self.hist, s["base_lr"], s["momentum"], s["weight_decay"], self.lr_mult, self.decay_mult)
         self.iter += 1
+
+
+class RefCaclaTrainer:
+    """cCaclaTrainer / cACTrainer (pool of one, eModeCacla, reward mode "start") in numpy fp64: critic and actor are RefQNet instances.
+    learning/CaclaTrainer.cpp:105-127 FetchActorMinibatch, :137-157 Step / BuildProblemY, :234-277 CalcNewCumulativeRewardBatch, :342-387
+    UpdateActorBatchBuffer, :420-462 UpdateBuffers; learning/ACTrainer.cpp:397-412 Step, :611-646 UpdateActor / StepActor, :271-284 BuildActorProblemY."""
+
+    def __init__(self, critic, critic_mults, actor, actor_mults, S, A, mem_size, batch, actor_batch, discount, num_init_samples, solver, seed,
+                 freeze_target_iters=0, init_input_offset_scale=True):
+        self.critic, self.actor_net, self.S, self.A = critic, actor, S, A
+        self.batch, self.actor_batch, self.discount, self.freeze = batch, actor_batch, discount, freeze_target_iters
+        self.W = 1 + 2 * S + A
+        self.mem = np.zeros((mem_size, self.W), np.float32); self.flags = np.zeros(mem_size, np.int64)
+        self.mem_size, self.head, self.num = mem_size, 0, 0
+        self.num_init_samples, self.solver, self.init_os = num_init_samples, solver, init_input_offset_scale
+        cat = lambda net, mults, k: np.concatenate([np.full(n, m[k]) for n, m in zip(net.sizes, mults)])
+        self.c_lr, self.c_dec, self.a_lr, self.a_dec = cat(critic, critic_mults, 0), cat(critic, critic_mults, 1), cat(actor, actor_mults, 0), cat(actor, actor_mults, 1)
+        self.wc = np.zeros(critic.num_params); self.wc_target = self.wc.copy(); self.hc = np.zeros(critic.num_params)
+        self.wa = np.zeros(actor.num_params); self.ha = np.zeros(actor.num_params)
+        self.in_off, self.in_scale = np.zeros(S), np.ones(S)
+        self.c_out_off, self.c_out_scale = np.full(1, -0.5), np.full(1, 2.0)
+        self.a_out_off, self.a_out_scale = np.zeros(A), np.ones(A)
+        self.rng = np.random.RandomState(seed)
+        self.iter = self.actor_iter = 0; self.stage_train = False
+        self.off_policy, self.actor_buf, self.actor_td = [], [], []
+        self.last_loss = self.last_actor_loss = None
+
+    def add_tuples(self, rows, flags):
+        out = []
+        for r, f in zip(rows, flags):
+            r = np.asarray(r, np.float32)
+            if not np.all(np.isfinite(r)):
+                out.append(-1); continue
+            t = self.head
+            self.mem[t] = r; self.flags[t] = int(f)
+            self.head = (self.head + 1) % self.mem_size; self.num = min(self.mem_size, self.num + 1)
+            if f & 2:
+                if t not in self.off_policy: self.off_policy.append(t)
+            else:
+                RefTrainerBook._remove(self.off_policy, t)
+            while t in self.actor_buf:
+                i = self.actor_buf.index(t); last, ltd = self.actor_buf.pop(), self.actor_td.pop()
+                if i < len(self.actor_buf): self.actor_buf[i] = last; self.actor_td[i] = ltd
+            out.append(t)
+        return out
+
+    def v(self, w, X):
+        X = np.atleast_2d(np.asarray(X, np.float64))
+        return (self.critic.forward(w, (X + self.in_off) * self.in_scale) / self.c_out_scale - self.c_out_off)[:, 0]
+
+    def _target(self):
+        return self.wc_target if self.freeze > 0 else self.wc
+
+    def new_v(self, ids):
+        S, A, g = self.S, self.A, self.discount
+        v_end = self.v(self._target(), self.mem[ids, 1 + S + A:].astype(np.float64))
+        r = self.mem[ids, 0].astype(np.float64) * (1.0 - g)
+        return np.where(self.flags[ids] & 1, r, r + g * v_end)
+
+    def _sgd(self, net, w, h, lr, dec, X, Y, out_off, out_scale):
+        x = (np.asarray(X, np.float64) + self.in_off) * self.in_scale
+        label = (Y + out_off) * out_scale
+        out = net.forward(w, x, keep=True)
+        loss = 0.5 * ((out - label) ** 2).sum() / x.shape[0]
+        grad = net.backward((out - label) / x.shape[0])
+        s = self.solver
+        w, h = caffe_sgd_step(w, grad, h, s["base_lr"], s["momentum"], s["weight_decay"], lr, dec)
+        return w, h, loss
+
+    def train(self):
+        if not self.stage_train and self.num >= self.num_init_samples and self.num > 0:
+            if self.num_init_samples > 1 and self.init_os:
+                X = self.mem[:self.num, 1:1 + self.S].astype(np.float64)
+                mean = X.mean(0); std = np.sqrt(((X - mean) ** 2).mean(0))
+                self.in_off, self.in_scale = -mean, np.where(std == 0, 0.0, 1.0 / np.where(std == 0, 1.0, std))
+            self.stage_train = True
+        if not self.stage_train:
+            return
+        S, A = self.S, self.A
+        ids = [int(self.rng.randint(0, self.num)) for _ in range(self.batch)]
+        self.wc, self.hc, self.last_loss = self._sgd(self.critic, self.wc, self.hc, self.c_lr, self.c_dec, self.mem[ids, 1:1 + S], self.new_v(ids)[:, None], self.c_out_off, self.c_out_scale)
+        # UpdateActor
+        n = len(self.off_policy)
+        drawn = []
+        for _ in range(min(self.actor_batch, n)):
+            t = self.off_policy[int(self.rng.randint(0, n))]
+            if t not in self.actor_buf and t not in drawn:
+                drawn.append(t)
+        if drawn:
+            td = self.new_v(drawn) - self.v(self._target(), self.mem[drawn, 1:1 + S].astype(np.float64))
+            for t, d in zip(drawn, td):
+                if d > 0:
+                    self.actor_buf.append(t); self.actor_td.append(float(d))
+        for _ in range(len(self.actor_buf) // self.actor_batch):
+            b = self.actor_buf[:self.actor_batch]
+            self.wa, self.ha, self.last_actor_loss = self._sgd(self.actor_net, self.wa, self.ha, self.a_lr, self.a_dec, self.mem[b, 1:1 + S],
+                                                               self.mem[b, 1 + S:1 + S + A].astype(np.float64), self.a_out_off, self.a_out_scale)
+            self.actor_iter += 1
+            del self.actor_buf[:self.actor_batch]; del self.actor_td[:self.actor_batch]
+        if self.freeze > 0 and self.iter > 0 and self.iter % self.freeze == 0:
+            self.wc_target = self.wc.copy()
+        self.iter += 1

@@ -375,3 +375,90 @@ def test_q_train_loop_end_to_end_on_cpu(da):
     assert np.all(np.isfinite(st["weights"])) and st["weights"].size == 461208
     io, isc, oo, osc = st["offset_scale"]
     assert len(oo) == 8 and np.all(oo == -0.5) and np.all(osc == 2)
+
+
+# ---- the CACLA trainer (cCaclaTrainer / cACTrainer) ---------------------------------------------------------------------------------------
+CRITIC = [os.path.join(NETS, "dog_critic_%s.prototxt" % k) for k in ("train", "solver", "deploy")]
+ACTOR = [os.path.join(NETS, "dog_actor_%s.prototxt" % k) for k in ("train", "solver", "deploy")]
+CA = 29
+
+
+def make_cacla_trainer(**kw):
+    from deepterrainrl_amd import trainer as tr
+    args = dict(mem_size=256, num_init_samples=100, freeze_target_iters=3, device="cpu", dtype=torch.float64, seed=4)
+    args.update(kw)
+    return tr.CaclaTrainer(CRITIC[0], CRITIC[1], ACTOR[0], ACTOR[1], S, CA, **args)
+
+
+def make_ref_cacla_trainer(om, t, seed):
+    from oracle import trainer_ref as ref
+    nets = []
+    for dep in (CRITIC[2], ACTOR[2]):
+        d = om.parse_deploy_prototxt(dep)
+        nets.append(ref.RefQNet(d.n_terrain, d.n_char, [(d.conv_ch[i], d.conv_k[i]) for i in range(3)], d.fc_terr, d.fc_trunk, d.fc_head, d.frag_size))
+    mults = [(1.0, 1.0), (2.0, 1.0)] * 3 + [(1.0, 1.0), (2.0, 0.0)] * 4
+    assert mults == [tuple(m) for m in t.net.blob_mults] == [tuple(m) for m in t.actor.net.blob_mults]
+    assert nets[0].num_params == t.net.num_params() and nets[1].num_params == t.actor.net.num_params()
+    return ref.RefCaclaTrainer(nets[0], mults, nets[1], mults, S, CA, t.mem_size, 32, 32, t.discount, t.num_init_samples,
+                               dict(base_lr=0.001, momentum=0.9, weight_decay=0.0005), seed, freeze_target_iters=t.freeze_target_iters)
+
+
+def cacla_rows(rng, n, p_off=0.5, p_fail=0.2):
+    rows = rng.normal(0, 1, size=(n, 1 + 2 * S + CA)).astype(np.float32)
+    rows[:, 0] = rng.uniform(0, 1, n)
+    flags = (rng.uniform(size=n) < p_off) * 2 + (rng.uniform(size=n) < p_fail) * 1
+    return rows, flags.astype(np.int64)
+
+
+def run_cacla_trainer_vs_restatement(om, device, dtype, tol, iters=14):
+    rng = np.random.RandomState(21)
+    rows, flags = cacla_rows(rng, 330)                                   # wraps the 256-slot ring: buffers are purged of overwritten slots
+    t = make_cacla_trainer(device=device, dtype=dtype, seed=13)
+    r = make_ref_cacla_trainer(om, t, 13)
+    wc0, wa0 = t.GetCriticWeights(), t.GetWeights()
+    t.SetCriticWeights(wc0); t.SetWeights(wa0)
+    r.wc = wc0.astype(np.float64); r.wc_target = r.wc.copy(); r.wa = wa0.astype(np.float64)
+    oo = rng.normal(0, 0.1, CA); osc = rng.uniform(0.5, 2, CA)
+    t.SetOutputOffsetScale(oo, osc); r.a_out_off, r.a_out_scale = oo, osc
+    slots = t.AddTuples(rows[:200], flags[:200]); assert list(slots) == r.add_tuples(rows[:200], flags[:200])
+    assert t.off_policy_buffer == r.off_policy
+    for k in range(iters):
+        t.Train(); r.train()
+        if k == 3:                                                      # new tuples arrive mid-training and overwrite old slots
+            slots = t.AddTuples(rows[200:], flags[200:]); assert list(slots) == r.add_tuples(rows[200:], flags[200:])
+            assert t.off_policy_buffer == r.off_policy
+        assert (t.GetIter(), t.actor_iter) == (r.iter, r.actor_iter), k
+        if dtype == torch.float64:
+            assert t.actor_batch_buffer == r.actor_buf and np.allclose(t.actor_batch_td, r.actor_td, rtol=0, atol=1e-9), k
+    assert r.iter == iters and r.actor_iter >= 2, r.actor_iter
+    wc, wa = t.GetCriticWeights().astype(np.float64), t.GetWeights().astype(np.float64)
+    if dtype == torch.float64:
+        wc, wa = t.net.flat.detach().cpu().numpy(), t.actor.net.flat.detach().cpu().numpy()
+    assert np.abs(wc - r.wc).max() < tol * np.abs(r.wc).max() and np.abs(wa - r.wa).max() < tol * np.abs(r.wa).max()
+    assert np.abs(wc - wc0).max() > 1e-4 and np.abs(wa - wa0).max() > 1e-4
+    io, isc, oo2, osc2 = t.GetOffsetScale()
+    assert np.allclose(io, r.in_off, atol=1e-6) and np.allclose(oo2, oo, atol=1e-6)
+    cio, _, coo, cosc = t.GetCriticOffsetScale()
+    assert np.allclose(cio, r.in_off, atol=1e-6) and coo[0] == -0.5 and cosc[0] == 2
+
+
+def test_cacla_trainer_iterations_match_the_numpy_restatement(om):
+    run_cacla_trainer_vs_restatement(om, "cpu", torch.float64, 1e-10)
+
+
+@pytest.mark.gpu
+def test_gpu_cacla_trainer_matches_the_numpy_restatement(om):
+    run_cacla_trainer_vs_restatement(om, "cuda", torch.float32, 3e-4)
+
+
+def test_cacla_train_loop_end_to_end_on_cpu(da):
+    """args/opt_args_train_cacla.txt through the whole loop: CACLA rollouts (actor on the device, off-policy flags) -> critic + actor updates -> the
+    actor's weights and normalisers back into the engine. (Identity input normaliser for the same reason as in the Q loop test.)"""
+    from deepterrainrl_amd import train_loop
+    from conftest import EmulScenario
+    st = train_loop.train("args/opt_args_train_cacla.txt", REFDATA, num_envs=48, max_frames=100, trainer_device="cpu", scenario_cls=EmulScenario,
+                          extra_args={"terrain_seed": 3, "trainer_num_init_samples": 60, "trainer_replay_mem_size": 512, "trainer_init_input_offset_scale": "false"})
+    assert st["frames"] == 100 and st["tuples"] >= 60 and st["iters"] >= 10
+    assert np.all(np.isfinite(st["weights"])) and st["weights"].size == 463917           # the actor's blobs: what dtrl_set_policy takes for dog_cacla
+    io, isc, oo, osc = st["offset_scale"]
+    assert len(oo) == 29 and np.all(np.isfinite(osc))
