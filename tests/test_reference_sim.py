@@ -245,6 +245,64 @@ def test_exp_q_head_tuples_match_the_reference(om):
     print("q head: tuples", n_t, "actions", sorted(acts))
 
 
+def test_goat_poli_eval_cliffs_matches_the_reference(om):
+    """goat_mace on cliffs_rugged, one physics substep per env-step (BASELINE config 5's scene): cGoatControllerMACE's target speed, the cliff terrain with
+    its slope / bump overlays, falls and resets -- the reference's scenario vs the oracle."""
+    arg = "args/goat_cliffs_args.txt"
+    m, _ = om.build_model(arg, REFERENCE)
+    pol = dog_policy(om)
+    e = om.OracleEnv(m, terrain_seed=8, policy=pol)
+    rs.nn_config(283, 90, _policy_raw_forward(e, pol))
+    r = rs.RefScenario("poli_eval", arg, REFERENCE, global_seed=3)
+    r.set_net_scale(*pol[2:])
+    r.seed_ground_and_reset(8)
+    ls = rs.LockStep(r, e)
+    prev = 0; n_states = 0
+    for f in range(120):
+        ls.update(); e.frame_end()
+        st_r = r.eval_stats(); st_o = e.stats()
+        assert st_r["cycles"] == st_o["cycles"] and st_r["episodes"] == st_o["episodes"], (f, st_r, st_o)
+        if st_o["cycles"] != prev:
+            prev = st_o["cycles"]
+            d = np.abs(r.poli_state() - e.poli_state())
+            assert d[201:].max() < 1e-9 * max(1.0, np.abs(e.poli_state()).max()) and d[:201].max() < 5e-4, (f, d[201:].max(), d[:201].max())   # (cliff faces: a 1e-6 x offset moves a sample across a 0.4 m step edge's lerp)
+            n_states += 1
+    info = check_records(ls.records, e.D, 120 * 20, tau_tol=1e-3, prm_tol=1e-4, ctx="goat cliffs")
+    assert n_states >= 6 and info["n_new_cycle"] >= 6
+    print("goat cliffs", info, e.stats())
+
+
+def test_raptor_exp_mace_tuples_match_the_reference(om):
+    """cScenarioExpMACE + cRaptorControllerMACE (args/opt_args_train_raptor_mace.txt): tuples with the stance-mirrored states, exploration off."""
+    import test_host_and_emul as T
+    arg = "args/opt_args_train_raptor_mace.txt"
+    m, _ = om.build_model(arg, REFERENCE, overrides={"policy_model": ""})
+    m.enable_explore = 0
+    pol = T.raptor_policy(om)
+    e = om.OracleEnv(m, terrain_seed=15, policy=pol)
+    rs.nn_config(275, 87, _policy_raw_forward(e, pol))
+    r = rs.RefScenario("exp_mace", arg, REFERENCE, global_seed=7)
+    r.set_net_scale(*pol[2:])
+    r.seed_ground_and_reset(15)
+    r.enable_explore(0)
+    r.command_action(0); e.command_action(0)
+    ls = rs.LockStep(r, e)
+    n_t = 0
+    for f in range(150):
+        ls.update(); e.frame_end()
+        a, fa = r.drain_tuples()
+        b, fb = e.drain_tuples(f64=True)
+        assert len(a) == len(b), (f, len(a), len(b))
+        for x, y, p, q_ in zip(a, b, fa, fb):
+            assert p == q_ and np.abs(x - y).max() < 5e-5 * max(1.0, np.abs(y).max()), (f, p, q_, np.abs(x - y).max())
+            n_t += 1
+        if e.stats()["resets"] > 0 and n_t >= 4:
+            break
+    second = next(k for k, (o, _) in enumerate(ls.records) if k > 0 and (o["flags"] & 4))
+    check_records(ls.records, e.D, 100, tau_tol=1e-4, prm_tol=1e-5, ctx="raptor exp", action_id_from=second)
+    assert n_t >= 4
+
+
 @pytest.mark.parametrize("arg,seed", [("args/dog_slopes_mixed_args.txt", 17), ("args/dog_narrow_gaps_args.txt", 9), ("args/goat_cliffs_args.txt", 3)])
 def test_ground_window_bit_exact_in_the_float_build(om, arg, seed):
     """'terrain indices bit-exact' against the reference's OWN cGroundVar2D (sim/GroundVar2D.cpp: Update / BuildSegment / tSegment::Init / SampleHeight /
