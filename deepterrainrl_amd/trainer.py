@@ -374,6 +374,9 @@ class MACETrainer:
     def AddTuples(self, rows, flags):
         """rows [n, W] float in the MACE layout, flags [n] tExpTuple bits. Returns the slot of every row (-1 = rejected by CheckTuple)."""
         rows = np.asarray(rows, np.float32).reshape(-1, self.W)
+        if rows.shape[0] > self.mem_size:      # more rows than slots: a slot would be written twice by ONE indexed store (order undefined); go ring by ring
+            flags = np.asarray(flags, np.int64)
+            return np.concatenate([self.AddTuples(rows[k:k + self.mem_size], flags[k:k + self.mem_size]) for k in range(0, rows.shape[0], self.mem_size)])
         ok = np.all(np.isfinite(rows), axis=1)
         slots = np.full(rows.shape[0], -1, np.int64)
         keep = np.nonzero(ok)[0]

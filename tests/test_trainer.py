@@ -345,6 +345,12 @@ def test_q_trainer_iterations_match_the_numpy_restatement(om):
     assert np.abs(a - r.w).max() < 1e-10 * np.abs(r.w).max() and np.abs(a - w0).max() > 1e-4
     io, isc, _, _ = t.GetOffsetScale()
     assert np.allclose(io, r.in_off, atol=1e-12) and np.allclose(isc, r.in_scale, rtol=1e-10)
+    # more rows than slots in ONE call: every slot ends up with the LAST row written to it, as if the rows had arrived one by one
+    t2 = make_q_trainer(seed=8)
+    t2.AddTuples(rows, flags)
+    ok = np.all(np.isfinite(rows), axis=1)
+    r2 = make_ref_q_trainer(om, t2, 8); r2.add_tuples(rows, flags)
+    assert (t2.head, t2.num_tuples) == (r2.head, r2.num) and np.array_equal(t2.mem.numpy(), r2.mem) and np.array_equal(t2.flags, r2.flags) and ok.sum() == 299
 
 
 @pytest.mark.gpu
