@@ -441,6 +441,35 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		m.lim_lo[j] -= ref_theta; m.lim_hi[j] -= ref_theta;
 	}
 	m.contact_tol = 0.001 / world_scale;   // sim/ContactManager.cpp:74-75, dist_tol in world-scaled units
+	// link--link collision pairs: same non-zero collision group, no hinge between the two, boxes overlapping in z (joint AttachZ accumulated down the
+	// chain + body AttachZ against the box depth Param2: the raptor's legs share a group but sit 0.16 m apart in z with 0.065 m deep boxes)
+	{
+		double zj[kMaxL], zc[kMaxL], zs[kMaxL];
+		for (int j = 0; j < L; ++j) {
+			zj[j] = (m.parent[j] >= 0 ? zj[m.parent[j]] : 0.0) + joints->arr[j].get_num("AttachZ", 0);
+			zc[j] = zj[j] + bodies->arr[j].get_num("AttachZ", 0);
+			zs[j] = bodies->arr[j].get_num("Param2", 0);
+			m.bt_cs[j] = std::cos(m.body_theta[j]); m.bt_sn[j] = std::sin(m.body_theta[j]);
+		}
+		int n = 0;
+		for (int a = 0; a < L; ++a) for (int b = a + 1; b < L; ++b) {
+			if (m.col[a] == 0 || m.col[a] != m.col[b] || m.parent[b] == a || m.parent[a] == b) continue;
+			if (std::fabs(zc[a] - zc[b]) >= 0.5 * (zs[a] + zs[b])) continue;
+			if (n >= kMaxCP) { err = "too many link--link collision pairs"; return false; }
+			m.cp_a[n] = static_cast<int8_t>(a); m.cp_b[n] = static_cast<int8_t>(b);
+			++n;
+		}
+		for (int j = 0; j < L; ++j) {
+			double hx = m.body_half[j][0], hy = m.body_half[j][1];
+			if (m.body_theta[j] != 0 && j != 0) hx = hy = std::sqrt(hx * hx + hy * hy);
+			const double grow = m.contact_tol + 1e-5;   // float rounding of the extents and of the test itself stays inside this
+			m.cp_half[j][0] = static_cast<float>((hx + grow) * 1.00001); m.cp_half[j][1] = static_cast<float>((hy + grow) * 1.00001);
+		}
+		m.n_cpairs = n;
+		m.cp_root_bt[0] = static_cast<float>(std::cos(m.body_theta[0])); m.cp_root_bt[1] = static_cast<float>(std::sin(m.body_theta[0]));
+		int lc = 1; args.ParseInt("link_contacts", lc);
+		m.link_contacts = lc != 0;
+	}
 	// contact sample points (4 corners + long-edge midpoints, DESIGN.md "Integrator v1") and end-effector points, joint frame
 	for (int j = 0; j < L; ++j) {
 		const double hx = m.body_half[j][0], hy = m.body_half[j][1];

@@ -79,6 +79,11 @@ struct HotModel {
 	real attach[kMaxL][2], lim_lo[kMaxL], lim_hi[kMaxL];
 	real body_attach[kMaxL][2];
 	real mass[kMaxL], inertia[kMaxL], sub_mass[kMaxL];
+	// link--link collision pairs (DevModel::cp_*): one lane per pair tests the two boxes for overlap every substep
+	int32_t n_cpairs;
+	int8_t cp_a[kMaxCP], cp_b[kMaxCP];
+	float cp_half[kMaxL][2];
+	float cp_root_bt[2];
 };
 
 struct DevBuffers {
@@ -137,6 +142,7 @@ struct WSBase {
 	// constraint rows
 	int32_t R, n_pts_active;   // n_pts_active (fast path): row count of the list built by the post-step contact pass for the next substep, -1 = none
 	int32_t row_kind[kMaxRows], row_link[kMaxRows];
+	int8_t row_link2[kMaxRows];   // link--link contact rows: the partner link the row pushes the other way (-1: the ground)
 	real row_x[kMaxRows], row_y[kMaxRows], row_dx[kMaxRows], row_dy[kMaxRows], row_tgt[kMaxRows];
 	real wv[kMaxRows], lam[kMaxRows], rinv[kMaxRows];
 	real dl;
@@ -212,6 +218,14 @@ DTRL_HD_INLINE real fast_rsqrt(real x)
 #endif
 }
 
+// angular rates are clamped to a quarter turn per substep (kMaxTurnPerSubstep): 4712 rad/s at 1/3000 s -- only a whipping tail of a crashed character gets
+// there; unclamped, the explicit Coriolis terms then overflow within a few substeps
+DTRL_HD_INLINE real clamp_turn_rate(real v, int dof, real h)
+{
+	if (dof < 2) return v;
+	const real vmax = kMaxTurnPerSubstep / h;
+	return v > vmax ? vmax : (v < -vmax ? -vmax : v);
+}
 DTRL_HD inline real wrap_pi(real a)
 {
 	const real pi = 3.14159265358979323846, two_pi = 6.283185307179586476925286766559;
@@ -273,7 +287,7 @@ DTRL_HD_INLINE real sample_ground(const GroundRec& g, const GroundHdr& gh, real 
 	c /= scale;
 	c += ((w - 1) * 0.5);
 	if (c > -tol && c < w - 1 + tol) { c = c < 0.0 ? 0.0 : (c > w - 1.0 ? w - 1.0 : c); }
-	c = c < 0.0 ? 0.0 : (c > w - 1.0 ? w - 1.0 : c);
+	c = !(c > 0.0) ? 0.0 : (c > w - 1.0 ? w - 1.0 : c);   // (written so that a NaN coordinate -- a state that has already blown up -- still indexes inside the segment)
 	int i = static_cast<int>(c);
 	int j = (i + 1 < w - 1) ? i + 1 : w - 1;
 	real lerp = c - i;
@@ -528,11 +542,96 @@ template <class W>
 DTRL_HD inline real row_jac(const W& ws, int r, int i)
 {
 	if (ws.row_kind[r] == 0) return (i == ws.row_link[r] + 2) ? ws.row_dx[r] : 0.0;
-	if (i == 0) return ws.row_dx[r];
-	if (i == 1) return ws.row_dy[r];
+	const int l2 = ws.row_link2[r];
+	if (i == 0) return l2 < 0 ? ws.row_dx[r] : 0.0;   // a link--link row is the difference of two point rows: the root translation drops out
+	if (i == 1) return l2 < 0 ? ws.row_dy[r] : 0.0;
 	const int a = i - 2;
-	if (!((ws.M.sub_mask[a] >> ws.row_link[r]) & 1u)) return 0.0;
-	return ws.row_dx[r] * (-(ws.row_y[r] - ws.py[a])) + ws.row_dy[r] * (ws.row_x[r] - ws.px[a]);
+	const int on = static_cast<int>((ws.M.sub_mask[a] >> ws.row_link[r]) & 1u) - (l2 < 0 ? 0 : static_cast<int>((ws.M.sub_mask[a] >> l2) & 1u));
+	if (on == 0) return 0.0;
+	const real jv = ws.row_dx[r] * (-(ws.row_y[r] - ws.py[a])) + ws.row_dy[r] * (ws.row_x[r] - ws.px[a]);
+	return on > 0 ? jv : -jv;
+}
+// velocity of the material point of link l that currently sits at (x, y), along (dx, dy)
+template <class W>
+DTRL_HD_INLINE real link_point_vel(const W& ws, int l, real x, real y, real dx, real dy)
+{
+	const real vx = ws.vpx[l] - ws.w[l] * (y - ws.py[l]);
+	const real vy = ws.vpy[l] + ws.w[l] * (x - ws.px[l]);
+	return dx * vx + dy * vy;
+}
+// J v of a point row at the current velocities (ground rows: the link's point; link--link rows: relative velocity of the two links' points)
+template <class W>
+DTRL_HD_INLINE real row_point_jv(const W& ws, int s)
+{
+	real jv = link_point_vel(ws, ws.row_link[s], ws.row_x[s], ws.row_y[s], ws.row_dx[s], ws.row_dy[s]);
+	const int l2 = ws.row_link2[s];
+	if (l2 >= 0) jv -= link_point_vel(ws, l2, ws.row_x[s], ws.row_y[s], ws.row_dx[s], ws.row_dy[s]);
+	return jv;
+}
+
+// ---- link--link contacts: sample point k of link P against the box of link Q (both kernels and the lane-loop build share this) ----
+struct PairHit { real x, y, depth, nx, ny; int active; };   // normal: pushes P out of Q
+template <class W>
+DTRL_HD_INLINE PairHit pair_point_eval(const W& ws, const DevModel& gm, int P, int Q, int k)
+{
+	PairHit r; r.x = 0; r.y = 0; r.depth = 0; r.nx = 0; r.ny = 0; r.active = 0;
+	const real lx = gm.pt_joint[P][k][0], ly = gm.pt_joint[P][k][1];
+	const real x = ws.px[P] + ws.cs[P] * lx - ws.sn[P] * ly;
+	const real y = ws.py[P] + ws.sn[P] * lx + ws.cs[P] * ly;
+	const real cq = ws.cs[Q] * gm.bt_cs[Q] - ws.sn[Q] * gm.bt_sn[Q], sq = ws.sn[Q] * gm.bt_cs[Q] + ws.cs[Q] * gm.bt_sn[Q];   // box frame of Q
+	const real dx = x - ws.cx[Q], dy = y - ws.cy[Q];
+	const real qx = cq * dx + sq * dy, qy = -sq * dx + cq * dy;
+	const real pen_x = gm.body_half[Q][0] - fabs(qx), pen_y = gm.body_half[Q][1] - fabs(qy);
+	if (!(pen_x > 0 && pen_y > 0)) return r;
+	real nlx = 0, nly = 0;
+	if (pen_x <= pen_y) { nlx = qx >= 0 ? 1.0 : -1.0; r.depth = pen_x; } else { nly = qy >= 0 ? 1.0 : -1.0; r.depth = pen_y; }
+	r.nx = cq * nlx - sq * nly; r.ny = sq * nlx + cq * nly;
+	r.x = x; r.y = y; r.active = 1;
+	return r;
+}
+// can pair pr touch at all? Separating-axis test of the two (slightly grown) boxes: second neighbours along a limb are always within each other's
+// bounding circles, so only an oriented test keeps the out-of-line contact code off the common path. Conservative by construction (cp_half)
+template <class W>
+DTRL_HD_INLINE bool pair_in_reach(const W& ws, int pr)
+{
+	const int a = ws.M.cp_a[pr], b = ws.M.cp_b[pr];
+	const real tx = ws.cx[b] - ws.cx[a], ty = ws.cy[b] - ws.cy[a];
+	real ca = ws.cs[a], sa = ws.sn[a];
+	const real cb = ws.cs[b], sb = ws.sn[b];
+	if (a == 0) { const real bc = ws.M.cp_root_bt[0], bs = ws.M.cp_root_bt[1]; const real c0 = ca * bc - sa * bs; sa = sa * bc + ca * bs; ca = c0; }   // (a < b: only a can be the root; float cos / sin: the grown extents absorb 1e-7)
+	const real hxa = ws.M.cp_half[a][0], hya = ws.M.cp_half[a][1], hxb = ws.M.cp_half[b][0], hyb = ws.M.cp_half[b][1];
+	const real c = fabs(ca * cb + sa * sb), s = fabs(ca * sb - sa * cb);
+	const bool sep = fabs(tx * ca + ty * sa) > hxa + hxb * c + hyb * s || fabs(-tx * sa + ty * ca) > hya + hxb * s + hyb * c
+		|| fabs(tx * cb + ty * sb) > hxb + hxa * c + hya * s || fabs(-tx * sb + ty * cb) > hyb + hxa * s + hya * c;
+	return !sep;
+}
+// candidate c (0..11) of a pair: a's six sample points against b, then b's six against a
+DTRL_HD_INLINE void pair_candidate(int a, int b, int c, int* P, int* Q, int* k) { const int side = c >= kPtsPerLink ? 1 : 0; *P = side ? b : a; *Q = side ? a : b; *k = c - side * kPtsPerLink; }
+// append the link--link contact rows behind the ground rows (serial form): per pair the deepest kMaxPtsPerLink penetrating candidates (ties: the earlier
+// candidate), in candidate order, while rows are left
+template <class W>
+DTRL_HD inline int append_pair_rows_serial(W& ws, const DevModel& gm, int R)
+{
+	for (int pr = 0; pr < ws.M.n_cpairs && R + 2 <= kMaxRows; ++pr) {
+		if (!pair_in_reach(ws, pr)) continue;
+		const int a = ws.M.cp_a[pr], b = ws.M.cp_b[pr];
+		PairHit hit[2 * kPtsPerLink];
+		for (int c = 0; c < 2 * kPtsPerLink; ++c) { int P, Q, k; pair_candidate(a, b, c, &P, &Q, &k); hit[c] = pair_point_eval(ws, gm, P, Q, k); }
+		for (int c = 0; c < 2 * kPtsPerLink && R + 2 <= kMaxRows; ++c) {
+			if (!hit[c].active) continue;
+			int rank = 0;
+			for (int o = 0; o < 2 * kPtsPerLink; ++o) if (o != c && hit[o].active && (hit[o].depth > hit[c].depth || (hit[o].depth == hit[c].depth && o < c))) ++rank;
+			if (rank >= kMaxPtsPerLink) continue;
+			int P, Q, k; pair_candidate(a, b, c, &P, &Q, &k);
+			// (velocity-level non-penetration only, no recovery term: a contact point can sit millimetres from the only hinge axis that could separate
+			// the two links, where 0.2 depth / h asks for thousands of rad/s; Bullet recovers penetration by split impulse, momentum-free as well)
+			ws.row_kind[R] = 1; ws.row_link[R] = P; ws.row_link2[R] = static_cast<int8_t>(Q); ws.row_x[R] = hit[c].x; ws.row_y[R] = hit[c].y;
+			ws.row_dx[R] = hit[c].nx; ws.row_dy[R] = hit[c].ny; ws.row_tgt[R] = 0; ++R;
+			ws.row_kind[R] = 2; ws.row_link[R] = P; ws.row_link2[R] = static_cast<int8_t>(Q); ws.row_x[R] = hit[c].x; ws.row_y[R] = hit[c].y;
+			ws.row_dx[R] = hit[c].ny; ws.row_dy[R] = -hit[c].nx; ws.row_tgt[R] = 0; ++R;
+		}
+	}
+	return R;
 }
 
 // world position of contact sample point pt (relative to the root origin) + ground test; shared by both kernel paths
@@ -581,7 +680,7 @@ DTRL_HD inline void detect_contacts(W& ws, const DevModel& gm, const GroundRec& 
 	if (lane == 0) {
 		uint32_t bits = 0;
 		for (int j = 0; j < ws.M.L; ++j) { int any = 0; for (int k = 0; k < kPtsPerLink; ++k) any |= ws.pt_active[j * kPtsPerLink + k] & 2; if (any) bits |= (1u << j); }
-		ws.st.contact_bits = bits;
+		ws.st.contact_bits = bits;   // (link--link contacts never set a flag: the character's parts are registered with filter eContactFlagEnvironment, scenarios/ScenarioSimChar.cpp:321)
 	}
 	LANES_END
 	// at most kMaxPtsPerLink constraint-carrying points per link: the deepest ones (ties: lower sample-point index). Two phases: every lane ranks
@@ -606,7 +705,7 @@ DTRL_HD inline void detect_contacts(W& ws, const DevModel& gm, const GroundRec& 
 
 // build the ordered row list: violated joint limits first (by joint id), then normal+tangent per active contact point
 template <class W>
-DTRL_HD inline void build_rows(W& ws, real h)
+DTRL_HD inline void build_rows(W& ws, const DevModel& gm, real h)
 {
 	LANES_BEGIN
 	if (lane == 0) {
@@ -615,8 +714,8 @@ DTRL_HD inline void build_rows(W& ws, real h)
 		for (int j = 1; j < ws.M.L; ++j) {
 			if (ws.M.lim_lo[j] > ws.M.lim_hi[j]) continue;
 			real th = ws.st.q[j + 2];
-			if (th <= ws.M.lim_lo[j] + kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_dx[R] = 1; ws.row_tgt[R] = kLimitErp * fmax(ws.M.lim_lo[j] - th, 0.0) * inv_h; ++R; }
-			else if (th >= ws.M.lim_hi[j] - kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_dx[R] = -1; ws.row_tgt[R] = kLimitErp * fmax(th - ws.M.lim_hi[j], 0.0) * inv_h; ++R; }
+			if (th <= ws.M.lim_lo[j] + kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_link2[R] = -1; ws.row_dx[R] = 1; ws.row_tgt[R] = kLimitErp * fmax(ws.M.lim_lo[j] - th, 0.0) * inv_h; ++R; }
+			else if (th >= ws.M.lim_hi[j] - kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_link2[R] = -1; ws.row_dx[R] = -1; ws.row_tgt[R] = kLimitErp * fmax(th - ws.M.lim_hi[j], 0.0) * inv_h; ++R; }
 		}
 		int cap = (kMaxRows - R) / 2, nc = 0;
 		// more penetrating points than rows: the deepest `cap` points overall get rows (ties: lower sample-point index)
@@ -634,12 +733,13 @@ DTRL_HD inline void build_rows(W& ws, real h)
 		for (int pt = 0; pt < ws.M.L * kPtsPerLink && nc < cap; ++pt) if (ws.pt_active[pt] & 1) {
 			const int j = pt / kPtsPerLink;
 			real t = kErp * fmax(ws.pt_depth[pt] - kSlop, 0.0) * inv_h;
-			ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_x[R] = ws.pt_x[pt]; ws.row_y[R] = ws.pt_y[pt];
+			ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_link2[R] = -1; ws.row_x[R] = ws.pt_x[pt]; ws.row_y[R] = ws.pt_y[pt];
 			ws.row_dx[R] = ws.pt_nx[pt]; ws.row_dy[R] = ws.pt_ny[pt]; ws.row_tgt[R] = fmin(t, kVDepenMax); ++R;
-			ws.row_kind[R] = 2; ws.row_link[R] = j; ws.row_x[R] = ws.pt_x[pt]; ws.row_y[R] = ws.pt_y[pt];
+			ws.row_kind[R] = 2; ws.row_link[R] = j; ws.row_link2[R] = -1; ws.row_x[R] = ws.pt_x[pt]; ws.row_y[R] = ws.pt_y[pt];
 			ws.row_dx[R] = ws.pt_ny[pt]; ws.row_dy[R] = -ws.pt_nx[pt]; ws.row_tgt[R] = 0; ++R;
 			++nc;
 		}
+		R = append_pair_rows_serial(ws, gm, R);   // link--link contacts take what is left of the row budget
 		ws.R = R;
 	}
 	LANES_END
@@ -679,12 +779,7 @@ DTRL_HD inline void build_delassus(W& ws, real h)
 		}
 		real jv;
 		if (ws.row_kind[s] == 0) jv = ws.row_dx[s] * ws.st.qd[ws.row_link[s] + 2];
-		else {
-			const int l = ws.row_link[s];
-			real vx = ws.vpx[l] - ws.w[l] * (ws.row_y[s] - ws.py[l]);
-			real vy = ws.vpy[l] + ws.w[l] * (ws.row_x[s] - ws.px[l]);
-			jv = ws.row_dx[s] * vx + ws.row_dy[s] * vy;
-		}
+		else jv = row_point_jv(ws, s);
 		real zz = 0;
 #pragma unroll 13
 		for (int i = 0; i < kMaxD; ++i) { const real zs = ws.Z[s][i], di = ws.dinv[i], z0 = ws.Z[R][i]; if (i < D) zz = fmadd(zs * di, z0, zz); }
@@ -745,7 +840,7 @@ DTRL_HD inline void finish_substep(W& ws, real h)
 		LANES_END
 	}
 	LANES_BEGIN
-	if (lane < D) { const int i = lane; real v = ws.st.qd[i] + ws.u[i]; ws.st.qd[i] = v; ws.st.q[i] += h * v; }
+	if (lane < D) { const int i = lane; real v = clamp_turn_rate(ws.st.qd[i] + ws.u[i], i, h); ws.st.qd[i] = v; ws.st.q[i] += h * v; }
 	LANES_END
 }
 
@@ -787,7 +882,7 @@ DTRL_HD inline void substep_ref(W& ws, const DevModel& gm, const GroundRec& g, r
 	{ PROF_T0(); mass_matrix(ws); PROF_ADD(ws, kProfMass); }
 	{ PROF_T0(); factorize(ws); PROF_ADD(ws, kProfFact); }
 	{ PROF_T0(); detect_contacts(ws, gm, g); PROF_ADD(ws, kProfDetect); }
-	{ PROF_T0(); build_rows(ws, h);
+	{ PROF_T0(); build_rows(ws, gm, h);
 	LANES_BEGIN
 	if (lane < ws.M.D) { ws.u[lane] = ws.st.tau[lane] - ws.b[lane]; if (__builtin_expect(ws.st.pert_on != 0, 0)) ws.u[lane] += perturb_gen_force(ws, lane); }
 	if (lane == 0) ws.cost += 8 + ws.R;
@@ -1760,8 +1855,11 @@ template <class W>
 DTRL_HD inline void load_hot_model(W& ws, const DevModel& gm)
 {
 	LANES_BEGIN
-	if (lane == 0) { ws.M.L = gm.L; ws.M.D = gm.D; ws.M.char_type = gm.char_type; ws.M.n_pairs = gm.n_pairs; }
+	if (lane == 0) { ws.M.L = gm.L; ws.M.D = gm.D; ws.M.char_type = gm.char_type; ws.M.n_pairs = gm.n_pairs; ws.M.n_cpairs = gm.link_contacts ? gm.n_cpairs : 0; }
 	for (int e = lane; e < gm.n_pairs; e += kGroup) { ws.M.pair_l[e] = gm.pair_l[e]; ws.M.pair_k[e] = gm.pair_k[e]; }
+	if (lane < gm.n_cpairs) { ws.M.cp_a[lane] = gm.cp_a[lane]; ws.M.cp_b[lane] = gm.cp_b[lane]; }
+	if (lane < gm.L) { ws.M.cp_half[lane][0] = gm.cp_half[lane][0]; ws.M.cp_half[lane][1] = gm.cp_half[lane][1]; }
+	if (lane < 2) ws.M.cp_root_bt[lane] = gm.cp_root_bt[lane];
 	if (lane < gm.L) {
 		const int j = lane;
 		ws.M.parent[j] = gm.parent[j]; ws.M.depth[j] = gm.depth[j]; ws.M.col[j] = gm.col[j];

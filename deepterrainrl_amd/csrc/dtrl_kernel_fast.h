@@ -344,6 +344,63 @@ __device__ __noinline__ unsigned row_cap_drop_mask(WSFast& ws, real d0, real d1,
 	__syncthreads();
 	return m;
 }
+// ---- link--link contacts on the wave: one lane per pair decides whether the two boxes can touch at all (hot path: a dozen instructions, almost always
+// "no"); the pairs in reach are then taken one at a time, twelve lanes evaluating the twelve candidates (cold path, out of line: nothing of it may
+// occupy registers in the physics loop). Same candidates, ranking and row order as append_pair_rows_serial().
+__device__ __forceinline__ unsigned long long pairs_in_reach(const WSFast& ws)
+{
+	const int lane = static_cast<int>(threadIdx.x);
+	return __ballot(lane < ws.M.n_cpairs && pair_in_reach(ws, lane));
+}
+// twelve candidates per pair, five pairs per pass (60 of the 64 lanes): the table reads of a pass travel together, the lane order (pair ascending, candidate
+// ascending) is the serial order, so the ballots give the same row positions and the same cut when the row budget runs out.
+// A pair rarely has more than kMaxPtsPerLink penetrating candidates: the depth ranking (two barriers, an LDS round trip) only runs when one does.
+// (Link--link contacts carry constraint rows but never set a link's contact flag: scenarios/ScenarioSimChar.cpp:321, sim/ContactManager.cpp:169-175.)
+constexpr int kPairCands = 2 * kPtsPerLink, kPairSlots = kGroup / kPairCands;
+__device__ __noinline__ int append_pair_rows_fast(WSFast& ws, const DevModel& gm, int R, unsigned long long reach)
+{
+	const int lane = opaque_lane();
+	const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+	const int slot = lane / kPairCands, cand = lane - slot * kPairCands;
+	while (reach != 0ull && R + 2 <= kMaxRows) {
+		int mypr = -1;
+#pragma unroll
+		for (int sidx = 0; sidx < kPairSlots; ++sidx) {
+			if (reach != 0ull) { const int pr = __ffsll(static_cast<long long>(reach)) - 1; reach &= reach - 1ull; if (slot == sidx) mypr = pr; }
+		}
+		int P = 0, Q = 0, k = 0;
+		PairHit hit; hit.active = 0; hit.depth = 0; hit.x = 0; hit.y = 0; hit.nx = 0; hit.ny = 0;
+		if (mypr >= 0) { pair_candidate(ws.M.cp_a[mypr], ws.M.cp_b[mypr], cand, &P, &Q, &k); hit = pair_point_eval(ws, gm, P, Q, k); }
+		const unsigned long long am = __ballot(hit.active);
+		if (am == 0ull) continue;
+		int keep = hit.active;
+		const int mine_cnt = __popcll((am >> (slot * kPairCands)) & ((1ull << kPairCands) - 1ull));
+		if (__builtin_expect(__ballot(lane < kPairSlots * kPairCands && mine_cnt > kMaxPtsPerLink) != 0ull, 0)) {
+			real* S = ws.Apk;   // (dead between the factorisation and the Delassus build, like in link_cap_drop_mask())
+			S[lane] = hit.active ? hit.depth : -1.0;
+			__syncthreads();
+			if (hit.active) {
+				int rank = 0;
+				for (int o = 0; o < kPairCands; ++o) { const real od = S[slot * kPairCands + o]; rank += (o != cand && od > 0 && (od > hit.depth || (od == hit.depth && o < cand))) ? 1 : 0; }
+				keep = rank < kMaxPtsPerLink;
+			}
+			__syncthreads();
+		}
+		const unsigned long long km = __ballot(keep);
+		const int room = (kMaxRows - R) / 2;
+		const int idx = __popcll(km & below);
+		if (keep && idx < room) {
+			const int Rw = R + 2 * idx;
+			ws.row_kind[Rw] = 1; ws.row_link[Rw] = P; ws.row_link2[Rw] = static_cast<int8_t>(Q); ws.row_x[Rw] = hit.x; ws.row_y[Rw] = hit.y;
+			ws.row_dx[Rw] = hit.nx; ws.row_dy[Rw] = hit.ny; ws.row_tgt[Rw] = 0;   // velocity-level only (append_pair_rows_serial)
+			ws.row_kind[Rw + 1] = 2; ws.row_link[Rw + 1] = P; ws.row_link2[Rw + 1] = static_cast<int8_t>(Q); ws.row_x[Rw + 1] = hit.x; ws.row_y[Rw + 1] = hit.y;
+			ws.row_dx[Rw + 1] = hit.ny; ws.row_dy[Rw + 1] = -hit.nx; ws.row_tgt[Rw + 1] = 0;
+		}
+		int n = __popcll(km); if (n > room) n = room;
+		R += 2 * n;
+	}
+	return R;
+}
 __device__ __forceinline__ void contact_bits_fast(WSFast& ws, unsigned long long m0, unsigned long long m1, unsigned long long m2)
 {
 	const int lane = static_cast<int>(threadIdx.x);
@@ -364,13 +421,13 @@ __device__ __forceinline__ void emit_contact_rows(WSFast& ws, const PtVal& p, in
 		const int R = R0 + 2 * rank;
 		const int j = pt / kPtsPerLink;
 		const real t = kErp * fmax(p.depth - kSlop, 0.0) * inv_h;
-		ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_x[R] = p.x; ws.row_y[R] = p.y;
+		ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_link2[R] = -1; ws.row_x[R] = p.x; ws.row_y[R] = p.y;
 		ws.row_dx[R] = p.nx; ws.row_dy[R] = p.ny; ws.row_tgt[R] = fmin(t, kVDepenMax);
-		ws.row_kind[R + 1] = 2; ws.row_link[R + 1] = j; ws.row_x[R + 1] = p.x; ws.row_y[R + 1] = p.y;
+		ws.row_kind[R + 1] = 2; ws.row_link[R + 1] = j; ws.row_link2[R + 1] = -1; ws.row_x[R + 1] = p.x; ws.row_y[R + 1] = p.y;
 		ws.row_dx[R + 1] = p.ny; ws.row_dy[R + 1] = -p.nx; ws.row_tgt[R + 1] = 0;
 	}
 }
-__device__ __forceinline__ void build_rows_fast(WSFast& ws, const ContactPts& c_in, real h)
+__device__ __forceinline__ void build_rows_fast(WSFast& ws, const DevModel& gm, const ContactPts& c_in, real h)
 {
 	ContactPts c = c_in;
 	const int lane = static_cast<int>(threadIdx.x);
@@ -386,7 +443,7 @@ __device__ __forceinline__ void build_rows_fast(WSFast& ws, const ContactPts& c_
 	const unsigned long long ml = __ballot(lim != 0);
 	const int rl = __popcll(ml & below);
 	int R0 = __popcll(ml); if (R0 > kMaxRows) R0 = kMaxRows;
-	if (lim != 0 && rl < kMaxRows) { ws.row_kind[rl] = 0; ws.row_link[rl] = lane; ws.row_dx[rl] = lim; ws.row_tgt[rl] = tgt; }
+	if (lim != 0 && rl < kMaxRows) { ws.row_kind[rl] = 0; ws.row_link[rl] = lane; ws.row_link2[rl] = -1; ws.row_dx[rl] = lim; ws.row_tgt[rl] = tgt; }
 	// contacts, ordered by sample-point index
 	const int cap = (kMaxRows - R0) / 2;
 	if (__builtin_expect(__popcll(c.m0) + __popcll(c.m1) + __popcll(c.m2) > cap, 0)) {   // wave-uniform
@@ -401,7 +458,11 @@ __device__ __forceinline__ void build_rows_fast(WSFast& ws, const ContactPts& c_
 	emit_contact_rows(ws, c.p1, lane + kGroup, n0 + __popcll(c.m1 & below), cap, R0, inv_h);
 	emit_contact_rows(ws, c.p2, lane + 2 * kGroup, n0 + n1 + __popcll(c.m2 & below), cap, R0, inv_h);
 	int nc = n0 + n1 + n2; if (nc > cap) nc = cap;
-	if (lane == 0) ws.R = R0 + 2 * nc;
+	int R = R0 + 2 * nc;
+	// link--link contacts take what is left of the row budget
+	const unsigned long long reach = pairs_in_reach(ws);
+	if (__builtin_expect(reach != 0ull, 0)) R = append_pair_rows_fast(ws, gm, R, reach);
+	if (lane == 0) ws.R = R;
 	__syncthreads();
 }
 
@@ -427,12 +488,7 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 		if (lane < R) {
 			const int sw = lane;
 			if (ws.row_kind[sw] == 0) jv = ws.row_dx[sw] * ws.st.qd[ws.row_link[sw] + 2];
-			else {
-				const int l = ws.row_link[sw];
-				const real vx = ws.vpx[l] - ws.w[l] * (ws.row_y[sw] - ws.py[l]);
-				const real vy = ws.vpy[l] + ws.w[l] * (ws.row_x[sw] - ws.px[l]);
-				jv = ws.row_dx[sw] * vx + ws.row_dy[sw] * vy;
-			}
+			else jv = row_point_jv(ws, sw);
 		}
 		const int zrow = c <= R ? c : 0;                        // rows above R are never stored; any finite-or-not value will do
 		v4d_t acc = {0, 0, 0, 0};
@@ -473,12 +529,7 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 		real jv = 0;
 		if (has_w) {
 			if (ws.row_kind[sw] == 0) jv = ws.row_dx[sw] * ws.st.qd[ws.row_link[sw] + 2];
-			else {
-				const int l = ws.row_link[sw];
-				const real vx = ws.vpx[l] - ws.w[l] * (ws.row_y[sw] - ws.py[l]);
-				const real vy = ws.vpy[l] + ws.w[l] * (ws.row_x[sw] - ws.px[l]);
-				jv = ws.row_dx[sw] * vx + ws.row_dy[sw] * vy;
-			}
+			else jv = row_point_jv(ws, sw);
 		}
 		const real* zs = ws.Z[s];
 		const real* zr = ws.Z[r];
@@ -592,7 +643,7 @@ struct FastPath {
 		} else {
 			ContactPts cp;
 			{ PROF_T0(); cp = eval_points<false>(ws, gm, g); PROF_ADD(ws, kProfDetect); }   // the per-link contact flags are the post-step pass's business (contacts() below)
-			{ PROF_T0(); build_rows_fast(ws, cp, h); PROF_ADD(ws, kProfRows); }
+			{ PROF_T0(); build_rows_fast(ws, gm, cp, h); PROF_ADD(ws, kProfRows); }
 		}
 		const int R = ws.R;
 		if (lane == 0) ws.cost += 8 + R;
@@ -611,9 +662,13 @@ struct FastPath {
 				const real dx = ws.row_dx[r];
 				if (kind == 0) return (lane == link + 2) ? dx : 0.0;
 				const real dy = ws.row_dy[r], x = ws.row_x[r], y = ws.row_y[r];
-				if (lane == 0) return dx;
-				if (lane == 1) return dy;
-				return ((mysub >> link) & 1u) ? dx * (-(y - mypy)) + dy * (x - mypx) : 0.0;
+				const int link2 = ws.row_link2[r];
+				if (lane == 0) return link2 < 0 ? dx : 0.0;
+				if (lane == 1) return link2 < 0 ? dy : 0.0;
+				const int on = static_cast<int>((mysub >> link) & 1u) - (link2 < 0 ? 0 : static_cast<int>((mysub >> link2) & 1u));
+				if (on == 0) return 0.0;
+				const real jr = dx * (-(y - mypy)) + dy * (x - mypx);
+				return on > 0 ? jr : -jr;
 			};
 			int r0 = 0;
 			for (; r0 + 4 <= R + 1; r0 += 4) {
@@ -650,7 +705,7 @@ struct FastPath {
 				u = s * dinv;
 			}
 			u = utsolve_regs<D>(hrow, u);
-			if (lane < D) { const real v = ws.st.qd[lane] + u; ws.st.qd[lane] = v; ws.st.q[lane] += h * v; }
+			if (lane < D) { const real v = clamp_turn_rate(ws.st.qd[lane] + u, lane, h); ws.st.qd[lane] = v; ws.st.q[lane] += h * v; }
 			__syncthreads();
 			PROF_ADD(ws, kProfFinish);
 		}
@@ -682,7 +737,7 @@ struct FastPath {
 	{
 		const ContactPts cp = eval_points<true>(ws, gm, g);
 		contact_bits_fast(ws, cp.f0, cp.f1, cp.f2);
-		build_rows_fast(ws, cp, h);
+		build_rows_fast(ws, gm, cp, h);
 		if (threadIdx.x == 0) ws.n_pts_active = ws.R;
 		__syncthreads();
 	}

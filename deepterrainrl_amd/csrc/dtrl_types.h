@@ -28,6 +28,7 @@ constexpr int kSegCap = 512;     // floats per heightfield segment slot (51 m at
 constexpr int kNumGroundSamples = 200;
 constexpr int kMaxFrags = 4;
 constexpr int kMaxPairs = kMaxL * kMaxDepth;
+constexpr int kMaxCP = 64;      // link--link collision pairs (dog 34, raptor 51); one lane per pair in the wave-wide proximity test
 
 // Integrator v1 constants (DESIGN.md "Integrator v1"; mirrored by oracle/or_sim.h SimConst)
 constexpr real kErp = 0.2;
@@ -38,6 +39,7 @@ constexpr real kLimitErp = 0.2;
 constexpr real kLimitSlop = 0.005;
 constexpr int kPgsIters = 10;
 constexpr real kGravityY = -9.8;
+constexpr real kMaxTurnPerSubstep = 1.5707963267948966;   // Bullet clamps a body's angular velocity so that it turns at most MAX_ANGVEL = pi / 2 per internal step (btRigidBody::integrateVelocities); here: every hinge rate and the root's spin
 
 enum Scenario { kScnSimChar = 0, kScnExp = 1, kScnPoliEval = 2 };
 
@@ -76,6 +78,16 @@ struct DevModel {
 	real init_pos_x, target_vel_x, total_mass;
 	real world_scale;
 	real contact_tol;                       // cContactManager::Update: a link is in contact when a point is within 0.001 (world-scaled units) of the surface = 0.001 / world_scale
+	// link--link collisions: links of one collision group that no hinge joins and whose boxes overlap in z collide with each other in the reference
+	// (GetPartColGroup == GetPartColMask, sim/SimDog.cpp:73-81, sim/SimRaptor.cpp; only constraint-linked bodies are excluded: sim/World.cpp:626 with
+	// sim/SimCharacter.cpp:864). cp_a < cp_b; cp_half = the box half extents the wave-wide overlap pre-test uses, grown by contact_tol. The pre-test
+	// takes a box's orientation from its joint frame; the ROOT's box may be rotated against it (dog / goat: 0.61 rad) by cp_root_bt = (cos, sin); any
+	// other link with a rotated box is replaced by the square around its bounding circle (conservative)
+	int32_t link_contacts, n_cpairs;
+	int8_t cp_a[kMaxCP], cp_b[kMaxCP];
+	float cp_half[kMaxL][2];
+	float cp_root_bt[2];
+	real bt_cs[kMaxL], bt_sn[kMaxL];        // cos / sin of body_theta (box frame against the joint frame)
 };
 
 // exploration knobs + seeds: may change between launches (dtrl_set_explore)

@@ -200,6 +200,24 @@ void ref_scn_set_contacts(void* h, int n, const int* link, const double* dist)
 		d->m_manifolds.push_back(m);
 	}
 }
+// appends link--link manifolds (body0 = part a, body1 = part b) behind the ground manifolds of ref_scn_set_contacts: what Bullet's narrowphase reports for
+// links of one collision group. The reference's cContactManager must not turn them into contact flags (parts are registered with filter
+// eContactFlagEnvironment, scenarios/ScenarioSimChar.cpp:321; cContactManager::IsValidContact, sim/ContactManager.cpp:169-175)
+void ref_scn_add_pair_contacts(void* h, int n, const int* link_a, const int* link_b, const double* dist)
+{
+	RefScn* s = static_cast<RefScn*>(h);
+	const auto& c = s->scn->GetCharacter();
+	btDispatcher* d = s->scn->GetWorld()->GetInternalWorld()->getDispatcher();
+	const double scale = s->scn->GetWorld()->GetScale();
+	for (int k = 0; k < n; ++k) {
+		btPersistentManifold m;
+		m.m_body0 = c->GetBodyPart(link_a[k])->GetRigidBody().get();
+		m.m_body1 = c->GetBodyPart(link_b[k])->GetRigidBody().get();
+		btManifoldPoint p; p.m_distance1 = static_cast<btScalar>(dist[k] * scale);
+		m.m_points.push_back(p);
+		d->m_manifolds.push_back(m);
+	}
+}
 void ref_scn_get_contact_flags(void* h, int* flags)
 {
 	RefScn* s = static_cast<RefScn*>(h);

@@ -1,12 +1,13 @@
 // Stand-in (test infrastructure, see ../../btBulletDynamicsCommon.h): the heightfield keeps the caller's data pointer, dimensions, height range
 // and local scaling; getAabb() returns the scaled box centred on the origin the way Bullet centres heightfields (half extents = (width-1)/2 etc.
-// times the scaling, vertical range centred on (min+max)/2) plus the collision margin.
+// times the scaling, vertical range centred on (min+max)/2) plus the collision margin -- which is 0 for concave shapes: btConcaveShape keeps its
+// own m_collisionMargin, initialised to 0 (unlike the convex shapes' CONVEX_DISTANCE_MARGIN 0.04), and btHeightfieldTerrainShape never sets it.
 #pragma once
 #include "btBulletDynamicsCommon.h"
 class btHeightfieldTerrainShape : public btConcaveShape {
 public:
 	btHeightfieldTerrainShape(int heightStickWidth, int heightStickLength, const void* data, btScalar heightScale, btScalar minHeight, btScalar maxHeight, int upAxis, PHY_ScalarType, bool flipQuadEdges)
-		: m_w(heightStickWidth), m_l(heightStickLength), m_data(data), m_hscale(heightScale), m_min(minHeight), m_max(maxHeight), m_up(upAxis), m_flip(flipQuadEdges) {}
+		: m_w(heightStickWidth), m_l(heightStickLength), m_data(data), m_hscale(heightScale), m_min(minHeight), m_max(maxHeight), m_up(upAxis), m_flip(flipQuadEdges) { m_margin = 0; }
 	void getAabb(const btTransform& t, btVector3& mn, btVector3& mx) const override
 	{
 		btVector3 half(btScalar(0.5) * (m_w - 1), btScalar(0.5) * (m_max - m_min), btScalar(0.5) * (m_l - 1));

@@ -115,6 +115,12 @@ void orc_stats(void* p, int64_t* resets, int64_t* cycles, int64_t* episodes, dou
 }
 // cCharController::CommandAction: replaces whatever is queued (the reference keeps a stack; the scenarios only ever queue one)
 void orc_command_action(void* p, int a) { Env& e = static_cast<OrcHandle*>(p)->env; e.commands.clear(); e.commands.push_back(a); }
+void orc_pair_distances(void* p, double* out)
+{
+	Env& e = static_cast<OrcHandle*>(p)->env;
+	ForwardKin(e.M, e.q, e.qd, e.B);
+	PairDistances(e.M, e.B, out);
+}
 void orc_frame_end(void* p) { static_cast<OrcHandle*>(p)->env.FrameEnd(); }
 // signed separation of every contact sample point [L * 6] at the current configuration (what a narrowphase would report as manifold distances)
 void orc_contact_distances(void* p, double* out)

@@ -29,7 +29,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_ref", "libdtrl_oracle.so")
 
-MAXL, MAXD, MAXP, MAXSETS, MAXACT, MAXTP = 24, 26, 40, 8, 16, 4
+MAXL, MAXD, MAXP, MAXSETS, MAXACT, MAXTP, MAXCP = 24, 26, 40, 8, 16, 4, 64
 
 
 class OrcModel(C.Structure):
@@ -58,6 +58,7 @@ class OrcModel(C.Structure):
         ("terrain_params", (C.c_double * 40) * MAXTP), ("terrain_blend", C.c_double),
         ("scenario", C.c_int32), ("tuple_buffer_size", C.c_int32), ("enable_explore", C.c_int32),
         ("exp_rate", C.c_double), ("exp_temp", C.c_double), ("exp_base_rate", C.c_double),
+        ("link_contacts", C.c_int32), ("n_cpairs", C.c_int32), ("cpair_a", C.c_int32 * MAXCP), ("cpair_b", C.c_int32 * MAXCP),
     ]
 
 
@@ -210,6 +211,25 @@ def build_model(arg_file, root, overrides=None):
         assert L == 19
         for j in range(L):
             m.col_group[j] = RAPTOR_COL[j]
+    # link--link collision pairs (sim/SimDog.cpp:73-81, sim/SimRaptor.cpp; sim/World.cpp:626): same non-zero collision group, not joined by a hinge, and
+    # overlapping in z (joint attach z accumulated down the chain + body attach z, box depth Param2): the raptor's two legs share a group but sit
+    # 0.16 m apart in z with 0.065 m deep boxes, so they pass each other freely
+    zpos = [0.0] * L
+    for j in range(L):
+        p = m.parent[j]
+        zpos[j] = (zpos[p] if p >= 0 else 0.0) + float(joints[j].get("AttachZ", 0))
+    zc = [zpos[j] + float(bodies[j].get("AttachZ", 0)) for j in range(L)]
+    n = 0
+    for a in range(L):
+        for b in range(a + 1, L):
+            if m.col_group[a] == 0 or m.col_group[a] != m.col_group[b] or m.parent[b] == a or m.parent[a] == b:
+                continue
+            if abs(zc[a] - zc[b]) >= 0.5 * (m.body_size[a][2] + m.body_size[b][2]):
+                continue
+            assert n < MAXCP
+            m.cpair_a[n] = a; m.cpair_b[n] = b; n += 1
+    m.n_cpairs = n
+    m.link_contacts = int(args.get("link_contacts", 1))
     ctrl = char["Controllers"]
     files = ctrl["Files"]
     m.n_sets = len(files)
@@ -414,6 +434,7 @@ def lib():
         L.orc_frame_end.argtypes = [C.c_void_p]
         L.orc_command_action.argtypes = [C.c_void_p, C.c_int]
         L.orc_contact_distances.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_pair_distances.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_time.restype = C.c_double; L.orc_time.argtypes = [C.c_void_p]
         L.orc_dist_log.restype = C.c_int
         L.orc_dist_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -514,6 +535,12 @@ class OracleEnv:
 
     def contact_distances(self):
         d = np.zeros((self.L, 6)); self.L_.orc_contact_distances(self.h, _p(d)); return d
+
+    def pair_distances(self):
+        """(pairs [n, 2], smallest separation of each link--link collision pair [n]; negative = overlapping)"""
+        n = self.m.n_cpairs
+        d = np.zeros(max(n, 1)); self.L_.orc_pair_distances(self.h, _p(d))
+        return np.array([(self.m.cpair_a[i], self.m.cpair_b[i]) for i in range(n)], np.int32).reshape(n, 2), d[:n]
 
     def dist_log(self):
         buf = np.zeros(4096); n = self.L_.orc_dist_log(self.h, _p(buf), 4096); return buf[:n].copy()

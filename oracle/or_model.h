@@ -12,6 +12,7 @@
 #define ORC_MAXSETS 8
 #define ORC_MAXACT 16
 #define ORC_MAXTP 4
+#define ORC_MAXCP 64
 
 extern "C" {
 
@@ -56,6 +57,11 @@ struct OrcModel {
 	int32_t tuple_buffer_size;
 	int32_t enable_explore;
 	double exp_rate, exp_temp, exp_base_rate;
+	// link--link collision pairs: links of one collision group that no hinge joins and whose boxes overlap in z collide with each other in the
+	// reference (cSimDog::GetPartColGroup == GetPartColMask, sim/SimDog.cpp:73-81; only constraint-linked bodies are excluded, sim/World.cpp:626,
+	// sim/SimCharacter.cpp:864). a < b. link_contacts = 0 switches the pair contacts off (the round-1 model)
+	int32_t link_contacts, n_cpairs;
+	int32_t cpair_a[ORC_MAXCP], cpair_b[ORC_MAXCP];
 };
 
 // MACE network family of data/policies/*/nets/*_mace3_deploy.prototxt

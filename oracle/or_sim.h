@@ -40,6 +40,7 @@ struct SimConst {
 	static constexpr int pts_per_link = 6;
 	static constexpr int max_pts_per_link = 4;      // points of one link--ground manifold
 	static constexpr double contact_dist_tol = 0.001;   // world-scaled units (sim/ContactManager.cpp:74)
+	static constexpr double max_turn_per_substep = 1.5707963267948966;
 };
 
 struct Bodies {
@@ -93,6 +94,16 @@ inline void LinkSamplePoint(const OrcModel& M, int j, int k, double& sx, double&
 }
 
 struct ContactPoint { int link; double x, y, depth, nx, ny; };
+
+// separation of a world point from box `q` (negative inside): max over the two face pairs of (|local coordinate| - half extent); *lx, *ly = local coordinates
+inline void PointInBox(const OrcModel& M, const Bodies& B, int q, double x, double y, double& pen_x, double& pen_y, double& lx, double& ly)
+{
+	const double c = std::cos(B.psi[q]), s = std::sin(B.psi[q]);
+	const double dx = x - B.cx[q], dy = y - B.cy[q];
+	lx = c * dx + s * dy; ly = -s * dx + c * dy;
+	pen_x = 0.5 * M.body_size[q][0] - std::fabs(lx);
+	pen_y = 0.5 * M.body_size[q][1] - std::fabs(ly);
+}
 
 // signed separation (negative = penetration) of every contact sample point from the heightfield, along the cell normal; +inf for links that collide with nothing
 inline void ContactDistances(const OrcModel& M, const Bodies& B, const Ground& g, double* out)
@@ -168,6 +179,64 @@ inline int DetectContacts(const OrcModel& M, const Bodies& B, const Ground& g, C
 	return n;
 }
 
+// ---- link--link contacts (same collision group, no hinge between them): the sample points of either box tested against the other box ----
+struct PairContact { int a, b; double x, y, depth, nx, ny; };   // the normal pushes link a along +n and link b along -n
+// candidates of pair (a, b) in the order: a's six sample points against b's box, then b's six against a's. Returns the number of penetrating candidates
+// written to cand (<= 12); *min_sep (may be null) = the smallest separation of any candidate point from the partner's box (what a narrowphase would
+// report as the pair manifold's distance). Link--link contacts never set a link's contact FLAG: cScenarioSimChar registers the character's parts with
+// filter eContactFlagEnvironment (scenarios/ScenarioSimChar.cpp:321), so cContactManager::IsValidContact (sim/ContactManager.cpp:169-175) drops them
+inline int PairCandidates(const OrcModel& M, const Bodies& B, int a, int b, PairContact* cand, double* min_sep)
+{
+	int n = 0;
+	for (int side = 0; side < 2; ++side) {
+		const int P = side == 0 ? a : b, Q = side == 0 ? b : a;
+		const double cp = std::cos(B.psi[P]), sp = std::sin(B.psi[P]);
+		const double cq = std::cos(B.psi[Q]), sq = std::sin(B.psi[Q]);
+		for (int k = 0; k < SimConst::pts_per_link; ++k) {
+			double sx, sy; LinkSamplePoint(M, P, k, sx, sy);
+			const double x = B.cx[P] + cp * sx - sp * sy, y = B.cy[P] + sp * sx + cp * sy;
+			double px, py, lx, ly; PointInBox(M, B, Q, x, y, px, py, lx, ly);
+			if (min_sep) *min_sep = std::min(*min_sep, std::max(-px, -py));
+			if (!(px > 0 && py > 0)) continue;
+			// push the point out through the nearest face of Q
+			double nlx = 0, nly = 0, depth;
+			if (px <= py) { nlx = lx >= 0 ? 1.0 : -1.0; depth = px; } else { nly = ly >= 0 ? 1.0 : -1.0; depth = py; }
+			PairContact& c = cand[n++];
+			c.a = P; c.b = Q; c.x = x; c.y = y; c.depth = depth;
+			c.nx = cq * nlx - sq * nly; c.ny = sq * nlx + cq * nly;
+		}
+	}
+	return n;
+}
+// smallest candidate separation of every pair [n_cpairs] (lock-step tests hand these to the reference as link--link manifolds)
+inline void PairDistances(const OrcModel& M, const Bodies& B, double* out)
+{
+	for (int pr = 0; pr < M.n_cpairs; ++pr) {
+		PairContact cand[2 * SimConst::pts_per_link];
+		out[pr] = 1e30;
+		PairCandidates(M, B, M.cpair_a[pr], M.cpair_b[pr], cand, &out[pr]);
+	}
+}
+// Link--link rows are velocity constraints WITHOUT a penetration-recovery term (v_n >= 0, friction as usual): the two links of a pair hang on one or two
+// hinges, a contact point can sit millimetres from the only axis that could separate them, and a Baumgarte target of 0.2 depth / h there asks for
+// thousands of rad/s (observed: |qd| > 2000 rad/s, then NaN). Bullet recovers penetration by split impulse, which adds no momentum either.
+// pair contacts in pair order; per pair the deepest max_pts_per_link candidates (ties: the earlier candidate), emitted in candidate order; at most `cap`
+inline int DetectPairContacts(const OrcModel& M, const Bodies& B, PairContact* out, int cap)
+{
+	if (!M.link_contacts) return 0;
+	int n = 0;
+	for (int pr = 0; pr < M.n_cpairs; ++pr) {
+		PairContact cand[2 * SimConst::pts_per_link];
+		const int nc = PairCandidates(M, B, M.cpair_a[pr], M.cpair_b[pr], cand, nullptr);
+		for (int i = 0; i < nc; ++i) {
+			int rank = 0;
+			for (int o = 0; o < nc; ++o) if (o != i && (cand[o].depth > cand[i].depth || (cand[o].depth == cand[i].depth && o < i))) ++rank;
+			if (rank < SimConst::max_pts_per_link && n < cap) out[n++] = cand[i];
+		}
+	}
+	return n;
+}
+
 // one substep. H and b (true bias, fix_cj) come from the caller's RBDModel evaluated at (q, qd).
 struct Integrator {
 	double Jr[SimConst::max_rows][ORC_MAXD];
@@ -239,6 +308,22 @@ struct Integrator {
 			PointJacobian(M, B, cp.link, cp.x, cp.y, cp.ny, -cp.nx, Jr[R], D);
 			kind[R] = 2; tgt[R] = 0; ++R;
 		}
+		// link--link contacts take what is left of the row budget, in pair order
+		PairContact pcs[SimConst::max_rows / 2];
+		const int npc = DetectPairContacts(M, B, pcs, (SimConst::max_rows - R) / 2);
+		for (int c = 0; c < npc; ++c) {
+			const PairContact& pc = pcs[c];
+			double jb[ORC_MAXD];
+			for (int t = 0; t < 2; ++t) {
+				const double dx = t == 0 ? pc.nx : pc.ny, dy = t == 0 ? pc.ny : -pc.nx;
+				PointJacobian(M, B, pc.a, pc.x, pc.y, dx, dy, Jr[R], D);
+				PointJacobian(M, B, pc.b, pc.x, pc.y, dx, dy, jb, D);
+				for (int i = 0; i < D; ++i) Jr[R][i] -= jb[i];
+				kind[R] = 1 + t;
+				tgt[R] = 0.0;   // velocity-level non-penetration only (see DetectPairContacts)
+				++R;
+			}
+		}
 		for (int r = 0; r < R; ++r) {
 			SolveLDLT(D, Hm, D, Jr[r], Yr[r]);
 			double a = 0; for (int i = 0; i < D; ++i) a += Jr[r][i] * Yr[r][i];
@@ -256,6 +341,10 @@ struct Integrator {
 				for (int i = 0; i < D; ++i) v[i] += Yr[r][i] * dl;
 			}
 		}
+		// Bullet clamps a body's angular velocity to MAX_ANGVEL = pi / 2 per internal step (btRigidBody::integrateVelocities); in joint coordinates: every hinge
+		// rate and the root's spin. 4712 rad/s at 1/3000 s: only the whipping tail of a crashed character gets there, and unclamped the explicit Coriolis terms overflow
+		const double vmax = SimConst::max_turn_per_substep / h;
+		for (int i = 2; i < D; ++i) v[i] = std::min(std::max(v[i], -vmax), vmax);
 		for (int i = 0; i < D; ++i) { qd[i] = v[i]; q[i] += h * v[i]; }
 	}
 };

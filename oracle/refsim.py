@@ -59,6 +59,7 @@ def lib(variant="f64"):
         L.ref_scn_command_action.argtypes = [vp, C.c_int]
         L.ref_scn_sample_ground.restype = C.c_double; L.ref_scn_sample_ground.argtypes = [vp, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.ref_scn_ground_segment.argtypes = [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ref_scn_add_pair_contacts.argtypes = [vp, C.c_int, vp, vp, vp]
         L.ref_scn_time.restype = C.c_double; L.ref_scn_time.argtypes = [vp]
         L.ref_scn_com.argtypes = [vp, vp, vp]
         L.ref_scn_drain_tuples.argtypes = [vp, vp, vp, C.c_int]
@@ -168,6 +169,10 @@ class RefScenario:
         buf = np.zeros(1024, np.float32); a, b = C.c_double(), C.c_double()
         n = lib(self.variant).ref_scn_ground_segment(self.h, slot, _p(buf), 1024, C.byref(a), C.byref(b)); return buf[:n].copy(), a.value, b.value
 
+    def add_pair_contacts(self, pairs, dists):
+        a = np.ascontiguousarray(pairs[:, 0], np.int32); b = np.ascontiguousarray(pairs[:, 1], np.int32); d = np.ascontiguousarray(dists, np.float64)
+        lib(self.variant).ref_scn_add_pair_contacts(self.h, len(d), _p(a), _p(b), _p(d))
+
     def time(self): return lib(self.variant).ref_scn_time(self.h)
 
     def com(self):
@@ -218,6 +223,11 @@ class LockStep:
         d = e.contact_distances()
         links, dists = np.nonzero(d < self.band)[0], d[d < self.band]
         self.ref.set_contacts(links, dists)
+        pairs, pd = e.pair_distances()                      # link--link manifolds go in as well: the reference's contact manager has to ignore them
+        near = pd < self.band
+        self.n_pair_manifolds = getattr(self, "n_pair_manifolds", 0) + int((pd < 0.001 / e.m.world_scale).sum())
+        if near.any():
+            self.ref.add_pair_contacts(pairs[near], pd[near])
         self.snap = self._oracle_snapshot()
         self.k += 1
 

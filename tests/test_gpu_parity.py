@@ -478,3 +478,7 @@ def test_packed_drain_equals_plain_drain(om):
     import test_boundary as B
     import deepterrainrl_amd as da_mod
     B.run_packed_drain_equals_plain_drain(da_mod.BatchScenario, om, to_ptr=lambda t: t.data_ptr(), read=lambda t: t.cpu().numpy())
+
+
+def test_link_link_contacts(da, om):
+    T.test_link_link_contacts_vs_oracle(da, om)

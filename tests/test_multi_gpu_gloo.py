@@ -86,8 +86,10 @@ dist.barrier(); dist.destroy_process_group()
 
 def test_two_rank_training_equals_single_process(tmp_path, da):
     """Rollout shards + tuple gather + trainer on rank 0 + policy broadcast (gloo, world size 2) == train() in one process, bit for bit."""
+    # (identity input normaliser: estimated from 30 tuples instead of the file's 50 000, a near-constant terrain feature gets a scale of 1e9 and the float32
+    # net overflows on the first batch -- cNeuralNet::CalcOffsetScale has no floor either; the normaliser itself is covered by tests/test_trainer.py)
     extra = {"terrain_seed": 3, "trainer_num_init_samples": 30, "trainer_replay_mem_size": 512, "trainer_freeze_target_iters": 4,
-             "init_exp_rate": 0.3, "init_exp_base_rate": 0.1}
+             "init_exp_rate": 0.3, "init_exp_base_rate": 0.1, "trainer_init_input_offset_scale": "false"}
     script = tmp_path / "train_worker.py"
     script.write_text(TRAIN_WORKER.format(repo=REPO, out=str(tmp_path), extra=extra))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
@@ -106,7 +108,7 @@ def test_two_rank_training_equals_single_process(tmp_path, da):
     assert r.returncode == 0, r.stderr[-3000:]
     s1 = np.load(tmp_path / "single_train.npz")
     assert int(d["iters"]) == int(s1["iters"]) >= 1 and int(d["tuples"]) == int(s1["tuples"])
-    assert np.array_equal(d["weights"], s1["weights"]) and np.array_equal(d["in_off"], s1["in_off"])
+    assert np.array_equal(d["weights"], s1["weights"]) and np.array_equal(d["in_off"], s1["in_off"]) and np.all(np.isfinite(d["weights"]))
 
 
 def test_shard_range():
