@@ -607,7 +607,7 @@ DTRL_HD_INLINE bool pair_in_reach(const W& ws, int pr)
 }
 // candidate c (0..11) of a pair: a's six sample points against b, then b's six against a
 DTRL_HD_INLINE void pair_candidate(int a, int b, int c, int* P, int* Q, int* k) { const int side = c >= kPtsPerLink ? 1 : 0; *P = side ? b : a; *Q = side ? a : b; *k = c - side * kPtsPerLink; }
-// append the link--link contact rows behind the ground rows (serial form): per pair the deepest kMaxPtsPerLink penetrating candidates (ties: the earlier
+// append the link--link contact rows behind the ground rows (serial form): per pair the deepest kMaxPtsPerPair penetrating candidates (ties: the earlier
 // candidate), in candidate order, while rows are left
 template <class W>
 DTRL_HD inline int append_pair_rows_serial(W& ws, const DevModel& gm, int R)
@@ -621,7 +621,7 @@ DTRL_HD inline int append_pair_rows_serial(W& ws, const DevModel& gm, int R)
 			if (!hit[c].active) continue;
 			int rank = 0;
 			for (int o = 0; o < 2 * kPtsPerLink; ++o) if (o != c && hit[o].active && (hit[o].depth > hit[c].depth || (hit[o].depth == hit[c].depth && o < c))) ++rank;
-			if (rank >= kMaxPtsPerLink) continue;
+			if (rank >= kMaxPtsPerPair) continue;
 			int P, Q, k; pair_candidate(a, b, c, &P, &Q, &k);
 			// (velocity-level non-penetration only, no recovery term: a contact point can sit millimetres from the only hinge axis that could separate
 			// the two links, where 0.2 depth / h asks for thousands of rad/s; Bullet recovers penetration by split impulse, momentum-free as well)

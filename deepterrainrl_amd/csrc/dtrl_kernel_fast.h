@@ -354,7 +354,7 @@ __device__ __forceinline__ unsigned long long pairs_in_reach(const WSFast& ws)
 }
 // twelve candidates per pair, five pairs per pass (60 of the 64 lanes): the table reads of a pass travel together, the lane order (pair ascending, candidate
 // ascending) is the serial order, so the ballots give the same row positions and the same cut when the row budget runs out.
-// A pair rarely has more than kMaxPtsPerLink penetrating candidates: the depth ranking (two barriers, an LDS round trip) only runs when one does.
+// When a pair has more than kMaxPtsPerPair penetrating candidates the depth ranking (two barriers, an LDS round trip) only runs when one does.
 // (Link--link contacts carry constraint rows but never set a link's contact flag: scenarios/ScenarioSimChar.cpp:321, sim/ContactManager.cpp:169-175.)
 constexpr int kPairCands = 2 * kPtsPerLink, kPairSlots = kGroup / kPairCands;
 __device__ __noinline__ int append_pair_rows_fast(WSFast& ws, const DevModel& gm, int R, unsigned long long reach)
@@ -375,14 +375,14 @@ __device__ __noinline__ int append_pair_rows_fast(WSFast& ws, const DevModel& gm
 		if (am == 0ull) continue;
 		int keep = hit.active;
 		const int mine_cnt = __popcll((am >> (slot * kPairCands)) & ((1ull << kPairCands) - 1ull));
-		if (__builtin_expect(__ballot(lane < kPairSlots * kPairCands && mine_cnt > kMaxPtsPerLink) != 0ull, 0)) {
+		if (__builtin_expect(__ballot(lane < kPairSlots * kPairCands && mine_cnt > kMaxPtsPerPair) != 0ull, 0)) {
 			real* S = ws.Apk;   // (dead between the factorisation and the Delassus build, like in link_cap_drop_mask())
 			S[lane] = hit.active ? hit.depth : -1.0;
 			__syncthreads();
 			if (hit.active) {
 				int rank = 0;
 				for (int o = 0; o < kPairCands; ++o) { const real od = S[slot * kPairCands + o]; rank += (o != cand && od > 0 && (od > hit.depth || (od == hit.depth && o < cand))) ? 1 : 0; }
-				keep = rank < kMaxPtsPerLink;
+				keep = rank < kMaxPtsPerPair;
 			}
 			__syncthreads();
 		}

@@ -23,6 +23,7 @@ constexpr int kMaxDepth = 12;    // longest root->link path (dog: 10)
 constexpr int kMaxRows = 24;     // constraint rows per substep (joint limits + 2 per contact point)
 constexpr int kPtsPerLink = 6;   // contact sample points per box link (4 corners + 2 long-edge midpoints)
 constexpr int kMaxPtsPerLink = 4;  // constraint-carrying points of one link--ground pair (Bullet's persistent manifold holds 4): the deepest ones
+constexpr int kMaxPtsPerPair = 2;  // constraint-carrying points of one link--link pair: in the plane two convex boxes touch along a segment at most, i.e. two points (the four points of Bullet's 3-D box--box manifold project onto two)
 constexpr int kMaxPts = kMaxL * kPtsPerLink;
 constexpr int kSegCap = 512;     // floats per heightfield segment slot (51 m at 0.1 m spacing)
 constexpr int kNumGroundSamples = 200;

@@ -39,6 +39,7 @@ struct SimConst {
 	static constexpr int max_rows = 24;
 	static constexpr int pts_per_link = 6;
 	static constexpr int max_pts_per_link = 4;      // points of one link--ground manifold
+	static constexpr int max_pts_per_pair = 2;      // points of one link--link manifold: two convex boxes in the plane touch along a segment at most (Bullet's four 3-D manifold points project onto two)
 	static constexpr double contact_dist_tol = 0.001;   // world-scaled units (sim/ContactManager.cpp:74)
 	static constexpr double max_turn_per_substep = 1.5707963267948966;
 };
@@ -220,7 +221,7 @@ inline void PairDistances(const OrcModel& M, const Bodies& B, double* out)
 // Link--link rows are velocity constraints WITHOUT a penetration-recovery term (v_n >= 0, friction as usual): the two links of a pair hang on one or two
 // hinges, a contact point can sit millimetres from the only axis that could separate them, and a Baumgarte target of 0.2 depth / h there asks for
 // thousands of rad/s (observed: |qd| > 2000 rad/s, then NaN). Bullet recovers penetration by split impulse, which adds no momentum either.
-// pair contacts in pair order; per pair the deepest max_pts_per_link candidates (ties: the earlier candidate), emitted in candidate order; at most `cap`
+// pair contacts in pair order; per pair the deepest max_pts_per_pair candidates (ties: the earlier candidate), emitted in candidate order; at most `cap`
 inline int DetectPairContacts(const OrcModel& M, const Bodies& B, PairContact* out, int cap)
 {
 	if (!M.link_contacts) return 0;
@@ -231,7 +232,7 @@ inline int DetectPairContacts(const OrcModel& M, const Bodies& B, PairContact* o
 		for (int i = 0; i < nc; ++i) {
 			int rank = 0;
 			for (int o = 0; o < nc; ++o) if (o != i && (cand[o].depth > cand[i].depth || (cand[o].depth == cand[i].depth && o < i))) ++rank;
-			if (rank < SimConst::max_pts_per_link && n < cap) out[n++] = cand[i];
+			if (rank < SimConst::max_pts_per_pair && n < cap) out[n++] = cand[i];
 		}
 	}
 	return n;
