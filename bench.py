@@ -231,7 +231,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: dog + GroundVar2D slopes_mixed, %d envs per MI355X, ImpPD + MACE actor/critic forward, poli_eval (args/dog_slopes_mixed_args.txt)" % n,
                        "envs_per_gpu": n, "global_envs": n * world, "env_steps_per_step": n * world * steps_per_frame,
-                       "substeps_per_env_step": 5, "parallelism": "env-sharded x%d, no data-path collective" % world, "terrain_gen": a.terrain_gen},
+                       "substeps_per_env_step": 5, "parallelism": "env-sharded x%d, no data-path collective" % world, "terrain_gen": a.terrain_gen, "link_contacts": 1},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": float(traffic) if traffic else None, "traffic_source": traffic_source,
                          "kernel": "dtrl_frame_kernel", "kernel_avg_ms": kern_ms, "kernel_launches": launches,

@@ -35,13 +35,13 @@ public:
 
 	// cScenarioSimChar::ParseArgs + cScenarioExp::ParseArgs (scenarios/ScenarioSimChar.cpp:76-108, scenarios/ScenarioExp.cpp:31-45): the engine parses
 	// the same keys itself, so they are forwarded as "-key= value" pairs. Extra keys (data_root, terrain_seed, rand_seed, global_env_offset,
-	// tuple_ring_capacity, terrain_gen) pass through when present.
+	// tuple_ring_capacity, terrain_gen, link_contacts) pass through when present.
 	virtual void ParseArgs(const cArgParser& parser)
 	{
 		static const char* const keys[] = {"scenario", "character_file", "state_file", "char_type", "char_ctrl", "terrain_file", "terrain_blend",
 			"world_scale", "num_update_steps", "num_sim_substeps", "char_init_pos_x", "policy_net", "policy_model", "critic_net", "critic_model",
 			"tuple_buffer_size", "exp_rate", "exp_temp", "exp_base_rate", "min_perturb", "max_perturb", "min_pertrub_duration", "max_perturb_duration",
-			"data_root", "terrain_seed", "rand_seed", "global_env_offset", "tuple_ring_capacity", "terrain_gen"};
+			"data_root", "terrain_seed", "rand_seed", "global_env_offset", "tuple_ring_capacity", "terrain_gen", "link_contacts"};
 		mArgs.clear();
 		for (size_t i = 0; i < sizeof(keys) / sizeof(keys[0]); ++i) {
 			std::string val;
