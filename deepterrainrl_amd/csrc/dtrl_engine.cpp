@@ -336,7 +336,8 @@ int Engine::DrainDeviceDistLog()
 	be_->Sync();
 	int32_t cnt = 0;
 	if (!be_->D2H(&cnt, buf_.dist_count, sizeof(cnt))) return Fail(DTRL_ERR_DEVICE, be_->error());
-	if (cnt > buf_.dist_cap) return Fail(DTRL_ERR_CAPACITY, "episode distance ring overflowed: call dtrl_get_dist_log more often");
+	const bool overflow = cnt > buf_.dist_cap;   // the ring keeps the first dist_cap records of the interval; the rest were counted, not stored
+	if (overflow) cnt = buf_.dist_cap;
 	if (cnt > 0) {
 		std::vector<DistRec> tmp(cnt);
 		if (!be_->D2H(tmp.data(), buf_.dist_ring, sizeof(DistRec) * cnt)) return Fail(DTRL_ERR_DEVICE, be_->error());
@@ -344,6 +345,7 @@ int Engine::DrainDeviceDistLog()
 		const int32_t zero = 0;
 		if (!be_->H2D(buf_.dist_count, &zero, sizeof(zero))) return Fail(DTRL_ERR_DEVICE, be_->error());
 	}
+	if (overflow) return Fail(DTRL_ERR_CAPACITY, "episode distance ring overflowed (records beyond its capacity were dropped): call dtrl_get_dist_log more often");
 	return DTRL_OK;
 }
 
