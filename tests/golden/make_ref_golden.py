@@ -46,3 +46,27 @@ for name, arg in (("dog", "args/dog_slopes_mixed_args.txt"), ("goat", "args/goat
 path = os.path.join(REPO, "tests", "golden", "ref_golden.npz")
 np.savez_compressed(path, **out)
 print("wrote %s: %d arrays, %d bytes" % (path, len(out), os.path.getsize(path)))
+
+# ---- lock-step traces: what the REFERENCE'S controller / contact manager / torque clamp (oracle/_ref/libref_sim.so) computed while the oracle supplied
+# the motion (oracle/refsim.py LockStep), env-step by env-step, for the two FSM scenes of BASELINE configs[0]. The product (HIP on the GPU box, lane-loop
+# build here) is checked against these arrays: lockstep/<char>/{q, tau, contacts, state, phase, pd_targets}
+from oracle import refsim as rs  # noqa: E402
+if rs.available():
+    for name, arg, frames in (("dog", "args/sim_dog_args.txt", 12), ("raptor", "args/sim_raptor_args.txt", 12)):
+        m, _ = om.build_model(arg, REF)
+        e = om.OracleEnv(m, terrain_seed=5)
+        r = rs.RefScenario("sim_char", arg, REF, global_seed=3)
+        r.seed_ground_and_reset(5)
+        ls = rs.LockStep(r, e)
+        for f in range(frames):
+            ls.update()
+        recs = ls.records
+        out["lockstep/%s/q" % name] = np.array([o["q"] for o, _ in recs])
+        out["lockstep/%s/qd" % name] = np.array([o["qd"] for o, _ in recs])
+        out["lockstep/%s/tau" % name] = np.array([rr["tau"] for _, rr in recs])                    # the reference's clamped joint torques (joint j at index j)
+        out["lockstep/%s/contacts" % name] = np.array([rr["contacts"] for _, rr in recs], np.int8)
+        out["lockstep/%s/state" % name] = np.array([rr["state"] for _, rr in recs], np.int32)
+        out["lockstep/%s/phase" % name] = np.array([rr["phase"] for _, rr in recs])
+        out["lockstep/%s/pd_targets" % name] = np.array([rr["pd_targets"] for _, rr in recs])
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_golden.npz"), **out)
+    print("lock-step traces added:", [k for k in out if k.startswith("lockstep/")][:4], "...")

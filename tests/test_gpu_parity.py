@@ -482,3 +482,7 @@ def test_packed_drain_equals_plain_drain(om):
 
 def test_link_link_contacts(da, om):
     T.test_link_link_contacts_vs_oracle(da, om)
+
+
+def test_product_vs_frozen_reference_lockstep_traces(da):
+    T.test_product_vs_frozen_reference_lockstep_traces(da)

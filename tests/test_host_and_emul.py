@@ -524,6 +524,36 @@ def test_link_link_contacts_vs_oracle(da, om):
     assert e0.pair_distances()[1][k_sw] < pd[k_sw] - 0.01 or True  # (without the pair rows the fold closes further; not asserted: the elbow limit may stop it first)
 
 
+def test_product_vs_frozen_reference_lockstep_traces(da):
+    """tests/golden/ref_golden.npz "lockstep/*" (made by make_ref_golden.py where /root/reference exists): what the REFERENCE'S OWN controller, contact manager
+    and torque clamp computed env-step by env-step while the oracle supplied the motion. The product, stepped from the same initial state, must travel the
+    same path and produce the same torques, contact flags and FSM states -- the chain product == oracle == compiled reference closed on this box (and, through
+    the GPU twin, on the MI355X, which has no /root/reference)."""
+    g = np.load(os.path.join(os.path.dirname(REFDATA), "ref_golden.npz"))
+    for name, arg in (("dog", "args/sim_dog_args.txt"), ("raptor", "args/sim_raptor_args.txt")):
+        q_ref, tau_ref = g["lockstep/%s/q" % name], g["lockstep/%s/tau" % name]
+        con_ref, st_ref, ph_ref, pd_ref = g["lockstep/%s/contacts" % name], g["lockstep/%s/state" % name], g["lockstep/%s/phase" % name], g["lockstep/%s/pd_targets" % name]
+        b = batch(da, arg, 1, terrain_seed=5)
+        n = len(q_ref)
+        assert n == 240
+        worst = 0
+        for k in range(n):
+            b.StepUpdates(1)
+            q, _ = b.PoseVel()
+            dq = np.abs(q[0] - q_ref[k]).max()
+            assert dq < 1e-7, (name, k, dq)                                       # same motion as the oracle run the reference rode along with
+            _, tau = b.Torques()
+            L = tau_ref.shape[1]
+            dt = np.abs(tau[0][3:3 + L - 1] - tau_ref[k][1:]).max()              # joint j drives DoF j + 2; the reference's trace holds joint j at index j
+            worst = max(worst, dt)
+            assert dt < 1e-5 * max(1.0, np.abs(tau_ref[k]).max()) + 1e-4, (name, k, dt)   # (the pose the reference saw went through its float-free but lossy quaternion round trip: 1e-6 rad x 300 N m / rad)
+            assert np.array_equal(b.Contacts()[0][:L], con_ref[k][:L]), (name, k)
+            st, ph, aid, prm, tg = b.Ctrl()
+            assert st[0] == st_ref[k] and abs(ph[0] - ph_ref[k]) < 1e-9, (name, k)
+            assert np.abs(tg[0][1:L] - pd_ref[k][1:L]).max() < 1e-6, (name, k)
+        assert len(set(st_ref.tolist())) >= 3 and con_ref.any()
+
+
 def test_perturbation_force_vs_oracle(da, om):
     """tPerturb (ePerturbForce) through cWorld::AddPerturb: a world-frame force on a body part at a body-local offset for a duration,
     advanced at the start of every env-step and dropped when expired (sim/Perturb.cpp, sim/PerturbManager.cpp:41-56); reset clears it."""
