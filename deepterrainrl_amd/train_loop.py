@@ -32,6 +32,19 @@ def parse_arg_file(path):
     return out
 
 
+def _make_trainer(args, data_root, train_net, solver, b, tkw):
+    """cScenarioTrain::BuildTrainer and its subclasses: *_mace controllers train with cMACETrainer, -char_ctrl= dog / raptor (the Q controllers,
+    scenarios/ScenarioSimChar.cpp:421-430) with cQNetTrainer, *_cacla with cCaclaTrainer (scenarios/ScenarioTrainCacla.cpp:21-52: -policy_* name the
+    ACTOR, -critic_* the critic the trainer steps first)."""
+    ctrl = args.get("char_ctrl", "")
+    if ctrl.endswith("_cacla"):
+        c_solver = os.path.join(data_root, args["critic_solver"])
+        m = re.search(r'net:\s*"([^"]+)"', open(c_solver).read())
+        c_train = os.path.join(data_root, m.group(1)) if m else os.path.join(data_root, args["critic_net"].replace("_deploy", "_train"))
+        return CaclaTrainer(c_train, c_solver, train_net, solver, b.S, b.A, **tkw)
+    return (QNetTrainer if ctrl in ("dog", "raptor") else MACETrainer)(train_net, solver, b.S, b.A, **tkw)
+
+
 def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, device_id=-1, extra_args=None, seed=0, log_every=0, out_scale_file=None,
           trainer_device=None, overlap=False, frames_per_drain=1, scenario_cls=BatchScenario):
     """extra_args override / extend the arg file (both for the engine and for the -trainer_* keys read here).
@@ -46,20 +59,10 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     solver = os.path.join(data_root, args["policy_solver"])
     train_net = os.path.join(data_root, re.search(r'net:\s*"([^"]+)"', open(solver).read()).group(1)) if re.search(r'net:\s*"', open(solver).read()) \
         else os.path.join(data_root, args["policy_net"].replace("_deploy", "_train"))
-    # -char_ctrl= dog / raptor are the Q controllers (scenarios/ScenarioSimChar.cpp:421-430): -scenario= train pairs them with cQNetTrainer
-    # (scenarios/ScenarioTrain.cpp BuildTrainer), the *_mace controllers with cMACETrainer
     tkw = dict(mem_size=geti("trainer_replay_mem_size", 500000), num_init_samples=geti("trainer_num_init_samples", 200),
                steps_per_iter=geti("trainer_num_steps_per_iters", 1), freeze_target_iters=geti("trainer_freeze_target_iters", 0),
                init_input_offset_scale=args.get("trainer_init_input_offset_scale", "false").lower() == "true", seed=seed, device=trainer_device)
-    if args.get("char_ctrl", "").endswith("_cacla"):
-        # cScenarioTrainCacla::ParseArgs (scenarios/ScenarioTrainCacla.cpp:21-34): -policy_* name the ACTOR, -critic_* the critic the trainer steps first
-        c_solver = os.path.join(data_root, args["critic_solver"])
-        m = re.search(r'net:\s*"([^"]+)"', open(c_solver).read())
-        c_train = os.path.join(data_root, m.group(1)) if m else os.path.join(data_root, args["critic_net"].replace("_deploy", "_train"))
-        t = CaclaTrainer(c_train, c_solver, train_net, solver, b.S, b.A, **tkw)
-    else:
-        trainer_cls = QNetTrainer if args.get("char_ctrl", "") in ("dog", "raptor") else MACETrainer
-        t = trainer_cls(train_net, solver, b.S, b.A, **tkw)
+    t = _make_trainer(args, data_root, train_net, solver, b, tkw)
     t.SetOutputOffsetScale(*b.BuildNNOutputOffsetScale())
     exp = dict(rate=getf("exp_rate", 0.2), temp=getf("exp_temp", 0.025), base=getf("exp_base_rate", 0.002))
     init = dict(rate=getf("init_exp_rate", 1.0), temp=getf("init_exp_temp", 20.0), base=getf("init_exp_base_rate", 1.0))
@@ -151,9 +154,10 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
         solver = os.path.join(data_root, args["policy_solver"])
         m = re.search(r'net:\s*"([^"]+)"', open(solver).read())
         train_net = os.path.join(data_root, m.group(1)) if m else os.path.join(data_root, args["policy_net"].replace("_deploy", "_train"))
-        t = MACETrainer(train_net, solver, b.S, b.A, mem_size=geti("trainer_replay_mem_size", 500000), num_init_samples=geti("trainer_num_init_samples", 200),
-                        steps_per_iter=geti("trainer_num_steps_per_iters", 1), freeze_target_iters=geti("trainer_freeze_target_iters", 0),
-                        init_input_offset_scale=args.get("trainer_init_input_offset_scale", "false").lower() == "true", seed=seed, device=trainer_device)
+        tkw = dict(mem_size=geti("trainer_replay_mem_size", 500000), num_init_samples=geti("trainer_num_init_samples", 200),
+                   steps_per_iter=geti("trainer_num_steps_per_iters", 1), freeze_target_iters=geti("trainer_freeze_target_iters", 0),
+                   init_input_offset_scale=args.get("trainer_init_input_offset_scale", "false").lower() == "true", seed=seed, device=trainer_device)
+        t = _make_trainer(args, data_root, train_net, solver, b, tkw)
         t.SetOutputOffsetScale(*b.BuildNNOutputOffsetScale())
     exp = dict(rate=getf("exp_rate", 0.2), temp=getf("exp_temp", 0.025), base=getf("exp_base_rate", 0.002))
     init = dict(rate=getf("init_exp_rate", 1.0), temp=getf("init_exp_temp", 20.0), base=getf("init_exp_base_rate", 1.0))
