@@ -254,7 +254,10 @@ def main():
     ex = None
     if ex_steps > 0:
         b.close()
-        ex = exchange_leg(da, dist, torch, world, rank, local_rank, n, ex_steps, max(a.warmup // 2, 2), a.bcast_every, w, load_scale())
+        try:
+            ex = exchange_leg(da, dist, torch, world, rank, local_rank, n, ex_steps, max(a.warmup // 2, 2), a.bcast_every, w, load_scale())
+        except Exception as exc:   # the headline measurement above stands on its own: report the failure instead of losing the line
+            ex = {"error": repr(exc)}
     if rank == 0:
         line["exchange"] = ex
         if world == 1 and not a.no_cpu_baseline:
