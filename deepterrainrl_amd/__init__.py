@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_cycle_info", "dtrl_get_action_table", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
     "dtrl_terrain_build", "dtrl_terrain_load_file", "dtrl_args_parse_string",
-    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed",
+    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed", "dtrl_get_policy_output",
 ]
 
 
@@ -74,6 +74,7 @@ def _bind(path):
     L.dtrl_get_cycle_info.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
     L.dtrl_get_action_table.argtypes = [vp, C.POINTER(C.c_int), vp]
     L.dtrl_get_poli_state.argtypes = [vp, vp, C.c_int, vp]
+    L.dtrl_get_policy_output.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_flags.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_contacts.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_ctrl.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
@@ -306,6 +307,13 @@ class BatchScenario:
         s = np.zeros((n, self.S))
         self._chk(self._lib.dtrl_get_poli_state(self._h, _p(ids), n, _p(s)))
         return s
+
+    def PolicyOutput(self, env_ids=None):
+        """cNeuralNet::GetLayerState("output") after the controller's last Eval, un-normalised like Eval's out_y (learning/NeuralNet.cpp:352-375, 814-834)."""
+        ids, n = self._ids(env_ids)
+        y = np.zeros((n, self.nn_out))
+        self._chk(self._lib.dtrl_get_policy_output(self._h, _p(ids), n, _p(y)))
+        return y
 
     def Flags(self, env_ids=None):
         ids, n = self._ids(env_ids)

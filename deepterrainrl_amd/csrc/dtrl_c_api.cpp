@@ -101,6 +101,7 @@ try {
 	return static_cast<dtrl_status>(b->eng.AddPerturb(env_ids, n, link, local_pos, force, duration));
 } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_apply_rand_force(dtrl_batch* b, const int32_t* env_ids, int n, uint64_t seed) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.ApplyRandForce(env_ids, n, seed)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_get_policy_output(dtrl_batch* b, const int32_t* env_ids, int n, double* y) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.GetPolicyOutput(env_ids, n, y)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_get_poli_state(dtrl_batch* b, const int32_t* env_ids, int n, double* s) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.GetPoliState(env_ids, n, s)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 
 dtrl_status dtrl_get_flags(dtrl_batch* b, const int32_t* env_ids, int n, uint32_t* bits)

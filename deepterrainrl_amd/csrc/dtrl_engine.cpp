@@ -200,16 +200,12 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	if (cfg_.has_policy_net) {
 		const NetDesc& d = cfg_.net;
 		buf_.net = d;
-		int cin = 1, w = d.n_terrain, mx = d.n_terrain;
-		for (int l = 0; l < 3; ++l) { w = w - d.conv_k[l] + 1; cin = d.conv_ch[l]; mx = std::max(mx, cin * w); }
-		mx = std::max(mx, d.fc_trunk + d.fc_head);
-		buf_.nn_scratch_stride = ((mx + d.fc_terr + d.n_char + 63) / 64) * 64;
-		buf_.nn_scratch = static_cast<real*>(alloc(sizeof(real) * 2 * static_cast<size_t>(buf_.nn_scratch_stride) * n_));
 		buf_.nn_out = static_cast<real*>(alloc(sizeof(real) * static_cast<size_t>(d.out_size) * n_));
 		float* w_dev = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(DevNumParams(d))));
 		real* io = static_cast<real*>(alloc(sizeof(real) * d.in_size)); real* is = static_cast<real*>(alloc(sizeof(real) * d.in_size));
 		real* oo = static_cast<real*>(alloc(sizeof(real) * d.out_size)); real* os = static_cast<real*>(alloc(sizeof(real) * d.out_size));
-		if (!buf_.nn_scratch || !buf_.nn_out || !w_dev || !io || !is || !oo || !os) return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
+		if (!buf_.nn_out || !w_dev || !io || !is || !oo || !os) return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
+		{ std::vector<real> zeros(static_cast<size_t>(d.out_size) * n_, 0.0); if (!be_->H2D(buf_.nn_out, zeros.data(), sizeof(real) * zeros.size())) return Fail(DTRL_ERR_DEVICE, be_->error()); }   // dtrl_get_policy_output before the first forward
 		buf_.weights = w_dev; buf_.in_off = io; buf_.in_scale = is; buf_.out_off = oo; buf_.out_scale = os;
 		cfg_.model.has_net = 1;
 		BuildRelayoutMap(relayout_);
@@ -517,7 +513,7 @@ int Engine::Reset(const int32_t* env_ids, int n, const uint64_t* seeds)
 	return DTRL_OK;
 }
 
-// device weight layout (dtrl_kernel.h conv_layer / fc_layer) as an index map into the caller's blob (Caffe blob order of the deploy net, W then b
+// device weight layout (dtrl_kernel.h conv_tile / fc_partial / fc_layer) as an index map into the caller's blob (Caffe blob order of the deploy net, W then b
 // per layer): conv blobs [cout][cin][k] -> [cin][k][cout]; InnerProduct blobs [nout][nin] -> [ceil(nin/4)][nout][4] (zero padded); biases
 // unchanged; same blob order. -1 = a padding / zero entry. CACLA actor: the all-zero critic head (val_ip0, val_ip1) is inserted behind the
 // trunk so that the device sees a one-fragment MACE net; the boundary keeps the actor's blob order and sizes.
@@ -551,7 +547,19 @@ void Engine::BuildRelayoutMap(std::vector<int32_t>& map) const
 		for (int o = 0; o < nout; ++o) map[dst + o] = user(src + o);
 		src += nout; dst += static_cast<size_t>(pad4(nout));
 	};
-	block(d.fc_terr, cin * wdt);
+	{
+		// terr_ip0 consumes conv2's output tile by tile (dtrl_kernel.h nn_eval): input (c, t) of Caffe's channel-major flattening sits at
+		// tile * cin * V + c * vt + (t - tile * V), V positions per tile (vt in the last one)
+		const int nout = d.fc_terr, V = kConvTile - (d.conv_k[1] - 1) - (d.conv_k[2] - 1);
+		for (int o = 0; o < nout; ++o) for (int c = 0; c < cin; ++c) for (int t = 0; t < wdt; ++t) {
+			const int tile = t / V, vt = std::min(V, wdt - tile * V);
+			const size_t i = static_cast<size_t>(tile) * cin * V + static_cast<size_t>(c) * vt + (t - tile * V);
+			map[dst + ((i / 4) * nout + o) * 4 + (i % 4)] = user(src + static_cast<size_t>(o) * cin * wdt + static_cast<size_t>(c) * wdt + t);
+		}
+		src += static_cast<size_t>(nout) * cin * wdt; dst += static_cast<size_t>(fc_dev_size(nout, cin * wdt));
+		for (int o = 0; o < nout; ++o) map[dst + o] = user(src + o);
+		src += nout; dst += static_cast<size_t>(pad4(nout));
+	}
 	block(d.fc_trunk, d.fc_terr + d.n_char);
 	block(d.fc_head, d.fc_trunk); block(d.n_frags, d.fc_head);
 	for (int f = 0; f < d.n_frags; ++f) { block(d.fc_head, d.fc_trunk); block(d.frag_size, d.fc_head); }
@@ -853,6 +861,20 @@ int Engine::GetPoliState(const int32_t* env_ids, int n, double* s)
 		int e = EnvIndex(env_ids, i);
 		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
 		if (!be_->D2H(s + static_cast<size_t>(i) * S_, buf_.poli_state + static_cast<size_t>(e) * S_, sizeof(real) * S_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	}
+	return DTRL_OK;
+}
+
+int Engine::GetPolicyOutput(const int32_t* env_ids, int n, double* y)
+{
+	if (n < 0 || !y) return Fail(DTRL_ERR_ARG, "bad arguments");
+	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
+	be_->Sync();
+	const int pad = cfg_.net.out_size - cfg_.user_out_size;   // the device net of a single-head controller carries an unused critic slot in front
+	for (int i = 0; i < n; ++i) {
+		int e = EnvIndex(env_ids, i);
+		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
+		if (!be_->D2H(y + static_cast<size_t>(i) * cfg_.user_out_size, buf_.nn_out + static_cast<size_t>(e) * cfg_.net.out_size + pad, sizeof(real) * cfg_.user_out_size)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	}
 	return DTRL_OK;
 }

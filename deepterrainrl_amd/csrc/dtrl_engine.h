@@ -75,6 +75,7 @@ public:
 	int AddPerturb(const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration);
 	int ApplyRandForce(const int32_t* env_ids, int n, uint64_t seed);
 	int GetPoliState(const int32_t* env_ids, int n, double* s);
+	int GetPolicyOutput(const int32_t* env_ids, int n, double* y);
 	int GroundWindowRec(int env, int32_t* w2, double* min_x2, double* max_x2, float* h0, float* h1, int cap, int64_t* num_builds);
 	int DrainTuplesPacked(float* block_dev, int block_rows, int* out_n);
 	int SampleGround(int env, int n, const double* x, double* h, int32_t* seg, int32_t* oi, int32_t* oj);

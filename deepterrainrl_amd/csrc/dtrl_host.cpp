@@ -306,7 +306,14 @@ bool ParseDeployPrototxt(const std::string& path, NetDesc& d, std::string& err, 
 	if (actor) { d.fc_terr = ips["terr_ip0"]; d.fc_trunk = ips["ip1"]; d.fc_head = ips["ip2"]; d.n_frags = 1; d.frag_size = ips["output"]; }
 	else { d.fc_terr = ips["terr_ip0"]; d.fc_trunk = ips["ip0"]; d.fc_head = ips["val_ip0"]; d.n_frags = ips["val_ip1"]; d.frag_size = ips["a0_ip1"]; }
 	if (d.n_frags > kMaxFrags) { err = "too many actor fragments"; return false; }
-	for (int l = 0; l < 3; ++l) if (d.conv_ch[l] % 16 != 0 || d.conv_ch[l] > 32 || d.conv_k[l] > 8 || d.conv_ch[l] * d.conv_k[l] > 128) { err = path + ": conv layer outside the supported family (channels 16 or 32, kernel <= 8, channels*kernel <= 128)"; return false; }
+	for (int l = 0; l < 3; ++l) if ((d.conv_ch[l] != 16 && d.conv_ch[l] != 32) || (d.conv_k[l] != 4 && d.conv_k[l] != 8)) { err = path + ": conv layer outside the supported family (16 or 32 channels, kernel width 4 or 8)"; return false; }
+	{
+		// the forward keeps its activations in the env's LDS workspace (dtrl_kernel.h nn_eval): tiles of kConvTile conv0 positions, of which V survive conv2
+		const int s0 = kConvTile + d.conv_k[1] - 1, s1 = kConvTile + d.conv_k[2] - 1, V = kConvTile - (d.conv_k[1] - 1) - (d.conv_k[2] - 1);
+		const bool fits = V >= 1 && d.conv_ch[0] * s0 <= kNNTileBuf && d.conv_ch[1] * s1 <= kNNTileBuf && d.conv_ch[2] * V <= kNNTileBuf && d.n_terrain + d.n_char <= kNNSideBuf
+			&& d.fc_terr <= kGroup && 2 * kFcChunk + d.fc_terr + d.n_char + d.fc_trunk + d.fc_head <= kNNTileBuf;
+		if (!fits) { err = path + ": layer sizes exceed the per-env on-chip workspace of the policy forward"; return false; }
+	}
 	d.in_size = d.n_terrain + d.n_char; d.out_size = d.n_frags + d.n_frags * d.frag_size;
 	int64_t n = 0; int cin = 1, w = d.n_terrain;
 	for (int l = 0; l < 3; ++l) { n += static_cast<int64_t>(d.conv_ch[l]) * cin * d.conv_k[l] + d.conv_ch[l]; cin = d.conv_ch[l]; w = w - d.conv_k[l] + 1; }

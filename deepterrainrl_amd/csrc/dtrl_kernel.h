@@ -93,7 +93,6 @@ struct DevBuffers {
 	real* poli_state;     // [N][S]
 	real* tup_s0;         // [N][S]
 	real* tup_a;          // [N][A]
-	real* nn_scratch;     // [N][2][nn_scratch_stride]
 	real* nn_out;         // [N][out_size]
 	float* tuple_rows;    // [cap][W]  MACE replay row layout [r | s | a | s'] (learning/MACETrainer.cpp:373-401)
 	uint32_t* tuple_flags;
@@ -101,7 +100,6 @@ struct DevBuffers {
 	int32_t* tuple_count; // device-wide atomic cursor
 	int32_t tuple_cap;
 	int32_t S, A, W;
-	int32_t nn_scratch_stride;
 	int32_t model_D;           // host-known DoF count
 	int32_t model_topo;        // compiled-in skeleton id (dtrl_topo.h; selects the register-resident kernel instantiation), 0 = none
 	unsigned long long* prof;  // [N][kProfMax] cycle counters (DTRL_PROFILE builds), else null
@@ -1035,86 +1033,178 @@ DTRL_HD inline void apply_action(W& ws, int id, const real* params, int P)
 }
 
 // ---- policy network: learning/NeuralNet.cpp:352-375 Eval on the MACE topology, all 64 lanes of the env's wavefront.
-// Activations ping-pong through a per-env HBM scratch slab (L2-resident: only envs at a cycle boundary touch theirs).
-// A forward pass by one wave is latency-bound unless every global load is issued a full block ahead of its use, so both
-// layer kinds are software-pipelined across lane phases (per-lane values that survive a phase boundary live in LANE_LOCAL
-// storage: registers under hipcc, a [lane] array in the lane-loop test build):
-//   conv1d: lanes <-> output positions; all (<= 32) output channels accumulate in registers so an input window is loaded
-//           once; the engine re-lays conv blobs as [cin][k][cout], the slice of input channel c+1 (k*cout <= 128 floats)
-//           is fetched coalesced and parked as doubles in LDS while channel c is consumed with ds_read broadcasts;
-//   FC:     lanes <-> outputs; the engine re-lays InnerProduct blobs as [nin/4][nout][4] so a lane fetches the weights of
-//           4 inputs with one 16-byte load; inputs are staged 64 at a time in LDS; weights of block b+1 are in flight
-//           while block b is consumed.
-// Accumulation order per output is the reference order (channel-major, then tap; input index ascending), so results do
-// not depend on the blocking. LDS scratch = the Z storage (dead while the controller picks an action).
-constexpr int kMaxConvCh = 32, kMaxConvK = 8, kConvSlice = 128, kFcChunk = 32;
+// No activation leaves the CU. The three conv layers and terr_ip0 are fused over TILES of output positions: a tile is 16 positions
+// of conv0's output (= one N-tile of the fp64 matrix pipe), of which 16 - (k1 - 1) are valid after conv1 and V = 16 - (k1 - 1) - (k2 - 1)
+// after conv2 (10 for the reference's 8/4/4 kernels; the halo is recomputed: 19 tiles instead of 12, +55 % multiply-adds on layers that
+// run on the matrix pipe at a fraction of the old vector cost). Each layer's tile lives in the Z storage (dead while the controller picks
+// an action): a layer accumulates its whole tile in registers (co x 16 outputs = 8 doubles per lane), and only then overwrites its
+// input tile. terr_ip0 consumes the V valid positions of a conv2 tile right away (lanes <-> its 64 outputs, running sums in a
+// register across tiles), so the 32 x 187 conv2 blob never exists anywhere; the engine lays terr_ip0's weights out tile-major to match
+// (BuildRelayoutMap). The normalised input sits in the side buffer (packed-Delassus storage on the fast path, H on the reference path),
+// the trunk / head activations (531 doubles) in Z.
+//   conv tile: out[o][j] = relu(b[o] + sum_{c, u} W[c][u][o] x[c][j + u]) as D = A B on v_mfma_f64_16x16x4_f64 with M = output channel,
+//              N = position, K = (c, u) flattened, A straight from the [cin][k][cout] weight blob (L2), B from the LDS tile. The MFMA
+//              accumulates in K order with fused multiply-adds (tools/microbench/mfma_f64_check.hip), i.e. the reference order
+//              (channel-major, then tap) of the scalar loop that the CPU builds run: bit-identical.
+//   FC:        lanes <-> outputs; the engine re-lays InnerProduct blobs as [nin/4][nout][4] so a lane fetches the weights of
+//              4 inputs with one 16-byte load; weights of chunk b+1 are in flight while chunk b is consumed.
+// Accumulation order per conv output is the reference order; terr_ip0 sums tile-major (tile, channel, position) instead of Caffe's
+// gemv order, which is unspecified anyway (the reference computes in fp32 through BLAS) -- the oracle sums channel-major and the
+// parity tests hold to their fp64 tolerance.
+constexpr int kMaxConvCh = 32, kMaxConvK = 8;
+static_assert(kNNTileBuf == (kMaxRows + 1) * kZStride, "the tile buffer of the policy forward is the Z storage");
+static_assert(kMaxConvCh * kConvTile % kGroup == 0, "lane-loop form of conv_tile");
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LANE_LOCAL(type, name, n) type name##_ll[1][n]
 #define LL(name) name##_ll[0]
+#define LL_IN(arr) arr[0]
 #else
 #define LANE_LOCAL(type, name, n) type name##_ll[::dtrl::kGroup][n]
 #define LL(name) name##_ll[lane]
+#define LL_IN(arr) arr[lane]
+#endif
+#define LL_ARR(name) name##_ll   // the whole lane-local object, to hand it to a callee (which indexes it with LL_IN)
+constexpr int kFcBatch = 8;
+#if defined(__HIP_DEVICE_COMPILE__)
+// scheduling hint: the batch's LDS reads (kFcBatch doubles) as one group ahead of its multiply-adds
+#define FC_SCHED_BATCH() do { __builtin_amdgcn_sched_group_barrier(0x100, kFcBatch / 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2 * kFcBatch, 0); } while (0)
+#else
+#define FC_SCHED_BATCH() do {} while (0)
 #endif
 DTRL_HD inline int64_t fc_dev_size(int nout, int nin) { return static_cast<int64_t>((nin + 3) / 4) * 4 * nout; }
 DTRL_HD inline int64_t pad4(int64_t n) { return (n + 3) / 4 * 4; }   // every device blob starts 16-byte aligned
 struct alignas(16) F4 { float v[4]; };
+DTRL_HD_INLINE real* nn_side_buf(WSRef& ws) { return &ws.H[0][0]; }
+DTRL_HD_INLINE real* nn_side_buf(WSFast& ws) { return &ws.Apk[0]; }
+static_assert(sizeof(WSRef::H) >= sizeof(real) * kNNSideBuf && sizeof(WSFast::Apk) >= sizeof(real) * kNNSideBuf, "side buffer of the policy forward");
 
-template <class W>
-DTRL_HD inline void conv_layer(W& ws, const float* Wd, const float* bias, int co, int cin, int k, int wdt, const real* a, real* out)
+// one position tile of a conv layer. x: LDS, channel stride xs, position index clamped to xlast (conv0 reads the input vector itself
+// and runs off its end in the last tile; the outputs that see a clamped or never-written input are the halo the next layer discards).
+// out (may alias x: everything is accumulated before anything is written): [o][os] for nv < 0, else the compact [o][nv] block of the
+// first nv positions that terr_ip0 consumes.
+// NB = K-steps (of 4 flattened (c, u) indices) per batch on the device: the batch's 2 NB weight loads are issued together, one batch ahead of
+// the matrix instructions that consume them (a one-wave forward is latency-bound otherwise); cin * k must be a multiple of 4 NB.
+template <int NB, class W>
+DTRL_HD inline void conv_tile(W& ws, const float* Wd, const float* bias, int co, int cin, int k, const real* x, int xs, int xlast, real* out, int os, int nv)
 {
-	real* lds = &ws.Z[0][0];   // two slices of kConvSlice doubles
-	const int wo = wdt - k + 1, nw = k * co;
-	for (int t0 = 0; t0 < wo; t0 += kGroup) {
-		LANE_LOCAL(real, acc, kMaxConvCh);
-		LANE_LOCAL(real, xc, kMaxConvK);
-		LANES_BEGIN
-		for (int e = lane; e < nw; e += kGroup) lds[e] = static_cast<real>(Wd[e]);
-		const int tt = (t0 + lane < wo) ? t0 + lane : wo - 1;
+	(void)ws;
+#if defined(__HIP_DEVICE_COMPILE__)
+	// operand layout: A[i = lane % 16][k = lane / 16], B[k = lane / 16][n = lane % 16], D register r = D[4 r + lane / 16][lane % 16]
+	typedef double v4d_t __attribute__((ext_vector_type(4)));
+	const int l = static_cast<int>(threadIdx.x), g = l >> 4, j = l & 15;
+	const bool two = co > kConvTile;                 // a 16-channel layer runs the second tile on the first one's weights and drops the result
+	v4d_t acc0, acc1;
 #pragma unroll
-		for (int u = 0; u < kMaxConvK; ++u) LL(xc)[u] = a[tt + (u < k ? u : 0)];
+	for (int r = 0; r < 4; ++r) { acc0[r] = static_cast<real>(bias[4 * r + g]); acc1[r] = static_cast<real>(bias[two ? 16 + 4 * r + g : 0]); }
+	const int nk = cin * k, ksh = (k == 8) ? 3 : 2;  // kernel widths are 4 or 8 (host check)
+	const float* w0 = Wd + g * co + j;              // this lane's A entries: W[kk + g][j] and W[kk + g][16 + j]
+	const float* w1 = w0 + (two ? kConvTile : 0);
+	float a0[NB], a1[NB];
 #pragma unroll
-		for (int o = 0; o < kMaxConvCh; ++o) LL(acc)[o] = static_cast<real>(bias[o < co ? o : 0]);   // clamped, not predicated: one memory wait for all
-		LANES_END
-		for (int c = 0; c < cin; ++c) {
-			LANES_BEGIN
-			const int cur = (c & 1) * kConvSlice, nxt = kConvSlice - cur;
-			const bool more = c + 1 < cin;
-			const int tt = (t0 + lane < wo) ? t0 + lane : wo - 1;
-			// issue the loads of channel c + 1 before the multiply-adds of channel c. Addresses are clamped instead of the
-			// loads being predicated or their results selected: any use of a loaded value ahead of the multiply-add blocks
-			// would put the memory wait in front of them (the scheduler does not move code across the uniform branches)
-			const int cn = more ? c + 1 : c;
-			const float* Wn = Wd + static_cast<int64_t>(cn) * nw;
-			const float wn0 = Wn[lane < nw ? lane : nw - 1];
-			const float wn1 = Wn[lane + kGroup < nw ? lane + kGroup : nw - 1];
-			real xn[kMaxConvK];
+	for (int q = 0; q < NB; ++q) { a0[q] = w0[4 * q * co]; a1[q] = w1[4 * q * co]; }
+	for (int kk = 0; kk < nk; kk += 4 * NB) {
+		const int kn = (kk + 4 * NB < nk) ? kk + 4 * NB : kk;   // next batch (the last one re-reads itself: no branch around the loads)
+		float n0[NB], n1[NB]; real b[NB];
 #pragma unroll
-			for (int u = 0; u < kMaxConvK; ++u) xn[u] = a[cn * wdt + tt + (u < k ? u : 0)];
+		for (int q = 0; q < NB; ++q) { n0[q] = w0[(kn + 4 * q) * co]; n1[q] = w1[(kn + 4 * q) * co]; }
 #pragma unroll
-			for (int u = 0; u < kMaxConvK; ++u) {
-				if (u >= k) break;
-				const real x = LL(xc)[u];
-				const real* wr = lds + cur + u * co;
-#pragma unroll
-				for (int ob = 0; ob < kMaxConvCh; ob += 8) {
-					if (ob >= co) break;
-#pragma unroll
-					for (int o = ob; o < ob + 8; ++o) LL(acc)[o] = fmadd(wr[o], x, LL(acc)[o]);
-				}
-			}
-			if (more) {
-				if (lane < nw) lds[nxt + lane] = static_cast<real>(wn0);
-				if (lane + kGroup < nw) lds[nxt + lane + kGroup] = static_cast<real>(wn1);
-#pragma unroll
-				for (int u = 0; u < kMaxConvK; ++u) LL(xc)[u] = xn[u];
-			}
-			LANES_END
+		for (int q = 0; q < NB; ++q) {
+			const int e = kk + 4 * q + g, c = e >> ksh, xi = j + (e & (k - 1));
+			b[q] = x[c * xs + (xi < xlast ? xi : xlast)];
 		}
-		LANES_BEGIN
-		const int t = t0 + lane;
-		if (t < wo) {
 #pragma unroll
-			for (int o = 0; o < kMaxConvCh; ++o) if (o < co) out[o * wo + t] = LL(acc)[o] < 0 ? 0 : LL(acc)[o];
+		for (int q = 0; q < NB; ++q) {
+			acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(static_cast<real>(a0[q]), b[q], acc0, 0, 0, 0);
+			acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(static_cast<real>(a1[q]), b[q], acc1, 0, 0, 0);
+		}
+#pragma unroll
+		for (int q = 0; q < NB; ++q) { a0[q] = n0[q]; a1[q] = n1[q]; }
+	}
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < 4; ++r) {
+		const int o0 = 4 * r + g, o1 = 16 + o0;
+		const real v0 = acc0[r] < 0 ? 0 : acc0[r], v1 = acc1[r] < 0 ? 0 : acc1[r];
+		if (nv < 0) { out[o0 * os + j] = v0; if (two) out[o1 * os + j] = v1; }
+		else if (j < nv) { out[o0 * nv + j] = v0; if (two) out[o1 * nv + j] = v1; }
+	}
+	__syncthreads();
+#else
+	constexpr int kPer = kMaxConvCh * kConvTile / kGroup;
+	LANE_LOCAL(real, acc, kPer);
+	LANES_BEGIN
+	for (int q = 0; q < kPer; ++q) {
+		const int idx = q * kGroup + lane, o = idx / kConvTile, j = idx % kConvTile;
+		if (o >= co) continue;
+		real a = static_cast<real>(bias[o]);
+		for (int c = 0; c < cin; ++c) for (int u = 0; u < k; ++u) {
+			const int xi = j + u;
+			a = fmadd(static_cast<real>(Wd[(c * k + u) * co + o]), x[c * xs + (xi < xlast ? xi : xlast)], a);
+		}
+		LL(acc)[q] = a < 0 ? 0 : a;
+	}
+	LANES_END
+	LANES_BEGIN
+	for (int q = 0; q < kPer; ++q) {
+		const int idx = q * kGroup + lane, o = idx / kConvTile, j = idx % kConvTile;
+		if (o >= co) continue;
+		if (nv < 0) out[o * os + j] = LL(acc)[q];
+		else if (j < nv) out[o * nv + j] = LL(acc)[q];
+	}
+	LANES_END
+#endif
+}
+// s[o] += sum_{i < nin} W[i][o] x[i] for the lane's output o (nout <= 64), x in LDS, weights in [nin/4][nout][4] blocks; input order ascending
+template <class W, class S>
+DTRL_HD inline void fc_partial(W& ws, const float* Wb, int nout, int nin, const real* x, S& s_ll)
+{
+	(void)ws;
+	const int nblk = (nin + 3) / 4;
+	constexpr int kQ = kFcChunk / 4;   // 16-byte weight loads per lane and chunk
+	LANE_LOCAL(float, wc, kFcChunk);
+	LANES_BEGIN
+	const int oc = lane < nout ? lane : nout - 1;
+#pragma unroll
+	for (int q = 0; q < kQ; ++q) {
+		const int bq = q < nblk ? q : nblk - 1;
+		const F4 w4 = *reinterpret_cast<const F4*>(Wb + (static_cast<int64_t>(bq) * nout + oc) * 4);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) LL(wc)[4 * q + r] = w4.v[r];
+	}
+	LANES_END
+	for (int i0 = 0; i0 < nin; i0 += kFcChunk) {
+		LANES_BEGIN
+		const int oc = lane < nout ? lane : nout - 1;
+		const bool more = i0 + kFcChunk < nin;
+		float wn[kFcChunk];
+		const int b1 = (i0 + kFcChunk) / 4;
+#pragma unroll
+		for (int q = 0; q < kQ; ++q) {   // next chunk's weights: clamped addresses, no selects (the loads must not wait for anything)
+			const int bq = b1 + q < nblk ? b1 + q : nblk - 1;
+			const F4 w4 = *reinterpret_cast<const F4*>(Wb + (static_cast<int64_t>(bq) * nout + oc) * 4);
+#pragma unroll
+			for (int r = 0; r < 4; ++r) wn[4 * q + r] = w4.v[r];
+		}
+		real acc = LL_IN(s_ll)[0];
+		const int nhere = (nin - i0 < kFcChunk) ? nin - i0 : kFcChunk;
+		if (nhere == kFcChunk) {
+#pragma unroll
+			for (int e0 = 0; e0 < kFcChunk; e0 += kFcBatch) {   // the batch's LDS reads in flight together, one wait per batch
+				real xv[kFcBatch];
+#pragma unroll
+				for (int r = 0; r < kFcBatch; ++r) xv[r] = x[i0 + e0 + r];
+				FC_SCHED_BATCH();
+#pragma unroll
+				for (int r = 0; r < kFcBatch; ++r) acc = fmadd(static_cast<real>(LL(wc)[e0 + r]), xv[r], acc);
+			}
+		} else {
+#pragma unroll
+			for (int e = 0; e < kFcChunk; ++e) if (e < nhere) acc = fmadd(static_cast<real>(LL(wc)[e]), x[i0 + e], acc);
+		}
+		LL_IN(s_ll)[0] = acc;
+		if (more) {
+#pragma unroll
+			for (int e = 0; e < kFcChunk; ++e) LL(wc)[e] = wn[e];
 		}
 		LANES_END
 	}
@@ -1145,7 +1235,7 @@ DTRL_HD inline void fc_layer(W& ws, const float* Wb, const float* b, int nout, i
 			const int o = o0 + lane;
 			const int cur = ((i0 / kFcChunk) & 1) * kFcChunk, nxt = kFcChunk - cur;
 			const bool more = i0 + kFcChunk < nin;
-			// next chunk: one input per lane, kQ 16-byte weight loads per lane; clamped addresses, no selects (see conv_layer)
+			// next chunk: one input per lane, kQ 16-byte weight loads per lane; clamped addresses, no selects (the loads must not wait for anything)
 			const int in = i0 + kFcChunk + (lane < kFcChunk ? lane : 0);
 			const real xn = x[in < nin ? in : nin - 1];
 			float wn[kFcChunk];
@@ -1162,7 +1252,14 @@ DTRL_HD inline void fc_layer(W& ws, const float* Wb, const float* b, int nout, i
 			const int nhere = (nin - i0 < kFcChunk) ? nin - i0 : kFcChunk;
 			if (nhere == kFcChunk) {   // straight-line block for full chunks
 #pragma unroll
-				for (int e = 0; e < kFcChunk; ++e) acc = fmadd(static_cast<real>(LL(wc)[e]), lds[cur + e], acc);
+				for (int e0 = 0; e0 < kFcChunk; e0 += kFcBatch) {   // the batch's LDS reads in flight together, one wait per batch
+				real xv[kFcBatch];
+#pragma unroll
+				for (int r = 0; r < kFcBatch; ++r) xv[r] = lds[cur + e0 + r];
+				FC_SCHED_BATCH();
+#pragma unroll
+				for (int r = 0; r < kFcBatch; ++r) acc = fmadd(static_cast<real>(LL(wc)[e0 + r]), xv[r], acc);
+			}
 			} else {
 #pragma unroll
 				for (int e = 0; e < kFcChunk; ++e) if (e < nhere) acc = fmadd(static_cast<real>(LL(wc)[e]), lds[cur + e], acc);
@@ -1185,36 +1282,48 @@ template <class W>
 DTRL_HD inline void nn_eval(W& ws, const DevBuffers& buf, int env)
 {
 	const NetDesc& d = buf.net;
-	real* s0 = buf.nn_scratch + static_cast<int64_t>(env) * 2 * buf.nn_scratch_stride;
-	real* s1 = s0 + buf.nn_scratch_stride;
 	const real* xin = buf.poli_state + static_cast<int64_t>(env) * buf.S;
 	real* y = buf.nn_out + static_cast<int64_t>(env) * d.out_size;
-	// normalised char features are kept at the tail of s1's slab until the trunk layer consumes them
-	real* xchar = s1 + buf.nn_scratch_stride - d.n_char;
-	LANES_BEGIN
-	for (int i = lane; i < d.n_terrain; i += kGroup) s0[i] = (xin[i] + buf.in_off[i]) * buf.in_scale[i];
-	for (int i = lane; i < d.n_char; i += kGroup) xchar[i] = (xin[d.n_terrain + i] + buf.in_off[d.n_terrain + i]) * buf.in_scale[d.n_terrain + i];
-	LANES_END
+	real* side = nn_side_buf(ws);        // [n_terrain | n_char] normalised input
+	real* tile = &ws.Z[0][0];
 	const float* p = buf.weights;
-	real* a = s0; real* bo = s1;
+	const float* Wc[3]; const float* bc[3];
 	int cin = 1, wdt = d.n_terrain;
-	PROF_T0();
 	for (int l = 0; l < 3; ++l) {
-		const int co = d.conv_ch[l], k = d.conv_k[l], wo = wdt - k + 1;
-		const float* Wc = p; const float* bias = p + pad4(static_cast<int64_t>(co) * cin * k);
-		conv_layer(ws, Wc, bias, co, cin, k, wdt, a, bo);
-		p = bias + pad4(co); real* t2 = a; a = bo; bo = t2; cin = co; wdt = wo;
+		Wc[l] = p; bc[l] = p + pad4(static_cast<int64_t>(d.conv_ch[l]) * cin * d.conv_k[l]);
+		p = bc[l] + pad4(d.conv_ch[l]); cin = d.conv_ch[l]; wdt = wdt - d.conv_k[l] + 1;
 	}
-	PROF_ADD(ws, kProfNNConv);
-	const int nflat = cin * wdt;
-	// terr_ip0: 5984 -> 64, output written right before the char features so the trunk input is contiguous
-	real* trunk_in = xchar - d.fc_terr;
-	{ PROF_T0(); fc_layer(ws, p, p + fc_dev_size(d.fc_terr, nflat), d.fc_terr, nflat, a, trunk_in, true); PROF_ADD(ws, kProfNNFcTerr); }
+	const int wo = wdt, nflat = cin * wo;                                   // conv2's width; terr_ip0's fan-in
+	const float* Wt = p; const float* bt = p + fc_dev_size(d.fc_terr, nflat);
+	p = bt + pad4(d.fc_terr);
+	const int s0 = kConvTile + d.conv_k[1] - 1, s1 = kConvTile + d.conv_k[2] - 1;   // tile row strides: 16 outputs + the next layer's reach
+	const int V = kConvTile - (d.conv_k[1] - 1) - (d.conv_k[2] - 1);
+	LANE_LOCAL(real, sterr, 1);
+	LANES_BEGIN
+	for (int i = lane; i < d.in_size; i += kGroup) side[i] = (xin[i] + buf.in_off[i]) * buf.in_scale[i];
+	LL(sterr)[0] = static_cast<real>(bt[lane < d.fc_terr ? lane : 0]);
+	LANES_END
+	PROF_T0();
+	for (int p0 = 0; p0 < wo; p0 += V) {
+		const int vt = (wo - p0 < V) ? wo - p0 : V;
+		conv_tile<1>(ws, Wc[0], bc[0], d.conv_ch[0], 1, d.conv_k[0], side + p0, 0, d.n_terrain - 1 - p0, tile, s0, -1);
+		conv_tile<8>(ws, Wc[1], bc[1], d.conv_ch[1], d.conv_ch[0], d.conv_k[1], tile, s0, s0 - 1, tile, s1, -1);
+		conv_tile<8>(ws, Wc[2], bc[2], d.conv_ch[2], d.conv_ch[1], d.conv_k[2], tile, s1, s1 - 1, tile, 0, vt);
+		const unsigned long long prof_fc_t0 = PROF_NOW();
+		fc_partial(ws, Wt + static_cast<int64_t>(p0) * cin * d.fc_terr, d.fc_terr, cin * vt, tile, LL_ARR(sterr));
+		PROF_ADD_SINCE(ws, kProfNNFcTerr, prof_fc_t0);
+	}
+	PROF_ADD(ws, kProfNNConv);   // conv tiles + terr_ip0 (kProfNNFcTerr is the terr_ip0 share)
 	const unsigned long long prof_rest_t0 = PROF_NOW();
-	p += fc_dev_size(d.fc_terr, nflat) + pad4(d.fc_terr);
+	// Z from here on: [0, 64) fc_layer's staging, then the trunk input [terr_ip0 | char features], the trunk and one head's hidden layer
 	const int ntr = d.fc_terr + d.n_char;
-	real* trunk = s0;               // conv activations are dead now (a == s1 after three swaps, trunk_in lives in s1's tail)
-	real* head = s0 + d.fc_trunk;
+	real* trunk_in = tile + 2 * kFcChunk;
+	real* trunk = trunk_in + ntr;
+	real* head = trunk + d.fc_trunk;
+	LANES_BEGIN
+	if (lane < d.fc_terr) trunk_in[lane] = LL(sterr)[0] < 0 ? 0 : LL(sterr)[0];
+	for (int i = lane; i < d.n_char; i += kGroup) trunk_in[d.fc_terr + i] = side[d.n_terrain + i];
+	LANES_END
 	fc_layer(ws, p, p + fc_dev_size(d.fc_trunk, ntr), d.fc_trunk, ntr, trunk_in, trunk, true);
 	p += fc_dev_size(d.fc_trunk, ntr) + pad4(d.fc_trunk);
 	fc_layer(ws, p, p + fc_dev_size(d.fc_head, d.fc_trunk), d.fc_head, d.fc_trunk, trunk, head, true);
@@ -1232,9 +1341,6 @@ DTRL_HD inline void nn_eval(W& ws, const DevBuffers& buf, int env)
 	LANES_END
 	PROF_ADD_SINCE(ws, kProfNNRest, prof_rest_t0);
 	PROF_COUNT(ws, kProfNNEvals);
-	LANES_BEGIN
-	(void)0;   // the forward's cost enters the work estimate as a PREDICTION for the next frame (env_frame), not as history
-	LANES_END
 }
 
 // cDogController(MACE)::UpdateAction: ParseGround + BuildPoliState + action decision + ApplyAction

@@ -5,7 +5,7 @@
 // consecutive elements of that env's record, so every load of a record field is a coalesced burst):
 //   EnvState   persistent simulation + controller state              (~4.5 KB, fp64)
 //   GroundRec  the env's two sliding heightfield segments (float)    (~4.2 KB)
-//   policy-state / tuple scratch and NN activation scratch live in separate per-env slabs (DevBuffers in the engine)
+//   policy-state / tuple scratch and the net's outputs live in separate per-env slabs (DevBuffers in the engine); the forward's activations stay in LDS
 #pragma once
 #include <cstdint>
 
@@ -165,6 +165,11 @@ struct EnvStatus {
 	double episode_dist;  // cScenarioPoliEval::RecordDistTraveled's dist (scenarios/ScenarioPoliEval.cpp:202-217) when need_reset & 2
 };
 
+// the policy forward keeps every activation in the env's LDS workspace (dtrl_kernel.h nn_eval): conv layers run on tiles of kConvTile
+// output positions inside a kNNTileBuf-double buffer, the normalised input sits in a kNNSideBuf-double side buffer
+constexpr int kConvTile = 16, kFcChunk = 32;
+constexpr int kNNTileBuf = (kMaxRows + 1) * (kMaxD + 1);
+constexpr int kNNSideBuf = kMaxL * (kMaxDepth + 2);
 // MACE network family (data/policies/*/nets/*_mace3_deploy.prototxt)
 struct NetDesc {
 	int32_t n_terrain, n_char;

@@ -148,6 +148,11 @@ dtrl_status dtrl_add_perturb(dtrl_batch* b, const int32_t* env_ids, int n, const
 dtrl_status dtrl_apply_rand_force(dtrl_batch* b, const int32_t* env_ids, int n, uint64_t seed);
 /* Replaces: cNNController::RecordPoliState (sim/TerrainRLCharController.cpp:120-123). */
 dtrl_status dtrl_get_poli_state(dtrl_batch* b, const int32_t* env_ids, int n, double* s);
+/* Replaces: cNeuralNet::GetLayerState("output", y) (learning/NeuralNet.cpp:814-834) after the controller's last cNeuralNet::Eval
+ * (learning/NeuralNet.cpp:352-375; what -record_nn_activation= true -nn_activation_layer= output writes, scenarios/ScenarioPoliEval.cpp:271-286)
+ * with the output un-normalisation of Eval applied: y[n][nn_out of dtrl_dims] = the net's outputs of each env's most recent action decision
+ * that evaluated the net (zeros before the first one). */
+dtrl_status dtrl_get_policy_output(dtrl_batch* b, const int32_t* env_ids, int n, double* y);
 /* fallen | stumbled<<1 | new_cycle<<2 | fsm_state<<8: cSimCharacter::HasFallen/HasStumbled, cCharController::IsNewCycle/GetState. */
 dtrl_status dtrl_get_flags(dtrl_batch* b, const int32_t* env_ids, int n, uint32_t* bits);
 /* Replaces: cSimCharacter::GetBodyPart(i)->GetPos() / GetLinearVelocity() / GetRotation() (sim/SimCharacter.cpp:317-352, sim/SimObj.cpp:

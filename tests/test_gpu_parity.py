@@ -46,6 +46,10 @@ def test_nn_forward(da, om):
     T.test_nn_forward_golden(da, om)
 
 
+def test_policy_output_all_net_families(da, om):
+    T.test_policy_output_vs_oracle_forward(da, om)
+
+
 def test_exploration_tuples(da, om):
     T.test_exploration_tuples_vs_oracle_and_golden(da, om)
 

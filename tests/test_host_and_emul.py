@@ -289,6 +289,47 @@ def test_nn_forward_golden(da, om):
     assert np.abs(prm[0][1:] - y[3 + 29 * a: 3 + 29 * (a + 1)] * np.where(np.arange(1, 30) == 1, np.sign(y[3 + 29 * a]), 1)).max() < 1e-7 * np.abs(y).max()
 
 
+def test_policy_output_vs_oracle_forward(da, om):
+    """The in-kernel forward by itself (conv stack + terr_ip0 fused over position tiles in LDS, trunk, heads; learning/NeuralNet.cpp:352-375):
+    dtrl_get_policy_output = cNeuralNet::GetLayerState("output") after the controller's last Eval, against the oracle's forward of the SAME recorded
+    policy state, for the four net families (MACE dog 283 -> 90, MACE raptor 275 -> 87 with its stance-mirrored input, Q 283 -> 8, CACLA actor 283 -> 29).
+    fp64 on both sides; terr_ip0 sums tile-major here and channel-major in the oracle, hence a tolerance (1e-14 of the largest output; observed 2.4e-16) and not bits."""
+    cases = []
+    pol = dog_policy(om)
+    cases.append(("args/dog_slopes_mixed_args.txt", {}, pol, pol, 40))
+    rp = raptor_policy(om)
+    cases.append(("args/raptor_narrow_gaps_args.txt", {}, rp, rp, 60))
+    for arg, net, seed in (("args/opt_args_train_q.txt", "dog_q_deploy.prototxt", 31), ("args/opt_args_train_cacla.txt", "dog_actor_deploy.prototxt", 77)):
+        desc = om.parse_deploy_prototxt(os.path.join(REFDATA, "data/policies/dog/nets", net))
+        w = om.actor_xavier_weights(desc, seed)
+        cases.append((arg, dict(exp_rate=0.0, exp_base_rate=0.0), (desc, w, None, None, None, None), None, 40))
+    for arg, over, pol, opol, frames in cases:
+        m, _ = om.build_model(arg, REFDATA, over)
+        n = 3
+        b = batch(da, arg, n, terrain_seed=70, rand_seed=2, **over)
+        assert np.array_equal(b.PolicyOutput(), np.zeros((n, b.nn_out)))          # nothing evaluated yet
+        if opol is None:   # single-head nets: the engine takes the net's own blob, the oracle the MACE-padded form (one zero critic slot in front)
+            oo, osc = b.BuildNNOutputOffsetScale()
+            io, isc = np.zeros(b.S), np.ones(b.S)
+            b.SetPolicy(pol[1], io, isc, oo, osc)
+            wm, oom, osm = om.actor_policy_to_mace(pol[0], pol[1], oo, osc)
+            opol = (pol[0], wm, io, isc, oom, osm)
+        else:
+            b.SetPolicy(pol[1], *pol[2:])
+        e = om.OracleEnv(m, terrain_seed=70, rng_seed=2, env_id=0, policy=opol)
+        seen = 0
+        for f in range(frames):
+            b.Update()
+            y = b.PolicyOutput(); s = b.RecordPoliState()
+            for i in range(n):
+                if not np.any(y[i]):
+                    continue
+                yo = e.nn_eval(s[i])[-b.nn_out:]
+                assert np.abs(y[i] - yo).max() <= 1e-14 * np.abs(yo).max(), (arg, f, i, np.abs(y[i] - yo).max())
+                seen += 1
+        assert seen >= frames, (arg, seen)
+
+
 def test_exploration_tuples_vs_oracle_and_golden(da, om):
     """cScenarioExp semantics with exploration on (args/opt_args_train_mace.txt): tuple rows [r | s | a | s'], flags and
     emitting env ids equal the oracle's and the committed golden rows (MACE replay layout, learning/MACETrainer.cpp:373-401)."""
