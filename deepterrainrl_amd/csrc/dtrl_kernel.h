@@ -1051,7 +1051,7 @@ DTRL_HD inline void apply_action(W& ws, int id, const real* params, int P)
 // Accumulation order per conv output is the reference order; terr_ip0 sums tile-major (tile, channel, position) instead of Caffe's
 // gemv order, which is unspecified anyway (the reference computes in fp32 through BLAS) -- the oracle sums channel-major and the
 // parity tests hold to their fp64 tolerance.
-constexpr int kMaxConvCh = 32, kMaxConvK = 8;
+constexpr int kMaxConvCh = 32;
 static_assert(kNNTileBuf == (kMaxRows + 1) * kZStride, "the tile buffer of the policy forward is the Z storage");
 static_assert(kMaxConvCh * kConvTile % kGroup == 0, "lane-loop form of conv_tile");
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -330,6 +330,24 @@ def test_policy_output_vs_oracle_forward(da, om):
         assert seen >= frames, (arg, seen)
 
 
+def test_policy_net_outside_the_on_chip_family_is_rejected(da, om, tmp_path):
+    """The forward keeps its activations in the env's LDS workspace, which bounds the deploy nets it takes: 16 / 32 conv channels, kernel widths 4 / 8,
+    tiles that fit the 625-double buffer. Anything else fails dtrl_create with a message (no silent fallback to another path)."""
+    import shutil
+    root = tmp_path / "refdata"
+    shutil.copytree(REFDATA, root)
+    net = root / "data" / "policies" / "dog" / "nets" / "dog_mace3_deploy.prototxt"
+    text = net.read_text()
+    for old, new, msg in (("kernel_w: 8", "kernel_w: 5", "kernel width 4 or 8"),
+                          ('name: "terr_conv2" type: "Convolution" num_output: 32 kernel_w: 4', 'name: "terr_conv2" type: "Convolution" num_output: 32 kernel_w: 8', "on-chip workspace")):
+        assert old in text
+        net.write_text(text.replace(old, new, 1))
+        with pytest.raises(da.DtrlError, match=msg):
+            Scenario("args/dog_slopes_mixed_args.txt", 1, data_root=str(root))
+    net.write_text(text)
+    Scenario("args/dog_slopes_mixed_args.txt", 1, data_root=str(root)).close()
+
+
 def test_exploration_tuples_vs_oracle_and_golden(da, om):
     """cScenarioExp semantics with exploration on (args/opt_args_train_mace.txt): tuple rows [r | s | a | s'], flags and
     emitting env ids equal the oracle's and the committed golden rows (MACE replay layout, learning/MACETrainer.cpp:373-401)."""
