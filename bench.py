@@ -65,7 +65,7 @@ def load_scale():
     return [np.asarray(d[k], np.float64) for k in ("InputOffset", "InputScale", "OutputOffset", "OutputScale")]
 
 
-def cpu_baseline(frames=100):
+def cpu_baseline(frames=60):
     """The oracle restatement (NOT Bullet -- the reference cannot be built here) timed on the host cores, bounded sample."""
     from oracle import model as om
     m, info = om.build_model(ARG_FILE, ROOT)
@@ -166,7 +166,7 @@ def main():
                     help="host: the reference's terrain generator streams (bit-exact windows), regenerated by host workers at the frame boundary (default, the parity-tested mode); "
                          "device: counter-based streams, windows generated and slid by the GPU, no host sync per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=100, help="outer frames of the bounded CPU-baseline sample (default: about 30 s of CPU work)")
+    ap.add_argument("--cpu-frames", type=int, default=60, help="outer frames of the bounded CPU-baseline sample (default: 20-30 s of CPU work on the box's 256 threads)")
     ap.add_argument("--exchange-steps", type=int, default=-1, help="timed frames of the exchange leg (default: half of --steps; 0 = skip)")
     ap.add_argument("--bcast-every", type=int, default=10, help="exchange leg: policy broadcast every K frames")
     a = ap.parse_args()
