@@ -65,6 +65,9 @@ def load_scale():
     return [np.asarray(d[k], np.float64) for k in ("InputOffset", "InputScale", "OutputOffset", "OutputScale")]
 
 
+EXCHANGE_GUARD_S = 180   # wall-clock bound of the exchange leg on a multi-rank run (see main)
+
+
 def cpu_baseline(frames=60):
     """The oracle restatement (NOT Bullet -- the reference cannot be built here) timed on the host cores, bounded sample."""
     from oracle import model as om
@@ -90,7 +93,7 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
         b = da.BatchScenario(EXCHANGE_ARG_FILE, n_local, data_root=ROOT, device_id=local_rank,
                              extra_args={"terrain_seed": 20260925, "rand_seed": 1, "global_env_offset": off})
         return b
-    sr = ShardedRollout(make, n * world, dist=dist if world > 1 else None, device=dev)
+    sr = ShardedRollout(make, n * world, dist=dist, device=dev)   # dist is None on a plain 1-GPU run (no collective), a process group otherwise
     b = sr.batch
     if rank == 0:
         sr.broadcast_policy(w, *scale, src=0)
@@ -104,7 +107,7 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
     pol = [v.clone() for v in sr._pol_views()]
 
     def fence():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,7 +148,7 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
     sr.UpdateEnd()
     if sr._pending is not None:
         sr.gather_tuples_end(dst=0)
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -153,7 +156,7 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
     return {"workload": "BASELINE configs[3] shape: dog slopes_mixed, exploration on (0.2 / 0.025 / 0.002), %d envs per GPU x %d GPUs; per outer frame: device tuple drain -> one all-gather (RCCL) on a side stream overlapped with the next frame kernel -> device replay ring on rank 0; one packed policy broadcast every %d frames" % (n, world, bcast_every),
             "env_steps_per_s": float(world) * n * steps * 20 / dt, "tuples_per_s": tuples / dt, "tuples": tuples, "steps": steps, "ms_per_step": dt / steps * 1e3,
             "exchange_wait_ms_per_step": sr.exchange_wait_s / steps * 1e3, "tuple_block_bytes": int(sr.block.numel() * 4), "policy_bytes": int(sr.pol_bytes),
-            "bcast_every": bcast_every, "dropped_tuples": b.TupleStats()["dropped"] - drop0, "kernel_avg_ms": kern_ms, "collective": "all_gather (RCCL)" if world > 1 else "none (1 rank: device drain + replay append only)"}
+            "bcast_every": bcast_every, "dropped_tuples": b.TupleStats()["dropped"] - drop0, "kernel_avg_ms": kern_ms, "collective": ("all_gather (RCCL)" + ("" if world > 1 else " on a one-rank group (DTRL_FORCE_COLLECTIVES)")) if sr.coll else "none (1 rank: device drain + replay append only)"}
 
 
 def main():
@@ -176,10 +179,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     import torch
-    if world > 1:
+    force = os.environ.get("DTRL_FORCE_COLLECTIVES") == "1"   # validation hook: a one-rank RCCL group, so that a 1-GPU box runs the collective code path
+    if world > 1 or force:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+        import datetime
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=EXCHANGE_GUARD_S + 60))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
@@ -254,10 +261,23 @@ def main():
     ex = None
     if ex_steps > 0:
         b.close()
+        guard = None
+        if rank == 0 and dist is not None:
+            # a collective that never completes (a rank died mid-exchange) must not cost the headline measurement above: after EXCHANGE_GUARD_S
+            # seconds rank 0 prints the line with the failure recorded and leaves; the other ranks end at the process group's timeout
+            import threading
+
+            def give_up():
+                line["exchange"] = {"error": "exchange leg did not finish within %d s" % EXCHANGE_GUARD_S}
+                print(json.dumps(line), flush=True)
+                os._exit(0)
+            guard = threading.Timer(EXCHANGE_GUARD_S, give_up); guard.daemon = True; guard.start()
         try:
-            ex = exchange_leg(da, dist, torch, world, rank, local_rank, n, ex_steps, max(a.warmup // 2, 2), a.bcast_every, w, load_scale())
+            ex = exchange_leg(da, dist, torch, world, rank, local_rank, n, ex_steps, max(a.warmup // 2, 30), a.bcast_every, w, load_scale())   # >= 30 untimed frames: the first tuples complete after two gait cycles (~25 frames)
         except Exception as exc:   # the headline measurement above stands on its own: report the failure instead of losing the line
             ex = {"error": repr(exc)}
+        if guard is not None:
+            guard.cancel()
     if rank == 0:
         line["exchange"] = ex
         if world == 1 and not a.no_cpu_baseline:

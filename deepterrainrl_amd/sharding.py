@@ -35,12 +35,18 @@ class ShardedRollout:
     """One rank's shard of a global batch + the two exchange steps. `dist` is torch.distributed (already initialised) or None.
     `device`: torch device of the exchange buffers -- the GPU the batch runs on (RCCL), or None / "cpu" with a gloo group."""
 
-    def __init__(self, make_batch, global_envs, dist=None, device=None):
+    def __init__(self, make_batch, global_envs, dist=None, device=None, force_collectives=None):
+        import os
         import torch
         self.torch = torch
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
+        # collectives run when there is more than one rank; force_collectives (or DTRL_FORCE_COLLECTIVES=1) runs them on a one-rank group as
+        # well, which is how the RCCL code path is exercised on a single-GPU box
+        if force_collectives is None:
+            force_collectives = os.environ.get("DTRL_FORCE_COLLECTIVES") == "1"
+        self.coll = dist is not None and (self.world > 1 or bool(force_collectives))
         self.offset, self.n_local = shard_range(global_envs, self.world, self.rank)
         self.global_envs = int(global_envs)
         self.batch = make_batch(self.n_local, self.offset)
@@ -49,7 +55,7 @@ class ShardedRollout:
         b = self.batch
         self.cap = int(b.TupleStats()["capacity"])
         caps = [self.cap]
-        if self.world > 1:
+        if self.coll:
             t = torch.tensor([self.cap], dtype=torch.int64, device=self.device)
             lst = [torch.zeros_like(t) for _ in range(self.world)]
             dist.all_gather(lst, t)
@@ -58,7 +64,7 @@ class ShardedRollout:
         W = b.W
         # this rank's block: header row + cap tuple rows, W floats + [flags, global env id] as int32 bit patterns
         self.block = torch.zeros((self.cap + 1, W + 2), dtype=torch.float32, device=self.device)
-        self.gathered = [torch.zeros_like(self.block) for _ in range(self.world)] if self.world > 1 else None
+        self.gathered = [torch.zeros_like(self.block) for _ in range(self.world)] if self.coll else None
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self._pending = None
         # policy buffer: [weights f32 | in_off | in_scale | out_off | out_scale f64], 8-byte aligned sections
@@ -90,7 +96,7 @@ class ShardedRollout:
         assert self._pending is None, "gather_tuples_begin called twice without gather_tuples_end"
         self.batch.DrainTuplesPacked(self.block.data_ptr(), self.cap)        # synchronised: the block is complete when this returns
         work = None
-        if self.world > 1:
+        if self.coll:
             if self.on_gpu:
                 with torch.cuda.stream(self.comm_stream):
                     work = self.dist.all_gather(self.gathered, self.block, async_op=True)
@@ -114,8 +120,8 @@ class ShardedRollout:
         self.exchange_wait_s += time.perf_counter() - t0
         if self.rank != dst:
             return None
-        blocks = self.gathered if self.world > 1 else [self.block]
-        if self.world == 1:
+        blocks = self.gathered if self.coll else [self.block]
+        if not self.coll:
             c = int(self.block[0, :1].view(torch.int32).item())       # one 4-byte read-back; the rows below are views into the block (valid until the next begin)
             blk = self.block[1:c + 1]
             meta = blk[:, W:].view(torch.int32)
@@ -155,7 +161,7 @@ class ShardedRollout:
             for v, a in zip(views, (weights, in_off, in_scale, out_off, out_scale)):
                 t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a, np.float32 if v.dtype == torch.float32 else np.float64))
                 v.copy_(t.to(self.device, dtype=v.dtype).reshape(-1))
-        if self.dist is not None and self.world > 1:
+        if self.coll:
             self.dist.broadcast(self.pol_buf, src=src)
         if self.on_gpu:
             torch.cuda.current_stream(self.device).synchronize()
