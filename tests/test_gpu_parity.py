@@ -50,6 +50,10 @@ def test_policy_output_all_net_families(da, om):
     T.test_policy_output_vs_oracle_forward(da, om)
 
 
+def test_policy_forward_other_shapes(da, om, tmp_path):
+    T.test_policy_forward_other_conv_shapes_and_nonzero_biases(da, om, tmp_path)
+
+
 def test_exploration_tuples(da, om):
     T.test_exploration_tuples_vs_oracle_and_golden(da, om)
 

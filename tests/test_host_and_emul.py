@@ -330,6 +330,47 @@ def test_policy_output_vs_oracle_forward(da, om):
         assert seen >= frames, (arg, seen)
 
 
+def test_policy_forward_other_conv_shapes_and_nonzero_biases(da, om, tmp_path):
+    """The tiled forward away from the shipped 16x8 / 32x4 / 32x4 stack: other channel counts and kernel widths change the tile strides, the number
+    of valid positions per tile (V = 10, 6, 10), leave a one-position last tile, run a 16-channel conv2 (one matrix tile instead of two) and give
+    terr_ip0 chunks that are not multiples of 32 inputs; biases are random here (the synthetic xavier blobs carry zero biases)."""
+    import shutil
+    root = tmp_path / "refdata"
+    shutil.copytree(REFDATA, root)
+    net = root / "data" / "policies" / "dog" / "nets" / "dog_mace3_deploy.prototxt"
+    text = net.read_text()
+    lines = ['layer { name: "terr_conv%d" type: "Convolution" num_output: %d kernel_w: %d }' % (i, c, k) for i, (c, k) in enumerate(((16, 8), (32, 4), (32, 4)))]
+    assert all(l in text for l in lines)
+    io, isc, oo, osc = om.load_scale_file(os.path.join(REFDATA, "data/policies/dog/models/dog_mace3_slopes_mixed_model_scale.txt"))
+    for shape in (((32, 4), (32, 4), (32, 4)), ((16, 4), (16, 8), (32, 4)), ((16, 8), (32, 4), (16, 4)), ((16, 8), (32, 4), (32, 4))):
+        t = text
+        for i, (c, k) in enumerate(shape):
+            t = t.replace(lines[i], 'layer { name: "terr_conv%d" type: "Convolution" num_output: %d kernel_w: %d }' % (i, c, k))
+        net.write_text(t)
+        desc = om.parse_deploy_prototxt(str(net))
+        w = om.xavier_weights(desc, 99)
+        rng = np.random.RandomState(5)
+        zero = w == 0
+        w[zero] = rng.uniform(-0.2, 0.2, int(zero.sum())).astype(np.float32)       # every bias
+        m, _ = om.build_model("args/dog_slopes_mixed_args.txt", str(root))
+        n = 2
+        b = Scenario("args/dog_slopes_mixed_args.txt", n, data_root=str(root), extra_args=dict(terrain_seed=12))
+        assert b.PolicyNumParams() == len(w)
+        b.SetPolicy(w, io, isc, oo, osc)
+        e = om.OracleEnv(m, terrain_seed=12, policy=(desc, w, io, isc, oo, osc))
+        seen = 0
+        for f in range(16):
+            b.Update()
+            y = b.PolicyOutput(); st = b.RecordPoliState()
+            for i in range(n):
+                if np.any(y[i]):
+                    yo = e.nn_eval(st[i])
+                    assert np.abs(y[i] - yo).max() <= 1e-14 * np.abs(yo).max(), (shape, f, i, np.abs(y[i] - yo).max())
+                    seen += 1
+        assert seen >= 16, (shape, seen)
+        b.close()
+
+
 def test_policy_net_outside_the_on_chip_family_is_rejected(da, om, tmp_path):
     """The forward keeps its activations in the env's LDS workspace, which bounds the deploy nets it takes: 16 / 32 conv channels, kernel widths 4 / 8,
     tiles that fit the 625-double buffer. Anything else fails dtrl_create with a message (no silent fallback to another path)."""
