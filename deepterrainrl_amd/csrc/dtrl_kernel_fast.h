@@ -630,11 +630,9 @@ struct FastPath {
 		const unsigned long long prof_sub_t0 = __builtin_readcyclecounter();
 #endif
 		if (!kin_valid) { PROF_T0(); kin_dyn_terms(ws); PROF_ADD(ws, kProfFK); }
-		real hrow[D];
-		{ PROF_T0(); mass_row<D>(ws, hrow); PROF_ADD(ws, kProfMass); }
-		real dinv;
-		{ PROF_T0(); dinv = factorize_regs<Topo>(ws, hrow); PROF_ADD(ws, kProfFact); }
-		// the post-step contact pass of the previous env-step (contacts() below) ran at this very configuration and left its constraint
+		// constraint rows first, factorisation second: the two are independent (both read the kinematics only), and in this order neither the
+		// 23 doubles of the lane's matrix row are live across the contact pass (and its out-of-line calls) nor the sample points across the elimination.
+		// The post-step contact pass of the previous env-step (contacts() below) ran at this very configuration and left its constraint
 		// row list in LDS: the first substep of an env-step takes it over instead of sampling the heightfield again
 		const int rows_ready = kin_valid ? ws.n_pts_active : -1;   // wave-uniform
 		if (rows_ready >= 0) {
@@ -645,6 +643,10 @@ struct FastPath {
 			{ PROF_T0(); cp = eval_points<false>(ws, gm, g); PROF_ADD(ws, kProfDetect); }   // the per-link contact flags are the post-step pass's business (contacts() below)
 			{ PROF_T0(); build_rows_fast(ws, gm, cp, h); PROF_ADD(ws, kProfRows); }
 		}
+		real hrow[D];
+		{ PROF_T0(); mass_row<D>(ws, hrow); PROF_ADD(ws, kProfMass); }
+		real dinv;
+		{ PROF_T0(); dinv = factorize_regs<Topo>(ws, hrow); PROF_ADD(ws, kProfFact); }
 		const int R = ws.R;
 		if (lane == 0) ws.cost += 8 + R;
 		{
