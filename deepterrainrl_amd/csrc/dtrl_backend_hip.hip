@@ -151,7 +151,8 @@ public:
 	void Free(void* p) override { hipFree(p); }
 	bool H2D(void* dst, const void* src, size_t n) override { return Check(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream_), "hipMemcpy H2D") && Check(hipStreamSynchronize(stream_), "sync"); }
 	bool H2DAsync(void* dst, const void* src, size_t n) override { return Check(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync H2D"); }
-	void* HostStaging(size_t bytes) override { void* p = nullptr; return Check(hipHostMalloc(&p, bytes, hipHostMallocDefault), "hipHostMalloc") ? p : nullptr; }
+	void* HostStaging(size_t bytes) override { void* p = nullptr; return Check(hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc") ? p : nullptr; }
+	bool SyncSelected() override { return Check(hipStreamSynchronize(stream_), "hipStreamSynchronize"); }
 	void FreeHostStaging(void* p) override { if (p) hipHostFree(p); }
 	bool D2H(void* dst, const void* src, size_t n) override { return Check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream_), "hipMemcpy D2H") && Check(hipStreamSynchronize(stream_), "sync"); }
 	bool D2D(void* dst, const void* src, size_t n) override { return Check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, stream_), "hipMemcpy D2D") && Check(hipStreamSynchronize(stream_), "sync"); }

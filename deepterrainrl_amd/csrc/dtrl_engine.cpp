@@ -218,6 +218,12 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	grounds_.resize(n_);
 	status_ = static_cast<EnvStatus*>(be_->HostStaging(sizeof(EnvStatus) * n_));
 	if (!status_) return Fail(DTRL_ERR_DEVICE, "host staging allocation failed: " + be_->error());
+	// host terrain mode: no copy at the frame boundary. The frame kernel writes its 24-byte status records straight into this page-locked host array,
+	// and the launch order, the reset lists and the regenerated terrain records are read by the kernels from the page-locked arrays the host filled
+	// (a copy is a blit kernel that queues behind 2048 resident wavefronts: ~160 us each, three to four per group-frame). In device terrain mode the status
+	// stays in device memory, where the boundary kernels read it.
+	zero_copy_ = !cfg_.device_terrain;
+	if (zero_copy_) buf_.status = status_;
 	double params[kNumTerrainParams];
 	LerpTerrainParams(cfg_, cfg_.terrain_blend, params);
 	if (cfg_.device_terrain) {
@@ -264,9 +270,9 @@ int Engine::ApplyResets(const std::vector<int32_t>& ids, int group)
 	if (ids.empty()) return DTRL_OK;
 	const int off = group >= 0 ? groups_[group].e0 : 0;
 	std::memcpy(pin_ids_ + off, ids.data(), sizeof(int32_t) * ids.size());
-	if (!be_->H2DAsync(d_env_list_ + off, pin_ids_ + off, sizeof(int32_t) * ids.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!zero_copy_ && !be_->H2DAsync(d_env_list_ + off, pin_ids_ + off, sizeof(int32_t) * ids.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
 	DevBuffers b = buf_;
-	b.env_list = d_env_list_ + off;
+	b.env_list = (zero_copy_ ? pin_ids_ : d_env_list_) + off;
 	b.reset_listed = 1;
 	if (!be_->Launch(d_model_, cfg_.run, b, static_cast<int>(ids.size()), 0, 0.0, false)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	return DTRL_OK;
@@ -286,7 +292,7 @@ int Engine::LaunchGroup(int group, int n_steps, double dt_step, bool frame_end)
 	const Group& g = groups_[group];
 	be_->SelectStream(group);
 	DevBuffers b = buf_;
-	b.env_list = d_order_ + g.e0;   // the group's launch order (global env ids), costliest first
+	b.env_list = (zero_copy_ ? pin_order_ : d_order_) + g.e0;   // the group's launch order (global env ids), costliest first
 	const double lt0 = g_ht.on ? now_s() : 0;
 	bool ok = be_->Launch(d_model_, cfg_.run, b, g.n, n_steps, dt_step, frame_end);
 	if (g_ht.on) g_ht.t_launch += now_s() - lt0;
@@ -356,7 +362,7 @@ int Engine::HostFrameWork(int group)
 	struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
 	// the status read-back synchronises the group's stream: its frame kernel and every upload queued during its previous frame
 	// have completed, so its slice of the staging arena can be reused from the start
-	if (!be_->D2H(status_ + e0, buf_.status + e0, sizeof(EnvStatus) * grp.n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!(zero_copy_ ? be_->SyncSelected() : be_->D2H(status_ + e0, buf_.status + e0, sizeof(EnvStatus) * grp.n))) return Fail(DTRL_ERR_DEVICE, be_->error());
 	const double ht1 = g_ht.on ? now_s() : 0;
 	reset_ids_.clear();
 	work_.clear();
@@ -385,7 +391,9 @@ int Engine::HostFrameWork(int group)
 			pin_stage_ids_[e0 + k] = e;
 		});
 		if (failed.load()) return Fail(DTRL_ERR_CAPACITY, "terrain segment exceeds kSegCap vertices");
-		if (!be_->H2DAsync(d_stage_recs_ + e0, pin_recs_ + e0, sizeof(GroundRec) * used) || !be_->H2DAsync(d_stage_ids_ + e0, pin_stage_ids_ + e0, sizeof(int32_t) * used)
+		if (zero_copy_) {
+			if (!be_->ScatterGround(buf_.gr, pin_recs_ + e0, pin_stage_ids_ + e0, used)) return Fail(DTRL_ERR_DEVICE, be_->error());   // the scatter kernel reads the host slice
+		} else if (!be_->H2DAsync(d_stage_recs_ + e0, pin_recs_ + e0, sizeof(GroundRec) * used) || !be_->H2DAsync(d_stage_ids_ + e0, pin_stage_ids_ + e0, sizeof(int32_t) * used)
 			|| !be_->ScatterGround(buf_.gr, d_stage_recs_ + e0, d_stage_ids_ + e0, used)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	}
 	const double ht2 = g_ht.on ? now_s() : 0;
@@ -398,7 +406,7 @@ int Engine::HostFrameWork(int group)
 	for (int e = e0; e < e1; ++e) ++bucket_[key(e) + 1];
 	for (int k = 0; k < kBuckets; ++k) bucket_[k + 1] += bucket_[k];
 	for (int e = e0; e < e1; ++e) pin_order_[e0 + bucket_[key(e)]++] = e;
-	if (!be_->H2DAsync(d_order_ + e0, pin_order_ + e0, sizeof(int32_t) * grp.n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!zero_copy_ && !be_->H2DAsync(d_order_ + e0, pin_order_ + e0, sizeof(int32_t) * grp.n)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	const double ht3 = g_ht.on ? now_s() : 0;
 	const int rc = ApplyResets(reset_ids_, group);
 	if (g_ht.on) { const double ht4 = now_s(); g_ht.t_sync += ht1 - ht0; g_ht.t_loop += ht2 - ht1; g_ht.t_sort += ht3 - ht2; g_ht.t_reset += ht4 - ht3; g_ht.regen += used; ++g_ht.n; }

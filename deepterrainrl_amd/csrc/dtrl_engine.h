@@ -18,7 +18,8 @@ public:
 	virtual bool H2D(void* dst, const void* src, size_t n) = 0;
 	// stream-ordered upload without a host sync; src must come from HostStaging() and stay untouched until the next Sync()/D2H()
 	virtual bool H2DAsync(void* dst, const void* src, size_t n) = 0;
-	virtual void* HostStaging(size_t bytes) = 0;   // page-locked host memory (plain malloc in the test backend)
+	virtual void* HostStaging(size_t bytes) = 0;   // page-locked host memory the device can address directly through the same pointer (coherent; plain malloc in the test backend)
+	virtual bool SyncSelected() = 0;               // wait for the selected stream
 	virtual void FreeHostStaging(void* p) = 0;
 	virtual bool D2H(void* dst, const void* src, size_t n) = 0;
 	virtual bool D2D(void* dst, const void* src, size_t n) = 0;   // device-to-device on the selected stream, synchronised before returning
@@ -118,7 +119,8 @@ private:
 	DevBuffers buf_{};
 	std::vector<void*> allocs_;
 	std::vector<GroundWindow> grounds_;
-	EnvStatus* status_ = nullptr;   // page-locked: the per-frame read-back lands here without a staging copy
+	EnvStatus* status_ = nullptr;   // page-locked; in host terrain mode the frame kernel writes it directly (zero_copy_), else the per-frame read-back lands here
+	bool zero_copy_ = false;        // host terrain mode: status, launch order, reset lists and terrain records cross the boundary without a copy (dtrl_engine.cpp Init)
 	GroundRec tmp_rec_;
 	TerrainCfg* d_tcfg_ = nullptr;
 	int32_t* d_tuple_rank_ = nullptr;

@@ -22,6 +22,7 @@ public:
 	bool H2DAsync(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
 	void* HostStaging(size_t bytes) override { return std::calloc(1, bytes ? bytes : 1); }
 	void FreeHostStaging(void* p) override { std::free(p); }
+	bool SyncSelected() override { return true; }
 	bool D2H(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
 	bool D2D(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
 	bool ScatterGround(GroundRec* gr, const GroundRec* staged, const int32_t* ids, int n) override { for (int k = 0; k < n; ++k) gr[ids[k]] = staged[k]; return true; }
