@@ -107,7 +107,7 @@ Engine::~Engine()
 	if (be_) {
 		be_->Sync();
 		for (void* p : allocs_) be_->Free(p);
-		be_->FreeHostStaging(pin_recs_); be_->FreeHostStaging(pin_order_); be_->FreeHostStaging(pin_ids_); be_->FreeHostStaging(pin_stage_ids_); be_->FreeHostStaging(status_);
+		be_->FreeHostStaging(pin_recs_); be_->FreeHostStaging(pin_order_); be_->FreeHostStaging(pin_ids_); be_->FreeHostStaging(pin_stage_ids_); be_->FreeHostStaging(status_); be_->FreeHostStaging(stage_slot_);
 		delete be_;
 	}
 }
@@ -223,7 +223,13 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	// (a copy is a blit kernel that queues behind 2048 resident wavefronts: ~160 us each, three to four per group-frame). In device terrain mode the status
 	// stays in device memory, where the boundary kernels read it.
 	zero_copy_ = !cfg_.device_terrain;
-	if (zero_copy_) buf_.status = status_;
+	if (zero_copy_) {
+		buf_.status = status_;
+		stage_slot_ = static_cast<int32_t*>(be_->HostStaging(sizeof(int32_t) * n_));
+		if (!stage_slot_) return Fail(DTRL_ERR_DEVICE, "host staging allocation failed: " + be_->error());
+		std::memset(stage_slot_, 0, sizeof(int32_t) * n_);
+		buf_.stage_slot = stage_slot_; buf_.gr_stage = pin_recs_;
+	}
 	double params[kNumTerrainParams];
 	LerpTerrainParams(cfg_, cfg_.terrain_blend, params);
 	if (cfg_.device_terrain) {
@@ -245,6 +251,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 		if (!g.FillRecord(recs[e], err_)) return DTRL_ERR_CAPACITY;
 	}
 	if (!be_->H2D(buf_.gr, recs.data(), sizeof(GroundRec) * n_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (stage_slot_) std::memset(stage_slot_, 0, sizeof(int32_t) * n_);
 	}
 	std::vector<EnvState> st(n_);
 	std::memset(st.data(), 0, sizeof(EnvState) * n_);
@@ -256,9 +263,18 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	return DTRL_OK;
 }
 
+// tmp_rec_ = the env's current ground record: the device copy, or -- host terrain mode -- the regenerated record still waiting in page-locked
+// memory for the env's next launch to copy it in (call after Sync())
+bool Engine::FetchGroundRec(int env)
+{
+	if (zero_copy_ && stage_slot_[env] > 0) { std::memcpy(&tmp_rec_, &pin_recs_[stage_slot_[env] - 1], sizeof(GroundRec)); return true; }
+	return be_->D2H(&tmp_rec_, &buf_.gr[env], sizeof(GroundRec));
+}
+
 bool Engine::UploadGround(int env)
 {
 	if (!grounds_[env].FillRecord(tmp_rec_, err_)) return false;
+	if (zero_copy_) stage_slot_[env] = 0;   // a record waiting for the env's next launch is superseded
 	if (!be_->H2D(&buf_.gr[env], &tmp_rec_, sizeof(GroundRec))) { err_ = be_->error(); return false; }
 	return true;
 }
@@ -389,12 +405,11 @@ int Engine::HostFrameWork(int group)
 			std::string err;
 			if (!g.FillRecord(pin_recs_[e0 + k], err)) failed.store(1);
 			pin_stage_ids_[e0 + k] = e;
+			if (zero_copy_) stage_slot_[e] = e0 + k + 1;   // the env's wavefront copies the record in at the start of its next launch (the reset launch below, or the next frame)
 		});
 		if (failed.load()) return Fail(DTRL_ERR_CAPACITY, "terrain segment exceeds kSegCap vertices");
-		if (zero_copy_) {
-			if (!be_->ScatterGround(buf_.gr, pin_recs_ + e0, pin_stage_ids_ + e0, used)) return Fail(DTRL_ERR_DEVICE, be_->error());   // the scatter kernel reads the host slice
-		} else if (!be_->H2DAsync(d_stage_recs_ + e0, pin_recs_ + e0, sizeof(GroundRec) * used) || !be_->H2DAsync(d_stage_ids_ + e0, pin_stage_ids_ + e0, sizeof(int32_t) * used)
-			|| !be_->ScatterGround(buf_.gr, d_stage_recs_ + e0, d_stage_ids_ + e0, used)) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (!zero_copy_ && (!be_->H2DAsync(d_stage_recs_ + e0, pin_recs_ + e0, sizeof(GroundRec) * used) || !be_->H2DAsync(d_stage_ids_ + e0, pin_stage_ids_ + e0, sizeof(int32_t) * used)
+			|| !be_->ScatterGround(buf_.gr, d_stage_recs_ + e0, d_stage_ids_ + e0, used))) return Fail(DTRL_ERR_DEVICE, be_->error());
 	}
 	const double ht2 = g_ht.on ? now_s() : 0;
 	// longest-processing-time-first: a launch is as long as its slowest wavefront (a stumbling character with ~20 constraint
@@ -891,8 +906,8 @@ int Engine::SampleGround(int env, int n, const double* x, double* h, int32_t* se
 {
 	if (env < 0 || env >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
 	be_->Sync();
-	// reads back the DEVICE copy of the env's ground record and applies the same sampling routine the kernel uses
-	if (!be_->D2H(&tmp_rec_, &buf_.gr[env], sizeof(GroundRec))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	// reads back the env's ground record as the kernel will see it and applies the same sampling routine the kernel uses
+	if (!FetchGroundRec(env)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	for (int i = 0; i < n; ++i) {
 		int a, b, s;
 		h[i] = sample_ground(tmp_rec_, x[i], nullptr, &a, &b, &s);
@@ -907,7 +922,7 @@ int Engine::GroundWindowRec(int env, int32_t* w2, double* min_x2, double* max_x2
 {
 	if (env < 0 || env >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
 	be_->Sync();
-	if (!be_->D2H(&tmp_rec_, &buf_.gr[env], sizeof(GroundRec))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!FetchGroundRec(env)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	float* dst[2] = {h0, h1};
 	for (int s = 0; s < 2; ++s) {
 		if (w2) w2[s] = tmp_rec_.w[s];

@@ -108,6 +108,7 @@ private:
 	int32_t* d_order_ = nullptr;         // launch order of the full-batch frame launches (costliest env first)
 	std::vector<int32_t> reset_ids_;
 	bool UploadGround(int env);
+	bool FetchGroundRec(int env);
 	int EnvIndex(const int32_t* env_ids, int i) const { return env_ids ? env_ids[i] : i; }
 
 	ScenarioConfig cfg_;
@@ -120,6 +121,7 @@ private:
 	std::vector<void*> allocs_;
 	std::vector<GroundWindow> grounds_;
 	EnvStatus* status_ = nullptr;   // page-locked; in host terrain mode the frame kernel writes it directly (zero_copy_), else the per-frame read-back lands here
+	int32_t* stage_slot_ = nullptr;  // page-locked [n]: slot + 1 of the env's regenerated terrain record in pin_recs_, 0 = none (cleared by the env's wavefront)
 	bool zero_copy_ = false;        // host terrain mode: status, launch order, reset lists and terrain records cross the boundary without a copy (dtrl_engine.cpp Init)
 	GroundRec tmp_rec_;
 	TerrainCfg* d_tcfg_ = nullptr;

@@ -110,6 +110,9 @@ struct DevBuffers {
 	GroundGen* gen;
 	const TerrainCfg* tcfg;
 	DistRec* dist_ring; int32_t* dist_count; int32_t dist_cap;
+	// host terrain mode: regenerated terrain windows wait in page-locked HOST memory (gr_stage[slot]); stage_slot[env] = slot + 1 tells the env's own
+	// wavefront to copy its record in at the start of its next launch (no upload, no scatter launch at the frame boundary); null otherwise
+	const GroundRec* gr_stage; int32_t* stage_slot;
 	const float* weights;
 	const real* in_off; const real* in_scale; const real* out_off; const real* out_scale;
 	NetDesc net;
@@ -1998,6 +2001,18 @@ DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, co
 		LANES_BEGIN
 		for (int i = lane; i < static_cast<int>(sizeof(EnvState) / 8); i += kGroup) dst[i] = src[i];
 		LANES_END
+	}
+	if (buf.stage_slot != nullptr) {
+		const int slot = buf.stage_slot[env] - 1;   // wave-uniform
+		if (__builtin_expect(slot >= 0, 0)) {
+			static_assert(sizeof(GroundRec) % 16 == 0, "GroundRec is copied as 16-byte words");
+			const F4* src = reinterpret_cast<const F4*>(&buf.gr_stage[slot]);
+			F4* dst = reinterpret_cast<F4*>(&buf.gr[env]);
+			LANES_BEGIN
+			for (int i = lane; i < static_cast<int>(sizeof(GroundRec) / 16); i += kGroup) dst[i] = src[i];
+			if (lane == 0) buf.stage_slot[env] = 0;
+			LANES_END
+		}
 	}
 	const GroundRec& g = buf.gr[env];
 	if (buf.reset_listed == 2 && ws.st.need_reset == 0 && ws.st.do_init == 0) return;   // wave-uniform: this env did not fall, nothing to do (state, status untouched)
