@@ -20,6 +20,11 @@ frame's experience tuples are drained device-to-device, all-gathered over RCCL o
 to a device replay ring on rank 0, and the policy is re-broadcast (one packed buffer) every --bcast-every frames -- the two exchange steps of
 the north star, measured with the same barrier / synchronize / max-over-ranks bracket. --exchange-steps 0 skips it.
 """
+import os
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default). The engine's two env-group streams must not share one: with
+# RCCL's and the framework's streams in the same process they did (measured: 11.2 M env-steps/s instead of 19.1 M as soon as a process group existed, i.e.
+# the two groups' frame kernels serialised). Has to be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import json
 import os
@@ -93,7 +98,7 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
         b = da.BatchScenario(EXCHANGE_ARG_FILE, n_local, data_root=ROOT, device_id=local_rank,
                              extra_args={"terrain_seed": 20260925, "rand_seed": 1, "global_env_offset": off})
         return b
-    sr = ShardedRollout(make, n * world, dist=dist, device=dev)   # dist is None on a plain 1-GPU run (no collective), a process group otherwise
+    sr = ShardedRollout(make, n * world, dist=dist, device=dev, pipelined=True)   # dist is None on a plain 1-GPU run (no collective), a process group otherwise
     b = sr.batch
     if rank == 0:
         sr.broadcast_policy(w, *scale, src=0)
@@ -113,10 +118,18 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
 
     def frame(k):
         nonlocal cursor, tuples
-        # Frame k is running (UpdateBegin was called). Everything below happens in the gap between two frame kernels, when the GPU is idle: a
-        # frame kernel fills every CU for ~4 ms, so small kernels or host syncs issued WHILE it runs wait for it (measured: 5 ms per frame lost
-        # that way). Only the collective itself overlaps the next frame; its result is consumed one frame later.
-        sr.UpdateEnd()                                   # frame k finished (status read-back, terrain windows, resets)
+        # Frame k is running (UpdateBegin was called). The engine keeps two tuple rings (dtrl_set_tuple_pipelining): frame k + 1 is launched as soon as
+        # frame k has ended, and frame k's tuples are drained, packed and gathered while it runs; the gathered block is consumed one frame later.
+        # What stays in the gap between two frame kernels is the frame-boundary host work and, every bcast_every frames, the policy hand-over.
+        if bcast_every > 0 and (k + 1) % bcast_every == 0:
+            sr.UpdateEnd()                               # frame k finished everywhere: the one place with a barrier, the policy hand-over
+            if rank == 0:
+                sr.broadcast_policy(*pol, src=0)
+            else:
+                sr.broadcast_policy(src=0)
+            sr.UpdateBegin()
+        else:
+            sr.UpdateEndBegin()                          # each env group: frame-boundary host work of frame k, then frame k + 1 at once (its tuples go to the other ring) ...
         if sr._pending is not None:
             g = sr.gather_tuples_end(dst=0)              # all-gather of frame k - 1's tuples: started a whole frame ago
             if rank == 0:
@@ -127,24 +140,22 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
                     if first < m:
                         replay[:m - first].copy_(rows[first:])
                     cursor = (cursor + m) % replay_cap; tuples += m
-        if bcast_every > 0 and (k + 1) % bcast_every == 0:
-            if rank == 0:
-                sr.broadcast_policy(*pol, src=0)
-            else:
-                sr.broadcast_policy(src=0)
-        sr.gather_tuples_begin()                         # drain frame k's tuples device-to-device, pack, start the all-gather on the comm stream
-        sr.UpdateBegin()                                 # frame k + 1
-    sr.UpdateBegin()
-    for k in range(warmup):
-        frame(k)
-    b.KernelTimeMs(); sr.exchange_wait_s = 0.0; tuples = 0
-    drop0 = b.TupleStats()["dropped"]
-    fence()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        frame(k)
-    fence()
-    dt = time.perf_counter() - t0
+        sr.gather_tuples_begin()                         # ... while frame k's tuples are drained device-to-device, packed and put on the wire
+    # the framework ops of this loop (replay append, count read-backs) go to a stream of their own: the legacy default stream would serialise them with
+    # every blocking stream of the process (the engine's CU-masked frame streams are such, DTRL_RESERVE_CUS)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        sr.UpdateBegin()
+        for k in range(warmup):
+            frame(k)
+        b.KernelTimeMs(); sr.exchange_wait_s = 0.0; tuples = 0
+        drop0 = b.TupleStats()["dropped"]
+        fence()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            frame(k)
+        fence()
+        dt = time.perf_counter() - t0
     sr.UpdateEnd()
     if sr._pending is not None:
         sr.gather_tuples_end(dst=0)
@@ -282,6 +293,11 @@ def main():
         line["exchange"] = ex
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_frames)
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)   # RCCL's version banner sits in the C stdio buffer: out with it first, the JSON line is the last line
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

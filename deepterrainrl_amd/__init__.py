@@ -17,6 +17,11 @@ Python host-side mirror of the reference's scenario interface for the rollout pa
 The product path is the HIP library ``lib/libdtrl.so``; importing works anywhere, but constructing a BatchScenario
 raises ``DtrlError`` when the library or a HIP device is missing -- there is no CPU fallback.
 """
+import os as _os
+# The engine drives its env groups on separate HIP streams that must not share a hardware queue (HIP multiplexes all streams of a process onto
+# GPU_MAX_HW_QUEUES = 4 queues by default; with RCCL and framework streams in the same process the groups' frame kernels ended up serialised). Takes effect
+# when the HIP runtime has not started yet (import this package before the first device call), and never overrides a value the user has set.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import ctypes as C
 import os
 
@@ -36,7 +41,7 @@ ABI_SYMBOLS = [
     "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_cycle_info", "dtrl_get_action_table", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
     "dtrl_terrain_build", "dtrl_terrain_load_file", "dtrl_args_parse_string",
-    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed", "dtrl_get_policy_output",
+    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed", "dtrl_get_policy_output", "dtrl_set_tuple_pipelining", "dtrl_step_end_begin",
 ]
 
 
@@ -75,6 +80,8 @@ def _bind(path):
     L.dtrl_get_action_table.argtypes = [vp, C.POINTER(C.c_int), vp]
     L.dtrl_get_poli_state.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_policy_output.argtypes = [vp, vp, C.c_int, vp]
+    L.dtrl_set_tuple_pipelining.argtypes = [vp, C.c_int]
+    L.dtrl_step_end_begin.argtypes = [vp, C.c_double]
     L.dtrl_get_flags.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_contacts.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_ctrl.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
@@ -163,6 +170,10 @@ class BatchScenario:
 
     def UpdateEnd(self):
         self._chk(self._lib.dtrl_step_end(self._h))
+
+    def UpdateEndBegin(self, dt=1.0 / 30.0):
+        """UpdateEnd() + UpdateBegin(dt) without the barrier between them (dtrl_step_end_begin): each env group is relaunched as soon as its own frame is done."""
+        self._chk(self._lib.dtrl_step_end_begin(self._h, float(dt)))
 
     def StepUpdates(self, n):
         self._chk(self._lib.dtrl_step_updates(self._h, int(n)))
@@ -307,6 +318,11 @@ class BatchScenario:
         s = np.zeros((n, self.S))
         self._chk(self._lib.dtrl_get_poli_state(self._h, _p(ids), n, _p(s)))
         return s
+
+    def SetTuplePipelining(self, on=True):
+        """Two tuple rings, switched by every UpdateBegin: UpdateEnd(f); UpdateBegin(f + 1); DrainTuplesPacked(...) hands out frame f's tuples while
+        frame f + 1 runs (the batched form of the reference's env threads feeding the trainer while the others keep stepping, scenarios/ScenarioTrain.cpp:376-410)."""
+        self._chk(self._lib.dtrl_set_tuple_pipelining(self._h, 1 if on else 0))
 
     def PolicyOutput(self, env_ids=None):
         """cNeuralNet::GetLayerState("output") after the controller's last Eval, un-normalised like Eval's out_y (learning/NeuralNet.cpp:352-375, 814-834)."""

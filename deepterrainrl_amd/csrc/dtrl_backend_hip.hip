@@ -134,8 +134,23 @@ public:
 		if (e != hipSuccess || count <= 0) { err = std::string("no usable HIP device (") + hipGetErrorString(e) + "); the engine has no CPU fallback"; return false; }
 		if (device_id >= 0) { e = hipSetDevice(device_id); if (e != hipSuccess) { err = std::string("hipSetDevice: ") + hipGetErrorString(e); return false; } }
 		streams_.assign(kNumStreams, nullptr);
+		// DTRL_RESERVE_CUS=k keeps k compute units per XCD out of the frame launches: a frame launch fills every wavefront slot of the CUs it may use for
+		// milliseconds, and whatever else needs the GPU meanwhile -- RCCL's collective kernels, the tuple drain, a trainer's copies -- would wait for a wavefront
+		// to retire (nothing does in the first ~2 ms of a frame). The env-group streams (the first kNumStreams / 2) get a CU mask without those units (mask
+		// bit i = compute unit i / #XCD of XCD i % #XCD, so the top 8 k bits are k units on each of the 8 XCDs); the other streams, and every other stream of
+		// the process, may use all of them. Costs k / 32 of the rollout rate; worth it when something has to overlap the rollout (multi-rank exchange).
+		int reserve = 0;
+		if (const char* env = std::getenv("DTRL_RESERVE_CUS")) reserve = std::max(0, std::min(8, std::atoi(env)));
+		hipDeviceProp_t prop;
+		int cus = 0;
+		if (reserve > 0 && hipGetDeviceProperties(&prop, device_id >= 0 ? device_id : 0) == hipSuccess) cus = prop.multiProcessorCount;
+		constexpr int kXcd = 8;
 		for (int i = 0; i < kNumStreams; ++i) {
-			e = hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking);
+			if (reserve > 0 && cus >= 2 * kXcd * reserve && i < kNumStreams / 2) {
+				std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+				for (int b = 0; b < cus - kXcd * reserve; ++b) mask[b / 32] |= 1u << (b % 32);
+				e = hipExtStreamCreateWithCUMask(&streams_[i], static_cast<uint32_t>(mask.size()), mask.data());
+			} else e = hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking);
 			if (e != hipSuccess) { err = std::string("hipStreamCreate: ") + hipGetErrorString(e); return false; }
 		}
 		stream_ = streams_[0];

@@ -216,6 +216,14 @@ dtrl_status dtrl_sample_ground(dtrl_batch* b, int env, int n, const double* x, d
 try {
 	CHECK_B(); return static_cast<dtrl_status>(b->eng.SampleGround(env, n, x, h, seg, i, j));
 } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_step_end_begin(dtrl_batch* b, double dt)
+try {
+	CHECK_B(); return static_cast<dtrl_status>(b->eng.StepEndBegin(dt));
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_set_tuple_pipelining(dtrl_batch* b, int on)
+try {
+	CHECK_B(); return static_cast<dtrl_status>(b->eng.SetTuplePipelining(on != 0));
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_drain_tuples_packed(dtrl_batch* b, float* block_dev, int block_rows, int* out_n)
 try {
 	CHECK_B(); return static_cast<dtrl_status>(b->eng.DrainTuplesPacked(block_dev, block_rows, out_n));

@@ -164,6 +164,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	buf_.tuple_env = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
 	buf_.tuple_count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));   // [0] ring cursor, [1] / [2] rows drained / dropped by packed drains since the last fold
 	d_tuple_rank_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
+	ring_[0].rows = buf_.tuple_rows; ring_[0].flags = buf_.tuple_flags; ring_[0].env = buf_.tuple_env; ring_[0].count = buf_.tuple_count;
 	d_env_list_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
 	d_order_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
 	if (cfg_.device_terrain) {
@@ -434,6 +435,7 @@ int Engine::StepBegin(double dt)
 	if (dt <= 0) return DTRL_OK;   // cScenarioSimChar::Update returns early (scenarios/ScenarioSimChar.cpp:148-151)
 	if (cfg_.model.has_net && !policy_set_) return Fail(DTRL_ERR_ARG, "policy_net was given but dtrl_set_policy has not been called");
 	const int steps = cfg_.model.num_update_steps;
+	if (tuple_pipelining_) { wr_ring_ ^= 1; UseRing(buf_, wr_ring_); }   // this frame's tuples go to the ring that is not being drained
 	for (size_t g = 0; g < groups_.size(); ++g) { int rc = LaunchGroup(static_cast<int>(g), steps, dt / steps, true); if (rc != DTRL_OK) return rc; }
 	step_pending_ = true;
 	return DTRL_OK;
@@ -444,6 +446,29 @@ int Engine::StepEnd()
 	if (!step_pending_) return DTRL_OK;
 	step_pending_ = false;
 	for (size_t g = 0; g < groups_.size(); ++g) { int rc = HostFrameWork(static_cast<int>(g)); if (rc != DTRL_OK) return rc; }
+	return DTRL_OK;
+}
+
+// dtrl_step_end + dtrl_step_begin without the barrier between them: every env group gets its frame-boundary host work and its next launch as soon as
+// ITS frame is done (the scheduling of RunFrames, one frame at a time), so one group's stragglers are covered by the other groups' next launches.
+// With tuple pipelining on, the new launches write the other tuple ring and the frame that has just ended can be drained when this returns.
+int Engine::StepEndBegin(double dt)
+{
+	if (!step_pending_) return StepBegin(dt);
+	if (dt <= 0) return StepEnd();
+	const int G = static_cast<int>(groups_.size());
+	const int steps = cfg_.model.num_update_steps;
+	if (tuple_pipelining_) { wr_ring_ ^= 1; UseRing(buf_, wr_ring_); }
+	std::vector<char> done(static_cast<size_t>(G), 0);
+	for (int remaining = G; remaining > 0; --remaining) {
+		int g = -1;
+		for (int c = 0; c < G; ++c) if (!done[c] && be_->StreamIdle(c)) { g = c; break; }
+		if (g < 0) for (int c = 0; c < G; ++c) if (!done[c]) { g = c; break; }
+		int rc = HostFrameWork(g);
+		if (rc == DTRL_OK) rc = LaunchGroup(g, steps, dt / steps, true);
+		if (rc != DTRL_OK) return rc;
+		done[g] = 1;
+	}
 	return DTRL_OK;
 }
 
@@ -701,12 +726,47 @@ int Engine::SetTerrainLerp(double lerp)
 	return DTRL_OK;
 }
 
+// ---- tuple rings. Without pipelining there is one ring and every drain waits for all streams. With it (SetTuplePipelining) dtrl_step_begin switches
+// the ring the kernels write; between dtrl_step_begin and dtrl_step_end the drains below work on the OTHER ring (the frame that has ended), on a stream of
+// their own, and do not wait for the frame in flight.
+int Engine::SetTuplePipelining(bool on)
+{
+	if (step_pending_) return Fail(DTRL_ERR_ARG, "dtrl_set_tuple_pipelining between dtrl_step_begin and dtrl_step_end");
+	if (!be_->Sync()) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (on && !ring_[1].rows) {
+		auto alloc = [&](size_t bytes) -> void* { void* p = be_->Alloc(bytes); if (p) allocs_.push_back(p); return p; };
+		ring_[1].rows = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(W_) * buf_.tuple_cap));
+		ring_[1].flags = static_cast<uint32_t*>(alloc(sizeof(uint32_t) * buf_.tuple_cap));
+		ring_[1].env = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
+		ring_[1].count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));
+		if (!ring_[1].rows || !ring_[1].flags || !ring_[1].env || !ring_[1].count) return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
+	}
+	if (!on && tuple_pipelining_) {
+		// back to one ring: whatever waits in the idle ring would be stranded
+		DevBuffers o = buf_; UseRing(o, wr_ring_ ^ 1);
+		int32_t cnt = 0;
+		if (!be_->D2H(&cnt, o.tuple_count, sizeof(cnt))) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (cnt != 0) return Fail(DTRL_ERR_ARG, "drain the pending tuples before switching tuple pipelining off");
+	}
+	tuple_pipelining_ = on;
+	return DTRL_OK;
+}
+bool Engine::DrainSync()
+{
+	if (tuple_pipelining_ && step_pending_) {   // the drain ring's frame ended with dtrl_step_end; the frame in flight writes the other ring
+		be_->SelectStream(be_->NumStreams() - 1);
+		return be_->SyncSelected();
+	}
+	be_->SelectStream(0);
+	return be_->Sync();
+}
 // rows the kernel could not store because the ring was full are counted, never silently lost: the cursor keeps counting past the capacity
 int Engine::PendingTuples(int32_t* stored, int32_t* overflow)
 {
 	int32_t cnt = 0;
-	be_->Sync();
-	if (!be_->D2H(&cnt, buf_.tuple_count, sizeof(cnt))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	DevBuffers d = buf_; UseRing(d, DrainRing());
+	struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
+	if (!DrainSync() || !be_->D2H(&cnt, d.tuple_count, sizeof(cnt))) return Fail(DTRL_ERR_DEVICE, be_->error());
 	*overflow = cnt > buf_.tuple_cap ? cnt - buf_.tuple_cap : 0;
 	*stored = cnt - *overflow;
 	return DTRL_OK;
@@ -719,14 +779,17 @@ int Engine::DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap,
 	if (rc != DTRL_OK) return rc;
 	int n = std::min<int>(cnt, cap);
 	if (n < cnt) return Fail(DTRL_ERR_CAPACITY, "caller buffer smaller than the number of pending tuples");
+	DevBuffers d = buf_; UseRing(d, DrainRing());
+	struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
+	if (tuple_pipelining_ && step_pending_) be_->SelectStream(be_->NumStreams() - 1);
 	if (n > 0) {
 		auto copy = [&](void* dst, const void* src, size_t bytes) { return device_dst ? be_->D2D(dst, src, bytes) : be_->D2H(dst, src, bytes); };
-		if (!copy(rows, buf_.tuple_rows, sizeof(float) * static_cast<size_t>(W_) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
-		if (flags && !copy(flags, buf_.tuple_flags, sizeof(uint32_t) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
-		if (env_ids && !copy(env_ids, buf_.tuple_env, sizeof(int32_t) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (!copy(rows, d.tuple_rows, sizeof(float) * static_cast<size_t>(W_) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (flags && !copy(flags, d.tuple_flags, sizeof(uint32_t) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (env_ids && !copy(env_ids, d.tuple_env, sizeof(int32_t) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	}
 	const int32_t zero = 0;
-	if (!be_->H2D(buf_.tuple_count, &zero, sizeof(zero))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!be_->H2D(d.tuple_count, &zero, sizeof(zero))) return Fail(DTRL_ERR_DEVICE, be_->error());
 	tuples_drained_ += n; tuples_dropped_ += over;
 	*out_n = n;
 	return DTRL_OK;
@@ -734,21 +797,27 @@ int Engine::DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap,
 // totals of the device-side (packed) drains -> host counters
 int Engine::FoldTupleTotals()
 {
-	int32_t c[4] = {0, 0, 0, 0};
-	be_->Sync();
-	if (!be_->D2H(c, buf_.tuple_count, sizeof(c))) return Fail(DTRL_ERR_DEVICE, be_->error());
-	if (c[1] || c[2]) {
-		tuples_drained_ += c[1]; tuples_dropped_ += c[2];
-		const int32_t zero[2] = {0, 0};
-		if (!be_->H2D(buf_.tuple_count + 1, zero, sizeof(zero))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
+	if (!DrainSync()) return Fail(DTRL_ERR_DEVICE, be_->error());
+	for (int r = 0; r < 2; ++r) {
+		if (!ring_[r].count || (tuple_pipelining_ && step_pending_ && r == wr_ring_)) continue;   // (the ring in flight folds after its frame)
+		int32_t c[4] = {0, 0, 0, 0};
+		if (!be_->D2H(c, ring_[r].count, sizeof(c))) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (c[1] || c[2]) {
+			tuples_drained_ += c[1]; tuples_dropped_ += c[2];
+			const int32_t zero[2] = {0, 0};
+			if (!be_->H2D(ring_[r].count + 1, zero, sizeof(zero))) return Fail(DTRL_ERR_DEVICE, be_->error());
+		}
 	}
 	return DTRL_OK;
 }
 int Engine::DrainTuplesPacked(float* block_dev, int block_rows, int* out_n)
 {
 	if (!block_dev || block_rows < 0) return Fail(DTRL_ERR_ARG, "bad arguments");
-	if (!be_->Sync()) return Fail(DTRL_ERR_DEVICE, be_->error());   // the frame kernels of every group have finished writing the ring
-	if (!be_->PackTuples(buf_, block_dev, block_rows, cfg_.run.env_id_base, d_tuple_rank_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	DevBuffers d = buf_; UseRing(d, DrainRing());
+	struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
+	if (!DrainSync()) return Fail(DTRL_ERR_DEVICE, be_->error());   // the frame kernels that wrote this ring have finished
+	if (!be_->PackTuples(d, block_dev, block_rows, cfg_.run.env_id_base, d_tuple_rank_)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	if (out_n) { int32_t n = 0; if (!be_->D2H(&n, block_dev, sizeof(n))) return Fail(DTRL_ERR_DEVICE, be_->error()); *out_n = n; }
 	return DTRL_OK;
 }

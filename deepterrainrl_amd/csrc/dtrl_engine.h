@@ -79,6 +79,8 @@ public:
 	int GetPolicyOutput(const int32_t* env_ids, int n, double* y);
 	int GroundWindowRec(int env, int32_t* w2, double* min_x2, double* max_x2, float* h0, float* h1, int cap, int64_t* num_builds);
 	int DrainTuplesPacked(float* block_dev, int block_rows, int* out_n);
+	int SetTuplePipelining(bool on);
+	int StepEndBegin(double dt);
 	int SampleGround(int env, int n, const double* x, double* h, int32_t* seg, int32_t* oi, int32_t* oj);
 	int EvalStats(double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets);
 	int KernelTime(double* avg_ms, int64_t* launches);
@@ -138,6 +140,15 @@ private:
 	std::vector<int32_t> bucket_;
 	std::vector<std::pair<int32_t, double>> dist_log_;   // (env, distance) of every recorded poli_eval episode, in completion order
 	int64_t tuples_drained_ = 0, tuples_dropped_ = 0;
+	// tuple pipelining (dtrl_set_tuple_pipelining): two tuple rings; every dtrl_step_begin switches the ring the kernels write, so the frame that
+	// has just ended can be drained on its own stream while the next frame already runs
+	struct TupleRing { float* rows = nullptr; uint32_t* flags = nullptr; int32_t* env = nullptr; int32_t* count = nullptr; };
+	TupleRing ring_[2];
+	int wr_ring_ = 0;
+	bool tuple_pipelining_ = false;
+	void UseRing(DevBuffers& b, int r) const { b.tuple_rows = ring_[r].rows; b.tuple_flags = ring_[r].flags; b.tuple_env = ring_[r].env; b.tuple_count = ring_[r].count; }
+	int DrainRing() const { return (tuple_pipelining_ && step_pending_) ? (wr_ring_ ^ 1) : wr_ring_; }   // the ring no kernel is writing
+	bool DrainSync();   // make the drain ring's contents final: all streams, or -- while a pipelined frame runs -- only the drain stream
 	int PendingTuples(int32_t* stored, int32_t* overflow);
 	GroundRec* d_stage_recs_ = nullptr;   // device staging for the frame's regenerated terrain records (per-group slices)
 	int32_t* d_stage_ids_ = nullptr; int32_t* pin_stage_ids_ = nullptr;

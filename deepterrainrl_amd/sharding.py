@@ -35,7 +35,7 @@ class ShardedRollout:
     """One rank's shard of a global batch + the two exchange steps. `dist` is torch.distributed (already initialised) or None.
     `device`: torch device of the exchange buffers -- the GPU the batch runs on (RCCL), or None / "cpu" with a gloo group."""
 
-    def __init__(self, make_batch, global_envs, dist=None, device=None, force_collectives=None):
+    def __init__(self, make_batch, global_envs, dist=None, device=None, force_collectives=None, pipelined=False):
         import os
         import torch
         self.torch = torch
@@ -73,6 +73,11 @@ class ShardedRollout:
         self.pol_bytes = self.w_bytes + 8 * (2 * b.S + 2 * b.nn_out)
         self.pol_buf = torch.zeros(self.pol_bytes, dtype=torch.uint8, device=self.device) if self.n_w else None
         self.exchange_wait_s = 0.0
+        # pipelined: the engine switches between two tuple rings at every UpdateBegin, so frame f's tuples are drained and gathered WHILE frame f + 1 runs:
+        # UpdateEnd (f) -> gather_tuples_end (f - 1) -> UpdateBegin (f + 1) -> gather_tuples_begin (f). Same tuple stream as the sequential protocol.
+        self.pipelined = bool(pipelined)
+        if self.pipelined:
+            b.SetTuplePipelining(True)
 
     # ---- rollout ----
     def Update(self, dt=1.0 / 30.0):
@@ -84,16 +89,22 @@ class ShardedRollout:
     def UpdateEnd(self):
         self.batch.UpdateEnd()
 
+    def UpdateEndBegin(self, dt=1.0 / 30.0):
+        self.batch.UpdateEndBegin(dt)
+
     # ---- (a) experience tuples ----
     def gather_tuples_begin(self):
-        """Drain this rank's finished tuples into its block and start the all-gather (asynchronous on the GPU). Call between UpdateEnd() of
-        frame f and UpdateBegin() of frame f + 1; the collective then overlaps frame f + 1's kernel. Collect it with gather_tuples_end() in the
+        """Drain this rank's finished tuples into its block and start the all-gather (asynchronous on the GPU). Sequential protocol: call between
+        UpdateEnd() of frame f and UpdateBegin() of frame f + 1; the collective then overlaps frame f + 1's kernel. Pipelined protocol (pipelined=True):
+        call right AFTER UpdateBegin() of frame f + 1 -- the drain itself (rank / pack kernels on the engine's drain stream) overlaps that frame too. Collect it with gather_tuples_end() in the
         NEXT gap (after UpdateEnd() of frame f + 1): a frame kernel fills every CU, so small kernels and host syncs issued while it runs stall
         until it ends (bench.py's exchange leg: UpdateEnd -> gather_tuples_end (previous frame) -> consume -> gather_tuples_begin -> UpdateBegin).
         The packing (sort by env id so that the gathered stream does not depend on how envs are sharded, flag word and GLOBAL env id appended to every
         row, header row with the count) is three small kernels inside the engine (dtrl_drain_tuples_packed): no framework op touches the rows."""
         torch = self.torch
         assert self._pending is None, "gather_tuples_begin called twice without gather_tuples_end"
+        if self.pipelined and self.on_gpu:
+            torch.cuda.current_stream(self.device).synchronize()                # consumers of the previous block contents (views handed out by gather_tuples_end) are done
         self.batch.DrainTuplesPacked(self.block.data_ptr(), self.cap)        # synchronised: the block is complete when this returns
         work = None
         if self.coll:

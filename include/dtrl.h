@@ -122,6 +122,19 @@ dtrl_status dtrl_drain_tuples_device(dtrl_batch* b, float* rows_dev, uint32_t* f
  * (stable: an env's tuples stay in time order), each [r | s | a | s' | flag word | GLOBAL env id], the last two as int32 bit patterns. The ring is
  * emptied. Everything runs on the device (rank, scatter-copy and header kernels); out_n, when not NULL, costs one 4-byte read-back. */
 dtrl_status dtrl_drain_tuples_packed(dtrl_batch* b, float* block_dev, int block_rows, int* out_n);
+/* Replaces: the concurrency of the reference's learner threads -- an env thread hands its tuples to the trainer under the trainer's lock while the other
+ * env threads keep stepping (scenarios/ScenarioTrain.cpp:322-338, 376-410; learning/NeuralNetLearner.cpp:33-46). Batched equivalent: with pipelining on,
+ * every dtrl_step_begin switches between two tuple rings, and a drain issued between dtrl_step_begin(f + 1) and dtrl_step_end(f + 1) returns the tuples of
+ * frame f from the ring that frame wrote, on a stream of its own, without waiting for frame f + 1 (dtrl_step_end(f); dtrl_step_begin(f + 1);
+ * dtrl_drain_tuples_packed(...) -> frame f's tuples while f + 1 runs). Outside a pending step a drain returns the ring of the last frame, as without
+ * pipelining. Off by default; the caller drains every frame while it is on (an undrained ring is not lost: it is appended to two frames later). Switching it off
+ * requires the idle ring to be empty. */
+dtrl_status dtrl_set_tuple_pipelining(dtrl_batch* b, int on);
+/* dtrl_step_end followed by dtrl_step_begin(dt) without the barrier between them (same results): each env group receives its frame-boundary host
+ * work and its next launch as soon as its own frame is done, so the slowest wavefronts of one group are covered by the other groups' next launches --
+ * what dtrl_run_frames does inside, one frame at a time, for callers that act between frames (drain tuples, scenarios/ScenarioTrain.cpp:376-410).
+ * Without a pending step it is dtrl_step_begin. */
+dtrl_status dtrl_step_end_begin(dtrl_batch* b, double dt);
 /* The reference never drops a tuple (scenarios/ScenarioTrain.cpp:376-410 trains whenever a scene's buffer is full). Here the ring holds
  * max(2 num_envs, -tuple_buffer_size=) rows (-tuple_ring_capacity= overrides); rows completed while it is full are COUNTED, not stored:
  * pending = rows waiting in the ring, drained = rows handed out so far, dropped = rows lost to a full ring since creation (stays 0 when

@@ -488,6 +488,12 @@ def test_packed_drain_equals_plain_drain(om):
     B.run_packed_drain_equals_plain_drain(da_mod.BatchScenario, om, to_ptr=lambda t: t.data_ptr(), read=lambda t: t.cpu().numpy())
 
 
+def test_pipelined_drain_equals_sequential(om):
+    import test_boundary as B
+    import deepterrainrl_amd as da_mod
+    B.run_pipelined_drain_equals_sequential(da_mod.BatchScenario, om, to_ptr=lambda t: t.data_ptr(), read=lambda t: t.cpu().numpy())
+
+
 def test_link_link_contacts(da, om):
     T.test_link_link_contacts_vs_oracle(da, om)
 
