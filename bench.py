@@ -131,7 +131,7 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
         else:
             sr.UpdateEndBegin()                          # each env group: frame-boundary host work of frame k, then frame k + 1 at once (its tuples go to the other ring) ...
         if sr._pending is not None:
-            g = sr.gather_tuples_end(dst=0)              # all-gather of frame k - 1's tuples: started a whole frame ago
+            g = sr.gather_tuples_end(dst=0, want_meta=False)   # all-gather of frame k - 1's tuples: started a whole frame ago
             if rank == 0:
                 rows = g[0]; m = int(rows.shape[0])
                 if m:                                    # append to the device replay ring: one copy, two when the ring wraps

@@ -115,9 +115,9 @@ class ShardedRollout:
                 work = self.dist.all_gather(self.gathered, self.block, async_op=True)
         self._pending = (work,)
 
-    def gather_tuples_end(self, dst=0):
+    def gather_tuples_end(self, dst=0, want_meta=True):
         """Wait for the all-gather. Returns (rows [n, W] float32, flags [n] int32, global env ids [n] int32) as tensors on self.device on rank
-        `dst`, None elsewhere."""
+        `dst`, None elsewhere; want_meta=False returns (rows, None, None) on a multi-rank group."""
         import time
         torch = self.torch
         work, = self._pending
@@ -139,6 +139,8 @@ class ShardedRollout:
             return blk[:, :W], meta[:, 0], meta[:, 1]
         counts = [int(x) for x in torch.stack([g[0, :1].view(torch.int32)[0] for g in blocks]).tolist()]
         rows = torch.cat([g[1:c + 1, :W] for g, c in zip(blocks, counts)])
+        if not want_meta:                 # (every framework op issued while a frame kernel runs waits for a wavefront slot: a consumer of the rows alone skips three)
+            return rows, None, None
         meta = torch.cat([g[1:c + 1, W:].view(torch.int32) for g, c in zip(blocks, counts)])
         return rows, meta[:, 0].contiguous(), meta[:, 1].contiguous()
 
