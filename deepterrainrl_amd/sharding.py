@@ -109,6 +109,7 @@ class ShardedRollout:
         work = None
         if self.coll:
             if self.on_gpu:
+                self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))   # readers of the previous gather result (queued on the caller's stream) come first
                 with torch.cuda.stream(self.comm_stream):
                     work = self.dist.all_gather(self.gathered, self.block, async_op=True)
             else:
