@@ -110,16 +110,6 @@ __global__ void dtrl_tuple_finish(DevBuffers buf, int block_rows, float* __restr
 	for (int i = t; i < buf.W + 2; i += static_cast<int>(blockDim.x)) block[i] = (i == 0) ? __int_as_float(n) : (i == 1) ? __int_as_float(cnt - n) : 0.0f;
 	if (t == 0) { buf.tuple_count[1] += n; buf.tuple_count[2] += cnt - n; buf.tuple_count[0] = 0; }
 }
-__global__ void dtrl_scatter_ground(GroundRec* __restrict__ gr, const GroundRec* __restrict__ staged, const int32_t* __restrict__ ids, int n)
-{
-	const int b = static_cast<int>(blockIdx.x);
-	if (b >= n) return;
-	static_assert(sizeof(GroundRec) % 16 == 0, "GroundRec is copied as 16-byte words");
-	const uint4* src = reinterpret_cast<const uint4*>(&staged[b]);
-	uint4* dst = reinterpret_cast<uint4*>(&gr[ids[b]]);
-	for (int i = static_cast<int>(threadIdx.x); i < static_cast<int>(sizeof(GroundRec) / 16); i += static_cast<int>(blockDim.x)) dst[i] = src[i];
-}
-
 class HipBackend : public Backend {
 public:
 	~HipBackend() override
@@ -175,12 +165,6 @@ public:
 	{
 		hipLaunchKernelGGL(dtrl_gather_f32, dim3(1024), dim3(256), 0, stream_, dst, src, idx, n);
 		return Check(hipGetLastError(), "gather launch") && Check(hipStreamSynchronize(stream_), "sync");
-	}
-	bool ScatterGround(GroundRec* gr, const GroundRec* staged, const int32_t* ids, int n) override
-	{
-		if (n <= 0) return true;
-		hipLaunchKernelGGL(dtrl_scatter_ground, dim3(n), dim3(256), 0, stream_, gr, staged, ids, n);
-		return Check(hipGetLastError(), "scatter launch");
 	}
 	bool PackTuples(const DevBuffers& buf, float* block, int block_rows, int64_t env_id_base, int32_t* rank) override
 	{

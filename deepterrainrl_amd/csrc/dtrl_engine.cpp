@@ -107,7 +107,7 @@ Engine::~Engine()
 	if (be_) {
 		be_->Sync();
 		for (void* p : allocs_) be_->Free(p);
-		be_->FreeHostStaging(pin_recs_); be_->FreeHostStaging(pin_order_); be_->FreeHostStaging(pin_ids_); be_->FreeHostStaging(pin_stage_ids_); be_->FreeHostStaging(status_); be_->FreeHostStaging(stage_slot_);
+		be_->FreeHostStaging(pin_recs_); be_->FreeHostStaging(pin_order_); be_->FreeHostStaging(pin_ids_); be_->FreeHostStaging(status_); be_->FreeHostStaging(stage_slot_);
 		delete be_;
 	}
 }
@@ -179,10 +179,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	pin_recs_ = static_cast<GroundRec*>(be_->HostStaging(sizeof(GroundRec) * n_));
 	pin_order_ = static_cast<int32_t*>(be_->HostStaging(sizeof(int32_t) * n_));
 	pin_ids_ = static_cast<int32_t*>(be_->HostStaging(sizeof(int32_t) * n_));
-	pin_stage_ids_ = static_cast<int32_t*>(be_->HostStaging(sizeof(int32_t) * n_));
-	d_stage_recs_ = static_cast<GroundRec*>(alloc(sizeof(GroundRec) * n_));
-	d_stage_ids_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
-	if (!pin_recs_ || !pin_order_ || !pin_ids_ || !pin_stage_ids_ || !d_stage_recs_ || !d_stage_ids_) return Fail(DTRL_ERR_DEVICE, "host staging allocation failed: " + be_->error());
+	if (!pin_recs_ || !pin_order_ || !pin_ids_) return Fail(DTRL_ERR_DEVICE, "host staging allocation failed: " + be_->error());
 	// env groups (one stream each). Two halves is the measured optimum (4096 envs on one MI355X: 1 group 10.1 M env-steps/s, 2 groups
 	// 13.7 M, 3: 10.9 M, 4: 12.6 M, 8: 6.3 M): one half fills the 2048 resident-wavefront slots while the other half's frame-boundary host
 	// work runs; more groups only add host work and launches. DTRL_GROUPS overrides.
@@ -379,7 +376,7 @@ int Engine::HostFrameWork(int group)
 	struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
 	// the status read-back synchronises the group's stream: its frame kernel and every upload queued during its previous frame
 	// have completed, so its slice of the staging arena can be reused from the start
-	if (!(zero_copy_ ? be_->SyncSelected() : be_->D2H(status_ + e0, buf_.status + e0, sizeof(EnvStatus) * grp.n))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!be_->SyncSelected()) return Fail(DTRL_ERR_DEVICE, be_->error());   // (the kernel wrote status_ itself: host terrain mode moves no copies, see Init)
 	const double ht1 = g_ht.on ? now_s() : 0;
 	reset_ids_.clear();
 	work_.clear();
@@ -392,7 +389,7 @@ int Engine::HostFrameWork(int group)
 	const int used = static_cast<int>(work_.size());
 	if (used > 0) {
 		// the rebuilds of one frame are independent (own RNG stream, own window per env): host workers share them; every rebuilt record goes into
-		// its slot of the group's page-locked slice, then ONE upload + one scatter launch replace a hipMemcpyAsync per env
+		// its slot of the group's page-locked slice, from which the env's own wavefront copies it in when its next launch starts (stage_slot_)
 		std::atomic<int> failed{0};
 		WorkerPool::Get().ParallelFor(used, [&](int k) {
 			const int e = work_[k];
@@ -405,12 +402,9 @@ int Engine::HostFrameWork(int group)
 			} else g.Update(s.root_x - 2, s.root_x + kViewDist + kViewPad);
 			std::string err;
 			if (!g.FillRecord(pin_recs_[e0 + k], err)) failed.store(1);
-			pin_stage_ids_[e0 + k] = e;
-			if (zero_copy_) stage_slot_[e] = e0 + k + 1;   // the env's wavefront copies the record in at the start of its next launch (the reset launch below, or the next frame)
+			stage_slot_[e] = e0 + k + 1;   // the env's wavefront copies the record in at the start of its next launch (the reset launch below, or the next frame)
 		});
 		if (failed.load()) return Fail(DTRL_ERR_CAPACITY, "terrain segment exceeds kSegCap vertices");
-		if (!zero_copy_ && (!be_->H2DAsync(d_stage_recs_ + e0, pin_recs_ + e0, sizeof(GroundRec) * used) || !be_->H2DAsync(d_stage_ids_ + e0, pin_stage_ids_ + e0, sizeof(int32_t) * used)
-			|| !be_->ScatterGround(buf_.gr, d_stage_recs_ + e0, d_stage_ids_ + e0, used))) return Fail(DTRL_ERR_DEVICE, be_->error());
 	}
 	const double ht2 = g_ht.on ? now_s() : 0;
 	// longest-processing-time-first: a launch is as long as its slowest wavefront (a stumbling character with ~20 constraint
@@ -422,7 +416,6 @@ int Engine::HostFrameWork(int group)
 	for (int e = e0; e < e1; ++e) ++bucket_[key(e) + 1];
 	for (int k = 0; k < kBuckets; ++k) bucket_[k + 1] += bucket_[k];
 	for (int e = e0; e < e1; ++e) pin_order_[e0 + bucket_[key(e)]++] = e;
-	if (!zero_copy_ && !be_->H2DAsync(d_order_ + e0, pin_order_ + e0, sizeof(int32_t) * grp.n)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	const double ht3 = g_ht.on ? now_s() : 0;
 	const int rc = ApplyResets(reset_ids_, group);
 	if (g_ht.on) { const double ht4 = now_s(); g_ht.t_sync += ht1 - ht0; g_ht.t_loop += ht2 - ht1; g_ht.t_sort += ht3 - ht2; g_ht.t_reset += ht4 - ht3; g_ht.regen += used; ++g_ht.n; }

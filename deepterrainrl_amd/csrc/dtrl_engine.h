@@ -25,9 +25,6 @@ public:
 	virtual bool D2D(void* dst, const void* src, size_t n) = 0;   // device-to-device on the selected stream, synchronised before returning
 	// dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 for i < n, all device pointers (policy hand-over without a host round trip); synchronised
 	virtual bool GatherF32(float* dst, const float* src, const int32_t* idx, size_t n) = 0;
-	// gr[ids[k]] = staged[k] for k < n (device pointers), queued on the selected stream: the frame's regenerated terrain windows arrive as ONE upload
-	// of a packed array + this scatter instead of one hipMemcpyAsync per env
-	virtual bool ScatterGround(GroundRec* gr, const GroundRec* staged, const int32_t* ids, int n) = 0;
 	// -terrain_gen= device: the frame-boundary terrain work of envs [e0, e0 + n) (or of env_list[0 .. n) when given), queued on the selected stream
 	// (tg_env_boundary, dtrl_terrain_dev.h); mode 0 = after a frame, 1 = (re)initialise
 	virtual bool TerrainBoundary(const DevBuffers& buf, int e0, int n, int mode, const int32_t* env_list) = 0;
@@ -150,8 +147,6 @@ private:
 	int DrainRing() const { return (tuple_pipelining_ && step_pending_) ? (wr_ring_ ^ 1) : wr_ring_; }   // the ring no kernel is writing
 	bool DrainSync();   // make the drain ring's contents final: all streams, or -- while a pipelined frame runs -- only the drain stream
 	int PendingTuples(int32_t* stored, int32_t* overflow);
-	GroundRec* d_stage_recs_ = nullptr;   // device staging for the frame's regenerated terrain records (per-group slices)
-	int32_t* d_stage_ids_ = nullptr; int32_t* pin_stage_ids_ = nullptr;
 	std::vector<int32_t> work_;
 	int32_t* d_relayout_ = nullptr;   // device weight index -> index into the caller's Caffe-order blob (-1 = padding), built at Create
 	std::string err_;

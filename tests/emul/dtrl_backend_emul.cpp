@@ -25,7 +25,6 @@ public:
 	bool SyncSelected() override { return true; }
 	bool D2H(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
 	bool D2D(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
-	bool ScatterGround(GroundRec* gr, const GroundRec* staged, const int32_t* ids, int n) override { for (int k = 0; k < n; ++k) gr[ids[k]] = staged[k]; return true; }
 	bool GatherF32(float* dst, const float* src, const int32_t* idx, size_t n) override { for (size_t i = 0; i < n; ++i) dst[i] = idx[i] >= 0 ? src[idx[i]] : 0.0f; return true; }
 	bool TerrainBoundary(const DevBuffers& buf, int e0, int n, int mode, const int32_t* env_list) override
 	{
