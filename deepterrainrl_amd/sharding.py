@@ -78,6 +78,12 @@ class ShardedRollout:
         self.pipelined = bool(pipelined)
         if self.pipelined:
             b.SetTuplePipelining(True)
+        # pipelined: two send blocks, used alternately, so that the drain of frame f never has to wait (on the host) for the readers of frame f - 1's block
+        # (its all-gather, or the views gather_tuples_end handed out on a one-rank run): a block is rewritten two frames after it was filled, and the event
+        # recorded behind its last readers has long fired by then
+        self.blocks = [self.block, torch.zeros_like(self.block)] if (self.pipelined and self.on_gpu) else [self.block]
+        self._bi = 0
+        self._busy = [None] * len(self.blocks)
 
     # ---- rollout ----
     def Update(self, dt=1.0 / 30.0):
@@ -103,8 +109,14 @@ class ShardedRollout:
         row, header row with the count) is three small kernels inside the engine (dtrl_drain_tuples_packed): no framework op touches the rows."""
         torch = self.torch
         assert self._pending is None, "gather_tuples_begin called twice without gather_tuples_end"
-        if self.pipelined and self.on_gpu:
-            torch.cuda.current_stream(self.device).synchronize()                # consumers of the previous block contents (views handed out by gather_tuples_end) are done
+        if len(self.blocks) > 1:
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device))   # behind every reader of the current block queued on the caller's stream so far
+            prev = self._busy[self._bi]
+            self._busy[self._bi] = ev if prev is None or not self.coll else prev       # (multi-rank: the block's reader is the all-gather, recorded below)
+            self._bi ^= 1
+            self.block = self.blocks[self._bi]
+            if self._busy[self._bi] is not None:
+                self._busy[self._bi].synchronize()                                     # two frames old: fired long ago
         self.batch.DrainTuplesPacked(self.block.data_ptr(), self.cap)        # synchronised: the block is complete when this returns
         work = None
         if self.coll:
@@ -112,6 +124,8 @@ class ShardedRollout:
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))   # readers of the previous gather result (queued on the caller's stream) come first
                 with torch.cuda.stream(self.comm_stream):
                     work = self.dist.all_gather(self.gathered, self.block, async_op=True)
+                    if len(self.blocks) > 1:
+                        ev = torch.cuda.Event(); ev.record(self.comm_stream); self._busy[self._bi] = ev
             else:
                 work = self.dist.all_gather(self.gathered, self.block, async_op=True)
         self._pending = (work,)
