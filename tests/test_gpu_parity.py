@@ -500,3 +500,53 @@ def test_link_link_contacts(da, om):
 
 def test_product_vs_frozen_reference_lockstep_traces(da):
     T.test_product_vs_frozen_reference_lockstep_traces(da)
+
+
+def test_sharded_rollout_pipelined_protocol_on_gpu(om):
+    """ShardedRollout on the GPU (comm / side streams, two send blocks, the engine's two tuple rings): the pipelined protocol
+    (UpdateEndBegin -> gather_tuples_end -> gather_tuples_begin, frame f's tuples travel while frame f + 1 runs) hands out, frame by frame,
+    exactly the rows / flags / global env ids of the sequential protocol (Update -> gather_tuples)."""
+    import torch
+    import deepterrainrl_amd as da_mod
+    from deepterrainrl_amd.sharding import ShardedRollout
+    pol = dog_policy(om)
+
+    def make(n_local, off):
+        return da_mod.BatchScenario("args/opt_args_train_mace.txt", n_local, data_root=REFDATA, extra_args={"terrain_seed": 5, "rand_seed": 3, "global_env_offset": off})
+    dev = torch.device("cuda", 0)
+    a = ShardedRollout(make, 48, device=dev)
+    b = ShardedRollout(make, 48, device=dev, pipelined=True)
+    for sr in (a, b):
+        sr.broadcast_policy(pol[1], *pol[2:], src=0)
+        sr.batch.SetExplore(True, 0.2, 0.025, 0.002)
+    frames = 60
+    seq = []
+    for f in range(frames):
+        a.Update()
+        a.gather_tuples_begin()
+        r, fl, ids = a.gather_tuples_end(dst=0)
+        seq.append((r.cpu().numpy().copy(), fl.cpu().numpy().copy(), ids.cpu().numpy().copy()))
+    pip = []
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        b.UpdateBegin()
+        for f in range(frames):
+            if f % 5 == 4:
+                b.UpdateEnd(); b.UpdateBegin()
+            else:
+                b.UpdateEndBegin()
+            if b._pending is not None:
+                r, fl, ids = b.gather_tuples_end(dst=0)
+                pip.append((r.cpu().numpy().copy(), fl.cpu().numpy().copy(), ids.cpu().numpy().copy()))
+            b.gather_tuples_begin()
+        b.UpdateEnd()
+        r, fl, ids = b.gather_tuples_end(dst=0)
+        pip.append((r.cpu().numpy().copy(), fl.cpu().numpy().copy(), ids.cpu().numpy().copy()))
+    assert len(pip) == frames
+    total = 0
+    for f in range(frames):
+        for x, y in zip(seq[f], pip[f]):
+            assert np.array_equal(x, y), f
+        total += len(seq[f][0])
+    assert total >= 40
+    assert b.batch.TupleStats()["dropped"] == 0
