@@ -60,3 +60,16 @@ def test_product_does_not_reference_the_oracle():
                 assert "libdtrl_oracle" not in src, f
                 assert "libdtrl_emul" not in src and "_lib_path" not in src, f
     assert not os.path.exists(os.path.join(pkg, "lib", "libdtrl_emul.so")) and not os.path.isdir(os.path.join(pkg, "csrc", "emul")), "the lane-loop test backend must live under tests/, not in the product package"
+
+
+def test_package_import_sets_hardware_queue_count_without_overriding():
+    """The engine's env-group streams must not share a HIP hardware queue: importing the package sets GPU_MAX_HW_QUEUES=8 when the user has not
+    set it, and leaves a user's value alone."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, sys; sys.path.insert(0, %r); import deepterrainrl_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % repo
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "5"
+    assert subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip() == "5"
