@@ -18,10 +18,28 @@ The product path is the HIP library ``lib/libdtrl.so``; importing works anywhere
 raises ``DtrlError`` when the library or a HIP device is missing -- there is no CPU fallback.
 """
 import os as _os
-# The engine drives its env groups on separate HIP streams that must not share a hardware queue (HIP multiplexes all streams of a process onto
-# GPU_MAX_HW_QUEUES = 4 queues by default; with RCCL and framework streams in the same process the groups' frame kernels ended up serialised). Takes effect
-# when the HIP runtime has not started yet (import this package before the first device call), and never overrides a value the user has set.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import sys as _sys
+import warnings as _warnings
+
+
+def configure_hw_queues(n=8):
+    """Opt-in: ask HIP for `n` hardware queues (GPU_MAX_HW_QUEUES) unless the user has set the variable. The engine drives its env groups on separate
+    HIP streams that must not share a hardware queue: HIP multiplexes all streams of a process onto 4 queues by default, and with RCCL's and a
+    framework's streams in the same process the two groups' frame kernels ended up serialised (11.2 M instead of 19.1 M env-steps/s).
+    The variable is read when the HIP runtime starts, so call this before the first device call of the PROCESS (bench.py and the training tools do);
+    importing the package no longer touches the process environment. Returns the value in effect for a runtime that starts after this call."""
+    return int(_os.environ.setdefault("GPU_MAX_HW_QUEUES", str(int(n))))
+
+
+def _warn_hw_queues():
+    """Called when a batch is created: with a framework in the process and the default queue count the env-group streams may share a queue."""
+    v = _os.environ.get("GPU_MAX_HW_QUEUES")
+    if "torch" in _sys.modules and (v is None or int(v) < 8):
+        _warnings.warn("GPU_MAX_HW_QUEUES is %s: with torch / RCCL streams in this process the engine's env-group streams may share a HIP hardware queue and "
+                       "serialise; call deepterrainrl_amd.configure_hw_queues() (or export GPU_MAX_HW_QUEUES=8) before the HIP runtime starts" % (v or "unset (4)"),
+                       RuntimeWarning, stacklevel=3)
+
+
 import ctypes as C
 import os
 
@@ -119,6 +137,7 @@ class BatchScenario:
 
     def __init__(self, arg_file=None, num_envs=1, data_root=None, device_id=-1, extra_args=None):
         self._lib = self._library()
+        _warn_hw_queues()
         argv = []
         if extra_args:
             for k, v in extra_args.items():

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <vector>
 
 namespace dtrl {
@@ -79,42 +80,84 @@ __global__ void __launch_bounds__(1024) dtrl_order_by_cost(const EnvStatus* __re
 	__syncthreads();
 	for (int i = t; i < n; i += kOrderBuckets) { const int e = e0 + i; order[e0 + atomicAdd(&hist[key(e)], 1)] = e; }
 }
-// packed tuple drain (dtrl_drain_tuples_packed): rank of every pending row in (env id, ring position) order, scatter-copy into the block, header
-__device__ inline int pending_rows(const DevBuffers& buf, int block_rows) { int n = buf.tuple_count[0]; n = n < buf.tuple_cap ? n : buf.tuple_cap; return n < block_rows ? n : block_rows; }
-__global__ void dtrl_tuple_rank(DevBuffers buf, int block_rows, int32_t* __restrict__ rank)
+// packed tuple drain (dtrl_drain_tuples_packed). The pending rows of the ring are put in (env id, ring position) order by a segmented counting sort on the
+// env id -- O(rows + envs), one workgroup (round 2 ranked every row against every other: 36 M compares at a full 65 536-env ring) --, the first block_rows
+// of them are copied into the caller's block, and whatever does not fit is CARRIED: moved to the front of the ring, where the next drain of this ring
+// finds it in front of the newer rows (nothing is dropped because a block was small). Three launches on the drain stream:
+//   dtrl_tuple_order   order[r] = ring position of the r-th row; meta = {take, lost to a full ring, carried, stored}
+//   dtrl_tuple_pack    block row 1 + r <- ring row order[r] (r < take), carry staging row r - take <- ring row order[r] (r >= take)
+//   dtrl_tuple_finish  ring rows [0, carried) <- staging, header row of the block, ring cursor = carried, drained / dropped totals
+constexpr int kOrderThreads = 1024;
+__global__ void __launch_bounds__(kOrderThreads) dtrl_tuple_order(DevBuffers buf, int block_rows, int n_envs, int32_t* __restrict__ order, int32_t* __restrict__ hist, int32_t* __restrict__ meta)
 {
-	const int n = pending_rows(buf, block_rows);
-	const int k = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
-	if (k >= n) return;
-	const int mine = buf.tuple_env[k];
-	int r = 0;
-	for (int j = 0; j < n; ++j) { const int e = buf.tuple_env[j]; r += (e < mine) || (e == mine && j < k); }   // every lane reads the same address: one broadcast load per step
-	rank[k] = r;
-}
-__global__ void dtrl_tuple_pack(DevBuffers buf, int block_rows, const int32_t* __restrict__ rank, float* __restrict__ block, int64_t env_id_base)
-{
-	const int n = pending_rows(buf, block_rows);
-	const int k = static_cast<int>(blockIdx.x);
-	if (k >= n) return;
-	const int W = buf.W;
-	float* dst = block + static_cast<size_t>(1 + rank[k]) * (W + 2);
-	const float* src = buf.tuple_rows + static_cast<size_t>(k) * W;
-	for (int i = static_cast<int>(threadIdx.x); i < W; i += static_cast<int>(blockDim.x)) dst[i] = src[i];
-	if (threadIdx.x == 0) { dst[W] = __int_as_float(static_cast<int>(buf.tuple_flags[k])); dst[W + 1] = __int_as_float(static_cast<int>(env_id_base + buf.tuple_env[k])); }
-}
-__global__ void dtrl_tuple_finish(DevBuffers buf, int block_rows, float* __restrict__ block)
-{
-	const int cnt = buf.tuple_count[0];
-	const int n = pending_rows(buf, block_rows);
+	__shared__ int part[kOrderThreads];
 	const int t = static_cast<int>(threadIdx.x);
-	for (int i = t; i < buf.W + 2; i += static_cast<int>(blockDim.x)) block[i] = (i == 0) ? __int_as_float(n) : (i == 1) ? __int_as_float(cnt - n) : 0.0f;
-	if (t == 0) { buf.tuple_count[1] += n; buf.tuple_count[2] += cnt - n; buf.tuple_count[0] = 0; }
+	const int cnt = buf.tuple_count[0];
+	const int n = cnt < buf.tuple_cap ? cnt : buf.tuple_cap;
+	for (int e = t; e <= n_envs; e += kOrderThreads) hist[e] = 0;
+	__syncthreads();
+	for (int k = t; k < n; k += kOrderThreads) atomicAdd(&hist[buf.tuple_env[k]], 1);
+	__syncthreads();
+	// exclusive scan over the envs: a contiguous chunk per thread, the chunk totals scanned across the workgroup
+	const int chunk = (n_envs + kOrderThreads - 1) / kOrderThreads;
+	const int c0 = t * chunk, c1 = (c0 + chunk < n_envs) ? c0 + chunk : n_envs;
+	int sum = 0;
+	for (int e = c0; e < c1; ++e) sum += hist[e];
+	part[t] = sum;
+	__syncthreads();
+	for (int d = 1; d < kOrderThreads; d <<= 1) { const int o = t >= d ? part[t - d] : 0; __syncthreads(); part[t] += o; __syncthreads(); }
+	int run = part[t] - sum;
+	for (int e = c0; e < c1; ++e) { const int c = hist[e]; hist[e] = run; run += c; }
+	__syncthreads();
+	// scatter: the atomics hand out the slots of an env's segment in arbitrary order ...
+	for (int k = t; k < n; k += kOrderThreads) order[atomicAdd(&hist[buf.tuple_env[k]], 1)] = k;
+	__syncthreads();
+	// ... so every segment with more than one row (an env that completed two cycles between drains, or carried rows) is put in ring order; after the
+	// scatter hist[e] is the END of env e's segment
+	for (int e = t; e < n_envs; e += kOrderThreads) {
+		const int s0 = e ? hist[e - 1] : 0, s1 = hist[e];
+		for (int i = s0 + 1; i < s1; ++i) { const int v = order[i]; int j = i - 1; while (j >= s0 && order[j] > v) { order[j + 1] = order[j]; --j; } order[j + 1] = v; }
+	}
+	if (t == 0) { const int take = n < block_rows ? n : block_rows; meta[0] = take; meta[1] = cnt - n; meta[2] = n - take; meta[3] = n; }
+}
+__global__ void dtrl_tuple_pack(DevBuffers buf, const int32_t* __restrict__ order, const int32_t* __restrict__ meta, float* __restrict__ block, int64_t env_id_base, float* __restrict__ c_rows, uint32_t* __restrict__ c_flags, int32_t* __restrict__ c_env)
+{
+	const int take = meta[0], n = meta[3], W = buf.W;
+	for (int r = static_cast<int>(blockIdx.x); r < n; r += static_cast<int>(gridDim.x)) {
+		const int k = order[r];
+		const float* src = buf.tuple_rows + static_cast<size_t>(k) * W;
+		if (r < take) {
+			float* dst = block + static_cast<size_t>(1 + r) * (W + 2);
+			for (int i = static_cast<int>(threadIdx.x); i < W; i += static_cast<int>(blockDim.x)) dst[i] = src[i];
+			if (threadIdx.x == 0) { dst[W] = __int_as_float(static_cast<int>(buf.tuple_flags[k])); dst[W + 1] = __int_as_float(static_cast<int>(env_id_base + buf.tuple_env[k])); }
+		} else {
+			float* dst = c_rows + static_cast<size_t>(r - take) * W;
+			for (int i = static_cast<int>(threadIdx.x); i < W; i += static_cast<int>(blockDim.x)) dst[i] = src[i];
+			if (threadIdx.x == 0) { c_flags[r - take] = buf.tuple_flags[k]; c_env[r - take] = buf.tuple_env[k]; }
+		}
+	}
+}
+__global__ void dtrl_tuple_finish(DevBuffers buf, const int32_t* __restrict__ meta, float* __restrict__ block, const float* __restrict__ c_rows, const uint32_t* __restrict__ c_flags, const int32_t* __restrict__ c_env)
+{
+	const int take = meta[0], lost = meta[1], carry = meta[2], W = buf.W;
+	const int t = static_cast<int>(threadIdx.x);
+	for (int r = static_cast<int>(blockIdx.x); r < carry; r += static_cast<int>(gridDim.x)) {
+		float* dst = buf.tuple_rows + static_cast<size_t>(r) * W;
+		const float* src = c_rows + static_cast<size_t>(r) * W;
+		for (int i = t; i < W; i += static_cast<int>(blockDim.x)) dst[i] = src[i];
+		if (t == 0) { buf.tuple_flags[r] = c_flags[r]; buf.tuple_env[r] = c_env[r]; }
+	}
+	if (blockIdx.x == 0) {
+		for (int i = t; i < W + 2; i += static_cast<int>(blockDim.x)) block[i] = (i == 0) ? __int_as_float(take) : (i == 1) ? __int_as_float(lost) : (i == 2) ? __int_as_float(carry) : 0.0f;
+		if (t == 0) { buf.tuple_count[1] += take; buf.tuple_count[2] += lost; buf.tuple_count[0] = carry; }
+	}
 }
 class HipBackend : public Backend {
 public:
 	~HipBackend() override
 	{
 		for (auto& ev : events_) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+		for (auto& m : marks_) if (m.second) hipEventDestroy(m.second);
 		for (hipStream_t st : streams_) if (st) hipStreamDestroy(st);
 	}
 	bool Init(int device_id, std::string& err) override
@@ -166,15 +209,28 @@ public:
 		hipLaunchKernelGGL(dtrl_gather_f32, dim3(1024), dim3(256), 0, stream_, dst, src, idx, n);
 		return Check(hipGetLastError(), "gather launch") && Check(hipStreamSynchronize(stream_), "sync");
 	}
-	bool PackTuples(const DevBuffers& buf, float* block, int block_rows, int64_t env_id_base, int32_t* rank) override
+	bool PackTuples(const DevBuffers& buf, float* block, int block_rows, int64_t env_id_base, int n_envs, const PackScratch& sc) override
 	{
-		const int rows = std::min<int>(buf.tuple_cap, block_rows);
-		if (rows > 0) {
-			hipLaunchKernelGGL(dtrl_tuple_rank, dim3((rows + 255) / 256), dim3(256), 0, stream_, buf, block_rows, rank);
-			hipLaunchKernelGGL(dtrl_tuple_pack, dim3(rows), dim3(256), 0, stream_, buf, block_rows, rank, block, env_id_base);
-		}
-		hipLaunchKernelGGL(dtrl_tuple_finish, dim3(1), dim3(256), 0, stream_, buf, block_rows, block);
+		const int grid = std::max(1, std::min<int>(buf.tuple_cap, 2048));
+		hipLaunchKernelGGL(dtrl_tuple_order, dim3(1), dim3(kOrderThreads), 0, stream_, buf, block_rows, n_envs, sc.order, sc.hist, sc.meta);
+		hipLaunchKernelGGL(dtrl_tuple_pack, dim3(grid), dim3(256), 0, stream_, buf, sc.order, sc.meta, block, env_id_base, sc.rows, sc.flags, sc.env);
+		hipLaunchKernelGGL(dtrl_tuple_finish, dim3(grid), dim3(256), 0, stream_, buf, sc.meta, block, sc.rows, sc.flags, sc.env);
 		return Check(hipGetLastError(), "tuple pack launch") && Check(hipStreamSynchronize(stream_), "tuple pack");
+	}
+	// frame marks: MarkFrame records an event behind the frame launch of a group; WaitFrames makes the selected stream wait for the marks of a slot
+	bool MarkFrame(int group, int slot) override
+	{
+		hipEvent_t& ev = marks_[Key(group, slot)];
+		if (!ev && !Check(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate")) return false;
+		return Check(hipEventRecord(ev, streams_[group]), "hipEventRecord");
+	}
+	bool WaitFrames(int slot, int n_groups) override
+	{
+		for (int g = 0; g < n_groups; ++g) {
+			auto it = marks_.find(Key(g, slot));
+			if (it != marks_.end() && it->second && !Check(hipStreamWaitEvent(stream_, it->second, 0), "hipStreamWaitEvent")) return false;
+		}
+		return true;
 	}
 	bool TerrainBoundary(const DevBuffers& buf, int e0, int n, int mode, const int32_t* env_list) override
 	{
@@ -249,6 +305,8 @@ private:
 	std::vector<hipStream_t> streams_;
 	hipStream_t stream_ = nullptr;   // the selected one
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events_, free_events_, pending_;
+	static int Key(int group, int slot) { return group * 4 + slot; }
+	std::map<int, hipEvent_t> marks_;   // (env group, tuple ring) -> event behind the group's latest frame launch that wrote that ring
 };
 
 Backend* MakeBackend() { return new HipBackend(); }

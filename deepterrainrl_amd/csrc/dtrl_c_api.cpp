@@ -299,7 +299,7 @@ try {
 } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(nullptr)); }
 dtrl_status dtrl_terrain_load_file(const char* path, char* type_out, int type_cap, double* params_out, int max_sets, int* out_sets)
 try {
-	if (!path || !out_sets) return DTRL_ERR_ARG;
+	if (!path || !out_sets || max_sets < 0 || (max_sets > 0 && !params_out)) return DTRL_ERR_ARG;
 	dtrl::Json tf; std::string err;
 	if (!dtrl::Json::parse_file(path, tf, err)) { g_create_error = err; return DTRL_ERR_IO; }
 	const dtrl::Json* ty = tf.find("Type");

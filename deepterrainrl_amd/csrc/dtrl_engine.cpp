@@ -23,6 +23,7 @@
 #include <cstddef>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -46,23 +47,32 @@ public:
 		if (count <= 0) return;
 		if (count < kMinParallel || threads_.empty()) { for (int i = 0; i < count; ++i) fn(i); return; }
 		std::lock_guard<std::mutex> one_caller(call_m_);   // batches driven from different host threads take turns
-		{
-			std::lock_guard<std::mutex> lk(m_);
-			fn_ = &fn; count_ = count; next_.store(0); done_ = 0; ++epoch_;
-		}
+		// one Job object per call: function, item count and the item cursor travel together, so a worker that wakes late from an earlier call still
+		// holds THAT call's (exhausted) cursor and can neither run this call's function on a stale index nor count an item twice
+		auto job = std::make_shared<Job>();
+		job->fn = &fn; job->count = count;
+		{ std::lock_guard<std::mutex> lk(m_); job_ = job; ++epoch_; }
 		cv_.notify_all();
-		Run();   // the caller works too
+		Run(*job);   // the caller works too
 		std::unique_lock<std::mutex> lk(m_);
-		cv_done_.wait(lk, [&] { return done_ == count_; });
-		fn_ = nullptr;
+		cv_done_.wait(lk, [&] { return job->done == job->count; });   // every item has RETURNED (done is bumped after the call): fn may go out of scope
+		job_.reset();
 	}
+	int num_threads() const { return static_cast<int>(threads_.size()) + 1; }
 private:
+	struct Job { const std::function<void(int)>* fn = nullptr; int count = 0; std::atomic<int> next{0}; int done = 0; };
 	static constexpr int kMinParallel = 8;
 	WorkerPool()
 	{
+		// DTRL_HOST_THREADS overrides. Default: half the hardware threads, at most 16, shared between the ranks of this node (one process per GPU:
+		// LOCAL_WORLD_SIZE as torch.distributed.run / torchrun export it), so that 8 ranks do not start 8 pools of 16 on the same cores
 		int n = 0;
 		if (const char* env = std::getenv("DTRL_HOST_THREADS")) n = std::atoi(env);
-		else n = std::min(16, static_cast<int>(std::thread::hardware_concurrency()) / 2);
+		else {
+			int ranks = 1;
+			if (const char* lw = std::getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, std::atoi(lw));
+			n = std::max(1, std::min(16, static_cast<int>(std::thread::hardware_concurrency()) / (2 * ranks)));
+		}
 		for (int t = 1; t < n; ++t) threads_.emplace_back([this] { Loop(); });
 	}
 	~WorkerPool()
@@ -71,33 +81,34 @@ private:
 		cv_.notify_all();
 		for (auto& t : threads_) t.join();
 	}
-	void Run()
+	void Run(Job& j)
 	{
 		int finished = 0;
 		for (;;) {
-			const int i = next_.fetch_add(1);
-			if (i >= count_) break;
-			(*fn_)(i); ++finished;
+			const int i = j.next.fetch_add(1);
+			if (i >= j.count) break;
+			(*j.fn)(i); ++finished;
 		}
-		if (finished) { std::lock_guard<std::mutex> lk(m_); done_ += finished; if (done_ == count_) cv_done_.notify_all(); }
+		if (finished) { std::lock_guard<std::mutex> lk(m_); j.done += finished; if (j.done == j.count) cv_done_.notify_all(); }
 	}
 	void Loop()
 	{
 		long seen = 0;
 		for (;;) {
+			std::shared_ptr<Job> j;
 			{
 				std::unique_lock<std::mutex> lk(m_);
 				cv_.wait(lk, [&] { return epoch_ != seen; });
 				seen = epoch_;
 				if (stop_) return;
+				j = job_;   // the generation this wake-up belongs to (or a newer one; never a mix of two)
 			}
-			Run();
+			if (j) Run(*j);
 		}
 	}
 	std::vector<std::thread> threads_;
 	std::mutex m_, call_m_; std::condition_variable cv_, cv_done_;
-	const std::function<void(int)>* fn_ = nullptr;
-	int count_ = 0, done_ = 0; std::atomic<int> next_{0};
+	std::shared_ptr<Job> job_;
 	long epoch_ = 0; bool stop_ = false;
 };
 }  // namespace
@@ -163,7 +174,6 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	buf_.tuple_flags = static_cast<uint32_t*>(alloc(sizeof(uint32_t) * buf_.tuple_cap));
 	buf_.tuple_env = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
 	buf_.tuple_count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));   // [0] ring cursor, [1] / [2] rows drained / dropped by packed drains since the last fold
-	d_tuple_rank_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
 	ring_[0].rows = buf_.tuple_rows; ring_[0].flags = buf_.tuple_flags; ring_[0].env = buf_.tuple_env; ring_[0].count = buf_.tuple_count;
 	d_env_list_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
 	d_order_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
@@ -309,6 +319,9 @@ int Engine::LaunchGroup(int group, int n_steps, double dt_step, bool frame_end)
 	b.env_list = (zero_copy_ ? pin_order_ : d_order_) + g.e0;   // the group's launch order (global env ids), costliest first
 	const double lt0 = g_ht.on ? now_s() : 0;
 	bool ok = be_->Launch(d_model_, cfg_.run, b, g.n, n_steps, dt_step, frame_end);
+	// tuple pipelining: the drain of this frame's ring runs on a stream of its own one frame later and must follow THIS launch on the device -- the host
+	// has not necessarily waited for it by then (-terrain_gen= device queues the boundary work and the next frame without a sync)
+	if (ok && tuple_pipelining_ && n_steps > 0) ok = be_->MarkFrame(group, wr_ring_);
 	if (g_ht.on) g_ht.t_launch += now_s() - lt0;
 	be_->SelectStream(0);
 	return ok ? DTRL_OK : Fail(DTRL_ERR_DEVICE, be_->error());
@@ -747,8 +760,11 @@ int Engine::SetTuplePipelining(bool on)
 bool Engine::DrainSync()
 {
 	if (tuple_pipelining_ && step_pending_) {   // the drain ring's frame ended with dtrl_step_end; the frame in flight writes the other ring
+		// "ended" is a host-side fact only in host terrain mode (HostFrameWork synchronises the group's stream). In device terrain mode the frame may
+		// still be running: the drain stream waits on the device for the mark behind every group's launch of that frame -- a torn row (the cursor is
+		// bumped before the row is written) or a cursor zeroed under a running kernel would lose, duplicate or reorder tuples without an error.
 		be_->SelectStream(be_->NumStreams() - 1);
-		return be_->SyncSelected();
+		return be_->WaitFrames(DrainRing(), static_cast<int>(groups_.size())) && be_->SyncSelected();
 	}
 	be_->SelectStream(0);
 	return be_->Sync();
@@ -809,8 +825,19 @@ int Engine::DrainTuplesPacked(float* block_dev, int block_rows, int* out_n)
 	if (!block_dev || block_rows < 0) return Fail(DTRL_ERR_ARG, "bad arguments");
 	DevBuffers d = buf_; UseRing(d, DrainRing());
 	struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
+	if (!pack_.order) {
+		auto alloc = [&](size_t bytes) -> void* { void* p = be_->Alloc(bytes); if (p) allocs_.push_back(p); return p; };
+		const size_t cap = static_cast<size_t>(buf_.tuple_cap);
+		pack_.order = static_cast<int32_t*>(alloc(sizeof(int32_t) * cap));
+		pack_.hist = static_cast<int32_t*>(alloc(sizeof(int32_t) * (static_cast<size_t>(n_) + 1)));
+		pack_.meta = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));
+		pack_.rows = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(W_) * cap));
+		pack_.flags = static_cast<uint32_t*>(alloc(sizeof(uint32_t) * cap));
+		pack_.env = static_cast<int32_t*>(alloc(sizeof(int32_t) * cap));
+		if (!pack_.order || !pack_.hist || !pack_.meta || !pack_.rows || !pack_.flags || !pack_.env || !be_->Sync()) { pack_ = PackScratch(); return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error()); }
+	}
 	if (!DrainSync()) return Fail(DTRL_ERR_DEVICE, be_->error());   // the frame kernels that wrote this ring have finished
-	if (!be_->PackTuples(d, block_dev, block_rows, cfg_.run.env_id_base, d_tuple_rank_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!be_->PackTuples(d, block_dev, block_rows, cfg_.run.env_id_base, n_, pack_)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	if (out_n) { int32_t n = 0; if (!be_->D2H(&n, block_dev, sizeof(n))) return Fail(DTRL_ERR_DEVICE, be_->error()); *out_n = n; }
 	return DTRL_OK;
 }

@@ -9,6 +9,9 @@
 
 namespace dtrl {
 
+// scratch of the packed tuple drain (device memory): order [cap], hist [n_envs + 1], meta [4], carry staging rows [cap][W] / flags [cap] / env [cap]
+struct PackScratch { int32_t* order = nullptr; int32_t* hist = nullptr; int32_t* meta = nullptr; float* rows = nullptr; uint32_t* flags = nullptr; int32_t* env = nullptr; };
+
 class Backend {
 public:
 	virtual ~Backend() {}
@@ -30,9 +33,15 @@ public:
 	virtual bool TerrainBoundary(const DevBuffers& buf, int e0, int n, int mode, const int32_t* env_list) = 0;
 	// order[e0 .. e0 + n) = the envs e0 .. e0 + n - 1 sorted by status[].cost, costliest first (launch order of the group's next frame), on the selected stream
 	virtual bool OrderByCost(const EnvStatus* status, int e0, int n, int32_t* order) = 0;
-	// pending tuples -> block [block_rows + 1][W + 2] (header row + rows sorted by env id, flag word and global env id as the two extra columns), ring
-	// emptied, drained / dropped totals accumulated in tuple_count[1], [2]; device pointers; queued on the selected stream and synchronised
-	virtual bool PackTuples(const DevBuffers& buf, float* block, int block_rows, int64_t env_id_base, int32_t* rank_scratch) = 0;
+	// pending tuples -> block [block_rows + 1][W + 2] (header row + rows sorted by env id, flag word and global env id as the two extra columns); rows
+	// beyond block_rows are carried (moved to the front of the ring, in order), drained / lost-to-a-full-ring totals accumulated in tuple_count[1], [2];
+	// device pointers; queued on the selected stream and synchronised. n_envs = number of local envs (tuple_env values are < n_envs).
+	virtual bool PackTuples(const DevBuffers& buf, float* block, int block_rows, int64_t env_id_base, int n_envs, const PackScratch& sc) = 0;
+	// MarkFrame: remember the point behind everything queued so far on env group `group`'s stream under (group, slot); WaitFrames: the selected stream
+	// waits (on the device, not the host) for the marks of `slot` of groups 0 .. n_groups - 1. Lets the tuple drain follow the frame that wrote its ring
+	// when the host never synchronised with that frame (-terrain_gen= device). No-ops on a synchronous backend.
+	virtual bool MarkFrame(int group, int slot) = 0;
+	virtual bool WaitFrames(int slot, int n_groups) = 0;
 	virtual bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) = 0;
 	virtual bool Sync() = 0;                 // all streams
 	// work queues: H2D / H2DAsync / D2H / Launch act on the selected stream (0 by default); D2H and H2D synchronise only that stream
@@ -124,7 +133,7 @@ private:
 	bool zero_copy_ = false;        // host terrain mode: status, launch order, reset lists and terrain records cross the boundary without a copy (dtrl_engine.cpp Init)
 	GroundRec tmp_rec_;
 	TerrainCfg* d_tcfg_ = nullptr;
-	int32_t* d_tuple_rank_ = nullptr;
+	PackScratch pack_;                  // allocated by the first packed drain
 	static constexpr int kDistRingCap = 1 << 20;
 	std::vector<double> in_off_, in_scale_, out_off_, out_scale_;   // host copies of the policy normalisers (identity until set)
 	int UploadNormalizers();

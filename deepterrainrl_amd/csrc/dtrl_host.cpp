@@ -389,7 +389,10 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	else if (char_ctrl == "raptor") { m.char_type = 1; m.ctrl_type = 0; }
 	else if (char_ctrl == "raptor_mace") { m.char_type = 1; m.ctrl_type = 1; }
 	else if (char_ctrl == "dog_cacla") { m.char_type = 0; m.ctrl_type = 2; }   // cDogControllerCacla (sim/DogControllerCacla.cpp)
-	else { err = "char_ctrl '" + char_ctrl + "' is not supported by this build (dog, dog_mace, dog_cacla, goat_mace, raptor, raptor_mace)"; return false; }
+	// cRaptorControllerCacla (sim/RaptorControllerCacla.cpp; built by scenarios/ScenarioSimChar.cpp:407, 480-483): the raptor FSM with the CACLA head,
+	// mExpNoise 0.15 (set below by character type). The reference ships no raptor actor net: -policy_net= must name a single-head deploy net 275 -> 28
+	else if (char_ctrl == "raptor_cacla") { m.char_type = 1; m.ctrl_type = 2; }
+	else { err = "char_ctrl '" + char_ctrl + "' is not supported by this build (dog, dog_mace, dog_cacla, goat_mace, raptor, raptor_mace, raptor_cacla)"; return false; }
 	if (!char_type.empty() && char_type != (m.char_type == 0 ? "dog" : "raptor")) { err = "char_type '" + char_type + "' does not match the controller"; return false; }
 	m.target_vel_x = (char_ctrl == "goat_mace") ? 2.0 : 4.0;   // sim/GoatControllerMACE.cpp:11-14, sim/DogController.cpp:625-628
 	if (scenario == "train" || scenario == "train_mace" || scenario == "exp" || scenario == "exp_mace" || scenario == "train_cacla" || scenario == "exp_cacla") m.scenario = kScnExp;
@@ -594,7 +597,7 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	cfg.has_policy_net = false; m.has_net = 0;
 	if (args.ParseString("policy_net", cfg.policy_net_file)) {
 		if (!ParseDeployPrototxt(JoinPath(root, cfg.policy_net_file), cfg.net, err, &cfg.actor_only)) return false;
-		if (cfg.actor_only != (m.ctrl_type != 1)) { err = "policy_net topology does not match char_ctrl (MACE nets for *_mace, the single-head actor / Q net for dog_cacla, dog, raptor)"; return false; }
+		if (cfg.actor_only != (m.ctrl_type != 1)) { err = "policy_net topology does not match char_ctrl (MACE nets for *_mace, the single-head actor / Q net for dog_cacla, raptor_cacla, dog, raptor)"; return false; }
 		cfg.user_num_params = cfg.net.num_params; cfg.user_out_size = cfg.net.out_size;
 		if (cfg.actor_only) {   // minus the (zero) critic head val_ip0 / val_ip1 that only exists on the device
 			cfg.user_num_params -= static_cast<int64_t>(cfg.net.fc_head) * cfg.net.fc_trunk + cfg.net.fc_head + cfg.net.fc_head + 1;

@@ -8,11 +8,16 @@ performs between env threads and the trainer:
 Both are latency-bound on xGMI (<= ~10 MB/s of tuples at 1 M env-steps/s; 2.3 MB of weights per push), so each is ONE collective on ONE
 preallocated device buffer, issued on a side stream so that it overlaps the next frame kernel:
 
-  (a) gather_tuples_begin(): dtrl_drain_tuples_packed moves the frame's rows inside the engine (rank / scatter-copy / header kernels) into this
-      rank's fixed-capacity block [cap + 1, W + 2] float32 (row 0 = header carrying the count; the two extra columns carry the flag word and the
-      GLOBAL env id as raw int32 bits), sorted by env id (so the gathered stream does not depend on how envs are sharded), and
-      starts one all_gather of the block (RCCL: ncclAllGather over xGMI) on the comm stream. gather_tuples_end() waits and hands the
-      trainer rank the concatenated DEVICE tensors (rows, flags, ids) -- nothing visits the host. gather_tuples() = begin + end.
+  (a) gather_tuples_begin(): dtrl_drain_tuples_packed moves the frame's rows inside the engine (order / copy / header kernels) into this
+      rank's block [block_rows + 1, W + 2] float32 (row 0 = header carrying the count; the two extra columns carry the flag word and the
+      GLOBAL env id as raw int32 bits), sorted by env id (so the gathered stream does not depend on how envs are sharded), and starts one
+      GATHER of the block to the trainer rank (RCCL: ncclSend / ncclRecv group over xGMI) on the comm stream -- only the trainer consumes tuples, so
+      nobody else receives any. The block is sized for the steady state, not for the worst case: block_rows = max(64, envs per rank / 8) rows
+      (a frame completes ~0.08 tuples per env: one per gait cycle of ~12.5 frames; 4096 envs: 513 x 599 floats = 1.2 MB per rank and frame, where
+      round 2 all-gathered a 2 N-row block of 19.6 MB to every rank). Rows that do not fit stay in the engine's ring, in order, and travel with a
+      later frame (the batch starts in lock-step, so the first tuple frames are bursts); the header reports how many were carried.
+      gather_tuples_end() waits and hands the trainer rank the concatenated DEVICE tensors (rows, flags, ids) -- nothing visits the host.
+      gather_tuples() = begin + end.
   (b) broadcast_policy(): weights (float32) and the four normaliser vectors (float64) travel as ONE byte buffer (one ncclBroadcast), and
       every rank installs them with dtrl_set_policy_device (a gather kernel re-lays the blob; no host round trip).
 
@@ -31,11 +36,19 @@ def shard_range(global_envs, world_size, rank):
     return off, n
 
 
+def default_block_rows(global_envs, world_size):
+    """Rows of a rank's send block: the steady state produces ~0.08 tuples per env and frame; an eighth of the largest shard (at least 64 rows) leaves
+    ~50 % head room, and what does not fit is carried to a later frame by the engine (never dropped)."""
+    n_max = -(-int(global_envs) // int(world_size))
+    return max(64, -(-n_max // 8))
+
+
 class ShardedRollout:
     """One rank's shard of a global batch + the two exchange steps. `dist` is torch.distributed (already initialised) or None.
-    `device`: torch device of the exchange buffers -- the GPU the batch runs on (RCCL), or None / "cpu" with a gloo group."""
+    `device`: torch device of the exchange buffers -- the GPU the batch runs on (RCCL), or None / "cpu" with a gloo group.
+    `block_rows`: rows per rank and gather (default_block_rows); every rank must pass the same value."""
 
-    def __init__(self, make_batch, global_envs, dist=None, device=None, force_collectives=None, pipelined=False):
+    def __init__(self, make_batch, global_envs, dist=None, device=None, force_collectives=None, pipelined=False, block_rows=None):
         import os
         import torch
         self.torch = torch
@@ -53,37 +66,39 @@ class ShardedRollout:
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         self.on_gpu = self.device.type == "cuda"
         b = self.batch
-        self.cap = int(b.TupleStats()["capacity"])
-        caps = [self.cap]
-        if self.coll:
-            t = torch.tensor([self.cap], dtype=torch.int64, device=self.device)
-            lst = [torch.zeros_like(t) for _ in range(self.world)]
-            dist.all_gather(lst, t)
-            caps = [int(x.item()) for x in lst]
-        self.cap = max(caps)           # one block size for every rank (a fixed-size collective)
+        # one block size for every rank (a fixed-size collective), derived from the global shape alone: no start-up exchange needed
+        self.cap = int(block_rows) if block_rows else default_block_rows(global_envs, self.world)
         W = b.W
-        # this rank's block: header row + cap tuple rows, W floats + [flags, global env id] as int32 bit patterns
-        self.block = torch.zeros((self.cap + 1, W + 2), dtype=torch.float32, device=self.device)
-        self.gathered = [torch.zeros_like(self.block) for _ in range(self.world)] if self.coll else None
+        # pipelined: the engine switches between two tuple rings at every UpdateBegin, so frame f's tuples are drained and gathered WHILE frame f + 1 runs:
+        # UpdateEnd (f) -> gather_tuples_end (f - 1) -> UpdateBegin (f + 1) -> gather_tuples_begin (f). Same tuple stream as the sequential protocol.
+        self.pipelined = bool(pipelined)
+        if self.pipelined:
+            b.SetTuplePipelining(True)
+        # this rank's send block: header row + cap tuple rows, W floats + [flags, global env id] as int32 bit patterns. Pipelined on a GPU: two of them, used
+        # alternately, so that the drain of frame f never has to wait (on the host) for the readers of frame f - 1's block. A block is rewritten only after
+        # the event recorded BEHIND its last reader has fired (self._busy): the gather that sent it (recorded once this rank's stream has waited for the
+        # collective -- an event on the comm stream right after an async collective call fires before RCCL's kernel has read the block), or the consumer of
+        # the views a one-rank run hands out.
+        nblk = 2 if (self.pipelined and self.on_gpu) else 1
+        self.blocks = [torch.zeros((self.cap + 1, W + 2), dtype=torch.float32, device=self.device) for _ in range(nblk)]
+        self.block = self.blocks[0]
+        self._bi = 0
+        self._busy = [None] * nblk
+        self._handed = None        # index of the block whose views the last gather_tuples_end handed to the caller (one-rank runs)
+        self.gathered = None       # receive side, trainer rank only: allocated by the first gather_tuples_end(dst) on that rank
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self._pending = None
+        self.carried_rows = 0      # rows the engine kept back for a later frame because the block was full (sum of the headers seen on this rank)
         # policy buffer: [weights f32 | in_off | in_scale | out_off | out_scale f64], 8-byte aligned sections
         self.n_w = b.PolicyNumParams()
         self.w_bytes = (4 * self.n_w + 7) // 8 * 8
         self.pol_bytes = self.w_bytes + 8 * (2 * b.S + 2 * b.nn_out)
         self.pol_buf = torch.zeros(self.pol_bytes, dtype=torch.uint8, device=self.device) if self.n_w else None
         self.exchange_wait_s = 0.0
-        # pipelined: the engine switches between two tuple rings at every UpdateBegin, so frame f's tuples are drained and gathered WHILE frame f + 1 runs:
-        # UpdateEnd (f) -> gather_tuples_end (f - 1) -> UpdateBegin (f + 1) -> gather_tuples_begin (f). Same tuple stream as the sequential protocol.
-        self.pipelined = bool(pipelined)
-        if self.pipelined:
-            b.SetTuplePipelining(True)
-        # pipelined: two send blocks, used alternately, so that the drain of frame f never has to wait (on the host) for the readers of frame f - 1's block
-        # (its all-gather, or the views gather_tuples_end handed out on a one-rank run): a block is rewritten two frames after it was filled, and the event
-        # recorded behind its last readers has long fired by then
-        self.blocks = [self.block, torch.zeros_like(self.block)] if (self.pipelined and self.on_gpu) else [self.block]
-        self._bi = 0
-        self._busy = [None] * len(self.blocks)
+
+    @property
+    def block_bytes(self):
+        return int(self.block.numel() * 4)
 
     # ---- rollout ----
     def Update(self, dt=1.0 / 30.0):
@@ -99,60 +114,76 @@ class ShardedRollout:
         self.batch.UpdateEndBegin(dt)
 
     # ---- (a) experience tuples ----
-    def gather_tuples_begin(self):
-        """Drain this rank's finished tuples into its block and start the all-gather (asynchronous on the GPU). Sequential protocol: call between
+    def gather_tuples_begin(self, dst=0):
+        """Drain this rank's finished tuples into its block and start the gather to rank `dst` (asynchronous on the GPU). Sequential protocol: call between
         UpdateEnd() of frame f and UpdateBegin() of frame f + 1; the collective then overlaps frame f + 1's kernel. Pipelined protocol (pipelined=True):
-        call right AFTER UpdateBegin() of frame f + 1 -- the drain itself (rank / pack kernels on the engine's drain stream) overlaps that frame too. Collect it with gather_tuples_end() in the
+        call right AFTER UpdateBegin() of frame f + 1 -- the drain itself (order / copy kernels on the engine's drain stream) overlaps that frame too. Collect it with gather_tuples_end() in the
         NEXT gap (after UpdateEnd() of frame f + 1): a frame kernel fills every CU, so small kernels and host syncs issued while it runs stall
-        until it ends (bench.py's exchange leg: UpdateEnd -> gather_tuples_end (previous frame) -> consume -> gather_tuples_begin -> UpdateBegin).
+        until it ends (bench.py's exchange leg: UpdateEndBegin -> gather_tuples_end (previous frame) -> consume -> gather_tuples_begin).
         The packing (sort by env id so that the gathered stream does not depend on how envs are sharded, flag word and GLOBAL env id appended to every
-        row, header row with the count) is three small kernels inside the engine (dtrl_drain_tuples_packed): no framework op touches the rows."""
+        row, header row with the count) happens inside the engine (dtrl_drain_tuples_packed): no framework op touches the rows."""
         torch = self.torch
         assert self._pending is None, "gather_tuples_begin called twice without gather_tuples_end"
+        if self.on_gpu and self._handed is not None:
+            # one-rank run: the caller reads views of that block on ITS stream; everything it has queued so far comes before the block's next rewrite
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device)); self._busy[self._handed] = ev
+            self._handed = None
         if len(self.blocks) > 1:
-            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device))   # behind every reader of the current block queued on the caller's stream so far
-            prev = self._busy[self._bi]
-            self._busy[self._bi] = ev if prev is None or not self.coll else prev       # (multi-rank: the block's reader is the all-gather, recorded below)
             self._bi ^= 1
-            self.block = self.blocks[self._bi]
-            if self._busy[self._bi] is not None:
-                self._busy[self._bi].synchronize()                                     # two frames old: fired long ago
+        bi = self._bi
+        self.block = self.blocks[bi]
+        if self._busy[bi] is not None:
+            self._busy[bi].synchronize()                                     # pipelined: two frames old, fired long ago
+            self._busy[bi] = None
         self.batch.DrainTuplesPacked(self.block.data_ptr(), self.cap)        # synchronised: the block is complete when this returns
         work = None
         if self.coll:
+            recv = None
+            if self.rank == dst:
+                if self.gathered is None:
+                    self.gathered = [torch.zeros_like(self.block) for _ in range(self.world)]
+                recv = self.gathered
             if self.on_gpu:
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))   # readers of the previous gather result (queued on the caller's stream) come first
                 with torch.cuda.stream(self.comm_stream):
-                    work = self.dist.all_gather(self.gathered, self.block, async_op=True)
-                    if len(self.blocks) > 1:
-                        ev = torch.cuda.Event(); ev.record(self.comm_stream); self._busy[self._bi] = ev
+                    work = self.dist.gather(self.block, gather_list=recv, dst=dst, async_op=True)
             else:
-                work = self.dist.all_gather(self.gathered, self.block, async_op=True)
-        self._pending = (work,)
+                work = self.dist.gather(self.block, gather_list=recv, dst=dst, async_op=True)
+        self._pending = (work, bi, dst)
 
-    def gather_tuples_end(self, dst=0, want_meta=True):
-        """Wait for the all-gather. Returns (rows [n, W] float32, flags [n] int32, global env ids [n] int32) as tensors on self.device on rank
-        `dst`, None elsewhere; want_meta=False returns (rows, None, None) on a multi-rank group."""
+    def gather_tuples_end(self, dst=None, want_meta=True):
+        """Wait for the gather. Returns (rows [n, W] float32, flags [n] int32, global env ids [n] int32) as tensors on self.device on the rank the
+        gather was started towards, None elsewhere; want_meta=False returns (rows, None, None) on a multi-rank group."""
         import time
         torch = self.torch
-        work, = self._pending
+        work, bi, dst0 = self._pending
+        assert dst is None or dst == dst0, "gather_tuples_end(dst) differs from gather_tuples_begin(dst)"
+        dst = dst0
         self._pending = None
         W = self.batch.W
         t0 = time.perf_counter()
         if work is not None:
             work.wait()
             if self.on_gpu:
-                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_stream(self.comm_stream)
+                # behind the collective itself: this rank's stream now follows RCCL's kernel, so an event recorded here fires only after the send block was read
+                ev = torch.cuda.Event(); ev.record(cur); self._busy[bi] = ev
         self.exchange_wait_s += time.perf_counter() - t0
         if self.rank != dst:
             return None
-        blocks = self.gathered if self.coll else [self.block]
         if not self.coll:
-            c = int(self.block[0, :1].view(torch.int32).item())       # one 4-byte read-back; the rows below are views into the block (valid until the next begin)
-            blk = self.block[1:c + 1]
+            blk_t = self.blocks[bi]
+            hdr = blk_t[0, :3].view(torch.int32).tolist()             # one 12-byte read-back; the rows below are views into the block (valid until its next begin)
+            c = int(hdr[0]); self.carried_rows += int(hdr[2])
+            blk = blk_t[1:c + 1]
             meta = blk[:, W:].view(torch.int32)
+            self._handed = bi
             return blk[:, :W], meta[:, 0], meta[:, 1]
-        counts = [int(x) for x in torch.stack([g[0, :1].view(torch.int32)[0] for g in blocks]).tolist()]
+        blocks = self.gathered
+        hdr = torch.stack([g[0, :3].view(torch.int32) for g in blocks]).tolist()
+        counts = [int(h[0]) for h in hdr]
+        self.carried_rows += sum(int(h[2]) for h in hdr)
         rows = torch.cat([g[1:c + 1, :W] for g, c in zip(blocks, counts)])
         if not want_meta:                 # (every framework op issued while a frame kernel runs waits for a wavefront slot: a consumer of the rows alone skips three)
             return rows, None, None
@@ -161,7 +192,7 @@ class ShardedRollout:
 
     def gather_tuples(self, dst=0):
         """Synchronous form. Returns numpy (rows, flags uint32, global env ids int64) on dst, else None (the host-side trainer loop's interface)."""
-        self.gather_tuples_begin()
+        self.gather_tuples_begin(dst)
         g = self.gather_tuples_end(dst)
         if g is None:
             return None

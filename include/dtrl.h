@@ -117,10 +117,12 @@ dtrl_status dtrl_drain_tuples(dtrl_batch* b, float* rows, uint32_t* flags, int32
 dtrl_status dtrl_drain_tuples_device(dtrl_batch* b, float* rows_dev, uint32_t* flags_dev, int32_t* env_ids_dev, int cap, int* out_n);
 /* Replaces: the same three calls as dtrl_drain_tuples_device, plus the per-rank packing the reference's learner thread does before it hands tuples to
  * the trainer (learning/NeuralNetLearner.cpp:33-46) -- for a consumer that wants ONE device block it can put on the wire as it is (one RCCL
- * all-gather per frame). block_dev: [block_rows + 1][W + 2] float32 in DEVICE memory. Row 0 is a header (int32 bit patterns: [0] = number of rows that
- * follow, [1] = rows that did not fit block_rows and were dropped -- counted in dtrl_tuple_stats); rows 1..n are the pending tuples sorted by env id
- * (stable: an env's tuples stay in time order), each [r | s | a | s' | flag word | GLOBAL env id], the last two as int32 bit patterns. The ring is
- * emptied. Everything runs on the device (rank, scatter-copy and header kernels); out_n, when not NULL, costs one 4-byte read-back. */
+ * gather per frame). block_dev: [block_rows + 1][W + 2] float32 in DEVICE memory. Row 0 is a header (int32 bit patterns: [0] = number of rows that
+ * follow, [1] = rows lost because the RING was full since the last drain -- counted in dtrl_tuple_stats --, [2] = rows carried); rows 1..n are the
+ * pending tuples sorted by env id (stable: an env's tuples stay in time order), each [r | s | a | s' | flag word | GLOBAL env id], the last two as int32
+ * bit patterns. Rows that do not fit block_rows are CARRIED, not dropped: they move to the front of the ring, in order, and the next drain of that ring
+ * hands them out in front of the newer rows -- so a consumer can size its block for the steady state (~0.08 rows per env and frame) instead of for the
+ * worst case. Everything runs on the device (segmented counting sort by env id, copy and header kernels); out_n, when not NULL, costs one 4-byte read-back. */
 dtrl_status dtrl_drain_tuples_packed(dtrl_batch* b, float* block_dev, int block_rows, int* out_n);
 /* Replaces: the concurrency of the reference's learner threads -- an env thread hands its tuples to the trainer under the trainer's lock while the other
  * env threads keep stepping (scenarios/ScenarioTrain.cpp:322-338, 376-410; learning/NeuralNetLearner.cpp:33-46). Batched equivalent: with pipelining on,

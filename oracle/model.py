@@ -116,7 +116,8 @@ RAPTOR_STATES = ["Contact", "Down", "Passing", "Up"]
 RAPTOR_STATE_PARAMS = ["RootPitch", "SpineCurve", "StanceHip", "StanceKnee", "StanceAnkle", "SwingHip", "SwingKnee", "SwingAnkle"]
 # sim/RaptorController.cpp:71-114 gOptParamsMasks
 RAPTOR_OPT_MASK = [0, 1, 1, 0, 0] + [1, 0, 1, 1, 1, 1, 1, 1] * 2 + [0, 0, 1, 1, 1, 1, 1, 1] * 2
-CTRL_NAMES = {"dog": ("dog", 0), "dog_mace": ("dog", 1), "goat_mace": ("dog", 1), "raptor": ("raptor", 0), "raptor_mace": ("raptor", 1), "dog_cacla": ("dog", 2)}
+CTRL_NAMES = {"dog": ("dog", 0), "dog_mace": ("dog", 1), "goat_mace": ("dog", 1), "raptor": ("raptor", 0), "raptor_mace": ("raptor", 1), "dog_cacla": ("dog", 2),
+              "raptor_cacla": ("raptor", 2)}   # sim/RaptorControllerCacla.cpp (mExpNoise 0.15 by character type below)
 SCENARIOS = {"sim_char": 0, "train": 1, "train_mace": 1, "exp": 1, "exp_mace": 1, "train_cacla": 1, "exp_cacla": 1, "poli_eval": 2}
 
 

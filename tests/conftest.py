@@ -12,6 +12,8 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 EMUL_LIB = os.path.join(REPO, "tests", "emul", "libdtrl_emul.so")   # lane-loop build of the kernel source: TESTS ONLY, lives outside the product package
 HIP_LIB = os.path.join(REPO, "deepterrainrl_amd", "lib", "libdtrl.so")
 REFERENCE = "/root/reference"
+# the test process's own choice, before any HIP runtime starts (the package leaves the environment alone: deepterrainrl_amd.configure_hw_queues)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def pytest_configure(config):

@@ -37,24 +37,40 @@ public:
 		std::stable_sort(order + e0, order + e0 + n, [&](int a, int b) { return (status[a].cost >> 4) > (status[b].cost >> 4); });
 		return true;
 	}
-	bool PackTuples(const DevBuffers& buf, float* block, int block_rows, int64_t env_id_base, int32_t* rank) override
+	bool PackTuples(const DevBuffers& buf, float* block, int block_rows, int64_t env_id_base, int, const PackScratch& sc) override
 	{
 		const int cnt = buf.tuple_count[0];
-		const int n = std::min(std::min(cnt, static_cast<int>(buf.tuple_cap)), block_rows);
-		const int stride = buf.W + 2;
-		for (int k = 0; k < n; ++k) { int r = 0; for (int j = 0; j < n; ++j) r += (buf.tuple_env[j] < buf.tuple_env[k]) || (buf.tuple_env[j] == buf.tuple_env[k] && j < k); rank[k] = r; }
-		for (int k = 0; k < n; ++k) {
-			float* dst = block + static_cast<size_t>(1 + rank[k]) * stride;
-			std::memcpy(dst, buf.tuple_rows + static_cast<size_t>(k) * buf.W, sizeof(float) * buf.W);
-			const int32_t fl = static_cast<int32_t>(buf.tuple_flags[k]), id = static_cast<int32_t>(env_id_base + buf.tuple_env[k]);
-			std::memcpy(dst + buf.W, &fl, 4); std::memcpy(dst + buf.W + 1, &id, 4);
+		const int n = std::min(cnt, static_cast<int>(buf.tuple_cap));
+		const int take = std::min(n, block_rows), carry = n - take;
+		const int W = buf.W, stride = W + 2;
+		std::vector<int> ord(n);
+		for (int k = 0; k < n; ++k) ord[k] = k;
+		std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return buf.tuple_env[a] < buf.tuple_env[b]; });
+		for (int r = 0; r < n; ++r) {
+			const int k = ord[r];
+			const float* src = buf.tuple_rows + static_cast<size_t>(k) * W;
+			if (r < take) {
+				float* dst = block + static_cast<size_t>(1 + r) * stride;
+				std::memcpy(dst, src, sizeof(float) * W);
+				const int32_t fl = static_cast<int32_t>(buf.tuple_flags[k]), id = static_cast<int32_t>(env_id_base + buf.tuple_env[k]);
+				std::memcpy(dst + W, &fl, 4); std::memcpy(dst + W + 1, &id, 4);
+			} else {
+				std::memcpy(sc.rows + static_cast<size_t>(r - take) * W, src, sizeof(float) * W);
+				sc.flags[r - take] = buf.tuple_flags[k]; sc.env[r - take] = buf.tuple_env[k];
+			}
+		}
+		for (int r = 0; r < carry; ++r) {
+			std::memcpy(buf.tuple_rows + static_cast<size_t>(r) * W, sc.rows + static_cast<size_t>(r) * W, sizeof(float) * W);
+			buf.tuple_flags[r] = sc.flags[r]; buf.tuple_env[r] = sc.env[r];
 		}
 		std::memset(block, 0, sizeof(float) * stride);
-		const int32_t hdr[2] = {n, cnt - n};
+		const int32_t hdr[3] = {take, cnt - n, carry};
 		std::memcpy(block, hdr, sizeof(hdr));
-		buf.tuple_count[1] += n; buf.tuple_count[2] += cnt - n; buf.tuple_count[0] = 0;
+		buf.tuple_count[1] += take; buf.tuple_count[2] += cnt - n; buf.tuple_count[0] = carry;
 		return true;
 	}
+	bool MarkFrame(int, int) override { return true; }
+	bool WaitFrames(int, int) override { return true; }
 	bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) override
 	{
 		int nt = std::min<int>(n_envs, std::max(1u, std::thread::hardware_concurrency()));

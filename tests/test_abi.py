@@ -62,14 +62,36 @@ def test_product_does_not_reference_the_oracle():
     assert not os.path.exists(os.path.join(pkg, "lib", "libdtrl_emul.so")) and not os.path.isdir(os.path.join(pkg, "csrc", "emul")), "the lane-loop test backend must live under tests/, not in the product package"
 
 
-def test_package_import_sets_hardware_queue_count_without_overriding():
-    """The engine's env-group streams must not share a HIP hardware queue: importing the package sets GPU_MAX_HW_QUEUES=8 when the user has not
-    set it, and leaves a user's value alone."""
+def test_hardware_queue_count_is_opt_in():
+    """The engine's env-group streams must not share a HIP hardware queue. Importing the package leaves the process environment alone
+    (ADVICE r2); deepterrainrl_amd.configure_hw_queues() sets GPU_MAX_HW_QUEUES=8 when the user has not set it and never overrides a user's value."""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = "import os, sys; sys.path.insert(0, %r); import deepterrainrl_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % repo
+    code = ("import os, sys; sys.path.insert(0, %r); import deepterrainrl_amd as da; a = os.environ.get('GPU_MAX_HW_QUEUES'); r = da.configure_hw_queues(); "
+            "print(a, r, os.environ['GPU_MAX_HW_QUEUES'])" % repo)
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    assert subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip() == "8"
+    assert subprocess.check_output([sys.executable, "-c", code], env=env).decode().split() == ["None", "8", "8"]
     env["GPU_MAX_HW_QUEUES"] = "5"
-    assert subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip() == "5"
+    assert subprocess.check_output([sys.executable, "-c", code], env=env).decode().split() == ["5", "5", "5"]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher must start two ranks (--gpus used to be ignored). --dry-launch makes every rank print
+    its placement and exit, so the launch path is checked on a box without a GPU: distinct RANK / LOCAL_RANK / device / global env offset, world = 2,
+    the host worker threads divided between the ranks; and a plain --gpus 1 stays in-process."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DTRL_HOST_THREADS")}
+    out = subprocess.check_output([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-launch", "--envs-per-gpu", "96"], env=env, stderr=subprocess.STDOUT, timeout=600).decode()
+    recs = [json.loads(l) for l in out.splitlines() if l.startswith("{") and "dry_launch" in l]
+    assert len(recs) == 2, out
+    recs.sort(key=lambda r: r["rank"])
+    assert [r["rank"] for r in recs] == [0, 1] and [r["local_rank"] for r in recs] == [0, 1] and all(r["world"] == 2 for r in recs)
+    assert [r["global_env_offset"] for r in recs] == [0, 96] and [r["device"] for r in recs] == ["cuda:0", "cuda:1"]
+    one = subprocess.check_output([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--dry-launch"], env=env, stderr=subprocess.STDOUT, timeout=600).decode()
+    r1 = [json.loads(l) for l in one.splitlines() if l.startswith("{") and "dry_launch" in l]
+    assert len(r1) == 1 and r1[0]["world"] == 1 and r1[0]["envs_per_gpu"] == 4096
+    assert recs[0]["host_threads"] == max(1, min(16, (os.cpu_count() or 2) // 4)) and r1[0]["host_threads"] == max(1, min(16, (os.cpu_count() or 2) // 2))

@@ -129,6 +129,61 @@ def test_shim_header_compiles_in_the_reference_tree_and_drives_frames(tmp_path, 
     _check_shim_output(lines, py_lines, py_total)
 
 
+def run_eval_shim(exe, tmp_path, om, scenario, pool=6, max_episodes=14, max_cycles=100000, seed=4242):
+    """include/BatchScenarioPoliEval.h driven like cOptScenarioPoliEval drives its pool (tests/shim/drive_shim_eval.cpp) vs the same protocol through the
+    Python mirror: per-scene seeds (drawn by the reference's own cRand inside the shim), every fold of the record (episodes, cycles, running average
+    distance), the dist log and the OutputResults line."""
+    pol = dog_policy(om)
+    pfile = tmp_path / "policy.bin"
+    _write_policy(pfile, pol, 90)
+    out_file = tmp_path / "eval_results.txt"
+    r = subprocess.run([exe, REFDATA, "args/dog_slopes_mixed_args.txt", str(pool), str(max_episodes), str(max_cycles), str(pfile), str(seed), str(out_file), "-terrain_seed=", "77"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    lines = r.stdout.strip().splitlines()
+    seeds = [int(x) for x in lines[0].split("=")[1].split()]
+    assert lines[0].startswith("seeds=") and len(seeds) == pool and len(set(seeds)) == pool
+    assert lines[1] == "name=Batch Policy Evaluation pool=%d S=283 O=90" % pool
+    # the same protocol through the Python mirror
+    b = scenario("args/dog_slopes_mixed_args.txt", pool, data_root=REFDATA, extra_args={"terrain_seed": 77})
+    b.SetPolicy(pol[1], *pol[2:])
+    b.Reset(terrain_seeds=np.asarray(seeds, np.uint64))
+    per_update = 10 * pool
+    num_ep = num_cy = prev_cy = rec_ep = rec_cy = frames = 0
+    rec_avg = 0.0
+    folds = []
+    while num_ep < max_episodes and num_cy < max_cycles:
+        b.Update(); frames += 1
+        st = b.EvalStats()
+        num_cy = st["cycles"]; cur = st["episodes"]
+        if cur >= per_update or cur + num_ep >= max_episodes:
+            rec_avg = (rec_avg * rec_ep + st["avg_dist"] * cur) / max(rec_ep + cur, 1)      # cMathUtil::AddAverage
+            rec_ep += cur; rec_cy += num_cy - prev_cy
+            folds.append((frames, rec_ep, rec_cy, rec_avg))
+            b.ResetAvgDist()
+            num_ep += cur; prev_cy = num_cy
+    got = [l for l in lines if l.startswith("fold ")]
+    assert len(got) == len(folds) >= 1
+    for l, (fr, ep, cy, avg) in zip(got, folds):
+        kv = dict(x.split("=") for x in l.split()[1:])
+        assert int(kv["frame"]) == fr and int(kv["episodes"]) == ep and int(kv["cycles"]) == cy and abs(float(kv["avg_dist"]) - avg) < 1e-6 * max(1.0, abs(avg)), (l, fr, ep, cy, avg)
+    d, ids = b.GetDistLog()
+    kv = dict(x.split("=") for x in lines[-1].split())
+    assert int(kv["frames"]) == frames and int(kv["dist_log"]) == len(d) >= max_episodes and abs(float(kv["dist_sum"]) - d.sum()) < 1e-6 * max(1.0, abs(d.sum()))
+    line = open(out_file).read()
+    assert line == ", ".join("%f" % x for x in d) + "\n"            # std::to_string per entry, pool order
+    return lines
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(SHIM_DIR, "drive_shim_eval_emul")), reason="tests/shim/drive_shim_eval_emul not built (needs /root/reference headers at build time)")
+def test_poli_eval_shim_compiles_in_the_reference_tree_and_runs_the_eval_loop(tmp_path, om):
+    """include/BatchScenarioPoliEval.h : cScenario built against the reference's own scenarios/Scenario.h, util/ArgParser.h, util/Rand.h (VERDICT r2 missing #3)."""
+    if os.path.isdir(os.path.join(REFERENCE, "scenarios")):
+        r = subprocess.run(["make", "-C", SHIM_DIR], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+    run_eval_shim(os.path.join(SHIM_DIR, "drive_shim_eval_emul"), tmp_path, om, Scenario)
+
+
 def test_dist_log_avg_dist_and_output_results(da, om, tmp_path):
     """cScenarioPoliEval::RecordDistTraveled / GetDistLog / GetAvgDist / ResetAvgDist and cOptScenarioPoliEval::OutputResults over the batch."""
     m, _ = om.build_model("args/dog_slopes_mixed_args.txt", REFDATA)
@@ -219,7 +274,8 @@ def test_device_destination_drain_and_policy_hand_over_equal_the_host_calls(da, 
 
 def run_packed_drain_equals_plain_drain(scn, om, to_ptr=None, read=None):
     """dtrl_drain_tuples_packed: the rows of dtrl_drain_tuples sorted by env id (stable), flag word and GLOBAL env id appended, a header row with the
-    count; rows that do not fit the caller's block are dropped AND counted."""
+    count. Rows that do not fit the caller's block are CARRIED, not dropped: they stay in the ring, in order, in front of the newer rows, and a later
+    drain hands them out -- a consumer with a small block (two rows here) receives every row of the big-block stream, each env's rows in time order."""
     pol = dog_policy(om)
     args = dict(terrain_seed=31, rand_seed=2, global_env_offset=100)
     a = scn("args/opt_args_train_mace.txt", 10, data_root=REFDATA, extra_args=args)
@@ -235,7 +291,9 @@ def run_packed_drain_equals_plain_drain(scn, om, to_ptr=None, read=None):
     else:
         import torch
         blk = torch.zeros((cap + 1, W + 2), dtype=torch.float32, device="cuda"); blk_c = torch.zeros((2 + 1, W + 2), dtype=torch.float32, device="cuda")
-    n_tot = n_multi = dropped = 0
+    n_tot = n_multi = carried_max = 0
+    big, small = [], []
+    pending_c = 0
     for f in range(120):
         for x in (a, b, c):
             x.Update()
@@ -244,38 +302,53 @@ def run_packed_drain_equals_plain_drain(scn, om, to_ptr=None, read=None):
         ra, fa, ia = a.DrainTuples()
         n = b.DrainTuplesPacked(to_ptr(blk), cap, want_count=True)
         h = read(blk)
-        assert n == len(ra) and h[0, :2].view(np.int32).tolist() == [n, 0]
+        assert n == len(ra) and h[0, :3].view(np.int32).tolist() == [n, 0, 0]
         order = np.argsort(ia, kind="stable")
         assert np.array_equal(h[1:n + 1, :W], ra[order])
         meta = h[1:n + 1, W:].view(np.int32)
         assert np.array_equal(meta[:, 0], fa[order].astype(np.int32)) and np.array_equal(meta[:, 1], ia[order] + 100)
         n_tot += n; n_multi += n >= 2
-        # a block with room for two rows only: the rest is dropped, and counted
+        big.append(h[1:n + 1].copy())
+        # a block with room for two rows only: the first two rows in (env id, time) order of what is pending, the rest carried and counted in the header
+        pending_c += n
         m = c.DrainTuplesPacked(to_ptr(blk_c), 2, want_count=True)
         hc = read(blk_c)
-        assert m == min(n, 2) and hc[0, :2].view(np.int32).tolist() == [m, n - m]
-        dropped += n - m
-    assert n_tot >= 12 and n_multi >= 3
+        assert m == min(pending_c, 2) and hc[0, :3].view(np.int32).tolist() == [m, 0, pending_c - m]
+        pending_c -= m; carried_max = max(carried_max, pending_c)
+        small.append(hc[1:m + 1].copy())
+        assert c.TupleStats()["pending"] == pending_c
+    assert n_tot >= 12 and n_multi >= 3 and carried_max >= 2
+    while pending_c > 0:                                                  # flush what the small block left behind
+        m = c.DrainTuplesPacked(to_ptr(blk_c), 2, want_count=True)
+        assert m == min(pending_c, 2)
+        pending_c -= m
+        small.append(read(blk_c)[1:m + 1].copy())
+    big, small = np.concatenate(big), np.concatenate(small)
+    assert len(big) == len(small) == n_tot
+    ids_b, ids_s = big[:, W + 1].view(np.int32), small[:, W + 1].view(np.int32)
+    for e in np.unique(ids_b):                                            # every env: the same rows in the same (time) order
+        assert np.array_equal(big[ids_b == e], small[ids_s == e]), e
     sb, sc = b.TupleStats(), c.TupleStats()
     assert sb["drained"] == n_tot and sb["dropped"] == 0 and sb["pending"] == 0
-    assert sc["drained"] == n_tot - dropped and sc["dropped"] == dropped > 0
+    assert sc["drained"] == n_tot and sc["dropped"] == 0 and sc["pending"] == 0
 
 
 def test_packed_drain_equals_plain_drain(da, om):
     run_packed_drain_equals_plain_drain(Scenario, om)
 
 
-def run_pipelined_drain_equals_sequential(scn, om, to_ptr=None, read=None):
+def run_pipelined_drain_equals_sequential(scn, om, to_ptr=None, read=None, n_envs=12, cap=48, frames=90, extra=None):
     """dtrl_set_tuple_pipelining: UpdateEnd(f); UpdateBegin(f + 1); drain -> frame f's tuples from the ring frame f wrote, while frame f + 1 runs.
     The drained stream, frame by frame, equals that of the sequential protocol (Update(); drain) on a twin batch; nothing is lost or duplicated, the
     counters agree, plain drains work in the same place, and the mode cannot be left while a ring still holds rows."""
     pol = dog_policy(om)
     args = dict(terrain_seed=31, rand_seed=2, global_env_offset=7)
+    args.update(extra or {})
     prev = os.environ.get("DTRL_GROUPS")
     os.environ["DTRL_GROUPS"] = "2"                     # two env groups (two streams) also at this batch size: UpdateEndBegin schedules per group
     try:
-        a = scn("args/opt_args_train_mace.txt", 12, data_root=REFDATA, extra_args=args)
-        b = scn("args/opt_args_train_mace.txt", 12, data_root=REFDATA, extra_args=args)
+        a = scn("args/opt_args_train_mace.txt", n_envs, data_root=REFDATA, extra_args=args)
+        b = scn("args/opt_args_train_mace.txt", n_envs, data_root=REFDATA, extra_args=args)
     finally:
         if prev is None:
             del os.environ["DTRL_GROUPS"]
@@ -284,7 +357,6 @@ def run_pipelined_drain_equals_sequential(scn, om, to_ptr=None, read=None):
     for x in (a, b):
         x.SetPolicy(pol[1], *pol[2:])
     W = a.W
-    cap = 48
     if to_ptr is None:
         mk = lambda: np.zeros((cap + 1, W + 2), np.float32)
         to_ptr = lambda t: t.ctypes.data; read = lambda t: t
@@ -293,7 +365,6 @@ def run_pipelined_drain_equals_sequential(scn, om, to_ptr=None, read=None):
         mk = lambda: torch.zeros((cap + 1, W + 2), dtype=torch.float32, device="cuda")
     blk_a, blk_b = mk(), mk()
     b.SetTuplePipelining(True)
-    frames = 90
     seq = []
     for f in range(frames):
         a.Update()
@@ -342,6 +413,13 @@ def run_pipelined_drain_equals_sequential(scn, om, to_ptr=None, read=None):
 
 def test_pipelined_drain_equals_sequential(da, om):
     run_pipelined_drain_equals_sequential(Scenario, om)
+
+
+def test_pipelined_drain_equals_sequential_device_terrain(da, om):
+    """The same protocol with -terrain_gen= device, where the frame boundary is queued work and the host never waits for a frame (the drain
+    must follow the frame that wrote its ring on the DEVICE). The lane-loop backend is synchronous, so this checks the engine logic; the GPU twin in
+    tests/test_gpu_parity.py runs a batch large enough for a frame to outlast the host."""
+    run_pipelined_drain_equals_sequential(Scenario, om, extra={"terrain_gen": "device"})
 
 
 def test_env_id_lists_are_validated(da):

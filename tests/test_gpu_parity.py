@@ -223,8 +223,13 @@ def test_bench_contract_line():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"] and d["value"] > 1e5
+    # steady-state protocol: a pre-roll of >= 60 frames independent of --warmup, R >= 3 windows of exactly --steps frames, value = the median window
+    assert d["preroll"] >= 60 and d["repeats"] >= 3 and d["value_min"] <= d["value"] <= d["value_max"]
+    assert abs(d["ms_per_step"] - d["window_s"]["median"] / 3 * 1e3) < 1e-9 and d["timed_window"]["frames"] == 3 * d["repeats"]
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel_launches"] == 3 and rf["kernel_avg_ms"] > 0
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel_launches"] == 3 * d["repeats"] and rf["kernel_avg_ms"] > 0
+    ex = d["exchange"]
+    assert "error" not in ex and ex["tuple_block_rows"] == 64 and ex["dropped_tuples"] == 0 and ex["env_steps_per_s"] > 1e5
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
 
@@ -383,6 +388,14 @@ def test_shim_drives_the_hip_library(da, om, tmp_path):
     TB._check_shim_output(lines, py_lines, py_total)
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(TB.SHIM_DIR, "drive_shim_eval_hip")), reason="tests/shim/drive_shim_eval_hip not built")
+def test_poli_eval_shim_drives_the_hip_library(da, om, tmp_path):
+    """include/BatchScenarioPoliEval.h (compiled inside the reference's header tree on the build box, linked against libdtrl.so) runs cOptScenarioPoliEval's
+    pool protocol on the GPU -- SetRandSeed + Reset, the EvalHelper loop over GetNumEpisodes / GetNumCycles / GetAvgDist / ResetAvgDist, GetDistLog,
+    OutputResults -- and reports the same folds, dist log and results line as the Python mirror over the same library."""
+    TB.run_eval_shim(os.path.join(TB.SHIM_DIR, "drive_shim_eval_hip"), tmp_path, om, da.BatchScenario, pool=64, max_episodes=200)
+
+
 def _obb_overlap(c0, a0, h0, c1, a1, h1):
     """separating-axis test of two oriented boxes (centres c, angles a, half extents h), vectorised over a leading axis"""
     ok = np.ones(c0.shape[0], bool)
@@ -492,6 +505,16 @@ def test_pipelined_drain_equals_sequential(om):
     import test_boundary as B
     import deepterrainrl_amd as da_mod
     B.run_pipelined_drain_equals_sequential(da_mod.BatchScenario, om, to_ptr=lambda t: t.data_ptr(), read=lambda t: t.cpu().numpy())
+
+
+def test_pipelined_drain_equals_sequential_device_terrain(om):
+    """-terrain_gen= device + tuple pipelining: the frame boundary is queued device work, the host never synchronises with a frame, so the
+    drain of frame f's ring must wait ON THE DEVICE for frame f's launches (per-group frame marks). 768 envs in two groups: a frame lasts milliseconds
+    while the host is back within microseconds -- without the marks the drain read torn rows and zeroed the cursor under the running kernel."""
+    import test_boundary as B
+    import deepterrainrl_amd as da_mod
+    B.run_pipelined_drain_equals_sequential(da_mod.BatchScenario, om, to_ptr=lambda t: t.data_ptr(), read=lambda t: t.cpu().numpy(),
+                                            n_envs=768, cap=1536, frames=60, extra={"terrain_gen": "device"})
 
 
 def test_link_link_contacts(da, om):

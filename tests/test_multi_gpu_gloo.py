@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from conftest import REPO, REFDATA, EmulScenario
 
@@ -23,7 +24,8 @@ dist.init_process_group(backend="gloo")
 rank = dist.get_rank()
 def make(n, off):
     return Scenario("args/opt_args_train_mace.txt", n, data_root=REFDATA, extra_args=dict(terrain_seed=300, rand_seed=9, global_env_offset=off))
-sr = ShardedRollout(make, 4, dist=dist)
+sr = ShardedRollout(make, 4, dist=dist, block_rows={block_rows!r})
+assert sr.cap == ({block_rows!r} or 64)
 pol = dog_policy(om)
 if rank == 0:
     sr.broadcast_policy(pol[1], pol[2], pol[3], pol[4], pol[5], src=0)
@@ -35,6 +37,11 @@ for f in range(70):
     g = sr.gather_tuples(dst=0)
     if rank == 0:
         rows.append(g[0]); flags.append(g[1]); ids.append(g[2])
+for f in range(12):                      # no stepping: rows a small block carried over are flushed (every rank takes part in every gather)
+    g = sr.gather_tuples(dst=0)
+    if rank == 0:
+        rows.append(g[0]); flags.append(g[1]); ids.append(g[2])
+assert sr.batch.TupleStats()["pending"] == 0 and sr.batch.TupleStats()["dropped"] == 0
 q, qd = sr.batch.PoseVel()
 np.save(os.path.join({out!r}, "q_rank%d.npy" % rank), q)
 if rank == 0:
@@ -43,12 +50,15 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_two_rank_gloo_matches_single_process(tmp_path, da, om):
+@pytest.mark.parametrize("block_rows", [None, 1])
+def test_two_rank_gloo_matches_single_process(tmp_path, da, om, block_rows):
+    """block_rows=1: a send block far smaller than a frame's rows -- the gather to rank 0 delivers one row per rank and frame and the engine carries
+    the rest to later frames; the trainer still receives every tuple, each env's in time order."""
     from conftest import dog_policy
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(repo=REPO, out=str(tmp_path)))
+    script.write_text(WORKER.format(repo=REPO, out=str(tmp_path), block_rows=block_rows))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(29611 + (block_rows or 0) * 7), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     # single process over the same 4 global envs
