@@ -246,8 +246,10 @@ def main():
     # frame-boundary host workers (terrain regeneration): the ranks of a node share its cores (the engine applies the same rule from LOCAL_WORLD_SIZE)
     host_threads = int(os.environ.get("DTRL_HOST_THREADS", "0")) or max(1, min(16, (os.cpu_count() or 2) // (2 * max(1, local_world))))
     if a.dry_launch:
-        print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus_arg": a.gpus, "envs_per_gpu": n,
-                          "global_env_offset": rank * n, "device": "cuda:%d" % local_rank, "host_threads": host_threads, "config": a.config}), flush=True)
+        rec = json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus_arg": a.gpus, "envs_per_gpu": n,
+                          "global_env_offset": rank * n, "device": "cuda:%d" % local_rank, "host_threads": host_threads, "config": a.config})
+        sys.stdout.flush()
+        os.write(1, (rec + "\n").encode())      # one write per rank: the ranks share the launcher's pipe, and print() hands over text and newline separately
         return
     os.environ.setdefault("DTRL_HOST_THREADS", str(host_threads))
 

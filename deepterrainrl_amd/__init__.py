@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_cycle_info", "dtrl_get_action_table", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
     "dtrl_terrain_build", "dtrl_terrain_load_file", "dtrl_args_parse_string",
-    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed", "dtrl_get_policy_output", "dtrl_set_tuple_pipelining", "dtrl_step_end_begin",
+    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed", "dtrl_get_policy_output", "dtrl_set_tuple_pipelining", "dtrl_step_end_begin", "dtrl_command_action",
 ]
 
 
@@ -91,6 +91,7 @@ def _bind(path):
     for name in ("dtrl_get_pose_vel", "dtrl_get_torques"):
         getattr(L, name).argtypes = [vp, vp, C.c_int, vp, vp]
     L.dtrl_set_pose_vel.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.dtrl_command_action.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_link_states.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.dtrl_add_perturb.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
     L.dtrl_apply_rand_force.argtypes = [vp, vp, C.c_int, C.c_uint64]
@@ -331,6 +332,12 @@ class BatchScenario:
         ids, n = self._ids(env_ids)
         q = np.ascontiguousarray(q, np.float64).reshape(n, self.D); qd = np.ascontiguousarray(qd, np.float64).reshape(n, self.D)
         self._chk(self._lib.dtrl_set_pose_vel(self._h, _p(ids), n, _p(q), _p(qd)))
+
+    def CommandAction(self, action_id, env_ids=None):
+        """cCharController::CommandAction on the listed envs (all by default): action_id (an int, or one per env) is taken at the next cycle."""
+        ids, n = self._ids(env_ids)
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(action_id, np.int32), (n,)))
+        self._chk(self._lib.dtrl_command_action(self._h, _p(ids), n, _p(a)))
 
     def RecordPoliState(self, env_ids=None):
         ids, n = self._ids(env_ids)

@@ -911,6 +911,27 @@ int Engine::SetPoseVel(const int32_t* env_ids, int n, const double* q, const dou
 	return DTRL_OK;
 }
 
+// cCharController::CommandAction (sim/DogController.cpp:309-320, sim/RaptorController.cpp): the base action the controller takes at its next cycle instead
+// of asking the policy. The reference keeps a STACK of commands (the latest is served first, older ones at later cycles); the engine keeps the top of
+// that stack only -- one pending command per env, a new one replaces it (cScenarioExp::Reset's random first action, scenarios/ScenarioExp.cpp:63-73,
+// sits in the same slot).
+int Engine::CommandAction(const int32_t* env_ids, int n, const int32_t* action_ids)
+{
+	if ((env_ids && n < 0) || !action_ids) return Fail(DTRL_ERR_ARG, "bad arguments");
+	be_->Sync();
+	const int cnt = env_ids ? n : n_;
+	EnvState st;
+	for (int i = 0; i < cnt; ++i) {
+		const int e = EnvIndex(env_ids, i);
+		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
+		if (action_ids[i] < 0 || action_ids[i] >= cfg_.model.n_actions) return Fail(DTRL_ERR_ARG, "action id out of range");   // the reference asserts (and ignores the command in release builds)
+		if (!be_->D2H(&st, &buf_.st[e], sizeof(EnvState))) return Fail(DTRL_ERR_DEVICE, be_->error());
+		st.cmd_action = action_ids[i];
+		if (!be_->H2D(&buf_.st[e], &st, sizeof(EnvState))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	}
+	return DTRL_OK;
+}
+
 // cScenarioSimChar::AddPerturb -> cWorld::AddPerturb (scenarios/ScenarioSimChar.cpp:204-207): a world-frame force on a body part at a
 // body-local offset for `duration` seconds of simulated time. Planar characters: the in-plane components. One slot per env.
 int Engine::AddPerturb(const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration)

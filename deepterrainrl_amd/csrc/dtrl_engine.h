@@ -79,6 +79,7 @@ public:
 	int SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, const double* is_dev, const double* oo_dev, const double* os_dev);
 	int GetStates(const int32_t* env_ids, int n, std::vector<EnvState>& out);
 	int SetPoseVel(const int32_t* env_ids, int n, const double* q, const double* qd);
+	int CommandAction(const int32_t* env_ids, int n, const int32_t* action_ids);
 	int AddPerturb(const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration);
 	int ApplyRandForce(const int32_t* env_ids, int n, uint64_t seed);
 	int GetPoliState(const int32_t* env_ids, int n, double* s);

@@ -149,6 +149,11 @@ dtrl_status dtrl_set_policy_device(dtrl_batch* b, const float* weights_dev, size
 
 /* Replaces: cSimCharacter::BuildPose / BuildVel (sim/SimCharacter.cpp:166-225). env_ids == NULL -> envs 0..n-1. */
 dtrl_status dtrl_get_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, double* q, double* qd);
+/* Replaces: cCharController::CommandAction (sim/CharController.h:23, sim/DogController.cpp:309-320): action_ids[i] (an index into the controller's
+ * action table, dtrl_get_action_table) is the base action env i takes at its next cycle instead of asking the policy. env_ids == NULL -> envs 0..n-1 =
+ * all envs, action_ids then holds num_envs entries. The reference keeps a stack of commands; the engine keeps its top only (one pending command per env,
+ * a new one replaces it -- also the random first action cScenarioExp::Reset queues, scenarios/ScenarioExp.cpp:63-73). */
+dtrl_status dtrl_command_action(dtrl_batch* b, const int32_t* env_ids, int n, const int32_t* action_ids);
 /* Replaces: cSimCharacter::SetPose / SetVel (sim/SimCharacter.cpp:665-683, 227-315). */
 dtrl_status dtrl_set_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, const double* q, const double* qd);
 

@@ -70,6 +70,10 @@ def test_cacla_action_selection(da, om):
     T.test_cacla_action_selection_and_tuples_vs_oracle(da, om)
 
 
+def test_raptor_cacla_action_selection(da, om, tmp_path):
+    T.test_raptor_cacla_action_selection_and_tuples_vs_oracle(da, om, tmp_path)
+
+
 def test_q_head_action_selection(da, om):
     T.test_q_head_action_selection_and_tuples_vs_oracle(da, om)
 
@@ -523,6 +527,22 @@ def test_link_link_contacts(da, om):
 
 def test_product_vs_frozen_reference_lockstep_traces(da):
     T.test_product_vs_frozen_reference_lockstep_traces(da)
+
+
+@pytest.mark.parametrize("run", T.CONFIG_RUNS, ids=[r[0] for r in T.CONFIG_RUNS])
+def test_product_vs_frozen_reference_config_traces(da, om, run):
+    """The HIP kernel on the MI355X against the compiled REFERENCE's frozen traces of the BASELINE scenes (tests/golden/ref_golden_configs.npz, made where
+    /root/reference exists): dog + slopes_mixed + MACE net through two falls (configs[1], two seeds), raptor + narrow_gaps with the stance-mirrored
+    state (configs[2]), goat + cliffs_rugged (configs[4]'s scene) -- torques, contact flags, FSM, actions, PD targets, policy states, counters, dist log."""
+    info = T.run_product_vs_frozen_reference_config(da, om, *run, scenario=da.BatchScenario)
+    print(run[0], info)
+    assert info["tracked"] >= 0.6 * info["frames"] and info["cycles"] >= 5 and info["contact_frames"] >= 20, info
+    assert info["resets_tracked"] >= 1, info
+
+
+@pytest.mark.parametrize("run", T.TUPLE_RUNS, ids=[r[0] for r in T.TUPLE_RUNS])
+def test_product_vs_frozen_reference_tuples(da, om, run):
+    T.test_product_vs_frozen_reference_tuples(da, om, run, scenario=da.BatchScenario)
 
 
 def test_sharded_rollout_pipelined_protocol_on_gpu(om):

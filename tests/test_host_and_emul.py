@@ -536,6 +536,60 @@ def test_cacla_action_selection_and_tuples_vs_oracle(da, om):
     assert set(b.Ctrl()[2].tolist()) <= set(range(-1, 8))                                  # gInvalidIdx after the actor, a table id after a base action
 
 
+def test_raptor_cacla_action_selection_and_tuples_vs_oracle(da, om, tmp_path):
+    """cRaptorControllerCacla (sim/RaptorControllerCacla.cpp; -char_ctrl= raptor_cacla, built by scenarios/ScenarioSimChar.cpp:407, 480-483): the raptor FSM
+    under the CACLA head with mExpNoise 0.15. The reference ships no raptor actor net, so the test derives one from dog_actor_deploy.prototxt
+    (275 inputs, 28 outputs = the raptor's optimisable parameters). Engine vs oracle: action ids / parameters per cycle, tuple rows and flags."""
+    src = open(os.path.join(REFDATA, "data/policies/dog/nets/dog_actor_deploy.prototxt")).read()
+    net = tmp_path / "raptor_actor_deploy.prototxt"
+    net.write_text(src.replace("input_dim: 283", "input_dim: 275").replace('name: "output" type: "InnerProduct" num_output: 29', 'name: "output" type: "InnerProduct" num_output: 28'))
+    over = dict(exp_rate=0.5, exp_base_rate=0.3, char_ctrl="raptor_cacla", scenario="train_cacla", policy_net=str(net), terrain_file="data/terrain/flat.txt")
+    arg = "args/opt_args_train_raptor_mace.txt"
+    m, _ = om.build_model(arg, REFDATA, over)
+    assert m.ctrl_type == 2 and m.char_type == 1 and abs(m.exp_noise - 0.15) < 1e-15
+    desc = om.parse_deploy_prototxt(str(net))
+    w = om.actor_xavier_weights(desc, 78)
+    n = 10
+    b = batch(da, arg, n, terrain_seed=41, rand_seed=6, **over)
+    assert b.L == 19 and b.S == 275 and b.A == 28 and b.nn_out == 28 and b.PolicyNumParams() == len(w) and b.num_frags == 0
+    oo, osc = b.BuildNNOutputOffsetScale()
+    io, isc = np.zeros(275), np.ones(275)
+    b.SetPolicy(w, io, isc, oo, osc)
+    wm, oom, osm = om.actor_policy_to_mace(desc, w, oo, osc)
+    es = [om.OracleEnv(m, terrain_seed=41 + i, rng_seed=6, env_id=i, policy=(desc, wm, io, isc, oom, osm)) for i in range(n)]
+    rows, flags, ids, when = [], [], [], []
+    first_stumble = np.full(n, 10 ** 9)
+    for f in range(120):
+        b.Update()
+        for e in es:
+            e.update()
+        r, fl, ei = b.DrainTuples()
+        rows.append(r); flags.append(fl); ids.append(ei); when.append(np.full(len(ei), f))
+        stum = (b.Flags() & 2) != 0
+        first_stumble = np.where(stum & (first_stumble > f), f, first_stumble)
+        if f in (8, 20):                                  # (env 1 stumbles at frame 22: contact switching amplifies rounding differences from there on)
+            st, ph, aid, prm, tg = b.Ctrl()
+            for i, e in enumerate(es):
+                so, pho, aido, prmo, tgo = e.ctrl()
+                assert aid[i] == aido and st[i] == so and np.abs(prm[i] - prmo).max() < 1e-6
+    rows = np.concatenate(rows); flags = np.concatenate(flags); ids = np.concatenate(ids); when = np.concatenate(when)
+    assert rows.shape[1] == 1 + 2 * 275 + 28
+    seen = set(); compared = 0
+    for i, e in enumerate(es):
+        ro, fo = e.drain_tuples(1024)
+        sel = ids == i
+        mine = rows[sel]; mf = flags[sel]
+        # a stumble is a contact-switching event that amplifies rounding differences (DESIGN 4, chaos note): rows are compared up to the env's first stumble
+        k = min(len(ro), int((when[sel] < first_stumble[i]).sum()), 4)
+        assert np.array_equal(mf[:k], fo[:k]) and np.all((mf.astype(np.int64) >> 2) == 0)
+        if k:
+            assert np.abs(mine[:k] - ro[:k]).max() < 2e-4 * max(1.0, np.abs(ro[:k]).max())
+        compared += k
+        seen.update(mf.tolist())
+    assert compared >= 6
+    assert any(f & 2 for f in seen) and any(not (f & 2) for f in seen)
+
+
 def test_q_head_action_selection_and_tuples_vs_oracle(da, om):
     """cDogControllerQ (args/opt_args_train_q.txt: -char_ctrl= dog with dog_q_deploy.prototxt, one output per base action): a random base action with
     probability exp_rate, else the base action with the largest value (sim/BaseControllerQ.cpp:32-87); tuples [r | s | a | s'] with a = one-hot over the
@@ -652,6 +706,143 @@ def test_product_vs_frozen_reference_lockstep_traces(da):
             assert st[0] == st_ref[k] and abs(ph[0] - ph_ref[k]) < 1e-9, (name, k)
             assert np.abs(tg[0][1:L] - pd_ref[k][1:L]).max() < 1e-6, (name, k)
         assert len(set(st_ref.tolist())) >= 3 and con_ref.any()
+
+
+CONFIG_RUNS = [  # tag, arg file, terrain seed, policy, extra args, tolerances (tau relative, params, terrain part of the policy state)
+    ("dog_sm32", "args/dog_slopes_mixed_args.txt", 32, "dog", {}, 1e-4, 1e-5, 5e-5),
+    ("dog_sm9", "args/dog_slopes_mixed_args.txt", 9, "dog", {}, 1e-4, 1e-5, 5e-5),
+    ("raptor_ng", "args/raptor_narrow_gaps_args.txt", 11, "raptor", {}, 1e-4, 1e-5, 5e-5),
+    ("goat_cliffs", "args/goat_cliffs_args.txt", 8, "dog", {}, 1e-3, 1e-4, 5e-4),
+]
+
+
+def _wrap(a):
+    return (a + np.pi) % (2 * np.pi) - np.pi
+
+
+def run_product_vs_frozen_reference_config(da, om, tag, arg, seed, polname, extra, tau_tol, prm_tol, terr_tol, scenario=None):
+    """One poli_eval run of tests/golden/ref_golden_configs.npz: the PRODUCT stepped frame by frame from the same seed and policy against what the
+    compiled REFERENCE computed (its own contact manager, FSM, action selection through the policy, PD targets, stable-PD torques + clamp, cycle / episode
+    counters, recorded policy states, episode distances, reset poses). Rigid contact dynamics amplify rounding differences while a character tumbles
+    (chaos note), so values are compared while the product's pose is within 1e-6 of the frozen motion; a reset both sides perform on the same
+    frame puts them back on one trajectory. Returns tracking statistics."""
+    g = np.load(os.path.join(os.path.dirname(REFDATA), "ref_golden_configs.npz"))
+    G = lambda k: g["%s/%s" % (tag, k)]
+    pol = dog_policy(om) if polname == "dog" else raptor_policy(om)
+    b = (scenario or Scenario)(arg, 1, data_root=REFDATA, extra_args=dict(terrain_seed=seed, **extra))
+    b.SetPolicy(pol[1], *pol[2:])
+    q_ref, tau_ref, con_ref = G("frame/q"), G("frame/tau"), G("frame/contacts")
+    F = len(q_ref); L = tau_ref.shape[1]; P = b.P
+    cyc_frames = {int(f): i for i, f in enumerate(G("cycle/frame"))}
+    tracking = True
+    n_tracked = n_cyc = n_resets_tracked = n_contact = 0
+    worst = dict(tau=0.0, q=0.0, prm=0.0, ps=0.0)
+    lost_at = []
+    for f in range(F):
+        b.Update()
+        q, qd = b.PoseVel()
+        dq = np.abs(np.concatenate([q[0][:2] - q_ref[f][:2], _wrap(q[0][2:] - q_ref[f][2:])])).max()
+        reset_ref = bool(G("frame/after_reset")[f])
+        if not tracking and reset_ref and dq < 1e-9:
+            tracking = True                                        # both reset on this frame, to the same pose on fresh terrain
+        if tracking and dq > 1e-6:
+            tracking = False; lost_at.append(f)
+        if not tracking:
+            continue
+        n_tracked += 1; worst["q"] = max(worst["q"], dq)
+        st = b.EvalStats()
+        assert st["cycles"] == G("frame/cycles")[f] and st["episodes"] == G("frame/episodes")[f], (tag, f, st)
+        assert abs(st["avg_dist"] - G("frame/avg_dist")[f]) < 1e-5, (tag, f)          # (an episode distance carries the pose difference of the frame it ended in: < 1e-6 while tracking)
+        if reset_ref:
+            n_resets_tracked += 1
+            assert dq < 1e-9, (tag, f, dq)                          # the reference's reset pose
+            continue
+        assert np.array_equal(b.Contacts()[0][:L], con_ref[f][:L]), (tag, f)
+        s_, ph, aid, prm, tg = b.Ctrl()
+        assert s_[0] == G("frame/state")[f] and abs(ph[0] - G("frame/phase")[f]) < 1e-9, (tag, f)
+        assert aid[0] == G("frame/action_id")[f], (tag, f, aid[0], G("frame/action_id")[f])
+        dp = np.abs(prm[0][:P] - G("frame/params")[f][:P]).max()
+        assert dp < prm_tol * max(1.0, np.abs(prm[0]).max()) + 1e-6, (tag, f, dp)
+        assert np.abs(tg[0][1:L] - G("frame/pd_targets")[f][1:L]).max() < 10 * prm_tol + 1e-6, (tag, f)
+        assert b.Flags()[0] == G("frame/flags")[f], (tag, f, hex(int(b.Flags()[0])), hex(int(G("frame/flags")[f])))
+        _, tau = b.Torques()
+        dt_ = np.abs(tau[0][3:3 + L - 1] - tau_ref[f][1:]).max()
+        assert dt_ < tau_tol * max(1.0, np.abs(tau_ref[f]).max()) + 400 * dq + 1e-4, (tag, f, dt_, dq)
+        worst["tau"] = max(worst["tau"], dt_); worst["prm"] = max(worst["prm"], dp); n_contact += int(con_ref[f].any())
+        if f in cyc_frames:
+            ps = b.RecordPoliState()[0]; ps_ref = G("cycle/poli_state")[cyc_frames[f]]
+            d = np.abs(ps - ps_ref)
+            assert d[201:].max() < 2e-6 * max(1.0, np.abs(ps_ref).max()) and d[:201].max() < terr_tol, (tag, f, d[201:].max(), d[:201].max())
+            worst["ps"] = max(worst["ps"], d.max()); n_cyc += 1
+    # the first 240 env-steps at env-step resolution (a twin batch: StepUpdates has no frame-end logic, and no fall happens that early)
+    b2 = (scenario or Scenario)(arg, 1, data_root=REFDATA, extra_args=dict(terrain_seed=seed, **extra))
+    b2.SetPolicy(pol[1], *pol[2:])
+    tau_s, con_s, st_s, ph_s = G("step/tau"), G("step/contacts"), G("step/state"), G("step/phase")
+    for k in range(len(tau_s)):
+        b2.StepUpdates(1)
+        _, tau = b2.Torques()
+        dt_ = np.abs(tau[0][3:3 + L - 1] - tau_s[k][1:]).max()
+        assert dt_ < tau_tol * max(1.0, np.abs(tau_s[k]).max()) + 1e-4, (tag, "env-step", k, dt_)
+        assert np.array_equal(b2.Contacts()[0][:L], con_s[k][:L]), (tag, "env-step", k)
+        s_, ph, _, _, _ = b2.Ctrl()
+        assert s_[0] == st_s[k] and abs(ph[0] - ph_s[k]) < 1e-9, (tag, "env-step", k)
+    d_log, _ = b.GetDistLog()
+    ref_log = G("dist_log")
+    k = min(len(d_log), len(ref_log)) if lost_at else len(ref_log)
+    assert len(d_log) >= k and (k == 0 or np.abs(d_log[:k] - ref_log[:k]).max() < 1e-5 or lost_at), (tag, d_log, ref_log)
+    return dict(frames=F, tracked=n_tracked, cycles=n_cyc, resets_tracked=n_resets_tracked, contact_frames=n_contact, lost_at=lost_at, worst=worst,
+                dist_log_equal=bool(len(d_log) == len(ref_log) and (len(ref_log) == 0 or np.abs(d_log - ref_log).max() < 1e-5)))
+
+
+@pytest.mark.parametrize("run", CONFIG_RUNS, ids=[r[0] for r in CONFIG_RUNS])
+def test_product_vs_frozen_reference_config_traces(da, om, run):
+    """every BASELINE scene (configs[1] dog + slopes_mixed + MACE net through two falls, configs[2] raptor + narrow_gaps with the mirrored
+    state, configs[4]'s goat + cliffs_rugged) has a product-vs-frozen-REFERENCE check that runs where /root/reference does not exist."""
+    info = run_product_vs_frozen_reference_config(da, om, *run)
+    print(run[0], info)
+    assert info["tracked"] >= 0.6 * info["frames"] and info["cycles"] >= 5 and info["contact_frames"] >= 20, info
+    assert info["resets_tracked"] >= 1, info
+
+
+TUPLE_RUNS = [("exp_mace", "args/opt_args_train_mace.txt", 21, "dog", 2), ("raptor_exp_mace", "args/opt_args_train_raptor_mace.txt", 15, "raptor", 0),
+              ("exp_q", "args/opt_args_train_q.txt", 33, "q", 1)]
+
+
+@pytest.mark.parametrize("run", TUPLE_RUNS, ids=[r[0] for r in TUPLE_RUNS])
+def test_product_vs_frozen_reference_tuples(da, om, run, scenario=None):
+    """The experience tuples the compiled REFERENCE's cScenarioExpMACE (dog, raptor) and cScenarioExp + cDogControllerQ recorded (exploration off, commanded
+    first action: its exploration draws from a clock-seeded global RNG) vs the rows the PRODUCT emits from the same seed, policy and command: arrival frame,
+    flag word, reward, state, action, next state."""
+    tag, arg, seed, polname, cmd = run
+    g = np.load(os.path.join(os.path.dirname(REFDATA), "ref_golden_configs.npz"))
+    rows_ref, fl_ref, fr_ref = g[tag + "/tuples/rows"], g[tag + "/tuples/flags"], g[tag + "/tuples/frame"]
+    b = (scenario or Scenario)(arg, 1, data_root=REFDATA, extra_args=dict(terrain_seed=seed))
+    if polname == "q":
+        desc = om.parse_deploy_prototxt(os.path.join(REFDATA, "data/policies/dog/nets/dog_q_deploy.prototxt"))
+        b.SetPolicy(om.actor_xavier_weights(desc, 5), np.zeros(283), np.ones(283), -0.5 * np.ones(8), 2 * np.ones(8))
+    else:
+        pol = dog_policy(om) if polname == "dog" else raptor_policy(om)
+        b.SetPolicy(pol[1], *pol[2:])
+    b.SetExplore(False, 0.2, 0.025, 0.002)
+    b.CommandAction(cmd)
+    q_ref = g[tag + "/frame/q"]
+    got = 0; tracking = True
+    for f in range(len(q_ref)):
+        b.Update()
+        r, fl, _ = b.DrainTuples()
+        q, _ = b.PoseVel()
+        if np.abs(q[0] - q_ref[f]).max() > 1e-6 and not g[tag + "/frame/after_reset"][f]:
+            tracking = False
+        if not tracking:
+            break
+        idx = np.nonzero(fr_ref == f)[0]
+        assert len(r) == len(idx), (tag, f, len(r), len(idx))
+        for j, (k, row) in enumerate(zip(idx, r)):
+            assert fl[j] == fl_ref[k], (tag, f)
+            d = np.abs(row.astype(np.float64) - rows_ref[k].astype(np.float64)).max()
+            assert d < 5e-5 * max(1.0, np.abs(rows_ref[k]).max()), (tag, f, d)        # (terrain features: the reference library keeps Bullet's transforms in double)
+            got += 1
+    assert got >= 4 and got >= len(rows_ref) - 2, (tag, got, len(rows_ref), tracking)
 
 
 def test_perturbation_force_vs_oracle(da, om):
