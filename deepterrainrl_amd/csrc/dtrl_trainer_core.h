@@ -1,0 +1,251 @@
+// dtrl_trainer_core.h -- host-side sequencing of the native trainer step (which GEMMs and element-wise passes, in which order), shared by the HIP
+// backend (dtrl_trainer.hip, the product) and the plain-loop check build (tests/emul/dtrl_trainer_emul.cpp, TESTS ONLY). See dtrl_trainer_ops.h.
+//
+// What one call does and what it replaces in the reference (pool size 1, synchronous mode):
+//   Eval         cNeuralNet::EvalBatch (normalise, forward, un-normalise)                                     learning/NeuralNet.cpp:352-375, 964-1036
+//   Step         cNeuralNet::Train on one batch: LoadTrainData (normalise data and labels), Caffe SGD step     learning/NeuralNet.cpp:1077-1122
+//   CriticStep   cMACETrainer::BuildProblemX / BuildProblemY (CalcNewCumulativeRewardBatch) + the solver step  learning/MACETrainer.cpp:163-250, 478-515
+//   ActorFilter  cMACETrainer::UpdateActorBatchBuffer's test  new_q > Q_target(s)                              learning/MACETrainer.cpp:577-609
+//   ActorStep    cMACETrainer::BuildActorProblemY + StepActor                                                  learning/MACETrainer.cpp:285-305, 611-633
+#pragma once
+#include "dtrl_trainer_ops.h"
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace dtrl_tr {
+
+// ---- element-wise functors (index space = [0, n)) ----
+struct FGatherNorm { NetDims d; Norm nm; const float* mem; int W; const int64_t* idx; int col0; float* xin;
+	TR_HD void operator()(int64_t i) const { gather_norm_elem(d, nm, mem, W, idx, col0, xin, i); } };
+struct FNormIn { NetDims d; Norm nm; const float* X; float* xin;     // xin = (X + in_off) * in_scale for caller-supplied rows
+	TR_HD void operator()(int64_t i) const { const int j = static_cast<int>(i % d.S); xin[i] = (X[i] + nm.in_off[j]) * nm.in_scale[j]; } };
+struct FTerrReduce { NetDims d; Work wk; TR_HD void operator()(int64_t i) const { terr_reduce_elem(d, wk, static_cast<int>(i)); } };
+struct FConvGrad { NetDims d; Work wk; int l; TR_HD void operator()(int64_t i) const { conv_grad_elem(d, wk, l, static_cast<int>(i)); } };
+struct FSgd { float* w; float* hist; const float* g; const float* rate_mult; const float* decay_mult; float rate, momentum, weight_decay;
+	TR_HD void operator()(int64_t i) const { sgd_elem(w, hist, g, rate_mult, decay_mult, rate, momentum, weight_decay, i); } };
+struct FUnnorm { Norm nm; const float* out; float* Y; int out_size;
+	TR_HD void operator()(int64_t i) const { Y[i] = unnorm_out(nm, out[i], static_cast<int>(i % out_size)); } };
+// new_q[m] = r (1 - discount), + discount max_f Q_target(s')[f] unless the tuple ended in a fall (CalcNewCumulativeRewardBatch); tout = the target net's
+// normalised outputs of the s' rows
+struct FNewQ { Norm nm; const float* mem; int W; const int64_t* idx; const int64_t* flags; const float* tout; int out_size, n_frags; float discount; float* newq;
+	TR_HD void operator()(int64_t m) const
+	{
+		const size_t row = static_cast<size_t>(idx[m]);
+		const float r = mem[row * W] * (1.0f - discount);
+		float q = unnorm_out(nm, tout[m * out_size], 0);
+		for (int f = 1; f < n_frags; ++f) { const float v = unnorm_out(nm, tout[m * out_size + f], f); q = v > q ? v : q; }
+		newq[m] = (flags[row] & 1) ? r : r + discount * q;
+	} };
+// label (normalised) and the loss gradient of one output element. mode 0: caller's labels Y (un-normalised); 1: critic (y = the net's own output,
+// entry a[m] replaced by new_q); 2: actor (entries of fragment a[m] replaced by the tuple's action parameters)
+struct FLabelDout { NetDims d; Norm nm; int mode; const float* Yext; const float* mem; int W, S; const int64_t* idx; const float* newq; int n_frags, frag_size; int rows;
+	const float* out; float* dout; float* sq;
+	TR_HD void operator()(int64_t i) const
+	{
+		const int m = static_cast<int>(i / d.out_size), j = static_cast<int>(i % d.out_size);
+		float y;
+		if (mode == 0) y = Yext[i];
+		else {
+			y = unnorm_out(nm, out[i], j);
+			const size_t row = static_cast<size_t>(idx[m]);
+			const int a = static_cast<int>(mem[row * W + 1 + S]);
+			if (mode == 1) { if (j == a) y = newq[m]; }
+			else { const int c0 = n_frags + a * frag_size; if (j >= c0 && j < c0 + frag_size) y = mem[row * W + 2 + S + (j - c0)]; }
+		}
+		const float label = (y + nm.out_off[j]) * nm.out_scale[j];
+		const float e = out[i] - label;
+		dout[i] = e / static_cast<float>(rows);
+		sq[i] = e * e;
+	} };
+struct FLossSum { const float* sq; int n; int rows; float* loss;   // EuclideanLoss = 1 / (2 N) sum e^2 (one thread: 2 880 terms)
+	TR_HD void operator()(int64_t) const { float s = 0; for (int i = 0; i < n; ++i) s += sq[i]; *loss = 0.5f * s / static_cast<float>(rows); } };
+// better[m] = new_q(s') > max_f Q_target(s)[f]; tout rows [0, n) = s, rows [n, 2n) = s'
+struct FActorFilter { Norm nm; const float* tout; int out_size, n_frags, n; const float* newq; int32_t* better;
+	TR_HD void operator()(int64_t m) const
+	{
+		float q = unnorm_out(nm, tout[m * out_size], 0);
+		for (int f = 1; f < n_frags; ++f) { const float v = unnorm_out(nm, tout[m * out_size + f], f); q = v > q ? v : q; }
+		better[m] = newq[m] > q ? 1 : 0;
+	} };
+
+struct TrainerConfig {
+	NetDims dims;
+	int batch = 32, max_eval = 64;
+	int n_frags = 0, frag_size = 0;    // MACE head layout (n_frags == 0: single-head net, CriticStep / Actor* unavailable)
+	float base_lr = 0.001f, momentum = 0.9f, weight_decay = 0.0005f, discount = 0.9f;
+};
+
+// BE: alloc / free / h2d / d2h / d2d / host_alloc / host_free / gemm(d, wk, g) / template for_each(n, functor) / sync() / begin_graph(key) ... see the backends
+template <class BE>
+class TrainerCore {
+public:
+	explicit TrainerCore(const TrainerConfig& c) : cfg(c) {}
+	~TrainerCore()
+	{
+		for (void* p : dev_) be.free_dev(p);
+		for (void* p : host_) be.free_host(p);
+	}
+	bool Init(std::string& err)
+	{
+		if (!be.init(err)) return false;
+		const NetDims& d = cfg.dims;
+		const size_t P = static_cast<size_t>(d.num_params);
+		w_cur = F(P); w_tgt = F(P); hist = F(P); grad = F(P); rate_mult = F(P); decay_mult = F(P);
+		in_off = F(d.S); in_scale = F(d.S); out_off = F(d.out_size); out_scale = F(d.out_size);
+		MakeWork(train, cfg.batch, true);
+		MakeWork(eval, cfg.max_eval, false);
+		newq = F(cfg.max_eval); sq = F(static_cast<size_t>(cfg.batch) * d.out_size);
+		// page-locked, device-visible: the host writes indices / reads the mask and the loss without a copy being queued
+		idx_host = static_cast<int64_t*>(HostAlloc(sizeof(int64_t) * 2 * cfg.max_eval));
+		better_host = static_cast<int32_t*>(HostAlloc(sizeof(int32_t) * cfg.max_eval));
+		loss_host = static_cast<float*>(HostAlloc(sizeof(float) * 4));
+		if (!be.ok()) { err = be.error(); return false; }
+		std::vector<float> ones(d.S > d.out_size ? d.S : d.out_size, 1.0f);
+		be.h2d(in_scale, ones.data(), sizeof(float) * d.S); be.h2d(out_scale, ones.data(), sizeof(float) * d.out_size);
+		std::vector<float> onesP(P, 1.0f);
+		be.h2d(rate_mult, onesP.data(), sizeof(float) * P); be.h2d(decay_mult, onesP.data(), sizeof(float) * P);
+		be.sync();
+		if (!be.ok()) { err = be.error(); return false; }
+		return true;
+	}
+	Norm norm() const { return Norm{in_off, in_scale, out_off, out_scale}; }
+
+	// ---- passes ----
+	void Forward(Work& wk, const float* weights, int rows)
+	{
+		const NetDims& d = cfg.dims;
+		wk.w = weights; wk.rows = rows;
+		for (int l = 0; l < 3; ++l) be.gemm(d, wk, make_gemm(d, rows, kConvFwd, l));
+		be.gemm(d, wk, make_gemm(d, rows, kTerrFwd));
+		be.for_each(static_cast<int64_t>(rows) * d.fc_terr, FTerrReduce{d, wk});
+		be.gemm(d, wk, make_gemm(d, rows, kIp0Fwd));
+		be.gemm(d, wk, make_gemm(d, rows, kHead0Fwd));
+		be.gemm(d, wk, make_gemm(d, rows, kHead1Fwd));
+	}
+	// gradient of the current net on the rows of `train` (dout filled), then the Caffe SGD update
+	void BackwardAndUpdate()
+	{
+		const NetDims& d = cfg.dims;
+		Work& wk = train;
+		const int rows = wk.rows;
+		wk.w = w_cur; wk.g = grad;
+		be.gemm(d, wk, make_gemm(d, rows, kHead1Bw)); be.gemm(d, wk, make_gemm(d, rows, kHead1Bx));
+		be.gemm(d, wk, make_gemm(d, rows, kHead0Bw)); be.gemm(d, wk, make_gemm(d, rows, kHead0Bx));
+		be.gemm(d, wk, make_gemm(d, rows, kIp0Bw)); be.gemm(d, wk, make_gemm(d, rows, kIp0Bx));
+		be.gemm(d, wk, make_gemm(d, rows, kTerrBw)); be.gemm(d, wk, make_gemm(d, rows, kTerrBx));
+		for (int l = 2; l >= 0; --l) {
+			GemmDesc g = make_gemm(d, rows, kConvBw, l); g.b_kfast = 1;
+			be.gemm(d, wk, g);
+			if (l > 0) be.gemm(d, wk, make_gemm(d, rows, kConvBx, l));
+		}
+		for (int l = 0; l < 3; ++l) be.for_each(static_cast<int64_t>(d.C[l + 1]) * (d.C[l] * d.Kw[l] + 1), FConvGrad{d, wk, l});
+		be.for_each(d.num_params, FSgd{w_cur, hist, grad, rate_mult, decay_mult, cfg.base_lr, cfg.momentum, cfg.weight_decay});
+	}
+
+	// ---- API ----
+	// Y[n][out] = un-normalised outputs of net `which` (0 current, 1 target) on X[n][S] (device pointers)
+	bool Eval(int which, const float* X, int n, float* Y)
+	{
+		if (n <= 0 || n > cfg.max_eval) return false;
+		const NetDims& d = cfg.dims;
+		be.for_each(static_cast<int64_t>(n) * d.S, FNormIn{d, norm(), X, eval.xin});
+		Forward(eval, which ? w_tgt : w_cur, n);
+		be.for_each(static_cast<int64_t>(n) * d.out_size, FUnnorm{norm(), eval.out, Y, d.out_size});
+		return be.ok();
+	}
+	// one solver iteration on caller-supplied (X, Y) of exactly `batch` rows; the loss lands in loss_host[0] (valid after Sync)
+	bool Step(const float* X, const float* Y)
+	{
+		const NetDims& d = cfg.dims;
+		const int n = cfg.batch;
+		be.for_each(static_cast<int64_t>(n) * d.S, FNormIn{d, norm(), X, train.xin});
+		Forward(train, w_cur, n);
+		be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d, norm(), 0, Y, nullptr, 0, d.S, nullptr, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
+		be.for_each(1, FLossSum{sq, n * d.out_size, n, loss_host});
+		BackwardAndUpdate();
+		return be.ok();
+	}
+	// replay memory binding: rows [mem_size][W] float32 in the MACE layout [r | s | a | s'], flag words int64 (device pointers, fixed for the trainer's life)
+	void BindReplay(const float* mem, const int64_t* flags, int W) { mem_ = mem; flags_ = flags; W_ = W; }
+
+	// idx_host[0 .. batch) = the critic minibatch's slots. loss -> loss_host[0]
+	bool CriticStep()
+	{
+		if (!mem_ || cfg.n_frags <= 0) return false;
+		const NetDims& d = cfg.dims;
+		const int n = cfg.batch, S = d.S, A = 1 + cfg.frag_size;
+		// Q_target(s') first (its activations live in `eval`), then the current net on s: the forward of the solver step IS the evaluation BuildProblemY needs
+		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{d, norm(), mem_, W_, idx_host, 1 + S + A, eval.xin});
+		Forward(eval, cfg_target_frozen ? w_tgt : w_cur, n);
+		be.for_each(n, FNewQ{norm(), mem_, W_, idx_host, flags_, eval.out, d.out_size, cfg.n_frags, cfg.discount, newq});
+		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{d, norm(), mem_, W_, idx_host, 1, train.xin});
+		Forward(train, w_cur, n);
+		be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
+		be.for_each(1, FLossSum{sq, n * d.out_size, n, loss_host});
+		BackwardAndUpdate();
+		return be.ok();
+	}
+	// idx_host[batch .. batch + n) = candidate slots (a window of their own: the critic step queued before may not have read its indices yet);
+	// better_host[0 .. n) = 1 where new_q > Q_target(s) (valid after Sync)
+	bool ActorFilter(int n)
+	{
+		if (!mem_ || cfg.n_frags <= 0 || n <= 0 || 2 * n > cfg.max_eval || n > cfg.batch) return false;
+		const NetDims& d = cfg.dims;
+		const int S = d.S, A = 1 + cfg.frag_size;
+		const float* wt = cfg_target_frozen ? w_tgt : w_cur;
+		const int64_t* idx = idx_host + cfg.batch;
+		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{d, norm(), mem_, W_, idx, 1, eval.xin});
+		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{d, norm(), mem_, W_, idx, 1 + S + A, eval.xin + static_cast<size_t>(n) * S});
+		Forward(eval, wt, 2 * n);
+		be.for_each(n, FNewQ{norm(), mem_, W_, idx, flags_, eval.out + static_cast<size_t>(n) * d.out_size, d.out_size, cfg.n_frags, cfg.discount, newq});
+		be.for_each(n, FActorFilter{norm(), eval.out, d.out_size, cfg.n_frags, n, newq, better_host});
+		return be.ok();
+	}
+	// idx_host[max_eval .. max_eval + batch) = the actor batch's slots (a second window, so that a filter's candidates stay intact). loss -> loss_host[1]
+	bool ActorStep()
+	{
+		if (!mem_ || cfg.n_frags <= 0) return false;
+		const NetDims& d = cfg.dims;
+		const int n = cfg.batch, S = d.S;
+		const int64_t* idx = idx_host + cfg.max_eval;
+		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{d, norm(), mem_, W_, idx, 1, train.xin});
+		Forward(train, w_cur, n);
+		be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d, norm(), 2, nullptr, mem_, W_, S, idx, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
+		be.for_each(1, FLossSum{sq, n * d.out_size, n, loss_host + 1});
+		BackwardAndUpdate();
+		return be.ok();
+	}
+	void UpdateTarget() { be.d2d(w_tgt, w_cur, sizeof(float) * cfg.dims.num_params); }
+
+	TrainerConfig cfg;
+	bool cfg_target_frozen = false;   // cMACETrainer::EnableTargetNet(): freeze_target_iters > 0, else the "target" is the current net
+	BE be;
+	float *w_cur = nullptr, *w_tgt = nullptr, *hist = nullptr, *grad = nullptr, *rate_mult = nullptr, *decay_mult = nullptr;
+	float *in_off = nullptr, *in_scale = nullptr, *out_off = nullptr, *out_scale = nullptr, *newq = nullptr, *sq = nullptr;
+	Work train{}, eval{};
+	int64_t* idx_host = nullptr; int32_t* better_host = nullptr; float* loss_host = nullptr;
+
+private:
+	float* F(size_t n) { void* p = be.alloc_dev(sizeof(float) * (n ? n : 1)); if (p) dev_.push_back(p); return static_cast<float*>(p); }
+	void* HostAlloc(size_t bytes) { void* p = be.alloc_host(bytes); if (p) { std::memset(p, 0, bytes); host_.push_back(p); } return p; }
+	void MakeWork(Work& wk, int rows, bool with_grad)
+	{
+		const NetDims& d = cfg.dims;
+		std::memset(&wk, 0, sizeof(wk));
+		wk.max_rows = rows; wk.rows = rows;
+		wk.xin = F(static_cast<size_t>(rows) * d.S);
+		for (int l = 0; l < 3; ++l) wk.act[l] = F(static_cast<size_t>(rows) * d.C[l + 1] * d.T[l + 1]);
+		wk.tp = F(static_cast<size_t>(d.n_slabs) * rows * d.fc_terr);
+		wk.t3 = F(static_cast<size_t>(rows) * d.fc_terr); wk.h = F(static_cast<size_t>(rows) * d.fc_trunk);
+		wk.hz = F(static_cast<size_t>(d.n_heads) * rows * d.fc_head); wk.out = F(static_cast<size_t>(rows) * d.out_size);
+		if (!with_grad) return;
+		wk.dout = F(static_cast<size_t>(rows) * d.out_size); wk.dhz = F(static_cast<size_t>(d.n_heads) * rows * d.fc_head);
+		wk.dh = F(static_cast<size_t>(rows) * d.fc_trunk); wk.dt3 = F(static_cast<size_t>(rows) * d.fc_terr);
+		for (int l = 0; l < 3; ++l) { wk.dy[l] = F(static_cast<size_t>(rows) * d.C[l + 1] * d.T[l + 1]); wk.pw[l] = F(static_cast<size_t>(rows) * d.C[l + 1] * (d.C[l] * d.Kw[l] + 1)); }
+	}
+	const float* mem_ = nullptr; const int64_t* flags_ = nullptr; int W_ = 0;
+	std::vector<void*> dev_, host_;
+};
+
+}  // namespace dtrl_tr

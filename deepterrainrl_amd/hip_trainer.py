@@ -1,0 +1,276 @@
+"""MI355X-native MACE trainer step: cMACETrainer's iteration on hand-written HIP kernels (include/dtrl_trainer.h, csrc/dtrl_trainer.hip).
+
+`HipMACETrainer` keeps cMACETrainer's host-side bookkeeping exactly as `trainer.MACETrainer` has it (replay slots, critic / actor index buffers with
+the reference's move-last-into-hole removal, minibatch draws, stages, target refresh schedule) and replaces everything that touched the network:
+
+  Step()       critic: slots -> page-locked index array -> dtrl_trainer_critic_step: gather + normalise s and s' from the replay rows, Q_target(s'),
+               forward of the current net, labels (new_q over the taken fragment's value), EuclideanLoss gradient, backward, Caffe SGD update
+  UpdateActor  dtrl_trainer_actor_filter (new_q > Q_target(s) for the candidates, mask read from page-locked memory) and dtrl_trainer_actor_step
+  Eval / _solver_step   dtrl_trainer_eval / dtrl_trainer_step for callers that bring their own batches
+
+One iteration is ~65 kernel launches on one stream and ONE host wait (the actor mask); weights, history, activations and the replay rows stay on the
+device, no framework op runs inside an iteration. `trainer.MACETrainer` (PyTorch ops replayed as HIP graphs) stays as the peer the tests compare
+against, `oracle/trainer_ref.py` as the oracle. The product path is lib/libdtrl.so; there is no CPU fallback (tests bind the plain-loop check build
+of the same operand definitions from tests/emul through `lib_path`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import LIB_PATH, DtrlError
+from .trainer import MACETrainer
+
+TRAINER_ABI_SYMBOLS = [
+    "dtrl_trainer_create", "dtrl_trainer_destroy", "dtrl_trainer_last_error", "dtrl_trainer_set_stream", "dtrl_trainer_sync", "dtrl_trainer_num_params",
+    "dtrl_trainer_set_params", "dtrl_trainer_get_params", "dtrl_trainer_params_device", "dtrl_trainer_set_normalizers", "dtrl_trainer_update_target",
+    "dtrl_trainer_eval", "dtrl_trainer_step", "dtrl_trainer_bind_replay", "dtrl_trainer_idx", "dtrl_trainer_better", "dtrl_trainer_loss",
+    "dtrl_trainer_critic_step", "dtrl_trainer_actor_filter", "dtrl_trainer_actor_step",
+]
+
+
+class TrainerDesc(C.Structure):
+    _fields_ = [("state_size", C.c_int32), ("n_terrain", C.c_int32), ("conv_ch", C.c_int32 * 3), ("conv_k", C.c_int32 * 3),
+                ("fc_terr", C.c_int32), ("fc_trunk", C.c_int32), ("fc_head", C.c_int32), ("n_heads", C.c_int32), ("head_out", C.c_int32 * 8),
+                ("n_frags", C.c_int32), ("frag_size", C.c_int32), ("batch", C.c_int32), ("max_eval", C.c_int32),
+                ("base_lr", C.c_float), ("momentum", C.c_float), ("weight_decay", C.c_float), ("discount", C.c_float), ("freeze_target", C.c_int32)]
+
+
+def _bind(path):
+    if not os.path.exists(path):
+        raise DtrlError("HIP extension missing: %s (run __graft_entry__.build() / make -C deepterrainrl_amd/csrc)" % path)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.dtrl_trainer_create.argtypes = [C.POINTER(TrainerDesc), C.c_int, C.POINTER(vp)]
+    L.dtrl_trainer_destroy.argtypes = [vp]
+    L.dtrl_trainer_last_error.restype = C.c_char_p; L.dtrl_trainer_last_error.argtypes = [vp]
+    L.dtrl_trainer_set_stream.argtypes = [vp, vp]
+    L.dtrl_trainer_sync.argtypes = [vp]
+    L.dtrl_trainer_num_params.restype = C.c_int64; L.dtrl_trainer_num_params.argtypes = [vp]
+    L.dtrl_trainer_set_params.argtypes = [vp, C.c_int, vp, C.c_int64]
+    L.dtrl_trainer_get_params.argtypes = [vp, C.c_int, vp, C.c_int64]
+    L.dtrl_trainer_params_device.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.dtrl_trainer_set_normalizers.argtypes = [vp, vp, vp, vp, vp]
+    L.dtrl_trainer_update_target.argtypes = [vp]
+    L.dtrl_trainer_eval.argtypes = [vp, C.c_int, vp, C.c_int, vp]
+    L.dtrl_trainer_step.argtypes = [vp, vp, vp]
+    L.dtrl_trainer_bind_replay.argtypes = [vp, vp, vp, C.c_int]
+    for name, ty in (("dtrl_trainer_idx", C.c_int64), ("dtrl_trainer_better", C.c_int32), ("dtrl_trainer_loss", C.c_float)):
+        getattr(L, name).restype = C.POINTER(ty); getattr(L, name).argtypes = [vp]
+    L.dtrl_trainer_critic_step.argtypes = [vp]
+    L.dtrl_trainer_actor_filter.argtypes = [vp, C.c_int]
+    L.dtrl_trainer_actor_step.argtypes = [vp]
+    return L
+
+
+def desc_from_net(desc, state_size, batch, max_eval, solver, discount, freeze_target):
+    """dtrl_trainer_desc from trainer.parse_net / parse_solver output."""
+    d = TrainerDesc()
+    d.state_size, d.n_terrain = state_size, desc["n_terrain"]
+    for l, cv in enumerate(desc["convs"]):
+        d.conv_ch[l], d.conv_k[l] = cv["num_output"], cv["kernel_w"]
+    ips = desc["ips"]
+    d.fc_terr = ips["terr_ip0"]["num_output"]
+    if desc["n_frags"] > 0:
+        d.fc_trunk, d.fc_head = ips["ip0"]["num_output"], ips["val_ip0"]["num_output"]
+        d.n_heads = 1 + desc["n_frags"]
+        d.head_out[0] = desc["n_frags"]
+        for f in range(desc["n_frags"]):
+            d.head_out[1 + f] = desc["frag_size"]
+    else:
+        d.fc_trunk, d.fc_head, d.n_heads = ips["ip1"]["num_output"], ips["ip2"]["num_output"], 1
+        d.head_out[0] = desc["frag_size"]
+    d.n_frags, d.frag_size = desc["n_frags"], desc["frag_size"]
+    d.batch, d.max_eval = batch, max_eval
+    d.base_lr, d.momentum, d.weight_decay, d.discount = solver["base_lr"], solver["momentum"], solver["weight_decay"], discount
+    d.freeze_target = 1 if freeze_target else 0
+    return d
+
+
+class NativeTrainer:
+    """Thin handle over the C ABI (one dtrl_trainer)."""
+
+    def __init__(self, cdesc, device_id=-1, lib_path=None):
+        self._lib = _bind(lib_path or LIB_PATH)
+        h = C.c_void_p()
+        rc = self._lib.dtrl_trainer_create(C.byref(cdesc), int(device_id), C.byref(h))
+        if rc != 0:
+            raise DtrlError("dtrl_trainer_create failed (%d): %s" % (rc, self._lib.dtrl_trainer_last_error(None).decode()))
+        self._h = h
+        self.num_params = int(self._lib.dtrl_trainer_num_params(h))
+        self.batch, self.max_eval = int(cdesc.batch), int(cdesc.max_eval)
+        self.idx = np.ctypeslib.as_array(self._lib.dtrl_trainer_idx(h), shape=(2 * self.max_eval,))
+        self.better = np.ctypeslib.as_array(self._lib.dtrl_trainer_better(h), shape=(self.max_eval,))
+        self.loss = np.ctypeslib.as_array(self._lib.dtrl_trainer_loss(h), shape=(4,))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dtrl_trainer_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DtrlError("dtrl_trainer call failed (%d): %s" % (rc, self._lib.dtrl_trainer_last_error(self._h).decode()))
+
+    def set_stream(self, ptr): self._chk(self._lib.dtrl_trainer_set_stream(self._h, C.c_void_p(ptr)))
+    def sync(self): self._chk(self._lib.dtrl_trainer_sync(self._h))
+
+    def set_params(self, which, a):
+        a = np.ascontiguousarray(a, np.float32); self._chk(self._lib.dtrl_trainer_set_params(self._h, which, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def get_params(self, which):
+        a = np.zeros(self.num_params, np.float32); self._chk(self._lib.dtrl_trainer_get_params(self._h, which, a.ctypes.data_as(C.c_void_p), a.size)); return a
+
+    def params_device(self, which=0):
+        p = C.c_void_p(); self._chk(self._lib.dtrl_trainer_params_device(self._h, which, C.byref(p))); return p.value
+
+    def set_normalizers(self, io=None, isc=None, oo=None, osc=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, np.float64) for a in (io, isc, oo, osc)]
+        self._chk(self._lib.dtrl_trainer_set_normalizers(self._h, *[None if a is None else a.ctypes.data_as(C.c_void_p) for a in arrs]))
+
+    def update_target(self): self._chk(self._lib.dtrl_trainer_update_target(self._h))
+    def eval(self, which, x_ptr, n, y_ptr): self._chk(self._lib.dtrl_trainer_eval(self._h, which, C.c_void_p(x_ptr), n, C.c_void_p(y_ptr)))
+    def step(self, x_ptr, y_ptr): self._chk(self._lib.dtrl_trainer_step(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
+    def bind_replay(self, mem_ptr, flags_ptr, W): self._chk(self._lib.dtrl_trainer_bind_replay(self._h, C.c_void_p(mem_ptr), C.c_void_p(flags_ptr), W))
+    def critic_step(self): self._chk(self._lib.dtrl_trainer_critic_step(self._h))
+    def actor_filter(self, n): self._chk(self._lib.dtrl_trainer_actor_filter(self._h, n))
+    def actor_step(self): self._chk(self._lib.dtrl_trainer_actor_step(self._h))
+
+
+class HipMACETrainer(MACETrainer):
+    """cMACETrainer with the network side on the native HIP step (see the module docstring). Same constructor as trainer.MACETrainer; float32 only
+    (the reference's Caffe nets are float32)."""
+
+    def __init__(self, *a, lib_path=None, **kw):
+        kw.setdefault("use_graphs", False)      # the torch peer's graph machinery is not used: nothing framework-side runs inside an iteration
+        kw["dtype"] = torch.float32
+        super().__init__(*a, **kw)
+        if self.solver["lr_policy"] != "fixed":
+            raise DtrlError("the native trainer step implements lr_policy \"fixed\" (what the shipped solver prototxts use)")
+        cdesc = desc_from_net(self.desc, self.S, self.batch, 2 * self.batch, self.solver, self.discount, self.freeze_target_iters > 0)
+        dev_id = self.device.index if self.device.type == "cuda" and self.device.index is not None else -1
+        self.nt = NativeTrainer(cdesc, dev_id, lib_path)
+        assert self.nt.num_params == self.net.num_params()
+        if self.device.type == "cuda":
+            self.nt.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.nt.set_params(0, self.net.get_flat())
+        self.nt.set_params(3, self.rate_mult.detach().cpu().numpy()); self.nt.set_params(4, self.decay_mult.detach().cpu().numpy())
+        self.nt.update_target()
+        self.nt.bind_replay(self.mem.data_ptr(), self.flags_dev.data_ptr(), self.W)
+        self._push_norm()
+
+    # ---- state that lives in the native trainer ----
+    def _push_norm(self):
+        f = lambda t: t.detach().to(torch.float64).cpu().numpy()
+        self.nt.set_normalizers(f(self.in_off), f(self.in_scale), f(self.out_off), f(self.out_scale))
+
+    def SetInputOffsetScale(self, off, scale):
+        super().SetInputOffsetScale(off, scale); self._push_norm()
+
+    def SetOutputOffsetScale(self, off, scale):
+        super().SetOutputOffsetScale(off, scale); self._push_norm()
+
+    def GetWeights(self):
+        return self.nt.get_params(0)
+
+    def SetWeights(self, w):
+        self.nt.set_params(0, np.asarray(w, np.float32)); self.nt.update_target()
+
+    def WeightsDevicePtr(self):
+        """device pointer of the current net's flat weights (Caffe blob order): dtrl_set_policy_device takes it as it is"""
+        return self.nt.params_device(0)
+
+    def UpdateTargetNet(self):
+        if hasattr(self, "nt"):
+            self.nt.update_target()
+        else:
+            super().UpdateTargetNet()          # (called once by the base constructor before the native trainer exists)
+
+    def OutputModel(self, model_file):
+        self.net.set_flat(self.GetWeights())    # the torch net is only a container here
+        super().OutputModel(model_file)
+
+    # ---- network calls ----
+    def _eval(self, net, X):
+        n = X.shape[0]
+        which = 0 if (net is self.net or not self.EnableTargetNet()) else 1
+        X = X.to(torch.float32).contiguous()
+        out = []
+        for k in range(0, n, self.nt.max_eval):
+            xs = X[k:k + self.nt.max_eval]
+            y = torch.empty((xs.shape[0], self.out_size), dtype=torch.float32, device=self.device)
+            self.nt.eval(which, xs.data_ptr(), xs.shape[0], y.data_ptr())
+            if self.device.type == "cuda":
+                pass                           # same stream as torch's: ordered
+            out.append(y)
+        self._keep = (X, out)                  # the kernels read X after this returns
+        return out[0] if len(out) == 1 else torch.cat(out)
+
+    def _solver_step(self, X, Y):
+        X = X.to(torch.float32).contiguous(); Y = Y.to(torch.float32).contiguous()
+        self.nt.step(X.data_ptr(), Y.data_ptr())
+        self._keep = (X, Y)
+        self.solver_iter += 1
+        self.nt.sync()
+        return torch.tensor(float(self.nt.loss[0]))
+
+    # ---- cMACETrainer::Step on the fused native calls ----
+    def Step(self):
+        ids = self.FetchMinibatch(self.batch)
+        succ = len(ids) >= self.batch
+        if succ:
+            if getattr(self, "_loss_pending", False):   # a critic step may still be queued (no actor filter waited since): it must have read its indices
+                self.nt.sync(); self._last_loss = float(self.nt.loss[0]); self._loss_pending = False
+            self.nt.idx[:self.batch] = ids
+            self.nt.critic_step()
+            self.solver_iter += 1
+            self._loss_pending = True
+        self.UpdateActor()
+        if self.EnableTargetNet() and self.iter > 0 and self.iter % self.freeze_target_iters == 0:
+            self.nt.update_target()
+        return succ
+
+    @property
+    def last_loss(self):
+        if getattr(self, "_loss_pending", False):
+            self.nt.sync(); self._last_loss = float(self.nt.loss[0]); self._loss_pending = False
+        return None if self._last_loss is None else float(self._last_loss)
+
+    @property
+    def last_actor_loss(self):
+        if getattr(self, "_aloss_pending", False):
+            self.nt.sync(); self._last_actor_loss = float(self.nt.loss[1]); self._aloss_pending = False
+        return None if self._last_actor_loss is None else float(self._last_actor_loss)
+
+    def UpdateActorBatchBuffer(self):
+        ids = self.FetchActorMinibatch(self.batch)
+        if not ids:
+            return
+        n = len(ids)
+        self.nt.idx[self.batch:self.batch + n] = ids   # (the previous filter was waited for, so its window is free)
+        self.nt.actor_filter(n)
+        self.nt.sync()                          # the one host wait of an iteration: the mask decides what enters the actor batch buffer
+        if getattr(self, "_loss_pending", False):
+            self._last_loss = float(self.nt.loss[0]); self._loss_pending = False
+        better = self.nt.better[:n].copy()
+        self.actor_batch_buffer += [t for t, b in zip(ids, better) if b]
+
+    def UpdateActor(self):
+        if self.stage_train:
+            self.UpdateActorBatchBuffer()
+        for _ in range(len(self.actor_batch_buffer) // self.batch):
+            ids = self.actor_batch_buffer[:self.batch]
+            if getattr(self, "_aloss_pending", False):
+                self.nt.sync(); self._last_actor_loss = float(self.nt.loss[1]); self._aloss_pending = False
+            self.nt.idx[self.nt.max_eval:self.nt.max_eval + self.batch] = ids
+            self.nt.actor_step()
+            self._aloss_pending = True
+            self.solver_iter += 1
+            self.actor_iter += 1
+            del self.actor_batch_buffer[:self.batch]

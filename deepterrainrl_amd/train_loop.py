@@ -32,7 +32,7 @@ def parse_arg_file(path):
     return out
 
 
-def _make_trainer(args, data_root, train_net, solver, b, tkw):
+def _make_trainer(args, data_root, train_net, solver, b, tkw, trainer="torch", trainer_lib=None):
     """cScenarioTrain::BuildTrainer and its subclasses: *_mace controllers train with cMACETrainer, -char_ctrl= dog / raptor (the Q controllers,
     scenarios/ScenarioSimChar.cpp:421-430) with cQNetTrainer, *_cacla with cCaclaTrainer (scenarios/ScenarioTrainCacla.cpp:21-52: -policy_* name the
     ACTOR, -critic_* the critic the trainer steps first)."""
@@ -42,11 +42,16 @@ def _make_trainer(args, data_root, train_net, solver, b, tkw):
         m = re.search(r'net:\s*"([^"]+)"', open(c_solver).read())
         c_train = os.path.join(data_root, m.group(1)) if m else os.path.join(data_root, args["critic_net"].replace("_deploy", "_train"))
         return CaclaTrainer(c_train, c_solver, train_net, solver, b.S, b.A, **tkw)
-    return (QNetTrainer if ctrl in ("dog", "raptor") else MACETrainer)(train_net, solver, b.S, b.A, **tkw)
+    if ctrl in ("dog", "raptor"):
+        return QNetTrainer(train_net, solver, b.S, b.A, **tkw)
+    if trainer == "hip":   # the MI355X-native step (hip_trainer.py): cMACETrainer's iteration on hand-written HIP kernels
+        from .hip_trainer import HipMACETrainer
+        return HipMACETrainer(train_net, solver, b.S, b.A, lib_path=trainer_lib, **tkw)
+    return MACETrainer(train_net, solver, b.S, b.A, **tkw)
 
 
 def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, device_id=-1, extra_args=None, seed=0, log_every=0, out_scale_file=None,
-          trainer_device=None, overlap=False, frames_per_drain=1, scenario_cls=BatchScenario):
+          trainer_device=None, overlap=False, frames_per_drain=1, scenario_cls=BatchScenario, trainer="torch", trainer_lib=None):
     """extra_args override / extend the arg file (both for the engine and for the -trainer_* keys read here).
     overlap=True trains on frame f's tuples while the GPU already rolls out frame f+1 (dtrl_step_begin / dtrl_step_end): the policy
     each frame runs with is one frame staler, as with the reference's concurrent env threads; overlap=False is the strictly
@@ -62,7 +67,7 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     tkw = dict(mem_size=geti("trainer_replay_mem_size", 500000), num_init_samples=geti("trainer_num_init_samples", 200),
                steps_per_iter=geti("trainer_num_steps_per_iters", 1), freeze_target_iters=geti("trainer_freeze_target_iters", 0),
                init_input_offset_scale=args.get("trainer_init_input_offset_scale", "false").lower() == "true", seed=seed, device=trainer_device)
-    t = _make_trainer(args, data_root, train_net, solver, b, tkw)
+    t = _make_trainer(args, data_root, train_net, solver, b, tkw, trainer, trainer_lib)
     t.SetOutputOffsetScale(*b.BuildNNOutputOffsetScale())
     exp = dict(rate=getf("exp_rate", 0.2), temp=getf("exp_temp", 0.025), base=getf("exp_base_rate", 0.002))
     init = dict(rate=getf("init_exp_rate", 1.0), temp=getf("init_exp_temp", 20.0), base=getf("init_exp_base_rate", 1.0))

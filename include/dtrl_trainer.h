@@ -1,0 +1,82 @@
+/* dtrl_trainer.h -- C ABI of the MI355X-native MACE trainer step (libdtrl.so): batch-32 forward / backward / Caffe-SGD update of the *_mace3 (and single-head)
+ * nets as hand-written HIP GEMM kernels with weights, solver history, activations and the replay rows resident on the device.
+ *
+ * The reference has no FFI here either; the seam is cNeuralNetTrainer / cMACETrainer's use of cNeuralNet (learning/NeuralNetTrainer.cpp:696-784,
+ * learning/MACETrainer.cpp:163-250, 346-372, 577-633; learning/NeuralNet.cpp:352-375, 1077-1122), which wraps Caffe's Forward and SGDSolver::Step.
+ * Every entry point below names the reference call it replaces. Plain pointers and sizes; "dev" pointers are device memory of the trainer's GPU
+ * (e.g. a framework tensor's data pointer), everything else is host memory. All calls are queued on the stream given to dtrl_trainer_set_stream
+ * (default: the legacy default stream) and return without waiting unless stated; dtrl_trainer_sync waits. Status codes as in dtrl.h (0 = ok). */
+#ifndef DTRL_TRAINER_H
+#define DTRL_TRAINER_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dtrl_trainer dtrl_trainer;
+
+/* Topology (the deploy / train prototxt of the family: slice -> 3 x Convolution + ReLU -> terr_ip0 + ReLU -> concat with the character slice -> trunk
+ * InnerProduct + ReLU -> n_heads x [InnerProduct + ReLU -> InnerProduct]) and the solver's hyper-parameters (base_lr, momentum, weight_decay of the solver
+ * prototxt; lr_policy "fixed"). MACE nets: head 0 = the critic (n_frags values), heads 1 .. n_frags = the actors (frag_size each); outputs are laid
+ * out head after head. Single-head nets (Q net, CACLA actor): n_heads = 1, n_frags = 0. Weight vector = Caffe blob order, weight then bias per layer. */
+typedef struct dtrl_trainer_desc {
+	int32_t state_size, n_terrain;
+	int32_t conv_ch[3], conv_k[3];
+	int32_t fc_terr, fc_trunk, fc_head;
+	int32_t n_heads, head_out[8];
+	int32_t n_frags, frag_size;
+	int32_t batch, max_eval;          /* solver batch (MemoryData batch_size, 32) and the largest evaluation batch (>= 2 x batch for dtrl_trainer_actor_filter) */
+	float base_lr, momentum, weight_decay, discount;
+	int32_t freeze_target;            /* cMACETrainer::EnableTargetNet(): != 0 -> critic targets come from the frozen copy (dtrl_trainer_update_target), else from the current net */
+} dtrl_trainer_desc;
+
+/* Replaces: cNeuralNet::LoadNet + LoadSolver (learning/NeuralNet.cpp:53-108): builds the net and the solver state on device `device_id` (-1: current). */
+int dtrl_trainer_create(const dtrl_trainer_desc* desc, int device_id, dtrl_trainer** out);
+void dtrl_trainer_destroy(dtrl_trainer* t);
+const char* dtrl_trainer_last_error(const dtrl_trainer* t);
+/* every later call is queued on this HIP stream (hipStream_t as a pointer; NULL = the legacy default stream), so it is ordered with the caller's own work */
+int dtrl_trainer_set_stream(dtrl_trainer* t, void* hip_stream);
+int dtrl_trainer_sync(dtrl_trainer* t);
+
+int64_t dtrl_trainer_num_params(const dtrl_trainer* t);
+/* Replaces: cNeuralNet::CopyModel / LoadModel / GetParams (learning/NeuralNet.cpp:636-658): which = 0 current net, 1 target net, 2 solver history,
+ * 3 lr_mult per element, 4 decay_mult per element (the per-blob multipliers of the train prototxt, expanded). Host arrays of num_params floats; synchronous. */
+int dtrl_trainer_set_params(dtrl_trainer* t, int which, const float* host, int64_t n);
+int dtrl_trainer_get_params(dtrl_trainer* t, int which, float* host, int64_t n);
+/* device pointer of the flat weight vector (which = 0 / 1): hand it to dtrl_set_policy_device without a host round trip (cNeuralNetLearner::SyncNet) */
+int dtrl_trainer_params_device(dtrl_trainer* t, int which, float** dev_ptr);
+/* Replaces: cNeuralNet::SetInputOffsetScale / SetOutputOffsetScale (learning/NeuralNet.cpp:217-260). Host doubles, state_size / out_size entries; NULL keeps. */
+int dtrl_trainer_set_normalizers(dtrl_trainer* t, const double* in_off, const double* in_scale, const double* out_off, const double* out_scale);
+/* Replaces: cMACETrainer::UpdateTargetNet (learning/MACETrainer.cpp:515-573): target <- current. */
+int dtrl_trainer_update_target(dtrl_trainer* t);
+
+/* Replaces: cNeuralNet::EvalBatch (learning/NeuralNet.cpp:377-410): Y_dev[n][out] = un-normalised outputs of net `which` on X_dev[n][state_size], n <= max_eval. */
+int dtrl_trainer_eval(dtrl_trainer* t, int which, const float* X_dev, int n, float* Y_dev);
+/* Replaces: cNeuralNet::Train (learning/NeuralNet.cpp:1077-1122) on one batch: data and labels normalised, EuclideanLoss, one Caffe SGD iteration
+ * (L2 regularisation with weight_decay x decay_mult, history = momentum x history + base_lr x lr_mult x diff, w -= history). X_dev[batch][state_size],
+ * Y_dev[batch][out] un-normalised labels. The loss lands in dtrl_trainer_loss()[0]. */
+int dtrl_trainer_step(dtrl_trainer* t, const float* X_dev, const float* Y_dev);
+
+/* The replay memory the MACE calls below read: rows [mem_size][W] float32 in the MACE layout [r | s | a = (fragment id, params) | s'] exactly as
+ * dtrl_drain_tuples emits them, and one int64 flag word per row (bit 0 = fail). Device pointers that stay valid for the trainer's life (mPlaybackMem). */
+int dtrl_trainer_bind_replay(dtrl_trainer* t, const float* mem_dev, const int64_t* flags_dev, int W);
+/* page-locked, device-visible host arrays owned by the trainer: the caller writes replay slots into idx ([0, batch): critic batch; [batch, 2 batch): actor
+ * candidates; [max_eval, max_eval + batch): actor batch -- separate windows, so that queued work never sees a later call's indices) and reads `better` and `loss` after dtrl_trainer_sync -- no copy is queued in either direction */
+int64_t* dtrl_trainer_idx(dtrl_trainer* t);
+int32_t* dtrl_trainer_better(dtrl_trainer* t);
+float* dtrl_trainer_loss(dtrl_trainer* t);
+/* Replaces: cMACETrainer::BuildProblemX / BuildProblemY (new_q = r (1 - discount) [+ discount max_f Q_target(s')] written over the taken fragment's value,
+ * learning/MACETrainer.cpp:163-250, 478-515) + cNeuralNet::Train on the batch idx[0 .. batch). loss -> dtrl_trainer_loss()[0]. */
+int dtrl_trainer_critic_step(dtrl_trainer* t);
+/* Replaces: the test of cMACETrainer::UpdateActorBatchBuffer (learning/MACETrainer.cpp:577-609) on the candidates idx[batch .. batch + n), n <= batch, 2 n <= max_eval:
+ * better[m] = (new_q(tuple m) > max_f Q_target(s_m)[f]). */
+int dtrl_trainer_actor_filter(dtrl_trainer* t, int n);
+/* Replaces: cMACETrainer::BuildActorProblemY + StepActor (learning/MACETrainer.cpp:285-305, 611-633) on idx[max_eval .. max_eval + batch): labels = the net's
+ * own outputs with the taken fragment's parameters replaced by the tuple's action. loss -> dtrl_trainer_loss()[1]. */
+int dtrl_trainer_actor_step(dtrl_trainer* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -49,6 +49,8 @@
 #include <cstring>
 #include <memory>
 
+#include "../or_bullet_si.h"   // TEST INFRASTRUCTURE: the maximal-coordinate sequential-impulse step (Bullet 2.8x's published algorithm restated) for ref_scn_use_bullet_si
+
 namespace {
 typedef void (*nn_forward_fn)(const double* x_norm, double* y_norm);
 typedef void (*step_hook_fn)(void* user, double dt, int substeps);
@@ -59,6 +61,7 @@ struct RefScn {
 	int kind = 0;
 	step_hook_fn hook = nullptr; void* hook_user = nullptr;
 	post_substep_fn post = nullptr; void* post_user = nullptr;
+	std::shared_ptr<bsi::Solver> si;
 };
 cTerrainRLCharController* Ctrl(RefScn* s) { return dynamic_cast<cTerrainRLCharController*>(s->scn->GetCharacter()->GetController().get()); }
 cImpPDController* ImpPD(RefScn* s)
@@ -118,6 +121,7 @@ void ref_scn_set_step_hook(void* h, step_hook_fn fn, void* user)
 {
 	RefScn* s = static_cast<RefScn*>(h);
 	s->hook = fn; s->hook_user = user;
+	if (s->si) return;   // the sequential-impulse integrator is installed: it calls the hook as an OBSERVER in front of its substeps (ref_scn_use_bullet_si)
 	s->scn->GetWorld()->GetInternalWorld()->m_stepHook = [s](btScalar dt, int substeps, btScalar) { if (s->hook) s->hook(s->hook_user, dt, substeps); };
 }
 // called after every iteration of the loop at scenarios/ScenarioSimChar.cpp:162-173 (after the scenario's own PostSubstepUpdate)
@@ -130,6 +134,52 @@ void ref_scn_set_post_substep(void* h, post_substep_fn fn, void* user)
 	scn->SetPostSubstepCallback([s](double dt) { if (s->post) s->post(s->post_user, dt); });
 }
 void ref_scn_update(void* h, double dt) { static_cast<RefScn*>(h)->scn->Update(dt); }
+
+// Physics = oracle/or_bullet_si.h: the stand-in world's stepSimulation(dt, n, dt / n) runs n sequential-impulse substeps on the reference's rigid bodies,
+// hinges and ground shapes (Bullet 2.8x's published algorithm and defaults), and the contact points it worked with are handed to the dispatcher as
+// manifolds, so that the reference's cContactManager derives its flags from them as it would from Bullet's. opts (NULL = defaults), in order:
+// iterations, erp, erp2, split_impulse, split_threshold, warmstarting, warmstart_factor, breaking, max_points, use_margin, link_contacts
+void ref_scn_use_bullet_si(void* h, const double* opts, int n_opts)
+{
+	RefScn* s = static_cast<RefScn*>(h);
+	s->si = std::make_shared<bsi::Solver>();
+	bsi::Params& p = s->si->prm;
+	auto opt = [&](int i, double def) { return (opts && i < n_opts) ? opts[i] : def; };
+	p.iterations = static_cast<int>(opt(0, p.iterations)); p.erp = opt(1, p.erp); p.erp2 = opt(2, p.erp2); p.split_impulse = static_cast<int>(opt(3, p.split_impulse));
+	p.split_threshold = opt(4, p.split_threshold); p.warmstarting = static_cast<int>(opt(5, p.warmstarting)); p.warmstart_factor = opt(6, p.warmstart_factor);
+	p.breaking = opt(7, p.breaking); p.max_points = static_cast<int>(opt(8, p.max_points)); p.use_margin = static_cast<int>(opt(9, p.use_margin)); p.link_contacts = static_cast<int>(opt(10, p.link_contacts));
+	btDiscreteDynamicsWorld* world = s->scn->GetWorld()->GetInternalWorld().get();
+	world->getConstraintSolver()->m_resetHook = [s]() { if (s->si) s->si->Reset(); };
+	world->m_stepHook = [s, world](btScalar dt, int substeps, btScalar fixed) {
+		if (s->hook) s->hook(s->hook_user, dt, substeps);   // observer: the state as the previous env-step left it (controller update included)
+		for (int i = 0; i < substeps; ++i) s->si->Step(world, fixed);
+		btDispatcher* d = world->getDispatcher();
+		d->m_manifolds.clear();
+		for (const bsi::Contact& c : s->si->contacts) {
+			btPersistentManifold m;
+			btManifoldPoint pt; pt.m_distance1 = static_cast<btScalar>(c.dist);
+			pt.m_positionWorldOnA = btVector3(static_cast<btScalar>(c.ax), static_cast<btScalar>(c.ay), 0); pt.m_positionWorldOnB = btVector3(static_cast<btScalar>(c.bx), static_cast<btScalar>(c.by), 0);
+			pt.m_normalWorldOnB = btVector3(static_cast<btScalar>(c.nx), static_cast<btScalar>(c.ny), 0);
+			m.m_points.push_back(pt);
+			m.m_body0 = s->si->BodyOf(c.a); m.m_body1 = c.obj_b;
+			d->m_manifolds.push_back(m);
+		}
+	};
+}
+// contacts of the last substep: n, then per contact link index of A (-1 if not a character part), of B (-1 = ground), distance (scaled units), applied normal impulse
+int ref_scn_si_contacts(void* h, int* link_a, int* link_b, double* dist, double* jn, int cap)
+{
+	RefScn* s = static_cast<RefScn*>(h);
+	if (!s->si) return 0;
+	const auto& c = s->scn->GetCharacter();
+	auto link_of = [&](const btCollisionObject* o) { for (int j = 0; j < c->GetNumBodyParts(); ++j) if (c->GetBodyPart(j)->GetRigidBody().get() == o) return j; return -1; };
+	int n = 0;
+	for (const bsi::Contact& ct : s->si->contacts) {
+		if (n >= cap) break;
+		link_a[n] = link_of(s->si->BodyOf(ct.a)); link_b[n] = ct.b >= 0 ? link_of(ct.obj_b) : -1; dist[n] = ct.dist; jn[n] = ct.jn; ++n;
+	}
+	return n;
+}
 
 void ref_scn_dims(void* h, int* num_joints, int* num_dof, int* poli_state, int* poli_action, int* num_params)
 {

@@ -513,7 +513,7 @@ private:
 	btOverlappingPairCache m_cache;
 };
 class btDbvtBroadphase : public btBroadphaseInterface {};
-class btConstraintSolver { public: virtual ~btConstraintSolver() {} virtual void reset() {} };
+class btConstraintSolver { public: virtual ~btConstraintSolver() {} virtual void reset() { if (m_resetHook) m_resetHook(); } std::function<void()> m_resetHook; };   // (cWorld::Reset calls reset(): the harness's integrator drops its cached contact impulses there)
 class btSequentialImpulseConstraintSolver : public btConstraintSolver {};
 
 // ---- world ----

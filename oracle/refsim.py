@@ -22,6 +22,9 @@ LIB_PATHS = {"f64": LIB_PATH, "f32": os.path.join(HERE, "_ref", "libref_sim_f32.
 _libs = {}
 NN_FWD = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double))
 STEP_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.c_int)
+POST_SUBSTEP = C.CFUNCTYPE(None, C.c_void_p, C.c_double)
+SI_OPTS = ("iterations", "erp", "erp2", "split_impulse", "split_threshold", "warmstarting", "warmstart_factor", "breaking", "max_points", "use_margin", "link_contacts")
+SI_DEFAULTS = dict(iterations=10, erp=0.2, erp2=0.8, split_impulse=1, split_threshold=-0.04, warmstarting=1, warmstart_factor=0.85, breaking=0.02, max_points=4, use_margin=1, link_contacts=1)
 
 
 def available():
@@ -64,6 +67,9 @@ def lib(variant="f64"):
         L.ref_scn_com.argtypes = [vp, vp, vp]
         L.ref_scn_drain_tuples.argtypes = [vp, vp, vp, C.c_int]
         L.ref_scn_eval_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), vp, C.c_int]
+        L.ref_scn_use_bullet_si.argtypes = [vp, vp, C.c_int]
+        L.ref_scn_si_contacts.argtypes = [vp, vp, vp, vp, vp, C.c_int]
+        L.ref_scn_set_post_substep.argtypes = [vp, POST_SUBSTEP, vp]
         _libs[variant] = L
     return _libs[variant]
 
@@ -117,6 +123,24 @@ class RefScenario:
         """fn(dt, substeps) is called in place of Bullet's stepSimulation."""
         self._hook = STEP_HOOK(lambda user, dt, n: fn(dt, n))
         lib(self.variant).ref_scn_set_step_hook(self.h, self._hook, None)
+
+    def use_bullet_si(self, **opts):
+        """Physics = oracle/or_bullet_si.h (the maximal-coordinate sequential-impulse restatement of Bullet 2.8x's published algorithm) instead of a
+        hook: the reference's own stepSimulation call then integrates its rigid bodies. opts override SI_DEFAULTS (Bullet's defaults)."""
+        unknown = set(opts) - set(SI_OPTS)
+        assert not unknown, unknown
+        v = np.array([float(opts.get(k, SI_DEFAULTS[k])) for k in SI_OPTS], np.float64)
+        lib(self.variant).ref_scn_use_bullet_si(self.h, _p(v), len(v))
+
+    def si_contacts(self, cap=256):
+        la = np.zeros(cap, np.int32); lb = np.zeros(cap, np.int32); d = np.zeros(cap); jn = np.zeros(cap)
+        n = lib(self.variant).ref_scn_si_contacts(self.h, _p(la), _p(lb), _p(d), _p(jn), cap)
+        return la[:n], lb[:n], d[:n], jn[:n]
+
+    def set_post_substep(self, fn):
+        """fn(dt) after every iteration of the env-step loop (scenarios/ScenarioSimChar.cpp:162-173)."""
+        self._post = POST_SUBSTEP(lambda user, dt: fn(dt))
+        lib(self.variant).ref_scn_set_post_substep(self.h, self._post, None)
 
     def pose_vel(self):
         q = np.zeros(self.D); qd = np.zeros(self.D); lib(self.variant).ref_scn_get_pose_vel(self.h, _p(q), _p(qd)); return q, qd

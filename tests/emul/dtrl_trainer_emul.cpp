@@ -1,0 +1,42 @@
+// dtrl_trainer_emul.cpp -- TESTS ONLY: the native trainer step's operand definitions and sequencing (deepterrainrl_amd/csrc/dtrl_trainer_ops.h,
+// dtrl_trainer_core.h) executed by plain host loops, so that the CPU box can check every GEMM's index arithmetic, the label construction and the
+// Caffe SGD rule against the torch / numpy restatements without a GPU. Linked into tests/emul/libdtrl_trainer_emul.so, which nothing in the product
+// loads (deepterrainrl_amd/hip_trainer.py binds lib/libdtrl.so and raises if the HIP library or device is missing).
+#include "dtrl_trainer_core.h"
+#include <cstdlib>
+#include <string>
+
+namespace dtrl_tr {
+struct EmulTrainerBE {
+	int device_id = -1;
+	std::string err_;
+	bool init(std::string&) { return true; }
+	bool ok() const { return err_.empty(); }
+	const std::string& error() const { return err_; }
+	void set_stream(void*) {}
+	void* alloc_dev(size_t bytes) { return std::calloc(1, bytes ? bytes : 1); }
+	void free_dev(void* p) { std::free(p); }
+	void* alloc_host(size_t bytes) { return std::calloc(1, bytes ? bytes : 1); }
+	void free_host(void* p) { std::free(p); }
+	void h2d(void* dst, const void* src, size_t n) { std::memcpy(dst, src, n); }
+	void d2h(void* dst, const void* src, size_t n) { std::memcpy(dst, src, n); }
+	void d2d(void* dst, const void* src, size_t n) { std::memcpy(dst, src, n); }
+	void sync() {}
+	void gemm(const NetDims& d, const Work& wk, const GemmDesc& g)
+	{
+		for (int z = 0; z < g.Z; ++z) {
+			const int k_begin = g.k0_step ? z * g.k0_step : 0;
+			const int k_end = g.k0_step ? (k_begin + g.k0_step < g.K ? k_begin + g.k0_step : g.K) : g.K;
+			for (int m = 0; m < g.M; ++m) for (int n = 0; n < g.N; ++n) {
+				float acc = 0;
+				for (int k = k_begin; k < k_end; ++k) acc = __builtin_fmaf(load_a(d, wk, g, z, m, k), load_b(d, wk, g, z, k, n), acc);
+				store_c(d, wk, g, z, m, n, acc);
+			}
+		}
+	}
+	template <class F> void for_each(int64_t n, const F& f) { for (int64_t i = 0; i < n; ++i) f(i); }
+};
+}  // namespace dtrl_tr
+
+using Backend = dtrl_tr::EmulTrainerBE;
+#include "dtrl_trainer_capi.inc"

@@ -1,0 +1,152 @@
+"""The MI355X-native MACE trainer step (include/dtrl_trainer.h, deepterrainrl_amd/csrc/dtrl_trainer*.{h,hip}, deepterrainrl_amd/hip_trainer.py).
+
+CPU tests run the SAME operand definitions and sequencing (dtrl_trainer_ops.h / dtrl_trainer_core.h) under plain host loops (tests/emul/libdtrl_trainer_emul.so,
+tests only) against (i) the torch peer trainer.MACETrainer in float32 -- forward, one solver step, the fused critic / actor calls -- and (ii) the whole-trainer
+numpy fp64 oracle oracle/trainer_ref.py over six iterations. The -m gpu twins run the HIP kernels of lib/libdtrl.so against the same oracle on the MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, REFDATA
+import test_trainer as TT
+
+EMUL_TRAINER_LIB = os.path.join(REPO, "tests", "emul", "libdtrl_trainer_emul.so")
+S, A, NF, FS = TT.S, TT.A, TT.NF, TT.FS
+
+
+def make_native(lib, device="cpu", **kw):
+    from deepterrainrl_amd import hip_trainer as ht
+    args = dict(mem_size=256, num_init_samples=100, freeze_target_iters=0, device=device, seed=21)
+    args.update(kw)
+    return ht.HipMACETrainer(TT.TRAIN, TT.SOLVER, S, A, lib_path=lib, **args)
+
+
+def make_peer(device="cpu", **kw):
+    args = dict(mem_size=256, num_init_samples=100, freeze_target_iters=0, device=device, dtype=torch.float32, seed=21, use_graphs=False)
+    args.update(kw)
+    return TT.make_trainer(**args)
+
+
+def test_trainer_abi_symbols_are_exported():
+    """every symbol include/dtrl_trainer.h declares is exported by the HIP library (and by the check build)"""
+    import ctypes
+    import re
+    from deepterrainrl_amd import hip_trainer as ht, LIB_PATH
+    hdr = open(os.path.join(REPO, "include", "dtrl_trainer.h")).read()
+    declared = sorted(set(re.findall(r"\b(dtrl_trainer_[a-z_]+)\s*\(", hdr)))
+    assert declared == sorted(ht.TRAINER_ABI_SYMBOLS)
+    for path in (LIB_PATH, EMUL_TRAINER_LIB):
+        L = ctypes.CDLL(path)
+        for s in declared:
+            assert hasattr(L, s), (path, s)
+
+
+def run_forward_and_step_vs_torch_peer(lib, device, tol):
+    """dtrl_trainer_eval / dtrl_trainer_step vs the torch net: outputs of both nets on 1, 32 and 64 rows, then one and two solver steps (gradient of every
+    blob through the update, momentum, weight decay with the per-blob multipliers) from the same weights, normalisers and history."""
+    rng = np.random.RandomState(5)
+    t = make_native(lib, device)
+    p = make_peer(device)
+    w0 = p.GetWeights().copy()       # (a float32 CPU net hands out a view of its own storage)
+    t.SetWeights(w0)
+    io = rng.normal(0, 0.3, S); isc = rng.uniform(0.5, 2.0, S); oo = rng.normal(0, 0.2, 90); osc = rng.uniform(0.5, 3.0, 90)
+    for x in (t, p):
+        x.SetInputOffsetScale(io, isc); x.SetOutputOffsetScale(oo, osc)
+    for n in (1, 32, 64):
+        X = torch.as_tensor(rng.normal(0, 1, (n, S)).astype(np.float32), device=device)
+        ya = t._eval(t.net, X); yb = p._eval(p.net, X)
+        if device != "cpu":
+            t.nt.sync()
+        d = (ya - yb).abs().max().item()
+        assert d < tol * max(1.0, yb.abs().max().item()), (n, d)
+    X = torch.as_tensor(rng.normal(0, 1, (32, S)).astype(np.float32), device=device)
+    Y = torch.as_tensor(rng.normal(0, 1, (32, 90)).astype(np.float32), device=device)
+    for k in range(2):
+        la = t._solver_step(X, Y); lb = p._solver_step(X, Y)
+        assert abs(float(la) - float(lb)) < 10 * tol * max(1.0, abs(float(lb))), (k, float(la), float(lb))
+        wa, wb = t.GetWeights().astype(np.float64), p.GetWeights().astype(np.float64)
+        dw = np.abs(wa - wb).max()
+        assert dw < tol * np.abs(wb).max() and np.abs(wb - w0).max() > 1e-5, (k, dw)
+        ha, hb = t.nt.get_params(2), p.hflat.detach().cpu().numpy()
+        assert np.abs(ha - hb).max() < tol * max(np.abs(hb).max(), 1e-3), k
+    # per-blob agreement (a wrong transpose in one small blob would hide behind the largest weight above)
+    off = 0
+    for b in p.net.blobs():
+        k = b.numel()
+        da = np.abs(wa[off:off + k] - wb[off:off + k]).max(); mv = np.abs(wb[off:off + k] - w0[off:off + k]).max()
+        assert da <= 50 * tol * max(mv, 1e-6) + 1e-7, (off, k, da, mv)
+        off += k
+
+
+def test_forward_and_step_vs_torch_peer():
+    run_forward_and_step_vs_torch_peer(EMUL_TRAINER_LIB, "cpu", 2e-5)
+
+
+def run_iterations_vs_numpy_oracle(om, lib, device, freeze, tol):
+    """cMACETrainer iterations through the fused native calls (critic step, actor filter, actor step) vs oracle/trainer_ref.py (numpy fp64): same
+    minibatches, critic targets, candidate decisions, labels, SGD -> same iteration counts, actor batch buffer and weights."""
+    rng = np.random.RandomState(9)
+    rows, flags = TT.random_rows(rng, 200, p_actor=0.5)
+    t = make_native(lib, device, freeze_target_iters=freeze)
+    r = TT.make_ref_trainer(om, t, 21, **({"freeze_target_iters": freeze} if freeze else {}))
+    w0 = t.GetWeights().copy()
+    r.set_weights(w0); t.SetWeights(w0)
+    t.AddTuples(rows, flags); r.add_tuples(rows, flags)
+    for k in range(6):
+        t.Train(); r.train()
+        assert (t.GetIter(), t.actor_iter) == (r.iter, r.actor_iter) and t.actor_batch_buffer == r.book.actor_batch, k
+        assert abs(t.last_loss - r.last_loss) < 1e-3 * max(1.0, abs(r.last_loss)), (k, t.last_loss, r.last_loss)
+    a = t.GetWeights().astype(np.float64)
+    assert r.iter == 6 and r.actor_iter >= 1
+    assert np.abs(a - r.w).max() < tol * np.abs(r.w).max() and np.abs(a - w0).max() > 1e-4, np.abs(a - r.w).max() / np.abs(r.w).max()
+    io, isc, _, _ = t.GetOffsetScale()
+    assert np.allclose(io, r.in_off, atol=1e-5) and np.allclose(isc, r.in_scale, rtol=1e-4)
+    return t
+
+
+@pytest.mark.parametrize("freeze", [0, 2])
+def test_iterations_vs_numpy_oracle(om, freeze):
+    run_iterations_vs_numpy_oracle(om, EMUL_TRAINER_LIB, "cpu", freeze, 2e-4)
+
+
+def test_train_loop_runs_on_the_native_trainer(da):
+    """train_loop.train(trainer="hip") end to end on the CPU check builds: rollouts (lane-loop engine) -> tuples -> native trainer step -> weights back."""
+    from conftest import EmulScenario
+    from deepterrainrl_amd import train_loop
+    extra = {"terrain_seed": 3, "trainer_num_init_samples": 30, "trainer_replay_mem_size": 512, "trainer_freeze_target_iters": 4,
+             "init_exp_rate": 0.3, "init_exp_base_rate": 0.1, "trainer_init_input_offset_scale": "false"}
+    st = train_loop.train("args/opt_args_train_mace.txt", REFDATA, num_envs=48, max_frames=70, trainer_device="cpu", scenario_cls=EmulScenario, extra_args=extra,
+                          trainer="hip", trainer_lib=EMUL_TRAINER_LIB)
+    assert st["iters"] >= 1 and np.all(np.isfinite(st["weights"])) and st["tuples"] >= 32
+
+
+# ---- the HIP kernels on the MI355X ----
+@pytest.mark.gpu
+def test_gpu_forward_and_step_vs_torch_peer():
+    run_forward_and_step_vs_torch_peer(None, "cuda", 5e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("freeze", [0, 2])
+def test_gpu_iterations_vs_numpy_oracle(om, freeze):
+    t = run_iterations_vs_numpy_oracle(om, None, "cuda", freeze, 2e-4)
+    maps = open("/proc/self/maps").read()
+    assert "libdtrl.so" in maps and t.mem.is_cuda
+
+
+@pytest.mark.gpu
+def test_gpu_equals_the_plain_loop_build(om):
+    """HIP kernels vs the plain-loop build of the same operand definitions: six iterations, identical decisions, weights within fp32 contraction noise."""
+    rng = np.random.RandomState(9)
+    rows, flags = TT.random_rows(rng, 200, p_actor=0.5)
+    a = make_native(None, "cuda"); b = make_native(EMUL_TRAINER_LIB, "cpu")
+    b.SetWeights(a.GetWeights())
+    for t in (a, b):
+        t.AddTuples(rows, flags)
+    for k in range(6):
+        a.Train(); b.Train()
+        assert (a.GetIter(), a.actor_iter, a.actor_batch_buffer) == (b.GetIter(), b.actor_iter, b.actor_batch_buffer), k
+    wa, wb = a.GetWeights().astype(np.float64), b.GetWeights().astype(np.float64)
+    assert np.abs(wa - wb).max() < 2e-5 * np.abs(wb).max()

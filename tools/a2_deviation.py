@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""(CPU, needs oracle/_ref/libref_sim.so = /root/reference compiled) How far is Integrator v1 from a Bullet-shaped integrator, behaviourally?
+
+SURVEY 8a row a2 -- what happens inside Bullet's stepSimulation -- is the one part of the hot path that cannot be pinned: Bullet is absent. This tool
+quantifies the modelling gap instead of leaving it open: the REFERENCE'S OWN scenario + controllers (compiled unchanged, oracle/_ref/libref_sim.so) are
+driven once by Integrator v1 (oracle/or_sim.h = the product kernel's model: reduced coordinates, Delassus-space PGS, no margins / warm start / split
+impulse; lock-step harness of oracle/refsim.py) and once by oracle/or_bullet_si.h (maximal coordinates, sequential impulse with Bullet 2.8x's published
+structure and defaults: ERP joints, 10 sweeps, warm-started persistent contacts, margins + breaking threshold, split impulse, angular-limit rows), on the
+same scenes, seeds and (synthetic) policies, and distribution-level statistics of the resulting behaviour are compared:
+
+  cycle_s      gait-cycle duration (time between new-cycle flags)               speed       mean forward speed of the root (m / s)
+  falls_k      falls (episode ends) per 1000 env-steps                           duty_front / duty_back   contact-flag duty cycle of the front / back foot
+  ep_dist      mean distance per episode (cScenarioPoliEval's dist log)          reward      mean cDogController / cRaptorController::CalcReward at cycle ends
+
+  python tools/a2_deviation.py [--seeds 6] [--frames 300] [--out profiles/r03_a2_deviation.txt] [--ablate]
+--ablate additionally runs the SI integrator with one Bullet feature removed at a time (margin, warm start, split impulse, link contacts, 4-point cap):
+a feature whose removal moves a statistic by more than the v1-vs-SI gap is one Integrator v1 should model.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+from oracle import model as om  # noqa: E402
+from oracle import refsim as rs  # noqa: E402
+
+REF = "/root/reference"
+FEET = {"dog": (16, 20), "raptor": (14, 18)}   # front / back end effector: dog finger, toe; raptor right toe, left toe (sim/SimDog.h:11-36, sim/SimRaptor.h)
+
+
+def policies():
+    from conftest import dog_policy
+    import test_host_and_emul as T
+    return {"dog": dog_policy(om), "raptor": T.raptor_policy(om)}
+
+
+SCENES = [  # tag, arg file, character, policy?, dims
+    ("dog flat FSM", "args/sim_dog_args.txt", "dog", None),
+    ("raptor flat FSM", "args/sim_raptor_args.txt", "raptor", None),
+    ("dog slopes_mixed + MACE net (configs[1])", "args/dog_slopes_mixed_args.txt", "dog", "dog"),
+    ("raptor narrow_gaps + MACE net (configs[2])", "args/raptor_narrow_gaps_args.txt", "raptor", "raptor"),
+    ("goat cliffs_rugged + MACE net (configs[4] scene)", "args/goat_cliffs_args.txt", "dog", "dog"),
+]
+
+
+def raw_forward(e, pol):
+    desc, w, io, isc, oo, osc = pol
+
+    def raw(x_norm):
+        x_raw = np.where(isc != 0, x_norm / np.where(isc != 0, isc, 1.0), 0.0) - io
+        y = e.nn_eval(x_raw)
+        return (y + oo) * osc
+    return raw
+
+
+class Stats:
+    def __init__(self, feet):
+        self.feet = feet
+        self.steps = 0; self.cycles = []; self.speed = 0.0; self.duty = np.zeros(2); self.rewards = []; self.falls = 0; self.dists = []
+        self._last_cycle_step = None
+
+    def env_step(self, contacts, flags, vx, dt=1.0 / 600.0):
+        self.steps += 1; self.speed += vx
+        self.duty += [contacts[self.feet[0]] != 0, contacts[self.feet[1]] != 0]
+        if flags & 4:
+            if self._last_cycle_step is not None:
+                self.cycles.append((self.steps - self._last_cycle_step) * dt)
+            self._last_cycle_step = self.steps
+
+    def episode_end(self):
+        self._last_cycle_step = None
+
+    def summary(self):
+        n = max(self.steps, 1)
+        c = np.array(self.cycles) if self.cycles else np.zeros(1)
+        return dict(env_steps=self.steps, cycle_s=float(c.mean()), cycle_sd=float(c.std()), n_cycles=len(self.cycles), speed=self.speed / n, falls_k=1000.0 * self.falls / n,
+                    duty_front=float(self.duty[0] / n), duty_back=float(self.duty[1] / n), ep_dist=float(np.mean(self.dists)) if self.dists else float("nan"),
+                    n_episodes=len(self.dists), reward=float(np.mean(self.rewards)) if self.rewards else float("nan"))
+
+
+def run(scene, integrator, seeds, frames, pols, si_opts=None):
+    tag, arg, char, polname = scene
+    st = Stats(FEET[char])
+    for seed in seeds:
+        m, _ = om.build_model(arg, REF)
+        pol = pols[polname] if polname else None
+        e = om.OracleEnv(m, terrain_seed=seed, policy=pol)
+        if pol is not None:
+            rs.nn_config(e.S if hasattr(e, "S") else len(pol[2]), len(pol[4]), raw_forward(e, pol))
+        r = rs.RefScenario("poli_eval", arg, REF, global_seed=seed + 1)
+        if pol is not None:
+            r.set_net_scale(*pol[2:])
+        r.seed_ground_and_reset(seed)
+        n_log = 0
+        if integrator == "v1":
+            ls = rs.LockStep(r, e)
+            for f in range(frames):
+                k0 = len(ls.records)
+                ls.update(); e.frame_end()
+                for o, rr in ls.records[k0:]:
+                    if rr.get("after_reset"):
+                        continue
+                    st.env_step(rr["contacts"], rr["flags"], rr["qd"][0])
+                    if rr["flags"] & 4:
+                        st.rewards.append(r.calc_reward())
+                log = r.eval_stats()["dist_log"]
+                if len(log) > n_log:
+                    st.dists += list(log[n_log:]); n_log = len(log)
+                if ls.records[-1][1].get("after_reset"):
+                    st.falls += 1; st.episode_end()
+        else:
+            r.use_bullet_si(**(si_opts or {}))
+
+            seen = [False]
+
+            def observe(dt=0, n=0):
+                # called in front of every env-step's physics (and once after Update): the state the previous env-step left behind, as in LockStep's records
+                if not seen[0]:
+                    seen[0] = True; return
+                fl = r.flags()
+                st.env_step(r.contact_flags(), fl, r.pose_vel()[1][0])
+                if fl & 4:
+                    st.rewards.append(r.calc_reward())
+            r.set_step_hook(observe)
+            for f in range(frames):
+                t0 = r.time()
+                r.update()
+                fell = r.time() < t0 + 0.5 / 30.0      # the scenario reset inside Update (fall): its last env-step is gone
+                if not fell:
+                    observe()
+                seen[0] = False
+                log = r.eval_stats()["dist_log"]
+                if len(log) > n_log:
+                    st.dists += list(log[n_log:]); n_log = len(log)
+                if fell:
+                    st.falls += 1; st.episode_end()
+    return st.summary()
+
+
+KEYS = ("cycle_s", "speed", "falls_k", "duty_front", "duty_back", "ep_dist", "reward")
+
+
+def fmt(s):
+    return "  ".join("%s %8.4f" % (k, s[k]) for k in KEYS) + "   (cycles %d, episodes %d, env-steps %d)" % (s["n_cycles"], s["n_episodes"], s["env_steps"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=6)
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--out", default="")
+    ap.add_argument("--ablate", action="store_true")
+    ap.add_argument("--scenes", default="", help="comma-separated scene indices (default: all)")
+    a = ap.parse_args()
+    assert rs.available(), "oracle/_ref/libref_sim.so missing: make -C oracle/_ref_build"
+    pols = policies()
+    seeds = list(range(101, 101 + a.seeds))
+    scenes = [SCENES[int(i)] for i in a.scenes.split(",")] if a.scenes else SCENES
+    lines = ["# Integrator v1 (product model) vs Bullet-shaped sequential impulse (oracle/or_bullet_si.h), both driven by the REFERENCE'S OWN controllers",
+             "# %d seeds x %d outer frames (%d env-steps) per cell; tools/a2_deviation.py" % (a.seeds, a.frames, a.seeds * a.frames * 20)]
+    results = {}
+    for sc in scenes:
+        t0 = time.time()
+        v1 = run(sc, "v1", seeds, a.frames, pols)
+        si = run(sc, "si", seeds, a.frames, pols)
+        results[sc[0]] = {"v1": v1, "si": si}
+        lines.append("\n## %s" % sc[0])
+        lines.append("  v1   " + fmt(v1))
+        lines.append("  SI   " + fmt(si))
+        lines.append("  rel  " + "  ".join("%s %+7.1f%%" % (k, 100.0 * (v1[k] - si[k]) / si[k]) if si[k] and np.isfinite(si[k]) and np.isfinite(v1[k]) else "%s     n/a" % k for k in KEYS))
+        if a.ablate:
+            for name, opts in (("no margin", dict(use_margin=0)), ("no warm start", dict(warmstarting=0)), ("no split impulse", dict(split_impulse=0)),
+                               ("no link contacts", dict(link_contacts=0)), ("1 point per pair", dict(max_points=1)), ("erp 0.8 joints", dict(erp=0.8)), ("20 iterations", dict(iterations=20))):
+                ab = run(sc, "si", seeds, a.frames, pols, si_opts=opts)
+                results[sc[0]]["si, " + name] = ab
+                lines.append("  SI, %-17s " % name + fmt(ab))
+        print("\n".join(lines[-(3 + (7 if a.ablate else 0)) - 1:]), "[%.0f s]" % (time.time() - t0), flush=True)
+    text = "\n".join(lines) + "\n"
+    if a.out:
+        open(a.out, "w").write(text)
+        json.dump(results, open(os.path.splitext(a.out)[0] + ".json", "w"), indent=1)
+    return results
+
+
+if __name__ == "__main__":
+    main()
