@@ -9,35 +9,54 @@
 #include "dtrl_trainer_core.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 
 namespace dtrl_tr {
 
-constexpr int kTM = 32, kTN = 64, kTK = 16, kThreads = 256;
+constexpr int kTM = 32, kTN = 64, kTK = 64, kThreads = 256;   // (a K chunk costs a global-memory round trip whatever its size: few, long chunks)
 
-__global__ void __launch_bounds__(kThreads) tr_gemm_kernel(NetDims d, Work wk, GemmDesc g)
+// OP is a compile-time constant so that the operand switch of load_a / load_b / store_c folds away in each instantiation; dims and work descriptors are
+// read through pointers (scalar loads from the device-resident copies; a by-value struct with run-time indexed arrays would live in scratch memory)
+template <int OP>
+__device__ __forceinline__ void tr_gemm_tile(const NetDims& d, const Work& wk, GemmDesc g, int z, float (&As)[kTK][kTM + 1], float (&Bs)[kTK][kTN + 1])
 {
-	__shared__ float As[kTK][kTM + 1];
-	__shared__ float Bs[kTK][kTN + 1];
+	g.op = OP;
 	const int tid = static_cast<int>(threadIdx.x), ty = tid >> 4, tx = tid & 15;
-	const int z = static_cast<int>(blockIdx.z), m0 = static_cast<int>(blockIdx.y) * kTM, n0 = static_cast<int>(blockIdx.x) * kTN;
+	const int m0 = static_cast<int>(blockIdx.y) * kTM, n0 = static_cast<int>(blockIdx.x) * kTN;
+	if (m0 >= g.M || n0 >= g.N) return;   // (a fused launch is sized for the larger of its two products)
 	const int k_begin = g.k0_step ? z * g.k0_step : 0;
 	const int k_end = g.k0_step ? (k_begin + g.k0_step < g.K ? k_begin + g.k0_step : g.K) : g.K;
-	float acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-	for (int k0 = k_begin; k0 < k_end; k0 += kTK) {
-		for (int e = tid; e < kTM * kTK; e += kThreads) {
+	constexpr int kRA = kTM * kTK / kThreads, kRB = kTK * kTN / kThreads;
+	float ra[kRA], rb[kRB];
+	// the operand elements of one K chunk, gathered into registers (the next chunk's loads are in flight while the current one is multiplied)
+	auto fetch = [&](int k0) {
+#pragma unroll
+		for (int i = 0; i < kRA; ++i) {
+			const int e = tid + i * kThreads;
 			int mm, kk;
 			if (g.a_kfast) { kk = e % kTK; mm = e / kTK; } else { mm = e % kTM; kk = e / kTM; }
 			const int m = m0 + mm, k = k0 + kk;
-			As[kk][mm] = (m < g.M && k < k_end) ? load_a(d, wk, g, z, m, k) : 0.0f;
+			ra[i] = (m < g.M && k < k_end) ? load_a(d, wk, g, z, m, k) : 0.0f;
 		}
-		for (int e = tid; e < kTK * kTN; e += kThreads) {
+#pragma unroll
+		for (int i = 0; i < kRB; ++i) {
+			const int e = tid + i * kThreads;
 			int nn, kk;
 			if (g.b_kfast) { kk = e % kTK; nn = e / kTK; } else { nn = e % kTN; kk = e / kTN; }
 			const int n = n0 + nn, k = k0 + kk;
-			Bs[kk][nn] = (n < g.N && k < k_end) ? load_b(d, wk, g, z, k, n) : 0.0f;
+			rb[i] = (n < g.N && k < k_end) ? load_b(d, wk, g, z, k, n) : 0.0f;
 		}
+	};
+	float acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+	fetch(k_begin);
+	for (int k0 = k_begin; k0 < k_end; k0 += kTK) {
+#pragma unroll
+		for (int i = 0; i < kRA; ++i) { const int e = tid + i * kThreads; if (g.a_kfast) As[e % kTK][e / kTK] = ra[i]; else As[e / kTM][e % kTM] = ra[i]; }
+#pragma unroll
+		for (int i = 0; i < kRB; ++i) { const int e = tid + i * kThreads; if (g.b_kfast) Bs[e % kTK][e / kTK] = rb[i]; else Bs[e / kTN][e % kTN] = rb[i]; }
 		__syncthreads();
+		if (k0 + kTK < k_end) fetch(k0 + kTK);
 #pragma unroll
 		for (int kk = 0; kk < kTK; ++kk) {
 			const float a0 = As[kk][ty], a1 = As[kk][ty + 16];
@@ -54,6 +73,47 @@ __global__ void __launch_bounds__(kThreads) tr_gemm_kernel(NetDims d, Work wk, G
 			const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
 			if (m < g.M && n < g.N) store_c(d, wk, g, z, m, n, acc[i][j]);
 		}
+}
+template <int OP>
+__global__ void __launch_bounds__(kThreads) tr_gemm_kernel(const NetDims* __restrict__ dp, const Work* __restrict__ wp, GemmDesc g)
+{
+	__shared__ float As[kTK][kTM + 1];
+	__shared__ float Bs[kTK][kTN + 1];
+	tr_gemm_tile<OP>(*dp, *wp, g, static_cast<int>(blockIdx.z), As, Bs);
+}
+// two independent products in one launch: blockIdx.z < ga.Z belongs to the first
+template <int OPA, int OPB>
+__global__ void __launch_bounds__(kThreads) tr_gemm2_kernel(const NetDims* __restrict__ dp, const Work* __restrict__ wp, GemmDesc ga, GemmDesc gb)
+{
+	__shared__ float As[kTK][kTM + 1];
+	__shared__ float Bs[kTK][kTN + 1];
+	const int z = static_cast<int>(blockIdx.z);
+	if (z < ga.Z) tr_gemm_tile<OPA>(*dp, *wp, ga, z, As, Bs); else tr_gemm_tile<OPB>(*dp, *wp, gb, z - ga.Z, As, Bs);
+}
+
+__global__ void __launch_bounds__(256) tr_sum_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out)
+{
+	__shared__ float part[256];
+	const int t = static_cast<int>(threadIdx.x);
+	float s = 0;
+	for (int i = t; i < n; i += 256) s += x[i];
+	part[t] = s;
+	__syncthreads();
+	for (int d = 128; d > 0; d >>= 1) { if (t < d) part[t] += part[t + d]; __syncthreads(); }
+	if (t == 0) *out = scale * part[0];
+}
+
+// t3 = relu(sum of the terr_ip0 split-K partials + bias): 16 lanes per output read the output's contiguous run of partials together (coalesced) and
+// combine with a butterfly -- a thread per output walks 94 strided addresses alone
+__global__ void __launch_bounds__(256) tr_terr_reduce_kernel(const NetDims* __restrict__ dp, const Work* __restrict__ wp, int n_out)
+{
+	const NetDims& d = *dp; const Work& wk = *wp;
+	const int lane16 = static_cast<int>(threadIdx.x) & 15;
+	const int o = (static_cast<int>(blockIdx.x) * 256 + static_cast<int>(threadIdx.x)) >> 4;
+	float s = 0;
+	if (o < n_out) { const float* p = wk.tp + static_cast<size_t>(o) * d.n_slabs; for (int z = lane16; z < d.n_slabs; z += 16) s += p[z]; }
+	for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+	if (o < n_out && lane16 == 0) { s += wk.w[d.bo_terr + o % d.fc_terr]; wk.t3[o] = s > 0 ? s : 0.0f; }
 }
 
 template <class F>
@@ -77,7 +137,12 @@ struct HipTrainerBE {
 	bool ok() const { return err_.empty(); }
 	const std::string& error() const { return err_; }
 	bool chk(hipError_t e, const char* what) { if (e == hipSuccess) return true; if (err_.empty()) err_ = std::string(what) + ": " + hipGetErrorString(e); return false; }
-	void set_stream(void* s) { stream = static_cast<hipStream_t>(s); }
+	void set_stream(void* s)
+	{
+		if (static_cast<hipStream_t>(s) == stream) return;
+		for (hipGraphExec_t& e : exec_) if (e) { hipGraphExecDestroy(e); e = nullptr; }   // recorded on the old stream's behalf: re-record
+		stream = static_cast<hipStream_t>(s);
+	}
 	void* alloc_dev(size_t bytes) { void* p = nullptr; if (!chk(hipMalloc(&p, bytes), "hipMalloc")) return nullptr; chk(hipMemset(p, 0, bytes), "hipMemset"); return p; }
 	void free_dev(void* p) { hipFree(p); }
 	void* alloc_host(size_t bytes) { void* p = nullptr; return chk(hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc") ? p : nullptr; }
@@ -86,11 +151,73 @@ struct HipTrainerBE {
 	void d2h(void* dst, const void* src, size_t n) { chk(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); chk(hipStreamSynchronize(stream), "sync"); }
 	void d2d(void* dst, const void* src, size_t n) { chk(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, stream), "hipMemcpy D2D"); }
 	void sync() { chk(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
-	void gemm(const NetDims& d, const Work& wk, const GemmDesc& g)
+	template <int OP> void launch(const NetDims* d, const Work* wk, const GemmDesc& g)
 	{
 		const dim3 grid((g.N + kTN - 1) / kTN, (g.M + kTM - 1) / kTM, g.Z);
-		hipLaunchKernelGGL(tr_gemm_kernel, grid, dim3(kThreads), 0, stream, d, wk, g);
+		hipLaunchKernelGGL(tr_gemm_kernel<OP>, grid, dim3(kThreads), 0, stream, d, wk, g);
+	}
+	void gemm(const NetDims* d, const Work* wk, const GemmDesc& g)
+	{
+		switch (g.op) {
+		case kConvFwd: launch<kConvFwd>(d, wk, g); break; case kTerrFwd: launch<kTerrFwd>(d, wk, g); break; case kIp0Fwd: launch<kIp0Fwd>(d, wk, g); break;
+		case kHead0Fwd: launch<kHead0Fwd>(d, wk, g); break; case kHead1Fwd: launch<kHead1Fwd>(d, wk, g); break; case kHead1Bw: launch<kHead1Bw>(d, wk, g); break;
+		case kHead1Bx: launch<kHead1Bx>(d, wk, g); break; case kHead0Bw: launch<kHead0Bw>(d, wk, g); break; case kHead0Bx: launch<kHead0Bx>(d, wk, g); break;
+		case kIp0Bw: launch<kIp0Bw>(d, wk, g); break; case kIp0Bx: launch<kIp0Bx>(d, wk, g); break; case kTerrBw: launch<kTerrBw>(d, wk, g); break;
+		case kTerrBx: launch<kTerrBx>(d, wk, g); break; case kConvBw: launch<kConvBw>(d, wk, g); break; case kConvBx: launch<kConvBx>(d, wk, g); break;
+		}
 		chk(hipGetLastError(), "gemm launch");
+	}
+	template <int OPA, int OPB> void launch2(const NetDims* d, const Work* wk, const GemmDesc& ga, const GemmDesc& gb)
+	{
+		const dim3 grid((std::max(ga.N, gb.N) + kTN - 1) / kTN, (std::max(ga.M, gb.M) + kTM - 1) / kTM, ga.Z + gb.Z);
+		hipLaunchKernelGGL((tr_gemm2_kernel<OPA, OPB>), grid, dim3(kThreads), 0, stream, d, wk, ga, gb);
+	}
+	void gemm2(const NetDims* d, const Work* wk, const GemmDesc& ga, const GemmDesc& gb)
+	{
+		if (ga.op == kHead1Bw && gb.op == kHead1Bx) launch2<kHead1Bw, kHead1Bx>(d, wk, ga, gb);
+		else if (ga.op == kHead0Bw && gb.op == kHead0Bx) launch2<kHead0Bw, kHead0Bx>(d, wk, ga, gb);
+		else if (ga.op == kIp0Bw && gb.op == kIp0Bx) launch2<kIp0Bw, kIp0Bx>(d, wk, ga, gb);
+		else if (ga.op == kTerrBw && gb.op == kTerrBx) launch2<kTerrBw, kTerrBx>(d, wk, ga, gb);
+		else if (ga.op == kConvBw && gb.op == kConvBx) launch2<kConvBw, kConvBx>(d, wk, ga, gb);
+		else { gemm(d, wk, ga); gemm(d, wk, gb); return; }
+		chk(hipGetLastError(), "gemm2 launch");
+	}
+	// a fixed launch sequence (pointers and shapes never change: the callers' inputs arrive through fixed page-locked / device buffers) recorded once as a
+	// HIP graph and replayed: ~35 launches of a few microseconds each are bound by the gaps between them, not by their work. Needs a stream of the
+	// trainer's own (the legacy default stream cannot be captured); DTRL_TRAINER_GRAPHS=0 keeps plain launches.
+	template <class Fn> void run_graph(int key, Fn fn)
+	{
+		static const bool enabled = []() { const char* e = std::getenv("DTRL_TRAINER_GRAPHS"); return !e || std::atoi(e) != 0; }();
+		if (!enabled || !stream || key < 0 || key >= kMaxGraphs || graph_failed_) { fn(); return; }
+		if (!exec_[key]) {
+			hipGraph_t graph = nullptr;
+			if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_failed_ = true; (void)hipGetLastError(); fn(); return; }
+			fn();
+			const hipError_t e1 = hipStreamEndCapture(stream, &graph);
+			if (e1 != hipSuccess || !graph || hipGraphInstantiate(&exec_[key], graph, nullptr, nullptr, 0) != hipSuccess) {
+				graph_failed_ = true; exec_[key] = nullptr; (void)hipGetLastError(); err_.clear();
+				if (graph) hipGraphDestroy(graph);
+				fn();   // nothing was executed during the failed capture
+				return;
+			}
+			hipGraphDestroy(graph);
+		}
+		chk(hipGraphLaunch(exec_[key], stream), "hipGraphLaunch");
+	}
+	static constexpr int kMaxGraphs = 8;
+	hipGraphExec_t exec_[kMaxGraphs] = {};
+	bool graph_failed_ = false;
+	~HipTrainerBE() { for (hipGraphExec_t e : exec_) if (e) hipGraphExecDestroy(e); }
+	template <class F> void terr_reduce(const NetDims* d, const Work* wk, int n_out, const F&)
+	{
+		hipLaunchKernelGGL(tr_terr_reduce_kernel, dim3((n_out * 16 + 255) / 256), dim3(256), 0, stream, d, wk, n_out);
+		chk(hipGetLastError(), "terr reduce launch");
+	}
+	// *out = scale * sum(x[0 .. n)): one workgroup, tree reduction in LDS
+	void loss_sum(const float* x, int n, float scale, float* out)
+	{
+		hipLaunchKernelGGL(tr_sum_kernel, dim3(1), dim3(256), 0, stream, x, n, scale, out);
+		chk(hipGetLastError(), "loss launch");
 	}
 	template <class F>
 	void for_each(int64_t n, const F& f)

@@ -16,12 +16,16 @@
 namespace dtrl_tr {
 
 // ---- element-wise functors (index space = [0, n)) ----
-struct FGatherNorm { NetDims d; Norm nm; const float* mem; int W; const int64_t* idx; int col0; float* xin;
-	TR_HD void operator()(int64_t i) const { gather_norm_elem(d, nm, mem, W, idx, col0, xin, i); } };
-struct FNormIn { NetDims d; Norm nm; const float* X; float* xin;     // xin = (X + in_off) * in_scale for caller-supplied rows
-	TR_HD void operator()(int64_t i) const { const int j = static_cast<int>(i % d.S); xin[i] = (X[i] + nm.in_off[j]) * nm.in_scale[j]; } };
-struct FTerrReduce { NetDims d; Work wk; TR_HD void operator()(int64_t i) const { terr_reduce_elem(d, wk, static_cast<int>(i)); } };
-struct FConvGrad { NetDims d; Work wk; int l; TR_HD void operator()(int64_t i) const { conv_grad_elem(d, wk, l, static_cast<int>(i)); } };
+struct FGatherNorm { int S; Norm nm; const float* mem; int W; const int64_t* idx; int col0; float* xin;
+	TR_HD void operator()(int64_t i) const { gather_norm_elem(S, nm, mem, W, idx, col0, xin, i); } };
+struct FNormIn { int S; Norm nm; const float* X; float* xin;     // xin = (X + in_off) * in_scale for caller-supplied rows
+	TR_HD void operator()(int64_t i) const { const int j = static_cast<int>(i % S); xin[i] = (X[i] + nm.in_off[j]) * nm.in_scale[j]; } };
+// (dims / work descriptors are read through pointers to their device-resident copies: a by-value struct whose arrays are indexed with a run-time layer or
+// head number would be spilled to scratch memory by the compiler, and every operand load would then pay a scratch access)
+struct FTerrReduce { const NetDims* d; const Work* wk; TR_HD void operator()(int64_t i) const { terr_reduce_elem(*d, *wk, static_cast<int>(i)); } };
+struct FDhSum { const NetDims* d; const Work* wk; TR_HD void operator()(int64_t i) const { dh_sum_elem(*d, *wk, static_cast<int>(i)); } };
+struct FConvGrad { const NetDims* d; const Work* wk; int n0, n1;   // the three conv layers' weight + bias gradients in one index space
+	TR_HD void operator()(int64_t i) const { const int l = i < n0 ? 0 : (i < n1 ? 1 : 2); conv_grad_elem(*d, *wk, l, static_cast<int>(i - (l == 0 ? 0 : (l == 1 ? n0 : n1)))); } };
 struct FSgd { float* w; float* hist; const float* g; const float* rate_mult; const float* decay_mult; float rate, momentum, weight_decay;
 	TR_HD void operator()(int64_t i) const { sgd_elem(w, hist, g, rate_mult, decay_mult, rate, momentum, weight_decay, i); } };
 struct FUnnorm { Norm nm; const float* out; float* Y; int out_size;
@@ -39,11 +43,11 @@ struct FNewQ { Norm nm; const float* mem; int W; const int64_t* idx; const int64
 	} };
 // label (normalised) and the loss gradient of one output element. mode 0: caller's labels Y (un-normalised); 1: critic (y = the net's own output,
 // entry a[m] replaced by new_q); 2: actor (entries of fragment a[m] replaced by the tuple's action parameters)
-struct FLabelDout { NetDims d; Norm nm; int mode; const float* Yext; const float* mem; int W, S; const int64_t* idx; const float* newq; int n_frags, frag_size; int rows;
+struct FLabelDout { int out_size; Norm nm; int mode; const float* Yext; const float* mem; int W, S; const int64_t* idx; const float* newq; int n_frags, frag_size; int rows;
 	const float* out; float* dout; float* sq;
 	TR_HD void operator()(int64_t i) const
 	{
-		const int m = static_cast<int>(i / d.out_size), j = static_cast<int>(i % d.out_size);
+		const int m = static_cast<int>(i / out_size), j = static_cast<int>(i % out_size);
 		float y;
 		if (mode == 0) y = Yext[i];
 		else {
@@ -58,8 +62,6 @@ struct FLabelDout { NetDims d; Norm nm; int mode; const float* Yext; const float
 		dout[i] = e / static_cast<float>(rows);
 		sq[i] = e * e;
 	} };
-struct FLossSum { const float* sq; int n; int rows; float* loss;   // EuclideanLoss = 1 / (2 N) sum e^2 (one thread: 2 880 terms)
-	TR_HD void operator()(int64_t) const { float s = 0; for (int i = 0; i < n; ++i) s += sq[i]; *loss = 0.5f * s / static_cast<float>(rows); } };
 // better[m] = new_q(s') > max_f Q_target(s)[f]; tout rows [0, n) = s, rows [n, 2n) = s'
 struct FActorFilter { Norm nm; const float* tout; int out_size, n_frags, n; const float* newq; int32_t* better;
 	TR_HD void operator()(int64_t m) const
@@ -95,7 +97,14 @@ public:
 		in_off = F(d.S); in_scale = F(d.S); out_off = F(d.out_size); out_scale = F(d.out_size);
 		MakeWork(train, cfg.batch, true);
 		MakeWork(eval, cfg.max_eval, false);
-		newq = F(cfg.max_eval); sq = F(static_cast<size_t>(cfg.batch) * d.out_size);
+		// device-resident descriptors (see FTerrReduce): the dims, and the work set as the three passes see it (current net + gradient; evaluation with the
+		// current / the target net)
+		train.w = w_cur; train.g = grad;
+		d_dims = static_cast<NetDims*>(Dev(sizeof(NetDims))); d_train = static_cast<Work*>(Dev(sizeof(Work))); d_eval_cur = static_cast<Work*>(Dev(sizeof(Work))); d_eval_tgt = static_cast<Work*>(Dev(sizeof(Work)));
+		if (!be.ok()) { err = be.error(); return false; }
+		{ Work e = eval; e.w = w_cur; be.h2d(d_eval_cur, &e, sizeof(Work)); e.w = w_tgt; be.h2d(d_eval_tgt, &e, sizeof(Work)); }
+		be.h2d(d_dims, &cfg.dims, sizeof(NetDims)); be.h2d(d_train, &train, sizeof(Work));
+		newq = F(2 * cfg.max_eval); sq = F(static_cast<size_t>(cfg.batch) * d.out_size);
 		// page-locked, device-visible: the host writes indices / reads the mask and the loss without a copy being queued
 		idx_host = static_cast<int64_t*>(HostAlloc(sizeof(int64_t) * 2 * cfg.max_eval));
 		better_host = static_cast<int32_t*>(HostAlloc(sizeof(int32_t) * cfg.max_eval));
@@ -112,34 +121,35 @@ public:
 	Norm norm() const { return Norm{in_off, in_scale, out_off, out_scale}; }
 
 	// ---- passes ----
-	void Forward(Work& wk, const float* weights, int rows)
+	// wk: one of the device-resident descriptors (d_train, d_eval_cur, d_eval_tgt)
+	void Forward(const Work* wk, int rows)
 	{
 		const NetDims& d = cfg.dims;
-		wk.w = weights; wk.rows = rows;
-		for (int l = 0; l < 3; ++l) be.gemm(d, wk, make_gemm(d, rows, kConvFwd, l));
-		be.gemm(d, wk, make_gemm(d, rows, kTerrFwd));
-		be.for_each(static_cast<int64_t>(rows) * d.fc_terr, FTerrReduce{d, wk});
-		be.gemm(d, wk, make_gemm(d, rows, kIp0Fwd));
-		be.gemm(d, wk, make_gemm(d, rows, kHead0Fwd));
-		be.gemm(d, wk, make_gemm(d, rows, kHead1Fwd));
+		for (int l = 0; l < 3; ++l) be.gemm(d_dims, wk, make_gemm(d, rows, kConvFwd, l));
+		be.gemm(d_dims, wk, make_gemm(d, rows, kTerrFwd));
+		be.terr_reduce(d_dims, wk, rows * d.fc_terr, FTerrReduce{d_dims, wk});
+		be.gemm(d_dims, wk, make_gemm(d, rows, kIp0Fwd));
+		be.gemm(d_dims, wk, make_gemm(d, rows, kHead0Fwd));
+		be.gemm(d_dims, wk, make_gemm(d, rows, kHead1Fwd));
 	}
 	// gradient of the current net on the rows of `train` (dout filled), then the Caffe SGD update
 	void BackwardAndUpdate()
 	{
 		const NetDims& d = cfg.dims;
-		Work& wk = train;
-		const int rows = wk.rows;
-		wk.w = w_cur; wk.g = grad;
-		be.gemm(d, wk, make_gemm(d, rows, kHead1Bw)); be.gemm(d, wk, make_gemm(d, rows, kHead1Bx));
-		be.gemm(d, wk, make_gemm(d, rows, kHead0Bw)); be.gemm(d, wk, make_gemm(d, rows, kHead0Bx));
-		be.gemm(d, wk, make_gemm(d, rows, kIp0Bw)); be.gemm(d, wk, make_gemm(d, rows, kIp0Bx));
-		be.gemm(d, wk, make_gemm(d, rows, kTerrBw)); be.gemm(d, wk, make_gemm(d, rows, kTerrBx));
+		const Work* wk = d_train;
+		const int rows = cfg.batch;
+		// a layer's weight gradient and data gradient read the same incoming gradient and are independent of each other: one launch per pair
+		be.gemm2(d_dims, wk, make_gemm(d, rows, kHead1Bw), make_gemm(d, rows, kHead1Bx));
+		be.gemm2(d_dims, wk, make_gemm(d, rows, kHead0Bw), make_gemm(d, rows, kHead0Bx));
+		be.for_each(static_cast<int64_t>(rows) * d.fc_trunk, FDhSum{d_dims, wk});
+		be.gemm2(d_dims, wk, make_gemm(d, rows, kIp0Bw), make_gemm(d, rows, kIp0Bx));
+		be.gemm2(d_dims, wk, make_gemm(d, rows, kTerrBw), make_gemm(d, rows, kTerrBx));
 		for (int l = 2; l >= 0; --l) {
 			GemmDesc g = make_gemm(d, rows, kConvBw, l); g.b_kfast = 1;
-			be.gemm(d, wk, g);
-			if (l > 0) be.gemm(d, wk, make_gemm(d, rows, kConvBx, l));
+			if (l > 0) be.gemm2(d_dims, wk, g, make_gemm(d, rows, kConvBx, l)); else be.gemm(d_dims, wk, g);
 		}
-		for (int l = 0; l < 3; ++l) be.for_each(static_cast<int64_t>(d.C[l + 1]) * (d.C[l] * d.Kw[l] + 1), FConvGrad{d, wk, l});
+		const int n0 = d.C[1] * (d.C[0] * d.Kw[0] + 1), n1 = n0 + d.C[2] * (d.C[1] * d.Kw[1] + 1), n2 = n1 + d.C[3] * (d.C[2] * d.Kw[2] + 1);
+		be.for_each(n2, FConvGrad{d_dims, wk, n0, n1});
 		be.for_each(d.num_params, FSgd{w_cur, hist, grad, rate_mult, decay_mult, cfg.base_lr, cfg.momentum, cfg.weight_decay});
 	}
 
@@ -149,8 +159,8 @@ public:
 	{
 		if (n <= 0 || n > cfg.max_eval) return false;
 		const NetDims& d = cfg.dims;
-		be.for_each(static_cast<int64_t>(n) * d.S, FNormIn{d, norm(), X, eval.xin});
-		Forward(eval, which ? w_tgt : w_cur, n);
+		be.for_each(static_cast<int64_t>(n) * d.S, FNormIn{d.S, norm(), X, eval.xin});
+		Forward(which ? d_eval_tgt : d_eval_cur, n);
 		be.for_each(static_cast<int64_t>(n) * d.out_size, FUnnorm{norm(), eval.out, Y, d.out_size});
 		return be.ok();
 	}
@@ -159,10 +169,10 @@ public:
 	{
 		const NetDims& d = cfg.dims;
 		const int n = cfg.batch;
-		be.for_each(static_cast<int64_t>(n) * d.S, FNormIn{d, norm(), X, train.xin});
-		Forward(train, w_cur, n);
-		be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d, norm(), 0, Y, nullptr, 0, d.S, nullptr, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
-		be.for_each(1, FLossSum{sq, n * d.out_size, n, loss_host});
+		be.for_each(static_cast<int64_t>(n) * d.S, FNormIn{d.S, norm(), X, train.xin});
+		Forward(d_train, n);
+		be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d.out_size, norm(), 0, Y, nullptr, 0, d.S, nullptr, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
+		be.loss_sum(sq, n * d.out_size, 0.5f / static_cast<float>(n), loss_host);
 		BackwardAndUpdate();
 		return be.ok();
 	}
@@ -170,21 +180,45 @@ public:
 	void BindReplay(const float* mem, const int64_t* flags, int W) { mem_ = mem; flags_ = flags; W_ = W; }
 
 	// idx_host[0 .. batch) = the critic minibatch's slots. loss -> loss_host[0]
-	bool CriticStep()
+	bool CriticStep() { if (!mem_ || cfg.n_frags <= 0) return false; be.run_graph(0, [this] { CriticStepBody(); }); return be.ok(); }
+	// frozen target only (cMACETrainer::EnableTargetNet()): the critic step and the actor candidates' test in ONE pass -- Q_target is needed on s' of the critic
+	// batch and on s, s' of the candidates, none of which depends on the critic update, so the target net runs once over [s'_critic | s_cand | s'_cand].
+	// idx_host[batch .. 2 batch) must hold `batch` valid slots (pad a shorter candidate list by repeating a slot; the caller ignores the padded answers).
+	bool CriticStepAndFilter()
 	{
-		if (!mem_ || cfg.n_frags <= 0) return false;
+		if (!mem_ || cfg.n_frags <= 0 || !cfg_target_frozen || cfg.max_eval < 3 * cfg.batch) return false;
+		be.run_graph(3, [this] {
+			const NetDims& d = cfg.dims;
+			const int n = cfg.batch, S = d.S, A = 1 + cfg.frag_size;
+			const int64_t* cand = idx_host + n;
+			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1 + S + A, eval.xin});
+			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, cand, 1, eval.xin + static_cast<size_t>(n) * S});
+			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, cand, 1 + S + A, eval.xin + static_cast<size_t>(2 * n) * S});
+			Forward(d_eval_tgt, 3 * n);
+			be.for_each(n, FNewQ{norm(), mem_, W_, idx_host, flags_, eval.out, d.out_size, cfg.n_frags, cfg.discount, newq});
+			be.for_each(n, FNewQ{norm(), mem_, W_, cand, flags_, eval.out + static_cast<size_t>(2 * n) * d.out_size, d.out_size, cfg.n_frags, cfg.discount, newq + n});
+			be.for_each(n, FActorFilter{norm(), eval.out + static_cast<size_t>(n) * d.out_size, d.out_size, cfg.n_frags, n, newq + n, better_host});
+			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1, train.xin});
+			Forward(d_train, n);
+			be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d.out_size, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
+			be.loss_sum(sq, n * d.out_size, 0.5f / static_cast<float>(n), loss_host);
+			BackwardAndUpdate();
+		});
+		return be.ok();
+	}
+	void CriticStepBody()
+	{
 		const NetDims& d = cfg.dims;
 		const int n = cfg.batch, S = d.S, A = 1 + cfg.frag_size;
 		// Q_target(s') first (its activations live in `eval`), then the current net on s: the forward of the solver step IS the evaluation BuildProblemY needs
-		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{d, norm(), mem_, W_, idx_host, 1 + S + A, eval.xin});
-		Forward(eval, cfg_target_frozen ? w_tgt : w_cur, n);
+		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1 + S + A, eval.xin});
+		Forward(cfg_target_frozen ? d_eval_tgt : d_eval_cur, n);
 		be.for_each(n, FNewQ{norm(), mem_, W_, idx_host, flags_, eval.out, d.out_size, cfg.n_frags, cfg.discount, newq});
-		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{d, norm(), mem_, W_, idx_host, 1, train.xin});
-		Forward(train, w_cur, n);
-		be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
-		be.for_each(1, FLossSum{sq, n * d.out_size, n, loss_host});
+		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1, train.xin});
+		Forward(d_train, n);
+		be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d.out_size, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
+		be.loss_sum(sq, n * d.out_size, 0.5f / static_cast<float>(n), loss_host);
 		BackwardAndUpdate();
-		return be.ok();
 	}
 	// idx_host[batch .. batch + n) = candidate slots (a window of their own: the critic step queued before may not have read its indices yet);
 	// better_host[0 .. n) = 1 where new_q > Q_target(s) (valid after Sync)
@@ -193,28 +227,26 @@ public:
 		if (!mem_ || cfg.n_frags <= 0 || n <= 0 || 2 * n > cfg.max_eval || n > cfg.batch) return false;
 		const NetDims& d = cfg.dims;
 		const int S = d.S, A = 1 + cfg.frag_size;
-		const float* wt = cfg_target_frozen ? w_tgt : w_cur;
 		const int64_t* idx = idx_host + cfg.batch;
-		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{d, norm(), mem_, W_, idx, 1, eval.xin});
-		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{d, norm(), mem_, W_, idx, 1 + S + A, eval.xin + static_cast<size_t>(n) * S});
-		Forward(eval, wt, 2 * n);
+		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx, 1, eval.xin});
+		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx, 1 + S + A, eval.xin + static_cast<size_t>(n) * S});
+		Forward(cfg_target_frozen ? d_eval_tgt : d_eval_cur, 2 * n);
 		be.for_each(n, FNewQ{norm(), mem_, W_, idx, flags_, eval.out + static_cast<size_t>(n) * d.out_size, d.out_size, cfg.n_frags, cfg.discount, newq});
 		be.for_each(n, FActorFilter{norm(), eval.out, d.out_size, cfg.n_frags, n, newq, better_host});
 		return be.ok();
 	}
 	// idx_host[max_eval .. max_eval + batch) = the actor batch's slots (a second window, so that a filter's candidates stay intact). loss -> loss_host[1]
-	bool ActorStep()
+	bool ActorStep() { if (!mem_ || cfg.n_frags <= 0) return false; be.run_graph(2, [this] { ActorStepBody(); }); return be.ok(); }
+	void ActorStepBody()
 	{
-		if (!mem_ || cfg.n_frags <= 0) return false;
 		const NetDims& d = cfg.dims;
 		const int n = cfg.batch, S = d.S;
 		const int64_t* idx = idx_host + cfg.max_eval;
-		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{d, norm(), mem_, W_, idx, 1, train.xin});
-		Forward(train, w_cur, n);
-		be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d, norm(), 2, nullptr, mem_, W_, S, idx, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
-		be.for_each(1, FLossSum{sq, n * d.out_size, n, loss_host + 1});
+		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx, 1, train.xin});
+		Forward(d_train, n);
+		be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d.out_size, norm(), 2, nullptr, mem_, W_, S, idx, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
+		be.loss_sum(sq, n * d.out_size, 0.5f / static_cast<float>(n), loss_host + 1);
 		BackwardAndUpdate();
-		return be.ok();
 	}
 	void UpdateTarget() { be.d2d(w_tgt, w_cur, sizeof(float) * cfg.dims.num_params); }
 
@@ -223,10 +255,12 @@ public:
 	BE be;
 	float *w_cur = nullptr, *w_tgt = nullptr, *hist = nullptr, *grad = nullptr, *rate_mult = nullptr, *decay_mult = nullptr;
 	float *in_off = nullptr, *in_scale = nullptr, *out_off = nullptr, *out_scale = nullptr, *newq = nullptr, *sq = nullptr;
-	Work train{}, eval{};
+	Work train{}, eval{};                 // host copies (pointers into device memory)
+	NetDims* d_dims = nullptr; Work* d_train = nullptr; Work* d_eval_cur = nullptr; Work* d_eval_tgt = nullptr;   // device-resident descriptors
 	int64_t* idx_host = nullptr; int32_t* better_host = nullptr; float* loss_host = nullptr;
 
 private:
+	void* Dev(size_t bytes) { void* p = be.alloc_dev(bytes); if (p) dev_.push_back(p); return p; }
 	float* F(size_t n) { void* p = be.alloc_dev(sizeof(float) * (n ? n : 1)); if (p) dev_.push_back(p); return static_cast<float*>(p); }
 	void* HostAlloc(size_t bytes) { void* p = be.alloc_host(bytes); if (p) { std::memset(p, 0, bytes); host_.push_back(p); } return p; }
 	void MakeWork(Work& wk, int rows, bool with_grad)
@@ -241,7 +275,7 @@ private:
 		wk.hz = F(static_cast<size_t>(d.n_heads) * rows * d.fc_head); wk.out = F(static_cast<size_t>(rows) * d.out_size);
 		if (!with_grad) return;
 		wk.dout = F(static_cast<size_t>(rows) * d.out_size); wk.dhz = F(static_cast<size_t>(d.n_heads) * rows * d.fc_head);
-		wk.dh = F(static_cast<size_t>(rows) * d.fc_trunk); wk.dt3 = F(static_cast<size_t>(rows) * d.fc_terr);
+		wk.dh = F(static_cast<size_t>(d.n_heads) * rows * d.fc_trunk); wk.dhs = F(static_cast<size_t>(rows) * d.fc_trunk); wk.dt3 = F(static_cast<size_t>(rows) * d.fc_terr);
 		for (int l = 0; l < 3; ++l) { wk.dy[l] = F(static_cast<size_t>(rows) * d.C[l + 1] * d.T[l + 1]); wk.pw[l] = F(static_cast<size_t>(rows) * d.C[l + 1] * (d.C[l] * d.Kw[l] + 1)); }
 	}
 	const float* mem_ = nullptr; const int64_t* flags_ = nullptr; int W_ = 0;

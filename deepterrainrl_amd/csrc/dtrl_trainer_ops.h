@@ -64,14 +64,15 @@ struct Work {
 	float* g;            // gradient, same layout as the weights
 	float* xin;          // [rows][S] normalised input
 	float* act[3];       // conv outputs, post-ReLU: [rows][C[l + 1]][T[l + 1]]
-	float* tp;           // [n_slabs][rows][fc_terr] terr_ip0 partial sums
+	float* tp;           // [rows][fc_terr][n_slabs] terr_ip0 partial sums
 	float* t3;           // [rows][fc_terr]
 	float* h;            // [rows][fc_trunk]
 	float* hz;           // [n_heads][rows][fc_head]
 	float* out;          // [rows][out_size] (normalised output space)
 	float* dout;         // [rows][out_size]
 	float* dhz;          // [n_heads][rows][fc_head]
-	float* dh;           // [rows][fc_trunk]
+	float* dh;           // [n_heads][rows][fc_trunk] per-head partial gradients wrt the trunk output (summed and ReLU-masked where they are read: dh_at)
+	float* dhs;          // [rows][fc_trunk] the heads' contributions summed and masked by the trunk's ReLU (dh_sum_elem)
 	float* dt3;          // [rows][fc_terr]
 	float* dy[3];        // gradient wrt the conv layers' pre-activations
 	float* pw[3];        // per-sample partial weight gradients of the conv layers: [rows][C[l + 1]][C[l] Kw[l] + 1]
@@ -92,6 +93,15 @@ TR_HD inline float conv_in(const NetDims& d, const Work& wk, int l, int z, int c
 {
 	return l == 0 ? wk.xin[static_cast<size_t>(z) * d.S + t] : wk.act[l - 1][(static_cast<size_t>(z) * d.C[l] + ci) * d.T[l] + t];
 }
+// gradient wrt the trunk's pre-activation: sum of the heads' contributions, masked by the trunk's ReLU
+TR_HD inline float dh_at(const NetDims& d, const Work& wk, int m, int n)
+{
+	const size_t i = static_cast<size_t>(m) * d.fc_trunk + n;
+	if (!(wk.h[i] > 0)) return 0.0f;
+	float s = 0;
+	for (int f = 0; f < d.n_heads; ++f) s += wk.dh[static_cast<size_t>(f) * wk.max_rows * d.fc_trunk + i];
+	return s;
+}
 TR_HD inline float concat_in(const NetDims& d, const Work& wk, int m, int k)
 {
 	return k < d.fc_terr ? wk.t3[static_cast<size_t>(m) * d.fc_terr + k] : wk.xin[static_cast<size_t>(m) * d.S + d.n_terr + (k - d.fc_terr)];
@@ -110,7 +120,7 @@ inline GemmDesc make_gemm(const NetDims& d, int rows, int op, int layer = 0)
 	case kHead1Bw: g.Z = d.n_heads; g.M = 0; for (int f = 0; f < d.n_heads; ++f) g.M = g.M > d.head_out[f] ? g.M : d.head_out[f]; g.N = d.fc_head + 1; g.K = rows; g.a_kfast = 0; break;
 	case kHead1Bx: g.Z = d.n_heads; g.M = rows; g.N = d.fc_head; g.K = 0; for (int f = 0; f < d.n_heads; ++f) g.K = g.K > d.head_out[f] ? g.K : d.head_out[f]; break;
 	case kHead0Bw: g.Z = d.n_heads; g.M = d.fc_head; g.N = d.fc_trunk + 1; g.K = rows; g.a_kfast = 0; break;
-	case kHead0Bx: g.M = rows; g.N = d.fc_trunk; g.K = d.n_heads * d.fc_head; break;
+	case kHead0Bx: g.Z = d.n_heads; g.M = rows; g.N = d.fc_trunk; g.K = d.fc_head; break;   // one product per head (summed by dh_at): n_heads x the workgroups, a quarter of the K loop
 	case kIp0Bw: g.M = d.fc_trunk; g.N = d.fc_terr + d.n_char + 1; g.K = rows; g.a_kfast = 0; break;
 	case kIp0Bx: g.M = rows; g.N = d.fc_terr; g.K = d.fc_trunk; break;
 	case kTerrBw: g.M = d.fc_terr; g.N = d.n_flat + 1; g.K = rows; g.a_kfast = 0; break;
@@ -134,9 +144,9 @@ TR_HD inline float load_a(const NetDims& d, const Work& wk, const GemmDesc& g, i
 	case kHead1Bw: return m < d.head_out[z] ? wk.dout[static_cast<size_t>(k) * d.out_size + d.out_off[z] + m] : 0.0f;
 	case kHead1Bx: return k < d.head_out[z] ? wk.dout[static_cast<size_t>(m) * d.out_size + d.out_off[z] + k] : 0.0f;
 	case kHead0Bw: return wk.dhz[(static_cast<size_t>(z) * wk.max_rows + k) * d.fc_head + m];
-	case kHead0Bx: return wk.dhz[(static_cast<size_t>(k / d.fc_head) * wk.max_rows + m) * d.fc_head + (k % d.fc_head)];
-	case kIp0Bw: return wk.dh[static_cast<size_t>(k) * d.fc_trunk + m];
-	case kIp0Bx: return wk.dh[static_cast<size_t>(m) * d.fc_trunk + k];
+	case kHead0Bx: return wk.dhz[(static_cast<size_t>(z) * wk.max_rows + m) * d.fc_head + k];
+	case kIp0Bw: return wk.dhs[static_cast<size_t>(k) * d.fc_trunk + m];
+	case kIp0Bx: return wk.dhs[static_cast<size_t>(m) * d.fc_trunk + k];
 	case kTerrBw: return wk.dt3[static_cast<size_t>(k) * d.fc_terr + m];
 	case kTerrBx: return wk.dt3[static_cast<size_t>(m) * d.fc_terr + k];
 	case kConvBw: return wk.dy[l][(static_cast<size_t>(z) * d.C[l + 1] + m) * d.T[l + 1] + k];
@@ -157,7 +167,7 @@ TR_HD inline float load_b(const NetDims& d, const Work& wk, const GemmDesc& g, i
 	case kHead1Bw: return n < d.fc_head ? wk.hz[(static_cast<size_t>(z) * wk.max_rows + k) * d.fc_head + n] : 1.0f;
 	case kHead1Bx: return k < d.head_out[z] ? wk.w[d.wo_h1[z] + static_cast<int64_t>(k) * d.fc_head + n] : 0.0f;
 	case kHead0Bw: return n < d.fc_trunk ? wk.h[static_cast<size_t>(k) * d.fc_trunk + n] : 1.0f;
-	case kHead0Bx: return wk.w[d.wo_h0[k / d.fc_head] + static_cast<int64_t>(k % d.fc_head) * d.fc_trunk + n];
+	case kHead0Bx: return wk.w[d.wo_h0[z] + static_cast<int64_t>(k) * d.fc_trunk + n];
 	case kIp0Bw: return n < g.N - 1 ? concat_in(d, wk, k, n) : 1.0f;
 	case kIp0Bx: return wk.w[d.wo_ip0 + static_cast<int64_t>(k) * (d.fc_terr + d.n_char) + n];
 	case kTerrBw: return n < d.n_flat ? wk.act[2][static_cast<size_t>(k) * d.n_flat + n] : 1.0f;
@@ -173,14 +183,14 @@ TR_HD inline void store_c(const NetDims& d, const Work& wk, const GemmDesc& g, i
 	const int l = g.layer;
 	switch (g.op) {
 	case kConvFwd: { const float v = acc + wk.w[d.bo_conv[l] + m]; wk.act[l][(static_cast<size_t>(z) * d.C[l + 1] + m) * d.T[l + 1] + n] = v > 0 ? v : 0.0f; break; }
-	case kTerrFwd: wk.tp[(static_cast<size_t>(z) * wk.max_rows + m) * d.fc_terr + n] = acc; break;
+	case kTerrFwd: wk.tp[(static_cast<size_t>(m) * d.fc_terr + n) * d.n_slabs + z] = acc; break;   // slab index fastest: the reduction reads one contiguous run per output
 	case kIp0Fwd: { const float v = acc + wk.w[d.bo_ip0 + n]; wk.h[static_cast<size_t>(m) * d.fc_trunk + n] = v > 0 ? v : 0.0f; break; }
 	case kHead0Fwd: { const float v = acc + wk.w[d.bo_h0[z] + n]; wk.hz[(static_cast<size_t>(z) * wk.max_rows + m) * d.fc_head + n] = v > 0 ? v : 0.0f; break; }
 	case kHead1Fwd: if (n < d.head_out[z]) wk.out[static_cast<size_t>(m) * d.out_size + d.out_off[z] + n] = acc + wk.w[d.bo_h1[z] + n]; break;
 	case kHead1Bw: if (m < d.head_out[z]) { if (n < d.fc_head) wk.g[d.wo_h1[z] + static_cast<int64_t>(m) * d.fc_head + n] = acc; else wk.g[d.bo_h1[z] + m] = acc; } break;
 	case kHead1Bx: wk.dhz[(static_cast<size_t>(z) * wk.max_rows + m) * d.fc_head + n] = wk.hz[(static_cast<size_t>(z) * wk.max_rows + m) * d.fc_head + n] > 0 ? acc : 0.0f; break;
 	case kHead0Bw: if (n < d.fc_trunk) wk.g[d.wo_h0[z] + static_cast<int64_t>(m) * d.fc_trunk + n] = acc; else wk.g[d.bo_h0[z] + m] = acc; break;
-	case kHead0Bx: wk.dh[static_cast<size_t>(m) * d.fc_trunk + n] = wk.h[static_cast<size_t>(m) * d.fc_trunk + n] > 0 ? acc : 0.0f; break;
+	case kHead0Bx: wk.dh[(static_cast<size_t>(z) * wk.max_rows + m) * d.fc_trunk + n] = acc; break;
 	case kIp0Bw: if (n < g.N - 1) wk.g[d.wo_ip0 + static_cast<int64_t>(m) * (g.N - 1) + n] = acc; else wk.g[d.bo_ip0 + m] = acc; break;
 	case kIp0Bx: wk.dt3[static_cast<size_t>(m) * d.fc_terr + n] = wk.t3[static_cast<size_t>(m) * d.fc_terr + n] > 0 ? acc : 0.0f; break;
 	case kTerrBw: if (n < d.n_flat) wk.g[d.wo_terr + static_cast<int64_t>(m) * d.n_flat + n] = acc; else wk.g[d.bo_terr + m] = acc; break;
@@ -196,10 +206,12 @@ TR_HD inline void terr_reduce_elem(const NetDims& d, const Work& wk, int i)
 {
 	const int m = i / d.fc_terr, n = i % d.fc_terr;
 	float s = 0;
-	for (int z = 0; z < d.n_slabs; ++z) s += wk.tp[(static_cast<size_t>(z) * wk.max_rows + m) * d.fc_terr + n];
+	const float* p = wk.tp + (static_cast<size_t>(m) * d.fc_terr + n) * d.n_slabs;
+	for (int z = 0; z < d.n_slabs; ++z) s += p[z];
 	s += wk.w[d.bo_terr + n];
 	wk.t3[i] = s > 0 ? s : 0.0f;
 }
+TR_HD inline void dh_sum_elem(const NetDims& d, const Work& wk, int i) { wk.dhs[i] = dh_at(d, wk, i / d.fc_trunk, i % d.fc_trunk); }
 // conv weight / bias gradients: sum of the per-sample partials
 TR_HD inline void conv_grad_elem(const NetDims& d, const Work& wk, int l, int i)
 {
@@ -221,9 +233,9 @@ TR_HD inline void sgd_elem(float* w, float* hist, const float* g, const float* r
 struct Norm { const float* in_off; const float* in_scale; const float* out_off; const float* out_scale; };
 
 // xin[row][j] = (mem[idx[row]][col0 + j] + in_off[j]) * in_scale[j]   (cNeuralNet::NormalizeInput)
-TR_HD inline void gather_norm_elem(const NetDims& d, const Norm& nm, const float* mem, int W, const int64_t* idx, int col0, float* xin, int64_t i)
+TR_HD inline void gather_norm_elem(int S, const Norm& nm, const float* mem, int W, const int64_t* idx, int col0, float* xin, int64_t i)
 {
-	const int row = static_cast<int>(i / d.S), j = static_cast<int>(i % d.S);
+	const int row = static_cast<int>(i / S), j = static_cast<int>(i % S);
 	xin[i] = (mem[static_cast<size_t>(idx[row]) * W + col0 + j] + nm.in_off[j]) * nm.in_scale[j];
 }
 TR_HD inline float unnorm_out(const Norm& nm, float y, int j) { return y / nm.out_scale[j] - nm.out_off[j]; }

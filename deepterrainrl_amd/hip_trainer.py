@@ -26,7 +26,7 @@ TRAINER_ABI_SYMBOLS = [
     "dtrl_trainer_create", "dtrl_trainer_destroy", "dtrl_trainer_last_error", "dtrl_trainer_set_stream", "dtrl_trainer_sync", "dtrl_trainer_num_params",
     "dtrl_trainer_set_params", "dtrl_trainer_get_params", "dtrl_trainer_params_device", "dtrl_trainer_set_normalizers", "dtrl_trainer_update_target",
     "dtrl_trainer_eval", "dtrl_trainer_step", "dtrl_trainer_bind_replay", "dtrl_trainer_idx", "dtrl_trainer_better", "dtrl_trainer_loss",
-    "dtrl_trainer_critic_step", "dtrl_trainer_actor_filter", "dtrl_trainer_actor_step",
+    "dtrl_trainer_critic_step", "dtrl_trainer_actor_filter", "dtrl_trainer_actor_step", "dtrl_trainer_debug_get", "dtrl_trainer_critic_step_and_filter",
 ]
 
 
@@ -51,6 +51,7 @@ def _bind(path):
     L.dtrl_trainer_set_params.argtypes = [vp, C.c_int, vp, C.c_int64]
     L.dtrl_trainer_get_params.argtypes = [vp, C.c_int, vp, C.c_int64]
     L.dtrl_trainer_params_device.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.dtrl_trainer_debug_get.argtypes = [vp, C.c_int, vp, C.c_int64]
     L.dtrl_trainer_set_normalizers.argtypes = [vp, vp, vp, vp, vp]
     L.dtrl_trainer_update_target.argtypes = [vp]
     L.dtrl_trainer_eval.argtypes = [vp, C.c_int, vp, C.c_int, vp]
@@ -59,6 +60,7 @@ def _bind(path):
     for name, ty in (("dtrl_trainer_idx", C.c_int64), ("dtrl_trainer_better", C.c_int32), ("dtrl_trainer_loss", C.c_float)):
         getattr(L, name).restype = C.POINTER(ty); getattr(L, name).argtypes = [vp]
     L.dtrl_trainer_critic_step.argtypes = [vp]
+    L.dtrl_trainer_critic_step_and_filter.argtypes = [vp]
     L.dtrl_trainer_actor_filter.argtypes = [vp, C.c_int]
     L.dtrl_trainer_actor_step.argtypes = [vp]
     return L
@@ -127,6 +129,9 @@ class NativeTrainer:
     def get_params(self, which):
         a = np.zeros(self.num_params, np.float32); self._chk(self._lib.dtrl_trainer_get_params(self._h, which, a.ctypes.data_as(C.c_void_p), a.size)); return a
 
+    def debug_get(self, which, n):
+        a = np.zeros(int(n), np.float32); self._chk(self._lib.dtrl_trainer_debug_get(self._h, which, a.ctypes.data_as(C.c_void_p), a.size)); return a
+
     def params_device(self, which=0):
         p = C.c_void_p(); self._chk(self._lib.dtrl_trainer_params_device(self._h, which, C.byref(p))); return p.value
 
@@ -139,6 +144,7 @@ class NativeTrainer:
     def step(self, x_ptr, y_ptr): self._chk(self._lib.dtrl_trainer_step(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
     def bind_replay(self, mem_ptr, flags_ptr, W): self._chk(self._lib.dtrl_trainer_bind_replay(self._h, C.c_void_p(mem_ptr), C.c_void_p(flags_ptr), W))
     def critic_step(self): self._chk(self._lib.dtrl_trainer_critic_step(self._h))
+    def critic_step_and_filter(self): self._chk(self._lib.dtrl_trainer_critic_step_and_filter(self._h))
     def actor_filter(self, n): self._chk(self._lib.dtrl_trainer_actor_filter(self._h, n))
     def actor_step(self): self._chk(self._lib.dtrl_trainer_actor_step(self._h))
 
@@ -153,12 +159,15 @@ class HipMACETrainer(MACETrainer):
         super().__init__(*a, **kw)
         if self.solver["lr_policy"] != "fixed":
             raise DtrlError("the native trainer step implements lr_policy \"fixed\" (what the shipped solver prototxts use)")
-        cdesc = desc_from_net(self.desc, self.S, self.batch, 2 * self.batch, self.solver, self.discount, self.freeze_target_iters > 0)
+        cdesc = desc_from_net(self.desc, self.S, self.batch, 3 * self.batch, self.solver, self.discount, self.freeze_target_iters > 0)
         dev_id = self.device.index if self.device.type == "cuda" and self.device.index is not None else -1
         self.nt = NativeTrainer(cdesc, dev_id, lib_path)
         assert self.nt.num_params == self.net.num_params()
-        if self.device.type == "cuda":
-            self.nt.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        # a stream of the trainer's own (its fixed launch sequences are recorded as HIP graphs, which the legacy default stream does not allow); ordered
+        # against the framework's stream where the two meet: replay rows written by AddTuples, tensors handed to / taken from _eval and _solver_step
+        self._stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        if self._stream is not None:
+            self.nt.set_stream(self._stream.cuda_stream)
         self.nt.set_params(0, self.net.get_flat())
         self.nt.set_params(3, self.rate_mult.detach().cpu().numpy()); self.nt.set_params(4, self.decay_mult.detach().cpu().numpy())
         self.nt.update_target()
@@ -196,24 +205,39 @@ class HipMACETrainer(MACETrainer):
         self.net.set_flat(self.GetWeights())    # the torch net is only a container here
         super().OutputModel(model_file)
 
+    def _after_torch(self):
+        """the trainer's stream waits for what the framework's current stream has queued (replay writes, input tensors)"""
+        if self._stream is not None:
+            self._stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _before_torch(self):
+        if self._stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._stream)
+
+    def AddTuples(self, rows, flags):
+        out = super().AddTuples(rows, flags)
+        self._replay_dirty = True
+        return out
+
     # ---- network calls ----
     def _eval(self, net, X):
         n = X.shape[0]
         which = 0 if (net is self.net or not self.EnableTargetNet()) else 1
         X = X.to(torch.float32).contiguous()
+        self._after_torch()
         out = []
         for k in range(0, n, self.nt.max_eval):
             xs = X[k:k + self.nt.max_eval]
             y = torch.empty((xs.shape[0], self.out_size), dtype=torch.float32, device=self.device)
             self.nt.eval(which, xs.data_ptr(), xs.shape[0], y.data_ptr())
-            if self.device.type == "cuda":
-                pass                           # same stream as torch's: ordered
             out.append(y)
+        self._before_torch()
         self._keep = (X, out)                  # the kernels read X after this returns
         return out[0] if len(out) == 1 else torch.cat(out)
 
     def _solver_step(self, X, Y):
         X = X.to(torch.float32).contiguous(); Y = Y.to(torch.float32).contiguous()
+        self._after_torch()
         self.nt.step(X.data_ptr(), Y.data_ptr())
         self._keep = (X, Y)
         self.solver_iter += 1
@@ -222,8 +246,30 @@ class HipMACETrainer(MACETrainer):
 
     # ---- cMACETrainer::Step on the fused native calls ----
     def Step(self):
+        if getattr(self, "_replay_dirty", False):
+            self._after_torch(); self._replay_dirty = False
         ids = self.FetchMinibatch(self.batch)
         succ = len(ids) >= self.batch
+        if succ and self.EnableTargetNet() and self.stage_train:
+            # frozen target: the candidates' test does not depend on the critic update -> one fused pass (dtrl_trainer_critic_step_and_filter). The
+            # candidates are drawn here, right behind the critic batch: the same position in the index stream as cMACETrainer::Step's order.
+            cand = self.FetchActorMinibatch(self.batch)
+            if getattr(self, "_loss_pending", False):
+                self.nt.sync(); self._last_loss = float(self.nt.loss[0]); self._loss_pending = False
+            B = self.batch
+            self.nt.idx[:B] = ids
+            self.nt.idx[B:2 * B] = (cand + [ids[0]] * (B - len(cand))) if cand else [ids[0]] * B
+            self.nt.critic_step_and_filter()
+            self.solver_iter += 1
+            self.nt.sync()                      # the one host wait of an iteration
+            self._last_loss = float(self.nt.loss[0])
+            if cand:
+                better = self.nt.better[:len(cand)].copy()
+                self.actor_batch_buffer += [t for t, b in zip(cand, better) if b]
+            self._run_actor_batches()
+            if self.iter > 0 and self.iter % self.freeze_target_iters == 0:
+                self.nt.update_target()
+            return succ
         if succ:
             if getattr(self, "_loss_pending", False):   # a critic step may still be queued (no actor filter waited since): it must have read its indices
                 self.nt.sync(); self._last_loss = float(self.nt.loss[0]); self._loss_pending = False
@@ -264,6 +310,9 @@ class HipMACETrainer(MACETrainer):
     def UpdateActor(self):
         if self.stage_train:
             self.UpdateActorBatchBuffer()
+        self._run_actor_batches()
+
+    def _run_actor_batches(self):
         for _ in range(len(self.actor_batch_buffer) // self.batch):
             ids = self.actor_batch_buffer[:self.batch]
             if getattr(self, "_aloss_pending", False):

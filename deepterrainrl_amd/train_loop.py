@@ -76,8 +76,20 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     chunk = max(1, geti("tuple_buffer_size", 32))
     max_iters = max_iters if max_iters is not None else geti("trainer_max_iter", 10 ** 9)
 
+    last_norm = [None]
+
     def sync(it):
-        b.SetPolicy(t.GetWeights(), *t.GetOffsetScale())
+        if hasattr(t, "WeightsDevicePtr"):
+            # native trainer: the weights go from the trainer's device buffer into the engine's layout by a gather kernel (dtrl_set_policy_device); the
+            # normalisers only travel (from the host) when they changed
+            t.nt.sync()
+            norm = t.GetOffsetScale()
+            if last_norm[0] is None or any(not np.array_equal(a, c) for a, c in zip(norm, last_norm[0])):
+                b.SetPolicy(t.GetWeights(), *norm); last_norm[0] = norm
+            else:
+                b.SetPolicyDevice(t.WeightsDevicePtr(), t.nt.num_params)
+        else:
+            b.SetPolicy(t.GetWeights(), *t.GetOffsetScale())
         b.SetExplore(1, anneal(it, n_anneal, init["rate"], exp["rate"]), anneal(it, n_anneal, init["temp"], exp["temp"]), anneal(it, n_base_anneal, init["base"], exp["base"]))
         phase = 1.0 if n_curr < 1 else min(max(it / float(n_curr), 0.0), 1.0)    # CalcCurriculumPhase (gInitCurriculumPhase at iter 0)
         b.SetTerrainParamsLerp(phase if it > 0 or n_curr < 1 else 0.0)

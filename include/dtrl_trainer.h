@@ -44,6 +44,9 @@ int64_t dtrl_trainer_num_params(const dtrl_trainer* t);
  * 3 lr_mult per element, 4 decay_mult per element (the per-blob multipliers of the train prototxt, expanded). Host arrays of num_params floats; synchronous. */
 int dtrl_trainer_set_params(dtrl_trainer* t, int which, const float* host, int64_t n);
 int dtrl_trainer_get_params(dtrl_trainer* t, int which, float* host, int64_t n);
+/* test / diagnosis: the first n floats of an internal device buffer (10 eval input, 11 eval output, 12 new_q, 13 train input, 14 train output,
+ * 15 loss gradient, 16 weight gradient); what cNeuralNet::GetLayerState offers for blobs. Synchronous. */
+int dtrl_trainer_debug_get(dtrl_trainer* t, int which, float* host, int64_t n);
 /* device pointer of the flat weight vector (which = 0 / 1): hand it to dtrl_set_policy_device without a host round trip (cNeuralNetLearner::SyncNet) */
 int dtrl_trainer_params_device(dtrl_trainer* t, int which, float** dev_ptr);
 /* Replaces: cNeuralNet::SetInputOffsetScale / SetOutputOffsetScale (learning/NeuralNet.cpp:217-260). Host doubles, state_size / out_size entries; NULL keeps. */
@@ -72,6 +75,10 @@ int dtrl_trainer_critic_step(dtrl_trainer* t);
 /* Replaces: the test of cMACETrainer::UpdateActorBatchBuffer (learning/MACETrainer.cpp:577-609) on the candidates idx[batch .. batch + n), n <= batch, 2 n <= max_eval:
  * better[m] = (new_q(tuple m) > max_f Q_target(s_m)[f]). */
 int dtrl_trainer_actor_filter(dtrl_trainer* t, int n);
+/* dtrl_trainer_critic_step and dtrl_trainer_actor_filter(batch) in one pass, for a FROZEN target net (freeze_target != 0, max_eval >= 3 x batch): Q_target is
+ * needed on s' of the critic batch and on s, s' of the actor candidates, and none of them depends on the critic update, so the target net is evaluated once
+ * over all three. idx[batch .. 2 batch) must hold `batch` valid slots (pad a shorter candidate list by repeating one; ignore the padded answers). */
+int dtrl_trainer_critic_step_and_filter(dtrl_trainer* t);
 /* Replaces: cMACETrainer::BuildActorProblemY + StepActor (learning/MACETrainer.cpp:285-305, 611-633) on idx[max_eval .. max_eval + batch): labels = the net's
  * own outputs with the taken fragment's parameters replaced by the tuple's action. loss -> dtrl_trainer_loss()[1]. */
 int dtrl_trainer_actor_step(dtrl_trainer* t);

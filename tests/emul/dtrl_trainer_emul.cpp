@@ -22,8 +22,13 @@ struct EmulTrainerBE {
 	void d2h(void* dst, const void* src, size_t n) { std::memcpy(dst, src, n); }
 	void d2d(void* dst, const void* src, size_t n) { std::memcpy(dst, src, n); }
 	void sync() {}
-	void gemm(const NetDims& d, const Work& wk, const GemmDesc& g)
+	void gemm2(const NetDims* d, const Work* wk, const GemmDesc& ga, const GemmDesc& gb) { gemm(d, wk, ga); gemm(d, wk, gb); }
+	template <class Fn> void run_graph(int, Fn fn) { fn(); }
+	template <class F> void terr_reduce(const NetDims*, const Work*, int n, const F& f) { for_each(n, f); }
+	void loss_sum(const float* x, int n, float scale, float* out) { float s = 0; for (int i = 0; i < n; ++i) s += x[i]; *out = scale * s; }
+	void gemm(const NetDims* dp, const Work* wp, const GemmDesc& g)
 	{
+		const NetDims& d = *dp; const Work& wk = *wp;
 		for (int z = 0; z < g.Z; ++z) {
 			const int k_begin = g.k0_step ? z * g.k0_step : 0;
 			const int k_end = g.k0_step ? (k_begin + g.k0_step < g.K ? k_begin + g.k0_step : g.K) : g.K;
