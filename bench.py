@@ -329,16 +329,14 @@ def main():
         concurrent = max(1, int(round(launches / float(frames_timed))))
         ach = B_ALG * env_steps_per_launch / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure comes from the latest committed
-        # rocprofv3 --pmc passes of this same command (tools/gpu_profile.sh -> tools/rocpd_summary.py -> profiles/hbm_traffic.json)
+        # rocprofv3 --pmc passes of this same command (tools/gpu_profile.sh -> tools/rocpd_summary.py -> profiles/hbm_traffic_config<N>.json)
         traffic = None; valu_insts = None; traffic_source = None
-        tj = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        tj = os.path.join(REPO, "profiles", "hbm_traffic_config%d.json" % a.config)
         if os.path.exists(tj) and n == cfg["envs"]:
             rec = json.load(open(tj))
-            if a.config != 1:
-                rec = rec.get("configs", {}).get(str(a.config))
             if rec:
                 traffic = rec.get("hbm_bytes_per_launch"); valu_insts = rec.get("sq_insts_valu_per_launch")
-                traffic_source = "profiles/hbm_traffic.json <- profiles/%s (rocprofv3 --pmc passes of this command at the same batch size; NOT counters of this run)" % rec.get("source")
+                traffic_source = "profiles/hbm_traffic_config%d.json <- profiles/%s (rocprofv3 --pmc passes of this command at the same batch size; NOT counters of this run)" % (a.config, rec.get("source"))
         resets = stats1["resets"] - stats0["resets"]; cycles = stats1["cycles"] - stats0["cycles"]
         rccl = None
         if dist is not None:

@@ -10,7 +10,7 @@ the reference's move-last-into-hole removal, minibatch draws, stages, target ref
 
 One iteration is ~65 kernel launches on one stream and ONE host wait (the actor mask); weights, history, activations and the replay rows stay on the
 device, no framework op runs inside an iteration. `trainer.MACETrainer` (PyTorch ops replayed as HIP graphs) stays as the peer the tests compare
-against, `oracle/trainer_ref.py` as the oracle. The product path is lib/libdtrl.so; there is no CPU fallback (tests bind the plain-loop check build
+against, the whole-trainer numpy restatement (test infrastructure) as the oracle. The product path is lib/libdtrl.so; there is no CPU fallback (tests bind the plain-loop check build
 of the same operand definitions from tests/emul through `lib_path`).
 """
 import ctypes as C

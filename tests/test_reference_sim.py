@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import REFERENCE, dog_policy
+from conftest import REFERENCE, REPO, dog_policy
 
 from oracle import refsim as rs
 
@@ -341,3 +341,32 @@ def test_ground_window_bit_exact_in_the_float_build(om, arg, seed):
     assert n > 16000
     if "slopes_mixed" in arg:
         assert e.stats()["terrain_builds"] >= builds0 + 2             # this one travels / falls far enough to move its window
+
+
+def test_integrator_v1_vs_bullet_shaped_sequential_impulse_bands(om):
+    """SURVEY 8a row a2 quantified: the REFERENCE'S OWN controllers (compiled, oracle/_ref/libref_sim.so) driven once by Integrator v1 (the product's
+    model, through the lock-step harness) and once by oracle/or_bullet_si.h (maximal coordinates, sequential impulse with Bullet 2.8x's published structure and
+    defaults) must produce the same gait within stated bands. Full study with ablations: tools/a2_deviation.py -> profiles/r03_a2_deviation.txt (10 seeds x 300
+    frames per scene; flat FSM scenes within 1.1 % on every statistic, dog slopes_mixed + MACE net within 3 % on cycle time / speed / duty / reward)."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import a2_deviation as a2
+    pols = a2.policies()
+    # (i) the clean gait comparison: FSM controllers on flat ground, no network, no falls
+    for scene, bands in ((a2.SCENES[0], dict(cycle_s=0.02, speed=0.04, reward=0.04, duty=0.03)), (a2.SCENES[1], dict(cycle_s=0.02, speed=0.04, reward=0.04, duty=0.03))):
+        v1 = a2.run(scene, "v1", [101, 102], 100, pols)
+        si = a2.run(scene, "si", [101, 102], 100, pols)
+        assert v1["falls_k"] == 0 and si["falls_k"] == 0, (scene[0], v1, si)
+        for k in ("cycle_s", "speed", "reward"):
+            assert abs(v1[k] - si[k]) <= bands[k] * abs(si[k]), (scene[0], k, v1[k], si[k])
+        for k in ("duty_front", "duty_back"):
+            assert abs(v1[k] - si[k]) <= bands["duty"], (scene[0], k, v1[k], si[k])
+        assert v1["n_cycles"] >= 10 and abs(v1["n_cycles"] - si["n_cycles"]) <= 1
+    # (ii) BASELINE configs[1]'s scene with the (synthetic) MACE policy: the same statistics over a short sample (3 seeds x 100 frames, ~45 cycles): wider bands
+    scene = a2.SCENES[2]
+    v1 = a2.run(scene, "v1", [101, 102, 103], 100, pols)
+    si = a2.run(scene, "si", [101, 102, 103], 100, pols)
+    print("slopes_mixed v1", v1); print("slopes_mixed SI", si)
+    assert abs(v1["cycle_s"] - si["cycle_s"]) <= 0.10 * si["cycle_s"] and abs(v1["speed"] - si["speed"]) <= 0.20 * abs(si["speed"])
+    assert abs(v1["duty_front"] - si["duty_front"]) <= 0.08 and abs(v1["duty_back"] - si["duty_back"]) <= 0.08
+    assert abs(v1["reward"] - si["reward"]) <= 0.2 * si["reward"]

@@ -9,7 +9,7 @@ import sys
 KERNEL = "dtrl_frame_kernel"
 
 
-def main(src, dst):
+def main(src, dst, cfg="1"):
     out = []
     traffic = {}
     bj = os.path.join(src, "bench.json")
@@ -17,11 +17,11 @@ def main(src, dst):
         for line in open(bj):
             line = line.strip()
             if line.startswith("{"):
-                out.append("## bench.py line (python bench.py --steps 60 --warmup 20)\n" + line + "\n")
+                out.append("## bench.py line (python bench.py --config %s --steps 60 --warmup 20)\n" % cfg + line + "\n")
     db = os.path.join(src, "stats", "stats_results.db")
     if os.path.exists(db):
         cur = sqlite3.connect(db).cursor()
-        out.append("## rocprofv3 --kernel-trace --stats -- python bench.py --steps 60 --warmup 20 --no-cpu-baseline")
+        out.append("## rocprofv3 --kernel-trace --stats -- python bench.py --config %s --steps 60 --warmup 20 --repeats 3 --no-cpu-baseline --exchange-steps 0" % cfg)
         out.append("%-60s %8s %14s %14s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for r in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
             out.append("%-60s %8d %14.1f %14.1f %8.3f" % (r[0][:60], r[1], r[2], r[3], r[4]))
@@ -31,16 +31,16 @@ def main(src, dst):
             out.append("  %8d %4d %10.3f %10.3f %10.3f %5s %5s %7s %7s" % (r[0], r[1], r[2] / 1e6, r[3] / 1e6, r[4] / 1e6, r[5], r[6], r[7], r[8]))
         dom = list(cur.execute("select grid_x from kernels where name like '%" + KERNEL + "%' group by grid_x order by sum(duration) desc limit 1"))
         if dom:
-            per_step = max(1, round(sum(1 for _ in cur.execute("select 1 from kernels where name like '%" + KERNEL + "%' and grid_x = ?", (dom[0][0],))) / 80.0))
-            last = [r[0] for r in cur.execute("select duration from kernels where name like '%" + KERNEL + "%' and grid_x = ? order by start desc limit ?", (dom[0][0], 60 * per_step))]
-            out.append("  timed region = last %d frame launches (grid %d, %d env-group launches per bench step): avg %.3f ms (compare roofline.kernel_avg_ms of the bench line)" % (len(last), dom[0][0], per_step, sum(last) / len(last) / 1e6))
+            per_step = 2   # env groups per frame (the engine splits a batch of >= 1024 envs in two)
+            last = [r[0] for r in cur.execute("select duration from kernels where name like '%" + KERNEL + "%' and grid_x = ? order by start desc limit ?", (dom[0][0], 180 * per_step))]
+            out.append("  timed region = last %d frame launches (grid %d, %d env-group launches per bench step, 3 windows x 60 frames): avg %.3f ms (compare roofline.kernel_avg_ms of the bench line)" % (len(last), dom[0][0], per_step, sum(last) / len(last) / 1e6))
         out.append("")
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_ic"):
         db = os.path.join(src, sub, "pmc_results.db")
         if not os.path.exists(db):
             continue
         cur = sqlite3.connect(db).cursor()
-        out.append("## rocprofv3 --pmc (%s pass) -- per-dispatch averages for %s (frame launches of the env groups only; bench.py --steps 20 --warmup 10)" % (sub, KERNEL))
+        out.append("## rocprofv3 --pmc (%s pass) -- per-dispatch averages for %s (frame launches of the env groups only; bench.py --config %s --steps 20 --warmup 10 --repeats 1: pre-roll + warm-up + window)" % (sub, KERNEL, cfg))
         q = ("select counter_name, count(*), avg(value), max(grid_size) from counters_collection where kernel_name like '%" + KERNEL + "%' "
              "and grid_size = (select grid_size from counters_collection where kernel_name like '%" + KERNEL + "%' group by grid_size order by count(*) desc limit 1) group by counter_name order by counter_name")
         for r in cur.execute(q):
@@ -60,10 +60,10 @@ def main(src, dst):
                "hbm_bytes_per_launch": 2.0 * traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"],
                "correction": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 read-request correction of MI355X_MICROARCH.md; separate --pmc passes)",
                "sq_insts_valu_per_launch": traffic.get("SQ_INSTS_VALU"),
-               "workload": "python bench.py --steps 20 --warmup 10 (4096 envs, full-batch frame launches only)"}
-        json.dump(rec, open(os.path.join(os.path.dirname(dst), "hbm_traffic.json"), "w"), indent=1)
+               "workload": "python bench.py --config %s --steps 20 --warmup 10 --repeats 1 (env-group frame launches only)" % cfg}
+        json.dump(rec, open(os.path.join(os.path.dirname(dst), "hbm_traffic_config%s.json" % cfg), "w"), indent=1)
     print("\n".join(out))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "1")
