@@ -451,6 +451,7 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		m.lim_lo[j] -= ref_theta; m.lim_hi[j] -= ref_theta;
 	}
 	m.contact_tol = 0.001 / world_scale;   // sim/ContactManager.cpp:74-75, dist_tol in world-scaled units
+	{ double margin = 0.04; args.ParseDouble("collision_margin", margin); m.contact_margin = margin / world_scale; }   // CONVEX_DISTANCE_MARGIN (world-scaled units)
 	// link--link collision pairs: same non-zero collision group, no hinge between the two, boxes overlapping in z (joint AttachZ accumulated down the
 	// chain + body AttachZ against the box depth Param2: the raptor's legs share a group but sit 0.16 m apart in z with 0.065 m deep boxes)
 	{
@@ -486,9 +487,16 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		const double c = std::cos(m.body_theta[j]), s = std::sin(m.body_theta[j]);
 		const double loc[kPtsPerLink][2] = {{-hx, -hy}, {hx, -hy}, {hx, hy}, {-hx, hy},
 			{hx >= hy ? 0.0 : -hx, hx >= hy ? -hy : 0.0}, {hx >= hy ? 0.0 : hx, hx >= hy ? hy : 0.0}};
+		// against the ground the boxes carry Bullet's collision margin (btBoxShape: core = half extents - margin, rounded by the margin; a half extent below
+		// the margin goes negative as Bullet's implicitShapeDimensions do): the ground test measures core point -> surface and subtracts the margin
+		const double gx = hx - m.contact_margin, gy = hy - m.contact_margin;
+		const double locg[kPtsPerLink][2] = {{-gx, -gy}, {gx, -gy}, {gx, gy}, {-gx, gy},
+			{hx >= hy ? 0.0 : -gx, hx >= hy ? -gy : 0.0}, {hx >= hy ? 0.0 : gx, hx >= hy ? gy : 0.0}};
 		for (int k = 0; k < kPtsPerLink; ++k) {
 			m.pt_joint[j][k][0] = m.body_attach[j][0] + c * loc[k][0] - s * loc[k][1];
 			m.pt_joint[j][k][1] = m.body_attach[j][1] + s * loc[k][0] + c * loc[k][1];
+			m.pt_ground[j][k][0] = m.body_attach[j][0] + c * locg[k][0] - s * locg[k][1];
+			m.pt_ground[j][k][1] = m.body_attach[j][1] + s * locg[k][0] + c * locg[k][1];
 		}
 		m.eff_joint[j][0] = m.body_attach[j][0] - s * (-hy);
 		m.eff_joint[j][1] = m.body_attach[j][1] + c * (-hy);

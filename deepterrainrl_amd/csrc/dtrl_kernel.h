@@ -644,16 +644,17 @@ DTRL_HD_INLINE PtVal contact_point_eval(const W& ws, const DevModel& gm, const G
 	const int j = pt / kPtsPerLink, k = pt - j * kPtsPerLink;
 	const GroundHdr gh = ground_header(g);   // issued with the sample point's local coordinates below: one trip to memory for both
 	if (ws.M.col[j] == 0) return r;
-	const real lx = gm.pt_joint[j][k][0], ly = gm.pt_joint[j][k][1];
+	const real lx = gm.pt_ground[j][k][0], ly = gm.pt_ground[j][k][1];   // point of the margin-shrunk box
 	const real c = ws.cs[j], s = ws.sn[j];
 	const real x = ws.px[j] + c * lx - s * ly;
 	const real y = ws.py[j] + s * lx + c * ly;
 	real slope;
 	const real h = sample_ground(g, gh, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
 	const real gap = h - (ws.st.q[1] + y);
-	if (!kNear && !(gap > 0)) return r;                 // inside a substep only penetrating points matter (depth = gap * ny, ny > 0): skip the normal
+	// inside a substep only penetrating points matter: depth = gap * ny + margin > 0 needs gap > -margin / ny, and 1 / ny = sqrt(1 + slope^2) <= 1 + |slope|
+	if (!kNear && !(gap + gm.contact_margin * (1.0 + fabs(slope)) > 0)) return r;
 	const real inv = fast_rsqrt(1.0 + slope * slope);
-	const real depth = gap * inv;                       // along the cell normal (ny = inv > 0)
+	const real depth = fmadd(gap, inv, gm.contact_margin);   // along the cell normal (ny = inv > 0), to the ROUNDED surface of the box (Bullet's collision margin)
 	if (kNear) r.near = depth >= -gm.contact_tol ? 1 : 0;   // cContactManager::Update: getDistance() <= dist_tol
 	if (!(depth > 0)) return r;
 	r.nx = -slope * inv; r.ny = inv;

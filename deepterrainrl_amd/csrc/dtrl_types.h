@@ -74,7 +74,9 @@ struct DevModel {
 	real act_blend[kMaxAct];
 	real ctrl_params[kMaxSets][kMaxP];
 	real pose0[kMaxD], vel0[kMaxD];
-	real pt_joint[kMaxL][kPtsPerLink][2];   // contact sample points in the JOINT frame: body_attach + R(body_theta) * corner
+	real pt_joint[kMaxL][kPtsPerLink][2];   // contact sample points in the JOINT frame: body_attach + R(body_theta) * corner (link--link tests: sharp boxes)
+	real pt_ground[kMaxL][kPtsPerLink][2];  // the same points of the MARGIN-SHRUNK box (ground test: core point -> surface, minus contact_margin)
+	real contact_margin;                    // Bullet's CONVEX_DISTANCE_MARGIN 0.04 in world-scaled units = 0.04 / world_scale metres (-collision_margin= overrides; 0 = sharp boxes)
 	real eff_joint[kMaxL][2];               // body-local (0, -size_y/2) in the joint frame (end-effector contact position)
 	real init_pos_x, target_vel_x, total_mass;
 	real world_scale;

@@ -62,6 +62,9 @@ struct OrcModel {
 	// sim/SimCharacter.cpp:864). a < b. link_contacts = 0 switches the pair contacts off (the round-1 model)
 	int32_t link_contacts, n_cpairs;
 	int32_t cpair_a[ORC_MAXCP], cpair_b[ORC_MAXCP];
+	// collision margin of the box links against the GROUND, metres: Bullet's CONVEX_DISTANCE_MARGIN 0.04 in world-scaled units = 0.04 / world_scale (1 cm for the
+	// dog at world scale 4, 4 cm for the goat scene whose arg file leaves the scale at 1). 0 = sharp boxes (the round-2 model, -collision_margin= 0)
+	double contact_margin;
 };
 
 // MACE network family of data/policies/*/nets/*_mace3_deploy.prototxt

@@ -22,6 +22,9 @@
 //     (sim/ContactManager.cpp:74-75: pt.getDistance() <= 0.001f), i.e. separation <= 0.001 / world_scale, not only when it penetrates;
 //   * at most 4 contact points per link and ground (Bullet's persistent manifold holds 4 points per pair): the deepest four of the link's
 //     penetrating sample points; when the row budget is exceeded the DEEPEST points overall get rows (not the lowest link ids).
+// Round 3: the box links carry Bullet's collision margin against the ground (M.contact_margin = 0.04 / world_scale): sample points sit on the margin-shrunk
+//   box and the separation is measured to the rounded surface. tools/a2_deviation.py found the margin to be what separated this model from the Bullet-shaped
+//   sequential-impulse integrator on the goat scene (world scale 1: a 4 cm margin on 3-5 cm thick links).
 #pragma once
 #include "or_rbd.h"
 #include "or_terrain.h"
@@ -80,17 +83,19 @@ inline void ForwardKin(const OrcModel& M, const double* q, const double* qd, Bod
 	}
 }
 
-// body-frame sample points of link j (documented contact model)
-inline void LinkSamplePoint(const OrcModel& M, int j, int k, double& sx, double& sy)
+// body-frame sample points of link j (documented contact model). shrink > 0: the points of the MARGIN-SHRUNK box (Bullet's btBoxShape keeps half extents -
+// margin as its core and adds the margin back as a rounding radius: the ground test below measures core point -> surface and subtracts the margin; a half
+// extent smaller than the margin goes negative, as Bullet's implicitShapeDimensions do)
+inline void LinkSamplePoint(const OrcModel& M, int j, int k, double& sx, double& sy, double shrink = 0.0)
 {
-	double hx = 0.5 * M.body_size[j][0], hy = 0.5 * M.body_size[j][1];
+	double hx = 0.5 * M.body_size[j][0] - shrink, hy = 0.5 * M.body_size[j][1] - shrink;
 	switch (k) {
 	case 0: sx = -hx; sy = -hy; break;
 	case 1: sx = hx; sy = -hy; break;
 	case 2: sx = hx; sy = hy; break;
 	case 3: sx = -hx; sy = hy; break;
-	case 4: if (hx >= hy) { sx = 0; sy = -hy; } else { sx = -hx; sy = 0; } break;
-	default: if (hx >= hy) { sx = 0; sy = hy; } else { sx = hx; sy = 0; } break;
+	case 4: if (M.body_size[j][0] >= M.body_size[j][1]) { sx = 0; sy = -hy; } else { sx = -hx; sy = 0; } break;
+	default: if (M.body_size[j][0] >= M.body_size[j][1]) { sx = 0; sy = hy; } else { sx = hx; sy = 0; } break;
 	}
 }
 
@@ -115,10 +120,10 @@ inline void ContactDistances(const OrcModel& M, const Bodies& B, const Ground& g
 			double& d = out[j * SimConst::pts_per_link + k];
 			d = 1e30;
 			if (M.col_group[j] == 0) continue;
-			double sx, sy; LinkSamplePoint(M, j, k, sx, sy);
+			double sx, sy; LinkSamplePoint(M, j, k, sx, sy, M.contact_margin);
 			double x = B.cx[j] + c * sx - s * sy, y = B.cy[j] + s * sx + c * sy;
 			double slope = g.SampleSlope(x);
-			d = -(g.SampleHeight(x) - y) / std::sqrt(1.0 + slope * slope);
+			d = -(g.SampleHeight(x) - y) / std::sqrt(1.0 + slope * slope) - M.contact_margin;
 		}
 	}
 }
@@ -137,14 +142,14 @@ inline int DetectContacts(const OrcModel& M, const Bodies& B, const Ground& g, C
 		if (M.col_group[j] == 0) continue;
 		double c = std::cos(B.psi[j]), s = std::sin(B.psi[j]);
 		for (int k = 0; k < SimConst::pts_per_link; ++k) {
-			double sx, sy; LinkSamplePoint(M, j, k, sx, sy);
+			double sx, sy; LinkSamplePoint(M, j, k, sx, sy, M.contact_margin);
 			double x = B.cx[j] + c * sx - s * sy;
 			double y = B.cy[j] + s * sx + c * sy;
 			double h = g.SampleHeight(x);
 			double slope = g.SampleSlope(x);
 			double inv = 1.0 / std::sqrt(1.0 + slope * slope);
 			double nx = -slope * inv, ny = inv;
-			double depth = (h - y) * ny;
+			double depth = std::fma(h - y, ny, M.contact_margin);   // the rounded corner reaches a margin beyond the core point (fused, as the kernel does)
 			if (depth >= -tol) flags[j] = true;                 // cContactManager::Update: distance <= dist_tol
 			ContactPoint& p = all[j * SimConst::pts_per_link + k];
 			p.link = j; p.x = x; p.y = y; p.depth = depth; p.nx = nx; p.ny = ny;

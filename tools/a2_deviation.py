@@ -80,7 +80,7 @@ class Stats:
         c = np.array(self.cycles) if self.cycles else np.zeros(1)
         return dict(env_steps=self.steps, cycle_s=float(c.mean()), cycle_sd=float(c.std()), n_cycles=len(self.cycles), speed=self.speed / n, falls_k=1000.0 * self.falls / n,
                     duty_front=float(self.duty[0] / n), duty_back=float(self.duty[1] / n), ep_dist=float(np.mean(self.dists)) if self.dists else float("nan"),
-                    n_episodes=len(self.dists), reward=float(np.mean(self.rewards)) if self.rewards else float("nan"))
+                    n_episodes=len(self.dists), reward=float(np.nanmean(self.rewards)) if self.rewards else float("nan"))
 
 
 def run(scene, integrator, seeds, frames, pols, si_opts=None):
