@@ -22,7 +22,7 @@ template <int OP>
 __device__ __forceinline__ void tr_gemm_tile(const NetDims& d, const Work& wk, GemmDesc g, int z, float (&As)[kTK][kTM + 1], float (&Bs)[kTK][kTN + 1])
 {
 	g.op = OP;
-	const int tid = static_cast<int>(threadIdx.x), ty = tid >> 4, tx = tid & 15;
+	const int tid = static_cast<int>(threadIdx.x);
 	const int m0 = static_cast<int>(blockIdx.y) * kTM, n0 = static_cast<int>(blockIdx.x) * kTN;
 	if (m0 >= g.M || n0 >= g.N) return;   // (a fused launch is sized for the larger of its two products)
 	const int k_begin = g.k0_step ? z * g.k0_step : 0;
@@ -48,7 +48,12 @@ __device__ __forceinline__ void tr_gemm_tile(const NetDims& d, const Work& wk, G
 			rb[i] = (n < g.N && k < k_end) ? load_b(d, wk, g, z, k, n) : 0.0f;
 		}
 	};
-	float acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+	// tile product on the fp32 matrix pipe: wavefront w owns the 32 x 32 sub-tile of columns 32 (w & 1) .. and the half (w >> 1) of every K chunk; one
+	// v_mfma_f32_32x32x2f32 per pair of k values (operands: A[i = lane % 32][k = lane / 32], B[k = lane / 32][j = lane % 32], one float each), the two K halves
+	// are added through LDS at the end. Per chunk and wave: 16 matrix instructions and 32 LDS reads (the VALU form took 512 FMAs and 384 reads)
+	typedef float v16f_t __attribute__((ext_vector_type(16)));
+	const int wave = tid >> 6, lane = tid & 63, nsub = wave & 1, khalf = wave >> 1, li = lane & 31, lk = lane >> 5;
+	v16f_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	fetch(k_begin);
 	for (int k0 = k_begin; k0 < k_end; k0 += kTK) {
 #pragma unroll
@@ -57,22 +62,31 @@ __device__ __forceinline__ void tr_gemm_tile(const NetDims& d, const Work& wk, G
 		for (int i = 0; i < kRB; ++i) { const int e = tid + i * kThreads; if (g.b_kfast) Bs[e % kTK][e / kTK] = rb[i]; else Bs[e / kTN][e % kTN] = rb[i]; }
 		__syncthreads();
 		if (k0 + kTK < k_end) fetch(k0 + kTK);
+		const int kb = khalf * (kTK / 2);
 #pragma unroll
-		for (int kk = 0; kk < kTK; ++kk) {
-			const float a0 = As[kk][ty], a1 = As[kk][ty + 16];
-			const float b0 = Bs[kk][tx], b1 = Bs[kk][tx + 16], b2 = Bs[kk][tx + 32], b3 = Bs[kk][tx + 48];
-			acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]); acc[0][2] = fmaf(a0, b2, acc[0][2]); acc[0][3] = fmaf(a0, b3, acc[0][3]);
-			acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]); acc[1][2] = fmaf(a1, b2, acc[1][2]); acc[1][3] = fmaf(a1, b3, acc[1][3]);
+		for (int kk = 0; kk < kTK / 2; kk += 2) {
+			const float a = As[kb + kk + lk][li];
+			const float b = Bs[kb + kk + lk][nsub * 32 + li];
+			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
 		}
 		__syncthreads();
 	}
+	// K halves: waves 2, 3 park their partial tiles in LDS (the operand tiles are dead), waves 0, 1 add and store. Result register r of lane l is
+	// C[8 (r / 4) + 4 (l / 32) + r % 4][l % 32]
+	float* part = &Bs[0][0];   // 2 x 32 x 32 floats = 8 KB of the 16.6 KB
+	if (khalf == 1) {
 #pragma unroll
-	for (int i = 0; i < 2; ++i)
+		for (int r = 0; r < 16; ++r) part[(nsub * 16 + r) * 64 + lane] = acc[r];
+	}
+	__syncthreads();
+	if (khalf == 0) {
 #pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
-			if (m < g.M && n < g.N) store_c(d, wk, g, z, m, n, acc[i][j]);
+		for (int r = 0; r < 16; ++r) {
+			const float v = acc[r] + part[(nsub * 16 + r) * 64 + lane];
+			const int m = m0 + 8 * (r >> 2) + 4 * lk + (r & 3), n = n0 + nsub * 32 + li;
+			if (m < g.M && n < g.N) store_c(d, wk, g, z, m, n, v);
 		}
+	}
 }
 template <int OP>
 __global__ void __launch_bounds__(kThreads) tr_gemm_kernel(const NetDims* __restrict__ dp, const Work* __restrict__ wp, GemmDesc g)

@@ -59,7 +59,7 @@ class OrcModel(C.Structure):
         ("scenario", C.c_int32), ("tuple_buffer_size", C.c_int32), ("enable_explore", C.c_int32),
         ("exp_rate", C.c_double), ("exp_temp", C.c_double), ("exp_base_rate", C.c_double),
         ("link_contacts", C.c_int32), ("n_cpairs", C.c_int32), ("cpair_a", C.c_int32 * MAXCP), ("cpair_b", C.c_int32 * MAXCP),
-        ("contact_margin", C.c_double),
+        ("contact_margin", C.c_double), ("warm_start", C.c_int32),
     ]
 
 
@@ -263,6 +263,7 @@ def build_model(arg_file, root, overrides=None):
     m.num_sim_substeps = int(args.get("num_sim_substeps", 1))
     m.world_scale = float(args.get("world_scale", 1))
     m.contact_margin = float(args.get("collision_margin", 0.04)) / m.world_scale   # CONVEX_DISTANCE_MARGIN, world-scaled units -> metres
+    m.warm_start = int(args.get("warm_start", 0))
     m.terrain_type = 0
     m.n_terrain_sets = 1
     dflt = [d for _, d in TERRAIN_PARAMS]

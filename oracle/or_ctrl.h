@@ -248,6 +248,7 @@ struct Env {
 	// ---- character reset: cSimCharacter::Reset + cScenarioSimChar::InitCharacterPos -----------------
 	void ResetCharacter()
 	{
+		integ.ResetWarmStart();
 		for (int i = 0; i < D; ++i) { q[i] = M.pose0[i]; qd[i] = M.vel0[i]; }
 		ForwardKin(M, q, qd, B);
 		// controller Reset (cTerrainRLCharController::Reset -> ApplyAction(default); cDogController::Reset)

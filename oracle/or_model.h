@@ -65,6 +65,7 @@ struct OrcModel {
 	// collision margin of the box links against the GROUND, metres: Bullet's CONVEX_DISTANCE_MARGIN 0.04 in world-scaled units = 0.04 / world_scale (1 cm for the
 	// dog at world scale 4, 4 cm for the goat scene whose arg file leaves the scale at 1). 0 = sharp boxes (the round-2 model, -collision_margin= 0)
 	double contact_margin;
+	int32_t warm_start;    // experiment switch (-warm_start= 1): constraint rows start the sweeps from 0.85 x their previous impulse (oracle only: tools/a2_deviation.py)
 };
 
 // MACE network family of data/policies/*/nets/*_mace3_deploy.prototxt

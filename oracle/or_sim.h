@@ -45,6 +45,7 @@ struct SimConst {
 	static constexpr int max_pts_per_pair = 2;      // points of one link--link manifold: two convex boxes in the plane touch along a segment at most (Bullet's four 3-D manifold points project onto two)
 	static constexpr double contact_dist_tol = 0.001;   // world-scaled units (sim/ContactManager.cpp:74)
 	static constexpr double max_turn_per_substep = 1.5707963267948966;
+	static constexpr double warmstart_factor = 0.85;   // btContactSolverInfo::m_warmstartingFactor
 };
 
 struct Bodies {
@@ -99,7 +100,7 @@ inline void LinkSamplePoint(const OrcModel& M, int j, int k, double& sx, double&
 	}
 }
 
-struct ContactPoint { int link; double x, y, depth, nx, ny; };
+struct ContactPoint { int link; double x, y, depth, nx, ny; int pt; };
 
 // separation of a world point from box `q` (negative inside): max over the two face pairs of (|local coordinate| - half extent); *lx, *ly = local coordinates
 inline void PointInBox(const OrcModel& M, const Bodies& B, int q, double x, double y, double& pen_x, double& pen_y, double& lx, double& ly)
@@ -152,7 +153,7 @@ inline int DetectContacts(const OrcModel& M, const Bodies& B, const Ground& g, C
 			double depth = std::fma(h - y, ny, M.contact_margin);   // the rounded corner reaches a margin beyond the core point (fused, as the kernel does)
 			if (depth >= -tol) flags[j] = true;                 // cContactManager::Update: distance <= dist_tol
 			ContactPoint& p = all[j * SimConst::pts_per_link + k];
-			p.link = j; p.x = x; p.y = y; p.depth = depth; p.nx = nx; p.ny = ny;
+			p.link = j; p.x = x; p.y = y; p.depth = depth; p.nx = nx; p.ny = ny; p.pt = j * SimConst::pts_per_link + k;
 			active[j * SimConst::pts_per_link + k] = depth > 0;
 		}
 	}
@@ -186,7 +187,7 @@ inline int DetectContacts(const OrcModel& M, const Bodies& B, const Ground& g, C
 }
 
 // ---- link--link contacts (same collision group, no hinge between them): the sample points of either box tested against the other box ----
-struct PairContact { int a, b; double x, y, depth, nx, ny; };   // the normal pushes link a along +n and link b along -n
+struct PairContact { int a, b; double x, y, depth, nx, ny; int cand, pair; };   // the normal pushes link a along +n and link b along -n
 // candidates of pair (a, b) in the order: a's six sample points against b's box, then b's six against a's. Returns the number of penetrating candidates
 // written to cand (<= 12); *min_sep (may be null) = the smallest separation of any candidate point from the partner's box (what a narrowphase would
 // report as the pair manifold's distance). Link--link contacts never set a link's contact FLAG: cScenarioSimChar registers the character's parts with
@@ -208,7 +209,7 @@ inline int PairCandidates(const OrcModel& M, const Bodies& B, int a, int b, Pair
 			double nlx = 0, nly = 0, depth;
 			if (px <= py) { nlx = lx >= 0 ? 1.0 : -1.0; depth = px; } else { nly = ly >= 0 ? 1.0 : -1.0; depth = py; }
 			PairContact& c = cand[n++];
-			c.a = P; c.b = Q; c.x = x; c.y = y; c.depth = depth;
+			c.a = P; c.b = Q; c.x = x; c.y = y; c.depth = depth; c.cand = side * SimConst::pts_per_link + k;
 			c.nx = cq * nlx - sq * nly; c.ny = sq * nlx + cq * nly;
 		}
 	}
@@ -237,7 +238,7 @@ inline int DetectPairContacts(const OrcModel& M, const Bodies& B, PairContact* o
 		for (int i = 0; i < nc; ++i) {
 			int rank = 0;
 			for (int o = 0; o < nc; ++o) if (o != i && (cand[o].depth > cand[i].depth || (cand[o].depth == cand[i].depth && o < i))) ++rank;
-			if (rank < SimConst::max_pts_per_pair && n < cap) out[n++] = cand[i];
+			if (rank < SimConst::max_pts_per_pair && n < cap) { out[n] = cand[i]; out[n].pair = pr; ++n; }
 		}
 	}
 	return n;
@@ -249,6 +250,12 @@ struct Integrator {
 	double Yr[SimConst::max_rows][ORC_MAXD];
 	double Arr[SimConst::max_rows], tgt[SimConst::max_rows], lam[SimConst::max_rows];
 	int kind[SimConst::max_rows];  // 0 = limit (lambda >= 0), 1 = contact normal, 2 = contact tangent (paired with previous row)
+	// warm starting (M.warm_start): a row keeps its identity across substeps -- limit (joint, side), ground contact (sample point, normal / tangent), link--link
+	// contact (pair, candidate, normal / tangent) -- and starts the sweeps from warmstart_factor x the impulse it ended the previous substep with (Bullet:
+	// btContactSolverInfo::m_warmstartingFactor 0.85 on the persistent manifold points' applied impulses)
+	int id[SimConst::max_rows], prev_id[SimConst::max_rows], prev_R = 0;
+	double prev_lam[SimConst::max_rows];
+	void ResetWarmStart() { prev_R = 0; }
 
 	void PointJacobian(const OrcModel& M, const Bodies& B, int link, double x, double y, double dx, double dy, double* row, int D) const
 	{
@@ -295,10 +302,10 @@ struct Integrator {
 			const double lo = M.lim_lo[j] - M.ref_theta[j], hi = M.lim_hi[j] - M.ref_theta[j];   // limits act on theta + ref_theta
 			if (th <= lo + SimConst::limit_slop && R < SimConst::max_rows) {
 				for (int i = 0; i < D; ++i) Jr[R][i] = 0;
-				Jr[R][j + 2] = 1; kind[R] = 0; tgt[R] = SimConst::limit_erp * std::max(lo - th, 0.0) / h; ++R;
+				Jr[R][j + 2] = 1; kind[R] = 0; id[R] = 2 * j; tgt[R] = SimConst::limit_erp * std::max(lo - th, 0.0) / h; ++R;
 			} else if (th >= hi - SimConst::limit_slop && R < SimConst::max_rows) {
 				for (int i = 0; i < D; ++i) Jr[R][i] = 0;
-				Jr[R][j + 2] = -1; kind[R] = 0; tgt[R] = SimConst::limit_erp * std::max(th - hi, 0.0) / h; ++R;
+				Jr[R][j + 2] = -1; kind[R] = 0; id[R] = 2 * j + 1; tgt[R] = SimConst::limit_erp * std::max(th - hi, 0.0) / h; ++R;
 			}
 		}
 		ContactPoint cps[SimConst::max_rows / 2];
@@ -308,11 +315,11 @@ struct Integrator {
 		for (int c = 0; c < nc; ++c) {
 			const ContactPoint& cp = cps[c];
 			PointJacobian(M, B, cp.link, cp.x, cp.y, cp.nx, cp.ny, Jr[R], D);
-			kind[R] = 1;
+			kind[R] = 1; id[R] = 64 + 2 * cp.pt;
 			double t = SimConst::erp * std::max(cp.depth - SimConst::slop, 0.0) / h;
 			tgt[R] = std::min(t, SimConst::v_depen_max); ++R;
 			PointJacobian(M, B, cp.link, cp.x, cp.y, cp.ny, -cp.nx, Jr[R], D);
-			kind[R] = 2; tgt[R] = 0; ++R;
+			kind[R] = 2; id[R] = 64 + 2 * cp.pt + 1; tgt[R] = 0; ++R;
 		}
 		// link--link contacts take what is left of the row budget, in pair order
 		PairContact pcs[SimConst::max_rows / 2];
@@ -325,7 +332,7 @@ struct Integrator {
 				PointJacobian(M, B, pc.a, pc.x, pc.y, dx, dy, Jr[R], D);
 				PointJacobian(M, B, pc.b, pc.x, pc.y, dx, dy, jb, D);
 				for (int i = 0; i < D; ++i) Jr[R][i] -= jb[i];
-				kind[R] = 1 + t;
+				kind[R] = 1 + t; id[R] = 64 + 2 * ORC_MAXL * SimConst::pts_per_link + 2 * (pc.pair * 2 * SimConst::pts_per_link + pc.cand) + t;
 				tgt[R] = 0.0;   // velocity-level non-penetration only (see DetectPairContacts)
 				++R;
 			}
@@ -334,6 +341,13 @@ struct Integrator {
 			SolveLDLT(D, Hm, D, Jr[r], Yr[r]);
 			double a = 0; for (int i = 0; i < D; ++i) a += Jr[r][i] * Yr[r][i];
 			Arr[r] = a; lam[r] = 0;
+		}
+		if (M.warm_start) {
+			for (int r = 0; r < R; ++r) {
+				if (Arr[r] < 1e-12) continue;
+				for (int p = 0; p < prev_R; ++p) if (prev_id[p] == id[r]) { lam[r] = SimConst::warmstart_factor * prev_lam[p]; break; }
+			}
+			for (int r = 0; r < R; ++r) if (lam[r] != 0) for (int i = 0; i < D; ++i) v[i] += Yr[r][i] * lam[r];
 		}
 		for (int it = 0; it < SimConst::pgs_iters; ++it) {
 			for (int r = 0; r < R; ++r) {
@@ -347,6 +361,8 @@ struct Integrator {
 				for (int i = 0; i < D; ++i) v[i] += Yr[r][i] * dl;
 			}
 		}
+		prev_R = R;
+		for (int r = 0; r < R; ++r) { prev_id[r] = id[r]; prev_lam[r] = lam[r]; }
 		// Bullet clamps a body's angular velocity to MAX_ANGVEL = pi / 2 per internal step (btRigidBody::integrateVelocities); in joint coordinates: every hinge
 		// rate and the root's spin. 4712 rad/s at 1/3000 s: only the whipping tail of a crashed character gets there, and unclamped the explicit Coriolis terms overflow
 		const double vmax = SimConst::max_turn_per_substep / h;

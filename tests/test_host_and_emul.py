@@ -805,7 +805,7 @@ def test_product_vs_frozen_reference_config_traces(da, om, run):
     assert info["resets_tracked"] >= min(1, CONFIG_MIN_RESETS[run[0]]), info
 
 
-TUPLE_RUNS = [("exp_mace", "args/opt_args_train_mace.txt", 21, "dog", 2), ("raptor_exp_mace", "args/opt_args_train_raptor_mace.txt", 15, "raptor", 0),
+TUPLE_RUNS = [("exp_mace", "args/opt_args_train_mace.txt", 21, "dog", 2), ("raptor_exp_mace", "args/opt_args_train_raptor_mace.txt", 29, "raptor", 0),
               ("exp_q", "args/opt_args_train_q.txt", 33, "q", 1)]
 
 

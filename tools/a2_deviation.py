@@ -83,11 +83,11 @@ class Stats:
                     n_episodes=len(self.dists), reward=float(np.nanmean(self.rewards)) if self.rewards else float("nan"))
 
 
-def run(scene, integrator, seeds, frames, pols, si_opts=None):
+def run(scene, integrator, seeds, frames, pols, si_opts=None, v1_overrides=None):
     tag, arg, char, polname = scene
     st = Stats(FEET[char])
     for seed in seeds:
-        m, _ = om.build_model(arg, REF)
+        m, _ = om.build_model(arg, REF, overrides=v1_overrides or {})
         pol = pols[polname] if polname else None
         e = om.OracleEnv(m, terrain_seed=seed, policy=pol)
         if pol is not None:
@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--ablate", action="store_true")
     ap.add_argument("--scenes", default="", help="comma-separated scene indices (default: all)")
+    ap.add_argument("--v1-warm-start", action="store_true", help="also run Integrator v1 with the oracle-only warm-start experiment switch (-warm_start= 1)")
     a = ap.parse_args()
     assert rs.available(), "oracle/_ref/libref_sim.so missing: make -C oracle/_ref_build"
     pols = policies()
@@ -173,6 +174,10 @@ def main():
         lines.append("  v1   " + fmt(v1))
         lines.append("  SI   " + fmt(si))
         lines.append("  rel  " + "  ".join("%s %+7.1f%%" % (k, 100.0 * (v1[k] - si[k]) / si[k]) if si[k] and np.isfinite(si[k]) and np.isfinite(v1[k]) else "%s     n/a" % k for k in KEYS))
+        if a.v1_warm_start:
+            ws = run(sc, "v1", seeds, a.frames, pols, v1_overrides={"warm_start": 1})
+            results[sc[0]]["v1, warm start"] = ws
+            lines.append("  v1 + warm start (oracle-only experiment)  " + fmt(ws))
         if a.ablate:
             for name, opts in (("no margin", dict(use_margin=0)), ("no warm start", dict(warmstarting=0)), ("no split impulse", dict(split_impulse=0)),
                                ("no link contacts", dict(link_contacts=0)), ("1 point per pair", dict(max_points=1)), ("erp 0.8 joints", dict(erp=0.8)), ("20 iterations", dict(iterations=20))):
