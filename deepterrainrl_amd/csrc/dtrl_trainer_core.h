@@ -18,6 +18,14 @@ namespace dtrl_tr {
 // ---- element-wise functors (index space = [0, n)) ----
 struct FGatherNorm { int S; Norm nm; const float* mem; int W; const int64_t* idx; int col0; float* xin;
 	TR_HD void operator()(int64_t i) const { gather_norm_elem(S, nm, mem, W, idx, col0, xin, i); } };
+// up to four windows of rows gathered in ONE launch: window v covers rows [v n, (v + 1) n) of xin and reads column col0[v] of the replay rows idx[v][.]
+struct FGatherMulti { int S; Norm nm; const float* mem; int W; int n; const int64_t* idx[4]; int col0[4]; float* xin;
+	TR_HD void operator()(int64_t i) const
+	{
+		const int64_t per = static_cast<int64_t>(n) * S;
+		const int v = static_cast<int>(i / per);
+		gather_norm_elem(S, nm, mem, W, idx[v], col0[v], xin + v * per, i - v * per);
+	} };
 struct FNormIn { int S; Norm nm; const float* X; float* xin;     // xin = (X + in_off) * in_scale for caller-supplied rows
 	TR_HD void operator()(int64_t i) const { const int j = static_cast<int>(i % S); xin[i] = (X[i] + nm.in_off[j]) * nm.in_scale[j]; } };
 // (dims / work descriptors are read through pointers to their device-resident copies: a by-value struct whose arrays are indexed with a run-time layer or
@@ -69,6 +77,32 @@ struct FActorFilter { Norm nm; const float* tout; int out_size, n_frags, n; cons
 		float q = unnorm_out(nm, tout[m * out_size], 0);
 		for (int f = 1; f < n_frags; ++f) { const float v = unnorm_out(nm, tout[m * out_size + f], f); q = v > q ? v : q; }
 		better[m] = newq[m] > q ? 1 : 0;
+	} };
+
+// the fused pass's targets in one launch: thread m < n -> new_q of critic row m; n <= m < 2 n -> candidate m - n: its new_q and the test against Q_target(s)
+struct FFusedTargets { Norm nm; const float* mem; int W; const int64_t* idx; const int64_t* cand; const int64_t* flags; const float* tout; int out_size, n_frags, n; float discount; float* newq; int32_t* better;
+	TR_HD void operator()(int64_t t) const
+	{
+		if (t < n) { FNewQ{nm, mem, W, idx, flags, tout, out_size, n_frags, discount, newq}(t); return; }
+		const int64_t m = t - n;
+		FNewQ{nm, mem, W, cand, flags, tout + static_cast<size_t>(2 * n) * out_size, out_size, n_frags, discount, newq + n}(m);
+		FActorFilter{nm, tout + static_cast<size_t>(n) * out_size, out_size, n_frags, n, newq + n, better}(m);
+	} };
+// SGD step with the conv layers' weight / bias gradients reduced from their per-sample partials on the fly (one launch instead of two)
+struct FSgdConv { const NetDims* d; const Work* wk; int64_t conv_end; float* w; float* hist; float* g; const float* rate_mult; const float* decay_mult; float rate, momentum, weight_decay;
+	TR_HD void operator()(int64_t i) const
+	{
+		if (i < conv_end) {
+			const NetDims& D = *d;
+			int l = 0; while (l < 2 && i >= D.wo_conv[l + 1]) ++l;
+			const int Kc = D.C[l] * D.Kw[l], N = Kc + 1, M = D.C[l + 1];
+			int m, n;
+			if (i >= D.bo_conv[l]) { m = static_cast<int>(i - D.bo_conv[l]); n = Kc; } else { const int64_t o = i - D.wo_conv[l]; m = static_cast<int>(o / Kc); n = static_cast<int>(o % Kc); }
+			float s = 0;
+			for (int z = 0; z < wk->rows; ++z) s += wk->pw[l][(static_cast<size_t>(z) * M + m) * N + n];
+			g[i] = s;
+		}
+		sgd_elem(w, hist, g, rate_mult, decay_mult, rate, momentum, weight_decay, i);
 	} };
 
 struct TrainerConfig {
@@ -148,9 +182,7 @@ public:
 			GemmDesc g = make_gemm(d, rows, kConvBw, l); g.b_kfast = 1;
 			if (l > 0) be.gemm2(d_dims, wk, g, make_gemm(d, rows, kConvBx, l)); else be.gemm(d_dims, wk, g);
 		}
-		const int n0 = d.C[1] * (d.C[0] * d.Kw[0] + 1), n1 = n0 + d.C[2] * (d.C[1] * d.Kw[1] + 1), n2 = n1 + d.C[3] * (d.C[2] * d.Kw[2] + 1);
-		be.for_each(n2, FConvGrad{d_dims, wk, n0, n1});
-		be.for_each(d.num_params, FSgd{w_cur, hist, grad, rate_mult, decay_mult, cfg.base_lr, cfg.momentum, cfg.weight_decay});
+		be.for_each(d.num_params, FSgdConv{d_dims, wk, d.wo_terr, w_cur, hist, grad, rate_mult, decay_mult, cfg.base_lr, cfg.momentum, cfg.weight_decay});
 	}
 
 	// ---- API ----
@@ -171,8 +203,7 @@ public:
 		const int n = cfg.batch;
 		be.for_each(static_cast<int64_t>(n) * d.S, FNormIn{d.S, norm(), X, train.xin});
 		Forward(d_train, n);
-		be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d.out_size, norm(), 0, Y, nullptr, 0, d.S, nullptr, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
-		be.loss_sum(sq, n * d.out_size, 0.5f / static_cast<float>(n), loss_host);
+		be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 0, Y, nullptr, 0, d.S, nullptr, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host);
 		BackwardAndUpdate();
 		return be.ok();
 	}
@@ -191,17 +222,12 @@ public:
 			const NetDims& d = cfg.dims;
 			const int n = cfg.batch, S = d.S, A = 1 + cfg.frag_size;
 			const int64_t* cand = idx_host + n;
-			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1 + S + A, eval.xin});
-			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, cand, 1, eval.xin + static_cast<size_t>(n) * S});
-			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, cand, 1 + S + A, eval.xin + static_cast<size_t>(2 * n) * S});
+			be.for_each(static_cast<int64_t>(3 * n) * S, FGatherMulti{S, norm(), mem_, W_, n, {idx_host, cand, cand, nullptr}, {1 + S + A, 1, 1 + S + A, 0}, eval.xin});
+			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1, train.xin});   // (independent of the target pass: queued first)
 			Forward(d_eval_tgt, 3 * n);
-			be.for_each(n, FNewQ{norm(), mem_, W_, idx_host, flags_, eval.out, d.out_size, cfg.n_frags, cfg.discount, newq});
-			be.for_each(n, FNewQ{norm(), mem_, W_, cand, flags_, eval.out + static_cast<size_t>(2 * n) * d.out_size, d.out_size, cfg.n_frags, cfg.discount, newq + n});
-			be.for_each(n, FActorFilter{norm(), eval.out + static_cast<size_t>(n) * d.out_size, d.out_size, cfg.n_frags, n, newq + n, better_host});
-			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1, train.xin});
+			be.for_each(2 * n, FFusedTargets{norm(), mem_, W_, idx_host, cand, flags_, eval.out, d.out_size, cfg.n_frags, n, cfg.discount, newq, better_host});
 			Forward(d_train, n);
-			be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d.out_size, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
-			be.loss_sum(sq, n * d.out_size, 0.5f / static_cast<float>(n), loss_host);
+			be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host);
 			BackwardAndUpdate();
 		});
 		return be.ok();
@@ -216,8 +242,7 @@ public:
 		be.for_each(n, FNewQ{norm(), mem_, W_, idx_host, flags_, eval.out, d.out_size, cfg.n_frags, cfg.discount, newq});
 		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1, train.xin});
 		Forward(d_train, n);
-		be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d.out_size, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
-		be.loss_sum(sq, n * d.out_size, 0.5f / static_cast<float>(n), loss_host);
+		be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host);
 		BackwardAndUpdate();
 	}
 	// idx_host[batch .. batch + n) = candidate slots (a window of their own: the critic step queued before may not have read its indices yet);
@@ -244,8 +269,7 @@ public:
 		const int64_t* idx = idx_host + cfg.max_eval;
 		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx, 1, train.xin});
 		Forward(d_train, n);
-		be.for_each(static_cast<int64_t>(n) * d.out_size, FLabelDout{d.out_size, norm(), 2, nullptr, mem_, W_, S, idx, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq});
-		be.loss_sum(sq, n * d.out_size, 0.5f / static_cast<float>(n), loss_host + 1);
+		be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 2, nullptr, mem_, W_, S, idx, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host + 1);
 		BackwardAndUpdate();
 	}
 	void UpdateTarget() { be.d2d(w_tgt, w_cur, sizeof(float) * cfg.dims.num_params); }

@@ -25,6 +25,7 @@ struct EmulTrainerBE {
 	void gemm2(const NetDims* d, const Work* wk, const GemmDesc& ga, const GemmDesc& gb) { gemm(d, wk, ga); gemm(d, wk, gb); }
 	template <class Fn> void run_graph(int, Fn fn) { fn(); }
 	template <class F> void terr_reduce(const NetDims*, const Work*, int n, const F& f) { for_each(n, f); }
+	template <class F> void label_loss(int n, const F& f, const float* sq, float scale, float* out) { for_each(n, f); loss_sum(sq, n, scale, out); }
 	void loss_sum(const float* x, int n, float scale, float* out) { float s = 0; for (int i = 0; i < n; ++i) s += x[i]; *out = scale * s; }
 	void gemm(const NetDims* dp, const Work* wp, const GemmDesc& g)
 	{

@@ -13,11 +13,12 @@ NETS = os.path.join(REPO, "tests", "golden", "refdata", "data/policies/dog/nets"
 TRAIN, SOLVER = (os.path.join(NETS, "dog_mace3_%s.prototxt" % k) for k in ("train", "solver"))
 S, A, NF = 283, 30, 3
 ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=400); ap.add_argument("--rows", type=int, default=20000); ap.add_argument("--only", default="", help="hip | torch")
+ap.add_argument("--repeats", type=int, default=3); ap.add_argument("--lib", default=None, help="another build of the native library (A/B runs)")
 a = ap.parse_args()
 rng = np.random.RandomState(1)
 rows = rng.normal(0, 1, size=(a.rows, 1 + 2 * S + A)).astype(np.float32); rows[:, 0] = rng.uniform(0, 1, a.rows); rows[:, 1 + S] = rng.randint(0, NF, a.rows)
 flags = ((rng.uniform(size=a.rows) < 0.4) * 4 + (rng.uniform(size=a.rows) < 0.2) * 1).astype(np.int64)
-for name, cls, kw in (("hip (native step)", ht.HipMACETrainer, {}), ("torch peer (HIP graphs)", tr.MACETrainer, {"dtype": torch.float32})):
+for name, cls, kw in (("hip (native step)", ht.HipMACETrainer, {"lib_path": a.lib} if a.lib else {}), ("torch peer (HIP graphs)", tr.MACETrainer, {"dtype": torch.float32})):
     if a.only and not name.startswith(a.only):
         continue
     t = cls(TRAIN, SOLVER, S, A, mem_size=1 << 16, num_init_samples=1000, freeze_target_iters=500, device="cuda", seed=3, **kw)
@@ -25,11 +26,14 @@ for name, cls, kw in (("hip (native step)", ht.HipMACETrainer, {}), ("torch peer
         t.AddTuples(rows[k:k + 4096], flags[k:k + 4096])
     for _ in range(30):
         t.Train()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter(); i0, a0 = t.GetIter(), t.actor_iter
-    for _ in range(a.iters):
-        t.Train()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print("%-26s %7.1f Train()/s  (%.3f ms per iteration; %d critic + %d actor solver steps in %d calls; loss %.5f)" % (
-        name, a.iters / dt, 1e3 * dt / a.iters, t.GetIter() - i0, t.actor_iter - a0, a.iters, t.last_loss), flush=True)
+    rates = []
+    for _ in range(a.repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); i0, a0 = t.GetIter(), t.actor_iter
+        for _ in range(a.iters):
+            t.Train()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rates.append(a.iters / dt)
+    print("%-26s %7.1f Train()/s  median of %s (%.3f ms per iteration; last window: %d critic + %d actor solver steps in %d calls; loss %.5f)" % (
+        name, float(np.median(rates)), ["%.0f" % r for r in rates], 1e3 / float(np.median(rates)), t.GetIter() - i0, t.actor_iter - a0, a.iters, t.last_loss), flush=True)
