@@ -1,0 +1,23 @@
+#!/bin/bash
+# One GPU-box visit at HEAD: the -m gpu suite, smoke(), the two bench configs' profiles, the trainer's rate + kernel table, the training loops.
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03_head
+mkdir -p $O
+cd $R
+python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+bash tools/gpu_profile.sh r03_cfg1 1 > $O/prof1.log 2>&1
+bash tools/gpu_profile.sh r03_cfg2 2 > $O/prof2.log 2>&1
+python tools/trainer_rate.py --iters 1000 > $O/trainer_rate.log 2>&1; cat $O/trainer_rate.log | grep Train
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/tr_stats -o tr -- python $R/tools/trainer_rate.py --iters 100 --repeats 1 --only hip > $O/tr_stats.log 2>&1
+DB=$(find $O/tr_stats -name "*.db" | head -1); python $R/tools/rocpd_top.py $DB 30 > $O/trainer_top.txt 2>&1; find $O -name "*.db" -delete; find $O -name "*.csv" -size +1M -delete
+cd $R
+for spec in "args/opt_args_train_mace.txt 4096" "args/opt_args_train_goat_mace.txt 8192" "args/opt_args_train_raptor_mace.txt 8192"; do
+  set -- $spec
+  echo "== $1 envs=$2 frames=600 trainer=hip --overlap" >> $O/train_loops.log
+  python tools/train_mace.py --arg-file $1 --envs $2 --frames 600 --trainer hip --overlap 2>&1 | tail -2 >> $O/train_loops.log
+done
+echo "== args/opt_args_train_mace.txt envs=4096 frames=600 trainer=hip (sequential)" >> $O/train_loops.log
+python tools/train_mace.py --arg-file args/opt_args_train_mace.txt --envs 4096 --frames 600 --trainer hip 2>&1 | tail -2 >> $O/train_loops.log
+cat $O/train_loops.log
