@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_cycle_info", "dtrl_get_action_table", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
     "dtrl_terrain_build", "dtrl_terrain_load_file", "dtrl_args_parse_string",
-    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed", "dtrl_get_policy_output", "dtrl_set_tuple_pipelining", "dtrl_step_end_begin", "dtrl_command_action",
+    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed", "dtrl_get_policy_output", "dtrl_set_tuple_pipelining", "dtrl_step_end_begin", "dtrl_command_action", "dtrl_side_stream",
 ]
 
 
@@ -92,6 +92,7 @@ def _bind(path):
         getattr(L, name).argtypes = [vp, vp, C.c_int, vp, vp]
     L.dtrl_set_pose_vel.argtypes = [vp, vp, C.c_int, vp, vp]
     L.dtrl_command_action.argtypes = [vp, vp, C.c_int, vp]
+    L.dtrl_side_stream.restype = C.c_void_p; L.dtrl_side_stream.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.dtrl_get_link_states.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.dtrl_add_perturb.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
     L.dtrl_apply_rand_force.argtypes = [vp, vp, C.c_int, C.c_uint64]
@@ -251,9 +252,13 @@ class BatchScenario:
 
     def DrainTuples(self, cap=None):
         cap = cap or max(2 * self.num_envs, 64)
-        rows = np.zeros((cap, self.W), np.float32); fl = np.zeros(cap, np.uint32); ids = np.zeros(cap, np.int32); n = C.c_int()
+        buf = getattr(self, "_drain_buf", None)
+        if buf is None or buf[0].shape[0] < cap:     # (20 MB at 4096 envs: kept, not allocated and zero-filled per call)
+            buf = self._drain_buf = (np.empty((cap, self.W), np.float32), np.empty(cap, np.uint32), np.empty(cap, np.int32))
+        rows, fl, ids = buf
+        n = C.c_int()
         self._chk(self._lib.dtrl_drain_tuples(self._h, _p(rows), _p(fl), _p(ids), cap, C.byref(n)))
-        return rows[:n.value], fl[:n.value], ids[:n.value]
+        return rows[:n.value].copy(), fl[:n.value].copy(), ids[:n.value].copy()
 
     def DrainTuplesDevice(self, rows_ptr, flags_ptr, ids_ptr, cap):
         """dtrl_drain_tuples_device: raw DEVICE pointers (e.g. tensor.data_ptr()) of float32 [cap, W] / uint32 [cap] / int32 [cap]; returns n."""
@@ -332,6 +337,13 @@ class BatchScenario:
         ids, n = self._ids(env_ids)
         q = np.ascontiguousarray(q, np.float64).reshape(n, self.D); qd = np.ascontiguousarray(qd, np.float64).reshape(n, self.D)
         self._chk(self._lib.dtrl_set_pose_vel(self._h, _p(ids), n, _p(q), _p(qd)))
+
+    def SideStream(self, k=0):
+        """(hipStream_t as an int, start delay in us measured at creation) of the k-th side stream: kernels queued there start on the compute units
+        `reserve_cus` keeps out of the frame launches, while a frame is in flight. (None, -1.0) without a reservation."""
+        d = C.c_double(-1.0)
+        p = self._lib.dtrl_side_stream(self._h, int(k), C.byref(d))
+        return (int(p) if p else None), float(d.value)
 
     def CommandAction(self, action_id, env_ids=None):
         """cCharController::CommandAction on the listed envs (all by default): action_id (an int, or one per env) is taken at the next cycle."""

@@ -10,6 +10,9 @@
 #include "dtrl_terrain_dev.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -38,6 +41,25 @@ __global__ void __launch_bounds__(kGroup, 2) dtrl_frame_kernel_fast(const DevMod
 }
 
 // dst[i] = idx[i] >= 0 ? src[idx[i]] : 0: re-lays a policy blob handed over in device memory into the kernel's weight layout
+// Calibration of the side streams (HipBackend::CalibrateSideStreams). dtrl_occupy: a stand-in for a frame launch's residency (one wavefront per workgroup,
+// 20 KB of LDS -> 8 per compute unit, alive for `ticks` of the 100 MHz wall clock); block 0 stamps its start. dtrl_stamp: when did this stream's kernel get to run.
+__global__ void __launch_bounds__(64) dtrl_occupy(long long ticks, long long* __restrict__ start_stamp)
+{
+	__shared__ float pad[5 * 1024];
+	const long long t0 = wall_clock64();
+	if (blockIdx.x == 0 && threadIdx.x == 0 && start_stamp) *start_stamp = t0;
+	pad[threadIdx.x] = 1.0f;
+	while (wall_clock64() - t0 < ticks) pad[threadIdx.x] += 1.0f;
+	if (pad[threadIdx.x] < 0) __builtin_trap();
+}
+__global__ void __launch_bounds__(256) dtrl_stamp(long long* __restrict__ out)
+{
+	__shared__ float pad[4 * 1024];          // (a side kernel's typical footprint: does not fit beside a resident frame workgroup set)
+	pad[threadIdx.x] = 1.0f;
+	__syncthreads();
+	if (blockIdx.x == 0 && threadIdx.x == 0) *out = wall_clock64() + (pad[1] > 2.0f ? 1 : 0);
+}
+
 __global__ void dtrl_gather_f32(float* __restrict__ dst, const float* __restrict__ src, const int32_t* __restrict__ idx, size_t n)
 {
 	for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
@@ -158,6 +180,7 @@ public:
 	{
 		for (auto& ev : events_) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
 		for (auto& m : marks_) if (m.second) hipEventDestroy(m.second);
+		if (!owned_.empty()) { for (int i = kNumStreams / 2; i < kNumStreams; ++i) streams_[i] = nullptr; for (hipStream_t st : owned_) hipStreamDestroy(st); }
 		for (hipStream_t st : streams_) if (st) hipStreamDestroy(st);
 	}
 	bool Init(int device_id, std::string& err) override
@@ -172,8 +195,9 @@ public:
 		// to retire (nothing does in the first ~2 ms of a frame). The env-group streams (the first kNumStreams / 2) get a CU mask without those units (mask
 		// bit i = compute unit i / #XCD of XCD i % #XCD, so the top 8 k bits are k units on each of the 8 XCDs); the other streams, and every other stream of
 		// the process, may use all of them. Costs k / 32 of the rollout rate; worth it when something has to overlap the rollout (multi-rank exchange).
-		int reserve = 0;
-		if (const char* env = std::getenv("DTRL_RESERVE_CUS")) reserve = std::max(0, std::min(8, std::atoi(env)));
+		int reserve = reserve_arg_;
+		if (reserve < 0) { reserve = 0; if (const char* env = std::getenv("DTRL_RESERVE_CUS")) reserve = std::atoi(env); }
+		reserve = std::max(0, std::min(8, reserve));
 		hipDeviceProp_t prop;
 		int cus = 0;
 		if (reserve > 0 && hipGetDeviceProperties(&prop, device_id >= 0 ? device_id : 0) == hipSuccess) cus = prop.multiProcessorCount;
@@ -187,8 +211,67 @@ public:
 			if (e != hipSuccess) { err = std::string("hipStreamCreate: ") + hipGetErrorString(e); return false; }
 		}
 		stream_ = streams_[0];
+		masked_ = reserve > 0 && cus >= 2 * kXcd * reserve;
+		if (masked_ && !CalibrateSideStreams(err)) return false;
 		return true;
 	}
+	// Which streams can actually USE the reserved compute units while frame launches are in flight? Measured on the MI355X (tools/microbench/cu_mask_probe.hip,
+	// DESIGN 9): a launch that is waiting for wavefront slots (the second env group's, while the first fills the unmasked units) holds up OTHER hardware queues
+	// too -- 3 to 5 of 10 plain streams of a process see their kernels start only when that launch has been placed or has finished (2.7 / 5.6 ms for a 3 ms
+	// occupant), although the reserved units are idle; the rest start within 7 us. Which streams are affected depends on how the runtime mapped them onto
+	// hardware queues, so it is measured here, once: two occupant launches on the env-group streams 0 and 1, a stamp kernel on every candidate stream, and the
+	// candidates ordered by how long after the occupants' start their stamp ran (worst of 3 rounds). The plain engine streams (kNumStreams / 2 ..) are then
+	// re-seated on the quickest candidates -- the tuple-drain stream first -- and the next two are handed out as side streams (dtrl_side_stream: the trainer's
+	// launches, the exchange's collective).
+	bool CalibrateSideStreams(std::string& err)
+	{
+		constexpr int kCand = 12, kBurst = 10;
+		constexpr long long kTicks = 120000;         // 1.2 ms per occupant
+		std::vector<hipStream_t> cand;
+		for (int i = kNumStreams / 2; i < kNumStreams; ++i) cand.push_back(streams_[i]);
+		while (static_cast<int>(cand.size()) < kCand) { hipStream_t st; if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break; cand.push_back(st); extra_.push_back(st); }
+		long long* stamps = nullptr;
+		if (!Check(hipHostMalloc(&stamps, sizeof(long long) * 4, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc")) { err = err_; return false; }
+		std::vector<long long> worst(cand.size(), 0);   // microseconds x 100 (the sort below only compares)
+		for (int r = 0; r < 2; ++r) {                 // (round 0 warms the code objects and the streams' queues up)
+			for (size_t c = 0; c < cand.size(); ++c) {
+				stamps[0] = 0;
+				hipDeviceSynchronize();
+				hipLaunchKernelGGL(dtrl_occupy, dim3(2048), dim3(64), 0, streams_[0], r == 0 ? 2000LL : kTicks, stamps);
+				hipLaunchKernelGGL(dtrl_occupy, dim3(2048), dim3(64), 0, streams_[1], r == 0 ? 2000LL : kTicks, static_cast<long long*>(nullptr));
+				while (*static_cast<volatile long long*>(stamps) == 0) {}        // the first occupant is running, the second waits for slots
+				std::this_thread::sleep_for(std::chrono::microseconds(r == 0 ? 0 : 200));
+				const auto t0 = std::chrono::steady_clock::now();
+				for (int k = 0; k < kBurst; ++k) hipLaunchKernelGGL(dtrl_stamp, dim3(96), dim3(256), 0, cand[c], stamps + 1);
+				if (!Check(hipStreamSynchronize(cand[c]), "side-stream calibration")) { err = err_; hipHostFree(stamps); return false; }
+				const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+				if (r > 0) worst[c] = static_cast<long long>(us * 100.0);
+			}
+		}
+		hipDeviceSynchronize();
+		hipHostFree(stamps);
+		std::vector<int> ord(cand.size());
+		for (size_t c = 0; c < cand.size(); ++c) ord[c] = static_cast<int>(c);
+		std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return worst[a] < worst[b]; });
+		side_delay_us_.clear();
+		for (int c : ord) side_delay_us_.push_back(worst[c] / 100.0);
+		// the drain stream (kNumStreams - 1) gets the quickest, then the two side streams, then the other plain engine streams
+		std::vector<hipStream_t> pick;
+		for (int c : ord) pick.push_back(cand[c]);
+		streams_[kNumStreams - 1] = pick[0];
+		side_[0] = pick[1]; side_[1] = pick[2];
+		for (int i = kNumStreams / 2, k = 3; i < kNumStreams - 1; ++i, ++k) streams_[i] = pick[k];
+		owned_.assign(cand.begin(), cand.end());      // every candidate stays alive (destroying one could re-seat the others) and is destroyed with the backend
+		if (std::getenv("DTRL_HOST_TIMING")) {
+			std::fprintf(stderr, "[dtrl] side-stream calibration: 10-kernel burst beside the occupants, us per candidate (sorted):");
+			for (double v : side_delay_us_) std::fprintf(stderr, " %.0f", v);
+			std::fprintf(stderr, "\n");
+		}
+		return true;
+	}
+	void SetReserveCus(int k) override { reserve_arg_ = k; }
+	void* SideStream(int k) override { return (masked_ && k >= 0 && k < 2) ? static_cast<void*>(side_[k]) : nullptr; }
+	double SideStreamDelayUs(int k) override { return (masked_ && k >= 0 && k + 1 < static_cast<int>(side_delay_us_.size())) ? side_delay_us_[k + 1] : -1.0; }
 	void* Alloc(size_t bytes) override
 	{
 		void* p = nullptr;
@@ -198,6 +281,7 @@ public:
 	}
 	void Free(void* p) override { hipFree(p); }
 	bool H2D(void* dst, const void* src, size_t n) override { return Check(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream_), "hipMemcpy H2D") && Check(hipStreamSynchronize(stream_), "sync"); }
+	bool D2HAsync(void* dst, const void* src, size_t n) override { return Check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync D2H"); }
 	bool H2DAsync(void* dst, const void* src, size_t n) override { return Check(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync H2D"); }
 	void* HostStaging(size_t bytes) override { void* p = nullptr; return Check(hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc") ? p : nullptr; }
 	bool SyncSelected() override { return Check(hipStreamSynchronize(stream_), "hipStreamSynchronize"); }
@@ -302,6 +386,11 @@ private:
 	double time_sum_ms_ = 0; int64_t time_n_ = 0;
 	bool Check(hipError_t e, const char* what) { if (e == hipSuccess) return true; err_ = std::string(what) + ": " + hipGetErrorString(e); return false; }
 	static constexpr int kNumStreams = 8;
+	int reserve_arg_ = -1;             // -reserve_cus= (else DTRL_RESERVE_CUS)
+	bool masked_ = false;
+	hipStream_t side_[2] = {nullptr, nullptr};
+	std::vector<hipStream_t> extra_, owned_;
+	std::vector<double> side_delay_us_;
 	std::vector<hipStream_t> streams_;
 	hipStream_t stream_ = nullptr;   // the selected one
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events_, free_events_, pending_;

@@ -93,6 +93,7 @@ try {
 	for (int i = 0; i < n; ++i) for (int k = 0; k < D; ++k) { if (q) q[i * D + k] = st[i].q[k]; if (qd) qd[i * D + k] = st[i].qd[k]; }
 	return DTRL_OK;
 } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+void* dtrl_side_stream(dtrl_batch* b, int k, double* start_delay_us) try { if (!b) return nullptr; return b->eng.SideStream(k, start_delay_us); } catch (...) { return nullptr; }
 dtrl_status dtrl_command_action(dtrl_batch* b, const int32_t* env_ids, int n, const int32_t* action_ids) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.CommandAction(env_ids, n, action_ids)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_set_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, const double* q, const double* qd) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetPoseVel(env_ids, n, q, qd)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_add_perturb(dtrl_batch* b, const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration)

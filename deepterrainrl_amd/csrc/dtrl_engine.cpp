@@ -118,7 +118,8 @@ Engine::~Engine()
 	if (be_) {
 		be_->Sync();
 		for (void* p : allocs_) be_->Free(p);
-		be_->FreeHostStaging(pin_recs_); be_->FreeHostStaging(pin_order_); be_->FreeHostStaging(pin_ids_); be_->FreeHostStaging(status_); be_->FreeHostStaging(stage_slot_);
+		for (void* p : host_allocs_) be_->FreeHostStaging(p);
+		be_->FreeHostStaging(pin_drain_); be_->FreeHostStaging(pin_recs_); be_->FreeHostStaging(pin_order_); be_->FreeHostStaging(pin_ids_); be_->FreeHostStaging(status_); be_->FreeHostStaging(stage_slot_);
 		delete be_;
 	}
 }
@@ -155,6 +156,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	W_ = 1 + 2 * S_ + A_;                               // learning/MACETrainer.cpp:373-376
 
 	be_ = MakeBackend();
+	{ int reserve = -1; if (args.ParseInt("reserve_cus", reserve)) be_->SetReserveCus(reserve); }   // (else the DTRL_RESERVE_CUS environment variable; include/dtrl.h: dtrl_side_stream)
 	if (!be_->Init(device_id, err_)) return DTRL_ERR_NO_DEVICE;
 
 	auto alloc = [&](size_t bytes) -> void* { void* p = be_->Alloc(bytes); if (p) allocs_.push_back(p); return p; };
@@ -170,11 +172,10 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	// (-tuple_ring_capacity= overrides; dtrl_tuple_stats reports how many rows were dropped because the ring was full)
 	buf_.tuple_cap = std::max(2 * n_, cfg_.tuple_buffer_size);
 	if (cfg_.tuple_ring_capacity > 0) buf_.tuple_cap = cfg_.tuple_ring_capacity;
-	buf_.tuple_rows = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(W_) * buf_.tuple_cap));
-	buf_.tuple_flags = static_cast<uint32_t*>(alloc(sizeof(uint32_t) * buf_.tuple_cap));
-	buf_.tuple_env = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
-	buf_.tuple_count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));   // [0] ring cursor, [1] / [2] rows drained / dropped by packed drains since the last fold
-	ring_[0].rows = buf_.tuple_rows; ring_[0].flags = buf_.tuple_flags; ring_[0].env = buf_.tuple_env; ring_[0].count = buf_.tuple_count;
+	// (-tuple_ring= host: page-locked host memory the kernels address through the same pointers -- a tuple is 2.4 KB of fire-and-forget stores over the link and
+	// one system-scope atomic on the cursor, ~0.6 MB per frame at 4096 dogs; dtrl_drain_tuples then reads the ring without queueing anything on the GPU)
+	if (!AllocRing(ring_[0])) return Fail(DTRL_ERR_DEVICE, "tuple ring allocation failed: " + be_->error());
+	UseRing(buf_, 0);
 	d_env_list_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
 	d_order_ = static_cast<int32_t*>(alloc(sizeof(int32_t) * n_));
 	if (cfg_.device_terrain) {
@@ -210,9 +211,10 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 		buf_.net = d;
 		buf_.nn_out = static_cast<real*>(alloc(sizeof(real) * static_cast<size_t>(d.out_size) * n_));
 		float* w_dev = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(DevNumParams(d))));
+		weights_alt_ = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(DevNumParams(d))));   // second weight buffer: hand-overs during a frame (SetPolicyDevice)
 		real* io = static_cast<real*>(alloc(sizeof(real) * d.in_size)); real* is = static_cast<real*>(alloc(sizeof(real) * d.in_size));
 		real* oo = static_cast<real*>(alloc(sizeof(real) * d.out_size)); real* os = static_cast<real*>(alloc(sizeof(real) * d.out_size));
-		if (!buf_.nn_out || !w_dev || !io || !is || !oo || !os) return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
+		if (!buf_.nn_out || !w_dev || !weights_alt_ || !io || !is || !oo || !os) return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
 		{ std::vector<real> zeros(static_cast<size_t>(d.out_size) * n_, 0.0); if (!be_->H2D(buf_.nn_out, zeros.data(), sizeof(real) * zeros.size())) return Fail(DTRL_ERR_DEVICE, be_->error()); }   // dtrl_get_policy_output before the first forward
 		buf_.weights = w_dev; buf_.in_off = io; buf_.in_scale = is; buf_.out_off = oo; buf_.out_scale = os;
 		cfg_.model.has_net = 1;
@@ -307,7 +309,9 @@ namespace {
 struct HostTiming {
 	bool on = std::getenv("DTRL_HOST_TIMING") != nullptr;
 	double t_sync = 0, t_loop = 0, t_sort = 0, t_reset = 0, t_launch = 0; long n = 0, regen = 0;
-	~HostTiming() { if (on && n) std::fprintf(stderr, "[dtrl host] per group-frame: status read-back %.1f us, env loop %.1f us (%.2f regen), order %.1f us, resets %.1f us, launch %.1f us (n=%ld)\n", 1e6 * t_sync / n, 1e6 * t_loop / n, double(regen) / n, 1e6 * t_sort / n, 1e6 * t_reset / n, 1e6 * t_launch / n, n); }
+	double d_wait = 0, d_count = 0, d_copy = 0; long d_n = 0;
+	~HostTiming() { if (on && d_n) std::fprintf(stderr, "[dtrl host] per tuple drain: wait for the ring's frame %.1f us, count read-back %.1f us, rows + reset %.1f us (n=%ld)\n", 1e6 * d_wait / d_n, 1e6 * d_count / d_n, 1e6 * d_copy / d_n, d_n);
+		if (on && n) std::fprintf(stderr, "[dtrl host] per group-frame: status read-back %.1f us, env loop %.1f us (%.2f regen), order %.1f us, resets %.1f us, launch %.1f us (n=%ld)\n", 1e6 * t_sync / n, 1e6 * t_loop / n, double(regen) / n, 1e6 * t_sort / n, 1e6 * t_reset / n, 1e6 * t_launch / n, n); }
 } g_ht;
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }
@@ -441,6 +445,7 @@ int Engine::StepBegin(double dt)
 	if (dt <= 0) return DTRL_OK;   // cScenarioSimChar::Update returns early (scenarios/ScenarioSimChar.cpp:148-151)
 	if (cfg_.model.has_net && !policy_set_) return Fail(DTRL_ERR_ARG, "policy_net was given but dtrl_set_policy has not been called");
 	const int steps = cfg_.model.num_update_steps;
+	ApplyPendingPolicy();
 	if (tuple_pipelining_) { wr_ring_ ^= 1; UseRing(buf_, wr_ring_); }   // this frame's tuples go to the ring that is not being drained
 	for (size_t g = 0; g < groups_.size(); ++g) { int rc = LaunchGroup(static_cast<int>(g), steps, dt / steps, true); if (rc != DTRL_OK) return rc; }
 	step_pending_ = true;
@@ -464,6 +469,7 @@ int Engine::StepEndBegin(double dt)
 	if (dt <= 0) return StepEnd();
 	const int G = static_cast<int>(groups_.size());
 	const int steps = cfg_.model.num_update_steps;
+	ApplyPendingPolicy();   // (every group's NEXT launch runs with the weights handed over during the frame that is ending)
 	if (tuple_pipelining_) { wr_ring_ ^= 1; UseRing(buf_, wr_ring_); }
 	std::vector<char> done(static_cast<size_t>(G), 0);
 	for (int remaining = G; remaining > 0; --remaining) {
@@ -489,6 +495,7 @@ int Engine::StepUpdates(int n)
 	if (n <= 0) return DTRL_OK;
 	if (cfg_.model.has_net && !policy_set_) return Fail(DTRL_ERR_ARG, "policy_net was given but dtrl_set_policy has not been called");
 	const double dt = (1.0 / 30.0) / cfg_.model.num_update_steps;
+	ApplyPendingPolicy();
 	for (size_t g = 0; g < groups_.size(); ++g) { int rc = LaunchGroup(static_cast<int>(g), n, dt, false); if (rc != DTRL_OK) return rc; }
 	for (size_t g = 0; g < groups_.size(); ++g) { int rc = HostFrameWork(static_cast<int>(g)); if (rc != DTRL_OK) return rc; }
 	return DTRL_OK;
@@ -503,6 +510,7 @@ int Engine::RunFrames(int frames, double dt)
 	if (cfg_.model.has_net && !policy_set_) return Fail(DTRL_ERR_ARG, "policy_net was given but dtrl_set_policy has not been called");
 	const int G = static_cast<int>(groups_.size());
 	const int steps = cfg_.model.num_update_steps;
+	ApplyPendingPolicy();
 	if (cfg_.device_terrain) {
 		// nothing on the host depends on a frame's outcome: queue everything; the streams run ahead of the host by as much as the HIP queues hold
 		for (int f = 0; f < frames; ++f) for (int g = 0; g < G; ++g) {
@@ -625,6 +633,7 @@ int Engine::SetPolicy(const float* w, size_t n, const double* io, const double* 
 	const NetDesc& d = cfg_.net;
 	if (!w || n != static_cast<size_t>(cfg_.user_num_params)) return Fail(DTRL_ERR_ARG, "weight count does not match the deploy prototxt");
 	be_->Sync();
+	policy_flip_pending_ = false;   // (a deferred device hand-over is superseded)
 	std::vector<float> dev_w(relayout_.size());
 	for (size_t i = 0; i < relayout_.size(); ++i) dev_w[i] = relayout_[i] >= 0 ? w[relayout_[i]] : 0.0f;
 	// CACLA actor: a neutral critic slot in front of the output normalisers (the device net's one zero critic output)
@@ -644,12 +653,28 @@ int Engine::SetPolicy(const float* w, size_t n, const double* io, const double* 
 
 // dtrl_set_policy with every pointer in DEVICE memory (the trainer's own tensors): no host round trip. Weights are gathered into the
 // device layout by a kernel; NULL normalisers keep their current values.
+// While a frame is in flight (between dtrl_step_begin and dtrl_step_end) a weights-only hand-over does NOT wait for it: the weights are gathered into a
+// second buffer on the drain stream and the kernels switch to it with the next frame launch (the same moment the synchronous path would have taken effect).
+void Engine::ApplyPendingPolicy()
+{
+	if (!policy_flip_pending_) return;
+	const float* cur = buf_.weights; buf_.weights = weights_alt_; weights_alt_ = const_cast<float*>(cur);
+	policy_flip_pending_ = false;
+}
 int Engine::SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, const double* is_dev, const double* oo_dev, const double* os_dev)
 {
 	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
 	const NetDesc& d = cfg_.net;
 	if (!w_dev || n != static_cast<size_t>(cfg_.user_num_params)) return Fail(DTRL_ERR_ARG, "weight count does not match the deploy prototxt");
+	if (step_pending_ && policy_set_ && weights_alt_ && !io_dev && !is_dev && !oo_dev && !os_dev) {
+		struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
+		be_->SelectStream(be_->NumStreams() - 1);
+		if (!be_->GatherF32(weights_alt_, w_dev, d_relayout_, relayout_.size())) return Fail(DTRL_ERR_DEVICE, be_->error());   // (synchronised: the caller may change w_dev when this returns)
+		policy_flip_pending_ = true;
+		return DTRL_OK;
+	}
 	be_->Sync();
+	ApplyPendingPolicy();
 	if (!be_->GatherF32(const_cast<float*>(buf_.weights), w_dev, d_relayout_, relayout_.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
 	if (in_off_.empty()) { in_off_.assign(d.in_size, 0.0); in_scale_.assign(d.in_size, 1.0); out_off_.assign(d.out_size, 0.0); out_scale_.assign(d.out_size, 1.0); int rc = UploadNormalizers(); if (rc != DTRL_OK) return rc; }
 	const int pad = d.out_size - cfg_.user_out_size;
@@ -735,23 +760,34 @@ int Engine::SetTerrainLerp(double lerp)
 // ---- tuple rings. Without pipelining there is one ring and every drain waits for all streams. With it (SetTuplePipelining) dtrl_step_begin switches
 // the ring the kernels write; between dtrl_step_begin and dtrl_step_end the drains below work on the OTHER ring (the frame that has ended), on a stream of
 // their own, and do not wait for the frame in flight.
+bool Engine::AllocRing(TupleRing& r)
+{
+	const size_t rb = sizeof(float) * static_cast<size_t>(W_) * buf_.tuple_cap, fb = sizeof(uint32_t) * static_cast<size_t>(buf_.tuple_cap), eb = sizeof(int32_t) * static_cast<size_t>(buf_.tuple_cap), cb = sizeof(int32_t) * 4;
+	auto get = [&](size_t bytes) -> void* {
+		void* p = cfg_.tuple_ring_host ? be_->HostStaging(bytes) : be_->Alloc(bytes);
+		if (!p) return nullptr;
+		if (cfg_.tuple_ring_host) { std::memset(p, 0, bytes); host_allocs_.push_back(p); } else allocs_.push_back(p);
+		return p;
+	};
+	r.rows = static_cast<float*>(get(rb)); r.flags = static_cast<uint32_t*>(get(fb)); r.env = static_cast<int32_t*>(get(eb));
+	r.count = static_cast<int32_t*>(get(cb));   // [0] ring cursor, [1] / [2] rows drained / dropped by packed drains since the last fold
+	return r.rows && r.flags && r.env && r.count;
+}
+// the ring's words as the host sees them: a plain read / write when the ring is host memory (no kernel is using it: callers hold DrainSync), else a copy
+bool Engine::RingRead(void* dst, const void* src, size_t n) { if (cfg_.tuple_ring_host) { std::memcpy(dst, src, n); return true; } return be_->D2H(dst, src, n); }
+bool Engine::RingWrite(void* dst, const void* src, size_t n) { if (cfg_.tuple_ring_host) { std::memcpy(dst, src, n); return true; } return be_->H2D(dst, src, n); }
 int Engine::SetTuplePipelining(bool on)
 {
 	if (step_pending_) return Fail(DTRL_ERR_ARG, "dtrl_set_tuple_pipelining between dtrl_step_begin and dtrl_step_end");
 	if (!be_->Sync()) return Fail(DTRL_ERR_DEVICE, be_->error());
 	if (on && !ring_[1].rows) {
-		auto alloc = [&](size_t bytes) -> void* { void* p = be_->Alloc(bytes); if (p) allocs_.push_back(p); return p; };
-		ring_[1].rows = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(W_) * buf_.tuple_cap));
-		ring_[1].flags = static_cast<uint32_t*>(alloc(sizeof(uint32_t) * buf_.tuple_cap));
-		ring_[1].env = static_cast<int32_t*>(alloc(sizeof(int32_t) * buf_.tuple_cap));
-		ring_[1].count = static_cast<int32_t*>(alloc(sizeof(int32_t) * 4));
-		if (!ring_[1].rows || !ring_[1].flags || !ring_[1].env || !ring_[1].count) return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
+		if (!AllocRing(ring_[1])) return Fail(DTRL_ERR_DEVICE, "tuple ring allocation failed: " + be_->error());
 	}
 	if (!on && tuple_pipelining_) {
 		// back to one ring: whatever waits in the idle ring would be stranded
 		DevBuffers o = buf_; UseRing(o, wr_ring_ ^ 1);
 		int32_t cnt = 0;
-		if (!be_->D2H(&cnt, o.tuple_count, sizeof(cnt))) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (!RingRead(&cnt, o.tuple_count, sizeof(cnt))) return Fail(DTRL_ERR_DEVICE, be_->error());
 		if (cnt != 0) return Fail(DTRL_ERR_ARG, "drain the pending tuples before switching tuple pipelining off");
 	}
 	tuple_pipelining_ = on;
@@ -775,7 +811,7 @@ int Engine::PendingTuples(int32_t* stored, int32_t* overflow)
 	int32_t cnt = 0;
 	DevBuffers d = buf_; UseRing(d, DrainRing());
 	struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
-	if (!DrainSync() || !be_->D2H(&cnt, d.tuple_count, sizeof(cnt))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!DrainSync() || !RingRead(&cnt, d.tuple_count, sizeof(cnt))) return Fail(DTRL_ERR_DEVICE, be_->error());
 	*overflow = cnt > buf_.tuple_cap ? cnt - buf_.tuple_cap : 0;
 	*stored = cnt - *overflow;
 	return DTRL_OK;
@@ -783,24 +819,70 @@ int Engine::PendingTuples(int32_t* stored, int32_t* overflow)
 int Engine::DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n, bool device_dst)
 {
 	if (cap < 0 || !out_n || (cap > 0 && !rows)) return Fail(DTRL_ERR_ARG, "bad arguments");
-	int32_t cnt = 0, over = 0;
-	int rc = PendingTuples(&cnt, &over);
-	if (rc != DTRL_OK) return rc;
-	int n = std::min<int>(cnt, cap);
-	if (n < cnt) return Fail(DTRL_ERR_CAPACITY, "caller buffer smaller than the number of pending tuples");
 	DevBuffers d = buf_; UseRing(d, DrainRing());
 	struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
-	if (tuple_pipelining_ && step_pending_) be_->SelectStream(be_->NumStreams() - 1);
-	if (n > 0) {
-		auto copy = [&](void* dst, const void* src, size_t bytes) { return device_dst ? be_->D2D(dst, src, bytes) : be_->D2H(dst, src, bytes); };
-		if (!copy(rows, d.tuple_rows, sizeof(float) * static_cast<size_t>(W_) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
-		if (flags && !copy(flags, d.tuple_flags, sizeof(uint32_t) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
-		if (env_ids && !copy(env_ids, d.tuple_env, sizeof(int32_t) * n)) return Fail(DTRL_ERR_DEVICE, be_->error());
+	// Host destination: everything goes through ONE page-locked staging area with two synchronisations (the count; then rows + flags + ids + the cursor's reset
+	// queued together) -- a copy into pageable caller memory is a staged, synchronous affair per call in the runtime (five of them before; with frames in
+	// flight each could wait for a wavefront slot).
+	if (cfg_.tuple_ring_host && !device_dst) {
+		const double ht0 = g_ht.on ? now_s() : 0;
+		if (!DrainSync()) return Fail(DTRL_ERR_DEVICE, be_->error());
+		const double ht1 = g_ht.on ? now_s() : 0;
+		const int32_t cnt_all = *d.tuple_count;
+		const int32_t over = cnt_all > buf_.tuple_cap ? cnt_all - buf_.tuple_cap : 0;
+		const int n = std::min<int>(cnt_all - over, cap);
+		if (n < cnt_all - over) return Fail(DTRL_ERR_CAPACITY, "caller buffer smaller than the number of pending tuples");
+		if (n > 0) {
+			std::memcpy(rows, d.tuple_rows, sizeof(float) * static_cast<size_t>(W_) * n);
+			if (flags) std::memcpy(flags, d.tuple_flags, sizeof(uint32_t) * static_cast<size_t>(n));
+			if (env_ids) std::memcpy(env_ids, d.tuple_env, sizeof(int32_t) * static_cast<size_t>(n));
+		}
+		*d.tuple_count = 0;
+		tuples_drained_ += n; tuples_dropped_ += over;
+		*out_n = n;
+		if (g_ht.on) { g_ht.d_wait += ht1 - ht0; g_ht.d_copy += now_s() - ht1; ++g_ht.d_n; }
+		return DTRL_OK;
 	}
-	const int32_t zero = 0;
-	if (!be_->H2D(d.tuple_count, &zero, sizeof(zero))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!pin_drain_) {
+		pin_drain_bytes_ = 64 + (sizeof(float) * static_cast<size_t>(W_) + sizeof(uint32_t) + sizeof(int32_t)) * static_cast<size_t>(buf_.tuple_cap);
+		pin_drain_ = static_cast<char*>(be_->HostStaging(pin_drain_bytes_));
+		if (!pin_drain_) return Fail(DTRL_ERR_DEVICE, "host staging allocation failed: " + be_->error());
+		std::memset(pin_drain_, 0, 64);
+	}
+	int32_t* p_cnt = reinterpret_cast<int32_t*>(pin_drain_); int32_t* p_zero = p_cnt + 1;   // (p_zero stays 0)
+	const double ht0 = g_ht.on ? now_s() : 0;
+	if (!DrainSync()) return Fail(DTRL_ERR_DEVICE, be_->error());
+	const double ht1 = g_ht.on ? now_s() : 0;
+	if (cfg_.tuple_ring_host) *p_cnt = *d.tuple_count;      // (device destination, host ring)
+	else if (!be_->D2HAsync(p_cnt, d.tuple_count, sizeof(int32_t)) || !be_->SyncSelected()) return Fail(DTRL_ERR_DEVICE, be_->error());
+	const double ht2 = g_ht.on ? now_s() : 0;
+	const int32_t cnt_all = *p_cnt;
+	const int32_t over = cnt_all > buf_.tuple_cap ? cnt_all - buf_.tuple_cap : 0;
+	const int32_t cnt = cnt_all - over;
+	const int n = std::min<int>(cnt, cap);
+	if (n < cnt) return Fail(DTRL_ERR_CAPACITY, "caller buffer smaller than the number of pending tuples");
+	const size_t rb = sizeof(float) * static_cast<size_t>(W_) * n, fb = sizeof(uint32_t) * static_cast<size_t>(n), eb = sizeof(int32_t) * static_cast<size_t>(n);
+	char* p_rows = pin_drain_ + 64; char* p_flags = p_rows + sizeof(float) * static_cast<size_t>(W_) * buf_.tuple_cap; char* p_env = p_flags + sizeof(uint32_t) * static_cast<size_t>(buf_.tuple_cap);
+	bool ok = true;
+	if (n > 0) {
+		if (device_dst) {
+			if (cfg_.tuple_ring_host) ok = be_->H2D(rows, d.tuple_rows, rb) && (!flags || be_->H2D(flags, d.tuple_flags, fb)) && (!env_ids || be_->H2D(env_ids, d.tuple_env, eb));
+			else ok = be_->D2D(rows, d.tuple_rows, rb) && (!flags || be_->D2D(flags, d.tuple_flags, fb)) && (!env_ids || be_->D2D(env_ids, d.tuple_env, eb));
+		} else {
+			ok = be_->D2HAsync(p_rows, d.tuple_rows, rb) && (!flags || be_->D2HAsync(p_flags, d.tuple_flags, fb)) && (!env_ids || be_->D2HAsync(p_env, d.tuple_env, eb));
+		}
+	}
+	if (cfg_.tuple_ring_host) { ok = ok && be_->SyncSelected(); *d.tuple_count = 0; }
+	else ok = ok && be_->H2DAsync(d.tuple_count, p_zero, sizeof(int32_t)) && be_->SyncSelected();
+	if (!ok) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (n > 0 && !device_dst) {
+		std::memcpy(rows, p_rows, rb);
+		if (flags) std::memcpy(flags, p_flags, fb);
+		if (env_ids) std::memcpy(env_ids, p_env, eb);
+	}
 	tuples_drained_ += n; tuples_dropped_ += over;
 	*out_n = n;
+	if (g_ht.on) { g_ht.d_wait += ht1 - ht0; g_ht.d_count += ht2 - ht1; g_ht.d_copy += now_s() - ht2; ++g_ht.d_n; }
 	return DTRL_OK;
 }
 // totals of the device-side (packed) drains -> host counters
@@ -811,11 +893,11 @@ int Engine::FoldTupleTotals()
 	for (int r = 0; r < 2; ++r) {
 		if (!ring_[r].count || (tuple_pipelining_ && step_pending_ && r == wr_ring_)) continue;   // (the ring in flight folds after its frame)
 		int32_t c[4] = {0, 0, 0, 0};
-		if (!be_->D2H(c, ring_[r].count, sizeof(c))) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (!RingRead(c, ring_[r].count, sizeof(c))) return Fail(DTRL_ERR_DEVICE, be_->error());
 		if (c[1] || c[2]) {
 			tuples_drained_ += c[1]; tuples_dropped_ += c[2];
 			const int32_t zero[2] = {0, 0};
-			if (!be_->H2D(ring_[r].count + 1, zero, sizeof(zero))) return Fail(DTRL_ERR_DEVICE, be_->error());
+			if (!RingWrite(ring_[r].count + 1, zero, sizeof(zero))) return Fail(DTRL_ERR_DEVICE, be_->error());
 		}
 	}
 	return DTRL_OK;

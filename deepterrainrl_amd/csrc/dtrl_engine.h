@@ -16,11 +16,18 @@ class Backend {
 public:
 	virtual ~Backend() {}
 	virtual bool Init(int device_id, std::string& err) = 0;
+	// -reserve_cus= k (before Init): keep k compute units per XCD out of the frame launches (HIP backend; see dtrl_side_stream in include/dtrl.h)
+	virtual void SetReserveCus(int) {}
+	// k = 0, 1: a stream (hipStream_t) whose kernels start on the reserved units while frame launches are in flight; nullptr without a reservation
+	virtual void* SideStream(int) { return nullptr; }
+	virtual double SideStreamDelayUs(int) { return -1.0; }
 	virtual void* Alloc(size_t bytes) = 0;   // zero-filled
 	virtual void Free(void* p) = 0;
 	virtual bool H2D(void* dst, const void* src, size_t n) = 0;
 	// stream-ordered upload without a host sync; src must come from HostStaging() and stay untouched until the next Sync()/D2H()
 	virtual bool H2DAsync(void* dst, const void* src, size_t n) = 0;
+	// stream-ordered download into HostStaging() memory without a host sync (valid after SyncSelected())
+	virtual bool D2HAsync(void* dst, const void* src, size_t n) = 0;
 	virtual void* HostStaging(size_t bytes) = 0;   // page-locked host memory the device can address directly through the same pointer (coherent; plain malloc in the test backend)
 	virtual bool SyncSelected() = 0;               // wait for the selected stream
 	virtual void FreeHostStaging(void* p) = 0;
@@ -80,6 +87,8 @@ public:
 	int GetStates(const int32_t* env_ids, int n, std::vector<EnvState>& out);
 	int SetPoseVel(const int32_t* env_ids, int n, const double* q, const double* qd);
 	int CommandAction(const int32_t* env_ids, int n, const int32_t* action_ids);
+	void ApplyPendingPolicy();
+	void* SideStream(int k, double* delay_us) { if (delay_us) *delay_us = be_ ? be_->SideStreamDelayUs(k) : -1.0; return be_ ? be_->SideStream(k) : nullptr; }
 	int AddPerturb(const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration);
 	int ApplyRandForce(const int32_t* env_ids, int n, uint64_t seed);
 	int GetPoliState(const int32_t* env_ids, int n, double* s);
@@ -124,6 +133,7 @@ private:
 	Backend* be_ = nullptr;
 	int n_ = 0, S_ = 0, A_ = 0, W_ = 0;
 	bool policy_set_ = false;
+	float* weights_alt_ = nullptr; bool policy_flip_pending_ = false;   // SetPolicyDevice during a frame: gathered here, switched in with the next launch
 	bool step_pending_ = false;
 	DevModel* d_model_ = nullptr;
 	DevBuffers buf_{};
@@ -142,6 +152,7 @@ private:
 	std::vector<int32_t> relayout_;
 	// page-locked staging for the per-frame uploads (terrain records, launch order, reset list): the copies are queued on the
 	// stream without a host sync; the arena is recycled after the next frame's status read-back (a stream sync)
+	char* pin_drain_ = nullptr; size_t pin_drain_bytes_ = 0;   // page-locked staging of dtrl_drain_tuples (count word + rows + flags + env ids)
 	GroundRec* pin_recs_ = nullptr;
 	int32_t* pin_order_ = nullptr; int32_t* pin_ids_ = nullptr;
 	std::vector<int32_t> bucket_;
@@ -151,6 +162,10 @@ private:
 	// has just ended can be drained on its own stream while the next frame already runs
 	struct TupleRing { float* rows = nullptr; uint32_t* flags = nullptr; int32_t* env = nullptr; int32_t* count = nullptr; };
 	TupleRing ring_[2];
+	std::vector<void*> host_allocs_;   // page-locked ring storage (-tuple_ring= host)
+	bool AllocRing(TupleRing& r);
+	bool RingRead(void* dst, const void* src, size_t n);
+	bool RingWrite(void* dst, const void* src, size_t n);
 	int wr_ring_ = 0;
 	bool tuple_pipelining_ = false;
 	void UseRing(DevBuffers& b, int r) const { b.tuple_rows = ring_[r].rows; b.tuple_flags = ring_[r].flags; b.tuple_env = ring_[r].env; b.tuple_count = ring_[r].count; }

@@ -594,6 +594,11 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	// exploration (scenarios/ScenarioExp.cpp:16-45)
 	cfg.tuple_buffer_size = 16; args.ParseInt("tuple_buffer_size", cfg.tuple_buffer_size);
 	cfg.tuple_ring_capacity = 0; args.ParseInt("tuple_ring_capacity", cfg.tuple_ring_capacity);
+	{
+		std::string where = "device"; args.ParseString("tuple_ring", where);
+		if (where != "device" && where != "host") { err = "-tuple_ring= must be device or host (page-locked host memory written by the kernels, read by dtrl_drain_tuples without a copy being queued)"; return false; }
+		cfg.tuple_ring_host = where == "host";
+	}
 	double exp_rate = 0.1, exp_temp = 1, exp_base = 0.01;   // cScenarioExp ctor defaults; mExpTemp is uninitialised there -> controller default 1
 	args.ParseDouble("exp_rate", exp_rate); args.ParseDouble("exp_temp", exp_temp); args.ParseDouble("exp_base_rate", exp_base);
 	cfg.run.enable_exp = (m.scenario == kScnExp) ? 1 : 0;

@@ -113,6 +113,7 @@ struct ScenarioConfig {
 	uint64_t terrain_seed = 0;
 	bool device_terrain = false;   // -terrain_gen= device: windows are generated and slid by the GPU at the frame boundary (dtrl_terrain_dev.h)
 	int tuple_buffer_size = 16;
+	bool tuple_ring_host = false;  // -tuple_ring= host: the tuple rings live in page-locked host memory the kernels write directly (drains without a device copy)
 	int tuple_ring_capacity = 0;   // -tuple_ring_capacity=: rows of the device tuple ring (0 = max(2 num_envs, tuple_buffer_size))
 	// cScenarioSimChar::ApplyRandForce ranges (scenarios/ScenarioSimChar.cpp:60-63, 88-91; the duration key's typo is the reference's)
 	double min_perturb = 50, max_perturb = 100, min_perturb_duration = 0.1, max_perturb_duration = 0.5;

@@ -1812,7 +1812,7 @@ DTRL_HD inline void scenario_new_cycle(W& ws, const DevModel& gm, const DevBuffe
 		int slot = -1;
 		if (ws.st.cycle_count > 1) {  // gNumWarmupCycles = 1 (scenarios/ScenarioExp.cpp:12, 314-318)
 #if defined(__HIP_DEVICE_COMPILE__)
-			slot = atomicAdd(buf.tuple_count, 1);
+			slot = __hip_atomic_fetch_add(buf.tuple_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (system scope: the ring may live in page-locked host memory, -tuple_ring= host)
 #else
 			slot = (*buf.tuple_count)++;
 #endif

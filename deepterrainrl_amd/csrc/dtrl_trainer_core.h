@@ -105,6 +105,16 @@ struct FSgdConv { const NetDims* d; const Work* wk; int64_t conv_end; float* w; 
 		sgd_elem(w, hist, g, rate_mult, decay_mult, rate, momentum, weight_decay, i);
 	} };
 
+// staged rows -> replay slots: element i = (row i / W, column i % W) of the page-locked staging area goes to slot (head + row) % mem_size; the flag word with column 0
+struct FAddStaged { const float* src; const int64_t* src_flags; float* mem; int64_t* flags; int W; int64_t head, mem_size;
+	TR_HD void operator()(int64_t i) const
+	{
+		const int64_t r = i / W; const int c = static_cast<int>(i - r * W);
+		const int64_t slot = (head + r) % mem_size;
+		mem[slot * W + c] = src[i];
+		if (c == 0) flags[slot] = src_flags[r];
+	} };
+
 struct TrainerConfig {
 	NetDims dims;
 	int batch = 32, max_eval = 64;
@@ -209,6 +219,23 @@ public:
 	}
 	// replay memory binding: rows [mem_size][W] float32 in the MACE layout [r | s | a | s'], flag words int64 (device pointers, fixed for the trainer's life)
 	void BindReplay(const float* mem, const int64_t* flags, int W) { mem_ = mem; flags_ = flags; W_ = W; }
+	// Staging area for new tuples: page-locked, device-visible rows [kStageRows][W] + flag words. The host writes a frame's rows there ONCE; AddStaged then moves
+	// rows [first, first + n) into the replay slots (head + i) % mem_size on the trainer's stream -- no copy is queued, no framework call, and the write is
+	// ordered with the steps around it (cExpBuffer / cNeuralNetTrainer::AddTuple, learning/NeuralNetTrainer.cpp:145-165: SetTuple at the head, advance the head).
+	static constexpr int kStageRows = 4096;
+	bool EnsureStage()
+	{
+		if (stage_rows || !mem_) return stage_rows != nullptr;
+		stage_rows = static_cast<float*>(HostAlloc(sizeof(float) * static_cast<size_t>(kStageRows) * W_));
+		stage_flags = static_cast<int64_t*>(HostAlloc(sizeof(int64_t) * kStageRows));
+		return stage_rows && stage_flags;
+	}
+	bool AddStaged(int first, int n, int64_t head, int64_t mem_size)
+	{
+		if (!EnsureStage() || first < 0 || n < 0 || first + n > kStageRows || mem_size <= 0 || head < 0 || head >= mem_size || n > mem_size) return false;
+		be.for_each(static_cast<int64_t>(n) * W_, FAddStaged{stage_rows + static_cast<size_t>(first) * W_, stage_flags + first, const_cast<float*>(mem_), const_cast<int64_t*>(flags_), W_, head, mem_size});
+		return be.ok();
+	}
 
 	// idx_host[0 .. batch) = the critic minibatch's slots. loss -> loss_host[0]
 	bool CriticStep() { if (!mem_ || cfg.n_frags <= 0) return false; be.run_graph(0, [this] { CriticStepBody(); }); return be.ok(); }
@@ -282,6 +309,7 @@ public:
 	Work train{}, eval{};                 // host copies (pointers into device memory)
 	NetDims* d_dims = nullptr; Work* d_train = nullptr; Work* d_eval_cur = nullptr; Work* d_eval_tgt = nullptr;   // device-resident descriptors
 	int64_t* idx_host = nullptr; int32_t* better_host = nullptr; float* loss_host = nullptr;
+	float* stage_rows = nullptr; int64_t* stage_flags = nullptr;
 
 private:
 	void* Dev(size_t bytes) { void* p = be.alloc_dev(bytes); if (p) dev_.push_back(p); return p; }

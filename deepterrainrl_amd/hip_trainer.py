@@ -27,6 +27,7 @@ TRAINER_ABI_SYMBOLS = [
     "dtrl_trainer_set_params", "dtrl_trainer_get_params", "dtrl_trainer_params_device", "dtrl_trainer_set_normalizers", "dtrl_trainer_update_target",
     "dtrl_trainer_eval", "dtrl_trainer_step", "dtrl_trainer_bind_replay", "dtrl_trainer_idx", "dtrl_trainer_better", "dtrl_trainer_loss",
     "dtrl_trainer_critic_step", "dtrl_trainer_actor_filter", "dtrl_trainer_actor_step", "dtrl_trainer_debug_get", "dtrl_trainer_critic_step_and_filter",
+    "dtrl_trainer_stage_rows", "dtrl_trainer_stage_flags", "dtrl_trainer_stage_capacity", "dtrl_trainer_add_staged",
 ]
 
 
@@ -59,6 +60,10 @@ def _bind(path):
     L.dtrl_trainer_bind_replay.argtypes = [vp, vp, vp, C.c_int]
     for name, ty in (("dtrl_trainer_idx", C.c_int64), ("dtrl_trainer_better", C.c_int32), ("dtrl_trainer_loss", C.c_float)):
         getattr(L, name).restype = C.POINTER(ty); getattr(L, name).argtypes = [vp]
+    L.dtrl_trainer_stage_rows.restype = C.POINTER(C.c_float); L.dtrl_trainer_stage_rows.argtypes = [vp]
+    L.dtrl_trainer_stage_flags.restype = C.POINTER(C.c_int64); L.dtrl_trainer_stage_flags.argtypes = [vp]
+    L.dtrl_trainer_stage_capacity.argtypes = [vp]
+    L.dtrl_trainer_add_staged.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int64]
     L.dtrl_trainer_critic_step.argtypes = [vp]
     L.dtrl_trainer_critic_step_and_filter.argtypes = [vp]
     L.dtrl_trainer_actor_filter.argtypes = [vp, C.c_int]
@@ -142,7 +147,16 @@ class NativeTrainer:
     def update_target(self): self._chk(self._lib.dtrl_trainer_update_target(self._h))
     def eval(self, which, x_ptr, n, y_ptr): self._chk(self._lib.dtrl_trainer_eval(self._h, which, C.c_void_p(x_ptr), n, C.c_void_p(y_ptr)))
     def step(self, x_ptr, y_ptr): self._chk(self._lib.dtrl_trainer_step(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
-    def bind_replay(self, mem_ptr, flags_ptr, W): self._chk(self._lib.dtrl_trainer_bind_replay(self._h, C.c_void_p(mem_ptr), C.c_void_p(flags_ptr), W))
+    def bind_replay(self, mem_ptr, flags_ptr, W):
+        self._chk(self._lib.dtrl_trainer_bind_replay(self._h, C.c_void_p(mem_ptr), C.c_void_p(flags_ptr), W))
+        self.stage_cap = self._lib.dtrl_trainer_stage_capacity(self._h)
+        pr, pf = self._lib.dtrl_trainer_stage_rows(self._h), self._lib.dtrl_trainer_stage_flags(self._h)
+        if not pr or not pf:
+            raise DtrlError("trainer staging area: " + (self._lib.dtrl_trainer_last_error(self._h) or b"allocation failed").decode())
+        self.stage_rows = np.ctypeslib.as_array(pr, shape=(self.stage_cap, W))
+        self.stage_flags = np.ctypeslib.as_array(pf, shape=(self.stage_cap,))
+
+    def add_staged(self, first, n, head, mem_size): self._chk(self._lib.dtrl_trainer_add_staged(self._h, first, n, head, mem_size))
     def critic_step(self): self._chk(self._lib.dtrl_trainer_critic_step(self._h))
     def critic_step_and_filter(self): self._chk(self._lib.dtrl_trainer_critic_step_and_filter(self._h))
     def actor_filter(self, n): self._chk(self._lib.dtrl_trainer_actor_filter(self._h, n))
@@ -173,6 +187,15 @@ class HipMACETrainer(MACETrainer):
         self.nt.update_target()
         self.nt.bind_replay(self.mem.data_ptr(), self.flags_dev.data_ptr(), self.W)
         self._push_norm()
+
+    def UseStream(self, stream_ptr):
+        """Run the trainer's launches on a stream made elsewhere (a hipStream_t as an int) -- the rollout engine's calibrated side stream
+        (BatchScenario.SideStream): its kernels then start on the compute units the frame launches leave free instead of queueing behind them."""
+        if self.device.type != "cuda":
+            return
+        self.nt.sync()
+        self._stream = torch.cuda.ExternalStream(int(stream_ptr), device=self.device)
+        self.nt.set_stream(int(stream_ptr))
 
     # ---- state that lives in the native trainer ----
     def _push_norm(self):
@@ -214,10 +237,26 @@ class HipMACETrainer(MACETrainer):
         if self._stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._stream)
 
-    def AddTuples(self, rows, flags):
+    def StageTuples(self, rows, flags):
+        """A frame's rows into the trainer's page-locked staging area (one host copy); AddTuples(..., staged=k) then stores rows [k, k + n) of it from the
+        device side on the trainer's stream. Returns how many rows were staged (the area's capacity bounds it; the caller stages the rest afterwards)."""
+        n = min(len(rows), self.nt.stage_cap)
+        self.nt.sync()                               # the previous frame's stores have executed
+        self.nt.stage_rows[:n] = rows[:n]; self.nt.stage_flags[:n] = flags[:n]
+        return n
+
+    def AddTuples(self, rows, flags, staged=None):
+        self._staged = staged
         out = super().AddTuples(rows, flags)
-        self._replay_dirty = True
+        self._staged = None
         return out
+
+    def _store_rows(self, slots, rows, flags, contiguous):
+        if self._staged is not None and contiguous and len(slots) <= self.mem_size:
+            self.nt.add_staged(self._staged, len(slots), int(slots[0]), self.mem_size)     # (every row of the chunk passed CheckTuple: staged row i -> slot head + i)
+        else:
+            super()._store_rows(slots, rows, flags, contiguous)
+            self._replay_dirty = True
 
     # ---- network calls ----
     def _eval(self, net, X):

@@ -57,6 +57,8 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     each frame runs with is one frame staler, as with the reference's concurrent env threads; overlap=False is the strictly
     sequential, reproducible schedule. frames_per_drain > 1 rolls out several outer frames per drain / policy sync (RunFrames: the env
     groups then run without a frame barrier between them, which is where the rollout engine is fastest)."""
+    if overlap:
+        extra_args = dict({"tuple_ring": "host"}, **(extra_args or {}))    # drains beside a running frame must not queue copies behind it (include/dtrl.h: dtrl_drain_tuples)
     args = parse_arg_file(os.path.join(data_root, arg_file))
     args.update({k: str(v) for k, v in (extra_args or {}).items()})
     geti = lambda k, d: int(args.get(k, d)); getf = lambda k, d: float(args.get(k, d))
@@ -69,6 +71,9 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
                init_input_offset_scale=args.get("trainer_init_input_offset_scale", "false").lower() == "true", seed=seed, device=trainer_device)
     t = _make_trainer(args, data_root, train_net, solver, b, tkw, trainer, trainer_lib)
     t.SetOutputOffsetScale(*b.BuildNNOutputOffsetScale())
+    side = b.SideStream(0) if hasattr(b, "SideStream") else (None, -1.0)
+    if side[0] is not None and hasattr(t, "UseStream"):
+        t.UseStream(side[0])     # (-reserve_cus= k in extra_args: the trainer's kernels run beside the rollout on the reserved compute units)
     exp = dict(rate=getf("exp_rate", 0.2), temp=getf("exp_temp", 0.025), base=getf("exp_base_rate", 0.002))
     init = dict(rate=getf("init_exp_rate", 1.0), temp=getf("init_exp_temp", 20.0), base=getf("init_exp_base_rate", 1.0))
     n_anneal, n_base_anneal = geti("trainer_num_anneal_iters", 1), geti("exp_base_anneal_iters", 1)
@@ -98,12 +103,25 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     frames = tuples = 0
     t0 = time.time()
     stats = {"log": []}
+    ph = {"rollout": 0.0, "drain": 0.0, "policy_sync": 0.0, "add_tuples": 0.0, "train": 0.0}   # host wall-clock seconds by phase (stats["phases"])
+    clk = time.perf_counter
+
     def feed(rows, flags, ids):
         o = np.argsort(ids, kind="stable")   # the device ring is filled in completion order; env-id order makes the run reproducible and shard-invariant
         rows, flags = rows[o], flags[o]
+        stage = getattr(t, "StageTuples", None)      # native trainer: the frame's rows go to its page-locked staging area once, chunks are stored from there
+        base = staged = 0
         for k in range(0, len(rows), chunk):
-            t.AddTuples(rows[k:k + chunk], flags[k:k + chunk])
+            c0 = clk()
+            if stage is not None:
+                if k + min(chunk, len(rows) - k) > base + staged:
+                    base = k; staged = stage(rows[k:], flags[k:])
+                t.AddTuples(rows[k:k + chunk], flags[k:k + chunk], staged=k - base)
+            else:
+                t.AddTuples(rows[k:k + chunk], flags[k:k + chunk])
+            c1 = clk()
             t.Train()
+            ph["add_tuples"] += c1 - c0; ph["train"] += clk() - c1
         return len(rows)
 
     def log():
@@ -113,38 +131,50 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
 
     if not overlap:
         while t.GetIter() < max_iters and (max_frames is None or frames < max_frames):
+            c0 = clk()
             if frames_per_drain > 1:
                 b.RunFrames(frames_per_drain)
             else:
                 b.Update(1.0 / 30.0)
             frames += frames_per_drain
-            n = feed(*b.DrainTuples())
+            c1 = clk()
+            drained = b.DrainTuples()
+            ph["rollout"] += c1 - c0; ph["drain"] += clk() - c1
+            n = feed(*drained)
             tuples += n
             if n:
-                sync(t.GetIter())
+                c0 = clk(); sync(t.GetIter()); ph["policy_sync"] += clk() - c0
             log()
     else:
-        pending = None
+        # frame f+1 is launched the moment frame f's boundary work is done (UpdateEndBegin); frame f's tuples are drained from the idle ring, trained on, and the
+        # weights handed over while f+1 runs -- they take effect with frame f+2's launch (dtrl_set_policy_device during a frame): frame f+2 runs on tuples <= f
+        b.SetTuplePipelining(True)
         b.UpdateBegin(1.0 / 30.0)
-        while True:
-            b.UpdateEnd()                                   # frame f is complete (host work done)
+        more = True
+        while more:
             frames += 1
-            drained = b.DrainTuples()
-            if pending is not None and pending[0].shape[0]:
-                sync(t.GetIter())                           # weights trained on frames <= f-1 go in before frame f+1 starts
             more = t.GetIter() < max_iters and (max_frames is None or frames < max_frames)
+            c0 = clk()
             if more:
-                b.UpdateBegin(1.0 / 30.0)                   # frame f+1 runs on the engine's stream ...
-            tuples += feed(*drained)                        # ... while the trainer works through frame f's tuples
-            pending = drained
+                b.UpdateEndBegin(1.0 / 30.0)                # frame f's boundary work, then frame f+1 runs on the engine's streams ...
+            else:
+                b.UpdateEnd()
+            c1 = clk()
+            drained = b.DrainTuples()                       # ... while frame f's tuples are read from the ring the kernels no longer write,
+            c2 = clk()
+            n = feed(*drained)                              # the trainer works through them,
+            tuples += n
+            c3 = clk()
+            if n:
+                sync(t.GetIter())                           # and the new weights are parked for the next launch
+            ph["rollout"] += c1 - c0; ph["drain"] += c2 - c1; ph["policy_sync"] += clk() - c3
             log()
-            if not more:
-                break
+        b.SetTuplePipelining(False)
     dt = time.time() - t0
     if out_scale_file:
         b.WriteOffsetScale(out_scale_file)
     stats.update(frames=frames, iters=t.GetIter(), tuples=tuples, seconds=dt, env_steps_per_s=frames * 20.0 * num_envs / dt,
-                 trainer_iters_per_s=t.GetIter() / dt, weights=t.GetWeights(), offset_scale=t.GetOffsetScale())
+                 trainer_iters_per_s=t.GetIter() / dt, weights=t.GetWeights(), offset_scale=t.GetOffsetScale(), phases=ph, side_stream_delay_us=side[1])
     return stats
 
 

@@ -299,11 +299,17 @@ class MACETrainer:
     def SetWeights(self, w):
         self.net.set_flat(w); self.UpdateTargetNet()
     def GetOffsetScale(self):
-        f = lambda t: t.detach().to(torch.float64).cpu().numpy()
-        return f(self.in_off), f(self.in_scale), f(self.out_off), f(self.out_scale)
+        # host copies, refreshed only after a setter ran: four device read-backs per policy hand-over would each wait behind whatever the GPU is busy with
+        c = getattr(self, "_norm_host", None)
+        if c is None:
+            f = lambda t: t.detach().to(torch.float64).cpu().numpy()
+            c = self._norm_host = (f(self.in_off), f(self.in_scale), f(self.out_off), f(self.out_scale))
+        return tuple(x.copy() for x in c)
     def SetInputOffsetScale(self, off, scale):   # in place: captured graphs keep pointing at these buffers
+        self._norm_host = None
         self.in_off.copy_(torch.as_tensor(off, device=self.device, dtype=self.dtype)); self.in_scale.copy_(torch.as_tensor(scale, device=self.device, dtype=self.dtype))
     def SetOutputOffsetScale(self, off, scale):
+        self._norm_host = None
         self.out_off.copy_(torch.as_tensor(off, device=self.device, dtype=self.dtype)); self.out_scale.copy_(torch.as_tensor(scale, device=self.device, dtype=self.dtype))
     def OutputModel(self, model_file):
         """cNeuralNetTrainer::OutputModel -> cNeuralNet::OutputModel (learning/NeuralNet.cpp:1139-1180): the net as a Caffe HDF5 model
@@ -382,9 +388,7 @@ class MACETrainer:
         keep = np.nonzero(ok)[0]
         if keep.size:
             slots[keep] = (self.head + np.arange(keep.size)) % self.mem_size
-            didx = self._idx(slots[keep])
-            self.mem[didx] = torch.as_tensor(rows[keep], device=self.device)
-            self.flags_dev[didx] = torch.as_tensor(np.asarray(flags, np.int64)[keep], device=self.device)
+            self._store_rows(slots[keep], rows[keep], np.asarray(flags, np.int64)[keep], keep.size == rows.shape[0])
             for i in keep:   # same order as the reference: write slot, advance head, then UpdateBuffers(slot)
                 t = int(slots[i])
                 self.flags[t] = int(flags[i])
@@ -393,6 +397,12 @@ class MACETrainer:
                 self.total_tuples += 1
                 self._update_buffers(t)
         return slots
+
+    def _store_rows(self, slots, rows, flags, contiguous):
+        """SetTuple for a batch of accepted rows (contiguous: no row of the call was rejected, i.e. row i of the call goes to slots[0] + i modulo the ring)"""
+        didx = self._idx(slots)
+        self.mem[didx] = torch.as_tensor(rows, device=self.device)
+        self.flags_dev[didx] = torch.as_tensor(flags, device=self.device)
 
     @staticmethod
     def _buf_add(buf, pos, t):

@@ -108,7 +108,10 @@ dtrl_status dtrl_set_explore(dtrl_batch* b, int enable, double rate, double temp
 dtrl_status dtrl_set_terrain_lerp(dtrl_batch* b, double lerp);
 
 /* Replaces: cScenarioExp::IsTupleBufferFull/GetTuples/ResetTupleBuffer (scenarios/ScenarioExp.h:16-38) for the whole batch.
- * rows: [cap][1 + 2S + A] float32 in the MACE replay row layout [r | s | a | s'] (learning/MACETrainer.cpp:373-401). */
+ * rows: [cap][1 + 2S + A] float32 in the MACE replay row layout [r | s | a | s'] (learning/MACETrainer.cpp:373-401).
+ * Where the rings live is a creation argument: `-tuple_ring= device` (default; the drain is a count read-back plus three copies through a page-locked staging
+ * area, two synchronisations) or `-tuple_ring= host` (page-locked host memory the kernels write directly: the drain queues NOTHING on the GPU -- with frames
+ * in flight every queued copy can wait milliseconds for a wavefront slot, measured 1.2-2.3 ms for the 4-byte count alone). Same rows either way. */
 dtrl_status dtrl_drain_tuples(dtrl_batch* b, float* rows, uint32_t* flags, int32_t* env_ids, int cap, int* out_n);
 
 /* dtrl_drain_tuples with DEVICE destination buffers (e.g. the trainer's replay tensors on the same GPU, or the send buffer of the RCCL tuple
@@ -144,8 +147,19 @@ dtrl_status dtrl_step_end_begin(dtrl_batch* b, double dt);
 dtrl_status dtrl_tuple_stats(dtrl_batch* b, int64_t* pending, int64_t* drained, int64_t* dropped, int32_t* capacity);
 /* dtrl_set_policy with every pointer in DEVICE memory (cNeuralNet::CopyModel is a memcpy per blob between two nets of one process,
  * learning/NeuralNet.cpp:636-658): the trainer's weight blob -- same Caffe blob order -- is re-laid into the kernel's layout by a gather kernel;
- * NULL normaliser pointers keep the current vectors. */
+ * NULL normaliser pointers keep the current vectors. Between dtrl_step_begin and dtrl_step_end a weights-only call does not wait for the frame in flight: the
+ * weights are gathered into a second buffer (weights_dev may be changed when the call returns) and every env's NEXT frame launch runs with them -- the moment the
+ * waiting form takes effect, too. */
 dtrl_status dtrl_set_policy_device(dtrl_batch* b, const float* weights_dev, size_t n, const double* in_off_dev, const double* in_scale_dev, const double* out_off_dev, const double* out_scale_dev);
+
+/* No counterpart in the reference (its trainer and its env threads share CPU cores under the OS scheduler; scenarios/ScenarioTrain.cpp runs them as threads
+ * of one process). On the GPU a frame launch fills every wavefront slot of the compute units it may use for milliseconds, so work that should run BESIDE the
+ * rollout -- the trainer's kernels, the exchange's collective -- needs (1) compute units the frame launches leave alone: `-reserve_cus= k` at creation (or
+ * DTRL_RESERVE_CUS=k) keeps k units per XCD out of them (k / 32 of the rollout rate), and (2) a hardware queue that is not held up by a frame launch waiting
+ * for slots: the engine measures its candidate streams at creation and hands out the two quickest. Returns a hipStream_t (k = 0, 1) owned by the batch, or
+ * NULL without a reservation; *start_delay_us (may be NULL) = how long a burst of 10 small kernels on that stream took beside two frame-sized occupant
+ * launches during the calibration (microseconds: about 70 on a free queue, a thousand or more on a held-up one). */
+void* dtrl_side_stream(dtrl_batch* b, int k, double* start_delay_us);
 
 /* Replaces: cSimCharacter::BuildPose / BuildVel (sim/SimCharacter.cpp:166-225). env_ids == NULL -> envs 0..n-1. */
 dtrl_status dtrl_get_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, double* q, double* qd);

@@ -64,6 +64,16 @@ int dtrl_trainer_step(dtrl_trainer* t, const float* X_dev, const float* Y_dev);
 /* The replay memory the MACE calls below read: rows [mem_size][W] float32 in the MACE layout [r | s | a = (fragment id, params) | s'] exactly as
  * dtrl_drain_tuples emits them, and one int64 flag word per row (bit 0 = fail). Device pointers that stay valid for the trainer's life (mPlaybackMem). */
 int dtrl_trainer_bind_replay(dtrl_trainer* t, const float* mem_dev, const int64_t* flags_dev, int W);
+/* New tuples without a queued copy or a framework call. dtrl_trainer_stage_rows / _flags: page-locked, device-visible staging arrays owned by the trainer
+ * ([dtrl_trainer_stage_capacity()][W] float32 rows as dtrl_drain_tuples emits them, one int64 flag word per row; valid after dtrl_trainer_bind_replay, NULL before).
+ * dtrl_trainer_add_staged moves staged rows [first, first + n) into the replay slots (head + i) % mem_size on the trainer's stream, ordered with the steps
+ * queued around it. Replaces: cNeuralNetTrainer::AddTuple's SetTuple(mBufferHead, tuple) (learning/NeuralNetTrainer.cpp:145-165); CheckTuple, the head and the
+ * actor / critic index buffers stay with the caller. The staged rows must stay untouched until the call has executed (dtrl_trainer_sync, or any later call
+ * whose result the host has read). */
+float* dtrl_trainer_stage_rows(dtrl_trainer* t);
+int64_t* dtrl_trainer_stage_flags(dtrl_trainer* t);
+int dtrl_trainer_stage_capacity(dtrl_trainer* t);
+int dtrl_trainer_add_staged(dtrl_trainer* t, int first, int n, int64_t head, int64_t mem_size);
 /* page-locked, device-visible host arrays owned by the trainer: the caller writes replay slots into idx ([0, batch): critic batch; [batch, 2 batch): actor
  * candidates; [max_eval, max_eval + batch): actor batch -- separate windows, so that queued work never sees a later call's indices) and reads `better` and `loss` after dtrl_trainer_sync -- no copy is queued in either direction */
 int64_t* dtrl_trainer_idx(dtrl_trainer* t);

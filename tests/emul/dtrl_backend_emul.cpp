@@ -20,6 +20,7 @@ public:
 	void Free(void* p) override { std::free(p); }
 	bool H2D(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
 	bool H2DAsync(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
+	bool D2HAsync(void* dst, const void* src, size_t n) override { std::memcpy(dst, src, n); return true; }
 	void* HostStaging(size_t bytes) override { return std::calloc(1, bytes ? bytes : 1); }
 	void FreeHostStaging(void* p) override { std::free(p); }
 	bool SyncSelected() override { return true; }

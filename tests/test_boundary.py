@@ -272,6 +272,43 @@ def test_device_destination_drain_and_policy_hand_over_equal_the_host_calls(da, 
     assert np.array_equal(a.PoseVel()[0], b.PoseVel()[0])
 
 
+def run_policy_hand_over_during_a_frame(scn, om, to_dev=None, n_envs=8, frames=40):
+    """dtrl_set_policy_device between dtrl_step_begin and dtrl_step_end does not wait for the frame: the weights go to the second buffer and the NEXT launch uses
+    them -- the same rollout as handing them over after dtrl_step_end. Policies alternate every third frame so that a missed or early switch shows."""
+    pol = dog_policy(om)
+    rng = np.random.RandomState(12)
+    w0 = np.ascontiguousarray(pol[1], np.float32)
+    ws = [w0, (w0 * (1 + 0.05 * rng.normal(size=w0.size))).astype(np.float32), (w0 * (1 + 0.05 * rng.normal(size=w0.size))).astype(np.float32)]
+    to_dev = to_dev or (lambda x: (x, x.ctypes.data))
+    held = [to_dev(w) for w in ws]
+    args = dict(terrain_seed=31, rand_seed=2)
+    a = scn("args/opt_args_train_mace.txt", n_envs, data_root=REFDATA, extra_args=args)
+    b = scn("args/opt_args_train_mace.txt", n_envs, data_root=REFDATA, extra_args=args)
+    for x in (a, b):
+        x.SetPolicy(pol[1], *pol[2:])
+    a.UpdateBegin()
+    for f in range(frames):
+        k = (f // 3) % 3
+        if f % 3 == 0:
+            a.SetPolicyDevice(held[k][1], w0.size)          # frame f in flight on `a`: parked, effective from frame f + 1
+        a.UpdateEnd()
+        b.Update()                                          # frame f on `b` with the weights frame f of `a` ran with
+        if f % 3 == 0:
+            b.SetPolicyDevice(held[k][1], w0.size)          # between frames: the waiting form
+        pa, pb = a.PoseVel(), b.PoseVel()
+        assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1]), f
+        a.UpdateBegin()
+    a.UpdateEnd()
+    b.Update()
+    ya, yb = a.PolicyOutput(), b.PolicyOutput()
+    assert np.array_equal(a.PoseVel()[0], b.PoseVel()[0])
+    assert np.abs(ya).max() > 0 and np.array_equal(ya, yb)
+
+
+def test_policy_hand_over_during_a_frame(da, om):
+    run_policy_hand_over_during_a_frame(Scenario, om)
+
+
 def run_packed_drain_equals_plain_drain(scn, om, to_ptr=None, read=None):
     """dtrl_drain_tuples_packed: the rows of dtrl_drain_tuples sorted by env id (stable), flag word and GLOBAL env id appended, a header row with the
     count. Rows that do not fit the caller's block are CARRIED, not dropped: they stay in the ring, in order, in front of the newer rows, and a later
@@ -337,7 +374,7 @@ def test_packed_drain_equals_plain_drain(da, om):
     run_packed_drain_equals_plain_drain(Scenario, om)
 
 
-def run_pipelined_drain_equals_sequential(scn, om, to_ptr=None, read=None, n_envs=12, cap=48, frames=90, extra=None):
+def run_pipelined_drain_equals_sequential(scn, om, to_ptr=None, read=None, n_envs=12, cap=48, frames=90, extra=None, extra_b=None):
     """dtrl_set_tuple_pipelining: UpdateEnd(f); UpdateBegin(f + 1); drain -> frame f's tuples from the ring frame f wrote, while frame f + 1 runs.
     The drained stream, frame by frame, equals that of the sequential protocol (Update(); drain) on a twin batch; nothing is lost or duplicated, the
     counters agree, plain drains work in the same place, and the mode cannot be left while a ring still holds rows."""
@@ -348,7 +385,7 @@ def run_pipelined_drain_equals_sequential(scn, om, to_ptr=None, read=None, n_env
     os.environ["DTRL_GROUPS"] = "2"                     # two env groups (two streams) also at this batch size: UpdateEndBegin schedules per group
     try:
         a = scn("args/opt_args_train_mace.txt", n_envs, data_root=REFDATA, extra_args=args)
-        b = scn("args/opt_args_train_mace.txt", n_envs, data_root=REFDATA, extra_args=args)
+        b = scn("args/opt_args_train_mace.txt", n_envs, data_root=REFDATA, extra_args=dict(args, **(extra_b or {})))
     finally:
         if prev is None:
             del os.environ["DTRL_GROUPS"]
@@ -420,6 +457,14 @@ def test_pipelined_drain_equals_sequential_device_terrain(da, om):
     must follow the frame that wrote its ring on the DEVICE). The lane-loop backend is synchronous, so this checks the engine logic; the GPU twin in
     tests/test_gpu_parity.py runs a batch large enough for a frame to outlast the host."""
     run_pipelined_drain_equals_sequential(Scenario, om, extra={"terrain_gen": "device"})
+
+
+def test_host_memory_tuple_ring_equals_the_device_ring(da, om):
+    """-tuple_ring= host (rings in page-locked host memory, written by the kernels, drained without a queued copy) hands out the device ring's tuple stream:
+    the pipelined protocol with plain and packed drains on the host ring vs the sequential protocol on the device ring."""
+    run_pipelined_drain_equals_sequential(Scenario, om, extra_b={"tuple_ring": "host"})
+    with pytest.raises(Exception):
+        Scenario("args/opt_args_train_mace.txt", 2, data_root=REFDATA, extra_args={"tuple_ring": "pinned"})
 
 
 def test_env_id_lists_are_validated(da):

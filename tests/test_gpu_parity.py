@@ -352,6 +352,18 @@ def test_env_id_validation_on_the_gpu(da, hip_boundary):
     TB.test_env_id_lists_are_validated(da)
 
 
+def test_policy_hand_over_during_a_frame_on_the_gpu(da, om):
+    """the deferred dtrl_set_policy_device (second weight buffer, switched in by the next launch) while a frame is REALLY in flight: same rollout as the waiting form"""
+    import torch
+    import test_boundary as TB
+    dev = torch.device("cuda", 0)
+    def to_dev(w):
+        t = torch.from_numpy(w).to(dev); torch.cuda.synchronize()
+        return (t, t.data_ptr())
+    TB.run_policy_hand_over_during_a_frame(da.BatchScenario, om, to_dev=to_dev, n_envs=256, frames=40)
+
+
+@pytest.mark.gpu
 def test_device_resident_tuple_drain_and_policy_hand_over(da, om):
     """dtrl_drain_tuples_device / dtrl_set_policy_device with torch CUDA tensors: identical rows and rollout to the host-pointer calls."""
     import torch
@@ -509,6 +521,15 @@ def test_pipelined_drain_equals_sequential(om):
     import test_boundary as B
     import deepterrainrl_amd as da_mod
     B.run_pipelined_drain_equals_sequential(da_mod.BatchScenario, om, to_ptr=lambda t: t.data_ptr(), read=lambda t: t.cpu().numpy())
+
+
+def test_host_memory_tuple_ring_equals_the_device_ring(om):
+    """-tuple_ring= host on the MI355X: the kernels write tuple rows into page-locked host memory (system-scope cursor atomic), the packed drain's kernels read
+    them from there, the plain drain is a host memcpy -- same tuple stream as the device ring, 768 envs so that frames outlast the host"""
+    import test_boundary as B
+    import deepterrainrl_amd as da_mod
+    B.run_pipelined_drain_equals_sequential(da_mod.BatchScenario, om, to_ptr=lambda t: t.data_ptr(), read=lambda t: t.cpu().numpy(), n_envs=768, cap=1536, frames=60,
+                                            extra_b={"tuple_ring": "host"})
 
 
 def test_pipelined_drain_equals_sequential_device_terrain(om):

@@ -122,7 +122,43 @@ def test_train_loop_runs_on_the_native_trainer(da):
     assert st["iters"] >= 1 and np.all(np.isfinite(st["weights"])) and st["tuples"] >= 32
 
 
+def run_staged_add_equals_plain_add(lib, device):
+    """dtrl_trainer_add_staged (rows stored from the page-locked staging area on the trainer's stream) vs the framework-side store: same replay memory, flag
+    words and training results -- through a ring wrap (300 rows into 256 slots) and a chunk holding a rejected (non-finite) row, which takes the plain path."""
+    rng = np.random.RandomState(4)
+    rows, flags = TT.random_rows(rng, 300, p_actor=0.5)
+    rows[70, 5] = np.nan
+    a = make_native(lib, device); b = make_native(lib, device)
+    b.SetWeights(a.GetWeights())
+    base = staged = 0
+    for k in range(0, 300, 32):
+        n = min(32, 300 - k)
+        if k + n > base + staged:
+            base = k; staged = a.StageTuples(rows[k:], flags[k:])
+        sa = a.AddTuples(rows[k:k + n], flags[k:k + n], staged=k - base)
+        sb = b.AddTuples(rows[k:k + n], flags[k:k + n])
+        assert np.array_equal(sa, sb)
+        a.Train(); b.Train()
+    a.nt.sync(); b.nt.sync()
+    if device != "cpu":
+        torch.cuda.synchronize()
+    ma, mb = a.mem.cpu().numpy(), b.mem.cpu().numpy()
+    assert np.array_equal(ma, mb) and np.array_equal(a.flags_dev.cpu().numpy(), b.flags_dev.cpu().numpy()) and np.abs(ma).max() > 0
+    assert (a.GetIter(), a.actor_iter, a.actor_batch_buffer) == (b.GetIter(), b.actor_iter, b.actor_batch_buffer) and a.GetIter() >= 5
+    assert np.array_equal(a.GetWeights(), b.GetWeights())
+
+
+def test_staged_add_equals_plain_add():
+    run_staged_add_equals_plain_add(EMUL_TRAINER_LIB, "cpu")
+
+
 # ---- the HIP kernels on the MI355X ----
+@pytest.mark.gpu
+def test_gpu_staged_add_equals_plain_add():
+    run_staged_add_equals_plain_add(None, "cuda")
+
+
+
 @pytest.mark.gpu
 def test_gpu_forward_and_step_vs_torch_peer():
     run_forward_and_step_vs_torch_peer(None, "cuda", 5e-5)
