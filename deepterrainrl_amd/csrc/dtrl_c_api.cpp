@@ -335,6 +335,7 @@ try {
 } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(nullptr)); }
 
 // not part of include/dtrl.h: developer hook used by tools/gpu_sections.py with the DTRL_PROFILE build
+int dtrlx_profile_env(dtrl_batch* b, int section, unsigned long long* out, int cap) try { return b ? b->eng.ProfileEnv(section, out, cap) : 1; } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 int dtrlx_profile_sections(dtrl_batch* b, unsigned long long* out, int cap) try { return b ? b->eng.ProfileSections(out, cap) : 1; } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 
 }  // extern "C"

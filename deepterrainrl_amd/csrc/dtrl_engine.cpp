@@ -1154,4 +1154,15 @@ int Engine::ProfileSections(unsigned long long* out, int cap)
 	return DTRL_OK;
 }
 
+// per-env values of one profile section (developer builds)
+int Engine::ProfileEnv(int section, unsigned long long* out, int cap)
+{
+	if (section < 0 || section >= kProfMax || !out || cap < n_) return Fail(DTRL_ERR_ARG, "bad arguments");
+	be_->Sync();
+	std::vector<unsigned long long> all(static_cast<size_t>(kProfMax) * n_);
+	if (!be_->D2H(all.data(), buf_.prof, all.size() * sizeof(unsigned long long))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	for (int e = 0; e < n_; ++e) out[e] = all[static_cast<size_t>(e) * kProfMax + section];
+	return DTRL_OK;
+}
+
 }  // namespace dtrl

@@ -100,7 +100,8 @@ public:
 	int SampleGround(int env, int n, const double* x, double* h, int32_t* seg, int32_t* oi, int32_t* oj);
 	int EvalStats(double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets);
 	int KernelTime(double* avg_ms, int64_t* launches);
-	int ProfileSections(unsigned long long* out, int cap);   // summed s_memtime ticks per kernel section (DTRL_PROFILE builds)
+	int ProfileSections(unsigned long long* out, int cap);
+	int ProfileEnv(int section, unsigned long long* out, int cap);   // summed s_memtime ticks per kernel section (DTRL_PROFILE builds)
 
 	const ScenarioConfig& cfg() const { return cfg_; }
 	int num_envs() const { return n_; }

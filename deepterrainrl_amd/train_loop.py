@@ -50,6 +50,27 @@ def _make_trainer(args, data_root, train_net, solver, b, tkw, trainer="torch", t
     return MACETrainer(train_net, solver, b.S, b.A, **tkw)
 
 
+def feed_chunks(t, rows, flags, chunk, ph=None):
+    """cScenarioTrain's schedule: one AddTuples + Train per `chunk` (-tuple_buffer_size=) tuples, in the order given. A native trainer gets the rows
+    through its page-locked staging area (written once, stored chunk by chunk from there)."""
+    clk = time.perf_counter
+    stage = getattr(t, "StageTuples", None)
+    base = staged = 0
+    for k in range(0, len(rows), chunk):
+        c0 = clk()
+        if stage is not None:
+            if k + min(chunk, len(rows) - k) > base + staged:
+                base = k; staged = stage(rows[k:], flags[k:])
+            t.AddTuples(rows[k:k + chunk], flags[k:k + chunk], staged=k - base)
+        else:
+            t.AddTuples(rows[k:k + chunk], flags[k:k + chunk])
+        c1 = clk()
+        t.Train()
+        if ph is not None:
+            ph["add_tuples"] += c1 - c0; ph["train"] += clk() - c1
+    return len(rows)
+
+
 def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, device_id=-1, extra_args=None, seed=0, log_every=0, out_scale_file=None,
           trainer_device=None, overlap=False, frames_per_drain=1, scenario_cls=BatchScenario, trainer="torch", trainer_lib=None):
     """extra_args override / extend the arg file (both for the engine and for the -trainer_* keys read here).
@@ -108,21 +129,7 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
 
     def feed(rows, flags, ids):
         o = np.argsort(ids, kind="stable")   # the device ring is filled in completion order; env-id order makes the run reproducible and shard-invariant
-        rows, flags = rows[o], flags[o]
-        stage = getattr(t, "StageTuples", None)      # native trainer: the frame's rows go to its page-locked staging area once, chunks are stored from there
-        base = staged = 0
-        for k in range(0, len(rows), chunk):
-            c0 = clk()
-            if stage is not None:
-                if k + min(chunk, len(rows) - k) > base + staged:
-                    base = k; staged = stage(rows[k:], flags[k:])
-                t.AddTuples(rows[k:k + chunk], flags[k:k + chunk], staged=k - base)
-            else:
-                t.AddTuples(rows[k:k + chunk], flags[k:k + chunk])
-            c1 = clk()
-            t.Train()
-            ph["add_tuples"] += c1 - c0; ph["train"] += clk() - c1
-        return len(rows)
+        return feed_chunks(t, rows[o], flags[o], chunk, ph)
 
     def log():
         if log_every and frames % log_every == 0:
@@ -179,7 +186,7 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
 
 
 def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, max_frames=None, extra_args=None, seed=0, device=None,
-                      trainer_device=None, local_device_id=-1, scenario_cls=BatchScenario):
+                      trainer_device=None, local_device_id=-1, scenario_cls=BatchScenario, trainer="torch", trainer_lib=None):
     """cScenarioTrain over several GPUs: one process per GPU (torch.distributed already initialised; backend "nccl" = RCCL on GPUs).
     Every rank rolls out its contiguous range of global env ids; each outer frame the ranks' drained MACE rows are gathered on rank 0
     (the only exchange on the experience side), rank 0 runs the trainer, then one broadcast carries [iteration, weights, normalisers]
@@ -204,7 +211,7 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
         tkw = dict(mem_size=geti("trainer_replay_mem_size", 500000), num_init_samples=geti("trainer_num_init_samples", 200),
                    steps_per_iter=geti("trainer_num_steps_per_iters", 1), freeze_target_iters=geti("trainer_freeze_target_iters", 0),
                    init_input_offset_scale=args.get("trainer_init_input_offset_scale", "false").lower() == "true", seed=seed, device=trainer_device)
-        t = _make_trainer(args, data_root, train_net, solver, b, tkw)
+        t = _make_trainer(args, data_root, train_net, solver, b, tkw, trainer, trainer_lib)
         t.SetOutputOffsetScale(*b.BuildNNOutputOffsetScale())
     exp = dict(rate=getf("exp_rate", 0.2), temp=getf("exp_temp", 0.025), base=getf("exp_base_rate", 0.002))
     init = dict(rate=getf("init_exp_rate", 1.0), temp=getf("init_exp_temp", 20.0), base=getf("init_exp_base_rate", 1.0))
@@ -238,9 +245,7 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
         got = False
         if rank == 0:
             rows, flags, _ = g
-            for k in range(0, len(rows), chunk):
-                t.AddTuples(rows[k:k + chunk], flags[k:k + chunk])
-                t.Train()
+            feed_chunks(t, rows, flags, chunk)
             tuples += len(rows); got = len(rows) > 0
         it = sync(got)
     dt = time.time() - t0

@@ -87,21 +87,24 @@ import torch, torch.distributed as dist
 from conftest import REFDATA, EmulScenario
 from deepterrainrl_amd import train_loop
 dist.init_process_group(backend="gloo")
-st = train_loop.train_distributed("args/opt_args_train_mace.txt", REFDATA, 64, dist, max_frames=90, trainer_device="cpu", scenario_cls=EmulScenario, extra_args={extra!r})
+st = train_loop.train_distributed("args/opt_args_train_mace.txt", REFDATA, 64, dist, max_frames={frames}, trainer_device="cpu", scenario_cls=EmulScenario, extra_args={extra!r}, trainer={trainer!r}, trainer_lib={lib!r})
 if dist.get_rank() == 0:
     np.savez(os.path.join({out!r}, "dist_train.npz"), weights=st["weights"], iters=st["iters"], tuples=st["tuples"], in_off=st["offset_scale"][0])
 dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_two_rank_training_equals_single_process(tmp_path, da):
-    """Rollout shards + tuple gather + trainer on rank 0 + policy broadcast (gloo, world size 2) == train() in one process, bit for bit."""
+@pytest.mark.parametrize("trainer,frames", [("torch", 90), ("hip", 60)])
+def test_two_rank_training_equals_single_process(tmp_path, da, trainer, frames):
+    """Rollout shards + tuple gather + trainer on rank 0 + policy broadcast (gloo, world size 2) == train() in one process, bit for bit -- with the PyTorch
+    peer trainer and with the native trainer step (its plain-loop check build here; rows reach it through the staging area on both sides)."""
+    lib = os.path.join(REPO, "tests", "emul", "libdtrl_trainer_emul.so") if trainer == "hip" else None
     # (identity input normaliser: estimated from 30 tuples instead of the file's 50 000, a near-constant terrain feature gets a scale of 1e9 and the float32
     # net overflows on the first batch -- cNeuralNet::CalcOffsetScale has no floor either; the normaliser itself is covered by tests/test_trainer.py)
     extra = {"terrain_seed": 3, "trainer_num_init_samples": 30, "trainer_replay_mem_size": 512, "trainer_freeze_target_iters": 4,
              "init_exp_rate": 0.3, "init_exp_base_rate": 0.1, "trainer_init_input_offset_scale": "false"}
     script = tmp_path / "train_worker.py"
-    script.write_text(TRAIN_WORKER.format(repo=REPO, out=str(tmp_path), extra=extra))
+    script.write_text(TRAIN_WORKER.format(repo=REPO, out=str(tmp_path), extra=extra, trainer=trainer, lib=lib, frames=frames))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29613", str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -111,9 +114,9 @@ def test_two_rank_training_equals_single_process(tmp_path, da):
     single = tmp_path / "train_single.py"
     single.write_text("import os, sys, numpy as np\nsys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
                       "from conftest import REFDATA, EmulScenario\nfrom deepterrainrl_amd import train_loop\n"
-                      "st = train_loop.train('args/opt_args_train_mace.txt', REFDATA, num_envs=64, max_frames=90, trainer_device='cpu', scenario_cls=EmulScenario, extra_args=%r)\n"
+                      "st = train_loop.train('args/opt_args_train_mace.txt', REFDATA, num_envs=64, max_frames=%d, trainer_device='cpu', scenario_cls=EmulScenario, extra_args=%r, trainer=%r, trainer_lib=%r)\n"
                       "np.savez(os.path.join(%r, 'single_train.npz'), weights=st['weights'], iters=st['iters'], tuples=st['tuples'], in_off=st['offset_scale'][0])\n"
-                      % (REPO, REPO, extra, str(tmp_path)))
+                      % (REPO, REPO, frames, extra, trainer, lib, str(tmp_path)))
     r = subprocess.run([sys.executable, str(single)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     s1 = np.load(tmp_path / "single_train.npz")

@@ -13,7 +13,7 @@ dev = torch.device("cuda", 0)
 make = lambda nl, off: da.BatchScenario(bench.EXCHANGE_ARG_FILE, nl, data_root=bench.ROOT, extra_args={"terrain_seed": 20260925, "rand_seed": 1, "global_env_offset": off})
 sr = ShardedRollout(make, n, device=dev)
 b = sr.batch
-sr.broadcast_policy(bench.xavier_weights(b.PolicyNumParams()), *bench.load_scale())
+sr.broadcast_policy(bench.xavier_weights(b.PolicyNumParams()), *bench.load_scale(bench.CONFIGS[1]))
 b.SetExplore(True, 0.2, 0.025, 0.002)
 T = dict(end=0.0, gbegin=0.0, begin=0.0, gend=0.0, append=0.0)
 replay = torch.zeros((1 << 18, b.W), device=dev); cur = 0

@@ -7,8 +7,8 @@ sys.path.insert(0, REPO)
 import deepterrainrl_amd as da
 import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-b = da.BatchScenario(bench.ARG_FILE, n, data_root=bench.ROOT, extra_args={"terrain_seed": 20260925, "rand_seed": 1})
-b.SetPolicy(bench.xavier_weights(b.PolicyNumParams()), *bench.load_scale())
+b = da.BatchScenario(bench.CONFIGS[1]["arg_file"], n, data_root=bench.ROOT, extra_args={"terrain_seed": 20260925, "rand_seed": 1})
+b.SetPolicy(bench.xavier_weights(b.PolicyNumParams()), *bench.load_scale(bench.CONFIGS[1]))
 prev = b.EvalStats()
 rows = []
 for f in range(100):

@@ -7,8 +7,8 @@ import deepterrainrl_amd as da
 import bench
 for n in [int(a) for a in sys.argv[1:]]:
     t0 = time.time()
-    b = da.BatchScenario(bench.ARG_FILE, n, data_root=bench.ROOT, extra_args={"terrain_seed": 1, "rand_seed": 1, "terrain_gen": os.environ.get("TERRAIN_GEN", "host")})
-    b.SetPolicy(bench.xavier_weights(b.PolicyNumParams()), *bench.load_scale())
+    b = da.BatchScenario(bench.CONFIGS[1]["arg_file"], n, data_root=bench.ROOT, extra_args={"terrain_seed": 1, "rand_seed": 1, "terrain_gen": os.environ.get("TERRAIN_GEN", "host")})
+    b.SetPolicy(bench.xavier_weights(b.PolicyNumParams()), *bench.load_scale(bench.CONFIGS[1]))
     t1 = time.time()
     b.RunFrames(20); b.KernelTimeMs()
     b.EvalStats()   # (synchronises: in device mode RunFrames only queues)

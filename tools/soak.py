@@ -6,8 +6,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import deepterrainrl_amd as da, bench
 n, frames = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, int(sys.argv[2]) if len(sys.argv) > 2 else 3000
-b = da.BatchScenario(bench.ARG_FILE, n, data_root=bench.ROOT, extra_args={"terrain_seed": 99, "rand_seed": 3})
-b.SetPolicy(bench.xavier_weights(b.PolicyNumParams()), *bench.load_scale())
+b = da.BatchScenario(bench.CONFIGS[1]["arg_file"], n, data_root=bench.ROOT, extra_args={"terrain_seed": 99, "rand_seed": 3})
+b.SetPolicy(bench.xavier_weights(b.PolicyNumParams()), *bench.load_scale(bench.CONFIGS[1]))
 prev = b.EvalStats(); t0 = time.time()
 for k in range(frames // 250):
     b.RunFrames(250)
