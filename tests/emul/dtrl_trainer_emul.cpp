@@ -27,9 +27,10 @@ struct EmulTrainerBE {
 	template <class F> void terr_reduce(const NetDims*, const Work*, int n, const F& f) { for_each(n, f); }
 	template <class F> void label_loss(int n, const F& f, const float* sq, float scale, float* out) { for_each(n, f); loss_sum(sq, n, scale, out); }
 	void loss_sum(const float* x, int n, float scale, float* out) { float s = 0; for (int i = 0; i < n; ++i) s += x[i]; *out = scale * s; }
-	void gemm(const NetDims* dp, const Work* wp, const GemmDesc& g)
+	// (the operand switch is folded per instantiation, as in the HIP kernel: the check build is what the CPU suite spends its trainer time in)
+	template <int OP> static void gemm_t(const NetDims& d, const Work& wk, GemmDesc g)
 	{
-		const NetDims& d = *dp; const Work& wk = *wp;
+		g.op = OP;
 		for (int z = 0; z < g.Z; ++z) {
 			const int k_begin = g.k0_step ? z * g.k0_step : 0;
 			const int k_end = g.k0_step ? (k_begin + g.k0_step < g.K ? k_begin + g.k0_step : g.K) : g.K;
@@ -38,6 +39,16 @@ struct EmulTrainerBE {
 				for (int k = k_begin; k < k_end; ++k) acc = __builtin_fmaf(load_a(d, wk, g, z, m, k), load_b(d, wk, g, z, k, n), acc);
 				store_c(d, wk, g, z, m, n, acc);
 			}
+		}
+	}
+	void gemm(const NetDims* dp, const Work* wp, const GemmDesc& g)
+	{
+		switch (g.op) {
+#define DTRL_TR_CASE(k) case k: gemm_t<k>(*dp, *wp, g); break;
+		DTRL_TR_CASE(0) DTRL_TR_CASE(1) DTRL_TR_CASE(2) DTRL_TR_CASE(3) DTRL_TR_CASE(4) DTRL_TR_CASE(5) DTRL_TR_CASE(6) DTRL_TR_CASE(7)
+		DTRL_TR_CASE(8) DTRL_TR_CASE(9) DTRL_TR_CASE(10) DTRL_TR_CASE(11) DTRL_TR_CASE(12) DTRL_TR_CASE(13) DTRL_TR_CASE(14)
+#undef DTRL_TR_CASE
+		default: break;
 		}
 	}
 	template <class F> void for_each(int64_t n, const F& f) { for (int64_t i = 0; i < n; ++i) f(i); }
