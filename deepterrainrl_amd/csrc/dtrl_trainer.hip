@@ -151,6 +151,26 @@ struct HipTrainerBE {
 	bool ok() const { return err_.empty(); }
 	const std::string& error() const { return err_; }
 	bool chk(hipError_t e, const char* what) { if (e == hipSuccess) return true; if (err_.empty()) err_ = std::string(what) + ": " + hipGetErrorString(e); return false; }
+	// fork(): what is queued next runs on a second stream, ordered behind everything queued so far; resume(): back on the trainer's stream WITHOUT waiting
+	// (what is queued next runs beside the second stream's work); join(): the trainer's stream waits for the second one. Lets two independent passes of a step (the target net on 96 rows, the current net on the batch) share the GPU instead of queueing their
+	// ~8 small launches each one after the other. Inside a graph capture the two become parallel branches of the graph. No-ops without a stream of the trainer's own.
+	void fork()
+	{
+		if (!stream || forked_) return;
+		if (!side_ && (hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming) != hipSuccess
+				|| hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming) != hipSuccess)) { side_ = nullptr; (void)hipGetLastError(); return; }
+		if (!chk(hipEventRecord(ev_fork_, stream), "fork record") || !chk(hipStreamWaitEvent(side_, ev_fork_, 0), "fork wait")) return;
+		main_ = stream; stream = side_; forked_ = true;
+	}
+	void resume() { if (forked_) stream = main_; }
+	void join()
+	{
+		if (!forked_) return;
+		chk(hipEventRecord(ev_join_, side_), "join record");
+		stream = main_; forked_ = false;
+		chk(hipStreamWaitEvent(stream, ev_join_, 0), "join wait");
+	}
+	hipStream_t side_ = nullptr, main_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr; bool forked_ = false;
 	void set_stream(void* s)
 	{
 		if (static_cast<hipStream_t>(s) == stream) return;
@@ -221,7 +241,7 @@ struct HipTrainerBE {
 	static constexpr int kMaxGraphs = 8;
 	hipGraphExec_t exec_[kMaxGraphs] = {};
 	bool graph_failed_ = false;
-	~HipTrainerBE() { for (hipGraphExec_t e : exec_) if (e) hipGraphExecDestroy(e); }
+	~HipTrainerBE() { for (hipGraphExec_t e : exec_) if (e) hipGraphExecDestroy(e); if (side_) { hipStreamDestroy(side_); hipEventDestroy(ev_fork_); hipEventDestroy(ev_join_); } }
 	template <class F> void terr_reduce(const NetDims* d, const Work* wk, int n_out, const F&)
 	{
 		hipLaunchKernelGGL(tr_terr_reduce_kernel, dim3((n_out * 16 + 255) / 256), dim3(256), 0, stream, d, wk, n_out);
@@ -231,6 +251,7 @@ struct HipTrainerBE {
 	template <class F> void label_loss(int n, const F& f, const float* sq, float scale, float* out)
 	{
 		// two launches: measured against a single-workgroup fused form (2035-2050 vs 2063-2071 Train()/s): the 12-block label pass + one reduction wins
+		// (the loss reduction on the second stream beside the backward pass: measured slower, 2190-2280 vs 2330/s -- the fork / join events cost more than its 6 us)
 		for_each(n, f); loss_sum(sq, n, scale, out);
 	}
 	// *out = scale * sum(x[0 .. n)): one workgroup, tree reduction in LDS

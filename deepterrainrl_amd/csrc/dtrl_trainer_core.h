@@ -249,11 +249,15 @@ public:
 			const NetDims& d = cfg.dims;
 			const int n = cfg.batch, S = d.S, A = 1 + cfg.frag_size;
 			const int64_t* cand = idx_host + n;
+			// the target net's pass over the 96 rows and the current net's forward over the batch share nothing but read-only inputs: two branches
+			be.fork();
 			be.for_each(static_cast<int64_t>(3 * n) * S, FGatherMulti{S, norm(), mem_, W_, n, {idx_host, cand, cand, nullptr}, {1 + S + A, 1, 1 + S + A, 0}, eval.xin});
-			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1, train.xin});   // (independent of the target pass: queued first)
 			Forward(d_eval_tgt, 3 * n);
 			be.for_each(2 * n, FFusedTargets{norm(), mem_, W_, idx_host, cand, flags_, eval.out, d.out_size, cfg.n_frags, n, cfg.discount, newq, better_host});
+			be.resume();
+			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1, train.xin});
 			Forward(d_train, n);
+			be.join();                     // the labels need new_q
 			be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host);
 			BackwardAndUpdate();
 		});

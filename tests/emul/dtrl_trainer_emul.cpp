@@ -14,6 +14,9 @@ struct EmulTrainerBE {
 	bool ok() const { return err_.empty(); }
 	const std::string& error() const { return err_; }
 	void set_stream(void*) {}
+	void fork() {}
+	void resume() {}
+	void join() {}
 	void* alloc_dev(size_t bytes) { return std::calloc(1, bytes ? bytes : 1); }
 	void free_dev(void* p) { std::free(p); }
 	void* alloc_host(size_t bytes) { return std::calloc(1, bytes ? bytes : 1); }
