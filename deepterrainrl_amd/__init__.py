@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_cycle_info", "dtrl_get_action_table", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
     "dtrl_terrain_build", "dtrl_terrain_load_file", "dtrl_args_parse_string",
-    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed", "dtrl_get_policy_output", "dtrl_set_tuple_pipelining", "dtrl_step_end_begin", "dtrl_command_action", "dtrl_side_stream",
+    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed", "dtrl_get_policy_output", "dtrl_set_tuple_pipelining", "dtrl_step_end_begin", "dtrl_command_action", "dtrl_side_stream", "dtrl_step_poll",
 ]
 
 
@@ -102,6 +102,7 @@ def _bind(path):
     L.dtrl_get_policy_output.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_set_tuple_pipelining.argtypes = [vp, C.c_int]
     L.dtrl_step_end_begin.argtypes = [vp, C.c_double]
+    L.dtrl_step_poll.argtypes = [vp, C.c_double, C.POINTER(C.c_int)]
     L.dtrl_get_flags.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_contacts.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_get_ctrl.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
@@ -195,6 +196,13 @@ class BatchScenario:
     def UpdateEndBegin(self, dt=1.0 / 30.0):
         """UpdateEnd() + UpdateBegin(dt) without the barrier between them (dtrl_step_end_begin): each env group is relaunched as soon as its own frame is done."""
         self._chk(self._lib.dtrl_step_end_begin(self._h, float(dt)))
+
+    def UpdatePoll(self, dt=1.0 / 30.0):
+        """dtrl_step_poll: relaunch, without blocking, every env group whose frame has already ended (between two UpdateEndBegin calls, after the drain).
+        Returns how many groups were relaunched."""
+        n = C.c_int(0)
+        self._chk(self._lib.dtrl_step_poll(self._h, float(dt), C.byref(n)))
+        return n.value
 
     def StepUpdates(self, n):
         self._chk(self._lib.dtrl_step_updates(self._h, int(n)))

@@ -261,6 +261,7 @@ public:
 		streams_[kNumStreams - 1] = pick[0];
 		side_[0] = pick[1]; side_[1] = pick[2];
 		for (int i = kNumStreams / 2, k = 3; i < kNumStreams - 1; ++i, ++k) streams_[i] = pick[k];
+		calibrated_ = true;
 		owned_.assign(cand.begin(), cand.end());      // every candidate stays alive (destroying one could re-seat the others) and is destroyed with the backend
 		if (std::getenv("DTRL_HOST_TIMING")) {
 			std::fprintf(stderr, "[dtrl] side-stream calibration: 10-kernel burst beside the occupants, us per candidate (sorted):");
@@ -270,8 +271,10 @@ public:
 		return true;
 	}
 	void SetReserveCus(int k) override { reserve_arg_ = k; }
-	void* SideStream(int k) override { return (masked_ && k >= 0 && k < 2) ? static_cast<void*>(side_[k]) : nullptr; }
-	double SideStreamDelayUs(int k) override { return (masked_ && k >= 0 && k + 1 < static_cast<int>(side_delay_us_.size())) ? side_delay_us_[k + 1] : -1.0; }
+	// (without a reservation there is nothing to hand out: measured, a calibrated stream then did no better than any other -- A/B on one box, dog training loop:
+	// 10.0 / 10.1 / 11.2 / 10.9 M with it, 11.2 / 11.3 / 11.2 / 11.2 M on the framework's own stream -- the occupants of the calibration leave room the frame kernel does not)
+	void* SideStream(int k) override { return (masked_ && calibrated_ && k >= 0 && k < 2) ? static_cast<void*>(side_[k]) : nullptr; }
+	double SideStreamDelayUs(int k) override { return (calibrated_ && k >= 0 && k + 1 < static_cast<int>(side_delay_us_.size())) ? side_delay_us_[k + 1] : -1.0; }
 	void* Alloc(size_t bytes) override
 	{
 		void* p = nullptr;
@@ -387,7 +390,7 @@ private:
 	bool Check(hipError_t e, const char* what) { if (e == hipSuccess) return true; err_ = std::string(what) + ": " + hipGetErrorString(e); return false; }
 	static constexpr int kNumStreams = 8;
 	int reserve_arg_ = -1;             // -reserve_cus= (else DTRL_RESERVE_CUS)
-	bool masked_ = false;
+	bool masked_ = false, calibrated_ = false;
 	hipStream_t side_[2] = {nullptr, nullptr};
 	std::vector<hipStream_t> extra_, owned_;
 	std::vector<double> side_delay_us_;

@@ -222,6 +222,10 @@ dtrl_status dtrl_step_end_begin(dtrl_batch* b, double dt)
 try {
 	CHECK_B(); return static_cast<dtrl_status>(b->eng.StepEndBegin(dt));
 } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_step_poll(dtrl_batch* b, double dt, int* relaunched)
+try {
+	CHECK_B(); return static_cast<dtrl_status>(b->eng.StepPoll(dt, relaunched));
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_set_tuple_pipelining(dtrl_batch* b, int on)
 try {
 	CHECK_B(); return static_cast<dtrl_status>(b->eng.SetTuplePipelining(on != 0));

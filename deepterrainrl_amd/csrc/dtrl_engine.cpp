@@ -455,6 +455,7 @@ int Engine::StepBegin(double dt)
 int Engine::StepEnd()
 {
 	if (!step_pending_) return DTRL_OK;
+	if (early_any_) return Fail(DTRL_ERR_ARG, "dtrl_step_end after dtrl_step_poll relaunched a group: the groups are a frame apart, call dtrl_step_end_begin first");
 	step_pending_ = false;
 	for (size_t g = 0; g < groups_.size(); ++g) { int rc = HostFrameWork(static_cast<int>(g)); if (rc != DTRL_OK) return rc; }
 	return DTRL_OK;
@@ -472,7 +473,10 @@ int Engine::StepEndBegin(double dt)
 	ApplyPendingPolicy();   // (every group's NEXT launch runs with the weights handed over during the frame that is ending)
 	if (tuple_pipelining_) { wr_ring_ ^= 1; UseRing(buf_, wr_ring_); }
 	std::vector<char> done(static_cast<size_t>(G), 0);
-	for (int remaining = G; remaining > 0; --remaining) {
+	int remaining = G;
+	for (int c = 0; c < G; ++c) if (c < static_cast<int>(early_.size()) && early_[c]) { done[c] = 1; --remaining; }   // relaunched by dtrl_step_poll already (into the ring just switched to)
+	early_.assign(static_cast<size_t>(G), 0); early_any_ = false;
+	for (; remaining > 0; --remaining) {
 		int g = -1;
 		for (int c = 0; c < G; ++c) if (!done[c] && be_->StreamIdle(c)) { g = c; break; }
 		if (g < 0) for (int c = 0; c < G; ++c) if (!done[c]) { g = c; break; }
@@ -480,6 +484,41 @@ int Engine::StepEndBegin(double dt)
 		if (rc == DTRL_OK) rc = LaunchGroup(g, steps, dt / steps, true);
 		if (rc != DTRL_OK) return rc;
 		done[g] = 1;
+	}
+	return DTRL_OK;
+}
+
+// Between two dtrl_step_end_begin calls, with tuple pipelining on and the idle ring drained: every env group whose frame has ALREADY ended gets its
+// boundary work and its next launch now (into the idle ring) instead of at the next dtrl_step_end_begin -- a caller that spends milliseconds between the two
+// calls (a trainer working through the drained tuples) would otherwise leave a finished group's half of the GPU idle until it comes back. Never blocks.
+// The next dtrl_step_end_begin handles the remaining groups only. Until then the tuple rings must not be touched (both are being written).
+int Engine::StepPoll(double dt, int* relaunched)
+{
+	if (relaunched) *relaunched = 0;
+	if (!step_pending_ || !tuple_pipelining_ || dt <= 0 || cfg_.device_terrain) return DTRL_OK;
+	const int G = static_cast<int>(groups_.size());
+	if (static_cast<int>(early_.size()) != G) early_.assign(static_cast<size_t>(G), 0);
+	if (!early_any_) {
+		// the ring the early launches will write must be empty: it is the one the caller has just drained
+		DevBuffers o = buf_; UseRing(o, wr_ring_ ^ 1);
+		int32_t cnt = 0;
+		if (cfg_.tuple_ring_host) cnt = *o.tuple_count;
+		else return DTRL_OK;   // (a device ring's cursor cannot be read without queueing a copy behind the frame: the early relaunch is a host-ring feature)
+		if (cnt != 0) return DTRL_OK;
+	}
+	const int steps = cfg_.model.num_update_steps;
+	for (int g = 0; g < G; ++g) {
+		if (early_[g] || !be_->StreamIdle(g)) continue;
+		int rc = HostFrameWork(g);
+		if (rc != DTRL_OK) return rc;
+		DevBuffers keep = buf_;
+		UseRing(buf_, wr_ring_ ^ 1);
+		const int ring_now = wr_ring_; wr_ring_ ^= 1;          // (LaunchGroup marks the frame under the ring it writes)
+		rc = LaunchGroup(g, steps, dt / steps, true);
+		wr_ring_ = ring_now; buf_ = keep;
+		if (rc != DTRL_OK) return rc;
+		early_[g] = 1; early_any_ = true;
+		if (relaunched) ++*relaunched;
 	}
 	return DTRL_OK;
 }
@@ -795,6 +834,7 @@ int Engine::SetTuplePipelining(bool on)
 }
 bool Engine::DrainSync()
 {
+	if (early_any_) { err_ = "tuple rings are both in use: dtrl_step_poll relaunched a group; call dtrl_step_end_begin (or dtrl_step_end) first"; return false; }
 	if (tuple_pipelining_ && step_pending_) {   // the drain ring's frame ended with dtrl_step_end; the frame in flight writes the other ring
 		// "ended" is a host-side fact only in host terrain mode (HostFrameWork synchronises the group's stream). In device terrain mode the frame may
 		// still be running: the drain stream waits on the device for the mark behind every group's launch of that frame -- a torn row (the cursor is

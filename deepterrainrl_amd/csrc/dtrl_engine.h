@@ -88,7 +88,7 @@ public:
 	int SetPoseVel(const int32_t* env_ids, int n, const double* q, const double* qd);
 	int CommandAction(const int32_t* env_ids, int n, const int32_t* action_ids);
 	void ApplyPendingPolicy();
-	void* SideStream(int k, double* delay_us) { if (delay_us) *delay_us = be_ ? be_->SideStreamDelayUs(k) : -1.0; return be_ ? be_->SideStream(k) : nullptr; }
+	void* SideStream(int k, double* delay_us) { void* s = be_ ? be_->SideStream(k) : nullptr; if (delay_us) *delay_us = be_ ? be_->SideStreamDelayUs(k) : -1.0; return s; }
 	int AddPerturb(const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration);
 	int ApplyRandForce(const int32_t* env_ids, int n, uint64_t seed);
 	int GetPoliState(const int32_t* env_ids, int n, double* s);
@@ -97,6 +97,7 @@ public:
 	int DrainTuplesPacked(float* block_dev, int block_rows, int* out_n);
 	int SetTuplePipelining(bool on);
 	int StepEndBegin(double dt);
+	int StepPoll(double dt, int* relaunched);
 	int SampleGround(int env, int n, const double* x, double* h, int32_t* seg, int32_t* oi, int32_t* oj);
 	int EvalStats(double* avg_dist, int64_t* episodes, int64_t* cycles, int64_t* resets);
 	int KernelTime(double* avg_ms, int64_t* launches);
@@ -134,6 +135,7 @@ private:
 	Backend* be_ = nullptr;
 	int n_ = 0, S_ = 0, A_ = 0, W_ = 0;
 	bool policy_set_ = false;
+	std::vector<char> early_; bool early_any_ = false;   // env groups dtrl_step_poll has relaunched ahead of the next dtrl_step_end_begin
 	float* weights_alt_ = nullptr; bool policy_flip_pending_ = false;   // SetPolicyDevice during a frame: gathered here, switched in with the next launch
 	bool step_pending_ = false;
 	DevModel* d_model_ = nullptr;

@@ -179,7 +179,7 @@ class HipMACETrainer(MACETrainer):
         assert self.nt.num_params == self.net.num_params()
         # a stream of the trainer's own (its fixed launch sequences are recorded as HIP graphs, which the legacy default stream does not allow); ordered
         # against the framework's stream where the two meet: replay rows written by AddTuples, tensors handed to / taken from _eval and _solver_step
-        self._stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None   # (a high-priority stream was measured: no gain beside the rollout)
         if self._stream is not None:
             self.nt.set_stream(self._stream.cuda_stream)
         self.nt.set_params(0, self.net.get_flat())

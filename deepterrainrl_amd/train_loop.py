@@ -50,7 +50,7 @@ def _make_trainer(args, data_root, train_net, solver, b, tkw, trainer="torch", t
     return MACETrainer(train_net, solver, b.S, b.A, **tkw)
 
 
-def feed_chunks(t, rows, flags, chunk, ph=None):
+def feed_chunks(t, rows, flags, chunk, ph=None, poll=None):
     """cScenarioTrain's schedule: one AddTuples + Train per `chunk` (-tuple_buffer_size=) tuples, in the order given. A native trainer gets the rows
     through its page-locked staging area (written once, stored chunk by chunk from there)."""
     clk = time.perf_counter
@@ -66,18 +66,25 @@ def feed_chunks(t, rows, flags, chunk, ph=None):
             t.AddTuples(rows[k:k + chunk], flags[k:k + chunk])
         c1 = clk()
         t.Train()
+        c2 = clk()
+        if poll is not None:
+            poll()                      # an env group whose frame ended meanwhile is relaunched now, not when the whole batch of tuples is through
         if ph is not None:
-            ph["add_tuples"] += c1 - c0; ph["train"] += clk() - c1
+            ph["add_tuples"] += c1 - c0; ph["train"] += c2 - c1
+            if poll is not None:
+                ph["rollout"] += clk() - c2
     return len(rows)
 
 
 def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, device_id=-1, extra_args=None, seed=0, log_every=0, out_scale_file=None,
-          trainer_device=None, overlap=False, frames_per_drain=1, scenario_cls=BatchScenario, trainer="torch", trainer_lib=None):
+          trainer_device=None, overlap=False, frames_per_drain=1, scenario_cls=BatchScenario, trainer="torch", trainer_lib=None, poll=False):
     """extra_args override / extend the arg file (both for the engine and for the -trainer_* keys read here).
     overlap=True trains on frame f's tuples while the GPU already rolls out frame f+1 (dtrl_step_begin / dtrl_step_end): the policy
     each frame runs with is one frame staler, as with the reference's concurrent env threads; overlap=False is the strictly
     sequential, reproducible schedule. frames_per_drain > 1 rolls out several outer frames per drain / policy sync (RunFrames: the env
-    groups then run without a frame barrier between them, which is where the rollout engine is fastest)."""
+    groups then run without a frame barrier between them, which is where the rollout engine is fastest). poll=True (with overlap) relaunches an env group
+    whose frame ends while the trainer is busy between two Train() calls (dtrl_step_poll) -- measured on one GPU: ~2 early relaunches per frame and no gain
+    (dog 9.95-11.2 M with, 11.2-11.4 M without: the trainer's kernels and the frame waves share the same wavefront slots either way), so it is off by default."""
     if overlap:
         extra_args = dict({"tuple_ring": "host"}, **(extra_args or {}))    # drains beside a running frame must not queue copies behind it (include/dtrl.h: dtrl_drain_tuples)
     args = parse_arg_file(os.path.join(data_root, arg_file))
@@ -127,9 +134,9 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     ph = {"rollout": 0.0, "drain": 0.0, "policy_sync": 0.0, "add_tuples": 0.0, "train": 0.0}   # host wall-clock seconds by phase (stats["phases"])
     clk = time.perf_counter
 
-    def feed(rows, flags, ids):
+    def feed(rows, flags, ids, poll=None):
         o = np.argsort(ids, kind="stable")   # the device ring is filled in completion order; env-id order makes the run reproducible and shard-invariant
-        return feed_chunks(t, rows[o], flags[o], chunk, ph)
+        return feed_chunks(t, rows[o], flags[o], chunk, ph, poll)
 
     def log():
         if log_every and frames % log_every == 0:
@@ -155,6 +162,7 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     else:
         # frame f+1 is launched the moment frame f's boundary work is done (UpdateEndBegin); frame f's tuples are drained from the idle ring, trained on, and the
         # weights handed over while f+1 runs -- they take effect with frame f+2's launch (dtrl_set_policy_device during a frame): frame f+2 runs on tuples <= f
+        want_poll = poll
         b.SetTuplePipelining(True)
         b.UpdateBegin(1.0 / 30.0)
         more = True
@@ -169,7 +177,11 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
             c1 = clk()
             drained = b.DrainTuples()                       # ... while frame f's tuples are read from the ring the kernels no longer write,
             c2 = clk()
-            n = feed(*drained)                              # the trainer works through them,
+            # (a group that finishes its frame while the trainer is busy is relaunched between two Train() calls -- only when another UpdateEndBegin is certain to follow)
+            sure = more and (max_frames is None or frames + 1 < max_frames) and t.GetIter() + len(drained[0]) // chunk + 2 < max_iters
+            def poll_fn():
+                ph["early_relaunches"] = ph.get("early_relaunches", 0) + b.UpdatePoll(1.0 / 30.0)
+            n = feed(*drained, poll=poll_fn if (want_poll and sure and hasattr(b, "UpdatePoll")) else None)   # the trainer works through them,
             tuples += n
             c3 = clk()
             if n:

@@ -140,6 +140,14 @@ dtrl_status dtrl_set_tuple_pipelining(dtrl_batch* b, int on);
  * what dtrl_run_frames does inside, one frame at a time, for callers that act between frames (drain tuples, scenarios/ScenarioTrain.cpp:376-410).
  * Without a pending step it is dtrl_step_begin. */
 dtrl_status dtrl_step_end_begin(dtrl_batch* b, double dt);
+/* For a caller that works for milliseconds between two dtrl_step_end_begin calls (a trainer going through the drained tuples, one Train() per 32 of them --
+ * the reference's env threads keep stepping meanwhile, scenarios/ScenarioTrain.cpp:376-410). Never blocks: every env group whose frame has ALREADY ended gets its
+ * frame-boundary work and its next launch now (writing the ring the caller has just drained) instead of waiting for the caller to come back; *relaunched (may be
+ * NULL) = how many groups that was. The next dtrl_step_end_begin then handles the other groups only. Needs tuple pipelining, `-tuple_ring= host` (the idle ring's
+ * cursor is checked without queueing a copy) and host terrain mode; otherwise, or when the idle ring still holds rows, it does nothing. After a relaunch both rings
+ * are being written: tuple drains and dtrl_step_end are refused until the next dtrl_step_end_begin. A group relaunched here runs its frame with the policy of the
+ * last hand-over that had taken effect (one frame staler than the groups relaunched later). */
+dtrl_status dtrl_step_poll(dtrl_batch* b, double dt, int* relaunched);
 /* The reference never drops a tuple (scenarios/ScenarioTrain.cpp:376-410 trains whenever a scene's buffer is full). Here the ring holds
  * max(2 num_envs, -tuple_buffer_size=) rows (-tuple_ring_capacity= overrides); rows completed while it is full are COUNTED, not stored:
  * pending = rows waiting in the ring, drained = rows handed out so far, dropped = rows lost to a full ring since creation (stays 0 when

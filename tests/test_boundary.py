@@ -459,6 +459,61 @@ def test_pipelined_drain_equals_sequential_device_terrain(da, om):
     run_pipelined_drain_equals_sequential(Scenario, om, extra={"terrain_gen": "device"})
 
 
+def run_step_poll_keeps_the_tuple_stream(scn, om, n_envs=12, frames=80, work=None):
+    """dtrl_step_poll between two dtrl_step_end_begin calls (groups that have finished are relaunched at once, into the ring just drained) does not change what
+    is drained frame by frame, nor the trajectories; rings are refused while both are being written."""
+    pol = dog_policy(om)
+    args = dict(terrain_seed=31, rand_seed=2, tuple_ring="host")
+    prev = os.environ.get("DTRL_GROUPS")
+    os.environ["DTRL_GROUPS"] = "2"
+    try:
+        a = scn("args/opt_args_train_mace.txt", n_envs, data_root=REFDATA, extra_args=args)
+        b = scn("args/opt_args_train_mace.txt", n_envs, data_root=REFDATA, extra_args=args)
+    finally:
+        if prev is None:
+            del os.environ["DTRL_GROUPS"]
+        else:
+            os.environ["DTRL_GROUPS"] = prev
+    for x in (a, b):
+        x.SetPolicy(pol[1], *pol[2:])
+    seq = []
+    for f in range(frames):
+        a.Update()
+        r, fl, ids = a.DrainTuples(); o = np.argsort(ids, kind="stable")
+        seq.append((r[o], fl[o], ids[o]))
+    b.SetTuplePipelining(True)
+    b.UpdateBegin()
+    early = total = 0
+    for f in range(frames):
+        if f + 1 < frames:
+            b.UpdateEndBegin()
+        else:
+            b.UpdateEnd()
+        r, fl, ids = b.DrainTuples(); o = np.argsort(ids, kind="stable")
+        assert np.array_equal(r[o], seq[f][0]) and np.array_equal(fl[o], seq[f][1]) and np.array_equal(ids[o], seq[f][2]), f
+        total += len(r)
+        if f + 2 < frames:
+            if work is not None:
+                work()                                   # (on the GPU: give the frame time to end, as a trainer's batch of Train() calls does)
+            k = b.UpdatePoll()
+            early += k
+            if k:
+                with pytest.raises(Exception):
+                    b.DrainTuples()                      # both rings are being written now
+                with pytest.raises(Exception):
+                    b.UpdateEnd()
+    assert total >= 20 and early >= 2
+    qa, qb = a.PoseVel(), b.PoseVel()
+    assert np.array_equal(qa[0], qb[0]) and np.array_equal(qa[1], qb[1])
+    b.SetTuplePipelining(False)
+    return early
+
+
+def test_step_poll_keeps_the_tuple_stream(da, om):
+    early = run_step_poll_keeps_the_tuple_stream(Scenario, om)
+    assert early == 2 * 78                              # the lane-loop backend is synchronous: every poll finds both groups finished
+
+
 def test_host_memory_tuple_ring_equals_the_device_ring(da, om):
     """-tuple_ring= host (rings in page-locked host memory, written by the kernels, drained without a queued copy) hands out the device ring's tuple stream:
     the pipelined protocol with plain and packed drains on the host ring vs the sequential protocol on the device ring."""

@@ -523,6 +523,18 @@ def test_pipelined_drain_equals_sequential(om):
     B.run_pipelined_drain_equals_sequential(da_mod.BatchScenario, om, to_ptr=lambda t: t.data_ptr(), read=lambda t: t.cpu().numpy())
 
 
+def test_step_poll_keeps_the_tuple_stream(om):
+    """dtrl_step_poll on the MI355X: sometimes no group, sometimes one, sometimes both have finished when the poll comes (a short sleep stands for the trainer's work)"""
+    import time
+    import test_boundary as B
+    import deepterrainrl_amd as da_mod
+    k = [0]
+    def work():
+        k[0] += 1
+        time.sleep(0.0004 * (k[0] % 4))
+    B.run_step_poll_keeps_the_tuple_stream(da_mod.BatchScenario, om, n_envs=1536, frames=60, work=work)
+
+
 def test_host_memory_tuple_ring_equals_the_device_ring(om):
     """-tuple_ring= host on the MI355X: the kernels write tuple rows into page-locked host memory (system-scope cursor atomic), the packed drain's kernels read
     them from there, the plain drain is a host memcpy -- same tuple stream as the device ring, 768 envs so that frames outlast the host"""

@@ -18,15 +18,16 @@ ap.add_argument("--overlap", action="store_true", help="train on frame f while f
 ap.add_argument("--trainer", choices=["torch", "hip"], default="hip", help="hip: the MI355X-native trainer step (hip_trainer.py); torch: the PyTorch peer (trainer.py, HIP-graph replay)")
 ap.add_argument("--reserve-cus", type=int, default=None, help="compute units per XCD kept out of the frame launches for the trainer's kernels (engine arg -reserve_cus=; default 0: measured 11.3 M env-steps/s without, 9.7 M with 2 per XCD -- the trainer's small GEMMs run 3x slower on 16-32 units than in the frame kernel's gaps on 256)")
 ap.add_argument("--init-samples", type=int, default=None, help="override -trainer_num_init_samples= (the arg files collect 50 000 tuples before the first iteration: ~235 frames of 4096 dogs)")
+ap.add_argument("--poll", action="store_true", help="with --overlap: relaunch env groups between Train() calls (dtrl_step_poll; measured: no gain on one GPU)")
 ap.add_argument("--out", default=None, help="write weights (.npy) and <out>_scale.txt")
 a = ap.parse_args()
 reserve = a.reserve_cus if a.reserve_cus is not None else 0
 st = train_loop.train(a.arg_file, a.data_root, a.envs, max_iters=a.iters, max_frames=a.frames, log_every=50, overlap=a.overlap, frames_per_drain=a.frames_per_drain,
                       extra_args=dict(({"reserve_cus": reserve} if reserve else {}), **({"trainer_num_init_samples": a.init_samples} if a.init_samples is not None else {})) or None,
-                      out_scale_file=(a.out + "_scale.txt") if a.out else None, trainer=a.trainer)
+                      out_scale_file=(a.out + "_scale.txt") if a.out else None, trainer=a.trainer, poll=a.poll)
 if a.out:
     np.save(a.out + ".npy", st["weights"])
 print("[trainer=%s reserve_cus=%d side-stream start delay %.0f us] " % (a.trainer, reserve, st["side_stream_delay_us"]), end="")
 print("frames %d  trainer iters %d  tuples %d  %.1f s  ->  %.2f M env-steps/s while training, %.1f trainer iters/s" % (
     st["frames"], st["iters"], st["tuples"], st["seconds"], st["env_steps_per_s"] / 1e6, st["trainer_iters_per_s"]))
-print("   host wall-clock by phase (ms per frame): " + "  ".join("%s %.2f" % (k, 1e3 * v / max(st["frames"], 1)) for k, v in st["phases"].items()))
+print("   host wall-clock by phase (ms per frame): " + "  ".join("%s %.2f" % (k, 1e3 * v / max(st["frames"], 1)) for k, v in st["phases"].items() if k != "early_relaunches") + "  | env groups relaunched between Train() calls: %d" % st["phases"].get("early_relaunches", 0))
