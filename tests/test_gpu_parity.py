@@ -238,6 +238,26 @@ def test_bench_contract_line():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
 
 
+def test_bench_under_a_launcher_with_the_rccl_path_on_one_rank():
+    """The N > 1 code path as far as one GPU can take it: bench.py started by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+    launcher's environment, as the driver starts it) with a one-rank RCCL group (DTRL_FORCE_COLLECTIVES=1): process-group start-up, the barrier / all-reduce of
+    the timed windows, the gather of the packed tuple block and the policy broadcast all run through RCCL; one JSON line from rank 0."""
+    import json, subprocess, sys
+    from conftest import REPO
+    env = dict(os.environ, DTRL_FORCE_COLLECTIVES="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--envs-per-gpu", "512", "--exchange-steps", "40", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl"] and d["rccl"]["ranks"] == 1 and d["value"] > 1e5
+    ex = d["exchange"]
+    assert "error" not in ex and "RCCL" in ex["collective"] and ex["tuples"] > 0 and ex["dropped_tuples"] == 0
+    assert ex["collective_bytes_per_frame"]["sent_per_rank"] == ex["tuple_block_bytes"] > 0
+
+
 def test_fsm_controllers_locomote_at_scale(da, om):
     """Behavioural sanity at batch scale (no network, shipped FSM parameters): the bounding dog and the running raptor make steady
     forward progress on flat ground in every env -- the same check tests/test_oracle_kat.py applies to the oracle's single env."""
