@@ -211,18 +211,25 @@ class ShardedRollout:
             secs.append(buf[o:o + 8 * n].view(torch.float64)); o += 8 * n
         return [w] + secs
 
-    def broadcast_policy(self, weights=None, in_off=None, in_scale=None, out_off=None, out_scale=None, src=0):
+    def broadcast_policy(self, weights=None, in_off=None, in_scale=None, out_off=None, out_scale=None, src=0, normalizers=True, want_host=True):
         """Trainer rank pushes the policy (numpy arrays or tensors); every rank installs it from the device buffer
-        (cNeuralNetLearner::SyncNet over one RCCL broadcast). Returns the five arrays as numpy (host copies for callers that log them)."""
+        (cNeuralNetLearner::SyncNet over one RCCL broadcast). Returns the five arrays as numpy (host copies for callers that log them; want_host=False: None).
+        normalizers=False (every rank must pass the same value) installs the weights only -- which, while a frame is in flight, does not wait for it
+        (dtrl_set_policy_device: second weight buffer, switched in by the next launch); the four vectors still travel in the one buffer, unused."""
         torch = self.torch
         views = self._pol_views()
         if self.rank == src:
             for v, a in zip(views, (weights, in_off, in_scale, out_off, out_scale)):
+                if a is None:
+                    continue
                 t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a, np.float32 if v.dtype == torch.float32 else np.float64))
                 v.copy_(t.to(self.device, dtype=v.dtype).reshape(-1))
         if self.coll:
             self.dist.broadcast(self.pol_buf, src=src)
         if self.on_gpu:
             torch.cuda.current_stream(self.device).synchronize()
-        self.batch.SetPolicyDevice(views[0].data_ptr(), self.n_w, *[v.data_ptr() for v in views[1:]])
-        return [v.cpu().numpy().copy() for v in views]
+        if normalizers:
+            self.batch.SetPolicyDevice(views[0].data_ptr(), self.n_w, *[v.data_ptr() for v in views[1:]])
+        else:
+            self.batch.SetPolicyDevice(views[0].data_ptr(), self.n_w)
+        return [v.cpu().numpy().copy() for v in views] if want_host else None

@@ -198,11 +198,14 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
 
 
 def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, max_frames=None, extra_args=None, seed=0, device=None,
-                      trainer_device=None, local_device_id=-1, scenario_cls=BatchScenario, trainer="torch", trainer_lib=None):
+                      trainer_device=None, local_device_id=-1, scenario_cls=BatchScenario, trainer="torch", trainer_lib=None, overlap=False):
     """cScenarioTrain over several GPUs: one process per GPU (torch.distributed already initialised; backend "nccl" = RCCL on GPUs).
     Every rank rolls out its contiguous range of global env ids; each outer frame the ranks' drained MACE rows are gathered on rank 0
     (the only exchange on the experience side), rank 0 runs the trainer, then one broadcast carries [iteration, weights, normalisers]
-    back (the only exchange on the policy side). Trajectories do not depend on the sharding, so the run equals train() on one process."""
+    back (the only exchange on the policy side). Trajectories do not depend on the sharding, so the run equals train() on one process.
+    overlap=True is train(overlap=True) across ranks: frame f+1 is relaunched on every rank before frame f's tuples are packed and gathered (the collective
+    runs beside frame f+1), rank 0 trains on frame f-1's rows meanwhile, and the broadcast weights are parked for the next launch when the normalisers have not
+    changed. Every tuple still reaches the trainer exactly once, in env-id order per frame; the policy a frame runs with is up to two frames staler."""
     import torch
     from .sharding import ShardedRollout
     args = parse_arg_file(os.path.join(data_root, arg_file))
@@ -213,7 +216,7 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
     def make(n, off):
         ea = dict(extra_args or {}); ea["global_env_offset"] = off
         return scenario_cls(arg_file, n, data_root=data_root, device_id=local_device_id, extra_args=ea)
-    sr = ShardedRollout(make, global_envs, dist=dist, device=device)
+    sr = ShardedRollout(make, global_envs, dist=dist, device=device, pipelined=overlap)
     b = sr.batch
     t = None
     if rank == 0:
@@ -231,17 +234,25 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
     chunk = max(1, geti("tuple_buffer_size", 32))
     max_iters = max_iters if max_iters is not None else geti("trainer_max_iter", 10 ** 9)
 
+    last_norm = [None]
+
     def sync(push):
-        # header [push?, iteration] from the trainer rank, then (if push) the policy itself
-        hdr = np.array([1 if push else 0, t.GetIter() if t is not None else 0], np.int64)
+        # header [push?, iteration, normalisers changed?] from the trainer rank, then (if push) the policy itself
+        norm_new = 1
+        if rank == 0 and push:
+            norm = t.GetOffsetScale()
+            norm_new = 0 if (last_norm[0] is not None and all(np.array_equal(a, c) for a, c in zip(norm, last_norm[0]))) else 1
+            last_norm[0] = norm
+        hdr = np.array([1 if push else 0, t.GetIter() if t is not None else 0, norm_new], np.int64)
         th = torch.from_numpy(hdr).to(sr.device)
         dist.broadcast(th, src=0)
-        push, it = int(th[0].item()), int(th[1].item())
+        push, it, norm_new = (int(x) for x in th.tolist())
         if push:
+            full = bool(norm_new) or not overlap      # (the sequential schedule keeps the one-call form: bit-identical to train())
             if rank == 0:
-                sr.broadcast_policy(t.GetWeights(), *t.GetOffsetScale(), src=0)
+                sr.broadcast_policy(t.GetWeights(), *(last_norm[0] if full else (None,) * 4), src=0, normalizers=full, want_host=False)
             else:
-                sr.broadcast_policy(src=0)
+                sr.broadcast_policy(src=0, normalizers=full, want_host=False)
         b.SetExplore(1, anneal(it, n_anneal, init["rate"], exp["rate"]), anneal(it, n_anneal, init["temp"], exp["temp"]), anneal(it, n_base_anneal, init["base"], exp["base"]))
         phase = 1.0 if n_curr < 1 else min(max(it / float(n_curr), 0.0), 1.0)
         b.SetTerrainParamsLerp(phase if it > 0 or n_curr < 1 else 0.0)
@@ -250,18 +261,72 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
     it = sync(True)
     frames = tuples = 0
     t0 = time.time()
-    while it < max_iters and (max_frames is None or frames < max_frames):
-        sr.Update(1.0 / 30.0)
-        frames += 1
-        g = sr.gather_tuples(dst=0)
-        got = False
-        if rank == 0:
-            rows, flags, _ = g
-            feed_chunks(t, rows, flags, chunk)
-            tuples += len(rows); got = len(rows) > 0
-        it = sync(got)
+
+    ph = {"rollout": 0.0, "gather_end": 0.0, "to_host": 0.0, "add_tuples": 0.0, "train": 0.0, "gather_begin": 0.0, "policy_sync": 0.0}   # host wall-clock by phase, this rank
+    clk = time.perf_counter
+
+    def consume(g):
+        """rank 0: gathered rows (tensors) -> the trainer, 32 at a time"""
+        nonlocal tuples
+        if rank != 0 or g is None:
+            return False
+        c0 = clk()
+        rows, flags = g[0], g[1]
+        if hasattr(rows, "cpu"):
+            rows, flags = rows.cpu().numpy(), flags.cpu().numpy().astype(np.uint32)
+        ph["to_host"] += clk() - c0
+        feed_chunks(t, rows, flags, chunk, ph)
+        tuples += len(rows)
+        return len(rows) > 0
+
+    import contextlib
+    # the framework ops of the loop (header read-backs, concatenations, copies) on a stream of their own: the legacy default stream synchronises with every
+    # blocking stream of the process, and the engine's CU-masked frame streams (-reserve_cus=) are such -- each op would wait for the frame in flight
+    side_ctx = torch.cuda.stream(torch.cuda.Stream(device=sr.device)) if sr.on_gpu else contextlib.nullcontext()
+    if not overlap:
+        with side_ctx:
+            while it < max_iters and (max_frames is None or frames < max_frames):
+                sr.Update(1.0 / 30.0)
+                frames += 1
+                it = sync(consume(sr.gather_tuples(dst=0)))
+    else:
+        with side_ctx:
+            sr.UpdateBegin(1.0 / 30.0)
+            more = True
+            while more:
+                frames += 1
+                more = it < max_iters and (max_frames is None or frames < max_frames)
+                c0 = clk()
+                if more:
+                    sr.UpdateEndBegin(1.0 / 30.0)            # frame f ended, frame f+1 runs ...
+                else:
+                    sr.UpdateEnd()
+                c1 = clk()
+                g = sr.gather_tuples_end(dst=0) if sr._pending is not None else None
+                c2 = clk()
+                got = consume(g)                             # ... rank 0 trains on frame f-1's rows (gathered during frame f),
+                c3 = clk()
+                sr.gather_tuples_begin(dst=0)                # frame f's rows are packed and put on the wire beside frame f+1,
+                c4 = clk()
+                it = sync(got)                               # and the new weights are parked for the next launch
+                ph["rollout"] += c1 - c0; ph["gather_end"] += c2 - c1; ph["gather_begin"] += c4 - c3; ph["policy_sync"] += clk() - c4
+            # flush: the last frame's gather, then whatever small blocks carried over (every rank takes part in every gather)
+            left = 1
+            while left > 0:
+                consume(sr.gather_tuples_end(dst=0))
+                st = b.TupleStats()
+                tl = torch.tensor([st["pending"]], dtype=torch.int64, device=sr.device)
+                dist.all_reduce(tl)
+                left = int(tl.item())
+                if left > 0:
+                    sr.gather_tuples_begin(dst=0)
+            try:
+                b.SetTuplePipelining(False)
+            except Exception:
+                pass       # rows a small block carried over sit in the idle ring: the run ends with them undelivered, as the reference's ends with part-filled scene buffers
+            it = sync(rank == 0 and t.GetIter() > 0)
     dt = time.time() - t0
-    out = dict(frames=frames, iters=it, seconds=dt, env_steps_per_s=frames * 20.0 * global_envs / dt, rank=rank, batch=b)
+    out = dict(frames=frames, iters=it, seconds=dt, env_steps_per_s=frames * 20.0 * global_envs / dt, rank=rank, batch=b, phases=ph)
     if rank == 0:
         out.update(tuples=tuples, weights=t.GetWeights(), offset_scale=t.GetOffsetScale())
     return out
