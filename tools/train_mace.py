@@ -22,7 +22,7 @@ ap.add_argument("--poll", action="store_true", help="with --overlap: relaunch en
 ap.add_argument("--distributed", action="store_true", help="train_loop.train_distributed: sharded rollout + tuple gather to rank 0 + policy broadcast (RCCL). Start with torch.distributed.run for N ranks; alone it runs a one-rank RCCL group (DTRL_FORCE_COLLECTIVES=1), the config-3/4 loop shape on one GPU")
 ap.add_argument("--out", default=None, help="write weights (.npy) and <out>_scale.txt")
 a = ap.parse_args()
-reserve = a.reserve_cus if a.reserve_cus is not None else 0
+reserve = a.reserve_cus if a.reserve_cus is not None else (1 if a.distributed else 0)   # (the exchange's collective and read-backs beside the rollout: 11.0 M with one unit per XCD set aside, 9.6 M without)
 if a.distributed:
     import torch, torch.distributed as dist
     os.environ.setdefault("DTRL_FORCE_COLLECTIVES", "1")
