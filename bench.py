@@ -150,16 +150,15 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
         nonlocal cursor, tuples
         # Frame k is running (UpdateBegin was called). The engine keeps two tuple rings (dtrl_set_tuple_pipelining): frame k + 1 is launched as soon as
         # frame k has ended, and frame k's tuples are drained, packed and gathered while it runs; the gathered block is consumed one frame later.
-        # What stays in the gap between two frame kernels is the frame-boundary host work and, every bcast_every frames, the policy hand-over.
+        # What stays in the gap between two frame kernels is the frame-boundary host work alone.
+        sr.UpdateEndBegin()                              # each env group: frame-boundary host work of frame k, then frame k + 1 at once (its tuples go to the other ring) ...
         if bcast_every > 0 and (k + 1) % bcast_every == 0:
-            sr.UpdateEnd()                               # frame k finished everywhere: the one place with a barrier, the policy hand-over
+            # the policy hand-over rides beside frame k + 1 as well: weights only (the normalisers have not changed), so every rank parks them in the engine's
+            # second weight buffer and frame k + 2's launch switches to it (dtrl_set_policy_device during a frame) -- no barrier left in the loop
             if rank == 0:
-                sr.broadcast_policy(*pol, src=0)
+                sr.broadcast_policy(pol[0], src=0, normalizers=False, want_host=False)
             else:
-                sr.broadcast_policy(src=0)
-            sr.UpdateBegin()
-        else:
-            sr.UpdateEndBegin()                          # each env group: frame-boundary host work of frame k, then frame k + 1 at once (its tuples go to the other ring) ...
+                sr.broadcast_policy(src=0, normalizers=False, want_host=False)
         if sr._pending is not None:
             g = sr.gather_tuples_end(dst=0, want_meta=False)   # gather of frame k - 1's tuples: started a whole frame ago
             if rank == 0:
