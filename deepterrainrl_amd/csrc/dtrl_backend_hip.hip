@@ -239,7 +239,11 @@ public:
 				hipDeviceSynchronize();
 				hipLaunchKernelGGL(dtrl_occupy, dim3(2048), dim3(64), 0, streams_[0], r == 0 ? 2000LL : kTicks, stamps);
 				hipLaunchKernelGGL(dtrl_occupy, dim3(2048), dim3(64), 0, streams_[1], r == 0 ? 2000LL : kTicks, static_cast<long long*>(nullptr));
-				while (*static_cast<volatile long long*>(stamps) == 0) {}        // the first occupant is running, the second waits for slots
+				{   // the first occupant is running, the second waits for slots (bounded wait: a launch that never starts must not hang the creation)
+					const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+					while (*static_cast<volatile long long*>(stamps) == 0 && std::chrono::steady_clock::now() < deadline) {}
+					if (*static_cast<volatile long long*>(stamps) == 0) { hipDeviceSynchronize(); hipHostFree(stamps); err = "side-stream calibration: the occupant kernel did not start within 2 s"; return false; }
+				}
 				std::this_thread::sleep_for(std::chrono::microseconds(r == 0 ? 0 : 200));
 				const auto t0 = std::chrono::steady_clock::now();
 				for (int k = 0; k < kBurst; ++k) hipLaunchKernelGGL(dtrl_stamp, dim3(96), dim3(256), 0, cand[c], stamps + 1);
