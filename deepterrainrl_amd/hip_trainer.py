@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import LIB_PATH, DtrlError
-from .trainer import MACETrainer
+from .trainer import MACETrainer, QNetTrainer, CaclaTrainer
 
 TRAINER_ABI_SYMBOLS = [
     "dtrl_trainer_create", "dtrl_trainer_destroy", "dtrl_trainer_last_error", "dtrl_trainer_set_stream", "dtrl_trainer_sync", "dtrl_trainer_num_params",
@@ -163,13 +163,15 @@ class NativeTrainer:
     def actor_step(self): self._chk(self._lib.dtrl_trainer_actor_step(self._h))
 
 
-class HipMACETrainer(MACETrainer):
-    """cMACETrainer with the network side on the native HIP step (see the module docstring). Same constructor as trainer.MACETrainer; float32 only
-    (the reference's Caffe nets are float32)."""
+class _HipNetSide:
+    """The network side of a trainer.py trainer on the native step (mixin in front of MACETrainer / QNetTrainer / CaclaTrainer): weights, solver history and
+    normalisers live in a dtrl_trainer, _eval / _solver_step are dtrl_trainer_eval / dtrl_trainer_step, new tuples are stored from the page-locked staging
+    area. float32 only (the shipped nets are float32-valued)."""
 
     def __init__(self, *a, lib_path=None, **kw):
         kw.setdefault("use_graphs", False)      # the torch peer's graph machinery is not used: nothing framework-side runs inside an iteration
         kw["dtype"] = torch.float32
+        self._lib_path = lib_path               # (CaclaTrainer.Reset, called by the base constructor, builds the actor's trainer with it)
         super().__init__(*a, **kw)
         if self.solver["lr_policy"] != "fixed":
             raise DtrlError("the native trainer step implements lr_policy \"fixed\" (what the shipped solver prototxts use)")
@@ -223,10 +225,6 @@ class HipMACETrainer(MACETrainer):
             self.nt.update_target()
         else:
             super().UpdateTargetNet()          # (called once by the base constructor before the native trainer exists)
-
-    def OutputModel(self, model_file):
-        self.net.set_flat(self.GetWeights())    # the torch net is only a container here
-        super().OutputModel(model_file)
 
     def _after_torch(self):
         """the trainer's stream waits for what the framework's current stream has queued (replay writes, input tensors)"""
@@ -282,6 +280,14 @@ class HipMACETrainer(MACETrainer):
         self.solver_iter += 1
         self.nt.sync()
         return torch.tensor(float(self.nt.loss[0]))
+
+
+class HipMACETrainer(_HipNetSide, MACETrainer):
+    """cMACETrainer with the network side on the native HIP step (see the module docstring). Same constructor as trainer.MACETrainer (+ lib_path)."""
+
+    def OutputModel(self, model_file):
+        self.net.set_flat(self.GetWeights())    # the torch net is only a container here
+        super().OutputModel(model_file)
 
     # ---- cMACETrainer::Step on the fused native calls ----
     def Step(self):
@@ -362,3 +368,37 @@ class HipMACETrainer(MACETrainer):
             self.solver_iter += 1
             self.actor_iter += 1
             del self.actor_batch_buffer[:self.batch]
+
+
+class HipQNetTrainer(_HipNetSide, QNetTrainer):
+    """cQNetTrainer (trainer.QNetTrainer: minibatch draw, Q targets) with the single-head net on the native step: two dtrl_trainer_eval passes and one
+    dtrl_trainer_step per iteration."""
+
+    def _q_problem(self, ids):
+        self._before_torch()                    # replay rows stored from the staging area on the trainer's stream are read by framework ops here
+        return super()._q_problem(ids)
+
+
+class HipCaclaTrainer(_HipNetSide, CaclaTrainer):
+    """cCaclaTrainer (trainer.CaclaTrainer: critic / actor schedule, TD-error filter) with BOTH single-head nets on the native step: this object's net is the
+    critic, self.actor is a HipQNetTrainer holding the actor net."""
+
+    def Reset(self):
+        super().Reset()
+        net_file, solver_file, S, A, kw = self._actor_args
+        kw = dict(kw); kw.pop("dtype", None); kw.pop("use_graphs", None)
+        self.actor = HipQNetTrainer(net_file, solver_file, S, A, lib_path=self._lib_path, **kw)
+        self.actor_batch = self.actor.batch
+
+    # the interface the training loop uses speaks for the ACTOR (what the rollout engine runs), as in trainer.CaclaTrainer
+    def GetWeights(self): return self.actor.GetWeights()
+    def SetWeights(self, w): self.actor.SetWeights(w)
+    def WeightsDevicePtr(self): return self.actor.WeightsDevicePtr()
+    @property
+    def policy_nt(self): return self.actor.nt
+
+    def GetCriticWeights(self):
+        return self.nt.get_params(0)
+
+    def SetCriticWeights(self, w):
+        self.nt.set_params(0, np.asarray(w, np.float32)); self.nt.update_target()

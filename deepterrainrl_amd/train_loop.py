@@ -41,8 +41,14 @@ def _make_trainer(args, data_root, train_net, solver, b, tkw, trainer="torch", t
         c_solver = os.path.join(data_root, args["critic_solver"])
         m = re.search(r'net:\s*"([^"]+)"', open(c_solver).read())
         c_train = os.path.join(data_root, m.group(1)) if m else os.path.join(data_root, args["critic_net"].replace("_deploy", "_train"))
+        if trainer == "hip":
+            from .hip_trainer import HipCaclaTrainer
+            return HipCaclaTrainer(c_train, c_solver, train_net, solver, b.S, b.A, lib_path=trainer_lib, **tkw)
         return CaclaTrainer(c_train, c_solver, train_net, solver, b.S, b.A, **tkw)
     if ctrl in ("dog", "raptor"):
+        if trainer == "hip":
+            from .hip_trainer import HipQNetTrainer
+            return HipQNetTrainer(train_net, solver, b.S, b.A, lib_path=trainer_lib, **tkw)
         return QNetTrainer(train_net, solver, b.S, b.A, **tkw)
     if trainer == "hip":   # the MI355X-native step (hip_trainer.py): cMACETrainer's iteration on hand-written HIP kernels
         from .hip_trainer import HipMACETrainer
@@ -115,12 +121,13 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
         if hasattr(t, "WeightsDevicePtr"):
             # native trainer: the weights go from the trainer's device buffer into the engine's layout by a gather kernel (dtrl_set_policy_device); the
             # normalisers only travel (from the host) when they changed
-            t.nt.sync()
+            nt = getattr(t, "policy_nt", t.nt)      # (CACLA: the actor's)
+            nt.sync()
             norm = t.GetOffsetScale()
             if last_norm[0] is None or any(not np.array_equal(a, c) for a, c in zip(norm, last_norm[0])):
                 b.SetPolicy(t.GetWeights(), *norm); last_norm[0] = norm
             else:
-                b.SetPolicyDevice(t.WeightsDevicePtr(), t.nt.num_params)
+                b.SetPolicyDevice(t.WeightsDevicePtr(), nt.num_params)
         else:
             b.SetPolicy(t.GetWeights(), *t.GetOffsetScale())
         b.SetExplore(1, anneal(it, n_anneal, init["rate"], exp["rate"]), anneal(it, n_anneal, init["temp"], exp["temp"]), anneal(it, n_base_anneal, init["base"], exp["base"]))

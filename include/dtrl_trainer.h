@@ -62,7 +62,8 @@ int dtrl_trainer_eval(dtrl_trainer* t, int which, const float* X_dev, int n, flo
 int dtrl_trainer_step(dtrl_trainer* t, const float* X_dev, const float* Y_dev);
 
 /* The replay memory the MACE calls below read: rows [mem_size][W] float32 in the MACE layout [r | s | a = (fragment id, params) | s'] exactly as
- * dtrl_drain_tuples emits them, and one int64 flag word per row (bit 0 = fail). Device pointers that stay valid for the trainer's life (mPlaybackMem). */
+ * dtrl_drain_tuples emits them, and one int64 flag word per row (bit 0 = fail). Device pointers that stay valid for the trainer's life (mPlaybackMem).
+ * A single-head net (Q, CACLA critic / actor: n_frags == 0) binds its replay memory [r | s | a | s'] of any action width for the staged stores alone. */
 int dtrl_trainer_bind_replay(dtrl_trainer* t, const float* mem_dev, const int64_t* flags_dev, int W);
 /* New tuples without a queued copy or a framework call. dtrl_trainer_stage_rows / _flags: page-locked, device-visible staging arrays owned by the trainer
  * ([dtrl_trainer_stage_capacity()][W] float32 rows as dtrl_drain_tuples emits them, one int64 flag word per row; valid after dtrl_trainer_bind_replay, NULL before).

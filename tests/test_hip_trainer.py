@@ -152,7 +152,68 @@ def test_staged_add_equals_plain_add():
     run_staged_add_equals_plain_add(EMUL_TRAINER_LIB, "cpu")
 
 
+def run_q_trainer_on_the_native_step(om, lib, device):
+    """cQNetTrainer's iterations with the single-head Q net on dtrl_trainer_eval / dtrl_trainer_step (hip_trainer.HipQNetTrainer; rows stored from the staging area)
+    vs oracle/trainer_ref.py's RefQTrainer: same minibatches, targets and SGD over six iterations through a ring wrap."""
+    from deepterrainrl_amd import hip_trainer as ht
+    rng = np.random.RandomState(12)
+    rows, flags = TT.q_rows(rng, 300)
+    t = ht.HipQNetTrainer(TT.QTRAIN, TT.QSOLVER, S, TT.QA, lib_path=lib, mem_size=256, num_init_samples=100, device=device, seed=8)
+    r = TT.make_ref_q_trainer(om, t, 8)
+    w0 = t.GetWeights(); t.SetWeights(w0); r.w = w0.astype(np.float64)
+    k = 0
+    while k < 300:
+        st = t.StageTuples(rows[k:], flags[k:])
+        for j in range(0, st, 50):
+            t.AddTuples(rows[k + j:k + j + 50], flags[k + j:k + j + 50], staged=j)
+        k += st
+    r.add_tuples(rows, flags)
+    for k in range(6):
+        t.Train(); r.train()
+        assert t.GetIter() == r.iter == k + 1
+    a = t.GetWeights().astype(np.float64)
+    assert np.abs(a - r.w).max() < 2e-4 * np.abs(r.w).max() and np.abs(a - w0).max() > 1e-4
+    assert abs(t.last_loss - r.last_loss) < 1e-3 * max(1.0, abs(r.last_loss))
+    return t
+
+
+def test_q_trainer_on_the_native_step(om):
+    run_q_trainer_on_the_native_step(om, EMUL_TRAINER_LIB, "cpu")
+
+
+def cacla_factory(lib):
+    def make(device, seed):
+        from deepterrainrl_amd import hip_trainer as ht
+        return ht.HipCaclaTrainer(TT.CRITIC[0], TT.CRITIC[1], TT.ACTOR[0], TT.ACTOR[1], S, TT.CA, lib_path=lib, mem_size=256, num_init_samples=100, freeze_target_iters=3, device=device, seed=seed)
+    return make
+
+
+def test_cacla_trainer_on_the_native_step(om):
+    """cCaclaTrainer with critic AND actor on the native step (hip_trainer.HipCaclaTrainer) vs RefCaclaTrainer: 14 iterations, mid-training arrivals, target refresh"""
+    TT.run_cacla_trainer_vs_restatement(om, "cpu", torch.float32, 3e-4, factory=cacla_factory(EMUL_TRAINER_LIB))
+
+
+@pytest.mark.parametrize("arg,nparams", [("args/opt_args_train_q.txt", 461208), ("args/opt_args_train_cacla.txt", 463917)])
+def test_q_and_cacla_train_loops_run_on_the_native_trainer(da, arg, nparams):
+    """the Q and CACLA training configurations end to end with trainer="hip" (check builds): rollouts -> tuples -> native eval / step -> policy hand-over from the
+    trainer's device buffer (CACLA: the actor's)"""
+    from conftest import EmulScenario
+    from deepterrainrl_amd import train_loop
+    st = train_loop.train(arg, REFDATA, num_envs=48, max_frames=55, trainer_device="cpu", scenario_cls=EmulScenario, trainer="hip", trainer_lib=EMUL_TRAINER_LIB,
+                          extra_args={"terrain_seed": 3, "trainer_num_init_samples": 60, "trainer_replay_mem_size": 512, "trainer_init_input_offset_scale": "false"})
+    assert st["frames"] == 55 and st["tuples"] >= 60 and st["iters"] >= 2
+    assert np.all(np.isfinite(st["weights"])) and st["weights"].size == nparams
+
+
 # ---- the HIP kernels on the MI355X ----
+@pytest.mark.gpu
+def test_gpu_q_and_cacla_trainers_on_the_native_step(om):
+    t = run_q_trainer_on_the_native_step(om, None, "cuda")
+    assert "libdtrl.so" in open("/proc/self/maps").read() and t.mem.is_cuda
+    TT.run_cacla_trainer_vs_restatement(om, "cuda", torch.float32, 3e-4, factory=cacla_factory(None))
+
+
+
 @pytest.mark.gpu
 def test_gpu_staged_add_equals_plain_add():
     run_staged_add_equals_plain_add(None, "cuda")

@@ -416,10 +416,10 @@ def cacla_rows(rng, n, p_off=0.5, p_fail=0.2):
     return rows, flags.astype(np.int64)
 
 
-def run_cacla_trainer_vs_restatement(om, device, dtype, tol, iters=14):
+def run_cacla_trainer_vs_restatement(om, device, dtype, tol, iters=14, factory=None):
     rng = np.random.RandomState(21)
     rows, flags = cacla_rows(rng, 330)                                   # wraps the 256-slot ring: buffers are purged of overwritten slots
-    t = make_cacla_trainer(device=device, dtype=dtype, seed=13)
+    t = factory(device=device, seed=13) if factory else make_cacla_trainer(device=device, dtype=dtype, seed=13)
     r = make_ref_cacla_trainer(om, t, 13)
     wc0, wa0 = t.GetCriticWeights(), t.GetWeights()
     t.SetCriticWeights(wc0); t.SetWeights(wa0)
