@@ -14,7 +14,7 @@ ap.add_argument("--envs", type=int, default=4096)
 ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--iters", type=int, default=None)
 ap.add_argument("--frames-per-drain", type=int, default=1)
-ap.add_argument("--overlap", action="store_true", help="train on frame f while frame f+1 rolls out (only pays off when the trainer has its own GPU: on one GPU the frame kernel fills every CU and the trainer's small kernels queue behind it -- measured 4.0 vs 4.7 M env-steps/s)")
+ap.add_argument("--overlap", action="store_true", help="train on frame f while frame f+1 rolls out: frame f+1 is relaunched before frame f's tuples are drained (host-memory tuple rings), the weights are parked for the next launch (dog, native trainer, one GPU: 9.1 M sequential, 11.2-11.5 M overlapped; with round 2's PyTorch trainer it did not pay: 4.0 vs 4.7 M)")
 ap.add_argument("--trainer", choices=["torch", "hip"], default="hip", help="hip: the MI355X-native trainer step (hip_trainer.py); torch: the PyTorch peer (trainer.py, HIP-graph replay)")
 ap.add_argument("--reserve-cus", type=int, default=None, help="compute units per XCD kept out of the frame launches for the trainer's kernels (engine arg -reserve_cus=; default 0: measured 11.3 M env-steps/s without, 9.7 M with 2 per XCD -- the trainer's small GEMMs run 3x slower on 16-32 units than in the frame kernel's gaps on 256)")
 ap.add_argument("--init-samples", type=int, default=None, help="override -trainer_num_init_samples= (the arg files collect 50 000 tuples before the first iteration: ~235 frames of 4096 dogs)")
