@@ -21,3 +21,6 @@ done
 echo "== args/opt_args_train_mace.txt envs=4096 frames=600 trainer=hip (sequential)" >> $O/train_loops.log
 python tools/train_mace.py --arg-file args/opt_args_train_mace.txt --envs 4096 --frames 600 --trainer hip 2>&1 | tail -2 >> $O/train_loops.log
 cat $O/train_loops.log
+# the exchange through a one-rank RCCL group and the training loop across ranks (one rank)
+DTRL_FORCE_COLLECTIVES=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_forced_rccl.json
+python tools/train_mace.py --distributed --overlap --envs 4096 --frames 600 --trainer hip 2>&1 | grep "distributed" > $O/train_distributed.log; cat $O/train_distributed.log
