@@ -300,6 +300,12 @@ public:
 		hipLaunchKernelGGL(dtrl_gather_f32, dim3(1024), dim3(256), 0, stream_, dst, src, idx, n);
 		return Check(hipGetLastError(), "gather launch") && Check(hipStreamSynchronize(stream_), "sync");
 	}
+	bool GatherF32On(void* stream, float* dst, const float* src, const int32_t* idx, size_t n) override
+	{
+		hipStream_t st = stream ? static_cast<hipStream_t>(stream) : stream_;
+		hipLaunchKernelGGL(dtrl_gather_f32, dim3(1024), dim3(256), 0, st, dst, src, idx, n);
+		return Check(hipGetLastError(), "gather launch") && Check(hipStreamSynchronize(st), "sync");
+	}
 	bool PackTuples(const DevBuffers& buf, float* block, int block_rows, int64_t env_id_base, int n_envs, const PackScratch& sc) override
 	{
 		const int grid = std::max(1, std::min<int>(buf.tuple_cap, 2048));

@@ -700,7 +700,7 @@ void Engine::ApplyPendingPolicy()
 	const float* cur = buf_.weights; buf_.weights = weights_alt_; weights_alt_ = const_cast<float*>(cur);
 	policy_flip_pending_ = false;
 }
-int Engine::SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, const double* is_dev, const double* oo_dev, const double* os_dev)
+int Engine::SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, const double* is_dev, const double* oo_dev, const double* os_dev, void* stream)
 {
 	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
 	const NetDesc& d = cfg_.net;
@@ -708,7 +708,9 @@ int Engine::SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, 
 	if (step_pending_ && policy_set_ && weights_alt_ && !io_dev && !is_dev && !oo_dev && !os_dev) {
 		struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
 		be_->SelectStream(be_->NumStreams() - 1);
-		if (!be_->GatherF32(weights_alt_, w_dev, d_relayout_, relayout_.size())) return Fail(DTRL_ERR_DEVICE, be_->error());   // (synchronised: the caller may change w_dev when this returns)
+		// (synchronised: the caller may change w_dev when this returns. On the caller's stream -- the trainer's -- the gather follows the steps queued there and
+		// ONE wait covers both; on the drain stream it would wait for a wavefront slot of its own behind the frame in flight)
+		if (!be_->GatherF32On(stream, weights_alt_, w_dev, d_relayout_, relayout_.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
 		policy_flip_pending_ = true;
 		return DTRL_OK;
 	}

@@ -35,6 +35,8 @@ public:
 	virtual bool D2D(void* dst, const void* src, size_t n) = 0;   // device-to-device on the selected stream, synchronised before returning
 	// dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 for i < n, all device pointers (policy hand-over without a host round trip); synchronised
 	virtual bool GatherF32(float* dst, const float* src, const int32_t* idx, size_t n) = 0;
+	// the same on a stream of the caller's (a hipStream_t; nullptr = the selected stream), synchronised: work the caller has queued there comes first
+	virtual bool GatherF32On(void* stream, float* dst, const float* src, const int32_t* idx, size_t n) { (void)stream; return GatherF32(dst, src, idx, n); }
 	// -terrain_gen= device: the frame-boundary terrain work of envs [e0, e0 + n) (or of env_list[0 .. n) when given), queued on the selected stream
 	// (tg_env_boundary, dtrl_terrain_dev.h); mode 0 = after a frame, 1 = (re)initialise
 	virtual bool TerrainBoundary(const DevBuffers& buf, int e0, int n, int mode, const int32_t* env_list) = 0;
@@ -83,7 +85,7 @@ public:
 	int TupleStats(int64_t* pending, int64_t* drained, int64_t* dropped, int32_t* capacity);
 	int GetDistLog(double* dist, int32_t* env_ids, int cap, int* out_n);
 	int ResetAvgDist();
-	int SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, const double* is_dev, const double* oo_dev, const double* os_dev);
+	int SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, const double* is_dev, const double* oo_dev, const double* os_dev, void* stream = nullptr);
 	int GetStates(const int32_t* env_ids, int n, std::vector<EnvState>& out);
 	int SetPoseVel(const int32_t* env_ids, int n, const double* q, const double* qd);
 	int CommandAction(const int32_t* env_ids, int n, const int32_t* action_ids);

@@ -171,7 +171,7 @@ class _HipNetSide:
     def __init__(self, *a, lib_path=None, **kw):
         kw.setdefault("use_graphs", False)      # the torch peer's graph machinery is not used: nothing framework-side runs inside an iteration
         kw["dtype"] = torch.float32
-        self._lib_path = lib_path               # (CaclaTrainer.Reset, called by the base constructor, builds the actor's trainer with it)
+        self._trainer_lib = lib_path               # (CaclaTrainer.Reset, called by the base constructor, builds the actor's trainer with it)
         super().__init__(*a, **kw)
         if self.solver["lr_policy"] != "fixed":
             raise DtrlError("the native trainer step implements lr_policy \"fixed\" (what the shipped solver prototxts use)")
@@ -219,6 +219,10 @@ class _HipNetSide:
     def WeightsDevicePtr(self):
         """device pointer of the current net's flat weights (Caffe blob order): dtrl_set_policy_device takes it as it is"""
         return self.nt.params_device(0)
+
+    def StreamPtr(self):
+        """the trainer's stream as a hipStream_t (int), or None on the CPU check build: dtrl_set_policy_device_on queues the hand-over behind the trainer's work"""
+        return int(self._stream.cuda_stream) if self._stream is not None else None
 
     def UpdateTargetNet(self):
         if hasattr(self, "nt"):
@@ -387,7 +391,7 @@ class HipCaclaTrainer(_HipNetSide, CaclaTrainer):
         super().Reset()
         net_file, solver_file, S, A, kw = self._actor_args
         kw = dict(kw); kw.pop("dtype", None); kw.pop("use_graphs", None)
-        self.actor = HipQNetTrainer(net_file, solver_file, S, A, lib_path=self._lib_path, **kw)
+        self.actor = HipQNetTrainer(net_file, solver_file, S, A, lib_path=self._trainer_lib, **kw)
         self.actor_batch = self.actor.batch
 
     # the interface the training loop uses speaks for the ACTOR (what the rollout engine runs), as in trainer.CaclaTrainer

@@ -122,12 +122,18 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
             # native trainer: the weights go from the trainer's device buffer into the engine's layout by a gather kernel (dtrl_set_policy_device); the
             # normalisers only travel (from the host) when they changed
             nt = getattr(t, "policy_nt", t.nt)      # (CACLA: the actor's)
-            nt.sync()
             norm = t.GetOffsetScale()
             if last_norm[0] is None or any(not np.array_equal(a, c) for a, c in zip(norm, last_norm[0])):
+                nt.sync()
                 b.SetPolicy(t.GetWeights(), *norm); last_norm[0] = norm
             else:
-                b.SetPolicyDevice(t.WeightsDevicePtr(), nt.num_params)
+                owner = getattr(t, "actor", t) if hasattr(t, "policy_nt") else t
+                sp = owner.StreamPtr() if hasattr(owner, "StreamPtr") else None
+                if sp is not None and hasattr(b, "SetPolicyDeviceOn"):
+                    b.SetPolicyDeviceOn(t.WeightsDevicePtr(), nt.num_params, sp)     # behind the trainer's queued work, one wait for both
+                else:
+                    nt.sync()
+                    b.SetPolicyDevice(t.WeightsDevicePtr(), nt.num_params)
         else:
             b.SetPolicy(t.GetWeights(), *t.GetOffsetScale())
         b.SetExplore(1, anneal(it, n_anneal, init["rate"], exp["rate"]), anneal(it, n_anneal, init["temp"], exp["temp"]), anneal(it, n_base_anneal, init["base"], exp["base"]))

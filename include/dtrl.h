@@ -159,6 +159,10 @@ dtrl_status dtrl_tuple_stats(dtrl_batch* b, int64_t* pending, int64_t* drained, 
  * weights are gathered into a second buffer (weights_dev may be changed when the call returns) and every env's NEXT frame launch runs with them -- the moment the
  * waiting form takes effect, too. */
 dtrl_status dtrl_set_policy_device(dtrl_batch* b, const float* weights_dev, size_t n, const double* in_off_dev, const double* in_scale_dev, const double* out_off_dev, const double* out_scale_dev);
+/* The weights-only form with the re-layout kernel queued on a stream of the CALLER's (a hipStream_t; the trainer's): it follows whatever the caller has queued
+ * there -- the trainer's last step -- and the call returns when it has run, so ONE host wait covers the trainer's pending work and the hand-over (during a frame the
+ * engine's own stream would have to find a wavefront slot of its own). Same semantics as dtrl_set_policy_device otherwise. */
+dtrl_status dtrl_set_policy_device_on(dtrl_batch* b, const float* weights_dev, size_t n, void* stream);
 
 /* No counterpart in the reference (its trainer and its env threads share CPU cores under the OS scheduler; scenarios/ScenarioTrain.cpp runs them as threads
  * of one process). On the GPU a frame launch fills every wavefront slot of the compute units it may use for milliseconds, so work that should run BESIDE the
