@@ -247,3 +247,22 @@ def test_gpu_equals_the_plain_loop_build(om):
         assert (a.GetIter(), a.actor_iter, a.actor_batch_buffer) == (b.GetIter(), b.actor_iter, b.actor_batch_buffer), k
     wa, wb = a.GetWeights().astype(np.float64), b.GetWeights().astype(np.float64)
     assert np.abs(wa - wb).max() < 2e-5 * np.abs(wb).max()
+
+
+@pytest.mark.gpu
+def test_gpu_overlapped_training_loop_is_reproducible():
+    """train_loop.train(trainer="hip", overlap=True) on the MI355X -- frames relaunched before the drain, tuple rings in host memory, tuples staged and stored on
+    the trainer's stream, weights parked for the next launch on the trainer's stream -- twice from the same seeds: every hand-over is host-ordered and the drained
+    rows are sorted by env id, so iteration counts, tuple counts and every weight must come out identical (a race in any of those pieces would show here)."""
+    from deepterrainrl_amd import train_loop
+    extra = {"terrain_seed": 3, "trainer_num_init_samples": 1500, "trainer_replay_mem_size": 20000, "trainer_freeze_target_iters": 50,
+             "init_exp_rate": 0.3, "init_exp_base_rate": 0.1, "trainer_init_input_offset_scale": "false"}
+    runs = []
+    for k in range(2):
+        st = train_loop.train("args/opt_args_train_mace.txt", REFDATA, num_envs=1536, max_frames=70, trainer_device="cuda", extra_args=dict(extra), trainer="hip", overlap=True, seed=5)
+        runs.append(st)
+        assert st["frames"] == 70 and st["iters"] >= 20 and np.all(np.isfinite(st["weights"]))
+    a, b = runs
+    assert (a["iters"], a["tuples"]) == (b["iters"], b["tuples"]) and a["tuples"] >= 1500
+    assert np.array_equal(a["weights"], b["weights"])
+    assert "libdtrl.so" in open("/proc/self/maps").read()
