@@ -272,7 +272,7 @@ def test_device_destination_drain_and_policy_hand_over_equal_the_host_calls(da, 
     assert np.array_equal(a.PoseVel()[0], b.PoseVel()[0])
 
 
-def run_policy_hand_over_during_a_frame(scn, om, to_dev=None, n_envs=8, frames=40):
+def run_policy_hand_over_during_a_frame(scn, om, to_dev=None, n_envs=8, frames=40, stream_ptr=None):
     """dtrl_set_policy_device between dtrl_step_begin and dtrl_step_end does not wait for the frame: the weights go to the second buffer and the NEXT launch uses
     them -- the same rollout as handing them over after dtrl_step_end. Policies alternate every third frame so that a missed or early switch shows."""
     pol = dog_policy(om)
@@ -289,8 +289,11 @@ def run_policy_hand_over_during_a_frame(scn, om, to_dev=None, n_envs=8, frames=4
     a.UpdateBegin()
     for f in range(frames):
         k = (f // 3) % 3
-        if f % 3 == 0:
-            a.SetPolicyDevice(held[k][1], w0.size)          # frame f in flight on `a`: parked, effective from frame f + 1
+        if f % 3 == 0:                                      # frame f in flight on `a`: parked, effective from frame f + 1
+            if f % 2 == 0:
+                a.SetPolicyDevice(held[k][1], w0.size)
+            else:
+                a.SetPolicyDeviceOn(held[k][1], w0.size, stream_ptr)     # the same with the re-layout kernel on a stream of the caller's (None: the engine's)
         a.UpdateEnd()
         b.Update()                                          # frame f on `b` with the weights frame f of `a` ran with
         if f % 3 == 0:

@@ -380,7 +380,8 @@ def test_policy_hand_over_during_a_frame_on_the_gpu(da, om):
     def to_dev(w):
         t = torch.from_numpy(w).to(dev); torch.cuda.synchronize()
         return (t, t.data_ptr())
-    TB.run_policy_hand_over_during_a_frame(da.BatchScenario, om, to_dev=to_dev, n_envs=256, frames=40)
+    side = torch.cuda.Stream(device=dev)
+    TB.run_policy_hand_over_during_a_frame(da.BatchScenario, om, to_dev=to_dev, n_envs=256, frames=40, stream_ptr=side.cuda_stream)
 
 
 @pytest.mark.gpu
