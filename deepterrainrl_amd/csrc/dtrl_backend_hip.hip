@@ -231,7 +231,8 @@ public:
 		for (int i = kNumStreams / 2; i < kNumStreams; ++i) cand.push_back(streams_[i]);
 		while (static_cast<int>(cand.size()) < kCand) { hipStream_t st; if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break; cand.push_back(st); extra_.push_back(st); }
 		long long* stamps = nullptr;
-		if (!Check(hipHostMalloc(&stamps, sizeof(long long) * 4, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc")) { err = err_; return false; }
+		auto drop_extras = [&]() { for (hipStream_t st : extra_) hipStreamDestroy(st); extra_.clear(); };   // (a failed calibration keeps the engine's own streams only)
+		if (!Check(hipHostMalloc(&stamps, sizeof(long long) * 4, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc")) { err = err_; drop_extras(); return false; }
 		std::vector<long long> worst(cand.size(), 0);   // microseconds x 100 (the sort below only compares)
 		for (int r = 0; r < 2; ++r) {                 // (round 0 warms the code objects and the streams' queues up)
 			for (size_t c = 0; c < cand.size(); ++c) {
@@ -242,12 +243,12 @@ public:
 				{   // the first occupant is running, the second waits for slots (bounded wait: a launch that never starts must not hang the creation)
 					const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
 					while (*static_cast<volatile long long*>(stamps) == 0 && std::chrono::steady_clock::now() < deadline) {}
-					if (*static_cast<volatile long long*>(stamps) == 0) { hipDeviceSynchronize(); hipHostFree(stamps); err = "side-stream calibration: the occupant kernel did not start within 2 s"; return false; }
+					if (*static_cast<volatile long long*>(stamps) == 0) { hipDeviceSynchronize(); hipHostFree(stamps); drop_extras(); err = "side-stream calibration: the occupant kernel did not start within 2 s"; return false; }
 				}
 				std::this_thread::sleep_for(std::chrono::microseconds(r == 0 ? 0 : 200));
 				const auto t0 = std::chrono::steady_clock::now();
 				for (int k = 0; k < kBurst; ++k) hipLaunchKernelGGL(dtrl_stamp, dim3(96), dim3(256), 0, cand[c], stamps + 1);
-				if (!Check(hipStreamSynchronize(cand[c]), "side-stream calibration")) { err = err_; hipHostFree(stamps); return false; }
+				if (!Check(hipStreamSynchronize(cand[c]), "side-stream calibration")) { err = err_; hipHostFree(stamps); drop_extras(); return false; }
 				const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
 				if (r > 0) worst[c] = static_cast<long long>(us * 100.0);
 			}
