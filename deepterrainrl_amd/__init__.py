@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_cycle_info", "dtrl_get_action_table", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
     "dtrl_terrain_build", "dtrl_terrain_load_file", "dtrl_args_parse_string",
-    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed", "dtrl_get_policy_output", "dtrl_set_tuple_pipelining", "dtrl_step_end_begin", "dtrl_command_action", "dtrl_side_stream", "dtrl_step_poll", "dtrl_set_policy_device_on",
+    "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed", "dtrl_get_policy_output", "dtrl_set_tuple_pipelining", "dtrl_step_end_begin", "dtrl_command_action", "dtrl_side_stream", "dtrl_step_poll", "dtrl_set_policy_device_on", "dtrl_set_policy_device_async",
 ]
 
 
@@ -119,6 +119,7 @@ def _bind(path):
     L.dtrl_tuple_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     L.dtrl_set_policy_device.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, vp]
     L.dtrl_set_policy_device_on.argtypes = [vp, vp, C.c_size_t, vp]
+    L.dtrl_set_policy_device_async.argtypes = [vp, vp, C.c_size_t, vp]
     L.dtrl_get_dist_log.argtypes = [vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.dtrl_reset_avg_dist.argtypes = [vp]
     L.dtrl_write_dist_log.argtypes = [vp, C.c_char_p]
@@ -295,6 +296,10 @@ class BatchScenario:
     def SetPolicyDeviceOn(self, weights_ptr, n, stream_ptr):
         """dtrl_set_policy_device_on: weights only, the re-layout kernel on the caller's stream (hipStream_t as an int), returns when it has run."""
         self._chk(self._lib.dtrl_set_policy_device_on(self._h, C.c_void_p(weights_ptr), int(n), C.c_void_p(int(stream_ptr)) if stream_ptr else None))
+
+    def SetPolicyDeviceAsync(self, weights_ptr, n, stream_ptr):
+        """dtrl_set_policy_device_async: weights only, the re-layout kernel queued on the caller's stream, NO host wait; every env's next launch waits for it on the device."""
+        self._chk(self._lib.dtrl_set_policy_device_async(self._h, C.c_void_p(weights_ptr), int(n), C.c_void_p(int(stream_ptr)) if stream_ptr else None))
 
     def GetDistLog(self):
         """cScenarioPoliEval::GetDistLog over the batch: (distances, env ids), grouped by env, episodes in time order."""

@@ -180,6 +180,7 @@ public:
 	{
 		for (auto& ev : events_) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
 		for (auto& m : marks_) if (m.second) hipEventDestroy(m.second);
+		if (policy_ready_) hipEventDestroy(policy_ready_);
 		if (!owned_.empty()) { for (int i = kNumStreams / 2; i < kNumStreams; ++i) streams_[i] = nullptr; for (hipStream_t st : owned_) hipStreamDestroy(st); }
 		for (hipStream_t st : streams_) if (st) hipStreamDestroy(st);
 	}
@@ -232,9 +233,12 @@ public:
 		while (static_cast<int>(cand.size()) < kCand) { hipStream_t st; if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break; cand.push_back(st); extra_.push_back(st); }
 		long long* stamps = nullptr;
 		auto drop_extras = [&]() { for (hipStream_t st : extra_) hipStreamDestroy(st); extra_.clear(); };   // (a failed calibration keeps the engine's own streams only)
+		// the assignment below hands out kNumStreams / 2 + 2 streams (the plain engine streams + two side streams): with fewer candidates (stream creation failed)
+		// there is nothing to choose from -- keep the engine's own streams, hand out no side streams
+		if (static_cast<int>(cand.size()) < kNumStreams - kNumStreams / 2 + 2) { drop_extras(); err = "side-stream calibration: could not create enough candidate streams"; return false; }
 		if (!Check(hipHostMalloc(&stamps, sizeof(long long) * 4, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc")) { err = err_; drop_extras(); return false; }
 		std::vector<long long> worst(cand.size(), 0);   // microseconds x 100 (the sort below only compares)
-		for (int r = 0; r < 2; ++r) {                 // (round 0 warms the code objects and the streams' queues up)
+		for (int r = 0; r < 3; ++r) {                 // (round 0 warms the code objects and the streams' queues up; the worse of rounds 1 and 2 counts)
 			for (size_t c = 0; c < cand.size(); ++c) {
 				stamps[0] = 0;
 				hipDeviceSynchronize();
@@ -250,7 +254,7 @@ public:
 				for (int k = 0; k < kBurst; ++k) hipLaunchKernelGGL(dtrl_stamp, dim3(96), dim3(256), 0, cand[c], stamps + 1);
 				if (!Check(hipStreamSynchronize(cand[c]), "side-stream calibration")) { err = err_; hipHostFree(stamps); drop_extras(); return false; }
 				const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-				if (r > 0) worst[c] = static_cast<long long>(us * 100.0);
+				if (r > 0) worst[c] = std::max(worst[c], static_cast<long long>(us * 100.0));
 			}
 		}
 		hipDeviceSynchronize();
@@ -327,6 +331,32 @@ public:
 		for (int g = 0; g < n_groups; ++g) {
 			auto it = marks_.find(Key(g, slot));
 			if (it != marks_.end() && it->second && !Check(hipStreamWaitEvent(stream_, it->second, 0), "hipStreamWaitEvent")) return false;
+		}
+		return true;
+	}
+	bool GatherF32Async(void* stream, float* dst, const float* src, const int32_t* idx, size_t n) override
+	{
+		hipStream_t st = static_cast<hipStream_t>(stream);
+		hipLaunchKernelGGL(dtrl_gather_f32, dim3(1024), dim3(256), 0, st, dst, src, idx, n);
+		if (!Check(hipGetLastError(), "gather launch")) return false;
+		if (!policy_ready_ && !Check(hipEventCreateWithFlags(&policy_ready_, hipEventDisableTiming), "hipEventCreate")) return false;
+		return Check(hipEventRecord(policy_ready_, st), "hipEventRecord");
+	}
+	bool WaitPolicyReady(int group) override { return !policy_ready_ || Check(hipStreamWaitEvent(streams_[group], policy_ready_, 0), "hipStreamWaitEvent"); }
+	bool SyncPolicyReady() override { return !policy_ready_ || Check(hipEventSynchronize(policy_ready_), "hipEventSynchronize"); }
+	// latest reader of weight buffer `wbuf` per env group (the double-buffered policy hand-over, Engine::SetPolicyDevice)
+	bool MarkWeightReader(int group, int wbuf) override
+	{
+		hipEvent_t& ev = marks_[Key(group, 8 + wbuf)];
+		if (!ev && !Check(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate")) return false;
+		return Check(hipEventRecord(ev, streams_[group]), "hipEventRecord");
+	}
+	bool WaitWeightReaders(void* stream, int wbuf, int n_groups) override
+	{
+		hipStream_t st = stream ? static_cast<hipStream_t>(stream) : stream_;
+		for (int g = 0; g < n_groups; ++g) {
+			auto it = marks_.find(Key(g, 8 + wbuf));
+			if (it != marks_.end() && it->second && !Check(hipStreamWaitEvent(st, it->second, 0), "hipStreamWaitEvent")) return false;
 		}
 		return true;
 	}
@@ -408,7 +438,8 @@ private:
 	std::vector<hipStream_t> streams_;
 	hipStream_t stream_ = nullptr;   // the selected one
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events_, free_events_, pending_;
-	static int Key(int group, int slot) { return group * 4 + slot; }
+	static int Key(int group, int slot) { return group * 16 + slot; }
+	hipEvent_t policy_ready_ = nullptr;   // behind the latest asynchronous policy gather (GatherF32Async)
 	std::map<int, hipEvent_t> marks_;   // (env group, tuple ring) -> event behind the group's latest frame launch that wrote that ring
 };
 

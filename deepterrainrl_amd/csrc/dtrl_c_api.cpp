@@ -268,6 +268,10 @@ dtrl_status dtrl_set_policy_device_on(dtrl_batch* b, const float* w_dev, size_t 
 try {
 	CHECK_B(); return static_cast<dtrl_status>(b->eng.SetPolicyDevice(w_dev, n, nullptr, nullptr, nullptr, nullptr, stream));
 } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_set_policy_device_async(dtrl_batch* b, const float* w_dev, size_t n, void* stream)
+try {
+	CHECK_B(); return static_cast<dtrl_status>(b->eng.SetPolicyDeviceAsync(w_dev, n, stream));
+} catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_get_dist_log(dtrl_batch* b, double* dist, int32_t* env_ids, int cap, int* out_n) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.GetDistLog(dist, env_ids, cap, out_n)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_reset_avg_dist(dtrl_batch* b) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.ResetAvgDist()); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 // cOptScenarioPoliEval::OutputResults (optimizer/scenarios/OptScenarioPoliEval.cpp:213-239): one line appended to `path`, the distances of every

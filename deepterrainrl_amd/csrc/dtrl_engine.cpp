@@ -212,6 +212,7 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 		buf_.nn_out = static_cast<real*>(alloc(sizeof(real) * static_cast<size_t>(d.out_size) * n_));
 		float* w_dev = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(DevNumParams(d))));
 		weights_alt_ = static_cast<float*>(alloc(sizeof(float) * static_cast<size_t>(DevNumParams(d))));   // second weight buffer: hand-overs during a frame (SetPolicyDevice)
+		weights_buf0_ = w_dev;
 		real* io = static_cast<real*>(alloc(sizeof(real) * d.in_size)); real* is = static_cast<real*>(alloc(sizeof(real) * d.in_size));
 		real* oo = static_cast<real*>(alloc(sizeof(real) * d.out_size)); real* os = static_cast<real*>(alloc(sizeof(real) * d.out_size));
 		if (!buf_.nn_out || !w_dev || !weights_alt_ || !io || !is || !oo || !os) return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error());
@@ -322,10 +323,14 @@ int Engine::LaunchGroup(int group, int n_steps, double dt_step, bool frame_end)
 	DevBuffers b = buf_;
 	b.env_list = (zero_copy_ ? pin_order_ : d_order_) + g.e0;   // the group's launch order (global env ids), costliest first
 	const double lt0 = g_ht.on ? now_s() : 0;
-	bool ok = be_->Launch(d_model_, cfg_.run, b, g.n, n_steps, dt_step, frame_end);
+	bool ok = true;
+	if (group < static_cast<int>(policy_wait_.size()) && policy_wait_[group]) { ok = be_->WaitPolicyReady(group); policy_wait_[group] = 0; }   // dtrl_set_policy_device_async
+	ok = ok && be_->Launch(d_model_, cfg_.run, b, g.n, n_steps, dt_step, frame_end);
 	// tuple pipelining: the drain of this frame's ring runs on a stream of its own one frame later and must follow THIS launch on the device -- the host
 	// has not necessarily waited for it by then (-terrain_gen= device queues the boundary work and the next frame without a sync)
 	if (ok && tuple_pipelining_ && n_steps > 0) ok = be_->MarkFrame(group, wr_ring_);
+	// the policy hand-over is double-buffered: remember which weight buffer this launch reads, so that a later gather INTO it can wait for the launch on the device
+	if (ok && weights_alt_ && n_steps > 0) ok = be_->MarkWeightReader(group, b.weights == weights_buf0_ ? 0 : 1);
 	if (g_ht.on) g_ht.t_launch += now_s() - lt0;
 	be_->SelectStream(0);
 	return ok ? DTRL_OK : Fail(DTRL_ERR_DEVICE, be_->error());
@@ -441,7 +446,7 @@ int Engine::HostFrameWork(int group)
 
 int Engine::StepBegin(double dt)
 {
-	if (step_pending_) return Fail(DTRL_ERR_ARG, "dtrl_step_begin called twice without dtrl_step_end");
+	if (step_pending_) return Fail(DTRL_ERR_ARG, early_any_ ? "dtrl_step_begin after dtrl_step_poll relaunched a group: call dtrl_step_end_begin" : "dtrl_step_begin called twice without dtrl_step_end");
 	if (dt <= 0) return DTRL_OK;   // cScenarioSimChar::Update returns early (scenarios/ScenarioSimChar.cpp:148-151)
 	if (cfg_.model.has_net && !policy_set_) return Fail(DTRL_ERR_ARG, "policy_net was given but dtrl_set_policy has not been called");
 	const int steps = cfg_.model.num_update_steps;
@@ -532,6 +537,7 @@ int Engine::Step(double dt)
 int Engine::StepUpdates(int n)
 {
 	if (n <= 0) return DTRL_OK;
+	if (early_any_ || step_pending_) return Fail(DTRL_ERR_ARG, "dtrl_step_updates while a frame is in flight (dtrl_step_begin / dtrl_step_poll): call dtrl_step_end_begin / dtrl_step_end first");
 	if (cfg_.model.has_net && !policy_set_) return Fail(DTRL_ERR_ARG, "policy_net was given but dtrl_set_policy has not been called");
 	const double dt = (1.0 / 30.0) / cfg_.model.num_update_steps;
 	ApplyPendingPolicy();
@@ -546,6 +552,7 @@ int Engine::StepUpdates(int n)
 int Engine::RunFrames(int frames, double dt)
 {
 	if (frames <= 0 || dt <= 0) return DTRL_OK;
+	if (early_any_ || step_pending_) return Fail(DTRL_ERR_ARG, "dtrl_run_frames while a frame is in flight (dtrl_step_begin / dtrl_step_poll): call dtrl_step_end_begin / dtrl_step_end first");
 	if (cfg_.model.has_net && !policy_set_) return Fail(DTRL_ERR_ARG, "policy_net was given but dtrl_set_policy has not been called");
 	const int G = static_cast<int>(groups_.size());
 	const int steps = cfg_.model.num_update_steps;
@@ -700,6 +707,23 @@ void Engine::ApplyPendingPolicy()
 	const float* cur = buf_.weights; buf_.weights = weights_alt_; weights_alt_ = const_cast<float*>(cur);
 	policy_flip_pending_ = false;
 }
+// dtrl_set_policy_device_async: the weights-only hand-over with NO host wait at all. The gather into the second weight buffer is queued on the caller's
+// stream (behind whatever produced w_dev there: a broadcast, the trainer's last step), every env group's NEXT launch waits for it on the device and switches
+// to the buffer. Valid at any time (frame in flight or not); w_dev must stay unchanged until the caller's stream has passed this point.
+int Engine::SetPolicyDeviceAsync(const float* w_dev, size_t n, void* stream)
+{
+	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
+	if (!w_dev || n != static_cast<size_t>(cfg_.user_num_params)) return Fail(DTRL_ERR_ARG, "weight count does not match the deploy prototxt");
+	if (!policy_set_ || !weights_alt_) return Fail(DTRL_ERR_ARG, "dtrl_set_policy_device_async needs a policy (normalisers) installed by dtrl_set_policy / dtrl_set_policy_device first");
+	if (!stream && std::string(be_->Name()) == "hip") return Fail(DTRL_ERR_ARG, "dtrl_set_policy_device_async: a stream (hipStream_t) of the caller's is required");
+	// a second asynchronous hand-over before any launch consumed the first: the first gather may still be writing the same buffer from another stream
+	if (policy_flip_pending_ && !policy_wait_.empty() && !be_->SyncPolicyReady()) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!be_->WaitWeightReaders(stream, weights_alt_ == weights_buf0_ ? 0 : 1, static_cast<int>(groups_.size()))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!be_->GatherF32Async(stream, weights_alt_, w_dev, d_relayout_, relayout_.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
+	policy_flip_pending_ = true;
+	policy_wait_.assign(groups_.size(), 1);
+	return DTRL_OK;
+}
 int Engine::SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, const double* is_dev, const double* oo_dev, const double* os_dev, void* stream)
 {
 	if (!cfg_.has_policy_net) return Fail(DTRL_ERR_ARG, "no -policy_net= in the arguments: this batch has no network");
@@ -710,11 +734,17 @@ int Engine::SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, 
 		be_->SelectStream(be_->NumStreams() - 1);
 		// (synchronised: the caller may change w_dev when this returns. On the caller's stream -- the trainer's -- the gather follows the steps queued there and
 		// ONE wait covers both; on the drain stream it would wait for a wavefront slot of its own behind the frame in flight)
+		// a frame kernel may still be READING the buffer about to be overwritten: a group dtrl_step_poll relaunched ran its launch on the buffer that the
+		// flip in the following dtrl_step_end_begin turned into weights_alt_ (that call skips the group without a sync), and in -terrain_gen= device mode no
+		// frame is ever waited for on the host. The gather waits on the device for every group's latest reader of this buffer (events of launches that have
+		// completed cost nothing; in host terrain mode without dtrl_step_poll they always have).
+		if (!be_->WaitWeightReaders(stream, weights_alt_ == weights_buf0_ ? 0 : 1, static_cast<int>(groups_.size()))) return Fail(DTRL_ERR_DEVICE, be_->error());
 		if (!be_->GatherF32On(stream, weights_alt_, w_dev, d_relayout_, relayout_.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
 		policy_flip_pending_ = true;
 		return DTRL_OK;
 	}
 	be_->Sync();
+	if (!policy_wait_.empty()) { if (!be_->SyncPolicyReady()) return Fail(DTRL_ERR_DEVICE, be_->error()); policy_wait_.assign(policy_wait_.size(), 0); }   // an asynchronous hand-over still on its way
 	ApplyPendingPolicy();
 	if (!be_->GatherF32(const_cast<float*>(buf_.weights), w_dev, d_relayout_, relayout_.size())) return Fail(DTRL_ERR_DEVICE, be_->error());
 	if (in_off_.empty()) { in_off_.assign(d.in_size, 0.0); in_scale_.assign(d.in_size, 1.0); out_off_.assign(d.out_size, 0.0); out_scale_.assign(d.out_size, 1.0); int rc = UploadNormalizers(); if (rc != DTRL_OK) return rc; }
@@ -834,9 +864,15 @@ int Engine::SetTuplePipelining(bool on)
 	tuple_pipelining_ = on;
 	return DTRL_OK;
 }
+// DrainSync failed: an API-order error (a drain while dtrl_step_poll's early relaunches hold both rings) is DTRL_ERR_ARG, anything else a device error
+int Engine::DrainFail()
+{
+	if (drain_order_error_) { drain_order_error_ = false; return Fail(DTRL_ERR_ARG, err_); }
+	return Fail(DTRL_ERR_DEVICE, be_->error());
+}
 bool Engine::DrainSync()
 {
-	if (early_any_) { err_ = "tuple rings are both in use: dtrl_step_poll relaunched a group; call dtrl_step_end_begin (or dtrl_step_end) first"; return false; }
+	if (early_any_) { err_ = "tuple rings are both in use: dtrl_step_poll relaunched a group; call dtrl_step_end_begin first"; drain_order_error_ = true; return false; }
 	if (tuple_pipelining_ && step_pending_) {   // the drain ring's frame ended with dtrl_step_end; the frame in flight writes the other ring
 		// "ended" is a host-side fact only in host terrain mode (HostFrameWork synchronises the group's stream). In device terrain mode the frame may
 		// still be running: the drain stream waits on the device for the mark behind every group's launch of that frame -- a torn row (the cursor is
@@ -853,7 +889,8 @@ int Engine::PendingTuples(int32_t* stored, int32_t* overflow)
 	int32_t cnt = 0;
 	DevBuffers d = buf_; UseRing(d, DrainRing());
 	struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
-	if (!DrainSync() || !RingRead(&cnt, d.tuple_count, sizeof(cnt))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!DrainSync()) return DrainFail();
+	if (!RingRead(&cnt, d.tuple_count, sizeof(cnt))) return Fail(DTRL_ERR_DEVICE, be_->error());
 	*overflow = cnt > buf_.tuple_cap ? cnt - buf_.tuple_cap : 0;
 	*stored = cnt - *overflow;
 	return DTRL_OK;
@@ -868,7 +905,7 @@ int Engine::DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap,
 	// flight each could wait for a wavefront slot).
 	if (cfg_.tuple_ring_host && !device_dst) {
 		const double ht0 = g_ht.on ? now_s() : 0;
-		if (!DrainSync()) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (!DrainSync()) return DrainFail();
 		const double ht1 = g_ht.on ? now_s() : 0;
 		const int32_t cnt_all = *d.tuple_count;
 		const int32_t over = cnt_all > buf_.tuple_cap ? cnt_all - buf_.tuple_cap : 0;
@@ -893,7 +930,7 @@ int Engine::DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap,
 	}
 	int32_t* p_cnt = reinterpret_cast<int32_t*>(pin_drain_); int32_t* p_zero = p_cnt + 1;   // (p_zero stays 0)
 	const double ht0 = g_ht.on ? now_s() : 0;
-	if (!DrainSync()) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!DrainSync()) return DrainFail();
 	const double ht1 = g_ht.on ? now_s() : 0;
 	if (cfg_.tuple_ring_host) *p_cnt = *d.tuple_count;      // (device destination, host ring)
 	else if (!be_->D2HAsync(p_cnt, d.tuple_count, sizeof(int32_t)) || !be_->SyncSelected()) return Fail(DTRL_ERR_DEVICE, be_->error());
@@ -931,7 +968,7 @@ int Engine::DrainTuples(float* rows, uint32_t* flags, int32_t* env_ids, int cap,
 int Engine::FoldTupleTotals()
 {
 	struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
-	if (!DrainSync()) return Fail(DTRL_ERR_DEVICE, be_->error());
+	if (!DrainSync()) return DrainFail();
 	for (int r = 0; r < 2; ++r) {
 		if (!ring_[r].count || (tuple_pipelining_ && step_pending_ && r == wr_ring_)) continue;   // (the ring in flight folds after its frame)
 		int32_t c[4] = {0, 0, 0, 0};
@@ -960,7 +997,7 @@ int Engine::DrainTuplesPacked(float* block_dev, int block_rows, int* out_n)
 		pack_.env = static_cast<int32_t*>(alloc(sizeof(int32_t) * cap));
 		if (!pack_.order || !pack_.hist || !pack_.meta || !pack_.rows || !pack_.flags || !pack_.env || !be_->Sync()) { pack_ = PackScratch(); return Fail(DTRL_ERR_DEVICE, "device allocation failed: " + be_->error()); }
 	}
-	if (!DrainSync()) return Fail(DTRL_ERR_DEVICE, be_->error());   // the frame kernels that wrote this ring have finished
+	if (!DrainSync()) return DrainFail();   // the frame kernels that wrote this ring have finished
 	if (!be_->PackTuples(d, block_dev, block_rows, cfg_.run.env_id_base, n_, pack_)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	if (out_n) { int32_t n = 0; if (!be_->D2H(&n, block_dev, sizeof(n))) return Fail(DTRL_ERR_DEVICE, be_->error()); *out_n = n; }
 	return DTRL_OK;

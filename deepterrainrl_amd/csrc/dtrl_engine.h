@@ -51,6 +51,19 @@ public:
 	// when the host never synchronised with that frame (-terrain_gen= device). No-ops on a synchronous backend.
 	virtual bool MarkFrame(int group, int slot) = 0;
 	virtual bool WaitFrames(int slot, int n_groups) = 0;
+	// MarkWeightReader: env group `group`'s latest launch reads weight buffer `wbuf` (0 / 1: the double-buffered policy hand-over) -- remember the point behind it;
+	// WaitWeightReaders: `stream` (nullptr = the selected stream) waits on the device for every group's latest reader of `wbuf`, so that a gather INTO that
+	// buffer cannot overtake a frame kernel still reading it (dtrl_step_poll relaunches, -terrain_gen= device frames the host never waited for). No-ops on a
+	// synchronous backend.
+	// the gather WITHOUT a host wait, on a stream of the caller's (required): src must stay unchanged until the work queued on that stream has passed this
+	// point. Records the "policy ready" point behind it; WaitPolicyReady makes env group `group`'s stream wait for it on the device (the next frame launch
+	// of a group must not start before the weights it will read are complete); SyncPolicyReady waits for it on the host. The synchronous test backend
+	// performs the gather at once.
+	virtual bool GatherF32Async(void* stream, float* dst, const float* src, const int32_t* idx, size_t n) { (void)stream; return GatherF32(dst, src, idx, n); }
+	virtual bool WaitPolicyReady(int group) { (void)group; return true; }
+	virtual bool SyncPolicyReady() { return true; }
+	virtual bool MarkWeightReader(int group, int wbuf) { (void)group; (void)wbuf; return true; }
+	virtual bool WaitWeightReaders(void* stream, int wbuf, int n_groups) { (void)stream; (void)wbuf; (void)n_groups; return true; }
 	virtual bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) = 0;
 	virtual bool Sync() = 0;                 // all streams
 	// work queues: H2D / H2DAsync / D2H / Launch act on the selected stream (0 by default); D2H and H2D synchronise only that stream
@@ -86,6 +99,7 @@ public:
 	int GetDistLog(double* dist, int32_t* env_ids, int cap, int* out_n);
 	int ResetAvgDist();
 	int SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, const double* is_dev, const double* oo_dev, const double* os_dev, void* stream = nullptr);
+	int SetPolicyDeviceAsync(const float* w_dev, size_t n, void* stream);
 	int GetStates(const int32_t* env_ids, int n, std::vector<EnvState>& out);
 	int SetPoseVel(const int32_t* env_ids, int n, const double* q, const double* qd);
 	int CommandAction(const int32_t* env_ids, int n, const int32_t* action_ids);
@@ -138,7 +152,8 @@ private:
 	int n_ = 0, S_ = 0, A_ = 0, W_ = 0;
 	bool policy_set_ = false;
 	std::vector<char> early_; bool early_any_ = false;   // env groups dtrl_step_poll has relaunched ahead of the next dtrl_step_end_begin
-	float* weights_alt_ = nullptr; bool policy_flip_pending_ = false;   // SetPolicyDevice during a frame: gathered here, switched in with the next launch
+	float* weights_alt_ = nullptr; const float* weights_buf0_ = nullptr; bool policy_flip_pending_ = false;
+	std::vector<char> policy_wait_;   // per env group: its next launch waits (on the device) for the asynchronous hand-over's gather   // SetPolicyDevice during a frame: gathered here, switched in with the next launch
 	bool step_pending_ = false;
 	DevModel* d_model_ = nullptr;
 	DevBuffers buf_{};
@@ -175,6 +190,7 @@ private:
 	bool tuple_pipelining_ = false;
 	void UseRing(DevBuffers& b, int r) const { b.tuple_rows = ring_[r].rows; b.tuple_flags = ring_[r].flags; b.tuple_env = ring_[r].env; b.tuple_count = ring_[r].count; }
 	int DrainRing() const { return (tuple_pipelining_ && step_pending_) ? (wr_ring_ ^ 1) : wr_ring_; }   // the ring no kernel is writing
+	int DrainFail(); bool drain_order_error_ = false;
 	bool DrainSync();   // make the drain ring's contents final: all streams, or -- while a pipelined frame runs -- only the drain stream
 	int PendingTuples(int32_t* stored, int32_t* overflow);
 	std::vector<int32_t> work_;

@@ -452,6 +452,15 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	}
 	m.contact_tol = 0.001 / world_scale;   // sim/ContactManager.cpp:74-75, dist_tol in world-scaled units
 	{ double margin = 0.04; args.ParseDouble("collision_margin", margin); m.contact_margin = margin / world_scale; }   // CONVEX_DISTANCE_MARGIN (world-scaled units)
+	{
+		// btBoxShape::btBoxShape -> setSafeMargin(halfExtents, 0.1) on the world-scaled half extents cWorld::BuildBoxShape hands over (sim/World.cpp:475-482): in metres the
+		// scale cancels out of the 0.1 x half-extent branch
+		int safe = 1; args.ParseInt("safe_margin", safe);
+		for (int j = 0; j < L; ++j) {
+			const double he = std::min(std::min(static_cast<double>(m.body_half[j][0]), static_cast<double>(m.body_half[j][1])), 0.5 * bodies->arr[j].get_num("Param2", 0));
+			m.link_margin[j] = safe ? std::min(static_cast<double>(m.contact_margin), 0.1 * he) : static_cast<double>(m.contact_margin);
+		}
+	}
 	// link--link collision pairs: same non-zero collision group, no hinge between the two, boxes overlapping in z (joint AttachZ accumulated down the
 	// chain + body AttachZ against the box depth Param2: the raptor's legs share a group but sit 0.16 m apart in z with 0.065 m deep boxes)
 	{
@@ -487,9 +496,9 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 		const double c = std::cos(m.body_theta[j]), s = std::sin(m.body_theta[j]);
 		const double loc[kPtsPerLink][2] = {{-hx, -hy}, {hx, -hy}, {hx, hy}, {-hx, hy},
 			{hx >= hy ? 0.0 : -hx, hx >= hy ? -hy : 0.0}, {hx >= hy ? 0.0 : hx, hx >= hy ? hy : 0.0}};
-		// against the ground the boxes carry Bullet's collision margin (btBoxShape: core = half extents - margin, rounded by the margin; a half extent below
-		// the margin goes negative as Bullet's implicitShapeDimensions do): the ground test measures core point -> surface and subtracts the margin
-		const double gx = hx - m.contact_margin, gy = hy - m.contact_margin;
+		// against the ground the boxes carry Bullet's collision margin (btBoxShape: core = half extents - margin, rounded by the margin; with the safe margin
+		// the core never inverts): the ground test measures core point -> surface and subtracts the margin
+		const double gx = hx - m.link_margin[j], gy = hy - m.link_margin[j];
 		const double locg[kPtsPerLink][2] = {{-gx, -gy}, {gx, -gy}, {gx, gy}, {-gx, gy},
 			{hx >= hy ? 0.0 : -gx, hx >= hy ? -gy : 0.0}, {hx >= hy ? 0.0 : gx, hx >= hy ? gy : 0.0}};
 		for (int k = 0; k < kPtsPerLink; ++k) {

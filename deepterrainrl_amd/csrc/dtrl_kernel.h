@@ -652,9 +652,10 @@ DTRL_HD_INLINE PtVal contact_point_eval(const W& ws, const DevModel& gm, const G
 	const real h = sample_ground(g, gh, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
 	const real gap = h - (ws.st.q[1] + y);
 	// inside a substep only penetrating points matter: depth = gap * ny + margin > 0 needs gap > -margin / ny, and 1 / ny = sqrt(1 + slope^2) <= 1 + |slope|
-	if (!kNear && !(gap + gm.contact_margin * (1.0 + fabs(slope)) > 0)) return r;
+	const real margin = gm.link_margin[j];
+	if (!kNear && !(gap + margin * (1.0 + fabs(slope)) > 0)) return r;
 	const real inv = fast_rsqrt(1.0 + slope * slope);
-	const real depth = fmadd(gap, inv, gm.contact_margin);   // along the cell normal (ny = inv > 0), to the ROUNDED surface of the box (Bullet's collision margin)
+	const real depth = fmadd(gap, inv, margin);   // along the cell normal (ny = inv > 0), to the ROUNDED surface of the box (Bullet's collision margin)
 	if (kNear) r.near = depth >= -gm.contact_tol ? 1 : 0;   // cContactManager::Update: getDistance() <= dist_tol
 	if (!(depth > 0)) return r;
 	r.nx = -slope * inv; r.ny = inv;

@@ -77,6 +77,10 @@ struct DevModel {
 	real pt_joint[kMaxL][kPtsPerLink][2];   // contact sample points in the JOINT frame: body_attach + R(body_theta) * corner (link--link tests: sharp boxes)
 	real pt_ground[kMaxL][kPtsPerLink][2];  // the same points of the MARGIN-SHRUNK box (ground test: core point -> surface, minus contact_margin)
 	real contact_margin;                    // Bullet's CONVEX_DISTANCE_MARGIN 0.04 in world-scaled units = 0.04 / world_scale metres (-collision_margin= overrides; 0 = sharp boxes)
+	// the margin a link's box actually carries, metres: btBoxShape's constructor calls setSafeMargin(halfExtents) -> min(CONVEX_DISTANCE_MARGIN, 0.1 x the smallest
+	// half extent) in world-scaled units (Bullet >= 2.80; the reference needs >= 2.82: sim/World.cpp:4-5 includes MLCPSolvers), e.g. 2.5 mm for a dog / goat toe and
+	// 7.5 mm for the torso at ANY world scale. -safe_margin= 0 gives every link contact_margin (the round-3 model)
+	real link_margin[kMaxL];
 	real eff_joint[kMaxL][2];               // body-local (0, -size_y/2) in the joint frame (end-effector contact position)
 	real init_pos_x, target_vel_x, total_mass;
 	real world_scale;

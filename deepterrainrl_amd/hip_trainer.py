@@ -256,9 +256,26 @@ class _HipNetSide:
     def _store_rows(self, slots, rows, flags, contiguous):
         if self._staged is not None and contiguous and len(slots) <= self.mem_size:
             self.nt.add_staged(self._staged, len(slots), int(slots[0]), self.mem_size)     # (every row of the chunk passed CheckTuple: staged row i -> slot head + i)
+            self._staged_dirty = True           # rows written on the TRAINER's stream: a framework read of self.mem / self.flags_dev must be ordered behind them
         else:
             super()._store_rows(slots, rows, flags, contiguous)
             self._replay_dirty = True
+
+    def _order_staged(self):
+        """Replay rows stored by add_staged are written asynchronously on the trainer's stream; every framework-side read of self.mem / self.flags_dev (the
+        normaliser statistics, HipCaclaTrainer's and HipQNetTrainer's minibatch rows) goes through here first, so that torch's current stream waits for
+        them. Beside a running frame those stores can sit in the queue for milliseconds -- without the wait a minibatch could be built from rows not yet
+        written. Lazy: one stream wait per batch of stores, none when nothing was staged."""
+        if getattr(self, "_staged_dirty", False):
+            self._before_torch(); self._staged_dirty = False
+
+    def _idx(self, ids):
+        self._order_staged()                    # every framework read of the replay memory indexes it through _idx
+        return super()._idx(ids)
+
+    def UpdateOffsetScale(self):
+        self._order_staged()                    # cNeuralNet::CalcOffsetScale reads the begin states of every stored tuple
+        super().UpdateOffsetScale()
 
     # ---- network calls ----
     def _eval(self, net, X):
@@ -379,7 +396,7 @@ class HipQNetTrainer(_HipNetSide, QNetTrainer):
     dtrl_trainer_step per iteration."""
 
     def _q_problem(self, ids):
-        self._before_torch()                    # replay rows stored from the staging area on the trainer's stream are read by framework ops here
+        self._order_staged()                    # replay rows stored from the staging area on the trainer's stream are read by framework ops here
         return super()._q_problem(ids)
 
 

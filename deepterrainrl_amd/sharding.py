@@ -226,10 +226,14 @@ class ShardedRollout:
                 v.copy_(t.to(self.device, dtype=v.dtype).reshape(-1))
         if self.coll:
             self.dist.broadcast(self.pol_buf, src=src)
+        if not normalizers:
+            # no host wait: the re-layout kernel is queued on this stream behind the broadcast (a synchronous-mode collective blocks the CURRENT stream on RCCL's),
+            # the engine's next frame launches wait for it on the device (dtrl_set_policy_device_async). pol_buf's next writer is the next broadcast_policy, queued
+            # on the same stream. (Round 3 synchronised the stream here: a host wait behind the frame kernel in flight, once per hand-over.)
+            st = torch.cuda.current_stream(self.device).cuda_stream if self.on_gpu else None
+            self.batch.SetPolicyDeviceAsync(views[0].data_ptr(), self.n_w, st)
+            return [v.cpu().numpy().copy() for v in views] if want_host else None
         if self.on_gpu:
             torch.cuda.current_stream(self.device).synchronize()
-        if normalizers:
-            self.batch.SetPolicyDevice(views[0].data_ptr(), self.n_w, *[v.data_ptr() for v in views[1:]])
-        else:
-            self.batch.SetPolicyDevice(views[0].data_ptr(), self.n_w)
+        self.batch.SetPolicyDevice(views[0].data_ptr(), self.n_w, *[v.data_ptr() for v in views[1:]])
         return [v.cpu().numpy().copy() for v in views] if want_host else None

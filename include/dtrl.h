@@ -163,6 +163,12 @@ dtrl_status dtrl_set_policy_device(dtrl_batch* b, const float* weights_dev, size
  * there -- the trainer's last step -- and the call returns when it has run, so ONE host wait covers the trainer's pending work and the hand-over (during a frame the
  * engine's own stream would have to find a wavefront slot of its own). Same semantics as dtrl_set_policy_device otherwise. */
 dtrl_status dtrl_set_policy_device_on(dtrl_batch* b, const float* weights_dev, size_t n, void* stream);
+/* The weights-only form with NO host wait: the re-layout kernel is queued on `stream` (a hipStream_t of the caller's, required) behind whatever produced
+ * weights_dev there -- an RCCL broadcast of cNeuralNetLearner::SyncNet's payload (learning/NeuralNetLearner.cpp:85-89), the trainer's last step -- and every env's
+ * NEXT frame launch waits for it ON THE DEVICE and runs with the new weights. Valid with or without a frame in flight. weights_dev must not change until the
+ * work queued on `stream` has passed this point (the caller's next write to it on the same stream is ordered by the stream). Needs normalisers installed by an
+ * earlier dtrl_set_policy / dtrl_set_policy_device. */
+dtrl_status dtrl_set_policy_device_async(dtrl_batch* b, const float* weights_dev, size_t n, void* stream);
 
 /* No counterpart in the reference (its trainer and its env threads share CPU cores under the OS scheduler; scenarios/ScenarioTrain.cpp runs them as threads
  * of one process). On the GPU a frame launch fills every wavefront slot of the compute units it may use for milliseconds, so work that should run BESIDE the

@@ -229,11 +229,24 @@ protected:
 	btScalar m_margin = 0.04f;   // Bullet's CONVEX_DISTANCE_MARGIN
 	void* m_user = nullptr;
 };
-class btConvexShape : public btCollisionShape {};
+class btConvexShape : public btCollisionShape {
+public:
+	// btConvexInternalShape::setSafeMargin (Bullet >= 2.80, "issue 349"): a convex shape never carries a margin above a tenth of its smallest dimension
+	void setSafeMargin(btScalar minDimension, btScalar defaultMarginMultiplier = btScalar(0.1))
+	{
+		const btScalar safe = defaultMarginMultiplier * minDimension;
+		if (safe < getMargin()) setMargin(safe);
+	}
+};
 class btConcaveShape : public btCollisionShape {};
 class btBoxShape : public btConvexShape {
 public:
-	explicit btBoxShape(const btVector3& half) : m_half(half) {}
+	// btBoxShape::btBoxShape: setSafeMargin(boxHalfExtents) before the implicit (core) dimensions are derived -> margin = min(0.04, 0.1 x smallest half extent)
+	explicit btBoxShape(const btVector3& half) : m_half(half) { setSafeMargin(std::min(half.x(), std::min(half.y(), half.z()))); }
+	// btCollisionShape::getAngularMotionDisc for a box centred on its origin = |half extents|; getContactBreakingThreshold(0.02) = disc x 0.02
+	// (btCollisionDispatcher::getNewManifold with CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD, the dispatcher's default flag)
+	btScalar getAngularMotionDisc() const { return m_half.length(); }
+	btScalar getContactBreakingThreshold(btScalar defaultContactThreshold) const { return getAngularMotionDisc() * defaultContactThreshold; }
 	btVector3 getHalfExtentsWithMargin() const { return m_half; }
 	btVector3 getHalfExtentsWithoutMargin() const { return m_half - btVector3(m_margin, m_margin, m_margin); }
 	void calculateLocalInertia(btScalar mass, btVector3& inertia) const override

@@ -59,7 +59,7 @@ class OrcModel(C.Structure):
         ("scenario", C.c_int32), ("tuple_buffer_size", C.c_int32), ("enable_explore", C.c_int32),
         ("exp_rate", C.c_double), ("exp_temp", C.c_double), ("exp_base_rate", C.c_double),
         ("link_contacts", C.c_int32), ("n_cpairs", C.c_int32), ("cpair_a", C.c_int32 * MAXCP), ("cpair_b", C.c_int32 * MAXCP),
-        ("contact_margin", C.c_double), ("warm_start", C.c_int32),
+        ("contact_margin", C.c_double), ("link_margin", C.c_double * MAXL), ("warm_start", C.c_int32),
     ]
 
 
@@ -263,6 +263,12 @@ def build_model(arg_file, root, overrides=None):
     m.num_sim_substeps = int(args.get("num_sim_substeps", 1))
     m.world_scale = float(args.get("world_scale", 1))
     m.contact_margin = float(args.get("collision_margin", 0.04)) / m.world_scale   # CONVEX_DISTANCE_MARGIN, world-scaled units -> metres
+    # btBoxShape::btBoxShape -> setSafeMargin(halfExtents, 0.1): margin = min(CONVEX_DISTANCE_MARGIN, 0.1 * smallest half extent), in the world-scaled units
+    # cWorld::BuildBoxShape hands to Bullet (sim/World.cpp:475-482: scale * size / 2)
+    safe = int(args.get("safe_margin", 1))
+    for j in range(L):
+        he = min(0.5 * m.body_size[j][k] for k in range(3))
+        m.link_margin[j] = min(m.contact_margin, 0.1 * he) if safe else m.contact_margin
     m.warm_start = int(args.get("warm_start", 0))
     m.terrain_type = 0
     m.n_terrain_sets = 1

@@ -25,7 +25,10 @@
 //   * contact row: rel_vel along the normal, positional error -penetration x erp / h (or, for a point still `dist` above the surface, the allowed
 //     approach -dist / h), split impulse: penetration below the threshold is recovered through push / turn velocities that move the transform but
 //     never enter the velocity (turn x 0.1); contact points persist between steps with their applied impulses while they stay within the breaking
-//     threshold 0.02, at most 4 per body pair (the deepest are kept); box margin 0.04 (CONVEX_DISTANCE_MARGIN; concave ground shapes: 0).
+//     threshold (0.02 x the pair's smaller angular-motion disc: btCollisionDispatcher::getNewManifold with its default flag
+//     CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD; 1.35 mm for a dog toe), at most 4 per body pair (the deepest are kept); box margin = min(0.04, 0.1 x the
+//     smallest half extent) (CONVEX_DISTANCE_MARGIN through btBoxShape's setSafeMargin; concave ground shapes: 0). Round 3 ran this comparator with 0.04 / 0.02
+//     on every box (the `safe_margin = 0, relative_breaking = 0` ablation reproduces it); at world scale 1 that inverted the goat's 2.5 cm boxes.
 // What is a stand-in here (Bullet's narrowphase cannot be restated without its source): contact GENERATION. Box vs ground: the four corners of the
 // margin-shrunk box against the terrain polyline (distance along the cell normal, minus the margin) plus terrain vertices against the box; box vs box
 // (same collision group, not hinge-linked, sim/SimDog.cpp:73-81): the corners of either margin-shrunk box against the other. The hinge's
@@ -53,6 +56,8 @@ struct Params {
 	int warmstarting = 1;            // SOLVER_USE_WARMSTARTING
 	double warmstart_factor = 0.85;  // m_warmstartingFactor
 	double breaking = 0.02;          // gContactBreakingThreshold
+	int relative_breaking = 1;       // CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD (btCollisionDispatcher's default): a pair's threshold = 0.02 x the smaller angular-motion disc
+	int safe_margin = 1;             // btBoxShape's setSafeMargin: margin = min(0.04, 0.1 x smallest half extent); 0 = 0.04 on every box (the round-3 comparator)
 	int max_points = 4;              // MANIFOLD_CACHE_SIZE
 	int use_margin = 1;              // box margins (0 = sharp boxes, distance without margin)
 	int link_contacts = 1;           // box-box contacts between same-group, not hinge-linked links
@@ -66,6 +71,7 @@ struct Body {
 	double dvx = 0, dvy = 0, dw = 0;     // solver body: delta velocities
 	double px = 0, py = 0, pw = 0;       // push / turn velocities (split impulse)
 	double hx = 0, hy = 0, margin = 0;   // box half extents (margin included, as btBoxShape stores them) and margin
+	double brk = 0;                      // contact breaking threshold of a manifold this body is the smaller partner of
 	bool is_box = false;
 	short group = 0, mask = 0;
 };
@@ -169,7 +175,8 @@ private:
 			b.inv_m = rb->getInvMass(); b.inv_i = rb->getInvInertiaDiagLocal().z() * rb->getAngularFactor().z();
 			if (const btBoxShape* box = dynamic_cast<const btBoxShape*>(rb->getCollisionShape())) {
 				const btVector3 he = box->getHalfExtentsWithMargin();
-				b.is_box = true; b.hx = he.x(); b.hy = he.y(); b.margin = prm.use_margin ? box->getMargin() : 0.0;
+				b.is_box = true; b.hx = he.x(); b.hy = he.y(); b.margin = prm.use_margin ? (prm.safe_margin ? static_cast<double>(box->getMargin()) : 0.04) : 0.0;
+				b.brk = prm.relative_breaking ? static_cast<double>(box->getContactBreakingThreshold(static_cast<btScalar>(prm.breaking))) : prm.breaking;
 			}
 			b.group = rb->getBroadphaseHandle()->m_collisionFilterGroup; b.mask = rb->getBroadphaseHandle()->m_collisionFilterMask;
 			index_[rb] = static_cast<int>(bodies_.size());
@@ -237,7 +244,7 @@ private:
 				const btBoxShape* ba = static_cast<const btBoxShape*>(A.rb->getCollisionShape()); const btBoxShape* bb = static_cast<const btBoxShape*>(B.rb->getCollisionShape());
 				const double za = A.rb->getCenterOfMassTransform().getOrigin().z(), zb = B.rb->getCenterOfMassTransform().getOrigin().z();
 				if (std::fabs(za - zb) > ba->getHalfExtentsWithMargin().z() + bb->getHalfExtentsWithMargin().z()) continue;
-				const double rr = std::hypot(A.hx, A.hy) + std::hypot(B.hx, B.hy) + prm.breaking;
+				const double rr = std::hypot(A.hx, A.hy) + std::hypot(B.hx, B.hy) + std::min(A.brk, B.brk);
 				if (std::hypot(A.x - B.x, A.y - B.y) > rr) continue;
 				std::vector<Contact> cand;
 				BoxBox(static_cast<int>(i), static_cast<int>(j), cand);
@@ -284,13 +291,13 @@ private:
 				c.dist = d - m;
 				c.bx = px - d * c.nx; c.by = py - d * c.ny;
 			}
-			if (c.dist > prm.breaking) continue;
+			if (c.dist > A.brk) continue;
 			c.ax = px - m * c.nx; c.ay = py - m * c.ny;   // the point of the rounded box closest to the surface
 			out.push_back(c);
 		}
 		if (gnd.plane) return;
 		// terrain vertices against the box (a crest poking into a face between two corners)
-		const double r = std::hypot(A.hx, A.hy) + prm.breaking;
+		const double r = std::hypot(A.hx, A.hy) + A.brk;
 		int i0 = static_cast<int>(std::floor((A.x - r - gnd.x0) / gnd.dx)), i1 = static_cast<int>(std::ceil((A.x + r - gnd.x0) / gnd.dx));
 		i0 = std::max(i0, 0); i1 = std::min(i1, gnd.n - 1);
 		const double cth = std::cos(A.th), sth = std::sin(A.th);
@@ -312,7 +319,7 @@ private:
 			c.nx = cth * nlx - sth * nly; c.ny = sth * nlx + cth * nly;   // from the vertex (ground) towards the box
 			if (c.ny < 0.2) continue;                                    // a vertex can only push upwards-ish (it is ground)
 			c.dist = d - m;
-			if (c.dist > prm.breaking) continue;
+			if (c.dist > A.brk) continue;
 			c.bx = vx; c.by = vy; c.ax = vx + c.dist * c.nx; c.ay = vy + c.dist * c.ny;
 			out.push_back(c);
 		}
@@ -335,7 +342,7 @@ private:
 					if (dxp < dyp) { nlx = lx > 0 ? 1 : -1; nly = 0; d = -dxp; } else { nlx = 0; nly = ly > 0 ? 1 : -1; d = -dyp; }
 				} else { const double ddx = lx - qx, ddy = ly - qy; d = std::hypot(ddx, ddy); nlx = ddx / d; nly = ddy / d; }
 				const double dist = d - m;
-				if (dist > prm.breaking) continue;
+				if (dist > std::min(P.brk, Q.brk)) continue;
 				// normal from Q towards P in world coordinates
 				const double nwx = cq * nlx - sq * nly, nwy = sq * nlx + cq * nly;
 				Contact c; c.a = ia; c.b = ib; c.obj_b = bodies_[ib].rb; c.mu = P.rb->getFriction() * Q.rb->getFriction(); c.key = 0x40u + static_cast<uint64_t>(side * 4 + k);

@@ -65,6 +65,11 @@ struct OrcModel {
 	// collision margin of the box links against the GROUND, metres: Bullet's CONVEX_DISTANCE_MARGIN 0.04 in world-scaled units = 0.04 / world_scale (1 cm for the
 	// dog at world scale 4, 4 cm for the goat scene whose arg file leaves the scale at 1). 0 = sharp boxes (the round-2 model, -collision_margin= 0)
 	double contact_margin;
+	// per-link margin actually used, metres. Bullet's btBoxShape constructor calls setSafeMargin(halfExtents): margin = min(CONVEX_DISTANCE_MARGIN, 0.1 x the
+	// smallest half extent) in world-scaled units (btConvexInternalShape::setSafeMargin, Bullet >= 2.80; the reference needs >= 2.82, sim/World.cpp:4-5), so a
+	// thin link carries a thin margin and the box core never inverts: dog / goat toe 2.5 mm, torso 7.5 mm at ANY world scale. -safe_margin= 0 restores the
+	// uniform round-3 value contact_margin for every link
+	double link_margin[ORC_MAXL];
 	int32_t warm_start;    // experiment switch (-warm_start= 1): constraint rows start the sweeps from 0.85 x their previous impulse (oracle only: tools/a2_deviation.py)
 };
 

@@ -121,10 +121,10 @@ inline void ContactDistances(const OrcModel& M, const Bodies& B, const Ground& g
 			double& d = out[j * SimConst::pts_per_link + k];
 			d = 1e30;
 			if (M.col_group[j] == 0) continue;
-			double sx, sy; LinkSamplePoint(M, j, k, sx, sy, M.contact_margin);
+			double sx, sy; LinkSamplePoint(M, j, k, sx, sy, M.link_margin[j]);
 			double x = B.cx[j] + c * sx - s * sy, y = B.cy[j] + s * sx + c * sy;
 			double slope = g.SampleSlope(x);
-			d = -(g.SampleHeight(x) - y) / std::sqrt(1.0 + slope * slope) - M.contact_margin;
+			d = -(g.SampleHeight(x) - y) / std::sqrt(1.0 + slope * slope) - M.link_margin[j];
 		}
 	}
 }
@@ -143,14 +143,14 @@ inline int DetectContacts(const OrcModel& M, const Bodies& B, const Ground& g, C
 		if (M.col_group[j] == 0) continue;
 		double c = std::cos(B.psi[j]), s = std::sin(B.psi[j]);
 		for (int k = 0; k < SimConst::pts_per_link; ++k) {
-			double sx, sy; LinkSamplePoint(M, j, k, sx, sy, M.contact_margin);
+			double sx, sy; LinkSamplePoint(M, j, k, sx, sy, M.link_margin[j]);
 			double x = B.cx[j] + c * sx - s * sy;
 			double y = B.cy[j] + s * sx + c * sy;
 			double h = g.SampleHeight(x);
 			double slope = g.SampleSlope(x);
 			double inv = 1.0 / std::sqrt(1.0 + slope * slope);
 			double nx = -slope * inv, ny = inv;
-			double depth = std::fma(h - y, ny, M.contact_margin);   // the rounded corner reaches a margin beyond the core point (fused, as the kernel does)
+			double depth = std::fma(h - y, ny, M.link_margin[j]);   // the rounded corner reaches a margin beyond the core point (fused, as the kernel does)
 			if (depth >= -tol) flags[j] = true;                 // cContactManager::Update: distance <= dist_tol
 			ContactPoint& p = all[j * SimConst::pts_per_link + k];
 			p.link = j; p.x = x; p.y = y; p.depth = depth; p.nx = nx; p.ny = ny; p.pt = j * SimConst::pts_per_link + k;

@@ -288,12 +288,15 @@ def run_policy_hand_over_during_a_frame(scn, om, to_dev=None, n_envs=8, frames=4
         x.SetPolicy(pol[1], *pol[2:])
     a.UpdateBegin()
     for f in range(frames):
-        k = (f // 3) % 3
+        k = (f // 3 + f // 9) % 3                              # (policy index and hand-over form both cycle with period 3: shift one against the other)
         if f % 3 == 0:                                      # frame f in flight on `a`: parked, effective from frame f + 1
-            if f % 2 == 0:
+            form = (f // 3) % 3
+            if form == 0:
                 a.SetPolicyDevice(held[k][1], w0.size)
-            else:
+            elif form == 1:
                 a.SetPolicyDeviceOn(held[k][1], w0.size, stream_ptr)     # the same with the re-layout kernel on a stream of the caller's (None: the engine's)
+            else:
+                a.SetPolicyDeviceAsync(held[k][1], w0.size, stream_ptr)  # no host wait at all: the next launches wait for the re-layout kernel on the device
         a.UpdateEnd()
         b.Update()                                          # frame f on `b` with the weights frame f of `a` ran with
         if f % 3 == 0:

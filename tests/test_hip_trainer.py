@@ -221,6 +221,36 @@ def test_gpu_staged_add_equals_plain_add():
 
 
 @pytest.mark.gpu
+def test_gpu_framework_reads_wait_for_staged_stores():
+    """rows stored from the staging area are written on the TRAINER's stream; a framework read of the replay memory on torch's current stream
+    (the normaliser statistics of UpdateOffsetScale, a CACLA / Q minibatch) must wait for them. The trainer's stream is held up by a long spin kernel in front
+    of the stores, as a frame kernel beside the trainer does."""
+    from deepterrainrl_amd import hip_trainer as ht
+    rng = np.random.RandomState(3)
+    rows, flags = TT.q_rows(rng, 120)
+    t = ht.HipQNetTrainer(TT.QTRAIN, TT.QSOLVER, S, TT.QA, lib_path=None, mem_size=256, num_init_samples=100000, device="cuda", seed=8)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(t._stream):
+        torch.cuda._sleep(int(2e8))            # ~100 ms in front of the stores on the trainer's stream
+    n = t.StageTuples(rows, flags)
+    assert n == 120
+    t.AddTuples(rows, flags, staged=0)
+    t.UpdateOffsetScale()
+    io, isc, _, _ = t.GetOffsetScale()
+    X = rows[:, 1:1 + S].astype(np.float64)
+    std = X.std(0)
+    assert np.allclose(np.asarray(io), -X.mean(0), atol=1e-6)
+    assert np.allclose(np.asarray(isc), np.where(std == 0, 0, 1.0 / np.where(std == 0, 1, std)), rtol=1e-5)
+    rows2, flags2 = TT.q_rows(rng, 64)
+    assert t.StageTuples(rows2, flags2) == 64      # (waits for the previous stores; the spin is then queued in front of the new ones)
+    with torch.cuda.stream(t._stream):
+        torch.cuda._sleep(int(2e8))
+    slots = t.AddTuples(rows2, flags2, staged=0)
+    got = t._rows(list(slots)).cpu().numpy()
+    assert np.array_equal(got, rows2.astype(np.float32))
+
+
+@pytest.mark.gpu
 def test_gpu_forward_and_step_vs_torch_peer():
     run_forward_and_step_vs_torch_peer(None, "cuda", 5e-5)
 
@@ -266,3 +296,68 @@ def test_gpu_overlapped_training_loop_is_reproducible():
     assert (a["iters"], a["tuples"]) == (b["iters"], b["tuples"]) and a["tuples"] >= 1500
     assert np.array_equal(a["weights"], b["weights"])
     assert "libdtrl.so" in open("/proc/self/maps").read()
+
+
+class _ReplayDraws:
+    """numpy RandomState's randint(lo, hi) call shape over a recorded list of draws (the reference trainer's cMathUtil::gRand stream, frozen)"""
+
+    def __init__(self, draws):
+        self.draws, self.k = [int(x) for x in draws], 0
+
+    def randint(self, lo, hi=None):
+        if hi is None:
+            lo, hi = 0, lo
+        v = self.draws[self.k]; self.k += 1
+        assert lo <= v < hi, "the product asked for a draw the reference did not make at this point (%d not in [%d, %d))" % (v, lo, hi)
+        return v
+
+
+def run_native_trainer_vs_frozen_reference_trainer(om, lib, device, tol):
+    """The native step against a run of the REFERENCE'S OWN cMACETrainer frozen on the CPU box (tests/golden/make_ref_golden_learn.py: /root/reference/learning compiled
+    unchanged; frozen target refreshed every 2 iterations, tuples arriving in three batches through a ring wrap): the product replays the reference's index draws and
+    must land on its iteration counters, stage and three index buffers after every Train(), consume exactly the draws the reference consumed, and end at its weights."""
+    g = np.load(os.path.join(REPO, "tests", "golden", "ref_golden_learn.npz"))
+    rng = np.random.RandomState(9)
+    rows, flags = TT.random_rows(rng, 420, p_actor=0.5)
+    d = om.parse_deploy_prototxt(TT.DEPLOY)
+    w0 = om.xavier_weights(d, int(g["w_seed"]))
+    t = make_native(lib, device, mem_size=256, num_init_samples=100, seed=21, freeze_target_iters=int(g["freeze"]))
+    t.rng = _ReplayDraws(g["draws"])
+    t.SetWeights(w0)
+    k = i = 0
+    for n_new, n_train in g["schedule"]:
+        t.AddTuples(rows[k:k + n_new], flags[k:k + n_new]); k += int(n_new)
+        for _ in range(int(n_train)):
+            t.Train()
+            assert [t.GetIter(), t.actor_iter, int(t.stage_train)] == g["s%d_counters" % i].tolist(), i
+            assert list(t.critic_buffer) == g["s%d_critic" % i].tolist() and list(t.actor_buffer) == g["s%d_actor" % i].tolist(), i
+            assert list(t.actor_batch_buffer) == g["s%d_actor_batch" % i].tolist(), i
+            i += 1
+    assert i == int(g["n_steps"]) and t.rng.k == len(t.rng.draws)
+    w = t.GetWeights().astype(np.float64)
+    scale = float(g["w_norm"]) / np.sqrt(w.size)
+    assert np.abs(w[g["pick"]] - g["w_pick"]).max() < tol * np.abs(g["w_pick"]).max(), np.abs(w[g["pick"]] - g["w_pick"]).max()
+    assert abs(np.linalg.norm(w) - float(g["w_norm"])) < tol * float(g["w_norm"]) and scale > 0
+    io, isc, _, _ = t.GetOffsetScale()
+    assert np.allclose(io, g["in_off"], rtol=0, atol=1e-6) and np.allclose(isc, g["in_scale"], rtol=1e-5)
+    return t
+
+
+def test_native_trainer_vs_frozen_reference_trainer(om):
+    run_native_trainer_vs_frozen_reference_trainer(om, EMUL_TRAINER_LIB, "cpu", 3e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_native_trainer_vs_frozen_reference_trainer(om):
+    t = run_native_trainer_vs_frozen_reference_trainer(om, None, "cuda", 3e-4)
+    assert "libdtrl.so" in open("/proc/self/maps").read() and t.mem.is_cuda
+
+
+@pytest.mark.gpu
+def test_gpu_native_trainers_vs_the_compiled_reference_trainers(om):
+    """On the GPU box the compiled reference trainers travel prebuilt (oracle/_ref/libref_learn.so): the HIP MACE trainer in lock-step with cMACETrainer itself"""
+    from oracle import reflearn
+    if not reflearn.available():
+        pytest.skip("oracle/_ref/libref_learn.so not shipped")
+    import test_reference_learn as TR
+    TR.run_reference_vs_product_mace(reflearn, om, make_native(None, "cuda", mem_size=256, num_init_samples=100, seed=21, freeze_target_iters=2), 3e-4, 2)

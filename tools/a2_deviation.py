@@ -75,6 +75,18 @@ class Stats:
     def episode_end(self):
         self._last_cycle_step = None
 
+    def raw(self):
+        return dict(steps=self.steps, cycles=list(self.cycles), speed=self.speed, duty=self.duty.tolist(), rewards=[float(x) for x in self.rewards], falls=self.falls,
+                    dists=[float(x) for x in self.dists])
+
+    @classmethod
+    def merged(cls, raws):
+        st = cls((0, 0))
+        for r in raws:
+            st.steps += r["steps"]; st.cycles += r["cycles"]; st.speed += r["speed"]; st.duty += np.array(r["duty"]); st.rewards += r["rewards"]; st.falls += r["falls"]
+            st.dists += r["dists"]
+        return st
+
     def summary(self):
         n = max(self.steps, 1)
         c = np.array(self.cycles) if self.cycles else np.zeros(1)
@@ -83,108 +95,167 @@ class Stats:
                     n_episodes=len(self.dists), reward=float(np.nanmean(self.rewards)) if self.rewards else float("nan"))
 
 
-def run(scene, integrator, seeds, frames, pols, si_opts=None, v1_overrides=None):
-    tag, arg, char, polname = scene
+_POLS = None
+
+
+def run_seed(job):
+    """One seed of one cell (a worker process of the pool): returns the raw accumulators."""
+    global _POLS
+    scene_idx, integrator, seed, frames, si_opts, v1_overrides = job
+    if _POLS is None:
+        _POLS = policies()
+    pols = _POLS
+    tag, arg, char, polname = SCENES[scene_idx]
     st = Stats(FEET[char])
-    for seed in seeds:
-        m, _ = om.build_model(arg, REF, overrides=v1_overrides or {})
-        pol = pols[polname] if polname else None
-        e = om.OracleEnv(m, terrain_seed=seed, policy=pol)
-        if pol is not None:
-            rs.nn_config(e.S if hasattr(e, "S") else len(pol[2]), len(pol[4]), raw_forward(e, pol))
-        r = rs.RefScenario("poli_eval", arg, REF, global_seed=seed + 1)
-        if pol is not None:
-            r.set_net_scale(*pol[2:])
-        r.seed_ground_and_reset(seed)
-        n_log = 0
-        if integrator == "v1":
-            ls = rs.LockStep(r, e)
-            for f in range(frames):
-                k0 = len(ls.records)
-                ls.update(); e.frame_end()
-                for o, rr in ls.records[k0:]:
-                    if rr.get("after_reset"):
-                        continue
-                    st.env_step(rr["contacts"], rr["flags"], rr["qd"][0])
-                    if rr["flags"] & 4:
-                        st.rewards.append(r.calc_reward())
-                log = r.eval_stats()["dist_log"]
-                if len(log) > n_log:
-                    st.dists += list(log[n_log:]); n_log = len(log)
-                if ls.records[-1][1].get("after_reset"):
-                    st.falls += 1; st.episode_end()
-        else:
-            r.use_bullet_si(**(si_opts or {}))
-
-            seen = [False]
-
-            def observe(dt=0, n=0):
-                # called in front of every env-step's physics (and once after Update): the state the previous env-step left behind, as in LockStep's records
-                if not seen[0]:
-                    seen[0] = True; return
-                fl = r.flags()
-                st.env_step(r.contact_flags(), fl, r.pose_vel()[1][0])
-                if fl & 4:
+    m, _ = om.build_model(arg, REF, overrides=v1_overrides or {})
+    pol = pols[polname] if polname else None
+    e = om.OracleEnv(m, terrain_seed=seed, policy=pol)
+    if pol is not None:
+        rs.nn_config(e.S if hasattr(e, "S") else len(pol[2]), len(pol[4]), raw_forward(e, pol))
+    r = rs.RefScenario("poli_eval", arg, REF, global_seed=seed + 1)
+    if pol is not None:
+        r.set_net_scale(*pol[2:])
+    r.seed_ground_and_reset(seed)
+    n_log = 0
+    if integrator == "v1":
+        ls = rs.LockStep(r, e)
+        for f in range(frames):
+            k0 = len(ls.records)
+            ls.update(); e.frame_end()
+            for o, rr in ls.records[k0:]:
+                if rr.get("after_reset"):
+                    continue
+                st.env_step(rr["contacts"], rr["flags"], rr["qd"][0])
+                if rr["flags"] & 4:
                     st.rewards.append(r.calc_reward())
-            r.set_step_hook(observe)
-            for f in range(frames):
-                t0 = r.time()
-                r.update()
-                fell = r.time() < t0 + 0.5 / 30.0      # the scenario reset inside Update (fall): its last env-step is gone
-                if not fell:
-                    observe()
-                seen[0] = False
-                log = r.eval_stats()["dist_log"]
-                if len(log) > n_log:
-                    st.dists += list(log[n_log:]); n_log = len(log)
-                if fell:
-                    st.falls += 1; st.episode_end()
-    return st.summary()
+            log = r.eval_stats()["dist_log"]
+            if len(log) > n_log:
+                st.dists += list(log[n_log:]); n_log = len(log)
+            if ls.records[-1][1].get("after_reset"):
+                st.falls += 1; st.episode_end()
+            del ls.records[:]
+    else:
+        r.use_bullet_si(**(si_opts or {}))
+
+        seen = [False]
+
+        def observe(dt=0, n=0):
+            # called in front of every env-step's physics (and once after Update): the state the previous env-step left behind, as in LockStep's records
+            if not seen[0]:
+                seen[0] = True; return
+            fl = r.flags()
+            st.env_step(r.contact_flags(), fl, r.pose_vel()[1][0])
+            if fl & 4:
+                st.rewards.append(r.calc_reward())
+        r.set_step_hook(observe)
+        for f in range(frames):
+            t0 = r.time()
+            r.update()
+            fell = r.time() < t0 + 0.5 / 30.0      # the scenario reset inside Update (fall): its last env-step is gone
+            if not fell:
+                observe()
+            seen[0] = False
+            log = r.eval_stats()["dist_log"]
+            if len(log) > n_log:
+                st.dists += list(log[n_log:]); n_log = len(log)
+            if fell:
+                st.falls += 1; st.episode_end()
+    return st.raw()
 
 
 KEYS = ("cycle_s", "speed", "falls_k", "duty_front", "duty_back", "ep_dist", "reward")
+_POOL = None
+
+
+def run(scene, integrator, seeds, frames, pols=None, si_opts=None, v1_overrides=None, jobs=1):
+    """All seeds of one cell. Returns the pooled summary plus `se`: the standard error of every statistic over the seeds (each seed an independent 300-frame
+    run; the per-seed value of a ratio statistic is that seed's own ratio) -- what the v1-vs-SI differences have to be read against."""
+    global _POOL
+    idx = SCENES.index(scene)
+    work = [(idx, integrator, sd, frames, si_opts, v1_overrides) for sd in seeds]
+    if jobs > 1:
+        if _POOL is None:
+            import multiprocessing as mp
+            _POOL = mp.get_context("fork").Pool(jobs)
+        raws = _POOL.map(run_seed, work, chunksize=1)
+    else:
+        raws = [run_seed(w) for w in work]
+    out = Stats.merged(raws).summary()
+    per = [Stats.merged([r]).summary() for r in raws]
+    out["se"] = {}
+    for k in KEYS:
+        v = np.array([p[k] for p in per], float); v = v[np.isfinite(v)]
+        out["se"][k] = float(v.std(ddof=1) / np.sqrt(len(v))) if len(v) > 1 else float("nan")
+    return out
 
 
 def fmt(s):
-    return "  ".join("%s %8.4f" % (k, s[k]) for k in KEYS) + "   (cycles %d, episodes %d, env-steps %d)" % (s["n_cycles"], s["n_episodes"], s["env_steps"])
+    return "  ".join("%s %8.4f (%.4f)" % (k, s[k], s["se"][k]) for k in KEYS) + "   (cycles %d, episodes %d, env-steps %d)" % (s["n_cycles"], s["n_episodes"], s["env_steps"])
+
+
+def rel_line(a, b):
+    """(a - b) / b per statistic, and z = the difference in units of its standard error over seeds"""
+    parts = []
+    for k in KEYS:
+        if b[k] and np.isfinite(b[k]) and np.isfinite(a[k]):
+            se = np.hypot(a["se"][k], b["se"][k])
+            parts.append("%s %+6.1f%% (%+.1f s.e.)" % (k, 100.0 * (a[k] - b[k]) / b[k], (a[k] - b[k]) / se if se > 0 else float("nan")))
+        else:
+            parts.append("%s     n/a" % k)
+    return "  ".join(parts)
+
+
+SI_ABLATIONS = (("no margin", dict(use_margin=0)), ("no warm start", dict(warmstarting=0)), ("no split impulse", dict(split_impulse=0)),
+                ("no link contacts", dict(link_contacts=0)), ("1 point per pair", dict(max_points=1)), ("erp 0.8 joints", dict(erp=0.8)), ("20 iterations", dict(iterations=20)),
+                ("round-3 comparator: margin 0.04 + breaking 0.02 on every box", dict(safe_margin=0, relative_breaking=0)))
+V1_ABLATIONS = (("warm start 0.85 (oracle-only switch)", dict(warm_start=1)), ("sharp boxes (-collision_margin= 0)", dict(collision_margin=0)),
+                ("round-3 model: 0.04 / world_scale on every link (-safe_margin= 0)", dict(safe_margin=0)), ("no link contacts", dict(link_contacts=0)))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=6)
+    ap.add_argument("--seed0", type=int, default=101)
     ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--jobs", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--out", default="")
-    ap.add_argument("--ablate", action="store_true")
+    ap.add_argument("--ablate", action="store_true", help="SI with one Bullet feature removed at a time")
+    ap.add_argument("--v1-ablate", action="store_true", help="Integrator v1 with one modelling switch changed at a time")
+    ap.add_argument("--null", action="store_true", help="also run SI on a DISJOINT seed set: the SI-vs-SI line is what sampling alone produces")
     ap.add_argument("--scenes", default="", help="comma-separated scene indices (default: all)")
-    ap.add_argument("--v1-warm-start", action="store_true", help="also run Integrator v1 with the oracle-only warm-start experiment switch (-warm_start= 1)")
     a = ap.parse_args()
     assert rs.available(), "oracle/_ref/libref_sim.so missing: make -C oracle/_ref_build"
-    pols = policies()
-    seeds = list(range(101, 101 + a.seeds))
+    seeds = list(range(a.seed0, a.seed0 + a.seeds))
     scenes = [SCENES[int(i)] for i in a.scenes.split(",")] if a.scenes else SCENES
     lines = ["# Integrator v1 (product model) vs Bullet-shaped sequential impulse (oracle/or_bullet_si.h), both driven by the REFERENCE'S OWN controllers",
-             "# %d seeds x %d outer frames (%d env-steps) per cell; tools/a2_deviation.py" % (a.seeds, a.frames, a.seeds * a.frames * 20)]
+             "# %d seeds x %d outer frames (%d env-steps) per cell; value (standard error over seeds); rel = (v1 - SI) / SI with the difference in standard errors; tools/a2_deviation.py"
+             % (a.seeds, a.frames, a.seeds * a.frames * 20)]
     results = {}
     for sc in scenes:
-        t0 = time.time()
-        v1 = run(sc, "v1", seeds, a.frames, pols)
-        si = run(sc, "si", seeds, a.frames, pols)
+        t0 = time.time(); n0 = len(lines)
+        v1 = run(sc, "v1", seeds, a.frames, jobs=a.jobs)
+        si = run(sc, "si", seeds, a.frames, jobs=a.jobs)
         results[sc[0]] = {"v1": v1, "si": si}
         lines.append("\n## %s" % sc[0])
         lines.append("  v1   " + fmt(v1))
         lines.append("  SI   " + fmt(si))
-        lines.append("  rel  " + "  ".join("%s %+7.1f%%" % (k, 100.0 * (v1[k] - si[k]) / si[k]) if si[k] and np.isfinite(si[k]) and np.isfinite(v1[k]) else "%s     n/a" % k for k in KEYS))
-        if a.v1_warm_start:
-            ws = run(sc, "v1", seeds, a.frames, pols, v1_overrides={"warm_start": 1})
-            results[sc[0]]["v1, warm start"] = ws
-            lines.append("  v1 + warm start (oracle-only experiment)  " + fmt(ws))
+        lines.append("  rel  " + rel_line(v1, si))
+        if a.null:
+            si2 = run(sc, "si", [sd + 1000 for sd in seeds], a.frames, jobs=a.jobs)
+            results[sc[0]]["si, disjoint seeds"] = si2
+            lines.append("  SI, disjoint seeds   " + fmt(si2))
+            lines.append("  null (SI' - SI) / SI " + rel_line(si2, si))
+        if a.v1_ablate:
+            for name, ov in V1_ABLATIONS:
+                ab = run(sc, "v1", seeds, a.frames, v1_overrides=ov, jobs=a.jobs)
+                results[sc[0]]["v1, " + name] = ab
+                lines.append("  v1, %s\n       %s\n       vs SI: %s" % (name, fmt(ab), rel_line(ab, si)))
         if a.ablate:
-            for name, opts in (("no margin", dict(use_margin=0)), ("no warm start", dict(warmstarting=0)), ("no split impulse", dict(split_impulse=0)),
-                               ("no link contacts", dict(link_contacts=0)), ("1 point per pair", dict(max_points=1)), ("erp 0.8 joints", dict(erp=0.8)), ("20 iterations", dict(iterations=20))):
-                ab = run(sc, "si", seeds, a.frames, pols, si_opts=opts)
+            for name, opts in SI_ABLATIONS:
+                ab = run(sc, "si", seeds, a.frames, si_opts=opts, jobs=a.jobs)
                 results[sc[0]]["si, " + name] = ab
-                lines.append("  SI, %-17s " % name + fmt(ab))
-        print("\n".join(lines[-(3 + (7 if a.ablate else 0)) - 1:]), "[%.0f s]" % (time.time() - t0), flush=True)
+                lines.append("  SI, %s\n       %s\n       v1 vs this: %s" % (name, fmt(ab), rel_line(v1, ab)))
+        print("\n".join(lines[n0:]), "[%.0f s]" % (time.time() - t0), flush=True)
     text = "\n".join(lines) + "\n"
     if a.out:
         open(a.out, "w").write(text)
