@@ -105,11 +105,16 @@ def cpu_baseline(cfg, frames=60):
     n_envs = cores * envs_per_thread
     t0 = time.time()
     rate, resets, cycles = om.batch_run(m, n_envs, cores, frames, terrain_seed0=0, rng_seed=0, policy=(desc, w, io, isc, oo, osc))
+    wall = time.time() - t0
+    # the single-thread figure beside the all-cores one (one thread, 8 envs, the same frames)
+    t1 = time.time()
+    rate1, _, _ = om.batch_run(m, envs_per_thread, 1, frames, terrain_seed0=0, rng_seed=0, policy=(desc, w, io, isc, oo, osc))
     return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs (%d per thread) x %d frames x 20 env-steps of the same workload on the fp64 oracle restatement (not Bullet), %.1f s wall" % (n_envs, envs_per_thread, frames, time.time() - t0)}
+            "sample": "%d envs (%d per thread) x %d frames x 20 env-steps of the same workload on the fp64 oracle restatement (not Bullet), %.1f s wall" % (n_envs, envs_per_thread, frames, wall),
+            "single_thread": {"value": rate1, "unit": "env-steps/s", "cores": 1, "sample": "%d envs x %d frames x 20 env-steps on one thread, %.1f s wall" % (envs_per_thread, frames, time.time() - t1)}}
 
 
-def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bcast_every, w, scale, reserve_cus):
+def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bcast_every, w, scale, reserve_cus, force_collectives=None):
     """BASELINE configs[3] at this world size: exploration rollouts + the two exchange steps, overlapped with stepping."""
     from deepterrainrl_amd.sharding import ShardedRollout
     dev = torch.device("cuda", local_rank)
@@ -122,7 +127,7 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
                              extra_args={"terrain_seed": 20260925, "rand_seed": 1, "global_env_offset": off})
         return b
     try:
-        sr = ShardedRollout(make, n * world, dist=dist, device=dev, pipelined=True)   # dist is None on a plain 1-GPU run (no collective), a process group otherwise
+        sr = ShardedRollout(make, n * world, dist=dist, device=dev, pipelined=True, force_collectives=force_collectives)   # dist None: no collective (the alternative leg of a 1-GPU run)
     finally:
         if reserve_cus is not None:
             if prev is None:
@@ -199,7 +204,7 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
            "collective_bytes_per_frame": {"sent_per_rank": sr.block_bytes if sr.coll else 0, "received_by_rank0": sr.block_bytes * (world if sr.coll else 0)},
            "carried_rows": sr.carried_rows, "policy_bytes": int(sr.pol_bytes), "reserve_cus_per_xcd": int(reserve_cus or 0),
            "bcast_every": bcast_every, "dropped_tuples": b.TupleStats()["dropped"] - drop0, "kernel_avg_ms": kern_ms,
-           "collective": ("gather to rank 0 (RCCL)" + ("" if world > 1 else " on a one-rank group (DTRL_FORCE_COLLECTIVES)")) if sr.coll else "none (1 rank: device drain + replay append only)"}
+           "collective": ("gather to rank 0 (RCCL)" + ("" if world > 1 else " on a one-rank group")) if sr.coll else "none (1 rank: device drain + replay append only)"}
     b.close()
     return res
 
@@ -230,6 +235,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=60, help="outer frames of the bounded CPU-baseline sample (default: 20-30 s of CPU work on the box's 256 threads)")
     ap.add_argument("--exchange-steps", type=int, default=-1, help="timed frames of the exchange leg (default: half of --steps, at least 50; 0 = skip)")
     ap.add_argument("--bcast-every", type=int, default=10, help="exchange leg: policy broadcast every K frames")
+    ap.add_argument("--no-rccl-leg", action="store_true", help="1-GPU run: do not open a one-rank RCCL group for the exchange leg (the leg then runs without any collective)")
     ap.add_argument("--dry-launch", action="store_true", help="every rank prints its placement (rank, local rank, world, global env offset, host threads) as one JSON line and exits: checks the launch path without a GPU")
     a = ap.parse_args()
 
@@ -336,6 +342,11 @@ def main():
             if rec:
                 traffic = rec.get("hbm_bytes_per_launch"); valu_insts = rec.get("sq_insts_valu_per_launch")
                 traffic_source = "profiles/hbm_traffic_config%d.json <- profiles/%s (rocprofv3 --pmc passes of this command at the same batch size; NOT counters of this run)" % (a.config, rec.get("source"))
+        meas_ghz = lanes = None
+        cj = os.path.join(REPO, "profiles", "shader_clock_config%d.json" % a.config)
+        if os.path.exists(cj):
+            crec = json.load(open(cj))
+            meas_ghz = crec.get("shader_clock_ghz"); lanes = crec.get("active_lanes_per_valu_instruction")
         resets = stats1["resets"] - stats0["resets"]; cycles = stats1["cycles"] - stats0["cycles"]
         rccl = None
         if dist is not None:
@@ -367,7 +378,12 @@ def main():
                                       "sq_insts_valu_per_launch": valu_insts, "per_env_step_per_wave": valu_insts / env_steps_per_launch,
                                       "issue_utilisation_per_launch": valu_insts * VALU_CYCLES / (kern_ms * 1e-3 * CLOCK_GHZ * 1e9 * SIMDS),
                                       "issue_utilisation_wall": valu_insts * VALU_CYCLES * launches / (wall * CLOCK_GHZ * 1e9 * SIMDS),
-                                      "assumes": "%d cycles per wave64 VALU instruction on a SIMD16, %d SIMDs, %.1f GHz; counter from the committed PMC pass" % (VALU_CYCLES, SIMDS, CLOCK_GHZ)}}},
+                                      "assumes": "%d cycles per wave64 VALU instruction on a SIMD16, %d SIMDs, %.1f GHz; counter from the committed PMC pass" % (VALU_CYCLES, SIMDS, CLOCK_GHZ),
+                                      # the clock the part actually ran at in the committed counter pass (GRBM_GUI_ACTIVE / 8 XCDs / kernel duration) and the two figures on it
+                                      "measured_clock_ghz": meas_ghz,
+                                      "issue_utilisation_per_launch_at_measured_clock": None if not meas_ghz else valu_insts * VALU_CYCLES / (kern_ms * 1e-3 * meas_ghz * 1e9 * SIMDS),
+                                      "issue_utilisation_wall_at_measured_clock": None if not meas_ghz else valu_insts * VALU_CYCLES * launches / (wall * meas_ghz * 1e9 * SIMDS),
+                                      "active_lanes_per_valu_instruction": lanes}}},
             "substeps_per_sec": value * 5, "stats": stats1,
             "timed_window": {"frames": frames_timed, "resets": resets, "cycles": cycles, "seconds": wall,
                              "resets_per_frame": resets / float(frames_timed), "preroll_resets_per_frame": rates,
@@ -389,10 +405,28 @@ def main():
                 os._exit(0)
             guard = threading.Timer(EXCHANGE_GUARD_S, give_up); guard.daemon = True; guard.start()
         # multi-rank: the collective's kernels need wavefront slots while a frame kernel holds every CU for milliseconds -> one CU per XCD kept free; and the plain setting beside it
+        # a plain 1-GPU run (the driver's BENCH line): the headline above ran WITHOUT a process group; the exchange leg now gets a one-rank RCCL group of its
+        # own, so that the record exercises the collective code path (gather + broadcast through RCCL) -- the no-group figure stays beside it as exchange_alt
+        leg_dist, leg_force = dist, None
         plan = [1, 0] if (dist is not None) else [None]
+        if dist is None and world == 1 and not a.no_rccl_leg:
+            try:
+                import datetime
+                import socket
+                import torch.distributed as tdist
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+                tdist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", local_rank),
+                                         timeout=datetime.timedelta(seconds=EXCHANGE_GUARD_S + 60))
+                leg_dist, leg_force, plan = tdist, True, [1, None]
+                line["rccl"] = {"ranks": 1, "version": ".".join(str(x) for x in torch.cuda.nccl.version()), "backend": tdist.get_backend(), "scope": "exchange leg only (the headline ran without a process group)"}
+            except Exception as exc:
+                line["rccl"] = {"ranks": 1, "error": "one-rank group for the exchange leg: %r" % (exc,)}
         for reserve in plan:
             try:
-                legs.append(exchange_leg(da, dist, torch, world, rank, local_rank, n, ex_steps, max(a.warmup // 2, 30), a.bcast_every, w, scale, reserve))   # >= 30 untimed frames: the first tuples complete after two gait cycles (~25 frames)
+                one_rank_alt = leg_force and reserve is None            # second leg of the plain 1-GPU run: no group, no reservation (round 3's figure)
+                legs.append(exchange_leg(da, None if one_rank_alt else leg_dist, torch, world, rank, local_rank, n, ex_steps, max(a.warmup // 2, 30), a.bcast_every, w, scale, reserve,
+                                         force_collectives=None if one_rank_alt else leg_force))   # >= 30 untimed frames: the first tuples complete after two gait cycles (~25 frames)
             except Exception as exc:   # the headline measurement above stands on its own: report the failure instead of losing the line
                 legs.append({"error": repr(exc), "reserve_cus_per_xcd": reserve})
         if guard is not None:
@@ -412,6 +446,13 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    else:
+        try:
+            import torch.distributed as tdist
+            if tdist.is_initialized():
+                tdist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

@@ -565,7 +565,7 @@ __device__ __forceinline__ real wave_shr1(real v)
 	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
 	return __hiloint2double(hi, lo);
 }
-constexpr int kPgsRegRows = 12;
+template <int kPgsRegRows>
 __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 {
 	const int lane = opaque_lane();
@@ -579,9 +579,9 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 	const int tri = lane * (lane + 1) / 2;
 	const real inf = __builtin_huge_val();
 	if (R <= kPgsRegRows) {
-		// up to twelve rows (99 % of the substeps with contacts; eight until round 3 -- with the collision margin 11 % of the substeps carry 7-12 rows:
-		// 15.7 -> 15.9 M env-steps/s): the lane's Delassus row lives in registers for all sweeps, no LDS read and
-		// no packed-index arithmetic per row update. Same operations on the same values as the general loop below
+		// up to kPgsRegRows rows (per skeleton, dtrl_topo.h; eight until round 3, twelve until round 4): the lane's Delassus row lives in registers for all
+		// sweeps, no LDS read and no packed-index arithmetic per row update. Same operations on the same values as the general loop below. The rare
+		// substeps with many rows matter out of proportion: they are what the slowest envs of a launch do in EVERY substep (a character lying on the ground)
 		real a[kPgsRegRows];
 #pragma unroll
 		for (int r = 0; r < kPgsRegRows; ++r) { const int mx = lane > r ? lane : r, mn = lane < r ? lane : r; a[r] = ws.Apk[(mine && r < R) ? mx * (mx + 1) / 2 + mn : 0]; }
@@ -697,7 +697,7 @@ struct FastPath {
 		}
 		if (R > 0) {
 			{ PROF_T0(); build_delassus_fast<D>(ws, h, dinv); PROF_ADD(ws, kProfDelassus); }
-			{ PROF_T0(); pgs_solve_fast(ws); PROF_ADD(ws, kProfPgs); }
+			{ PROF_T0(); pgs_solve_fast<Topo::kPgsRegRows>(ws); PROF_ADD(ws, kProfPgs); }
 		}
 		{
 			PROF_T0();

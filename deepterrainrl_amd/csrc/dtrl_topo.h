@@ -11,11 +11,16 @@ namespace dtrl {
 struct TopoDog {
 	static constexpr int kId = 1;
 	static constexpr int L = 21;
+	// constraint rows the projected Gauss-Seidel keeps in registers (dtrl_kernel_fast.h pgs_solve_fast). A launch lasts as long as its slowest env, and the slowest
+	// envs of a frame are characters lying on 13-24 rows per substep: with every row count on the register path the dog's 2048-env launch went 4.71 -> 4.45 ms
+	// (16.7 -> 17.8 M env-steps/s, same box, profiles/r04_pgs_rows_ab.txt)
+	static constexpr int kPgsRegRows = 24;
 	static constexpr int parent(int l) { constexpr int p[L] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 0, 9, 10, 11, 5, 13, 14, 15, 0, 17, 18, 19}; return p[l]; }
 };
 struct TopoRaptor {
 	static constexpr int kId = 2;
 	static constexpr int L = 19;
+	static constexpr int kPgsRegRows = 12;   // (the raptor's kernel instance spills with more: 18.4 M at 12, 18.1 M at 18, 17.2 M at 24)
 	static constexpr int parent(int l) { constexpr int p[L] = {-1, 0, 1, 2, 3, 4, 0, 6, 7, 8, 9, 0, 11, 12, 13, 0, 15, 16, 17}; return p[l]; }
 };
 

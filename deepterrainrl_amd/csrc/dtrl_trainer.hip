@@ -171,10 +171,11 @@ struct HipTrainerBE {
 		chk(hipStreamWaitEvent(stream, ev_join_, 0), "join wait");
 	}
 	hipStream_t side_ = nullptr, main_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr; bool forked_ = false;
+	void drop_graphs() { for (hipGraphExec_t& e : exec_) if (e) { hipGraphExecDestroy(e); e = nullptr; } }   // recorded launches carry pointers by value: re-record
 	void set_stream(void* s)
 	{
 		if (static_cast<hipStream_t>(s) == stream) return;
-		for (hipGraphExec_t& e : exec_) if (e) { hipGraphExecDestroy(e); e = nullptr; }   // recorded on the old stream's behalf: re-record
+		drop_graphs();   // recorded on the old stream's behalf
 		stream = static_cast<hipStream_t>(s);
 	}
 	void* alloc_dev(size_t bytes) { void* p = nullptr; if (!chk(hipMalloc(&p, bytes), "hipMalloc")) return nullptr; chk(hipMemset(p, 0, bytes), "hipMemset"); return p; }

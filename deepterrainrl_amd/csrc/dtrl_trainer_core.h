@@ -105,6 +105,36 @@ struct FSgdConv { const NetDims* d; const Work* wk; int64_t conv_end; float* w; 
 		sgd_elem(w, hist, g, rate_mult, decay_mult, rate, momentum, weight_decay, i);
 	} };
 
+// the same reduction WITHOUT the update (data-parallel step: the flat gradient leaves the trainer for an all-reduce): g[i] for the conv range, and the sample
+// count the gradient was averaged over in the slot behind the last parameter
+struct FConvReduce { const NetDims* d; const Work* wk; int64_t conv_end; float* g; int64_t num_params; float count;
+	TR_HD void operator()(int64_t i) const
+	{
+		if (i == conv_end) { g[num_params] = count; return; }
+		const NetDims& D = *d;
+		int l = 0; while (l < 2 && i >= D.wo_conv[l + 1]) ++l;
+		const int Kc = D.C[l] * D.Kw[l], N = Kc + 1, M = D.C[l + 1];
+		int m, n;
+		if (i >= D.bo_conv[l]) { m = static_cast<int>(i - D.bo_conv[l]); n = Kc; } else { const int64_t o = i - D.wo_conv[l]; m = static_cast<int>(o / Kc); n = static_cast<int>(o % Kc); }
+		float s = 0;
+		for (int z = 0; z < wk->rows; ++z) s += wk->pw[l][(static_cast<size_t>(z) * M + m) * N + n];
+		g[i] = s;
+	} };
+// Caffe SGD step on a gradient that was SUMMED over ranks (all-reduce): g[num_params] = total number of samples behind it; every rank's share was the mean over
+// its own `batch` rows, so the mean over all samples is g[i] * batch / g[num_params]. No samples anywhere (count 0): no update, the history stays
+struct FSgdScaled { float* w; float* hist; const float* g; const float* rate_mult; const float* decay_mult; float rate, momentum, weight_decay; int64_t num_params; float batch; float* count_out;
+	TR_HD void operator()(int64_t i) const
+	{
+		const float count = g[num_params];
+		if (i == 0 && count_out) *count_out = count;
+		if (!(count > 0)) return;
+		const float gi = g[i] * (batch / count);
+		const float diff = gi + weight_decay * decay_mult[i] * w[i];
+		const float hv = momentum * hist[i] + rate * rate_mult[i] * diff;
+		hist[i] = hv; w[i] = w[i] - hv;
+	} };
+struct FZero { float* p; TR_HD void operator()(int64_t i) const { p[i] = 0.0f; } };
+
 // staged rows -> replay slots: element i = (row i / W, column i % W) of the page-locked staging area goes to slot (head + row) % mem_size; the flag word with column 0
 struct FAddStaged { const float* src; const int64_t* src_flags; float* mem; int64_t* flags; int W; int64_t head, mem_size;
 	TR_HD void operator()(int64_t i) const
@@ -137,7 +167,7 @@ public:
 		if (!be.init(err)) return false;
 		const NetDims& d = cfg.dims;
 		const size_t P = static_cast<size_t>(d.num_params);
-		w_cur = F(P); w_tgt = F(P); hist = F(P); grad = F(P); rate_mult = F(P); decay_mult = F(P);
+		w_cur = F(P); w_tgt = F(P); hist = F(P); grad = F(P + 1); grad_own = grad; rate_mult = F(P); decay_mult = F(P);   // (grad[P]: sample count of the data-parallel step)
 		in_off = F(d.S); in_scale = F(d.S); out_off = F(d.out_size); out_scale = F(d.out_size);
 		MakeWork(train, cfg.batch, true);
 		MakeWork(eval, cfg.max_eval, false);
@@ -179,6 +209,19 @@ public:
 	// gradient of the current net on the rows of `train` (dout filled), then the Caffe SGD update
 	void BackwardAndUpdate()
 	{
+		Backward();
+		const NetDims& d = cfg.dims;
+		be.for_each(d.num_params, FSgdConv{d_dims, d_train, d.wo_terr, w_cur, hist, grad, rate_mult, decay_mult, cfg.base_lr, cfg.momentum, cfg.weight_decay});
+	}
+	// the data-parallel form: the flat gradient (conv partials reduced, sample count behind it) is left in `grad` for the caller's all-reduce; ApplyGrad updates
+	void BackwardOnly()
+	{
+		Backward();
+		const NetDims& d = cfg.dims;
+		be.for_each(d.wo_terr + 1, FConvReduce{d_dims, d_train, d.wo_terr, grad, d.num_params, static_cast<float>(cfg.batch)});
+	}
+	void Backward()
+	{
 		const NetDims& d = cfg.dims;
 		const Work* wk = d_train;
 		const int rows = cfg.batch;
@@ -192,7 +235,6 @@ public:
 			GemmDesc g = make_gemm(d, rows, kConvBw, l); g.b_kfast = 1;
 			if (l > 0) be.gemm2(d_dims, wk, g, make_gemm(d, rows, kConvBx, l)); else be.gemm(d_dims, wk, g);
 		}
-		be.for_each(d.num_params, FSgdConv{d_dims, wk, d.wo_terr, w_cur, hist, grad, rate_mult, decay_mult, cfg.base_lr, cfg.momentum, cfg.weight_decay});
 	}
 
 	// ---- API ----
@@ -305,10 +347,62 @@ public:
 	}
 	void UpdateTarget() { be.d2d(w_tgt, w_cur, sizeof(float) * cfg.dims.num_params); }
 
+	// ---- data-parallel step (SURVEY 5 last row; learning/ParamServer.cpp:65-90 is what it stands in for): gradient here, all-reduce at the caller, update here ----
+	// The gradient buffer [num_params + 1] may be the caller's (device memory it can hand to a collective): BindGrad; nullptr = the trainer's own again
+	void BindGrad(float* g) { grad = g ? g : grad_own; train.g = grad; be.h2d(d_train, &train, sizeof(Work)); be.drop_graphs(); }   // (the recorded update launches carry the old pointer)
+	bool GradStep(const float* X, const float* Y)
+	{
+		const NetDims& d = cfg.dims;
+		const int n = cfg.batch;
+		be.for_each(static_cast<int64_t>(n) * d.S, FNormIn{d.S, norm(), X, train.xin});
+		Forward(d_train, n);
+		be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 0, Y, nullptr, 0, d.S, nullptr, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host);
+		BackwardOnly();
+		return be.ok();
+	}
+	// cMACETrainer's critic batch idx_host[0 .. batch): everything of CriticStep but the update
+	bool CriticGrad()
+	{
+		if (!mem_ || cfg.n_frags <= 0) return false;
+		const NetDims& d = cfg.dims;
+		const int n = cfg.batch, S = d.S, A = 1 + cfg.frag_size;
+		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1 + S + A, eval.xin});
+		Forward(cfg_target_frozen ? d_eval_tgt : d_eval_cur, n);
+		be.for_each(n, FNewQ{norm(), mem_, W_, idx_host, flags_, eval.out, d.out_size, cfg.n_frags, cfg.discount, newq});
+		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1, train.xin});
+		Forward(d_train, n);
+		be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host);
+		BackwardOnly();
+		return be.ok();
+	}
+	// the actor batch idx_host[max_eval .. max_eval + batch): everything of ActorStep but the update
+	bool ActorGrad()
+	{
+		if (!mem_ || cfg.n_frags <= 0) return false;
+		const NetDims& d = cfg.dims;
+		const int n = cfg.batch, S = d.S;
+		const int64_t* idx = idx_host + cfg.max_eval;
+		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx, 1, train.xin});
+		Forward(d_train, n);
+		be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 2, nullptr, mem_, W_, S, idx, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host + 1);
+		BackwardOnly();
+		return be.ok();
+	}
+	// a rank without a batch this round contributes nothing: gradient and count zero
+	bool ZeroGrad() { be.for_each(cfg.dims.num_params + 1, FZero{grad}); return be.ok(); }
+	// the update from the (all-reduced) gradient; the total sample count lands in loss_host[slot] (2: critic round, 3: actor round; valid after Sync)
+	bool ApplyGrad(int slot)
+	{
+		if (slot < 2 || slot > 3) return false;
+		const NetDims& d = cfg.dims;
+		be.for_each(d.num_params, FSgdScaled{w_cur, hist, grad, rate_mult, decay_mult, cfg.base_lr, cfg.momentum, cfg.weight_decay, d.num_params, static_cast<float>(cfg.batch), loss_host + slot});
+		return be.ok();
+	}
+
 	TrainerConfig cfg;
 	bool cfg_target_frozen = false;   // cMACETrainer::EnableTargetNet(): freeze_target_iters > 0, else the "target" is the current net
 	BE be;
-	float *w_cur = nullptr, *w_tgt = nullptr, *hist = nullptr, *grad = nullptr, *rate_mult = nullptr, *decay_mult = nullptr;
+	float *w_cur = nullptr, *w_tgt = nullptr, *hist = nullptr, *grad = nullptr, *grad_own = nullptr, *rate_mult = nullptr, *decay_mult = nullptr;
 	float *in_off = nullptr, *in_scale = nullptr, *out_off = nullptr, *out_scale = nullptr, *newq = nullptr, *sq = nullptr;
 	Work train{}, eval{};                 // host copies (pointers into device memory)
 	NetDims* d_dims = nullptr; Work* d_train = nullptr; Work* d_eval_cur = nullptr; Work* d_eval_tgt = nullptr;   // device-resident descriptors

@@ -28,6 +28,7 @@ TRAINER_ABI_SYMBOLS = [
     "dtrl_trainer_eval", "dtrl_trainer_step", "dtrl_trainer_bind_replay", "dtrl_trainer_idx", "dtrl_trainer_better", "dtrl_trainer_loss",
     "dtrl_trainer_critic_step", "dtrl_trainer_actor_filter", "dtrl_trainer_actor_step", "dtrl_trainer_debug_get", "dtrl_trainer_critic_step_and_filter",
     "dtrl_trainer_stage_rows", "dtrl_trainer_stage_flags", "dtrl_trainer_stage_capacity", "dtrl_trainer_add_staged",
+    "dtrl_trainer_bind_grad", "dtrl_trainer_grad_device", "dtrl_trainer_grad_step", "dtrl_trainer_critic_grad", "dtrl_trainer_actor_grad", "dtrl_trainer_zero_grad", "dtrl_trainer_apply_grad",
 ]
 
 
@@ -68,6 +69,12 @@ def _bind(path):
     L.dtrl_trainer_critic_step_and_filter.argtypes = [vp]
     L.dtrl_trainer_actor_filter.argtypes = [vp, C.c_int]
     L.dtrl_trainer_actor_step.argtypes = [vp]
+    L.dtrl_trainer_bind_grad.argtypes = [vp, vp]
+    L.dtrl_trainer_grad_device.argtypes = [vp, C.POINTER(vp)]
+    L.dtrl_trainer_grad_step.argtypes = [vp, vp, vp]
+    for name in ("critic_grad", "actor_grad", "zero_grad"):
+        getattr(L, "dtrl_trainer_" + name).argtypes = [vp]
+    L.dtrl_trainer_apply_grad.argtypes = [vp, C.c_int]
     return L
 
 
@@ -161,6 +168,15 @@ class NativeTrainer:
     def critic_step_and_filter(self): self._chk(self._lib.dtrl_trainer_critic_step_and_filter(self._h))
     def actor_filter(self, n): self._chk(self._lib.dtrl_trainer_actor_filter(self._h, n))
     def actor_step(self): self._chk(self._lib.dtrl_trainer_actor_step(self._h))
+    # data-parallel step (include/dtrl_trainer.h): gradient only / update from the all-reduced gradient
+    def bind_grad(self, ptr): self._chk(self._lib.dtrl_trainer_bind_grad(self._h, C.c_void_p(ptr) if ptr else None))
+    def grad_device(self):
+        p = C.c_void_p(); self._chk(self._lib.dtrl_trainer_grad_device(self._h, C.byref(p))); return p.value
+    def grad_step(self, x_ptr, y_ptr): self._chk(self._lib.dtrl_trainer_grad_step(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
+    def critic_grad(self): self._chk(self._lib.dtrl_trainer_critic_grad(self._h))
+    def actor_grad(self): self._chk(self._lib.dtrl_trainer_actor_grad(self._h))
+    def zero_grad(self): self._chk(self._lib.dtrl_trainer_zero_grad(self._h))
+    def apply_grad(self, slot): self._chk(self._lib.dtrl_trainer_apply_grad(self._h, int(slot)))
 
 
 class _HipNetSide:
@@ -389,6 +405,131 @@ class HipMACETrainer(_HipNetSide, MACETrainer):
             self.solver_iter += 1
             self.actor_iter += 1
             del self.actor_batch_buffer[:self.batch]
+
+
+class HipMACETrainerDP(HipMACETrainer):
+    """cMACETrainer stepped DATA-PARALLEL across the ranks of a process group (last row; the in-scope form of BASELINE configs[3] / [4]): every rank keeps
+    the tuples of ITS OWN env shard in its own replay memory and runs the native forward / backward on minibatches drawn from it; per Train() the ranks all-reduce
+    (sum) the flat gradient twice -- once for the critic round, once for the actor round -- on the trainer's stream (RCCL; 570 474 + 1 floats = 2.28 MB) and apply
+    the identical Caffe SGD update, so the weights stay equal on all ranks with no tuple gather and no weight broadcast. What the reference does for trainer fan-in is a
+    pool of learners pushing gradients to a parameter server asynchronously (learning/AsyncMACETrainer.cpp:14-45, learning/ParamServer.cpp:65-90); this is its
+    synchronous counterpart.
+      * a rank whose critic buffer cannot fill a batch yet (or that holds no full actor batch) contributes a zero gradient with sample count 0: the update divides by
+        the total count, so the step is the mean over the samples that exist; a round in which NO rank has a batch changes nothing;
+      * ONE actor round per Train() (the reference loops while full batches remain, learning/MACETrainer.cpp:611-626; here a second full batch waits for the next call):
+        every rank must issue the same sequence of collectives;
+      * the stage switch happens when EVERY rank has its trainer_num_init_samples (all-reduce MIN of a flag), and the input normaliser of the switch is computed from
+        the pooled sums of all ranks' begin states (all-reduce of [n, sum x, sum x^2] in float64): cNeuralNet::CalcOffsetScale over the union of the replay memories;
+      * iteration counters, target refreshes and the exploration anneal follow the agreed counts and therefore coincide on all ranks.
+    `dist`: torch.distributed (initialised); with a one-rank group the trainer equals HipMACETrainer's unfused path step for step (tested)."""
+
+    def __init__(self, *a, dist=None, **kw):
+        super().__init__(*a, **kw)
+        self.dist = dist
+        P = self.nt.num_params
+        if self.device.type == "cuda":
+            self.grad = torch.zeros(P + 1, dtype=torch.float32, device=self.device)
+            self.nt.bind_grad(self.grad.data_ptr())
+        else:
+            g = (C.c_float * (P + 1)).from_address(self.nt.grad_device())
+            self.grad = torch.from_numpy(np.ctypeslib.as_array(g))
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.collective_s = 0.0
+
+    def _allreduce_grad(self):
+        if self.dist is None or self.world == 1 and not getattr(self, "force_collectives", False):
+            return
+        if self._stream is not None:
+            with torch.cuda.stream(self._stream):     # behind the gradient kernels on the trainer's stream; the update queued next follows the collective
+                self.dist.all_reduce(self.grad)
+        else:
+            self.dist.all_reduce(self.grad)
+
+    def _agree(self, value, op):
+        if self.dist is None or self.world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.int64, device=self.device if self.device.type == "cuda" else "cpu")
+        self.dist.all_reduce(t, op=op)
+        return int(t.item())
+
+    def UpdateOffsetScale(self):
+        if self.dist is None or self.world == 1:
+            return super().UpdateOffsetScale()
+        self._order_staged()
+        X = self.mem[:self.num_tuples, 1:1 + self.S].to(torch.float64)
+        pooled = torch.cat([torch.tensor([float(X.shape[0])], dtype=torch.float64, device=X.device), X.sum(0), (X * X).sum(0)])
+        if self.dist is not None and self.world > 1:
+            self.dist.all_reduce(pooled)
+        n = pooled[0]; mean = pooled[1:1 + self.S] / n
+        var = (pooled[1 + self.S:] / n - mean * mean).clamp_min(0.0)
+        std = var.sqrt()
+        self.SetInputOffsetScale(-mean, torch.where(std == 0, torch.zeros_like(std), 1.0 / std))
+
+    def Train(self):
+        if not self.stage_train:
+            ready = int(self.num_tuples >= self.num_init_samples and self.num_tuples > 0)
+            if self.dist is not None and self.world > 1:
+                ready = self._agree(ready, self.dist.ReduceOp.MIN)       # the switch (and its pooled normaliser) happens on all ranks in the same call
+            if ready:
+                if self.num_init_samples > 1 and self.init_input_offset_scale:
+                    self.UpdateOffsetScale()
+                self.stage_train = True
+        if self.stage_train:
+            succ = False
+            for _ in range(self.steps_per_iter):
+                succ = self.Step()
+            if succ:
+                self.iter += 1
+
+    def Step(self):
+        if getattr(self, "_replay_dirty", False):
+            self._after_torch(); self._replay_dirty = False
+        B = self.batch
+        ids = self.FetchMinibatch(B)
+        if len(ids) >= B:
+            self.nt.idx[:B] = ids
+            self.nt.critic_grad()
+        else:
+            self.nt.zero_grad()
+        self._allreduce_grad()
+        self.nt.apply_grad(2)
+        # the candidates' test runs against the target net (frozen: unchanged by the update above; not frozen: the updated net, as cMACETrainer::Step orders it)
+        self.UpdateActorBatchBuffer()                      # one host wait: the mask (and with it the critic round's sample count)
+        n_critic = float(self.nt.loss[2])
+        if len(ids) >= B:
+            self._last_loss = float(self.nt.loss[0])
+        if n_critic > 0:
+            self.solver_iter += 1
+        if len(self.actor_batch_buffer) >= B:
+            self.nt.idx[self.nt.max_eval:self.nt.max_eval + B] = self.actor_batch_buffer[:B]
+            self.nt.actor_grad()
+            del self.actor_batch_buffer[:B]
+            had_actor = True
+        else:
+            self.nt.zero_grad()
+            had_actor = False
+        self._allreduce_grad()
+        self.nt.apply_grad(3)
+        self.nt.sync()
+        if had_actor:
+            self._last_actor_loss = float(self.nt.loss[1])
+        if float(self.nt.loss[3]) > 0:
+            self.solver_iter += 1; self.actor_iter += 1
+        succ = n_critic > 0
+        if self.EnableTargetNet() and self.iter > 0 and self.iter % self.freeze_target_iters == 0:
+            self.nt.update_target()
+        return succ
+
+    def UpdateActorBatchBuffer(self):
+        ids = self.FetchActorMinibatch(self.batch) if self.stage_train else []
+        n = len(ids)
+        if n:
+            self.nt.idx[self.batch:self.batch + n] = ids
+            self.nt.actor_filter(n)
+        self.nt.sync()
+        if n:
+            better = self.nt.better[:n].copy()
+            self.actor_batch_buffer += [t for t, b in zip(ids, better) if b]
 
 
 class HipQNetTrainer(_HipNetSide, QNetTrainer):

@@ -210,15 +210,124 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     return stats
 
 
+def train_data_parallel(arg_file, data_root, global_envs, dist, max_iters=None, max_frames=None, extra_args=None, seed=0, trainer_device=None,
+                        local_device_id=-1, scenario_cls=BatchScenario, trainer_lib=None, overlap=False):
+    """cScenarioTrain over several GPUs WITHOUT a trainer rank (train_distributed(mode="data_parallel")): every rank rolls out its shard of the global env ids,
+    keeps ITS OWN tuples in its own replay memory, and steps hip_trainer.HipMACETrainerDP -- two gradient all-reduces per Train() (2.28 MB each) are the only exchange;
+    no tuple gather, no weight broadcast: the weights are equal on all ranks because the updates are. Each rank hands its own trainer's weights to its own rollout
+    engine (device pointer, no communication). Per outer frame the ranks agree (one all-reduce MAX of an integer) on how many Train() calls the frame gets --
+    max over ranks of (new tuples // tuple_buffer_size), the reference's one-Train-per-32-tuples schedule applied to the busiest rank -- so that every rank issues the
+    same sequence of collectives; a rank with fewer new tuples still trains (a minibatch is drawn from the whole replay memory, new or not).
+    What a rank's trainer sees is 1 / world of the experience: the replay memory, the critic / actor buffers and the minibatch draws are per rank. It is NOT the
+    gathered form's tuple stream (train_distributed's default mode reproduces train() bit for bit; this mode trades that for a trainer that scales with the ranks)."""
+    import torch
+    from .hip_trainer import HipMACETrainerDP
+    from .sharding import shard_range
+    args = parse_arg_file(os.path.join(data_root, arg_file))
+    args.update({k: str(v) for k, v in (extra_args or {}).items()})
+    geti = lambda k, d: int(args.get(k, d)); getf = lambda k, d: float(args.get(k, d))
+    if not args.get("char_ctrl", "").endswith("_mace"):
+        raise ValueError("the data-parallel step is built for the MACE trainers (-char_ctrl= *_mace)")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    off, n_local = shard_range(global_envs, world, rank)
+    ea = dict(extra_args or {}); ea["global_env_offset"] = off
+    if overlap:
+        ea.setdefault("tuple_ring", "host")
+    b = scenario_cls(arg_file, n_local, data_root=data_root, device_id=local_device_id, extra_args=ea)
+    solver = os.path.join(data_root, args["policy_solver"])
+    m = re.search(r'net:\s*"([^"]+)"', open(solver).read())
+    train_net = os.path.join(data_root, m.group(1)) if m else os.path.join(data_root, args["policy_net"].replace("_deploy", "_train"))
+    t = HipMACETrainerDP(train_net, solver, b.S, b.A, dist=dist, lib_path=trainer_lib, mem_size=geti("trainer_replay_mem_size", 500000),
+                         num_init_samples=max(1, geti("trainer_num_init_samples", 200) // world),      # the file's count is for the whole experience stream
+                         steps_per_iter=geti("trainer_num_steps_per_iters", 1), freeze_target_iters=geti("trainer_freeze_target_iters", 0),
+                         init_input_offset_scale=args.get("trainer_init_input_offset_scale", "false").lower() == "true", seed=seed + 7919 * rank, device=trainer_device)
+    # identical initial weights: rank 0's
+    w = torch.from_numpy(np.ascontiguousarray(t.GetWeights(), np.float32))
+    wd = w.to(t.device) if t.device.type == "cuda" else w
+    dist.broadcast(wd, src=0)
+    t.SetWeights(wd.cpu().numpy())
+    t.SetOutputOffsetScale(*b.BuildNNOutputOffsetScale())
+    exp = dict(rate=getf("exp_rate", 0.2), temp=getf("exp_temp", 0.025), base=getf("exp_base_rate", 0.002))
+    init = dict(rate=getf("init_exp_rate", 1.0), temp=getf("init_exp_temp", 20.0), base=getf("init_exp_base_rate", 1.0))
+    n_anneal, n_base_anneal, n_curr = geti("trainer_num_anneal_iters", 1), geti("exp_base_anneal_iters", 1), geti("trainer_curriculum_iters", 0)
+    chunk = max(1, geti("tuple_buffer_size", 32))
+    max_iters = max_iters if max_iters is not None else geti("trainer_max_iter", 10 ** 9)
+    last_norm = [None]
+
+    def sync(it):
+        norm = t.GetOffsetScale()
+        if last_norm[0] is None or any(not np.array_equal(a, c) for a, c in zip(norm, last_norm[0])):
+            t.nt.sync()
+            b.SetPolicy(t.GetWeights(), *norm); last_norm[0] = norm
+        else:
+            sp = t.StreamPtr()
+            if sp is not None and hasattr(b, "SetPolicyDeviceOn"):
+                b.SetPolicyDeviceOn(t.WeightsDevicePtr(), t.nt.num_params, sp)
+            else:
+                t.nt.sync(); b.SetPolicyDevice(t.WeightsDevicePtr(), t.nt.num_params)
+        b.SetExplore(1, anneal(it, n_anneal, init["rate"], exp["rate"]), anneal(it, n_anneal, init["temp"], exp["temp"]), anneal(it, n_base_anneal, init["base"], exp["base"]))
+        phase = 1.0 if n_curr < 1 else min(max(it / float(n_curr), 0.0), 1.0)
+        b.SetTerrainParamsLerp(phase if it > 0 or n_curr < 1 else 0.0)
+
+    sync(0)
+    frames = tuples = 0
+    carry = 0          # new tuples not yet accounted for by a Train() call (the reference trains once per full scene buffer)
+    t0 = time.time()
+    count = torch.zeros(1, dtype=torch.int64, device=t.device if t.device.type == "cuda" else "cpu")
+    if overlap:
+        b.SetTuplePipelining(True); b.UpdateBegin(1.0 / 30.0)
+    more = True
+    while more:
+        frames += 1
+        more = t.GetIter() < max_iters and (max_frames is None or frames < max_frames)
+        if overlap:
+            b.UpdateEndBegin(1.0 / 30.0) if more else b.UpdateEnd()
+        else:
+            b.Update(1.0 / 30.0)
+        rows, flags, ids = b.DrainTuples()
+        o = np.argsort(ids, kind="stable")
+        rows, flags = rows[o], flags[o]
+        if len(rows):
+            k = 0
+            while k < len(rows):
+                st = t.StageTuples(rows[k:], flags[k:])
+                for j in range(0, st, chunk):
+                    t.AddTuples(rows[k + j:k + j + chunk], flags[k + j:k + j + chunk], staged=j)
+                k += st
+        tuples += len(rows); carry += len(rows)
+        count[0] = carry // chunk
+        dist.all_reduce(count, op=dist.ReduceOp.MAX)
+        n_train = int(count.item())
+        carry = max(0, carry - n_train * chunk)
+        for _ in range(n_train):
+            t.Train()
+        if n_train:
+            sync(t.GetIter())
+    if overlap:
+        b.SetTuplePipelining(False)
+    dt = time.time() - t0
+    return dict(frames=frames, iters=t.GetIter(), actor_iters=t.actor_iter, seconds=dt, env_steps_per_s=frames * 20.0 * global_envs / dt, rank=rank, batch=b, tuples=tuples,
+                weights=t.GetWeights(), offset_scale=t.GetOffsetScale(), trainer=t)
+
+
 def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, max_frames=None, extra_args=None, seed=0, device=None,
-                      trainer_device=None, local_device_id=-1, scenario_cls=BatchScenario, trainer="torch", trainer_lib=None, overlap=False):
+                      trainer_device=None, local_device_id=-1, scenario_cls=BatchScenario, trainer="torch", trainer_lib=None, overlap=False, mode="gather"):
     """cScenarioTrain over several GPUs: one process per GPU (torch.distributed already initialised; backend "nccl" = RCCL on GPUs).
     Every rank rolls out its contiguous range of global env ids; each outer frame the ranks' drained MACE rows are gathered on rank 0
     (the only exchange on the experience side), rank 0 runs the trainer, then one broadcast carries [iteration, weights, normalisers]
     back (the only exchange on the policy side). Trajectories do not depend on the sharding, so the run equals train() on one process.
     overlap=True is train(overlap=True) across ranks: frame f+1 is relaunched on every rank before frame f's tuples are packed and gathered (the collective
     runs beside frame f+1), rank 0 trains on frame f-1's rows meanwhile, and the broadcast weights are parked for the next launch when the normalisers have not
-    changed. Every tuple still reaches the trainer exactly once, in env-id order per frame; the policy a frame runs with is up to two frames staler."""
+    changed. Every tuple still reaches the trainer exactly once, in env-id order per frame; the policy a frame runs with is up to two frames staler.
+    WHAT IS GUARANTEED about the tuple stream: with a send block that holds a frame's rows (the default block of N / 8 rows per rank once the lock-step start has
+    spread out; always in the gloo tests' 32-env shards) the sequential mode equals train() in one process bit for bit and does not depend on the number of ranks.
+    When a frame produces more rows than the block holds, the surplus is carried to later frames (never dropped): every tuple arrives exactly once and each env's
+    tuples arrive in time order, but the interleaving across envs -- and with it the trainer's minibatches -- then depends on the block size and the number of
+    ranks. Pass block_rows = the worst case (2 x envs per rank) through ShardedRollout when run-to-run equality across world sizes matters more than the 1.2 MB block.
+    mode="data_parallel": no trainer rank at all -- see train_data_parallel."""
+    if mode == "data_parallel":      # no trainer rank: every rank trains on its own tuples, gradients all-reduced (train_data_parallel above)
+        return train_data_parallel(arg_file, data_root, global_envs, dist, max_iters=max_iters, max_frames=max_frames, extra_args=extra_args, seed=seed,
+                                   trainer_device=trainer_device, local_device_id=local_device_id, scenario_cls=scenario_cls, trainer_lib=trainer_lib, overlap=overlap)
     import torch
     from .sharding import ShardedRollout
     args = parse_arg_file(os.path.join(data_root, arg_file))

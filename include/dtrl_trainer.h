@@ -94,6 +94,25 @@ int dtrl_trainer_critic_step_and_filter(dtrl_trainer* t);
  * own outputs with the taken fragment's parameters replaced by the tuple's action. loss -> dtrl_trainer_loss()[1]. */
 int dtrl_trainer_actor_step(dtrl_trainer* t);
 
+
+/* ---- data-parallel step: every rank steps on a minibatch of ITS OWN tuples, one all-reduce of the flat gradient, the identical update on all ranks ----
+ * Stands in for the reference's answer to trainer fan-in -- a pool of learners pushing gradients to cParamServer::UpdateNet (learning/ParamServer.cpp:65-90,
+ * learning/AsyncMACETrainer.cpp:14-45; asynchronous, out of scope as code) -- in its synchronous form (last row: 570 474 floats = 2.28 MB per all-reduce).
+ * The gradient buffer holds num_params + 1 floats: the mean gradient over the rank's `batch` rows and, behind it, the number of rows (batch, or 0 after
+ * dtrl_trainer_zero_grad). The caller SUMS it over the ranks (RCCL all-reduce on the trainer's stream); dtrl_trainer_apply_grad rescales by batch / total rows, so
+ * ranks that had no batch this round simply do not count, and applies the Caffe SGD rule. With one rank and no all-reduce, grad + apply == the fused step. */
+/* the caller's device buffer of num_params + 1 floats becomes the gradient buffer (e.g. a framework tensor a collective can take); NULL = the trainer's own. Synchronises. */
+int dtrl_trainer_bind_grad(dtrl_trainer* t, float* grad_dev);
+int dtrl_trainer_grad_device(dtrl_trainer* t, float** grad_dev);
+/* dtrl_trainer_step / dtrl_trainer_critic_step / dtrl_trainer_actor_step up to and including the backward pass: the gradient is left in the buffer, nothing is updated
+ * (cNeuralNet::ForwardBackward, learning/NeuralNet.cpp:247-261, is the reference's call of this shape: cNeuralNetTrainer::UpdateNet's asynchronous branch) */
+int dtrl_trainer_grad_step(dtrl_trainer* t, const float* X_dev, const float* Y_dev);
+int dtrl_trainer_critic_grad(dtrl_trainer* t);
+int dtrl_trainer_actor_grad(dtrl_trainer* t);
+int dtrl_trainer_zero_grad(dtrl_trainer* t);
+/* Caffe SGD update from the (summed) gradient buffer; the total row count lands in dtrl_trainer_loss()[slot], slot = 2 (critic round) or 3 (actor round); count 0 = no update */
+int dtrl_trainer_apply_grad(dtrl_trainer* t, int slot);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,8 @@ struct Params {
 	double warmstart_factor = 0.85;  // m_warmstartingFactor
 	double breaking = 0.02;          // gContactBreakingThreshold
 	int relative_breaking = 1;       // CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD (btCollisionDispatcher's default): a pair's threshold = 0.02 x the smaller angular-motion disc
+	int vertex_contacts = 1;         // terrain vertices against the box faces (part of the stand-in contact generation); 0 = corners only, as Integrator v1 samples
+	int friction_warmstart = 1;      // warm start the friction rows as well (SOLVER_USE_WARMSTARTING covers them in Bullet 2.8x's setFrictionConstraintImpulse); 0 = normals only
 	int safe_margin = 1;             // btBoxShape's setSafeMargin: margin = min(0.04, 0.1 x smallest half extent); 0 = 0.04 on every box (the round-3 comparator)
 	int max_points = 4;              // MANIFOLD_CACHE_SIZE
 	int use_margin = 1;              // box margins (0 = sharp boxes, distance without margin)
@@ -295,7 +297,7 @@ private:
 			c.ax = px - m * c.nx; c.ay = py - m * c.ny;   // the point of the rounded box closest to the surface
 			out.push_back(c);
 		}
-		if (gnd.plane) return;
+		if (gnd.plane || !prm.vertex_contacts) return;
 		// terrain vertices against the box (a crest poking into a face between two corners)
 		const double r = std::hypot(A.hx, A.hy) + A.brk;
 		int i0 = static_cast<int>(std::floor((A.x - r - gnd.x0) / gnd.dx)), i1 = static_cast<int>(std::ceil((A.x + r - gnd.x0) / gnd.dx));
@@ -492,7 +494,7 @@ private:
 			Finish(f);
 			f.rhs = -RelVel(f) * f.dinv;
 			f.lo = 0; f.hi = 0;   // set from the normal impulse inside the iterations
-			f.imp = prm.warmstarting ? c.jt * prm.warmstart_factor : 0.0;
+			f.imp = (prm.warmstarting && prm.friction_warmstart) ? c.jt * prm.warmstart_factor : 0.0;
 			if (f.imp != 0) Apply(f, f.imp);
 			rows_.push_back(f);
 		}

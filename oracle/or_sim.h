@@ -353,6 +353,10 @@ struct Integrator {
 			for (int r = 0; r < R; ++r) {
 				if (Arr[r] < 1e-12) continue;
 				double w = 0; for (int i = 0; i < D; ++i) w += Jr[r][i] * v[i];
+				// -warm_start= 2 (oracle-only experiment): Bullet's friction rows are resolved only while their normal row carries an impulse
+				// (btSequentialImpulseConstraintSolver::solveSingleIteration: `if (totalImpulse > 0)`), so a warm-started friction impulse of a contact that is
+				// separating in this substep stays applied instead of being clamped back to zero
+				if (M.warm_start == 2 && kind[r] == 2 && !(lam[r - 1] > 0)) continue;
 				double nl = lam[r] + (tgt[r] - w) / Arr[r];
 				if (kind[r] == 2) { double lim = SimConst::mu * lam[r - 1]; nl = std::min(std::max(nl, -lim), lim); }
 				else nl = std::max(nl, 0.0);

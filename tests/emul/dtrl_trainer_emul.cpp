@@ -14,6 +14,7 @@ struct EmulTrainerBE {
 	bool ok() const { return err_.empty(); }
 	const std::string& error() const { return err_; }
 	void set_stream(void*) {}
+	void drop_graphs() {}
 	void fork() {}
 	void resume() {}
 	void join() {}

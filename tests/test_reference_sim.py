@@ -343,30 +343,69 @@ def test_ground_window_bit_exact_in_the_float_build(om, arg, seed):
         assert e.stats()["terrain_builds"] >= builds0 + 2             # this one travels / falls far enough to move its window
 
 
+def _in_band(v1, si, key, rel=None, absolute=None, nse=3.0):
+    """|v1 - SI| inside the stated band (relative to SI, or absolute), or inside `nse` standard errors of the difference over the seeds (the statistics of a
+    stumbling character under a synthetic policy are noisy: tools/a2_deviation.py prints both for the 32-seed study)"""
+    d = abs(v1[key] - si[key])
+    band = rel * abs(si[key]) if rel is not None else absolute
+    se = float(np.hypot(v1["se"][key], si["se"][key]))
+    return d <= band or (np.isfinite(se) and d <= nse * se)
+
+
 def test_integrator_v1_vs_bullet_shaped_sequential_impulse_bands(om):
-    """SURVEY 8a row a2 quantified: the REFERENCE'S OWN controllers (compiled, oracle/_ref/libref_sim.so) driven once by Integrator v1 (the product's
-    model, through the lock-step harness) and once by oracle/or_bullet_si.h (maximal coordinates, sequential impulse with Bullet 2.8x's published structure and
-    defaults) must produce the same gait within stated bands. Full study with ablations: tools/a2_deviation.py -> profiles/r03_a2_deviation.txt (10 seeds x 300
-    frames per scene; flat FSM scenes within 1.1 % on every statistic, dog slopes_mixed + MACE net within 3 % on cycle time / speed / duty / reward)."""
+    """SURVEY 8a row a2 quantified on ALL FIVE scenes of the study: the REFERENCE'S OWN controllers (compiled, oracle/_ref/libref_sim.so) driven once by
+    Integrator v1 (the product's model, through the lock-step harness) and once by oracle/or_bullet_si.h (maximal coordinates, sequential impulse with Bullet 2.8x's
+    published structure and defaults) must produce the same gait within stated bands. Full study with ablations and standard errors: tools/a2_deviation.py ->
+    profiles/r04_a2_deviation.txt (32 seeds x 300 frames per cell). Bands below are on short samples; a statistic passes inside its band OR inside 3 standard errors of
+    the difference over the seeds.
+      flat FSM scenes (deterministic)           cycle 2 %, speed 3 %, reward 3 %, duty 0.01
+      dog + slopes_mixed + MACE net  configs[1] cycle 5 %, speed 10 %, reward 10 %, duty 0.03, falls 3 s.e.
+      goat + cliffs_rugged           configs[4] cycle 12 %, reward 15 %, duty 0.05, speed / falls 3 s.e.
+      raptor + narrow_gaps           configs[2] the one scene with an attributed gap: the comparator WARM-STARTS ITS FRICTION ROWS (Bullet >= 2.81 covers them with
+                                                SOLVER_USE_WARMSTARTING) and resolves a friction row only while its normal row carries an impulse, so a stance foot's friction
+                                                impulse persists; Integrator v1 re-solves every row from zero. Held two ways: (a) v1 vs the comparator with normals-only warm
+                                                start: cycle 5 %, speed 10 %, reward 10 %, duty 0.03, falls 25 %; (b) v1 with the oracle-only switch -warm_start= 2 (the same
+                                                rule restated in the reduced-coordinate sweep) vs the comparator as it is: cycle 10 %, speed 15 %, reward 20 %, duty 0.04, falls 30 %."""
     import sys
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import a2_deviation as a2
-    pols = a2.policies()
+    jobs = min(4, os.cpu_count() or 1)
+
+    def pair(scene, seeds, frames, si_opts=None, v1_overrides=None):
+        v1 = a2.run(scene, "v1", seeds, frames, v1_overrides=v1_overrides, jobs=jobs)
+        si = a2.run(scene, "si", seeds, frames, si_opts=si_opts, jobs=jobs)
+        print(scene[0], si_opts, v1_overrides); print("  v1 " + a2.fmt(v1)); print("  SI " + a2.fmt(si)); print("  rel " + a2.rel_line(v1, si))
+        return v1, si
+
+    def hold(v1, si, tag, cycle, speed, reward, duty, falls):
+        bad = []
+        for key, rel in (("cycle_s", cycle), ("speed", speed), ("reward", reward), ("falls_k", falls)):
+            if rel is not None and not _in_band(v1, si, key, rel=rel):
+                bad.append(key)
+            if rel is None and not _in_band(v1, si, key, absolute=0.0):
+                bad.append(key)
+        for key in ("duty_front", "duty_back"):
+            if not _in_band(v1, si, key, absolute=duty):
+                bad.append(key)
+        assert not bad, (tag, bad, {k: (v1[k], si[k]) for k in bad})
     # (i) the clean gait comparison: FSM controllers on flat ground, no network, no falls
-    for scene, bands in ((a2.SCENES[0], dict(cycle_s=0.02, speed=0.04, reward=0.04, duty=0.03)), (a2.SCENES[1], dict(cycle_s=0.02, speed=0.04, reward=0.04, duty=0.03))):
-        v1 = a2.run(scene, "v1", [101, 102], 100, pols)
-        si = a2.run(scene, "si", [101, 102], 100, pols)
+    for scene in (a2.SCENES[0], a2.SCENES[1]):
+        v1, si = pair(scene, [101, 102], 100)
         assert v1["falls_k"] == 0 and si["falls_k"] == 0, (scene[0], v1, si)
-        for k in ("cycle_s", "speed", "reward"):
-            assert abs(v1[k] - si[k]) <= bands[k] * abs(si[k]), (scene[0], k, v1[k], si[k])
+        for k, band in (("cycle_s", 0.02), ("speed", 0.03), ("reward", 0.03)):
+            assert abs(v1[k] - si[k]) <= band * abs(si[k]), (scene[0], k, v1[k], si[k])
         for k in ("duty_front", "duty_back"):
-            assert abs(v1[k] - si[k]) <= bands["duty"], (scene[0], k, v1[k], si[k])
+            assert abs(v1[k] - si[k]) <= 0.01, (scene[0], k, v1[k], si[k])
         assert v1["n_cycles"] >= 10 and abs(v1["n_cycles"] - si["n_cycles"]) <= 1
-    # (ii) BASELINE configs[1]'s scene with the (synthetic) MACE policy: the same statistics over a short sample (3 seeds x 100 frames, ~45 cycles): wider bands
-    scene = a2.SCENES[2]
-    v1 = a2.run(scene, "v1", [101, 102, 103], 100, pols)
-    si = a2.run(scene, "si", [101, 102, 103], 100, pols)
-    print("slopes_mixed v1", v1); print("slopes_mixed SI", si)
-    assert abs(v1["cycle_s"] - si["cycle_s"]) <= 0.10 * si["cycle_s"] and abs(v1["speed"] - si["speed"]) <= 0.20 * abs(si["speed"])
-    assert abs(v1["duty_front"] - si["duty_front"]) <= 0.08 and abs(v1["duty_back"] - si["duty_back"]) <= 0.08
-    assert abs(v1["reward"] - si["reward"]) <= 0.2 * si["reward"]
+    seeds8 = list(range(201, 209))
+    # (ii) BASELINE configs[1]'s scene with the (synthetic) MACE policy
+    v1, si = pair(a2.SCENES[2], seeds8, 150)
+    hold(v1, si, "dog slopes_mixed", 0.05, 0.10, 0.10, 0.03, None)
+    # (iii) configs[2]'s scene: the attributed gap, held from both sides
+    v1, si = pair(a2.SCENES[3], seeds8, 150, si_opts=dict(friction_warmstart=0))
+    hold(v1, si, "raptor narrow_gaps vs SI with normals-only warm start", 0.05, 0.10, 0.10, 0.03, 0.25)
+    v1w, sid = pair(a2.SCENES[3], seeds8, 150, v1_overrides=dict(warm_start=2))
+    hold(v1w, sid, "raptor narrow_gaps, v1 with Bullet's friction warm-start rule vs SI", 0.10, 0.15, 0.20, 0.04, 0.30)
+    # (iv) configs[4]'s scene (goat, world scale 1, one substep of 1/600 s per env-step): a slow, often-falling character under this policy -> a larger sample
+    v1, si = pair(a2.SCENES[4], list(range(201, 217)), 200)
+    hold(v1, si, "goat cliffs_rugged", 0.12, None, 0.15, 0.05, None)

@@ -3,8 +3,8 @@
 
 SURVEY 8a row a2 -- what happens inside Bullet's stepSimulation -- is the one part of the hot path that cannot be pinned: Bullet is absent. This tool
 quantifies the modelling gap instead of leaving it open: the REFERENCE'S OWN scenario + controllers (compiled unchanged, oracle/_ref/libref_sim.so) are
-driven once by Integrator v1 (oracle/or_sim.h = the product kernel's model: reduced coordinates, Delassus-space PGS, no margins / warm start / split
-impulse; lock-step harness of oracle/refsim.py) and once by oracle/or_bullet_si.h (maximal coordinates, sequential impulse with Bullet 2.8x's published
+driven once by Integrator v1 (oracle/or_sim.h = the product kernel's model: reduced coordinates, Delassus-space PGS, Bullet's per-box safe margin, no warm
+start / split impulse; lock-step harness of oracle/refsim.py) and once by oracle/or_bullet_si.h (maximal coordinates, sequential impulse with Bullet 2.8x's published
 structure and defaults: ERP joints, 10 sweeps, warm-started persistent contacts, margins + breaking threshold, split impulse, angular-limit rows), on the
 same scenes, seeds and (synthetic) policies, and distribution-level statistics of the resulting behaviour are compared:
 
@@ -12,9 +12,11 @@ same scenes, seeds and (synthetic) policies, and distribution-level statistics o
   falls_k      falls (episode ends) per 1000 env-steps                           duty_front / duty_back   contact-flag duty cycle of the front / back foot
   ep_dist      mean distance per episode (cScenarioPoliEval's dist log)          reward      mean cDogController / cRaptorController::CalcReward at cycle ends
 
-  python tools/a2_deviation.py [--seeds 6] [--frames 300] [--out profiles/r03_a2_deviation.txt] [--ablate]
---ablate additionally runs the SI integrator with one Bullet feature removed at a time (margin, warm start, split impulse, link contacts, 4-point cap):
-a feature whose removal moves a statistic by more than the v1-vs-SI gap is one Integrator v1 should model.
+  python tools/a2_deviation.py [--seeds 32] [--frames 300] [--jobs 8] [--null] [--ablate] [--v1-ablate] [--out profiles/r04_a2_deviation.txt]
+Every statistic is printed with its standard error over the seeds (each seed an independent run) and every difference in units of its standard error; --null
+adds SI on a disjoint seed set (what sampling alone produces). --ablate runs the SI integrator with one Bullet feature removed at a time (margin, warm start, friction
+warm start, split impulse, link contacts, 4-point cap, ...): a feature whose removal reproduces Integrator v1 is what carries a v1-vs-SI gap. --v1-ablate runs
+Integrator v1 with one modelling switch changed at a time.
 """
 import argparse
 import json
@@ -207,8 +209,10 @@ def rel_line(a, b):
 
 SI_ABLATIONS = (("no margin", dict(use_margin=0)), ("no warm start", dict(warmstarting=0)), ("no split impulse", dict(split_impulse=0)),
                 ("no link contacts", dict(link_contacts=0)), ("1 point per pair", dict(max_points=1)), ("erp 0.8 joints", dict(erp=0.8)), ("20 iterations", dict(iterations=20)),
+                ("no FRICTION warm start (normals only)", dict(friction_warmstart=0)), ("no terrain-vertex contacts", dict(vertex_contacts=0)),
                 ("round-3 comparator: margin 0.04 + breaking 0.02 on every box", dict(safe_margin=0, relative_breaking=0)))
-V1_ABLATIONS = (("warm start 0.85 (oracle-only switch)", dict(warm_start=1)), ("sharp boxes (-collision_margin= 0)", dict(collision_margin=0)),
+V1_ABLATIONS = (("warm start 0.85 (oracle-only switch)", dict(warm_start=1)),
+                ("warm start 0.85 with Bullet's rule that a friction row is resolved only while its normal row carries an impulse (oracle-only switch -warm_start= 2)", dict(warm_start=2)), ("sharp boxes (-collision_margin= 0)", dict(collision_margin=0)),
                 ("round-3 model: 0.04 / world_scale on every link (-safe_margin= 0)", dict(safe_margin=0)), ("no link contacts", dict(link_contacts=0)))
 
 

@@ -35,7 +35,8 @@ def main(src, dst, cfg="1"):
             last = [r[0] for r in cur.execute("select duration from kernels where name like '%" + KERNEL + "%' and grid_x = ? order by start desc limit ?", (dom[0][0], 180 * per_step))]
             out.append("  timed region = last %d frame launches (grid %d, %d env-group launches per bench step, 3 windows x 60 frames): avg %.3f ms (compare roofline.kernel_avg_ms of the bench line)" % (len(last), dom[0][0], per_step, sum(last) / len(last) / 1e6))
         out.append("")
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_ic"):
+    vals = {}
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_ic", "pmc_lanes", "pmc_pipes"):
         db = os.path.join(src, sub, "pmc_results.db")
         if not os.path.exists(db):
             continue
@@ -52,7 +53,25 @@ def main(src, dst, cfg="1"):
                 traffic[r[0]] = r[2] * 1024.0
             if r[0] == "SQ_INSTS_VALU":
                 traffic[r[0]] = r[2]
+            vals[(sub, r[0])] = r[2]
         out.append("")
+    # derived figures
+    der = []
+    lanes = None
+    if ("pmc_lanes", "SQ_THREAD_CYCLES_VALU") in vals and vals.get(("pmc_lanes", "SQ_ACTIVE_INST_VALU")):
+        lanes = vals[("pmc_lanes", "SQ_THREAD_CYCLES_VALU")] / vals[("pmc_lanes", "SQ_ACTIVE_INST_VALU")]
+        der.append("  active lanes per VALU instruction = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = %.1f of 64 (%.0f %%)" % (lanes, 100.0 * lanes / 64.0))
+    if ("pmc_sq2", "GRBM_GUI_ACTIVE") in vals:
+        try:
+            cur = sqlite3.connect(os.path.join(src, "pmc_sq2", "pmc_results.db")).cursor()
+            r = list(cur.execute("select avg(duration), count(*) from kernels where name like '%" + KERNEL + "%' and grid_x = (select grid_x from kernels where name like '%" + KERNEL + "%' group by grid_x order by sum(duration) desc limit 1)"))[0]
+            ghz = vals[("pmc_sq2", "GRBM_GUI_ACTIVE")] / 8.0 / r[0]     # GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles; duration in ns
+            der.append("  shader clock while the kernel ran = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same pass (%.3f ms over %d launches) = %.2f GHz" % (r[0] / 1e6, r[1], ghz))
+            json.dump({"shader_clock_ghz": ghz, "active_lanes_per_valu_instruction": lanes, "source": os.path.basename(dst)}, open(os.path.join(os.path.dirname(dst), "shader_clock_config%s.json" % cfg), "w"))
+        except Exception as e:   # (older rocpd schemas: no kernels view in a counter pass)
+            der.append("  shader clock: not derived (%s)" % e)
+    if der:
+        out.append("## derived\n" + "\n".join(der) + "\n")
     open(dst, "w").write("\n".join(out) + "\n")
     if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
         # MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B -> doubled; WRITE_SIZE is uncalibrated (taken as is)
