@@ -191,12 +191,14 @@ int Engine::Create(const char* const* argv, int argc, int num_envs, int device_i
 	pin_order_ = static_cast<int32_t*>(be_->HostStaging(sizeof(int32_t) * n_));
 	pin_ids_ = static_cast<int32_t*>(be_->HostStaging(sizeof(int32_t) * n_));
 	if (!pin_recs_ || !pin_order_ || !pin_ids_) return Fail(DTRL_ERR_DEVICE, "host staging allocation failed: " + be_->error());
-	// env groups (one stream each): one group fills the resident-wavefront slots while another's frame-boundary host work runs, and a group's launch lasts as
-	// long as ITS slowest env -- smaller groups wait for fewer stragglers. Round 1 (boundary work = copies + scatter launches) measured 2 as the optimum
-	// (1: 10.1, 2: 13.7, 3: 10.9, 4: 12.6, 8: 6.3 M env-steps/s); since the zero-copy boundary (v12) four groups are ahead for the dog (4096 envs, same box:
-	// 17.77 -> 17.87 M; 16.7 -> 17.0 M before the register PGS covered every row count) and equal for the raptor at 8192. DTRL_GROUPS overrides.
+	// env groups (one stream each): one group fills the resident-wavefront slots while another's frame-boundary host work runs. Round 1 (boundary work = copies
+	// + scatter launches) measured 2 as the optimum (1: 10.1, 2: 13.7, 3: 10.9, 4: 12.6, 8: 6.3 M env-steps/s). Round 4, zero-copy boundary: a group's launch lasts
+	// as long as ITS slowest env, so while the slowest envs (characters lying on 13-24 constraint rows) ran the slow Gauss-Seidel path, smaller groups were ahead
+	// (2 / 3 / 4 groups: 16.7 / 16.8 / 17.0 M); with every row count on the register path the tail is gone and the count no longer matters for the rollout
+	// (17.73 / 17.76 / 17.78 M) while the per-frame loops pay for every extra group's boundary work (exchange leg without a collective 16.9 / 16.6 / 15.8 M):
+	// two it stays. DTRL_GROUPS overrides.
 	{
-		int G = n_ >= 2048 ? 4 : (n_ >= 1024 ? 2 : 1);
+		int G = n_ >= 1024 ? 2 : 1;
 		if (const char* env = std::getenv("DTRL_GROUPS")) G = std::max(1, std::min(be_->NumStreams(), std::atoi(env)));
 		G = std::min(G, n_);
 		groups_.clear();

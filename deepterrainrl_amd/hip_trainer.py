@@ -28,7 +28,8 @@ TRAINER_ABI_SYMBOLS = [
     "dtrl_trainer_eval", "dtrl_trainer_step", "dtrl_trainer_bind_replay", "dtrl_trainer_idx", "dtrl_trainer_better", "dtrl_trainer_loss",
     "dtrl_trainer_critic_step", "dtrl_trainer_actor_filter", "dtrl_trainer_actor_step", "dtrl_trainer_debug_get", "dtrl_trainer_critic_step_and_filter",
     "dtrl_trainer_stage_rows", "dtrl_trainer_stage_flags", "dtrl_trainer_stage_capacity", "dtrl_trainer_add_staged",
-    "dtrl_trainer_bind_grad", "dtrl_trainer_grad_device", "dtrl_trainer_grad_step", "dtrl_trainer_critic_grad", "dtrl_trainer_actor_grad", "dtrl_trainer_zero_grad", "dtrl_trainer_apply_grad",
+    "dtrl_trainer_create_from_files", "dtrl_trainer_dims", "dtrl_trainer_init_xavier", "dtrl_trainer_eval_host", "dtrl_trainer_step_host", "dtrl_trainer_get_normalizers",
+    "dtrl_trainer_copy_model", "dtrl_trainer_bind_grad", "dtrl_trainer_grad_device", "dtrl_trainer_grad_step", "dtrl_trainer_critic_grad", "dtrl_trainer_actor_grad", "dtrl_trainer_zero_grad", "dtrl_trainer_apply_grad",
 ]
 
 

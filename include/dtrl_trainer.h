@@ -95,6 +95,22 @@ int dtrl_trainer_critic_step_and_filter(dtrl_trainer* t);
 int dtrl_trainer_actor_step(dtrl_trainer* t);
 
 
+/* ---- for a C++ host that speaks the reference's cNeuralNet interface (include/BatchNeuralNet.h): files in, host arrays in and out ----
+ * Replaces cNeuralNet::LoadNet + LoadSolver (learning/NeuralNet.cpp:62-79, 110-136) WITH the file reading: net_file = the deploy or train prototxt of the family,
+ * solver_file = the solver prototxt (NULL / "": evaluation only); the train net named by the solver (`net: "..."`, resolved against data_root, else
+ * <x>_solver -> <x>_train, else <net>_deploy -> <net>_train) supplies the MemoryData batch_size and the per-blob lr_mult / decay_mult. max_eval = 3 x batch. */
+int dtrl_trainer_create_from_files(const char* net_file, const char* solver_file, const char* data_root, float discount, int freeze_target, int device_id, dtrl_trainer** out);
+int dtrl_trainer_dims(const dtrl_trainer* t, int* in_size, int* out_size, int* batch, int* max_eval);
+/* what a freshly built Caffe net holds: "xavier" weights (uniform +- sqrt(3 / fan_in)), zero biases, in both nets; history cleared */
+int dtrl_trainer_init_xavier(dtrl_trainer* t, uint64_t seed);
+/* cNeuralNet::Eval / EvalBatch (learning/NeuralNet.cpp:352-387) and cNeuralNet::Train (:229-245) on HOST arrays of doubles (Eigen's storage, row-major copies):
+ * staged through device buffers of the trainer, synchronous. Any n for the evaluation; exactly `batch` rows for the step. */
+int dtrl_trainer_eval_host(dtrl_trainer* t, int which, const double* X, int n, double* Y);
+int dtrl_trainer_step_host(dtrl_trainer* t, const double* X, const double* Y, double* loss);
+int dtrl_trainer_get_normalizers(dtrl_trainer* t, double* in_off, double* in_scale, double* out_off, double* out_scale);
+/* cNeuralNet::CopyModel (learning/NeuralNet.cpp:722-733): parameters + normalisers of src's current net into dst's, device to device */
+int dtrl_trainer_copy_model(dtrl_trainer* dst, dtrl_trainer* src);
+
 /* ---- data-parallel step: every rank steps on a minibatch of ITS OWN tuples, one all-reduce of the flat gradient, the identical update on all ranks ----
  * Stands in for the reference's answer to trainer fan-in -- a pool of learners pushing gradients to cParamServer::UpdateNet (learning/ParamServer.cpp:65-90,
  * learning/AsyncMACETrainer.cpp:14-45; asynchronous, out of scope as code) -- in its synchronous form (last row: 570 474 floats = 2.28 MB per all-reduce).

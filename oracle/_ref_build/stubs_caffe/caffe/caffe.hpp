@@ -27,5 +27,6 @@ public:
 	std::string mFile;
 	Phase mPhase;
 	int mHarnessId = -1;
+	std::shared_ptr<void> mImpl;      // (libref_learn_native.so: the cBatchNeuralNet the wrapper stands for)
 };
 }  // namespace caffe

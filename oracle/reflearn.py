@@ -18,7 +18,11 @@ from . import trainer_ref as ref
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_ref", "libref_learn.so")
-_lib = None
+# the same reference trainers with the PRODUCT's nets behind cNeuralNet (oracle/_ref_build/ref_learn_net_native.cpp over include/BatchNeuralNet.h): the plain-loop
+# check build of the native step on the CPU box, lib/libdtrl.so on the GPU box
+NATIVE_LIB_PATH = os.path.join(HERE, "_ref", "libref_learn_native.so")
+NATIVE_HIP_LIB_PATH = os.path.join(HERE, "_ref", "libref_learn_native_hip.so")
+_libs = {}
 
 NET_NEW = C.CFUNCTYPE(C.c_int, C.c_char_p)
 NET_FREE = C.CFUNCTYPE(None, C.c_int)
@@ -46,10 +50,10 @@ def available():
     return os.path.exists(LIB_PATH)
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        L = C.CDLL(LIB_PATH)
+def lib(path=None):
+    path = path or LIB_PATH
+    if path not in _libs:
+        L = C.CDLL(path)
         vp = C.c_void_p
         L.ref_learn_set_harness.argtypes = [C.POINTER(HarnessStruct)]
         L.ref_learn_seed_rand.argtypes = [C.c_ulong]
@@ -69,8 +73,13 @@ def lib():
         L.ref_learn_mem_row.argtypes = [vp, C.c_int, vp, vp]
         for name in ("set_input_offset_scale", "set_output_offset_scale", "set_actor_output_offset_scale", "set_critic_output_offset_scale", "get_input_offset_scale"):
             getattr(L, "ref_learn_" + name).argtypes = [vp, vp, vp, C.c_int]
-        _lib = L
-    return _lib
+        if hasattr(L, "ref_learn_native_config"):
+            L.ref_learn_native_config.argtypes = [C.c_char_p, C.c_int]
+            L.ref_learn_native_num_params.restype = C.c_longlong; L.ref_learn_native_num_params.argtypes = [C.c_int]
+            L.ref_learn_native_get_params.argtypes = [C.c_int, vp, C.c_longlong]
+            L.ref_learn_native_set_params.argtypes = [C.c_int, vp, C.c_longlong]
+        _libs[path] = L
+    return _libs[path]
 
 
 class RefRandStream:
@@ -169,8 +178,8 @@ class RefTrainer:
     """cMACETrainer / cQNetTrainer / cCaclaTrainer of the reference behind ref_learn_api.cpp's C ABI."""
 
     def __init__(self, kind, harness, net_file, solver_file, mem_size, num_init_samples, discount, freeze_target_iters=0, init_input_offset_scale=True,
-                 num_frags=1, frag_size=1, actor_net_file="", actor_solver_file="", seed=0):
-        self._L = lib()
+                 num_frags=1, frag_size=1, actor_net_file="", actor_solver_file="", seed=0, lib_path=None):
+        self._L = lib(lib_path)
         self.harness = harness
         self._L.ref_learn_seed_rand(int(seed))
         p = Params(net_file.encode(), solver_file.encode(), actor_net_file.encode(), actor_solver_file.encode(), int(mem_size), 1, int(num_init_samples), 1,
@@ -216,6 +225,17 @@ class RefTrainer:
 
     def pool_net(self, i=0):
         return self.harness.nets[self._L.ref_learn_pool_net(self._h, i)]
+
+    # native variant (libref_learn_native*.so): the pool nets are the product's; their Caffe-blob-order weight vectors by pool index
+    def pool_weights(self, i=0):
+        nid = self._L.ref_learn_pool_net(self._h, i)
+        w = np.zeros(int(self._L.ref_learn_native_num_params(nid)), np.float32)
+        assert self._L.ref_learn_native_get_params(nid, w.ctypes.data, w.size) == 0
+        return w
+
+    def set_pool_weights(self, i, w):
+        w = np.ascontiguousarray(w, np.float32)
+        assert self._L.ref_learn_native_set_params(self._L.ref_learn_pool_net(self._h, i), w.ctypes.data, w.size) == 0
 
     def num_pool(self): return self._L.ref_learn_num_pool(self._h)
 

@@ -439,3 +439,19 @@ def test_data_parallel_trainer_on_one_rank_equals_the_plain_native_trainer(om):
     assert np.array_equal(a.GetWeights(), b.GetWeights())
     ioa, isa, _, _ = a.GetOffsetScale(); iob, isb, _, _ = b.GetOffsetScale()
     assert np.allclose(ioa, iob, atol=1e-6) and np.allclose(isa, isb, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_batch_neural_net_shim_and_the_reference_trainer_on_the_hip_nets(om):
+    """include/BatchNeuralNet.h on the HIP library: (i) the driver compiled inside the reference's header tree (tests/shim/drive_shim_net_hip, prebuilt) through
+    cNeuralNet's calls; (ii) the reference's own cMACETrainer with its nets forwarded to the shim (oracle/_ref/libref_learn_native_hip.so, prebuilt) against
+    HipMACETrainer on the MI355X."""
+    import subprocess
+    from oracle import reflearn
+    exe = os.path.join(REPO, "tests", "shim", "drive_shim_net_hip")
+    if not os.path.exists(exe) or not os.path.exists(reflearn.NATIVE_HIP_LIB_PATH) or not reflearn.available():
+        pytest.skip("prebuilt shim driver / libref_learn_native_hip.so not shipped")
+    r = subprocess.run([exe, REFDATA, "/tmp"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "shim net ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    import test_reference_learn as TR
+    TR.run_reference_trainer_on_the_product_nets(reflearn, om, reflearn.NATIVE_HIP_LIB_PATH, make_native(None, "cuda", mem_size=256, num_init_samples=100, seed=21, freeze_target_iters=2), 3e-4)

@@ -206,7 +206,7 @@ from conftest import REFDATA, EmulScenario
 from deepterrainrl_amd import train_loop
 dist.init_process_group(backend="gloo")
 rank = dist.get_rank()
-st = train_loop.train_distributed("args/opt_args_train_mace.txt", REFDATA, 64, dist, max_frames=60, trainer_device="cpu", scenario_cls=EmulScenario, extra_args={extra!r},
+st = train_loop.train_distributed("args/opt_args_train_mace.txt", REFDATA, 128, dist, max_frames=80, trainer_device="cpu", scenario_cls=EmulScenario, extra_args={extra!r},
                                   trainer="hip", trainer_lib={lib!r}, mode="data_parallel")
 t = st["trainer"]
 X = t.mem[:t.num_tuples, 1:1 + t.S].to(torch.float64)
@@ -231,7 +231,7 @@ def test_two_rank_data_parallel_training(tmp_path, da):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     a, b = np.load(tmp_path / "dp_rank0.npz"), np.load(tmp_path / "dp_rank1.npz")
-    assert int(a["frames"]) == int(b["frames"]) == 60
+    assert int(a["frames"]) == int(b["frames"]) == 80
     assert int(a["iters"]) == int(b["iters"]) >= 2 and int(a["actor_iters"]) == int(b["actor_iters"])
     assert np.array_equal(a["weights"], b["weights"]) and np.array_equal(a["hist"], b["hist"]) and np.all(np.isfinite(a["weights"]))
     assert np.abs(a["hist"]).max() > 0                                                   # updates happened

@@ -210,3 +210,53 @@ def test_reference_mace_trainer_vs_native_step_check_build(rl, om, freeze):
     """the native step (plain-loop check build of the HIP trainer's operand definitions, float32) against the compiled reference"""
     import test_hip_trainer as TH
     run_reference_vs_product_mace(rl, om, TH.make_native(TH.EMUL_TRAINER_LIB, mem_size=256, num_init_samples=100, seed=21, freeze_target_iters=freeze), 3e-4, freeze)
+
+
+def run_reference_trainer_on_the_product_nets(rl, om, lib_path, product, tol):
+    """INTEGRATION.md 4b made concrete: the reference's OWN cMACETrainer (compiled unchanged) with every cNeuralNet forwarded to include/BatchNeuralNet.h's
+    cBatchNeuralNet over the native trainer step (oracle/_ref/libref_learn_native*.so) -- its replay memory, buffers, draws, labels and schedule, the product's
+    forward / backward / Caffe SGD -- against hip_trainer.HipMACETrainer, where the product's own host bookkeeping drives the same native step: same tuples, same
+    random stream -> same buffers and counters at every Train(), weights within float32 rounding of the label arithmetic (double in the reference's trainer)."""
+    from conftest import REFDATA
+    L = rl.lib(lib_path)
+    L.ref_learn_native_config(REFDATA.encode(), -1)
+    rng = np.random.RandomState(9)
+    rows, flags = TT.random_rows(rng, 420, p_actor=0.5)
+    R = rl.RefTrainer("mace", None, TT.DEPLOY, TT.SOLVER, mem_size=256, num_init_samples=100, discount=0.9, freeze_target_iters=2, num_frags=NF, frag_size=FS, seed=78, lib_path=lib_path)
+    assert (R.S, R.A, R.batch, R.num_pool()) == (S, A, 32, 2)
+    t = product
+    t.rng = rl.RefRandStream(78)
+    w0 = t.GetWeights().copy()
+    t.SetWeights(w0)
+    for i in range(R.num_pool()):
+        R.set_pool_weights(i, w0)
+    k = 0
+    for n_new, n_train in ((60, 2), (150, 5), (210, 6)):
+        assert R.add_rows(rows[k:k + n_new], flags[k:k + n_new]) == list(t.AddTuples(rows[k:k + n_new], flags[k:k + n_new]))
+        k += n_new
+        for j in range(n_train):
+            R.train(); t.Train()
+            assert (R.iter, R.actor_iter, R.stage_train) == (t.GetIter(), t.actor_iter, t.stage_train), (k, j)
+            assert (R.buffer(0), R.buffer(1), R.buffer(2)) == (list(t.critic_buffer), list(t.actor_buffer), list(t.actor_batch_buffer)), (k, j)
+    a, b = R.pool_weights(0).astype(np.float64), t.GetWeights().astype(np.float64)
+    assert R.iter == 11 and R.actor_iter >= 2
+    assert np.abs(a - b).max() < tol * np.abs(b).max() and np.abs(b - w0).max() > 1e-4
+    R.close()
+
+
+def test_reference_mace_trainer_running_on_the_product_nets(rl, om):
+    if not os.path.exists(rl.NATIVE_LIB_PATH):
+        pytest.skip("oracle/_ref/libref_learn_native.so not built")
+    import test_hip_trainer as TH
+    run_reference_trainer_on_the_product_nets(rl, om, rl.NATIVE_LIB_PATH, TH.make_native(TH.EMUL_TRAINER_LIB, mem_size=256, num_init_samples=100, seed=21, freeze_target_iters=2), 3e-4)
+
+
+def test_batch_neural_net_shim_inside_the_reference_tree():
+    """include/BatchNeuralNet.h compiled against /root/reference's headers (tests/shim/Makefile) and driven through cNeuralNet's calls on the plain-loop check build"""
+    import subprocess
+    from conftest import REFDATA
+    exe = os.path.join(REPO, "tests", "shim", "drive_shim_net_emul")
+    if not os.path.exists(exe):
+        pytest.skip("tests/shim/drive_shim_net_emul not built")
+    r = subprocess.run([exe, REFDATA, "/tmp"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "shim net ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

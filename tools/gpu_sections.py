@@ -9,8 +9,9 @@ import bench
 NAMES = ["FK", "Mass", "Bias", "Fact", "Detect", "Rows", "Fsub", "Delassus", "Pgs", "Finish", "Ctrl(incl Action)", "Action", "FrameIO", "Total", "RowsSum", "Substeps", "P1cum", "P2cum", "P3cum", "P4cum", "nR0", "nR1_6", "nR7_12", "nR13_18", "nR19_24", "tR0", "tR1_6", "tR7_12", "tR13_18", "tR19_24", "nnConv", "nnFcTerr", "nnRest", "nnEvals", "cFsm", "cFeedback(+action)", "cPdSetup", "cPdSolve", "cGrav", "cTail"]
 da.LIB_PATH = os.environ.get("DTRL_PROF_LIB") or os.path.join(REPO, "deepterrainrl_amd", "lib", "libdtrl_prof.so")   # developer build with section counters
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-b = da.BatchScenario(bench.CONFIGS[1]["arg_file"], n, data_root=bench.ROOT, extra_args={"terrain_seed": 20260925, "rand_seed": 1, "link_contacts": int(os.environ.get("LINK_CONTACTS", "1"))})
-b.SetPolicy(bench.xavier_weights(b.PolicyNumParams()), *bench.load_scale(bench.CONFIGS[1]))
+CFG = bench.CONFIGS[int(sys.argv[3]) if len(sys.argv) > 3 else 1]
+b = da.BatchScenario(CFG["arg_file"], n, data_root=bench.ROOT, extra_args={"terrain_seed": 20260925, "rand_seed": 1, "link_contacts": int(os.environ.get("LINK_CONTACTS", "1"))})
+b.SetPolicy(bench.xavier_weights(b.PolicyNumParams(), CFG["n_char"], CFG["frag"]), *bench.load_scale(CFG))
 b.RunFrames(int(sys.argv[2]) if len(sys.argv) > 2 else 30)
 out = (C.c_ulonglong * 40)()
 b._lib.dtrlx_profile_sections(b._h, out, 40)
