@@ -8,6 +8,7 @@
 // the device. Accumulation runs in k order per output, so results are deterministic and equal the plain-loop check build up to fp32 contraction.
 #include "dtrl_trainer_core.h"
 #include <hip/hip_runtime.h>
+#include "dtrl_trainer_fused.h"
 #include <algorithm>
 #include <cstdlib>
 #include <string>
@@ -260,6 +261,37 @@ struct HipTrainerBE {
 	{
 		hipLaunchKernelGGL(tr_sum_kernel, dim3(1), dim3(256), 0, stream, x, n, scale, out);
 		chk(hipGetLastError(), "loss launch");
+	}
+	// ---- per-sample fused passes (dtrl_trainer_fused.h): 1 + 1 + 1 launches instead of 8 + 8 + 1. DTRL_TRAINER_FUSED=0 keeps the layer-by-layer form (A/B) ----
+	FusedPlan plan_;
+	bool fused_bwd_ = false;
+	// DTRL_TRAINER_FUSED: 0 = layer-by-layer everywhere, 1 = per-sample fused FORWARD passes (default: measured ahead), 2 = fused forward and backward (measured behind: a
+	// sample's backward chain is bound by ONE compute unit's vector issue rate, 32 of 256 units busy -- profiles/r04_trainer.txt)
+	void setup_fused(const NetDims& d)
+	{
+		plan_ = fused_plan(d);
+		const char* e = std::getenv("DTRL_TRAINER_FUSED");
+		const int mode = e ? std::atoi(e) : 1;
+		if (mode == 0) plan_.ok = false;
+		fused_bwd_ = mode >= 2;
+	}
+	bool fused_forward(const NetDims* d, const Work* wk, int rows, bool store)
+	{
+		if (!plan_.ok || rows <= 0) return false;
+		if (store) hipLaunchKernelGGL(tr_fused_forward_kernel<true>, dim3(rows), dim3(kFT), plan_.lds_bytes, stream, d, wk, plan_.size_a, plan_.size_b);
+		else hipLaunchKernelGGL(tr_fused_forward_kernel<false>, dim3(rows), dim3(kFT), plan_.lds_bytes, stream, d, wk, plan_.size_a, plan_.size_b);
+		chk(hipGetLastError(), "fused forward launch");
+		return true;
+	}
+	bool fused_backward(const NetDims* d, const Work* wk, const NetDims& hd, int rows, const SgdArgs& a)
+	{
+		if (!plan_.ok || !fused_bwd_ || rows <= 0) return false;
+		hipLaunchKernelGGL(tr_fused_backward_x_kernel, dim3(rows), dim3(kFT), plan_.lds_bytes, stream, d, wk, plan_.size_a, plan_.size_b);
+		const int conv_blocks = static_cast<int>((hd.wo_terr + 3) / 4);
+		const int fc_blocks = static_cast<int>((hd.num_params - hd.wo_terr + 255) / 256);
+		hipLaunchKernelGGL(tr_fused_grad_kernel, dim3(conv_blocks + fc_blocks), dim3(256), 0, stream, d, wk, conv_blocks, a);
+		chk(hipGetLastError(), "fused backward launch");
+		return true;
 	}
 	template <class F>
 	void for_each(int64_t n, const F& f)

@@ -9,6 +9,7 @@
 //   ActorStep    cMACETrainer::BuildActorProblemY + StepActor                                                  learning/MACETrainer.cpp:285-305, 611-633
 #pragma once
 #include "dtrl_trainer_ops.h"
+#include "dtrl_trainer_fused.h"
 #include <cstring>
 #include <string>
 #include <vector>
@@ -166,6 +167,7 @@ public:
 	{
 		if (!be.init(err)) return false;
 		const NetDims& d = cfg.dims;
+		be.setup_fused(d);
 		const size_t P = static_cast<size_t>(d.num_params);
 		w_cur = F(P); w_tgt = F(P); hist = F(P); grad = F(P + 1); grad_own = grad; rate_mult = F(P); decay_mult = F(P);   // (grad[P]: sample count of the data-parallel step)
 		in_off = F(d.S); in_scale = F(d.S); out_off = F(d.out_size); out_scale = F(d.out_size);
@@ -199,6 +201,7 @@ public:
 	void Forward(const Work* wk, int rows)
 	{
 		const NetDims& d = cfg.dims;
+		if (be.fused_forward(d_dims, wk, rows, wk == d_train)) return;     // one launch, one workgroup per sample (dtrl_trainer_fused.h); the check build takes the layer-by-layer form below
 		for (int l = 0; l < 3; ++l) be.gemm(d_dims, wk, make_gemm(d, rows, kConvFwd, l));
 		be.gemm(d_dims, wk, make_gemm(d, rows, kTerrFwd));
 		be.terr_reduce(d_dims, wk, rows * d.fc_terr, FTerrReduce{d_dims, wk});
@@ -209,15 +212,17 @@ public:
 	// gradient of the current net on the rows of `train` (dout filled), then the Caffe SGD update
 	void BackwardAndUpdate()
 	{
-		Backward();
 		const NetDims& d = cfg.dims;
+		if (be.fused_backward(d_dims, d_train, d, cfg.batch, SgdArgs{w_cur, hist, grad, rate_mult, decay_mult, cfg.base_lr, cfg.momentum, cfg.weight_decay, 1, static_cast<float>(cfg.batch)})) return;
+		Backward();
 		be.for_each(d.num_params, FSgdConv{d_dims, d_train, d.wo_terr, w_cur, hist, grad, rate_mult, decay_mult, cfg.base_lr, cfg.momentum, cfg.weight_decay});
 	}
 	// the data-parallel form: the flat gradient (conv partials reduced, sample count behind it) is left in `grad` for the caller's all-reduce; ApplyGrad updates
 	void BackwardOnly()
 	{
-		Backward();
 		const NetDims& d = cfg.dims;
+		if (be.fused_backward(d_dims, d_train, d, cfg.batch, SgdArgs{w_cur, hist, grad, rate_mult, decay_mult, cfg.base_lr, cfg.momentum, cfg.weight_decay, 0, static_cast<float>(cfg.batch)})) return;
+		Backward();
 		be.for_each(d.wo_terr + 1, FConvReduce{d_dims, d_train, d.wo_terr, grad, d.num_params, static_cast<float>(cfg.batch)});
 	}
 	void Backward()

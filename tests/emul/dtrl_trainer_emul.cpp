@@ -15,6 +15,10 @@ struct EmulTrainerBE {
 	const std::string& error() const { return err_; }
 	void set_stream(void*) {}
 	void drop_graphs() {}
+	// (the per-sample fused passes are device code: the check build always runs the layer-by-layer form, which is what the fused kernels are tested against)
+	void setup_fused(const NetDims&) {}
+	bool fused_forward(const NetDims*, const Work*, int, bool) { return false; }
+	template <class A> bool fused_backward(const NetDims*, const Work*, const NetDims&, int, const A&) { return false; }
 	void fork() {}
 	void resume() {}
 	void join() {}
