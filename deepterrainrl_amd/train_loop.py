@@ -311,7 +311,7 @@ def train_data_parallel(arg_file, data_root, global_envs, dist, max_iters=None, 
 
 
 def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, max_frames=None, extra_args=None, seed=0, device=None,
-                      trainer_device=None, local_device_id=-1, scenario_cls=BatchScenario, trainer="torch", trainer_lib=None, overlap=False, mode="gather"):
+                      trainer_device=None, local_device_id=-1, scenario_cls=BatchScenario, trainer="torch", trainer_lib=None, overlap=False, mode="gather", block_rows=None):
     """cScenarioTrain over several GPUs: one process per GPU (torch.distributed already initialised; backend "nccl" = RCCL on GPUs).
     Every rank rolls out its contiguous range of global env ids; each outer frame the ranks' drained MACE rows are gathered on rank 0
     (the only exchange on the experience side), rank 0 runs the trainer, then one broadcast carries [iteration, weights, normalisers]
@@ -323,7 +323,8 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
     spread out; always in the gloo tests' 32-env shards) the sequential mode equals train() in one process bit for bit and does not depend on the number of ranks.
     When a frame produces more rows than the block holds, the surplus is carried to later frames (never dropped): every tuple arrives exactly once and each env's
     tuples arrive in time order, but the interleaving across envs -- and with it the trainer's minibatches -- then depends on the block size and the number of
-    ranks. Pass block_rows = the worst case (2 x envs per rank) through ShardedRollout when run-to-run equality across world sizes matters more than the 1.2 MB block.
+    ranks. Pass block_rows = the worst case (2 x envs per rank) when run-to-run equality across world sizes matters more than the 1.2 MB block. Both schedules end
+    with a flush: gathers repeat until no rank's ring holds a carried row, so `tuples` == the rows the engines completed whatever the block size.
     mode="data_parallel": no trainer rank at all -- see train_data_parallel."""
     if mode == "data_parallel":      # no trainer rank: every rank trains on its own tuples, gradients all-reduced (train_data_parallel above)
         return train_data_parallel(arg_file, data_root, global_envs, dist, max_iters=max_iters, max_frames=max_frames, extra_args=extra_args, seed=seed,
@@ -338,7 +339,7 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
     def make(n, off):
         ea = dict(extra_args or {}); ea["global_env_offset"] = off
         return scenario_cls(arg_file, n, data_root=data_root, device_id=local_device_id, extra_args=ea)
-    sr = ShardedRollout(make, global_envs, dist=dist, device=device, pipelined=overlap)
+    sr = ShardedRollout(make, global_envs, dist=dist, device=device, pipelined=overlap, block_rows=block_rows)
     b = sr.batch
     t = None
     if rank == 0:
@@ -411,6 +412,15 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
                 sr.Update(1.0 / 30.0)
                 frames += 1
                 it = sync(consume(sr.gather_tuples(dst=0)))
+            # flush: rows a small block carried over (bursts above block_rows) still sit in some rank's ring; every rank takes part in every gather
+            got = False
+            while True:
+                tl = torch.tensor([b.TupleStats()["pending"]], dtype=torch.int64, device=sr.device)
+                dist.all_reduce(tl)
+                if int(tl.item()) == 0:
+                    break
+                got = consume(sr.gather_tuples(dst=0)) or got
+            it = sync(got)
     else:
         with side_ctx:
             sr.UpdateBegin(1.0 / 30.0)
@@ -450,5 +460,5 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
     dt = time.time() - t0
     out = dict(frames=frames, iters=it, seconds=dt, env_steps_per_s=frames * 20.0 * global_envs / dt, rank=rank, batch=b, phases=ph)
     if rank == 0:
-        out.update(tuples=tuples, weights=t.GetWeights(), offset_scale=t.GetOffsetScale())
+        out.update(tuples=tuples, weights=t.GetWeights(), offset_scale=t.GetOffsetScale(), carried_rows=sr.carried_rows)
     return out

@@ -590,6 +590,7 @@ def test_product_vs_frozen_reference_config_traces(da, om, run):
     state (configs[2]), goat + cliffs_rugged (configs[4]'s scene) -- torques, contact flags, FSM, actions, PD targets, policy states, counters, dist log."""
     info = T.run_product_vs_frozen_reference_config(da, om, *run, scenario=da.BatchScenario)
     print(run[0], info)
+    T.report_tracked("hip:" + run[0], info)
     assert info["tracked"] >= 0.6 * info["frames"] and info["cycles"] >= 5 and info["contact_frames"] >= 20, info
     assert info["resets_tracked"] >= min(1, T.CONFIG_MIN_RESETS[run[0]]), info
 

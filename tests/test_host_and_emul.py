@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import REFDATA, EmulScenario, GOLDEN, dog_policy
+from conftest import REFDATA, REPO, EmulScenario, GOLDEN, dog_policy
 
 Scenario = EmulScenario   # the GPU twin (tests/test_gpu_parity.py) points this at the product class
 
@@ -795,12 +795,26 @@ def run_product_vs_frozen_reference_config(da, om, tag, arg, seed, polname, extr
                 dist_log_equal=bool(len(d_log) == len(ref_log) and (len(ref_log) == 0 or np.abs(d_log - ref_log).max() < 1e-5)))
 
 
+def report_tracked(tag, info):
+    """The tracked fraction of a frozen-reference run goes on record even under `pytest -q`: as a warning (pytest's summary prints
+    warnings at any verbosity) and, where gpurun_out/ exists, as a line of gpurun_out/frozen_reference_tracking.txt."""
+    import warnings
+    line = "frozen-reference run %s: tracked %d of %d frames (%d resets, %d cycles); worst |dq| %.1e, |dtau| %.1e" % (
+        tag, info["tracked"], info["frames"], info["resets_tracked"], info["cycles"], info["worst"]["q"], info["worst"]["tau"])
+    warnings.warn(line)
+    out = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "frozen_reference_tracking.txt"), "a") as f:
+            f.write(line + "\n")
+
+
 @pytest.mark.parametrize("run", CONFIG_RUNS, ids=[r[0] for r in CONFIG_RUNS])
 def test_product_vs_frozen_reference_config_traces(da, om, run):
     """every BASELINE scene (configs[1] dog + slopes_mixed + MACE net through two falls, configs[2] raptor + narrow_gaps with the mirrored
     state, configs[4]'s goat + cliffs_rugged) has a product-vs-frozen-REFERENCE check that runs where /root/reference does not exist."""
     info = run_product_vs_frozen_reference_config(da, om, *run)
     print(run[0], info)
+    report_tracked(run[0], info)
     assert info["tracked"] >= 0.6 * info["frames"] and info["cycles"] >= 5 and info["contact_frames"] >= 20, info
     assert info["resets_tracked"] >= min(1, CONFIG_MIN_RESETS[run[0]]), info
 

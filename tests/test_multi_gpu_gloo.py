@@ -132,32 +132,38 @@ from conftest import REFDATA, EmulScenario
 from deepterrainrl_amd import train_loop
 dist.init_process_group(backend="gloo")
 st = train_loop.train_distributed("args/opt_args_train_mace.txt", REFDATA, 64, dist, max_frames=60, trainer_device="cpu", scenario_cls=EmulScenario, extra_args={extra!r},
-                                  trainer="hip", trainer_lib={lib!r}, overlap=True)
+                                  trainer="hip", trainer_lib={lib!r}, overlap={overlap!r}, block_rows={block_rows!r})
 drained = torch.tensor([st["batch"].TupleStats()["drained"], st["batch"].TupleStats()["dropped"], st["batch"].TupleStats()["pending"]], dtype=torch.int64)
 dist.all_reduce(drained)
 if dist.get_rank() == 0:
-    np.savez(os.path.join({out!r}, "overlap_train.npz"), weights=st["weights"], iters=st["iters"], tuples=st["tuples"], frames=st["frames"], drained=drained.numpy())
+    np.savez(os.path.join({out!r}, "overlap_train.npz"), weights=st["weights"], iters=st["iters"], tuples=st["tuples"], frames=st["frames"], drained=drained.numpy(),
+             carried=st["carried_rows"])
 dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_two_rank_overlapped_training_delivers_every_tuple(tmp_path, da):
-    """train_distributed(overlap=True) on two gloo ranks with the native trainer's check build: frames relaunched before the gather, rank 0 training on the
-    previous frame's rows, weights parked for the next launch -- every tuple the ranks' engines drained reaches the trainer exactly once, none dropped, the
-    trainer iterates and the weights stay finite."""
+@pytest.mark.parametrize("overlap,block_rows", [(True, None), (False, 2)], ids=["overlapped", "sequential_small_block"])
+def test_two_rank_training_delivers_every_tuple(tmp_path, da, overlap, block_rows):
+    """train_distributed on two gloo ranks with the native trainer's check build. overlapped: frames relaunched before the gather, rank 0 training on the
+    previous frame's rows, weights parked for the next launch. sequential_small_block: a send block of 2 rows per rank, far below the lock-step start's bursts
+    (32 envs per rank finish their first cycles within a few frames of each other) -- rows are carried from frame to frame and the run ends with the flush.
+    What is guaranteed either way: every tuple the ranks' engines completed reaches the trainer exactly once, none dropped, none left in a ring; the trainer
+    iterates and the weights stay finite."""
     lib = os.path.join(REPO, "tests", "emul", "libdtrl_trainer_emul.so")
     extra = {"terrain_seed": 3, "trainer_num_init_samples": 30, "trainer_replay_mem_size": 512, "trainer_freeze_target_iters": 4,
              "init_exp_rate": 0.3, "init_exp_base_rate": 0.1, "trainer_init_input_offset_scale": "false"}
     script = tmp_path / "overlap_worker.py"
-    script.write_text(OVERLAP_WORKER.format(repo=REPO, out=str(tmp_path), extra=extra, lib=lib))
+    script.write_text(OVERLAP_WORKER.format(repo=REPO, out=str(tmp_path), extra=extra, lib=lib, overlap=overlap, block_rows=block_rows))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29617" if overlap else "29619", str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = np.load(tmp_path / "overlap_train.npz")
     drained, dropped, pending = (int(x) for x in d["drained"])
     assert int(d["frames"]) == 60 and int(d["iters"]) >= 1 and np.all(np.isfinite(d["weights"]))
     assert int(d["tuples"]) == drained >= 40 and dropped == 0 and pending == 0
+    if block_rows:
+        assert int(d["carried"]) > 0          # the small block did carry rows (otherwise this case checks nothing)
 
 
 def test_shard_range():
