@@ -565,6 +565,34 @@ __device__ __forceinline__ real wave_shr1(real v)
 	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
 	return __hiloint2double(hi, lo);
 }
+template <int r, int K>
+__device__ __forceinline__ void pgs_rows_load(real (&a)[K], const WSFast& ws, int lane, bool mine, int R)
+{
+	if constexpr (r < K) {
+		if (r < R) {
+			const int mx = lane > r ? lane : r, mn = lane < r ? lane : r;
+			a[r] = ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0];
+			pgs_rows_load<r + 1, K>(a, ws, lane, mine, R);
+		}
+	}
+}
+template <int r, int K>
+__device__ __forceinline__ void pgs_rows_sweep(const real (&a)[K], real& w, real& lam, real rinv, bool tang, unsigned long long actR, int lane, int R)
+{
+	if constexpr (r < K) {
+		if (r < R) {
+			if ((actR >> r) & 1ull) {
+				const real lim = kMu * wave_shr1(lam);
+				const real lo = tang ? -lim : 0.0, hi = tang ? lim : __builtin_huge_val();
+				const real nl = fmin(fmax(fmadd(-w, rinv, lam), lo), hi);
+				const real dl = bcast(nl - lam, r);
+				if (lane == r) lam = nl;
+				w = fmadd(a[r], dl, w);
+			}
+			pgs_rows_sweep<r + 1, K>(a, w, lam, rinv, tang, actR, lane, R);
+		}
+	}
+}
 template <int kPgsRegRows>
 __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 {
@@ -582,22 +610,13 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 		// up to kPgsRegRows rows (per skeleton, dtrl_topo.h; eight until round 3, twelve until round 4): the lane's Delassus row lives in registers for all
 		// sweeps, no LDS read and no packed-index arithmetic per row update. Same operations on the same values as the general loop below. The rare
 		// substeps with many rows matter out of proportion: they are what the slowest envs of a launch do in EVERY substep (a character lying on the ground)
+		// The row sequences are NESTED (row r + 1 sits inside `if (r < R)` of row r), so a substep leaves them at its first absent row with one scalar compare + branch
+		// per row that exists: tested row by row, the 24 - R absent rows of the dog's instance cost 4 dependent SALU instructions each, ten sweeps per substep --
+		// +4 k cycles on the typical substep with 3 rows (round 4).
 		real a[kPgsRegRows];
-#pragma unroll
-		for (int r = 0; r < kPgsRegRows; ++r) { const int mx = lane > r ? lane : r, mn = lane < r ? lane : r; a[r] = ws.Apk[(mine && r < R) ? mx * (mx + 1) / 2 + mn : 0]; }
-		for (int it = 0; it < kPgsIters; ++it) {
-#pragma unroll
-			for (int r = 0; r < kPgsRegRows; ++r) {
-				if (r < R && ((act >> r) & 1ull)) {
-					const real lim = kMu * wave_shr1(lam);
-					const real lo = tang ? -lim : 0.0, hi = tang ? lim : inf;
-					const real nl = fmin(fmax(fmadd(-w, rinv, lam), lo), hi);
-					const real dl = bcast(nl - lam, r);
-					if (lane == r) lam = nl;
-					w = fmadd(a[r], dl, w);
-				}
-			}
-		}
+		pgs_rows_load<0, kPgsRegRows>(a, ws, lane, mine, R);
+		const unsigned long long actR = act & ((R < 64) ? ((1ull << R) - 1ull) : ~0ull);
+		for (int it = 0; it < kPgsIters; ++it) pgs_rows_sweep<0, kPgsRegRows>(a, w, lam, rinv, tang, actR, lane, R);
 		if (mine) ws.lam[lane] = lam;
 		__syncthreads();
 		return;

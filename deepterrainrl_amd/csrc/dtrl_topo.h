@@ -14,13 +14,19 @@ struct TopoDog {
 	// constraint rows the projected Gauss-Seidel keeps in registers (dtrl_kernel_fast.h pgs_solve_fast). A launch lasts as long as its slowest env, and the slowest
 	// envs of a frame are characters lying on 13-24 rows per substep: with every row count on the register path the dog's 2048-env launch went 4.71 -> 4.45 ms
 	// (16.7 -> 17.8 M env-steps/s, same box, profiles/r04_pgs_rows_ab.txt)
-	static constexpr int kPgsRegRows = 24;
+#ifndef DTRL_PGS_ROWS_DOG
+#define DTRL_PGS_ROWS_DOG 24
+#endif
+	static constexpr int kPgsRegRows = DTRL_PGS_ROWS_DOG;
 	static constexpr int parent(int l) { constexpr int p[L] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 0, 9, 10, 11, 5, 13, 14, 15, 0, 17, 18, 19}; return p[l]; }
 };
 struct TopoRaptor {
 	static constexpr int kId = 2;
 	static constexpr int L = 19;
-	static constexpr int kPgsRegRows = 12;   // (the raptor's kernel instance spills with more: 18.4 M at 12, 18.1 M at 18, 17.2 M at 24)
+#ifndef DTRL_PGS_ROWS_RAPTOR
+#define DTRL_PGS_ROWS_RAPTOR 16
+#endif
+	static constexpr int kPgsRegRows = DTRL_PGS_ROWS_RAPTOR;   // (nested row sequences, round 4: 18.65 M at 12, 18.88 M at 16, 18.82 M at 24 -- the raptor's instance pays for the registers of 24; flat sequences had 18.4 / 18.1 / 17.2 M at 12 / 18 / 24)
 	static constexpr int parent(int l) { constexpr int p[L] = {-1, 0, 1, 2, 3, 4, 0, 6, 7, 8, 9, 0, 11, 12, 13, 0, 15, 16, 17}; return p[l]; }
 };
 

@@ -199,7 +199,7 @@ def run_reference_vs_product_mace(rl, om, t, tol, freeze, get_w=None):
     R.close()
 
 
-@pytest.mark.parametrize("freeze", [0, 2])
+@pytest.mark.parametrize("freeze", [2])      # (freeze 0 is covered against the numpy restatement above and against the native step below; the torch peer takes 20 s per case)
 def test_reference_mace_trainer_vs_product_torch_trainer(rl, om, freeze):
     run_reference_vs_product_mace(rl, om, TT.make_trainer(mem_size=256, num_init_samples=100, seed=21, freeze_target_iters=freeze), 1e-10, freeze,
                                   get_w=lambda t: t.net.flat.detach().numpy().astype(np.float64))

@@ -1,13 +1,13 @@
 #!/bin/bash
 # One GPU-box visit at HEAD: the -m gpu suite, smoke(), the two bench configs' profiles, the trainer's rate + kernel table, the training loops.
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03_head
+O=$R/gpurun_out/r04_head
 mkdir -p $O
 cd $R
 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-bash tools/gpu_profile.sh r03_cfg1 1 > $O/prof1.log 2>&1
-bash tools/gpu_profile.sh r03_cfg2 2 > $O/prof2.log 2>&1
+bash tools/gpu_profile.sh r04_cfg1 1 > $O/prof1.log 2>&1
+bash tools/gpu_profile.sh r04_cfg2 2 > $O/prof2.log 2>&1
 python tools/trainer_rate.py --iters 1000 > $O/trainer_rate.log 2>&1; cat $O/trainer_rate.log | grep Train
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/tr_stats -o tr -- python $R/tools/trainer_rate.py --iters 100 --repeats 1 --only hip > $O/tr_stats.log 2>&1
