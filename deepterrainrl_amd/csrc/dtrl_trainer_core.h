@@ -51,7 +51,7 @@ struct FNewQ { Norm nm; const float* mem; int W; const int64_t* idx; const int64
 		newq[m] = (flags[row] & 1) ? r : r + discount * q;
 	} };
 // label (normalised) and the loss gradient of one output element. mode 0: caller's labels Y (un-normalised); 1: critic (y = the net's own output,
-// entry a[m] replaced by new_q); 2: actor (entries of fragment a[m] replaced by the tuple's action parameters)
+// entry a[m] replaced by new_q); 2: actor (entries of fragment a[m] replaced by the tuple's action parameters); 3-5: the single-head trainers (below)
 struct FLabelDout { int out_size; Norm nm; int mode; const float* Yext; const float* mem; int W, S; const int64_t* idx; const float* newq; int n_frags, frag_size; int rows;
 	const float* out; float* dout; float* sq;
 	TR_HD void operator()(int64_t i) const
@@ -62,9 +62,21 @@ struct FLabelDout { int out_size; Norm nm; int mode; const float* Yext; const fl
 		else {
 			y = unnorm_out(nm, out[i], j);
 			const size_t row = static_cast<size_t>(idx[m]);
+			if (mode >= 3) {
+				// single-head trainers. 3: cQNetTrainer::BuildProblemY (learning/QNetTrainer.cpp:57-83): the net's own outputs with the entry of the action taken
+				// (tuple.mAction.maxCoeff: the FIRST maximum of the one-hot block) replaced by new_q; 4: cCaclaTrainer's critic (learning/CaclaTrainer.cpp:234-277):
+				// the label is new_v; 5: its actor (BuildTupleActorY, :342-387): the action parameters the tuple carries
+				if (mode == 3) {
+					const float* act = mem + row * W + 1 + S;
+					int a = 0; for (int k = 1; k < out_size; ++k) if (act[k] > act[a]) a = k;
+					if (j == a) y = newq[m];
+				} else if (mode == 4) y = newq[m];
+				else y = mem[row * W + 1 + S + j];
+			} else {
 			const int a = static_cast<int>(mem[row * W + 1 + S]);
 			if (mode == 1) { if (j == a) y = newq[m]; }
 			else { const int c0 = n_frags + a * frag_size; if (j >= c0 && j < c0 + frag_size) y = mem[row * W + 2 + S + (j - c0)]; }
+			}
 		}
 		const float label = (y + nm.out_off[j]) * nm.out_scale[j];
 		const float e = out[i] - label;
@@ -72,12 +84,13 @@ struct FLabelDout { int out_size; Norm nm; int mode; const float* Yext; const fl
 		sq[i] = e * e;
 	} };
 // better[m] = new_q(s') > max_f Q_target(s)[f]; tout rows [0, n) = s, rows [n, 2n) = s'
-struct FActorFilter { Norm nm; const float* tout; int out_size, n_frags, n; const float* newq; int32_t* better;
+struct FActorFilter { Norm nm; const float* tout; int out_size, n_frags, n; const float* newq; int32_t* better; float* td = nullptr;
 	TR_HD void operator()(int64_t m) const
 	{
 		float q = unnorm_out(nm, tout[m * out_size], 0);
 		for (int f = 1; f < n_frags; ++f) { const float v = unnorm_out(nm, tout[m * out_size + f], f); q = v > q ? v : q; }
 		better[m] = newq[m] > q ? 1 : 0;
+		if (td) td[m] = newq[m] - q;       // the TD error cCaclaTrainer keeps beside the slot (learning/CaclaTrainer.cpp:365-378)
 	} };
 
 // the fused pass's targets in one launch: thread m < n -> new_q of critic row m; n <= m < 2 n -> candidate m - n: its new_q and the test against Q_target(s)
@@ -184,6 +197,7 @@ public:
 		// page-locked, device-visible: the host writes indices / reads the mask and the loss without a copy being queued
 		idx_host = static_cast<int64_t*>(HostAlloc(sizeof(int64_t) * 2 * cfg.max_eval));
 		better_host = static_cast<int32_t*>(HostAlloc(sizeof(int32_t) * cfg.max_eval));
+		td_host = static_cast<float*>(HostAlloc(sizeof(float) * cfg.max_eval));
 		loss_host = static_cast<float*>(HostAlloc(sizeof(float) * 4));
 		if (!be.ok()) { err = be.error(); return false; }
 		std::vector<float> ones(d.S > d.out_size ? d.S : d.out_size, 1.0f);
@@ -350,6 +364,59 @@ public:
 		be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 2, nullptr, mem_, W_, S, idx, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host + 1);
 		BackwardAndUpdate();
 	}
+	// ---- single-head trainers on replay rows [r | s | a (A entries) | s'] (n_frags == 0): the whole iteration in one recorded launch sequence ----
+	int ActionWidth() const { return W_ - 1 - 2 * cfg.dims.S; }
+	// kind 0 = cQNetTrainer::Step's solver iteration (learning/QNetTrainer.cpp:27-83, 142-163): new_q = r (1 - g) [+ g max_a' Q(s')[a'] unless the tuple failed] with the
+	//          net itself as reference (pool of one), label = own outputs with the taken action's entry replaced;
+	// kind 1 = cCaclaTrainer's critic iteration (learning/CaclaTrainer.cpp:149-157, 234-277): new_v = r (1 - g) [+ g V_target(s')], label = new_v.
+	// idx_host[0 .. batch) = the minibatch's slots; loss -> loss_host[0]
+	bool ValueStep(int kind)
+	{
+		if (!mem_ || cfg.n_frags != 0 || kind < 0 || kind > 1 || ActionWidth() < 1 || (kind == 0 && ActionWidth() != cfg.dims.out_size) || (kind == 1 && cfg.dims.out_size != 1)) return false;
+		be.run_graph(4 + kind, [this, kind] {
+			const NetDims& d = cfg.dims;
+			const int n = cfg.batch, S = d.S, A = ActionWidth();
+			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1 + S + A, eval.xin});
+			Forward((kind == 1 && cfg_target_frozen) ? d_eval_tgt : d_eval_cur, n);
+			be.for_each(n, FNewQ{norm(), mem_, W_, idx_host, flags_, eval.out, d.out_size, d.out_size, cfg.discount, newq});   // (the maximum over ALL outputs = the entry argmax picks)
+			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1, train.xin});
+			Forward(d_train, n);
+			be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 3 + kind, nullptr, mem_, W_, S, idx_host, newq, 0, 0, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host);
+			BackwardAndUpdate();
+		});
+		return be.ok();
+	}
+	// cCaclaTrainer::UpdateActorBatchBuffer's test (learning/CaclaTrainer.cpp:342-387) on the CRITIC's trainer: candidates idx_host[batch .. batch + n);
+	// td_host[m] = new_v(s') - V_target(s), better_host[m] = td > 0 (valid after Sync)
+	bool TdFilter(int n)
+	{
+		if (!mem_ || cfg.n_frags != 0 || cfg.dims.out_size != 1 || n <= 0 || 2 * n > cfg.max_eval || n > cfg.batch) return false;
+		const NetDims& d = cfg.dims;
+		const int S = d.S, A = ActionWidth();
+		const int64_t* idx = idx_host + cfg.batch;
+		const Work* tgt = cfg_target_frozen ? d_eval_tgt : d_eval_cur;
+		be.for_each(static_cast<int64_t>(2 * n) * S, FGatherMulti{S, norm(), mem_, W_, n, {idx, idx, nullptr, nullptr}, {1, 1 + S + A, 0, 0}, eval.xin});
+		Forward(tgt, 2 * n);
+		be.for_each(n, FNewQ{norm(), mem_, W_, idx, flags_, eval.out + static_cast<size_t>(n), 1, 1, cfg.discount, newq});
+		be.for_each(n, FActorFilter{norm(), eval.out, 1, 1, n, newq, better_host, td_host});
+		return be.ok();
+	}
+	// one solver iteration towards the action parameters the tuples carry (cCaclaTrainer's actor, BuildTupleActorY): slots idx_host[max_eval .. max_eval + batch)
+	// of the replay memory this trainer is bound to (the critic's); loss -> loss_host[0]
+	bool ActionStep()
+	{
+		if (!mem_ || cfg.n_frags != 0 || ActionWidth() != cfg.dims.out_size) return false;
+		be.run_graph(6, [this] {
+			const NetDims& d = cfg.dims;
+			const int n = cfg.batch, S = d.S;
+			const int64_t* idx = idx_host + cfg.max_eval;
+			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx, 1, train.xin});
+			Forward(d_train, n);
+			be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 5, nullptr, mem_, W_, S, idx, nullptr, 0, 0, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host);
+			BackwardAndUpdate();
+		});
+		return be.ok();
+	}
 	void UpdateTarget() { be.d2d(w_tgt, w_cur, sizeof(float) * cfg.dims.num_params); }
 
 	// ---- data-parallel step (SURVEY 5 last row; learning/ParamServer.cpp:65-90 is what it stands in for): gradient here, all-reduce at the caller, update here ----
@@ -411,7 +478,7 @@ public:
 	float *in_off = nullptr, *in_scale = nullptr, *out_off = nullptr, *out_scale = nullptr, *newq = nullptr, *sq = nullptr;
 	Work train{}, eval{};                 // host copies (pointers into device memory)
 	NetDims* d_dims = nullptr; Work* d_train = nullptr; Work* d_eval_cur = nullptr; Work* d_eval_tgt = nullptr;   // device-resident descriptors
-	int64_t* idx_host = nullptr; int32_t* better_host = nullptr; float* loss_host = nullptr;
+	int64_t* idx_host = nullptr; int32_t* better_host = nullptr; float* loss_host = nullptr; float* td_host = nullptr;
 	float* stage_rows = nullptr; int64_t* stage_flags = nullptr;
 
 private:

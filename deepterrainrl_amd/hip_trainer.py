@@ -30,6 +30,7 @@ TRAINER_ABI_SYMBOLS = [
     "dtrl_trainer_stage_rows", "dtrl_trainer_stage_flags", "dtrl_trainer_stage_capacity", "dtrl_trainer_add_staged",
     "dtrl_trainer_create_from_files", "dtrl_trainer_dims", "dtrl_trainer_init_xavier", "dtrl_trainer_eval_host", "dtrl_trainer_step_host", "dtrl_trainer_get_normalizers",
     "dtrl_trainer_copy_model", "dtrl_trainer_bind_grad", "dtrl_trainer_grad_device", "dtrl_trainer_grad_step", "dtrl_trainer_critic_grad", "dtrl_trainer_actor_grad", "dtrl_trainer_zero_grad", "dtrl_trainer_apply_grad",
+    "dtrl_trainer_value_step", "dtrl_trainer_td_filter", "dtrl_trainer_td", "dtrl_trainer_action_step",
 ]
 
 
@@ -76,6 +77,10 @@ def _bind(path):
     for name in ("critic_grad", "actor_grad", "zero_grad"):
         getattr(L, "dtrl_trainer_" + name).argtypes = [vp]
     L.dtrl_trainer_apply_grad.argtypes = [vp, C.c_int]
+    L.dtrl_trainer_value_step.argtypes = [vp, C.c_int]
+    L.dtrl_trainer_td_filter.argtypes = [vp, C.c_int]
+    L.dtrl_trainer_td.restype = C.POINTER(C.c_float); L.dtrl_trainer_td.argtypes = [vp]
+    L.dtrl_trainer_action_step.argtypes = [vp]
     return L
 
 
@@ -118,6 +123,7 @@ class NativeTrainer:
         self.idx = np.ctypeslib.as_array(self._lib.dtrl_trainer_idx(h), shape=(2 * self.max_eval,))
         self.better = np.ctypeslib.as_array(self._lib.dtrl_trainer_better(h), shape=(self.max_eval,))
         self.loss = np.ctypeslib.as_array(self._lib.dtrl_trainer_loss(h), shape=(4,))
+        self.td = np.ctypeslib.as_array(self._lib.dtrl_trainer_td(h), shape=(self.max_eval,))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -178,6 +184,9 @@ class NativeTrainer:
     def actor_grad(self): self._chk(self._lib.dtrl_trainer_actor_grad(self._h))
     def zero_grad(self): self._chk(self._lib.dtrl_trainer_zero_grad(self._h))
     def apply_grad(self, slot): self._chk(self._lib.dtrl_trainer_apply_grad(self._h, int(slot)))
+    def value_step(self, kind): self._chk(self._lib.dtrl_trainer_value_step(self._h, int(kind)))
+    def td_filter(self, n): self._chk(self._lib.dtrl_trainer_td_filter(self._h, int(n)))
+    def action_step(self): self._chk(self._lib.dtrl_trainer_action_step(self._h))
 
 
 class _HipNetSide:
@@ -533,18 +542,55 @@ class HipMACETrainerDP(HipMACETrainer):
             self.actor_batch_buffer += [t for t, b in zip(ids, better) if b]
 
 
-class HipQNetTrainer(_HipNetSide, QNetTrainer):
-    """cQNetTrainer (trainer.QNetTrainer: minibatch draw, Q targets) with the single-head net on the native step: two dtrl_trainer_eval passes and one
-    dtrl_trainer_step per iteration."""
+class _LossOnDemand:
+    """The loss of the last native iteration is read from page-locked memory when somebody asks, not after every step (no host wait inside Train())."""
+
+    @property
+    def last_loss(self):
+        if getattr(self, "_loss_pending", False):
+            self.nt.sync(); self._last_loss = float(self.nt.loss[0]); self._loss_pending = False
+        return None if self._last_loss is None else float(self._last_loss)
+
+    def _settle(self):
+        """a queued iteration must have read its index window before the host rewrites it"""
+        if getattr(self, "_loss_pending", False):
+            self.nt.sync(); self._last_loss = float(self.nt.loss[0]); self._loss_pending = False
+
+
+class HipQNetTrainer(_LossOnDemand, _HipNetSide, QNetTrainer):
+    """cQNetTrainer (trainer.QNetTrainer: minibatch draw) with the single-head net on the native step. Round 4: the whole iteration -- gather s', forward, new_q,
+    gather s, forward, labels (own outputs with the taken action's entry replaced), backward, SGD -- is ONE recorded launch sequence (dtrl_trainer_value_step, kind 0);
+    the host's part is the minibatch's slot indices in page-locked memory. native_targets=False keeps round 3's form (two dtrl_trainer_eval passes, the targets as
+    framework ops, dtrl_trainer_step)."""
+
+    native_targets = True
 
     def _q_problem(self, ids):
         self._order_staged()                    # replay rows stored from the staging area on the trainer's stream are read by framework ops here
         return super()._q_problem(ids)
 
+    def Step(self):
+        if not self.native_targets:
+            return super().Step()
+        if getattr(self, "_replay_dirty", False):
+            self._after_torch(); self._replay_dirty = False
+        ids = self.FetchMinibatch(self.batch)
+        if len(ids) >= self.batch:
+            self._settle()
+            self.nt.idx[:self.batch] = ids
+            self.nt.value_step(0)
+            self.solver_iter += 1
+            self._loss_pending = True
+        return True
 
-class HipCaclaTrainer(_HipNetSide, CaclaTrainer):
-    """cCaclaTrainer (trainer.CaclaTrainer: critic / actor schedule, TD-error filter) with BOTH single-head nets on the native step: this object's net is the
-    critic, self.actor is a HipQNetTrainer holding the actor net."""
+
+class HipCaclaTrainer(_LossOnDemand, _HipNetSide, CaclaTrainer):
+    """cCaclaTrainer (trainer.CaclaTrainer: critic / actor schedule, off-policy candidates) with BOTH single-head nets on the native step: this object's net is the
+    critic, self.actor is a HipQNetTrainer holding the actor net. Round 4: critic iteration = dtrl_trainer_value_step (kind 1), the candidates' TD test =
+    dtrl_trainer_td_filter (mask and TD errors read from page-locked memory after the one host wait of a Train()), actor iteration = dtrl_trainer_action_step on the
+    actor's trainer, which is bound to the critic's replay memory and runs on the critic's stream (one queue: stores, critic, filter, actor stay in program order)."""
+
+    native_targets = True
 
     def Reset(self):
         super().Reset()
@@ -552,6 +598,76 @@ class HipCaclaTrainer(_HipNetSide, CaclaTrainer):
         kw = dict(kw); kw.pop("dtype", None); kw.pop("use_graphs", None)
         self.actor = HipQNetTrainer(net_file, solver_file, S, A, lib_path=self._trainer_lib, **kw)
         self.actor_batch = self.actor.batch
+        self._actor_bound = False
+
+    def _bind_actor(self):
+        """the actor's trainer reads the tuples' states and actions from THIS trainer's replay memory, on this trainer's stream"""
+        if not self._actor_bound:
+            self.actor.nt.sync()
+            self.actor.nt.bind_replay(self.mem.data_ptr(), self.flags_dev.data_ptr(), self.W)
+            if self._stream is not None:
+                self.actor._stream = self._stream; self.actor.nt.set_stream(self._stream.cuda_stream)
+            self._actor_bound = True
+
+    def UseStream(self, stream_ptr):
+        super().UseStream(stream_ptr)
+        if self.device.type == "cuda":
+            self.actor.UseStream(stream_ptr)
+
+    def Step(self):
+        if not self.native_targets:
+            return super().Step()
+        if getattr(self, "_replay_dirty", False):
+            self._after_torch(); self._replay_dirty = False
+        self._bind_actor()
+        ids = self.FetchMinibatch(self.batch)
+        if len(ids) >= self.batch:
+            self._settle()
+            self.nt.idx[:self.batch] = ids
+            self.nt.value_step(1)
+            self.solver_iter += 1
+            self._loss_pending = True
+        self.UpdateActor()
+        if self.EnableTargetNet() and self.iter > 0 and self.iter % self.freeze_target_iters == 0:
+            self.nt.update_target()
+        return True
+
+    def UpdateActorBatchBuffer(self):
+        if not self.native_targets:
+            return super().UpdateActorBatchBuffer()
+        n = len(self.off_policy_buffer)
+        ids = []
+        for _ in range(min(self.actor_batch, n)):
+            t = self.off_policy_buffer[int(self.rng.randint(0, n))]
+            if t not in self.actor_batch_buffer and t not in ids:
+                ids.append(t)
+        if not ids:
+            return
+        k = len(ids)
+        self.nt.idx[self.batch:self.batch + k] = ids        # (the previous filter was waited for, so its window is free)
+        self.nt.td_filter(k)
+        self.nt.sync()                                       # the one host wait of a Train(): the mask decides what enters the actor batch buffer
+        if getattr(self, "_loss_pending", False):
+            self._last_loss = float(self.nt.loss[0]); self._loss_pending = False
+        for t, b, d in zip(ids, self.nt.better[:k].copy(), self.nt.td[:k].copy()):
+            if b:
+                self.actor_batch_buffer.append(t); self.actor_batch_td.append(float(d))
+
+    def UpdateActor(self):
+        if not self.native_targets:
+            return super().UpdateActor()
+        if self.stage_train:
+            self.UpdateActorBatchBuffer()
+        B = self.actor_batch
+        for _ in range(len(self.actor_batch_buffer) // B):
+            self.actor._settle()
+            ant = self.actor.nt
+            ant.idx[ant.max_eval:ant.max_eval + B] = self.actor_batch_buffer[:B]
+            ant.action_step()
+            self.actor._loss_pending = True
+            self.actor.solver_iter += 1
+            self.actor_iter += 1
+            del self.actor_batch_buffer[:B]; del self.actor_batch_td[:B]
 
     # the interface the training loop uses speaks for the ACTOR (what the rollout engine runs), as in trainer.CaclaTrainer
     def GetWeights(self): return self.actor.GetWeights()

@@ -129,6 +129,21 @@ int dtrl_trainer_zero_grad(dtrl_trainer* t);
 /* Caffe SGD update from the (summed) gradient buffer; the total row count lands in dtrl_trainer_loss()[slot], slot = 2 (critic round) or 3 (actor round); count 0 = no update */
 int dtrl_trainer_apply_grad(dtrl_trainer* t, int slot);
 
+/* ---- single-head trainers (n_frags == 0) on replay rows [r | s | a (A entries) | s']: one recorded launch sequence per iteration, no framework op between the
+ * minibatch's slots and the updated weights ----
+ * dtrl_trainer_value_step: slots dtrl_trainer_idx()[0 .. batch); loss -> dtrl_trainer_loss()[0].
+ *   kind 0 = cQNetTrainer's solver iteration (learning/QNetTrainer.cpp:27-83, 142-163): new_q = r (1 - discount) [+ discount max_a' Q(s')[a'] unless the tuple failed], the
+ *            net itself as reference net (pool of one); label = the net's own outputs, the entry of the action taken (first maximum of the one-hot block) := new_q. A == out_size.
+ *   kind 1 = cCaclaTrainer's critic iteration (learning/CaclaTrainer.cpp:149-157, 234-277): new_v = r (1 - discount) [+ discount V_target(s')]; label = new_v. out_size == 1. */
+int dtrl_trainer_value_step(dtrl_trainer* t, int kind);
+/* cCaclaTrainer::UpdateActorBatchBuffer's TD test (learning/CaclaTrainer.cpp:342-387) on the critic's trainer: candidates dtrl_trainer_idx()[batch .. batch + n), n <= batch;
+ * after dtrl_trainer_sync: dtrl_trainer_td()[m] = new_v(s'_m) - V_target(s_m), dtrl_trainer_better()[m] = (td > 0) */
+int dtrl_trainer_td_filter(dtrl_trainer* t, int n);
+float* dtrl_trainer_td(dtrl_trainer* t);
+/* cCaclaTrainer's actor iteration (BuildTupleActorY): one solver step of THIS net towards the action parameters of the tuples in slots dtrl_trainer_idx()[max_eval ..
+ * max_eval + batch) of the replay memory it is bound to (bind the actor's trainer to the critic's memory); A == out_size; loss -> dtrl_trainer_loss()[0] */
+int dtrl_trainer_action_step(dtrl_trainer* t);
+
 #ifdef __cplusplus
 }
 #endif

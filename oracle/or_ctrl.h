@@ -808,7 +808,7 @@ struct Env {
 				pert.torque = rx * pert.fy - ry * pert.fx;
 			}
 		}
-		for (int s = 0; s < M.num_sim_substeps; ++s) integ.Substep(M, rbd, ground, h, q, qd, tau_applied, &pert);  // UpdateWorld
+		for (int s = 0; s < M.num_sim_substeps; ++s) { integ.sub_ix = s; integ.Substep(M, rbd, ground, h, q, qd, tau_applied, &pert); }  // UpdateWorld
 		ForwardKin(M, q, qd, B);
 		{   // cContactManager::Update at the post-step configuration
 			ContactPoint tmp[1];

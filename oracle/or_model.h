@@ -71,6 +71,9 @@ struct OrcModel {
 	// uniform round-3 value contact_margin for every link
 	double link_margin[ORC_MAXL];
 	int32_t warm_start;    // experiment switch (-warm_start= 1): constraint rows start the sweeps from 0.85 x their previous impulse (oracle only: tools/a2_deviation.py)
+	// -mass_matrix_every= N: the joint-space inertia H(q) is rebuilt (and factorised) at every N-th substep of an env-step and held in between; bias forces, contact
+	// geometry and constraint Jacobians are evaluated at the current configuration in every substep. 1 = every substep (rounds 1-3)
+	int32_t mass_matrix_every;
 };
 
 // MACE network family of data/policies/*/nets/*_mace3_deploy.prototxt

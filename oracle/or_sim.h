@@ -274,13 +274,16 @@ struct Integrator {
 	// the body's COM plus the torque rel_pos x force evaluated when cWorld::Update applies it, and holds both over the substeps
 	struct PerturbForce { int link = -1; double fx = 0, fy = 0, torque = 0; bool on = false; };
 
+	int sub_ix = 0;                       // index of the substep within its env-step
+	double Hm[ORC_MAXD * ORC_MAXD];       // joint-space inertia the substep solves with
 	void Substep(const OrcModel& M, RBDModel& rbd, const Ground& ground, double h, double* q, double* qd, const double* tau, const PerturbForce* pf = nullptr)
 	{
 		const int D = rbd.D;
 		rbd.Update(q, qd, /*fix_cj=*/true);
 		Bodies B; ForwardKin(M, q, qd, B);
-		double Hm[ORC_MAXD * ORC_MAXD];
-		for (int i = 0; i < D; ++i) for (int k = 0; k < D; ++k) Hm[i * D + k] = rbd.H[i][k];
+		// -mass_matrix_every= N: H of the env-step's substeps 0, N, 2N ... is held for the substeps in between (sub_ix is set by the caller)
+		if (M.mass_matrix_every <= 1 || sub_ix % M.mass_matrix_every == 0)
+			for (int i = 0; i < D; ++i) for (int k = 0; k < D; ++k) Hm[i * D + k] = rbd.H[i][k];
 		double rhs[ORC_MAXD], dv[ORC_MAXD], v[ORC_MAXD];
 		for (int i = 0; i < D; ++i) rhs[i] = tau[i] - rbd.C[i];
 		if (pf && pf->on) {
