@@ -576,24 +576,34 @@ __device__ __forceinline__ void pgs_rows_load(real (&a)[K], const WSFast& ws, in
 		}
 	}
 }
-template <int r, int K>
-__device__ __forceinline__ void pgs_rows_sweep(const real (&a)[K], real& w, real& lam, real rinv, bool tang, unsigned long long actR, int lane, int R)
+// one sweep over rows r, r + 1, ...: rows below K read the lane's Delassus entry from registers, rows K .. kMaxRows - 1 (the tail only characters lying on the
+// ground reach) from LDS, fetched one row update ahead (a_pref) so that the load's latency sits under the previous row's dependent chain
+template <int r, int K, int kEnd>
+__device__ __forceinline__ void pgs_rows_sweep(const real (&a)[K], const WSFast& ws, real& w, real& lam, real rinv, bool tang, bool mine, unsigned long long actR, int lane, int R, real a_pref)
 {
-	if constexpr (r < K) {
+	if constexpr (r < kEnd) {
 		if (r < R) {
+			real a_sr;
+			if constexpr (r < K) a_sr = a[r]; else a_sr = a_pref;
+			real a_nx = 0.0;
+			if constexpr (r + 1 >= K && r + 1 < kEnd) {
+				constexpr int rn = r + 1;
+				const int mx = lane > rn ? lane : rn, mn = lane < rn ? lane : rn;
+				a_nx = ws.Apk[(mine && rn < R) ? mx * (mx + 1) / 2 + mn : 0];
+			}
 			if ((actR >> r) & 1ull) {
 				const real lim = kMu * wave_shr1(lam);
 				const real lo = tang ? -lim : 0.0, hi = tang ? lim : __builtin_huge_val();
 				const real nl = fmin(fmax(fmadd(-w, rinv, lam), lo), hi);
 				const real dl = bcast(nl - lam, r);
 				if (lane == r) lam = nl;
-				w = fmadd(a[r], dl, w);
+				w = fmadd(a_sr, dl, w);
 			}
-			pgs_rows_sweep<r + 1, K>(a, w, lam, rinv, tang, actR, lane, R);
+			pgs_rows_sweep<r + 1, K, kEnd>(a, ws, w, lam, rinv, tang, mine, actR, lane, R, a_nx);
 		}
 	}
 }
-template <int kPgsRegRows>
+template <int kPgsRegRows, bool kTailInSweep>
 __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 {
 	const int lane = opaque_lane();
@@ -604,23 +614,26 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 	if (mine) { const real ass = ws.Apk[lane * (lane + 3) / 2]; rinv = (ass >= 1e-12) ? 1.0 / ass : 0.0; }
 	const bool tang = mine && ws.row_kind[lane] == 2;
 	const unsigned long long act = __ballot(rinv != 0.0);
-	const int tri = lane * (lane + 1) / 2;
-	const real inf = __builtin_huge_val();
-	if (R <= kPgsRegRows) {
-		// up to kPgsRegRows rows (per skeleton, dtrl_topo.h; eight until round 3, twelve until round 4): the lane's Delassus row lives in registers for all
-		// sweeps, no LDS read and no packed-index arithmetic per row update. Same operations on the same values as the general loop below. The rare
-		// substeps with many rows matter out of proportion: they are what the slowest envs of a launch do in EVERY substep (a character lying on the ground)
-		// The row sequences are NESTED (row r + 1 sits inside `if (r < R)` of row r), so a substep leaves them at its first absent row with one scalar compare + branch
-		// per row that exists: tested row by row, the 24 - R absent rows of the dog's instance cost 4 dependent SALU instructions each, ten sweeps per substep --
-		// +4 k cycles on the typical substep with 3 rows (round 4).
+	// The lane's Delassus row: the first kPgsRegRows entries (per skeleton, dtrl_topo.h; eight until round 3, twelve in round 3) live in registers for all sweeps
+	// -- no LDS read and no packed-index arithmetic per row update -- and the entries of the tail rows come from LDS one update ahead. Same operations on the
+	// same values in the same order as pgs_solve() of dtrl_kernel.h. The rare substeps with many rows matter out of proportion: they are what the slowest envs of
+	// a launch do in EVERY substep (a character lying on the ground), and a launch lasts as long as its slowest env.
+	// The row sequences are NESTED (row r + 1 sits inside `if (r < R)` of row r), so a substep leaves them at its first absent row with one scalar compare + branch
+	// per row that exists: tested row by row, the 24 - R absent rows cost 4 dependent SALU instructions each, ten sweeps per substep -- +4 k cycles on the typical
+	// substep with 3 rows (round 4).
+	// Per skeleton (dtrl_topo.h, same-box A/B in profiles/r04_pgs_rows_ab.txt): the dog's instance keeps 20 rows in registers and runs the tail rows inside the same
+	// unrolled sweep (kTailInSweep); the raptor's pays for that longer sweep body with spills, keeps 16 and sends a substep with more rows through the plain loop below.
+	if (kTailInSweep || R <= kPgsRegRows) {
 		real a[kPgsRegRows];
 		pgs_rows_load<0, kPgsRegRows>(a, ws, lane, mine, R);
 		const unsigned long long actR = act & ((R < 64) ? ((1ull << R) - 1ull) : ~0ull);
-		for (int it = 0; it < kPgsIters; ++it) pgs_rows_sweep<0, kPgsRegRows>(a, w, lam, rinv, tang, actR, lane, R);
+		for (int it = 0; it < kPgsIters; ++it) pgs_rows_sweep<0, kPgsRegRows, (kTailInSweep ? kMaxRows : kPgsRegRows)>(a, ws, w, lam, rinv, tang, mine, actR, lane, R, 0.0);
 		if (mine) ws.lam[lane] = lam;
 		__syncthreads();
 		return;
 	}
+	const int tri = lane * (lane + 1) / 2;
+	const real inf = __builtin_huge_val();
 	real a_nx = mine ? ws.Apk[tri] : 0.0;   // column 0; the column of the next row update is fetched one update ahead
 	for (int it = 0; it < kPgsIters; ++it) {
 		for (int r = 0; r < R; ++r) {
@@ -716,7 +729,7 @@ struct FastPath {
 		}
 		if (R > 0) {
 			{ PROF_T0(); build_delassus_fast<D>(ws, h, dinv); PROF_ADD(ws, kProfDelassus); }
-			{ PROF_T0(); pgs_solve_fast<Topo::kPgsRegRows>(ws); PROF_ADD(ws, kProfPgs); }
+			{ PROF_T0(); pgs_solve_fast<Topo::kPgsRegRows, Topo::kPgsTailInSweep>(ws); PROF_ADD(ws, kProfPgs); }
 		}
 		{
 			PROF_T0();

@@ -635,12 +635,7 @@ class HipCaclaTrainer(_LossOnDemand, _HipNetSide, CaclaTrainer):
     def UpdateActorBatchBuffer(self):
         if not self.native_targets:
             return super().UpdateActorBatchBuffer()
-        n = len(self.off_policy_buffer)
-        ids = []
-        for _ in range(min(self.actor_batch, n)):
-            t = self.off_policy_buffer[int(self.rng.randint(0, n))]
-            if t not in self.actor_batch_buffer and t not in ids:
-                ids.append(t)
+        ids = self._draw_actor_candidates()
         if not ids:
             return
         k = len(ids)

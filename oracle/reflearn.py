@@ -90,9 +90,11 @@ class RefRandStream:
         self._L = lib()
         self._h = self._L.ref_learn_rand_new(int(seed))
 
-    def randint(self, lo, hi=None):
+    def randint(self, lo, hi=None, size=None):
         if hi is None:
             lo, hi = 0, lo
+        if size is not None:
+            return np.array([self.randint(lo, hi) for _ in range(size)], np.int64)
         return int(self._L.ref_learn_rand_int(self._h, int(lo), int(hi)))
 
     def __del__(self):

@@ -304,9 +304,11 @@ class _ReplayDraws:
     def __init__(self, draws):
         self.draws, self.k = [int(x) for x in draws], 0
 
-    def randint(self, lo, hi=None):
+    def randint(self, lo, hi=None, size=None):
         if hi is None:
             lo, hi = 0, lo
+        if size is not None:
+            return np.array([self.randint(lo, hi) for _ in range(size)], np.int64)
         v = self.draws[self.k]; self.k += 1
         assert lo <= v < hi, "the product asked for a draw the reference did not make at this point (%d not in [%d, %d))" % (v, lo, hi)
         return v

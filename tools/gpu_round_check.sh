@@ -18,6 +18,10 @@ for spec in "args/opt_args_train_mace.txt 4096" "args/opt_args_train_goat_mace.t
   echo "== $1 envs=$2 frames=600 trainer=hip --overlap" >> $O/train_loops.log
   python tools/train_mace.py --arg-file $1 --envs $2 --frames 600 --trainer hip --overlap 2>&1 | tail -2 >> $O/train_loops.log
 done
+for a in args/opt_args_train_q.txt args/opt_args_train_cacla.txt; do
+  echo "== $a envs=4096 frames=300 trainer=hip --overlap --init-samples 5000" >> $O/train_loops.log
+  python tools/train_mace.py --arg-file $a --envs 4096 --frames 300 --trainer hip --overlap --init-samples 5000 2>&1 | grep -a "env-steps/s" | tail -1 >> $O/train_loops.log
+done
 echo "== args/opt_args_train_mace.txt envs=4096 frames=600 trainer=hip (sequential)" >> $O/train_loops.log
 python tools/train_mace.py --arg-file args/opt_args_train_mace.txt --envs 4096 --frames 600 --trainer hip 2>&1 | tail -2 >> $O/train_loops.log
 cat $O/train_loops.log
