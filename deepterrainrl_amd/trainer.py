@@ -333,7 +333,7 @@ class MACETrainer:
         self.SetWeights(caffe_hdf5.load_mace_weights(model_file, self.num_frags))
 
     def GetIter(self): return self.iter
-    def GetNumTuples(self): return self.num_tuples
+    def GetNumTuples(self): return self.total_tuples      # cNeuralNetTrainer::GetNumTuples returns mTotalTuples (learning/NeuralNetTrainer.cpp:286-289): every tuple ever stored, not the ring's fill
     def EnableTargetNet(self): return self.freeze_target_iters > 0
     def UpdateTargetNet(self):
         """cMACETrainer::UpdateTargetNet; without freezing (freeze_target_iters == 0) the target IS the current net (GetTargetNetID)."""

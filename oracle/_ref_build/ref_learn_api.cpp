@@ -10,6 +10,8 @@
 #include "learning/MACETrainer.h"
 #include "learning/QNetTrainer.h"
 #include "learning/CaclaTrainer.h"
+#include "learning/NeuralNetLearner.h"
+#include "learning/ACLearner.h"
 #include "util/MathUtil.h"
 #include "util/Rand.h"
 #include "ref_learn_harness.h"
@@ -51,7 +53,12 @@ struct CaclaProbe : public cCaclaTrainer, public Probe {
 	const std::vector<int>* Buffer(int w) override { return w == 1 ? &mOffPolicyBuffer : w == 2 ? &mActorBatchBuffer : nullptr; }
 	int ActorIter() override { return mActorIter; }
 };
-struct Handle { std::shared_ptr<cNeuralNetTrainer> trainer; Probe* probe = nullptr; };
+struct Handle {
+	std::shared_ptr<cNeuralNetTrainer> trainer; Probe* probe = nullptr;
+	// the env side of the reference (scenarios/ScenarioExp*.cpp hand their tuple buffer to a cNeuralNetLearner; learning/NeuralNetLearner.cpp:33-46): a learner the
+	// trainer itself hands out (RequestLearner: cNeuralNetLearner, or cACLearner from cACTrainer), with nets of its own standing for the controller's
+	std::shared_ptr<cNeuralNetLearner> learner; std::unique_ptr<cNeuralNet> learner_net, learner_critic;
+};
 Eigen::VectorXd Vec(const double* p, int n) { Eigen::VectorXd v(n); for (int i = 0; i < n; ++i) v[i] = p[i]; return v; }
 }  // namespace
 
@@ -103,6 +110,30 @@ int ref_learn_add_tuple(void* hv, double reward, unsigned int flags, const doubl
 	return h->trainer->AddTuple(t);
 }
 void ref_learn_train(void* hv) { static_cast<Handle*>(hv)->trainer->Train(); }
+// cNeuralNetLearner::Train(tuples) (learning/NeuralNetLearner.cpp:33-46, unchanged): Lock, UpdateTrainer, AddTuples, Train, SyncNet (CopyModel of the trainer's net into the
+// learner's, i.e. the controller's), Unlock -- the call cScenarioExp makes when its tuple buffer is full. n rows of [reward | flags], states and actions as separate arrays.
+// Returns the harness id of the learner's (actor) net, whose parameters after the call are what the env threads would run with.
+int ref_learn_learner_train(void* hv, int n, const double* reward, const unsigned int* flags, const double* s_beg, const double* s_end, const double* action, int S, int A)
+{
+	Handle* h = static_cast<Handle*>(hv);
+	if (!h->learner) {
+		h->trainer->RequestLearner(h->learner);
+		h->learner_net.reset(new cNeuralNet());
+		h->learner->SetNet(h->learner_net.get());
+		if (auto ac = std::dynamic_pointer_cast<cACLearner>(h->learner)) { h->learner_critic.reset(new cNeuralNet()); ac->SetCriticNet(h->learner_critic.get()); }
+		h->learner->Init();        // LoadNet(trainer's net file) + SyncNet
+	}
+	std::vector<tExpTuple> tuples(static_cast<size_t>(n));
+	for (int i = 0; i < n; ++i) {
+		tExpTuple& t = tuples[static_cast<size_t>(i)];
+		t.mReward = reward[i]; t.mFlags = flags[i];
+		t.mStateBeg = Vec(s_beg + static_cast<size_t>(i) * S, S); t.mStateEnd = Vec(s_end + static_cast<size_t>(i) * S, S); t.mAction = Vec(action + static_cast<size_t>(i) * A, A);
+	}
+	h->learner->Train(tuples);
+	return NetId(h->learner_net);
+}
+int ref_learn_learner_iter(void* hv) { Handle* h = static_cast<Handle*>(hv); return h->learner ? h->learner->GetIter() : -1; }
+int ref_learn_learner_num_tuples(void* hv) { Handle* h = static_cast<Handle*>(hv); return h->learner ? h->learner->GetNumTuples() : -1; }
 int ref_learn_iter(void* hv) { return static_cast<Handle*>(hv)->trainer->GetIter(); }
 int ref_learn_actor_iter(void* hv) { return static_cast<Handle*>(hv)->probe->ActorIter(); }
 int ref_learn_stage(void* hv) { return static_cast<Handle*>(hv)->probe->Stage(); }

@@ -64,6 +64,8 @@ def lib(path=None):
         L.ref_learn_trainer_create.restype = vp; L.ref_learn_trainer_create.argtypes = [C.c_int, C.POINTER(Params)]
         L.ref_learn_trainer_destroy.argtypes = [vp]
         L.ref_learn_add_tuple.argtypes = [vp, C.c_double, C.c_uint, vp, vp, vp, C.c_int, C.c_int]
+        L.ref_learn_learner_train.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int]
+        L.ref_learn_learner_iter.argtypes = [vp]; L.ref_learn_learner_num_tuples.argtypes = [vp]
         for name in ("train",):
             getattr(L, "ref_learn_" + name).argtypes = [vp]
         for name in ("iter", "actor_iter", "stage", "head", "num_stored", "num_tuples", "batch_size", "state_size", "action_size", "num_pool", "actor_net", "mem_cols"):
@@ -212,6 +214,21 @@ class RefTrainer:
         return out
 
     def train(self): self._L.ref_learn_train(self._h)
+
+    def learner_train(self, rows, flags):
+        """cNeuralNetLearner::Train(tuples) of the reference (learning/NeuralNetLearner.cpp:33-46): AddTuples + Train + SyncNet through a learner the trainer handed out
+        (RequestLearner), exactly what cScenarioExp calls when its tuple buffer is full. Returns the harness net the learner synchronised (the env side's policy)."""
+        S, A = self.S, self.A
+        r = np.ascontiguousarray(np.asarray(rows, np.float64))
+        rew = np.ascontiguousarray(r[:, 0]); sb = np.ascontiguousarray(r[:, 1:1 + S]); ac = np.ascontiguousarray(r[:, 1 + S:1 + S + A]); se = np.ascontiguousarray(r[:, 1 + S + A:1 + 2 * S + A])
+        fl = np.ascontiguousarray(np.asarray(flags, np.uint32))
+        nid = self._L.ref_learn_learner_train(self._h, len(r), rew.ctypes.data, fl.ctypes.data, sb.ctypes.data, se.ctypes.data, ac.ctypes.data, S, A)
+        return self.harness.nets[nid] if self.harness is not None and hasattr(self.harness, "nets") else nid
+
+    @property
+    def learner_iter(self): return self._L.ref_learn_learner_iter(self._h)
+    @property
+    def learner_num_tuples(self): return self._L.ref_learn_learner_num_tuples(self._h)
     @property
     def iter(self): return self._L.ref_learn_iter(self._h)
     @property

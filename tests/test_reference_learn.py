@@ -88,6 +88,40 @@ def test_reference_mace_trainer_vs_numpy_restatement(rl, om, freeze):
     R.close()
 
 
+def test_reference_learner_route_vs_the_training_loops_chunk_protocol(rl, om):
+    """The ENV side of the reference's trainer seam, compiled unchanged: cNeuralNetLearner::Train(tuples) (learning/NeuralNetLearner.cpp:33-46 -- what cScenarioExp calls
+    when its tuple buffer is full: AddTuples, Train, SyncNet under the trainer's lock) through a learner the trainer itself handed out (RequestLearner), fed 32 tuples at a
+    time. Against it: the restatement driven chunk by chunk, and the PRODUCT's loop protocol train_loop.feed_chunks (AddTuples + Train per -tuple_buffer_size= tuples) on the
+    torch trainer. Bookkeeping identical after every chunk; the net the learner synchronised (the controller's, i.e. what the env threads would run) equals the trainer's."""
+    from deepterrainrl_amd import train_loop
+    rng = np.random.RandomState(9)
+    rows, flags = TT.random_rows(rng, 320, p_actor=0.5)
+    H = mace_harness(rl, om)
+    R = rl.RefTrainer("mace", H, TT.DEPLOY, TT.SOLVER, mem_size=256, num_init_samples=100, discount=0.9, freeze_target_iters=2, num_frags=NF, frag_size=FS, seed=77)
+    t = TT.make_trainer(mem_size=256, num_init_samples=100, seed=21, freeze_target_iters=2)
+    r = TT.make_ref_trainer(om, t, 21, freeze_target_iters=2)
+    r.rng = rl.RefRandStream(77)
+    t.rng = rl.RefRandStream(77)
+    w0 = t.GetWeights().astype(np.float64)
+    t.SetWeights(t.GetWeights())                 # (the fp64 peer starts from the float32-valued blobs as well)
+    r.set_weights(w0)
+    for i in range(R.num_pool()):
+        R.pool_net(i).w = w0.copy()
+    for k in range(0, 320, 32):
+        learner_net = R.learner_train(rows[k:k + 32], flags[k:k + 32])
+        r.add_tuples(rows[k:k + 32], flags[k:k + 32]); r.train()
+        train_loop.feed_chunks(t, rows[k:k + 32], flags[k:k + 32], 32)
+        st, b = book_state(R), r.book
+        assert st["critic"] == list(b.critic) and st["actor"] == list(b.actor) and st["actor_batch"] == list(b.actor_batch), k
+        assert (st["head"], st["num"], st["iter"], st["actor_iter"], st["stage"]) == (b.head, b.num, r.iter, r.actor_iter, r.stage_train), k
+        assert (R.learner_iter, R.learner_num_tuples) == (r.iter, k + 32) == (t.GetIter(), t.GetNumTuples()), k     # GetNumTuples = mTotalTuples: every tuple ever stored
+        assert np.array_equal(learner_net.w, R.pool_net(0).w), k                       # SyncNet: CopyModel of the trainer's net
+        assert np.abs(R.pool_net(0).w - r.w).max() <= 1e-12 * np.abs(r.w).max(), k
+        assert np.abs(t.net.flat.detach().numpy().astype(np.float64) - r.w).max() <= 1e-10 * np.abs(r.w).max(), k
+    assert r.iter == 7 and r.actor_iter >= 1 and np.abs(r.w - w0).max() > 1e-4
+    R.close()
+
+
 def q_harness(rl, om, deploys, out_sizes):
     """single-head nets (dog_q / dog_critic / dog_actor): the prototxt path picks the topology"""
     from oracle import trainer_ref as ref
