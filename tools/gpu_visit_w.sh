@@ -1,0 +1,8 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT
+cd $R
+for rep in 1 2 3; do
+for c in 1 2; do
+for v in h0 h1 h2 h3 h4; do python tools/ab/run_ab.py $R/tools/ab/libdtrl_$v.so $c 2; done
+done
+done
