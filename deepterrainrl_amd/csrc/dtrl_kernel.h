@@ -42,7 +42,7 @@
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LANES_BEGIN { const int lane = static_cast<int>(threadIdx.x);
-#define LANES_END } __syncthreads();
+#define LANES_END } ::dtrl::env_sync();
 #else
 #define LANES_BEGIN for (int lane = 0; lane < ::dtrl::kGroup; ++lane) {
 #define LANES_END }
@@ -64,6 +64,31 @@
 #endif
 
 namespace dtrl {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// The synchronisation point between two lane phases of ONE env. An env is one 64-lane wavefront = one whole workgroup (dtrl_backend_hip.hip), so there is nobody
+// to wait for: a wavefront's LDS (and memory) instructions are executed in program order, and what the phases need is only that the COMPILER keeps the accesses on
+// their side of the point. __syncthreads() asks for more -- its workgroup-scope fences become `s_waitcnt vmcnt(0) lgkmcnt(0)` (every outstanding LDS and memory
+// operation drained, a scheduling wall) although hipcc already drops the s_barrier of a one-wave workgroup -- so the env uses WAVEFRONT-scope fences around a wave
+// barrier (AMDGPU memory model: no instruction required at wavefront scope); the s_waitcnt a value actually needs is placed by the compiler where it is used.
+// -DDTRL_WAVE_SYNC=0 restores __syncthreads().
+#ifndef DTRL_WAVE_SYNC
+#define DTRL_WAVE_SYNC 1
+#endif
+__device__ __forceinline__ void env_sync()
+{
+#if DTRL_WAVE_SYNC
+	static_assert(kGroup == 64, "env_sync(): one wavefront per env");
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+	__syncthreads();
+#endif
+}
+#else
+inline void env_sync() {}      // (the lane-loop build runs a phase to its end before the next one starts)
+#endif
 
 enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfRows, kProfFsub, kProfDelassus, kProfPgs, kProfFinish, kProfCtrl, kProfAction, kProfFrameIO, kProfTotal, kProfRowsSum, kProfSubsteps, kProfP1, kProfP2, kProfP3, kProfP4, kProfR0, kProfR1_6, kProfR7_12, kProfR13_18, kProfR19_24, kProfT0, kProfT1_6, kProfT7_12, kProfT13_18, kProfT19_24, kProfNNConv, kProfNNFcTerr, kProfNNRest, kProfNNEvals, kProfC_Fsm, kProfC_Feedback, kProfC_PdSetup, kProfC_PdSolve, kProfC_Grav, kProfC_Tail, kProfMax };
 
@@ -433,7 +458,7 @@ DTRL_HD inline void kin_dyn_terms(W& ws)
 			}
 		}
 	}
-	__syncthreads();
+	env_sync();
 #else
 	LANES_BEGIN
 	if (lane < ws.M.L) {
@@ -1125,7 +1150,7 @@ DTRL_HD inline void conv_tile(W& ws, const float* Wd, const float* bias, int co,
 #pragma unroll
 		for (int q = 0; q < NB; ++q) { a0[q] = n0[q]; a1[q] = n1[q]; }
 	}
-	__syncthreads();
+	env_sync();
 #pragma unroll
 	for (int r = 0; r < 4; ++r) {
 		const int o0 = 4 * r + g, o1 = 16 + o0;
@@ -1133,7 +1158,7 @@ DTRL_HD inline void conv_tile(W& ws, const float* Wd, const float* bias, int co,
 		if (nv < 0) { out[o0 * os + j] = v0; if (two) out[o1 * os + j] = v1; }
 		else if (j < nv) { out[o0 * nv + j] = v0; if (two) out[o1 * nv + j] = v1; }
 	}
-	__syncthreads();
+	env_sync();
 #else
 	constexpr int kPer = kMaxConvCh * kConvTile / kGroup;
 	LANE_LOCAL(real, acc, kPer);
@@ -1991,7 +2016,7 @@ DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, co
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DTRL_PROFILE)
 	const unsigned long long prof_frame_t0 = __builtin_readcyclecounter();
 	if (threadIdx.x < kProfMax) ws.prof[threadIdx.x] = 0;
-	__syncthreads();
+	env_sync();
 #endif
 	load_hot_model(ws, gm);
 	LANES_BEGIN
@@ -2040,7 +2065,7 @@ DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, co
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DTRL_PROFILE)
 	if (buf.prof && n_steps > 0) {
 		if (threadIdx.x == 0) ws.prof[kProfTotal] += __builtin_readcyclecounter() - prof_frame_t0;
-		__syncthreads();
+		env_sync();
 		if (threadIdx.x < kProfMax) buf.prof[static_cast<int64_t>(env) * kProfMax + threadIdx.x] += ws.prof[threadIdx.x];
 	}
 #endif

@@ -53,7 +53,7 @@ __device__ __forceinline__ void mass_row(WSFast& ws, real (&h)[D])
 #pragma unroll
 		for (int e = 0; e < (kFill / 2 + kGroup - 1) / kGroup; ++e) if (d + e * kGroup < kFill / 2) T2[d + e * kGroup] = z2;
 	}
-	__syncthreads();
+	env_sync();
 	if (hinge) {
 		const int base = l * (l + 5) / 2;
 		const real m = ws.sm[l], mx = ws.smx[l], my = ws.smy[l];
@@ -70,14 +70,14 @@ __device__ __forceinline__ void mass_row(WSFast& ws, real (&h)[D])
 		const real pax = ws.px[a], pay = ws.py[a];
 		T[pl * (pl + 5) / 2 + 2 + a] = I - ((plx + pax) * mx + (ply + pay) * my) + m * (plx * pax + ply * pay);
 	}
-	__syncthreads();
+	env_sync();
 	const real M0 = ws.sm[0];
 	const real* Tl = T + (d < D ? d : 0);
 	h[0] = (d == 0) ? M0 : 0.0;
 	h[1] = (d == 1) ? M0 : 0.0;
 #pragma unroll
 	for (int c = 2; c < D; ++c) h[c] = Tl[(c - 2) * (c + 3) / 2];   // base_{c-2} + lane
-	__syncthreads();   // T is dead; the storage may be reused
+	env_sync();   // T is dead; the storage may be reused
 }
 
 // ---- lane-predicated updates through EXEC ----
@@ -204,11 +204,11 @@ __device__ __forceinline__ real factorize_regs(WSFast& ws, real (&h)[Topo::L + 2
 	real* S = ws.Apk;
 #pragma unroll
 	for (int k = 1; k < D; ++k) if (lane < k) S[k * (k - 1) / 2 + lane] = h[k];
-	__syncthreads();
+	env_sync();
 	const int base = lane * (lane - 1) / 2;
 #pragma unroll
 	for (int k = 0; k < D - 1; ++k) if (lane > k && lane < D) h[k] = S[base + k];
-	__syncthreads();
+	env_sync();
 	return dinv;
 }
 // z = U^-1 rhs (lane i holds component i): from the last DoF up
@@ -284,7 +284,7 @@ __device__ __noinline__ unsigned link_cap_drop_mask(WSFast& ws, real d0, real d1
 	if (lane < npts) S[lane] = d0;
 	if (lane + kGroup < npts) S[lane + kGroup] = d1;
 	if (lane + 2 * kGroup < npts) S[lane + 2 * kGroup] = d2;
-	__syncthreads();
+	env_sync();
 	auto over = [&](real d, int pt) -> unsigned {
 		if (!(d > 0)) return 0u;
 		const int base = (pt / kPtsPerLink) * kPtsPerLink;
@@ -293,7 +293,7 @@ __device__ __noinline__ unsigned link_cap_drop_mask(WSFast& ws, real d0, real d1
 		return rank >= kMaxPtsPerLink ? 1u : 0u;
 	};
 	const unsigned m = over(d0, lane) | (over(d1, lane + kGroup) << 1) | (over(d2, lane + 2 * kGroup) << 2);
-	__syncthreads();
+	env_sync();
 	return m;
 }
 // kFlags: also find the points within contact_tol of the surface (the per-link contact flags the controller reads: only the post-step pass needs them)
@@ -333,7 +333,7 @@ __device__ __noinline__ unsigned row_cap_drop_mask(WSFast& ws, real d0, real d1,
 	if (lane < npts) S[lane] = d0;
 	if (lane + kGroup < npts) S[lane + kGroup] = d1;
 	if (lane + 2 * kGroup < npts) S[lane + 2 * kGroup] = d2;
-	__syncthreads();
+	env_sync();
 	auto over = [&](real d, int pt) -> unsigned {
 		if (!(d > 0)) return 0u;
 		int rank = 0;
@@ -341,7 +341,7 @@ __device__ __noinline__ unsigned row_cap_drop_mask(WSFast& ws, real d0, real d1,
 		return rank >= cap ? 1u : 0u;
 	};
 	const unsigned m = over(d0, lane) | (over(d1, lane + kGroup) << 1) | (over(d2, lane + 2 * kGroup) << 2);
-	__syncthreads();
+	env_sync();
 	return m;
 }
 // ---- link--link contacts on the wave: one lane per pair decides whether the two boxes can touch at all (hot path: a dozen instructions, almost always
@@ -378,13 +378,13 @@ __device__ __noinline__ int append_pair_rows_fast(WSFast& ws, const DevModel& gm
 		if (__builtin_expect(__ballot(lane < kPairSlots * kPairCands && mine_cnt > kMaxPtsPerPair) != 0ull, 0)) {
 			real* S = ws.Apk;   // (dead between the factorisation and the Delassus build, like in link_cap_drop_mask())
 			S[lane] = hit.active ? hit.depth : -1.0;
-			__syncthreads();
+			env_sync();
 			if (hit.active) {
 				int rank = 0;
 				for (int o = 0; o < kPairCands; ++o) { const real od = S[slot * kPairCands + o]; rank += (o != cand && od > 0 && (od > hit.depth || (od == hit.depth && o < cand))) ? 1 : 0; }
 				keep = rank < kMaxPtsPerPair;
 			}
-			__syncthreads();
+			env_sync();
 		}
 		const unsigned long long km = __ballot(keep);
 		const int room = (kMaxRows - R) / 2;
@@ -413,7 +413,7 @@ __device__ __forceinline__ void detect_contacts_fast(WSFast& ws, const DevModel&
 {
 	const ContactPts c = eval_points<true>(ws, gm, g);
 	contact_bits_fast(ws, c.f0, c.f1, c.f2);
-	__syncthreads();
+	env_sync();
 }
 __device__ __forceinline__ void emit_contact_rows(WSFast& ws, const PtVal& p, int pt, int rank, int cap, int R0, real inv_h)
 {
@@ -463,7 +463,7 @@ __device__ __forceinline__ void build_rows_fast(WSFast& ws, const DevModel& gm, 
 	const unsigned long long reach = pairs_in_reach(ws);
 	if (__builtin_expect(reach != 0ull, 0)) R = append_pair_rows_fast(ws, gm, R, reach);
 	if (lane == 0) ws.R = R;
-	__syncthreads();
+	env_sync();
 }
 
 // Delassus matrix A = Z D^-1 Z^T, entry-parallel: the R (R + 1) / 2 lower-triangle entries are dealt round-robin to all 64
@@ -507,9 +507,9 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 			if (i < R && c <= i) ws.Apk[i * (i + 1) / 2 + c] = acc[r];
 			if (i < R && c == R) ws.wv[i] = acc[r];               // zz_i, finished below
 		}
-		__syncthreads();
+		env_sync();
 		if (lane < R) ws.wv[lane] = jv + h * ws.wv[lane] - ws.row_tgt[lane];
-		__syncthreads();
+		env_sync();
 		return;
 	}
 	const real* di = ws.dinv;   // general path (16+ rows, 0.2 % of the substeps): entry-parallel dot products
@@ -550,7 +550,7 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 		for (int i = 0; i < D; ++i) a = fmadd(zs[i] * di[i], zr[i], a);
 		ws.Apk[e] = a;
 	}
-	__syncthreads();
+	env_sync();
 }
 
 // projected Gauss-Seidel in lambda space with the row state in registers: lane s owns row s (w_s, lambda_s, 1/A_ss, kind).
@@ -629,7 +629,7 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 		const unsigned long long actR = act & ((R < 64) ? ((1ull << R) - 1ull) : ~0ull);
 		for (int it = 0; it < kPgsIters; ++it) pgs_rows_sweep<0, kPgsRegRows, (kTailInSweep ? kMaxRows : kPgsRegRows)>(a, ws, w, lam, rinv, tang, mine, actR, lane, R, 0.0);
 		if (mine) ws.lam[lane] = lam;
-		__syncthreads();
+		env_sync();
 		return;
 	}
 	const int tri = lane * (lane + 1) / 2;
@@ -650,7 +650,7 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 		}
 	}
 	if (mine) ws.lam[lane] = lam;
-	__syncthreads();
+	env_sync();
 }
 
 template <class Topo>
@@ -670,7 +670,7 @@ struct FastPath {
 		const int rows_ready = kin_valid ? ws.n_pts_active : -1;   // wave-uniform
 		if (rows_ready >= 0) {
 			if (lane == 0) { ws.R = rows_ready; ws.n_pts_active = -1; }
-			__syncthreads();
+			env_sync();
 		} else {
 			ContactPts cp;
 			{ PROF_T0(); cp = eval_points<false>(ws, gm, g); PROF_ADD(ws, kProfDetect); }   // the per-link contact flags are the post-step pass's business (contacts() below)
@@ -724,7 +724,7 @@ struct FastPath {
 				if (lane < D) ws.Z[r0][lane] = z[0];
 			}
 			if (lane < D) ws.dinv[lane] = dinv;   // the Delassus product reads 1/d per DoF from LDS
-			__syncthreads();
+			env_sync();
 			PROF_ADD(ws, kProfFsub);
 		}
 		if (R > 0) {
@@ -741,7 +741,7 @@ struct FastPath {
 			}
 			u = utsolve_regs<D>(hrow, u);
 			if (lane < D) { const real v = clamp_turn_rate(ws.st.qd[lane] + u, lane, h); ws.st.qd[lane] = v; ws.st.q[lane] += h * v; }
-			__syncthreads();
+			env_sync();
 			PROF_ADD(ws, kProfFinish);
 		}
 #if defined(DTRL_PROFILE)
@@ -761,10 +761,10 @@ struct FastPath {
 		z = usolve_regs<D>(hrow, z);
 		real u = z * dinv;
 		u = utsolve_regs<D>(hrow, u);
-		__syncthreads();
+		env_sync();
 		if (lane < D) ws.u[lane] = u;
 		if (lane == 0) ws.R = 0;
-		__syncthreads();
+		env_sync();
 	}
 	// cContactManager::Update at the post-step configuration: the controller needs the per-link flags; the same pass builds the row list of
 	// the next env-step's first substep (same q, same heightfield window within a launch)
@@ -774,7 +774,7 @@ struct FastPath {
 		contact_bits_fast(ws, cp.f0, cp.f1, cp.f2);
 		build_rows_fast(ws, gm, cp, h);
 		if (threadIdx.x == 0) ws.n_pts_active = ws.R;
-		__syncthreads();
+		env_sync();
 	}
 };
 
