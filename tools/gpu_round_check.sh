@@ -28,3 +28,8 @@ cat $O/train_loops.log
 # the exchange through a one-rank RCCL group and the training loop across ranks (one rank)
 DTRL_FORCE_COLLECTIVES=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_forced_rccl.json
 python tools/train_mace.py --distributed --overlap --envs 4096 --frames 600 --trainer hip 2>&1 | grep "distributed" > $O/train_distributed.log; cat $O/train_distributed.log
+# per-section cycles of the frame kernel (profile build) for both configs, and a short soak
+cd $R
+python tools/gpu_sections.py 4096 60 1 > $O/sections_cfg1.txt 2>&1
+python tools/gpu_sections.py 8192 60 2 > $O/sections_cfg2.txt 2>&1
+python tools/soak.py 4096 1500 2>&1 | tail -2 > $O/soak.txt; cat $O/soak.txt
