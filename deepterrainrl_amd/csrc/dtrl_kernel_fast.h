@@ -565,9 +565,6 @@ __device__ __forceinline__ real wave_shr1(real v)
 	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
 	return __hiloint2double(hi, lo);
 }
-#ifndef DTRL_PGS_KIND_BRANCH
-#define DTRL_PGS_KIND_BRANCH 0
-#endif
 template <int r, int K>
 __device__ __forceinline__ void pgs_rows_load(real (&a)[K], const WSFast& ws, int lane, bool mine, int R)
 {
@@ -582,7 +579,7 @@ __device__ __forceinline__ void pgs_rows_load(real (&a)[K], const WSFast& ws, in
 // one sweep over rows r, r + 1, ...: rows below K read the lane's Delassus entry from registers, rows K .. kMaxRows - 1 (the tail only characters lying on the
 // ground reach) from LDS, fetched one row update ahead (a_pref) so that the load's latency sits under the previous row's dependent chain
 template <int r, int K, int kEnd>
-__device__ __forceinline__ void pgs_rows_sweep(const real (&a)[K], const WSFast& ws, real& w, real& lam, real rinv, bool tang, bool mine, unsigned long long actR, unsigned long long tangR, int lane, int R, real a_pref)
+__device__ __forceinline__ void pgs_rows_sweep(const real (&a)[K], const WSFast& ws, real& w, real& lam, real rinv, bool tang, bool mine, unsigned long long actR, int lane, int R, real a_pref)
 {
 	if constexpr (r < kEnd) {
 		if (r < R) {
@@ -595,22 +592,16 @@ __device__ __forceinline__ void pgs_rows_sweep(const real (&a)[K], const WSFast&
 				a_nx = ws.Apk[(mine && rn < R) ? mx * (mx + 1) / 2 + mn : 0];
 			}
 			if ((actR >> r) & 1ull) {
-#if DTRL_PGS_KIND_BRANCH
-				// wave-uniform branch on the kind of row r (only lane r's candidate counts): a normal / limit row needs neither the friction bound of the row before it
-				// nor the upper clamp (fmin(x, inf) = x)
-				real nl;
-				if ((tangR >> r) & 1ull) { const real lim = kMu * wave_shr1(lam); nl = fmin(fmax(fmadd(-w, rinv, lam), -lim), lim); }
-				else nl = fmax(fmadd(-w, rinv, lam), 0.0);
-#else
+				// (a wave-uniform branch on the kind of row r -- normal rows need neither the friction bound nor the upper clamp -- was measured twice, round 1 and
+				// round 4 under the ILP scheduler: -6 % / -3 %. The selects are cheaper than the branch.)
 				const real lim = kMu * wave_shr1(lam);
 				const real lo = tang ? -lim : 0.0, hi = tang ? lim : __builtin_huge_val();
 				const real nl = fmin(fmax(fmadd(-w, rinv, lam), lo), hi);
-#endif
 				const real dl = bcast(nl - lam, r);
 				if (lane == r) lam = nl;
 				w = fmadd(a_sr, dl, w);
 			}
-			pgs_rows_sweep<r + 1, K, kEnd>(a, ws, w, lam, rinv, tang, mine, actR, tangR, lane, R, a_nx);
+			pgs_rows_sweep<r + 1, K, kEnd>(a, ws, w, lam, rinv, tang, mine, actR, lane, R, a_nx);
 		}
 	}
 }
@@ -638,8 +629,7 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 		real a[kPgsRegRows];
 		pgs_rows_load<0, kPgsRegRows>(a, ws, lane, mine, R);
 		const unsigned long long actR = act & ((R < 64) ? ((1ull << R) - 1ull) : ~0ull);
-		const unsigned long long tangR = __ballot(tang);
-		for (int it = 0; it < kPgsIters; ++it) pgs_rows_sweep<0, kPgsRegRows, (kTailInSweep ? kMaxRows : kPgsRegRows)>(a, ws, w, lam, rinv, tang, mine, actR, tangR, lane, R, 0.0);
+		for (int it = 0; it < kPgsIters; ++it) pgs_rows_sweep<0, kPgsRegRows, (kTailInSweep ? kMaxRows : kPgsRegRows)>(a, ws, w, lam, rinv, tang, mine, actR, lane, R, 0.0);
 		if (mine) ws.lam[lane] = lam;
 		env_sync();
 		return;
