@@ -240,7 +240,7 @@ struct HipTrainerBE {
 		}
 		chk(hipGraphLaunch(exec_[key], stream), "hipGraphLaunch");
 	}
-	static constexpr int kMaxGraphs = 8;
+	static constexpr int kMaxGraphs = 12;
 	hipGraphExec_t exec_[kMaxGraphs] = {};
 	bool graph_failed_ = false;
 	~HipTrainerBE() { for (hipGraphExec_t e : exec_) if (e) hipGraphExecDestroy(e); if (side_) { hipStreamDestroy(side_); hipEventDestroy(ev_fork_); hipEventDestroy(ev_join_); } }

@@ -436,28 +436,32 @@ public:
 	bool CriticGrad()
 	{
 		if (!mem_ || cfg.n_frags <= 0) return false;
-		const NetDims& d = cfg.dims;
-		const int n = cfg.batch, S = d.S, A = 1 + cfg.frag_size;
-		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1 + S + A, eval.xin});
-		Forward(cfg_target_frozen ? d_eval_tgt : d_eval_cur, n);
-		be.for_each(n, FNewQ{norm(), mem_, W_, idx_host, flags_, eval.out, d.out_size, cfg.n_frags, cfg.discount, newq});
-		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1, train.xin});
-		Forward(d_train, n);
-		be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host);
-		BackwardOnly();
+		be.run_graph(7, [this] {      // (recorded like the fused steps; BindGrad drops the recordings, they carry the gradient buffer's address)
+			const NetDims& d = cfg.dims;
+			const int n = cfg.batch, S = d.S, A = 1 + cfg.frag_size;
+			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1 + S + A, eval.xin});
+			Forward(cfg_target_frozen ? d_eval_tgt : d_eval_cur, n);
+			be.for_each(n, FNewQ{norm(), mem_, W_, idx_host, flags_, eval.out, d.out_size, cfg.n_frags, cfg.discount, newq});
+			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1, train.xin});
+			Forward(d_train, n);
+			be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host);
+			BackwardOnly();
+		});
 		return be.ok();
 	}
 	// the actor batch idx_host[max_eval .. max_eval + batch): everything of ActorStep but the update
 	bool ActorGrad()
 	{
 		if (!mem_ || cfg.n_frags <= 0) return false;
-		const NetDims& d = cfg.dims;
-		const int n = cfg.batch, S = d.S;
-		const int64_t* idx = idx_host + cfg.max_eval;
-		be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx, 1, train.xin});
-		Forward(d_train, n);
-		be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 2, nullptr, mem_, W_, S, idx, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host + 1);
-		BackwardOnly();
+		be.run_graph(8, [this] {
+			const NetDims& d = cfg.dims;
+			const int n = cfg.batch, S = d.S;
+			const int64_t* idx = idx_host + cfg.max_eval;
+			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx, 1, train.xin});
+			Forward(d_train, n);
+			be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 2, nullptr, mem_, W_, S, idx, nullptr, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host + 1);
+			BackwardOnly();
+		});
 		return be.ok();
 	}
 	// a rank without a batch this round contributes nothing: gradient and count zero

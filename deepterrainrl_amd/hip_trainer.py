@@ -445,6 +445,8 @@ class HipMACETrainerDP(HipMACETrainer):
             self.grad = torch.from_numpy(np.ctypeslib.as_array(g))
         self.world = dist.get_world_size() if dist is not None else 1
         self.collective_s = 0.0
+        # DTRL_FORCE_COLLECTIVES=1 (as for sharding.ShardedRollout): issue the gradient all-reduces on a one-rank group too -- the RCCL path on a 1-GPU box
+        self.force_collectives = os.environ.get("DTRL_FORCE_COLLECTIVES", "0") == "1"
 
     def _allreduce_grad(self):
         if self.dist is None or self.world == 1 and not getattr(self, "force_collectives", False):

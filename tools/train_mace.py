@@ -20,9 +20,10 @@ ap.add_argument("--reserve-cus", type=int, default=None, help="compute units per
 ap.add_argument("--init-samples", type=int, default=None, help="override -trainer_num_init_samples= (the arg files collect 50 000 tuples before the first iteration: ~235 frames of 4096 dogs)")
 ap.add_argument("--poll", action="store_true", help="with --overlap: relaunch env groups between Train() calls (dtrl_step_poll; measured: no gain on one GPU)")
 ap.add_argument("--distributed", action="store_true", help="train_loop.train_distributed: sharded rollout + tuple gather to rank 0 + policy broadcast (RCCL). Start with torch.distributed.run for N ranks; alone it runs a one-rank RCCL group (DTRL_FORCE_COLLECTIVES=1), the config-3/4 loop shape on one GPU")
+ap.add_argument("--data-parallel", action="store_true", help="with --distributed: no trainer rank -- every rank trains on its own tuples, gradients all-reduced (train_distributed(mode=\"data_parallel\"))")
 ap.add_argument("--out", default=None, help="write weights (.npy) and <out>_scale.txt")
 a = ap.parse_args()
-reserve = a.reserve_cus if a.reserve_cus is not None else (1 if a.distributed else 0)   # (the exchange's collective and read-backs beside the rollout: 11.0 M with one unit per XCD set aside, 9.6 M without)
+reserve = a.reserve_cus if a.reserve_cus is not None else (1 if (a.distributed and not a.data_parallel) else 0)   # (the exchange's collective and read-backs beside the rollout: 11.0 M with one unit per XCD set aside, 9.6 M without)
 if a.distributed:
     import torch, torch.distributed as dist
     os.environ.setdefault("DTRL_FORCE_COLLECTIVES", "1")
@@ -34,11 +35,12 @@ if a.distributed:
     world = dist.get_world_size()
     ea = dict(({"trainer_num_init_samples": a.init_samples} if a.init_samples is not None else {}), **({"reserve_cus": reserve} if reserve else {})) or None
     st = train_loop.train_distributed(a.arg_file, a.data_root, a.envs * world, dist, max_iters=a.iters, max_frames=a.frames, extra_args=ea, device="cuda:%d" % lr,
-                                      trainer_device="cuda:%d" % lr, local_device_id=lr, trainer=a.trainer, overlap=a.overlap)
+                                      trainer_device="cuda:%d" % lr, local_device_id=lr, trainer=a.trainer, overlap=a.overlap, mode="data_parallel" if a.data_parallel else "gather")
     if dist.get_rank() == 0:
-        print("[distributed x%d, trainer=%s, overlap=%s] frames %d  trainer iters %d  tuples %d  %.1f s  ->  %.2f M env-steps/s while training (all ranks), %.1f trainer iters/s" % (
-            world, a.trainer, a.overlap, st["frames"], st["iters"], st["tuples"], st["seconds"], st["env_steps_per_s"] / 1e6, st["iters"] / st["seconds"]))
-        print("   [distributed] rank 0 host wall-clock by phase (ms per frame): " + "  ".join("%s %.2f" % (k, 1e3 * v / max(st["frames"], 1)) for k, v in st["phases"].items()))
+        print("[distributed x%d%s, trainer=%s, overlap=%s] frames %d  trainer iters %d  tuples %d  %.1f s  ->  %.2f M env-steps/s while training (all ranks), %.1f trainer iters/s" % (
+            world, " data-parallel" if a.data_parallel else "", a.trainer, a.overlap, st["frames"], st["iters"], st["tuples"], st["seconds"], st["env_steps_per_s"] / 1e6, st["iters"] / st["seconds"]))
+        if "phases" in st:
+            print("   [distributed] rank 0 host wall-clock by phase (ms per frame): " + "  ".join("%s %.2f" % (k, 1e3 * v / max(st["frames"], 1)) for k, v in st["phases"].items()))
     dist.barrier(); dist.destroy_process_group()
     sys.exit(0)
 st = train_loop.train(a.arg_file, a.data_root, a.envs, max_iters=a.iters, max_frames=a.frames, log_every=50, overlap=a.overlap, frames_per_drain=a.frames_per_drain,
