@@ -94,7 +94,7 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("trainer,frames", [("torch", 90), ("hip", 45)])
+@pytest.mark.parametrize("trainer,frames", [("torch", 60), ("hip", 45)])
 def test_two_rank_training_equals_single_process(tmp_path, da, trainer, frames):
     """Rollout shards + tuple gather + trainer on rank 0 + policy broadcast (gloo, world size 2) == train() in one process, bit for bit -- with the PyTorch
     peer trainer and with the native trainer step (its plain-loop check build here; rows reach it through the staging area on both sides)."""

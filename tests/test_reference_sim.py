@@ -369,7 +369,7 @@ def test_integrator_v1_vs_bullet_shaped_sequential_impulse_bands(om):
     import sys
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import a2_deviation as a2
-    jobs = min(4, os.cpu_count() or 1)
+    jobs = min(8, os.cpu_count() or 1)
 
     def pair(scene, seeds, frames, si_opts=None, v1_overrides=None):
         v1 = a2.run(scene, "v1", seeds, frames, v1_overrides=v1_overrides, jobs=jobs)
