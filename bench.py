@@ -93,6 +93,25 @@ def load_scale(cfg):
 EXCHANGE_GUARD_S = 180   # wall-clock bound of the exchange leg on a multi-rank run (see main)
 
 
+def host_parallelism():
+    """CPUs this process may actually use: the affinity mask, cut down to the cgroup's CPU quota where there is one (the GPU boxes report 256 logical CPUs and run
+    the job under cpu.max = 16 CPUs: 256 threads there are 16 CPUs' worth of throttled time slices)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                                       # cgroup v2
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    try:                                                       # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            n = min(n, max(1, int(q / p + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(cfg, frames=60):
     """The oracle restatement (NOT Bullet -- the reference cannot be built here) timed on the host cores, bounded sample."""
     from oracle import model as om
@@ -100,18 +119,20 @@ def cpu_baseline(cfg, frames=60):
     desc = om.parse_deploy_prototxt(os.path.join(ROOT, info["args"]["policy_net"]))
     w = om.xavier_weights(desc, 1234)
     io, isc, oo, osc = load_scale(cfg)
-    cores = os.cpu_count() or 1
-    envs_per_thread = 8
-    n_envs = cores * envs_per_thread
+    cores = host_parallelism()                  # threads used = CPUs this process can run on at once (cgroup quota respected)
+    n_envs = 2048                                # the same bounded sample whatever the thread count
+    envs_per_thread = (n_envs + cores - 1) // cores
+    n_envs = envs_per_thread * cores
     t0 = time.time()
     rate, resets, cycles = om.batch_run(m, n_envs, cores, frames, terrain_seed0=0, rng_seed=0, policy=(desc, w, io, isc, oo, osc))
     wall = time.time() - t0
     # the single-thread figure beside the all-cores one (one thread, 8 envs, the same frames)
     t1 = time.time()
-    rate1, _, _ = om.batch_run(m, envs_per_thread, 1, frames, terrain_seed0=0, rng_seed=0, policy=(desc, w, io, isc, oo, osc))
+    rate1, _, _ = om.batch_run(m, 8, 1, frames, terrain_seed0=0, rng_seed=0, policy=(desc, w, io, isc, oo, osc))
     return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs (%d per thread) x %d frames x 20 env-steps of the same workload on the fp64 oracle restatement (not Bullet), %.1f s wall" % (n_envs, envs_per_thread, frames, wall),
-            "single_thread": {"value": rate1, "unit": "env-steps/s", "cores": 1, "sample": "%d envs x %d frames x 20 env-steps on one thread, %.1f s wall" % (envs_per_thread, frames, time.time() - t1)}}
+            "single_thread": {"value": rate1, "unit": "env-steps/s", "cores": 1, "sample": "%d envs x %d frames x 20 env-steps on one thread, %.1f s wall" % (8, frames, time.time() - t1)},
+            "logical_cpus": os.cpu_count() or 1}
 
 
 def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bcast_every, w, scale, reserve_cus, force_collectives=None):
