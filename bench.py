@@ -253,7 +253,7 @@ def main():
                     help="host: the reference's terrain generator streams (bit-exact windows), regenerated by host workers at the frame boundary (default, the parity-tested mode); "
                          "device: counter-based streams, windows generated and slid by the GPU, no host sync per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=60, help="outer frames of the bounded CPU-baseline sample (default: 20-30 s of CPU work on the box's 256 threads)")
+    ap.add_argument("--cpu-frames", type=int, default=60, help="outer frames of the bounded CPU-baseline sample (default: 15-30 s of CPU work on the CPUs the box grants)")
     ap.add_argument("--exchange-steps", type=int, default=-1, help="timed frames of the exchange leg (default: half of --steps, at least 50; 0 = skip)")
     ap.add_argument("--bcast-every", type=int, default=10, help="exchange leg: policy broadcast every K frames")
     ap.add_argument("--no-rccl-leg", action="store_true", help="1-GPU run: do not open a one-rank RCCL group for the exchange leg (the leg then runs without any collective)")
