@@ -270,7 +270,7 @@ def main():
     cfg = CONFIGS[a.config]
     n = a.envs_per_gpu or cfg["envs"]
     # frame-boundary host workers (terrain regeneration): the ranks of a node share its cores (the engine applies the same rule from LOCAL_WORLD_SIZE)
-    host_threads = int(os.environ.get("DTRL_HOST_THREADS", "0")) or max(1, min(16, (os.cpu_count() or 2) // (2 * max(1, local_world))))
+    host_threads = int(os.environ.get("DTRL_HOST_THREADS", "0")) or max(2, min(16, host_parallelism() // (2 * max(1, local_world))))   # (CPUs the cgroup grants, not logical CPUs: 4 / 8 / 16 threads measured equal at one rank)
     if a.dry_launch:
         rec = json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus_arg": a.gpus, "envs_per_gpu": n,
                           "global_env_offset": rank * n, "device": "cuda:%d" % local_rank, "host_threads": host_threads, "config": a.config})
