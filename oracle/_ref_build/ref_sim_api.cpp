@@ -138,7 +138,7 @@ void ref_scn_update(void* h, double dt) { static_cast<RefScn*>(h)->scn->Update(d
 // Physics = oracle/or_bullet_si.h: the stand-in world's stepSimulation(dt, n, dt / n) runs n sequential-impulse substeps on the reference's rigid bodies,
 // hinges and ground shapes (Bullet 2.8x's published algorithm and defaults), and the contact points it worked with are handed to the dispatcher as
 // manifolds, so that the reference's cContactManager derives its flags from them as it would from Bullet's. opts (NULL = defaults), in order:
-// iterations, erp, erp2, split_impulse, split_threshold, warmstarting, warmstart_factor, breaking, max_points, use_margin, link_contacts, safe_margin, relative_breaking, vertex_contacts, friction_warmstart
+// iterations, erp, erp2, split_impulse, split_threshold, warmstarting, warmstart_factor, breaking, max_points, use_margin, link_contacts, safe_margin, relative_breaking, vertex_contacts, friction_warmstart, friction_skip, friction_dir, interleave, friction_ws_lifted (the last four: diagnostics, see bsi::Params)
 void ref_scn_use_bullet_si(void* h, const double* opts, int n_opts)
 {
 	RefScn* s = static_cast<RefScn*>(h);
@@ -150,6 +150,7 @@ void ref_scn_use_bullet_si(void* h, const double* opts, int n_opts)
 	p.breaking = opt(7, p.breaking); p.max_points = static_cast<int>(opt(8, p.max_points)); p.use_margin = static_cast<int>(opt(9, p.use_margin)); p.link_contacts = static_cast<int>(opt(10, p.link_contacts));
 	p.safe_margin = static_cast<int>(opt(11, p.safe_margin)); p.relative_breaking = static_cast<int>(opt(12, p.relative_breaking));
 	p.vertex_contacts = static_cast<int>(opt(13, p.vertex_contacts)); p.friction_warmstart = static_cast<int>(opt(14, p.friction_warmstart));
+	p.friction_skip = static_cast<int>(opt(15, p.friction_skip)); p.friction_dir = static_cast<int>(opt(16, p.friction_dir)); p.interleave = static_cast<int>(opt(17, p.interleave)); p.friction_ws_lifted = static_cast<int>(opt(18, p.friction_ws_lifted));
 	btDiscreteDynamicsWorld* world = s->scn->GetWorld()->GetInternalWorld().get();
 	world->getConstraintSolver()->m_resetHook = [s]() { if (s->si) s->si->Reset(); };
 	world->m_stepHook = [s, world](btScalar dt, int substeps, btScalar fixed) {

@@ -59,7 +59,7 @@ class OrcModel(C.Structure):
         ("scenario", C.c_int32), ("tuple_buffer_size", C.c_int32), ("enable_explore", C.c_int32),
         ("exp_rate", C.c_double), ("exp_temp", C.c_double), ("exp_base_rate", C.c_double),
         ("link_contacts", C.c_int32), ("n_cpairs", C.c_int32), ("cpair_a", C.c_int32 * MAXCP), ("cpair_b", C.c_int32 * MAXCP),
-        ("contact_margin", C.c_double), ("link_margin", C.c_double * MAXL), ("warm_start", C.c_int32), ("mass_matrix_every", C.c_int32),
+        ("contact_margin", C.c_double), ("link_margin", C.c_double * MAXL), ("warm_start", C.c_int32), ("link_brk", C.c_double * MAXL), ("mass_matrix_every", C.c_int32),
     ]
 
 
@@ -269,7 +269,10 @@ def build_model(arg_file, root, overrides=None):
     for j in range(L):
         he = min(0.5 * m.body_size[j][k] for k in range(3))
         m.link_margin[j] = min(m.contact_margin, 0.1 * he) if safe else m.contact_margin
-    m.warm_start = int(args.get("warm_start", 0))
+    m.warm_start = int(args.get("warm_start", 1))
+    brk = float(args.get("contact_breaking", 0.02))   # gContactBreakingThreshold x the box's angular-motion disc |half extents| (the world scale cancels)
+    for j in range(L):
+        m.link_brk[j] = brk * 0.5 * (m.body_size[j][0] ** 2 + m.body_size[j][1] ** 2 + m.body_size[j][2] ** 2) ** 0.5
     m.mass_matrix_every = max(1, int(args.get("mass_matrix_every", 1)))
     m.terrain_type = 0
     m.n_terrain_sets = 1

@@ -39,6 +39,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -63,6 +65,10 @@ struct Params {
 	int max_points = 4;              // MANIFOLD_CACHE_SIZE
 	int use_margin = 1;              // box margins (0 = sharp boxes, distance without margin)
 	int link_contacts = 1;           // box-box contacts between same-group, not hinge-linked links
+	int friction_skip = 1;           // diagnostic: Bullet resolves a friction row only while its normal row carries an impulse (solveSingleIteration: `if (totalImpulse > 0)`); 0 = always (the box clamps to +-mu x 0)
+	int friction_dir = 1;            // diagnostic: 1 = Bullet's direction (along the relative tangential velocity, else plane space); 0 = always the plane-space vector
+	int friction_ws_lifted = 1;      // diagnostic: 0 = a point above the surface (dist > 0) does not warm start its friction row
+	int interleave = 0;              // diagnostic: 1 = each contact's normal row followed by its friction row (Integrator v1's order) instead of all normals, then all friction rows
 	double limit_bias = 0.3, limit_relax = 1.0;   // btHingeConstraint::setLimit defaults (_biasFactor, _relaxationFactor)
 };
 
@@ -102,6 +108,8 @@ public:
 	Params prm;
 	std::vector<Contact> contacts;       // of the last substep (published to the dispatcher by the harness)
 	long substeps = 0;
+	bool diag_on = std::getenv("BSI_DIAG") != nullptr; double diag[2][5][5] = {};
+	~Solver() { if (diag_on) for (int g = 0; g < 2; ++g) { std::fprintf(stderr, "BSI_DIAG %s substeps %ld\n", g ? "link-link" : "ground", substeps); const char* nm[5] = {"skipped,imp!=0 count", "skipped sum|imp|", "resolved count", "resolved sum|imp|", "skipped,imp==0 count"}; for (int k = 0; k < 5; ++k) { std::fprintf(stderr, "  %-22s", nm[k]); for (int b = 0; b < 5; ++b) std::fprintf(stderr, " %12.4g", diag[g][k][b]); std::fprintf(stderr, "\n"); } } }
 
 	void Reset() { cache_.clear(); contacts.clear(); }
 	const btRigidBody* BodyOf(int i) const { return (i >= 0 && i < static_cast<int>(bodies_.size())) ? bodies_[i].rb : nullptr; }
@@ -129,12 +137,24 @@ public:
 		if (prm.split_impulse) for (int it = 0; it < prm.iterations; ++it) for (size_t r = n_joint_rows_; r < rows_.size(); ++r) if (rows_[r].normal_row < 0 && rows_[r].contact >= 0) ResolvePush(rows_[r]);
 		for (int it = 0; it < prm.iterations; ++it) {
 			for (int r = 0; r < n_joint_rows_; ++r) Resolve(rows_[r]);
-			for (size_t r = n_joint_rows_; r < rows_.size(); ++r) if (rows_[r].normal_row < 0) Resolve(rows_[r]);
-			for (size_t r = n_joint_rows_; r < rows_.size(); ++r) if (rows_[r].normal_row >= 0) {
-				Row& f = rows_[r];
+			auto friction = [&](Row& f) {
 				const double tot = rows_[f.normal_row].imp;
-				if (tot > 0) { f.lo = -f.mu * tot; f.hi = f.mu * tot; Resolve(f); }
+				if (tot > 0 || !prm.friction_skip) { f.lo = -f.mu * tot; f.hi = f.mu * tot; Resolve(f); }
+			};
+			if (prm.interleave) {
+				for (size_t r = n_joint_rows_; r < rows_.size(); ++r) { if (rows_[r].normal_row < 0) Resolve(rows_[r]); else friction(rows_[r]); }
+				continue;
 			}
+			for (size_t r = n_joint_rows_; r < rows_.size(); ++r) if (rows_[r].normal_row < 0) Resolve(rows_[r]);
+			for (size_t r = n_joint_rows_; r < rows_.size(); ++r) if (rows_[r].normal_row >= 0) friction(rows_[r]);
+		}
+		if (diag_on) for (size_t r = n_joint_rows_; r < rows_.size(); ++r) if (rows_[r].normal_row >= 0) {
+			const Row& f = rows_[r]; const Contact& c = contacts[f.contact];
+			const int g = c.b >= 0 ? 1 : 0;
+			const bool skipped = !(rows_[f.normal_row].imp > 0);
+			const int bin = c.dist < -1e-3 ? 0 : c.dist < 0 ? 1 : c.dist < 1e-4 ? 2 : c.dist < 1e-3 ? 3 : 4;
+			if (skipped) { if (f.imp != 0) { diag[g][0][bin] += 1; diag[g][1][bin] += std::fabs(f.imp); } else diag[g][4][bin] += 1; }
+			else { diag[g][2][bin] += 1; diag[g][3][bin] += std::fabs(f.imp); }
 		}
 		// write back: velocities, cached impulses, transforms
 		for (size_t r = n_joint_rows_; r < rows_.size(); ++r) {
@@ -488,13 +508,13 @@ private:
 			const double rvx = vax - vbx, rvy = vay - vby, rn = rvx * c.nx + rvy * c.ny;
 			double tx = rvx - rn * c.nx, ty = rvy - rn * c.ny;
 			const double t2 = tx * tx + ty * ty;
-			if (t2 > SIMD_EPSILON) { const double tl = std::sqrt(t2); tx /= tl; ty /= tl; } else { tx = -c.ny; ty = c.nx; }
+			if (t2 > SIMD_EPSILON && prm.friction_dir) { const double tl = std::sqrt(t2); tx /= tl; ty /= tl; } else { tx = -c.ny; ty = c.nx; }
 			Row f; f.a = c.a; f.b = c.b; f.contact = static_cast<int>(ci); f.normal_row = ni; f.mu = c.mu;
 			f.nax = tx; f.nay = ty; f.aa = rax * ty - ray * tx; f.nbx = -tx; f.nby = -ty; f.ab = -(rbx * ty - rby * tx);
 			Finish(f);
 			f.rhs = -RelVel(f) * f.dinv;
 			f.lo = 0; f.hi = 0;   // set from the normal impulse inside the iterations
-			f.imp = (prm.warmstarting && prm.friction_warmstart) ? c.jt * prm.warmstart_factor : 0.0;
+			f.imp = (prm.warmstarting && prm.friction_warmstart && (prm.friction_ws_lifted == 1 || (prm.friction_ws_lifted == 0 && !(c.dist > 0)) || (prm.friction_ws_lifted == 2 && c.dist > 0) || (prm.friction_ws_lifted == 3 && c.b < 0) || (prm.friction_ws_lifted == 4 && c.b >= 0))) ? c.jt * prm.warmstart_factor : 0.0;
 			if (f.imp != 0) Apply(f, f.imp);
 			rows_.push_back(f);
 		}

@@ -70,7 +70,20 @@ struct OrcModel {
 	// thin link carries a thin margin and the box core never inverts: dog / goat toe 2.5 mm, torso 7.5 mm at ANY world scale. -safe_margin= 0 restores the
 	// uniform round-3 value contact_margin for every link
 	double link_margin[ORC_MAXL];
-	int32_t warm_start;    // experiment switch (-warm_start= 1): constraint rows start the sweeps from 0.85 x their previous impulse (oracle only: tools/a2_deviation.py)
+	// Bullet's contact persistence (round 5; sim/World.cpp:61-77 builds a default btSequentialImpulseConstraintSolver, whose btContactSolverInfo has
+	// SOLVER_USE_WARMSTARTING with factor 0.85 on the persistent manifold points' applied NORMAL and FRICTION impulses):
+	//   warm_start 1 (default, what the product kernels run): a contact row (ground: sample point; link--link: pair + candidate) keeps its identity across substeps
+	//     and env-steps and starts the sweeps from 0.85 x the impulse it ended the previous substep with (limit rows start from zero: the solver zeroes the rows of
+	//     typed constraints); a sweep resolves the limit rows, then every normal row, then every friction row (solveSingleIteration's order), and a friction row
+	//     only while its normal row carries an impulse (`if (totalImpulse > 0)`), so that the cached friction impulse of a contact without normal force stays applied;
+	//   warm_start 0: every row from zero, one interleaved sweep (rounds 1-4).
+	//   Oracle-only ablations (tools/a2_deviation.py): 2 = as 1 with the interleaved sweep; 3 = as 1 with Bullet's friction direction (along the pre-solve
+	//     tangential velocity, else plane space); 4 = plain warm start of every row without the friction rule (round 4's -warm_start= 1).
+	int32_t warm_start;
+	// contact_breaking (default 0.02 = gContactBreakingThreshold, relative: btCollisionDispatcher's default CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD): a ground
+	// sample point carries rows while it is within link_brk[j] = contact_breaking x |half extents| ABOVE the surface (the persistent manifold keeps such a point;
+	// its normal row lets it approach by its distance per substep: Bullet's `velocityError -= penetration / dt` for positive distance). 0 = rows only while penetrating
+	double link_brk[ORC_MAXL];
 	// -mass_matrix_every= N: the joint-space inertia H(q) is rebuilt (and factorised) at every N-th substep of an env-step and held in between; bias forces, contact
 	// geometry and constraint Jacobians are evaluated at the current configuration in every substep. 1 = every substep (rounds 1-3)
 	int32_t mass_matrix_every;

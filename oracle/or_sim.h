@@ -11,7 +11,9 @@
 // Model (one substep of length h):
 //   H(q) v+ = H v + h (tau - b(q,v)) + J^T lambda,   q+ = q + h v+
 //   rows of J: joint limits within limit_slop of a stop (unit rows) and, per penetrating contact sample point, a normal and a
-//   tangent row; lambda solved by 10 sweeps of projected Gauss-Seidel in a fixed row order, no warm start;
+//   tangent row; lambda solved by 10 sweeps of projected Gauss-Seidel in a fixed row order; since round 5 with Bullet's contact persistence (or_model.h:
+//   warm_start, link_brk): contact rows start from 0.85 x their previous impulse, a sweep takes limits -> normals -> friction rows, a friction row is resolved only
+//   while its normal row carries an impulse, and a sample point keeps its rows while it is within the manifold's breaking threshold above the surface;
 //   normal target velocity = min(ERP * max(depth - slop, 0) / h, v_depen_max); friction box |lt| <= mu * ln.
 //   Contact sample points per box link: 4 corners + midpoints of the two long edges, tested against the
 //   heightfield polyline; depth measured along the cell normal.
@@ -154,7 +156,7 @@ inline int DetectContacts(const OrcModel& M, const Bodies& B, const Ground& g, C
 			if (depth >= -tol) flags[j] = true;                 // cContactManager::Update: distance <= dist_tol
 			ContactPoint& p = all[j * SimConst::pts_per_link + k];
 			p.link = j; p.x = x; p.y = y; p.depth = depth; p.nx = nx; p.ny = ny; p.pt = j * SimConst::pts_per_link + k;
-			active[j * SimConst::pts_per_link + k] = depth > 0;
+			active[j * SimConst::pts_per_link + k] = depth > -M.link_brk[j];   // penetrating, or within the manifold's breaking threshold above the surface
 		}
 	}
 	// a point outranks another when it is deeper (ties: lower sample-point index)
@@ -250,9 +252,10 @@ struct Integrator {
 	double Yr[SimConst::max_rows][ORC_MAXD];
 	double Arr[SimConst::max_rows], tgt[SimConst::max_rows], lam[SimConst::max_rows];
 	int kind[SimConst::max_rows];  // 0 = limit (lambda >= 0), 1 = contact normal, 2 = contact tangent (paired with previous row)
-	// warm starting (M.warm_start): a row keeps its identity across substeps -- limit (joint, side), ground contact (sample point, normal / tangent), link--link
-	// contact (pair, candidate, normal / tangent) -- and starts the sweeps from warmstart_factor x the impulse it ended the previous substep with (Bullet:
-	// btContactSolverInfo::m_warmstartingFactor 0.85 on the persistent manifold points' applied impulses)
+	// warm starting (M.warm_start, or_model.h): a row keeps its identity across substeps -- 16-bit ids shared with the kernels (dtrl_kernel.h row_id): ground contact
+	// 2 x sample point + (0 normal, 1 tangent); link--link contact 256 + 2 x (pair x 12 + candidate) + (0, 1); limit rows 32768 + 2 x joint + side (never matched under
+	// Bullet's rule) -- and starts the sweeps from warmstart_factor x the impulse it ended the previous substep with (btContactSolverInfo::m_warmstartingFactor 0.85 on
+	// the persistent manifold points' m_appliedImpulse / m_appliedImpulseLateral1)
 	int id[SimConst::max_rows], prev_id[SimConst::max_rows], prev_R = 0;
 	double prev_lam[SimConst::max_rows];
 	void ResetWarmStart() { prev_R = 0; }
@@ -305,10 +308,10 @@ struct Integrator {
 			const double lo = M.lim_lo[j] - M.ref_theta[j], hi = M.lim_hi[j] - M.ref_theta[j];   // limits act on theta + ref_theta
 			if (th <= lo + SimConst::limit_slop && R < SimConst::max_rows) {
 				for (int i = 0; i < D; ++i) Jr[R][i] = 0;
-				Jr[R][j + 2] = 1; kind[R] = 0; id[R] = 2 * j; tgt[R] = SimConst::limit_erp * std::max(lo - th, 0.0) / h; ++R;
+				Jr[R][j + 2] = 1; kind[R] = 0; id[R] = 32768 + 2 * j; tgt[R] = SimConst::limit_erp * std::max(lo - th, 0.0) / h; ++R;
 			} else if (th >= hi - SimConst::limit_slop && R < SimConst::max_rows) {
 				for (int i = 0; i < D; ++i) Jr[R][i] = 0;
-				Jr[R][j + 2] = -1; kind[R] = 0; id[R] = 2 * j + 1; tgt[R] = SimConst::limit_erp * std::max(th - hi, 0.0) / h; ++R;
+				Jr[R][j + 2] = -1; kind[R] = 0; id[R] = 32768 + 2 * j + 1; tgt[R] = SimConst::limit_erp * std::max(th - hi, 0.0) / h; ++R;
 			}
 		}
 		ContactPoint cps[SimConst::max_rows / 2];
@@ -318,11 +321,11 @@ struct Integrator {
 		for (int c = 0; c < nc; ++c) {
 			const ContactPoint& cp = cps[c];
 			PointJacobian(M, B, cp.link, cp.x, cp.y, cp.nx, cp.ny, Jr[R], D);
-			kind[R] = 1; id[R] = 64 + 2 * cp.pt;
+			kind[R] = 1; id[R] = 2 * cp.pt;
 			double t = SimConst::erp * std::max(cp.depth - SimConst::slop, 0.0) / h;
-			tgt[R] = std::min(t, SimConst::v_depen_max); ++R;
+			tgt[R] = cp.depth < 0 ? cp.depth / h : std::min(t, SimConst::v_depen_max); ++R;   // a point still above the surface may approach by its distance per substep
 			PointJacobian(M, B, cp.link, cp.x, cp.y, cp.ny, -cp.nx, Jr[R], D);
-			kind[R] = 2; id[R] = 64 + 2 * cp.pt + 1; tgt[R] = 0; ++R;
+			kind[R] = 2; id[R] = 2 * cp.pt + 1; tgt[R] = 0; ++R;
 		}
 		// link--link contacts take what is left of the row budget, in pair order
 		PairContact pcs[SimConst::max_rows / 2];
@@ -335,7 +338,7 @@ struct Integrator {
 				PointJacobian(M, B, pc.a, pc.x, pc.y, dx, dy, Jr[R], D);
 				PointJacobian(M, B, pc.b, pc.x, pc.y, dx, dy, jb, D);
 				for (int i = 0; i < D; ++i) Jr[R][i] -= jb[i];
-				kind[R] = 1 + t; id[R] = 64 + 2 * ORC_MAXL * SimConst::pts_per_link + 2 * (pc.pair * 2 * SimConst::pts_per_link + pc.cand) + t;
+				kind[R] = 1 + t; id[R] = 256 + 2 * (pc.pair * 2 * SimConst::pts_per_link + pc.cand) + t;
 				tgt[R] = 0.0;   // velocity-level non-penetration only (see DetectPairContacts)
 				++R;
 			}
@@ -345,21 +348,32 @@ struct Integrator {
 			double a = 0; for (int i = 0; i < D; ++i) a += Jr[r][i] * Yr[r][i];
 			Arr[r] = a; lam[r] = 0;
 		}
-		if (M.warm_start) {
+		const int ws = M.warm_start;
+		const bool rule = ws == 1 || ws == 2 || ws == 3;   // Bullet's contact persistence (or_model.h)
+		if (ws == 3) {
+			// (ablation) Bullet's friction direction: along the relative tangential velocity before the solve, else the plane-space vector (-n_y, n_x)
+			for (int r = 0; r < R; ++r) if (kind[r] == 2) {
+				double w = 0; for (int i = 0; i < D; ++i) w += Jr[r][i] * v[i];
+				if (!(w * w > 1.1920929e-7) || w < 0) for (int i = 0; i < D; ++i) { Jr[r][i] = -Jr[r][i]; Yr[r][i] = -Yr[r][i]; }
+			}
+		}
+		if (ws) {
 			for (int r = 0; r < R; ++r) {
 				if (Arr[r] < 1e-12) continue;
+				if (rule && kind[r] == 0) continue;
 				for (int p = 0; p < prev_R; ++p) if (prev_id[p] == id[r]) { lam[r] = SimConst::warmstart_factor * prev_lam[p]; break; }
 			}
 			for (int r = 0; r < R; ++r) if (lam[r] != 0) for (int i = 0; i < D; ++i) v[i] += Yr[r][i] * lam[r];
 		}
+		const int passes = (ws == 1 || ws == 3) ? 2 : 1;   // pass 0: limit + normal rows, pass 1: friction rows (btSequentialImpulseConstraintSolver::solveSingleIteration)
 		for (int it = 0; it < SimConst::pgs_iters; ++it) {
+			for (int pass = 0; pass < passes; ++pass)
 			for (int r = 0; r < R; ++r) {
+				if (passes == 2 && ((pass == 0) == (kind[r] == 2))) continue;
 				if (Arr[r] < 1e-12) continue;
+				// a friction row is resolved only while its normal row carries an impulse: the cached friction impulse of a contact without normal force stays applied
+				if (rule && kind[r] == 2 && !(lam[r - 1] > 0)) continue;
 				double w = 0; for (int i = 0; i < D; ++i) w += Jr[r][i] * v[i];
-				// -warm_start= 2 (oracle-only experiment): Bullet's friction rows are resolved only while their normal row carries an impulse
-				// (btSequentialImpulseConstraintSolver::solveSingleIteration: `if (totalImpulse > 0)`), so a warm-started friction impulse of a contact that is
-				// separating in this substep stays applied instead of being clamped back to zero
-				if (M.warm_start == 2 && kind[r] == 2 && !(lam[r - 1] > 0)) continue;
 				double nl = lam[r] + (tgt[r] - w) / Arr[r];
 				if (kind[r] == 2) { double lim = SimConst::mu * lam[r - 1]; nl = std::min(std::max(nl, -lim), lim); }
 				else nl = std::max(nl, 0.0);

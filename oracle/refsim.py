@@ -23,8 +23,8 @@ _libs = {}
 NN_FWD = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double))
 STEP_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.c_int)
 POST_SUBSTEP = C.CFUNCTYPE(None, C.c_void_p, C.c_double)
-SI_OPTS = ("iterations", "erp", "erp2", "split_impulse", "split_threshold", "warmstarting", "warmstart_factor", "breaking", "max_points", "use_margin", "link_contacts", "safe_margin", "relative_breaking", "vertex_contacts", "friction_warmstart")
-SI_DEFAULTS = dict(iterations=10, erp=0.2, erp2=0.8, split_impulse=1, split_threshold=-0.04, warmstarting=1, warmstart_factor=0.85, breaking=0.02, max_points=4, use_margin=1, link_contacts=1, safe_margin=1, relative_breaking=1, vertex_contacts=1, friction_warmstart=1)
+SI_OPTS = ("iterations", "erp", "erp2", "split_impulse", "split_threshold", "warmstarting", "warmstart_factor", "breaking", "max_points", "use_margin", "link_contacts", "safe_margin", "relative_breaking", "vertex_contacts", "friction_warmstart", "friction_skip", "friction_dir", "interleave", "friction_ws_lifted")
+SI_DEFAULTS = dict(iterations=10, erp=0.2, erp2=0.8, split_impulse=1, split_threshold=-0.04, warmstarting=1, warmstart_factor=0.85, breaking=0.02, max_points=4, use_margin=1, link_contacts=1, safe_margin=1, relative_breaking=1, vertex_contacts=1, friction_warmstart=1, friction_skip=1, friction_dir=1, interleave=0, friction_ws_lifted=1)
 
 
 def available():
