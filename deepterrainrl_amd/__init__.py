@@ -56,7 +56,7 @@ TUPLE_FAIL, TUPLE_EXP_CRITIC, TUPLE_EXP_ACTOR = 1, 2, 4
 ABI_SYMBOLS = [
     "dtrl_create", "dtrl_destroy", "dtrl_reset", "dtrl_step", "dtrl_step_begin", "dtrl_step_end", "dtrl_step_updates", "dtrl_run_frames", "dtrl_set_policy",
     "dtrl_policy_num_params", "dtrl_build_output_offset_scale", "dtrl_load_scale_file", "dtrl_write_scale_file", "dtrl_set_explore", "dtrl_set_terrain_lerp", "dtrl_drain_tuples",
-    "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_cycle_info", "dtrl_get_action_table", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
+    "dtrl_get_pose_vel", "dtrl_set_pose_vel", "dtrl_get_contact_cache", "dtrl_set_contact_cache", "dtrl_get_link_states", "dtrl_add_perturb", "dtrl_apply_rand_force", "dtrl_get_cycle_info", "dtrl_get_action_table", "dtrl_get_poli_state", "dtrl_get_flags", "dtrl_get_torques", "dtrl_get_contacts",
     "dtrl_get_ctrl", "dtrl_sample_ground", "dtrl_eval_stats", "dtrl_dims", "dtrl_kernel_time_ms", "dtrl_last_error", "dtrl_version",
     "dtrl_terrain_build", "dtrl_terrain_load_file", "dtrl_args_parse_string",
     "dtrl_drain_tuples_device", "dtrl_tuple_stats", "dtrl_set_policy_device", "dtrl_get_dist_log", "dtrl_reset_avg_dist", "dtrl_write_dist_log", "dtrl_get_ground_window", "dtrl_drain_tuples_packed", "dtrl_get_policy_output", "dtrl_set_tuple_pipelining", "dtrl_step_end_begin", "dtrl_command_action", "dtrl_side_stream", "dtrl_step_poll", "dtrl_set_policy_device_on", "dtrl_set_policy_device_async",
@@ -91,6 +91,8 @@ def _bind(path):
     for name in ("dtrl_get_pose_vel", "dtrl_get_torques"):
         getattr(L, name).argtypes = [vp, vp, C.c_int, vp, vp]
     L.dtrl_set_pose_vel.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.dtrl_get_contact_cache.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    L.dtrl_set_contact_cache.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.dtrl_command_action.argtypes = [vp, vp, C.c_int, vp]
     L.dtrl_side_stream.restype = C.c_void_p; L.dtrl_side_stream.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.dtrl_get_link_states.argtypes = [vp, vp, C.c_int, vp, vp, vp]
@@ -355,6 +357,18 @@ class BatchScenario:
         ids, n = self._ids(env_ids)
         q = np.ascontiguousarray(q, np.float64).reshape(n, self.D); qd = np.ascontiguousarray(qd, np.float64).reshape(n, self.D)
         self._chk(self._lib.dtrl_set_pose_vel(self._h, _p(ids), n, _p(q), _p(qd)))
+
+    def ContactCache(self, env_ids=None):
+        """The persistent contact points of Bullet's manifolds (dtrl_get_contact_cache): (count[n], ids[n, 24], lambda[n, 24]) -- with (q, qd) the whole dynamic state."""
+        ids, n = self._ids(env_ids)
+        cnt = np.zeros(n, np.int32); rid = np.zeros((n, 24), np.int32); lam = np.zeros((n, 24))
+        self._chk(self._lib.dtrl_get_contact_cache(self._h, _p(ids), n, _p(cnt), _p(rid), _p(lam)))
+        return cnt, rid, lam
+
+    def SetContactCache(self, count, row_ids, lam, env_ids=None):
+        ids, n = self._ids(env_ids)
+        cnt = np.ascontiguousarray(count, np.int32).reshape(n); rid = np.ascontiguousarray(row_ids, np.int32).reshape(n, 24); lam = np.ascontiguousarray(lam, np.float64).reshape(n, 24)
+        self._chk(self._lib.dtrl_set_contact_cache(self._h, _p(ids), n, _p(cnt), _p(rid), _p(lam)))
 
     def SideStream(self, k=0):
         """(hipStream_t as an int, start delay in us measured at creation) of the k-th side stream: kernels queued there start on the compute units

@@ -96,6 +96,8 @@ try {
 void* dtrl_side_stream(dtrl_batch* b, int k, double* start_delay_us) try { if (!b) return nullptr; return b->eng.SideStream(k, start_delay_us); } catch (...) { return nullptr; }
 dtrl_status dtrl_command_action(dtrl_batch* b, const int32_t* env_ids, int n, const int32_t* action_ids) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.CommandAction(env_ids, n, action_ids)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_set_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, const double* q, const double* qd) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetPoseVel(env_ids, n, q, qd)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_get_contact_cache(dtrl_batch* b, const int32_t* env_ids, int n, int32_t* count, int32_t* ids, double* lambda) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.GetContactCache(env_ids, n, count, ids, lambda)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
+dtrl_status dtrl_set_contact_cache(dtrl_batch* b, const int32_t* env_ids, int n, const int32_t* count, const int32_t* ids, const double* lambda) try { CHECK_B(); return static_cast<dtrl_status>(b->eng.SetContactCache(env_ids, n, count, ids, lambda)); } catch (...) { return static_cast<dtrl_status>(dtrl_on_exception(b)); }
 dtrl_status dtrl_add_perturb(dtrl_batch* b, const int32_t* env_ids, int n, const int32_t* link, const double* local_pos, const double* force, const double* duration)
 try {
 	CHECK_B();

@@ -1075,6 +1075,41 @@ int Engine::SetPoseVel(const int32_t* env_ids, int n, const double* q, const dou
 	return DTRL_OK;
 }
 
+// the persistent contact points' identities and applied impulses (EnvState::ws_*; include/dtrl.h dtrl_get_contact_cache)
+int Engine::GetContactCache(const int32_t* env_ids, int n, int32_t* count, int32_t* ids, double* lambda)
+{
+	if (n < 0 || !count || !ids || !lambda) return Fail(DTRL_ERR_ARG, "bad arguments");
+	std::vector<EnvState> st; int rc = GetStates(env_ids, n, st);
+	if (rc != DTRL_OK) return rc;
+	const int cnt = static_cast<int>(st.size());
+	for (int i = 0; i < cnt; ++i) {
+		count[i] = st[i].ws_R;
+		for (int k = 0; k < kMaxRows; ++k) { ids[i * kMaxRows + k] = k < st[i].ws_R ? st[i].ws_id[k] : 0xffff; lambda[i * kMaxRows + k] = k < st[i].ws_R ? st[i].ws_lam[k] : 0.0; }
+	}
+	return DTRL_OK;
+}
+int Engine::SetContactCache(const int32_t* env_ids, int n, const int32_t* count, const int32_t* ids, const double* lambda)
+{
+	if (n < 0 || !count || !ids || !lambda) return Fail(DTRL_ERR_ARG, "bad arguments");
+	be_->Sync();
+	const int cnt = env_ids ? n : n_;
+	EnvState st;
+	for (int i = 0; i < cnt; ++i) {
+		const int e = EnvIndex(env_ids, i);
+		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
+		if (count[i] < 0 || count[i] > kMaxRows) return Fail(DTRL_ERR_ARG, "contact cache: row count out of range");
+		if (!be_->D2H(&st, &buf_.st[e], sizeof(EnvState))) return Fail(DTRL_ERR_DEVICE, be_->error());
+		st.ws_R = count[i];
+		for (int k = 0; k < kMaxRows; ++k) {
+			const bool on = k < count[i];
+			if (on && (ids[i * kMaxRows + k] < 0 || ids[i * kMaxRows + k] > 0xffff)) return Fail(DTRL_ERR_ARG, "contact cache: row id out of range");
+			st.ws_id[k] = on ? static_cast<uint16_t>(ids[i * kMaxRows + k]) : 0xffff; st.ws_lam[k] = on ? lambda[i * kMaxRows + k] : 0.0;
+		}
+		if (!be_->H2D(&buf_.st[e], &st, sizeof(EnvState))) return Fail(DTRL_ERR_DEVICE, be_->error());
+	}
+	return DTRL_OK;
+}
+
 // cCharController::CommandAction (sim/DogController.cpp:309-320, sim/RaptorController.cpp): the base action the controller takes at its next cycle instead
 // of asking the policy. The reference keeps a STACK of commands (the latest is served first, older ones at later cycles); the engine keeps the top of
 // that stack only -- one pending command per env, a new one replaces it (cScenarioExp::Reset's random first action, scenarios/ScenarioExp.cpp:63-73,

@@ -102,6 +102,8 @@ public:
 	int SetPolicyDeviceAsync(const float* w_dev, size_t n, void* stream);
 	int GetStates(const int32_t* env_ids, int n, std::vector<EnvState>& out);
 	int SetPoseVel(const int32_t* env_ids, int n, const double* q, const double* qd);
+	int GetContactCache(const int32_t* env_ids, int n, int32_t* count, int32_t* ids, double* lambda);
+	int SetContactCache(const int32_t* env_ids, int n, const int32_t* count, const int32_t* ids, const double* lambda);
 	int CommandAction(const int32_t* env_ids, int n, const int32_t* action_ids);
 	void ApplyPendingPolicy();
 	void* SideStream(int k, double* delay_us) { void* s = be_ ? be_->SideStream(k) : nullptr; if (delay_us) *delay_us = be_ ? be_->SideStreamDelayUs(k) : -1.0; return s; }

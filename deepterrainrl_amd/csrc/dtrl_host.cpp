@@ -461,6 +461,19 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 			m.link_margin[j] = safe ? std::min(static_cast<double>(m.contact_margin), 0.1 * he) : static_cast<double>(m.contact_margin);
 		}
 	}
+	{
+		// Bullet's contact persistence (DevModel::warm_start, link_brk): breaking threshold = gContactBreakingThreshold x the box's angular-motion disc |half extents|
+		// (btCollisionShape::getContactBreakingThreshold under the dispatcher's default relative flag; world-scaled on both sides, so the scale cancels)
+		int ws = 1; args.ParseInt("warm_start", ws);
+		if (ws != 0 && ws != 1) { err = "-warm_start= takes 0 or 1"; return false; }
+		m.warm_start = ws;
+		double brk = 0.02; args.ParseDouble("contact_breaking", brk);
+		if (!(brk >= 0)) { err = "-contact_breaking= must be >= 0"; return false; }
+		for (int j = 0; j < L; ++j) {
+			const double hx = m.body_half[j][0], hy = m.body_half[j][1], hz = 0.5 * bodies->arr[j].get_num("Param2", 0);
+			m.link_brk[j] = brk * std::sqrt(hx * hx + hy * hy + hz * hz);
+		}
+	}
 	// link--link collision pairs: same non-zero collision group, no hinge between the two, boxes overlapping in z (joint AttachZ accumulated down the
 	// chain + body AttachZ against the box depth Param2: the raptor's legs share a group but sit 0.16 m apart in z with 0.065 m deep boxes)
 	{

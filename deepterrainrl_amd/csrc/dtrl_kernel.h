@@ -96,6 +96,7 @@ enum ProfSection { kProfFK, kProfMass, kProfBias, kProfFact, kProfDetect, kProfR
 // limits and body angles stay in the HBM/L2-resident DevModel)
 struct HotModel {
 	int32_t L, D, char_type, n_pairs;
+	int32_t warm_start;   // DevModel::warm_start (Bullet's contact persistence)
 	int32_t parent[kMaxL], depth[kMaxL], col[kMaxL];
 	int8_t pair_l[kMaxPairs], pair_k[kMaxPairs];
 	alignas(4) int8_t path[kMaxL][kMaxDepth];   // read four entries at a time (path_word())
@@ -170,7 +171,8 @@ struct WSBase {
 	int32_t row_kind[kMaxRows], row_link[kMaxRows];
 	int8_t row_link2[kMaxRows];   // link--link contact rows: the partner link the row pushes the other way (-1: the ground)
 	real row_x[kMaxRows], row_y[kMaxRows], row_dx[kMaxRows], row_dy[kMaxRows], row_tgt[kMaxRows];
-	real wv[kMaxRows], lam[kMaxRows], rinv[kMaxRows];
+	uint16_t row_id[kMaxRows];    // identity of the row across substeps (EnvState::ws_id); the impulses live in st.ws_lam (the solve's lambda array AND the persistent cache)
+	real wv[kMaxRows], rinv[kMaxRows];
 	real dl;
 	// time-multiplexed: the controller scratch is only live outside substep(), where Z rows >= 1 are unused
 	union {
@@ -631,6 +633,13 @@ DTRL_HD_INLINE bool pair_in_reach(const W& ws, int pr)
 		|| fabs(tx * cb + ty * sb) > hxb + hxa * c + hya * s || fabs(-tx * sb + ty * cb) > hyb + hxa * s + hya * c;
 	return !sep;
 }
+// row identities across substeps (EnvState::ws_id; the same numbers as oracle/or_sim.h): ground contact 2 x sample point + (0 normal, 1 tangent), link--link contact
+// 512 + 2 x (pair x 12 + candidate) + (0, 1), limit rows kNoRowId
+constexpr uint16_t kNoRowId = 0xffffu;
+constexpr int kFirstPairRowId = 512;
+DTRL_HD_INLINE uint16_t ground_row_id(int pt, int t) { return static_cast<uint16_t>(2 * pt + t); }
+DTRL_HD_INLINE uint16_t pair_row_id(int pr, int cand, int t) { return static_cast<uint16_t>(kFirstPairRowId + 2 * (pr * 2 * kPtsPerLink + cand) + t); }
+static_assert(2 * kMaxPts <= kFirstPairRowId && kFirstPairRowId + 2 * kMaxCP * 2 * kPtsPerLink < 0xffff, "row id ranges");
 // candidate c (0..11) of a pair: a's six sample points against b, then b's six against a
 DTRL_HD_INLINE void pair_candidate(int a, int b, int c, int* P, int* Q, int* k) { const int side = c >= kPtsPerLink ? 1 : 0; *P = side ? b : a; *Q = side ? a : b; *k = c - side * kPtsPerLink; }
 // append the link--link contact rows behind the ground rows (serial form): per pair the deepest kMaxPtsPerPair penetrating candidates (ties: the earlier
@@ -652,16 +661,16 @@ DTRL_HD inline int append_pair_rows_serial(W& ws, const DevModel& gm, int R)
 			// (velocity-level non-penetration only, no recovery term: a contact point can sit millimetres from the only hinge axis that could separate
 			// the two links, where 0.2 depth / h asks for thousands of rad/s; Bullet recovers penetration by split impulse, momentum-free as well)
 			ws.row_kind[R] = 1; ws.row_link[R] = P; ws.row_link2[R] = static_cast<int8_t>(Q); ws.row_x[R] = hit[c].x; ws.row_y[R] = hit[c].y;
-			ws.row_dx[R] = hit[c].nx; ws.row_dy[R] = hit[c].ny; ws.row_tgt[R] = 0; ++R;
+			ws.row_dx[R] = hit[c].nx; ws.row_dy[R] = hit[c].ny; ws.row_tgt[R] = 0; ws.row_id[R] = pair_row_id(pr, c, 0); ++R;
 			ws.row_kind[R] = 2; ws.row_link[R] = P; ws.row_link2[R] = static_cast<int8_t>(Q); ws.row_x[R] = hit[c].x; ws.row_y[R] = hit[c].y;
-			ws.row_dx[R] = hit[c].ny; ws.row_dy[R] = -hit[c].nx; ws.row_tgt[R] = 0; ++R;
+			ws.row_dx[R] = hit[c].ny; ws.row_dy[R] = -hit[c].nx; ws.row_tgt[R] = 0; ws.row_id[R] = pair_row_id(pr, c, 1); ++R;
 		}
 	}
 	return R;
 }
 
 // world position of contact sample point pt (relative to the root origin) + ground test; shared by both kernel paths
-struct PtVal { real x, y, depth, nx, ny; int active; int near; };   // active: penetrating (gets constraint rows); near: within contact_tol of the surface (sets the link's contact flag)
+struct PtVal { real x, y, depth, nx, ny; int active; int near; };   // active: penetrating or within the breaking threshold above the surface (gets constraint rows; depth < 0 for the latter); near: within contact_tol of the surface (sets the link's contact flag)
 template <bool kNear = true, class W>
 DTRL_HD_INLINE PtVal contact_point_eval(const W& ws, const DevModel& gm, const GroundRec& g, int pt)
 {
@@ -676,13 +685,14 @@ DTRL_HD_INLINE PtVal contact_point_eval(const W& ws, const DevModel& gm, const G
 	real slope;
 	const real h = sample_ground(g, gh, ws.st.q[0] + x, &slope, nullptr, nullptr, nullptr);
 	const real gap = h - (ws.st.q[1] + y);
-	// inside a substep only penetrating points matter: depth = gap * ny + margin > 0 needs gap > -margin / ny, and 1 / ny = sqrt(1 + slope^2) <= 1 + |slope|
-	const real margin = gm.link_margin[j];
-	if (!kNear && !(gap + margin * (1.0 + fabs(slope)) > 0)) return r;
+	// inside a substep only the points that carry rows matter: penetrating ones and -- Bullet's persistent manifold -- those within the breaking threshold above the surface
+	const real margin = gm.link_margin[j], brk = gm.link_brk[j];
+	// (rows: depth = gap * ny + margin > -brk needs gap > -(margin + brk) / ny, and 1 / ny = sqrt(1 + slope^2) <= 1 + |slope|)
+	if (!kNear && !(gap + (margin + brk) * (1.0 + fabs(slope)) > 0)) return r;
 	const real inv = fast_rsqrt(1.0 + slope * slope);
 	const real depth = fmadd(gap, inv, margin);   // along the cell normal (ny = inv > 0), to the ROUNDED surface of the box (Bullet's collision margin)
 	if (kNear) r.near = depth >= -gm.contact_tol ? 1 : 0;   // cContactManager::Update: getDistance() <= dist_tol
-	if (!(depth > 0)) return r;
+	if (!(depth > -brk)) return r;
 	r.nx = -slope * inv; r.ny = inv;
 	r.depth = depth;
 	r.x = x; r.y = y;
@@ -731,6 +741,13 @@ DTRL_HD inline void detect_contacts(W& ws, const DevModel& gm, const GroundRec& 
 	LANES_END
 }
 
+// target normal velocity of a ground contact row: Baumgarte recovery of the penetration beyond the slop, capped; a point still above the surface (depth < 0, kept by the
+// manifold's breaking threshold) may approach by its distance per substep (Bullet: `velocityError -= penetration / dt` for positive distance)
+DTRL_HD_INLINE real normal_row_target(real depth, real inv_h)
+{
+	const real t = kErp * fmax(depth - kSlop, 0.0) * inv_h;
+	return depth < 0 ? depth * inv_h : fmin(t, kVDepenMax);
+}
 // build the ordered row list: violated joint limits first (by joint id), then normal+tangent per active contact point
 template <class W>
 DTRL_HD inline void build_rows(W& ws, const DevModel& gm, real h)
@@ -742,8 +759,8 @@ DTRL_HD inline void build_rows(W& ws, const DevModel& gm, real h)
 		for (int j = 1; j < ws.M.L; ++j) {
 			if (ws.M.lim_lo[j] > ws.M.lim_hi[j]) continue;
 			real th = ws.st.q[j + 2];
-			if (th <= ws.M.lim_lo[j] + kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_link2[R] = -1; ws.row_dx[R] = 1; ws.row_tgt[R] = kLimitErp * fmax(ws.M.lim_lo[j] - th, 0.0) * inv_h; ++R; }
-			else if (th >= ws.M.lim_hi[j] - kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_link2[R] = -1; ws.row_dx[R] = -1; ws.row_tgt[R] = kLimitErp * fmax(th - ws.M.lim_hi[j], 0.0) * inv_h; ++R; }
+			if (th <= ws.M.lim_lo[j] + kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_link2[R] = -1; ws.row_dx[R] = 1; ws.row_tgt[R] = kLimitErp * fmax(ws.M.lim_lo[j] - th, 0.0) * inv_h; ws.row_id[R] = kNoRowId; ++R; }
+			else if (th >= ws.M.lim_hi[j] - kLimitSlop && R < kMaxRows) { ws.row_kind[R] = 0; ws.row_link[R] = j; ws.row_link2[R] = -1; ws.row_dx[R] = -1; ws.row_tgt[R] = kLimitErp * fmax(th - ws.M.lim_hi[j], 0.0) * inv_h; ws.row_id[R] = kNoRowId; ++R; }
 		}
 		int cap = (kMaxRows - R) / 2, nc = 0;
 		// more penetrating points than rows: the deepest `cap` points overall get rows (ties: lower sample-point index)
@@ -760,11 +777,10 @@ DTRL_HD inline void build_rows(W& ws, const DevModel& gm, real h)
 		}
 		for (int pt = 0; pt < ws.M.L * kPtsPerLink && nc < cap; ++pt) if (ws.pt_active[pt] & 1) {
 			const int j = pt / kPtsPerLink;
-			real t = kErp * fmax(ws.pt_depth[pt] - kSlop, 0.0) * inv_h;
 			ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_link2[R] = -1; ws.row_x[R] = ws.pt_x[pt]; ws.row_y[R] = ws.pt_y[pt];
-			ws.row_dx[R] = ws.pt_nx[pt]; ws.row_dy[R] = ws.pt_ny[pt]; ws.row_tgt[R] = fmin(t, kVDepenMax); ++R;
+			ws.row_dx[R] = ws.pt_nx[pt]; ws.row_dy[R] = ws.pt_ny[pt]; ws.row_tgt[R] = normal_row_target(ws.pt_depth[pt], inv_h); ws.row_id[R] = ground_row_id(pt, 0); ++R;
 			ws.row_kind[R] = 2; ws.row_link[R] = j; ws.row_link2[R] = -1; ws.row_x[R] = ws.pt_x[pt]; ws.row_y[R] = ws.pt_y[pt];
-			ws.row_dx[R] = ws.pt_ny[pt]; ws.row_dy[R] = -ws.pt_nx[pt]; ws.row_tgt[R] = 0; ++R;
+			ws.row_dx[R] = ws.pt_ny[pt]; ws.row_dy[R] = -ws.pt_nx[pt]; ws.row_tgt[R] = 0; ws.row_id[R] = ground_row_id(pt, 1); ++R;
 			++nc;
 		}
 		R = append_pair_rows_serial(ws, gm, R);   // link--link contacts take what is left of the row budget
@@ -812,7 +828,6 @@ DTRL_HD inline void build_delassus(W& ws, real h)
 #pragma unroll 13
 		for (int i = 0; i < kMaxD; ++i) { const real zs = ws.Z[s][i], di = ws.dinv[i], z0 = ws.Z[R][i]; if (i < D) zz = fmadd(zs * di, z0, zz); }
 		ws.wv[s] = jv + h * zz - ws.row_tgt[s];
-		ws.lam[s] = 0;
 		ws.rinv[s] = (ws.A[s][s] >= 1e-12) ? 1.0 / ws.A[s][s] : 0.0;   // rows with a vanishing effective mass are skipped
 	}
 	LANES_END
@@ -821,30 +836,69 @@ DTRL_HD inline void build_delassus(W& ws, real h)
 	LANES_END
 }
 
-// projected Gauss-Seidel in lambda space, fixed row order, kPgsIters sweeps, no warm start.
-// LDS form (reference for the register/readlane form used by the tuned kernel).
+// Bullet's persistent contact points: every row of the fresh list looks its identity up among the rows of the last solved substep and starts from kWarmFactor x the
+// impulse that row ended with (limit rows and new contacts from zero); the list then becomes the cache. Runs once per substep, after the rows exist (built in this
+// substep or taken over from the post-step contact pass), in both kernels
+template <class W>
+DTRL_HD inline void warm_match(W& ws)
+{
+	const int R = ws.R;
+	LANES_BEGIN
+	if (lane < R) {
+		real l0 = 0.0;
+		const int id = ws.row_id[lane];
+		if (ws.M.warm_start != 0 && id < kFirstPairRowId) {   // ground contact rows only: limit rows and link--link rows start from zero (DevModel::warm_start)
+			int hit = -1;
+			for (int p = 0; p < ws.st.ws_R; ++p) hit = (ws.st.ws_id[p] == id) ? p : hit;
+			if (hit >= 0) l0 = kWarmFactor * ws.st.ws_lam[hit];
+		}
+		ws.wv[lane] = l0;   // (wv is free until the Delassus build)
+	}
+	LANES_END
+	LANES_BEGIN
+	if (lane < R) { ws.st.ws_lam[lane] = ws.wv[lane]; ws.st.ws_id[lane] = ws.row_id[lane]; }
+	if (lane == 0) ws.st.ws_R = R;
+	LANES_END
+}
+
+// projected Gauss-Seidel in lambda space, kPgsIters sweeps. LDS form (reference for the register/readlane form used by the tuned kernel).
+// With Bullet's contact persistence (DevModel::warm_start): the rows start from the impulses warm_match() left in st.ws_lam (w += A lambda_0 first), a sweep takes the
+// limit and normal rows in list order, then the friction rows, and a friction row is resolved only while its normal row (the row before it) carries an impulse.
 template <class W>
 DTRL_HD inline void pgs_solve(W& ws)
 {
 	const int R = ws.R;
+	const bool warm = ws.M.warm_start != 0;
+	for (int r = 0; r < R; ++r) {
+		LANES_BEGIN
+		if (lane == 0) { const real l0 = (ws.rinv[r] != 0.0) ? ws.st.ws_lam[r] : 0.0; ws.st.ws_lam[r] = l0; ws.dl = l0; }   // rows with a vanishing effective mass stay at zero
+		LANES_END
+		LANES_BEGIN
+		if (lane < R) ws.wv[lane] = fmadd(ws.A[lane][r], ws.dl, ws.wv[lane]);
+		LANES_END
+	}
 	for (int it = 0; it < kPgsIters; ++it) {
-		for (int r = 0; r < R; ++r) {
-			LANES_BEGIN
-			if (lane == 0) {
-				real ri = ws.rinv[r], dl = 0;
-				if (ri != 0.0) {
-					real nl = fmadd(-ws.wv[r], ri, ws.lam[r]);
-					if (ws.row_kind[r] == 2) { real lim = kMu * ws.lam[r - 1]; nl = fmin(fmax(nl, -lim), lim); }
-					else nl = fmax(nl, 0.0);
-					dl = nl - ws.lam[r];
-					ws.lam[r] = nl;
+		for (int pass = 0; pass < (warm ? 2 : 1); ++pass) {
+			for (int r = 0; r < R; ++r) {
+				if (warm && ((pass == 0) == (ws.row_kind[r] == 2))) continue;
+				LANES_BEGIN
+				if (lane == 0) {
+					real ri = ws.rinv[r], dl = 0;
+					const bool hold = warm && ws.row_kind[r] == 2 && !(ws.st.ws_lam[r - 1] > kHoldEps);
+					if (ri != 0.0 && !hold) {
+						real nl = fmadd(-ws.wv[r], ri, ws.st.ws_lam[r]);
+						if (ws.row_kind[r] == 2) { real lim = kMu * ws.st.ws_lam[r - 1]; nl = fmin(fmax(nl, -lim), lim); }
+						else nl = fmax(nl, 0.0);
+						dl = nl - ws.st.ws_lam[r];
+						ws.st.ws_lam[r] = nl;
+					}
+					ws.dl = dl;
 				}
-				ws.dl = dl;
+				LANES_END
+				LANES_BEGIN
+				if (lane < R) ws.wv[lane] = fmadd(ws.A[lane][r], ws.dl, ws.wv[lane]);
+				LANES_END
 			}
-			LANES_END
-			LANES_BEGIN
-			if (lane < R) ws.wv[lane] = fmadd(ws.A[lane][r], ws.dl, ws.wv[lane]);
-			LANES_END
 		}
 	}
 }
@@ -858,7 +912,7 @@ DTRL_HD inline void finish_substep(W& ws, real h)
 	if (lane < D) {
 		const int i = lane;
 		real s = h * ws.Z[R][i];
-		for (int r = 0; r < R; ++r) s = fmadd(ws.Z[r][i], ws.lam[r], s);
+		for (int r = 0; r < R; ++r) s = fmadd(ws.Z[r][i], ws.st.ws_lam[r], s);
 		ws.u[i] = s * ws.dinv[i];
 	}
 	LANES_END
@@ -910,7 +964,7 @@ DTRL_HD inline void substep_ref(W& ws, const DevModel& gm, const GroundRec& g, r
 	{ PROF_T0(); mass_matrix(ws); PROF_ADD(ws, kProfMass); }
 	{ PROF_T0(); factorize(ws); PROF_ADD(ws, kProfFact); }
 	{ PROF_T0(); detect_contacts(ws, gm, g); PROF_ADD(ws, kProfDetect); }
-	{ PROF_T0(); build_rows(ws, gm, h);
+	{ PROF_T0(); build_rows(ws, gm, h); warm_match(ws);
 	LANES_BEGIN
 	if (lane < ws.M.D) { ws.u[lane] = ws.st.tau[lane] - ws.b[lane]; if (__builtin_expect(ws.st.pert_on != 0, 0)) ws.u[lane] += perturb_gen_force(ws, lane); }
 	if (lane == 0) ws.cost += 8 + ws.R;
@@ -1944,6 +1998,7 @@ DTRL_HD inline void reset_env(W& ws, const DevModel& gm, const RunParams& rp, co
 		ws.st.fall_dist_counter = 5; ws.st.prev_check[0] = ws.st.q[0]; ws.st.prev_check[1] = ws.st.q[1]; ws.st.fail_fall_dist = 0;
 		ws.st.fall_contact_counter = 0.1; ws.st.sum_fall_contact = 0;
 		ws.st.contact_bits = 0;
+		ws.st.ws_R = 0;   // cWorld::Reset / a re-created character: no persistent contact points
 		ws.st.time = 0;
 		ws.st.pert_link = -1; ws.st.pert_on = 0;   // cWorld::Reset clears the perturbation manager (sim/World.cpp:76-82)
 		// cScenarioSimChar::InitCharacterPos
@@ -1991,7 +2046,7 @@ template <class W>
 DTRL_HD inline void load_hot_model(W& ws, const DevModel& gm)
 {
 	LANES_BEGIN
-	if (lane == 0) { ws.M.L = gm.L; ws.M.D = gm.D; ws.M.char_type = gm.char_type; ws.M.n_pairs = gm.n_pairs; ws.M.n_cpairs = gm.link_contacts ? gm.n_cpairs : 0; }
+	if (lane == 0) { ws.M.L = gm.L; ws.M.D = gm.D; ws.M.char_type = gm.char_type; ws.M.n_pairs = gm.n_pairs; ws.M.n_cpairs = gm.link_contacts ? gm.n_cpairs : 0; ws.M.warm_start = gm.warm_start; }
 	for (int e = lane; e < gm.n_pairs; e += kGroup) { ws.M.pair_l[e] = gm.pair_l[e]; ws.M.pair_k[e] = gm.pair_k[e]; }
 	if (lane < gm.n_cpairs) { ws.M.cp_a[lane] = gm.cp_a[lane]; ws.M.cp_b[lane] = gm.cp_b[lane]; }
 	if (lane < gm.L) { ws.M.cp_half[lane][0] = gm.cp_half[lane][0]; ws.M.cp_half[lane][1] = gm.cp_half[lane][1]; }

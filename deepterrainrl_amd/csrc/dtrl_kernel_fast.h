@@ -275,7 +275,9 @@ __device__ __forceinline__ unsigned link_field(unsigned long long m0, unsigned l
 // ground with five or six of its sample points below the surface): the depths go once through LDS (the packed-matrix storage is dead between
 // the factorisation and the Delassus build, and before the controller's mass rows) so that a point sees the other sample points of its link
 // Takes and returns scalars only (an aggregate passed by reference to a non-inlined function would live in scratch memory on the hot path):
-// d0..d2 = depth of the lane's three sample points or -1 when not penetrating; returns bit k set when point k is dropped
+// d0..d2 = depth of the lane's three sample points or kNoPoint when the point carries no rows (a row-carrying point within the breaking threshold above
+// the surface has a small negative depth); returns bit k set when point k is dropped
+constexpr real kNoPoint = -1.0e30;
 __device__ __noinline__ unsigned link_cap_drop_mask(WSFast& ws, real d0, real d1, real d2)
 {
 	const int lane = opaque_lane();
@@ -286,7 +288,7 @@ __device__ __noinline__ unsigned link_cap_drop_mask(WSFast& ws, real d0, real d1
 	if (lane + 2 * kGroup < npts) S[lane + 2 * kGroup] = d2;
 	env_sync();
 	auto over = [&](real d, int pt) -> unsigned {
-		if (!(d > 0)) return 0u;
+		if (!(d > kNoPoint)) return 0u;
 		const int base = (pt / kPtsPerLink) * kPtsPerLink;
 		int rank = 0;
 		for (int k = 0; k < kPtsPerLink; ++k) { const int o = base + k; const real od = S[o]; rank += (o != pt && (od > d || (od == d && o < pt))) ? 1 : 0; }
@@ -314,7 +316,7 @@ __device__ __forceinline__ ContactPts eval_points(WSFast& ws, const DevModel& gm
 	if ((c.m0 | c.m1 | c.m2) != 0ull) {   // wave-uniform: somebody penetrates; does any link have more than kMaxPtsPerLink such points?
 		const int many = (lane < ws.M.L) && __popc(link_field(c.m0, c.m1, c.m2, lane)) > kMaxPtsPerLink;
 		if (__builtin_expect(__ballot(many) != 0ull, 0)) {
-			const unsigned drop = link_cap_drop_mask(ws, c.p0.active ? c.p0.depth : -1.0, c.p1.active ? c.p1.depth : -1.0, c.p2.active ? c.p2.depth : -1.0);
+			const unsigned drop = link_cap_drop_mask(ws, c.p0.active ? c.p0.depth : kNoPoint, c.p1.active ? c.p1.depth : kNoPoint, c.p2.active ? c.p2.depth : kNoPoint);
 			if (drop & 1u) c.p0.active = 0;
 			if (drop & 2u) c.p1.active = 0;
 			if (drop & 4u) c.p2.active = 0;
@@ -335,7 +337,7 @@ __device__ __noinline__ unsigned row_cap_drop_mask(WSFast& ws, real d0, real d1,
 	if (lane + 2 * kGroup < npts) S[lane + 2 * kGroup] = d2;
 	env_sync();
 	auto over = [&](real d, int pt) -> unsigned {
-		if (!(d > 0)) return 0u;
+		if (!(d > kNoPoint)) return 0u;
 		int rank = 0;
 		for (int o = 0; o < npts; ++o) { const real od = S[o]; rank += (o != pt && (od > d || (od == d && o < pt))) ? 1 : 0; }
 		return rank >= cap ? 1u : 0u;
@@ -393,6 +395,7 @@ __device__ __noinline__ int append_pair_rows_fast(WSFast& ws, const DevModel& gm
 			const int Rw = R + 2 * idx;
 			ws.row_kind[Rw] = 1; ws.row_link[Rw] = P; ws.row_link2[Rw] = static_cast<int8_t>(Q); ws.row_x[Rw] = hit.x; ws.row_y[Rw] = hit.y;
 			ws.row_dx[Rw] = hit.nx; ws.row_dy[Rw] = hit.ny; ws.row_tgt[Rw] = 0;   // velocity-level only (append_pair_rows_serial)
+			ws.row_id[Rw] = pair_row_id(mypr, cand, 0); ws.row_id[Rw + 1] = pair_row_id(mypr, cand, 1);
 			ws.row_kind[Rw + 1] = 2; ws.row_link[Rw + 1] = P; ws.row_link2[Rw + 1] = static_cast<int8_t>(Q); ws.row_x[Rw + 1] = hit.x; ws.row_y[Rw + 1] = hit.y;
 			ws.row_dx[Rw + 1] = hit.ny; ws.row_dy[Rw + 1] = -hit.nx; ws.row_tgt[Rw + 1] = 0;
 		}
@@ -420,9 +423,9 @@ __device__ __forceinline__ void emit_contact_rows(WSFast& ws, const PtVal& p, in
 	if (p.active && rank < cap) {
 		const int R = R0 + 2 * rank;
 		const int j = pt / kPtsPerLink;
-		const real t = kErp * fmax(p.depth - kSlop, 0.0) * inv_h;
 		ws.row_kind[R] = 1; ws.row_link[R] = j; ws.row_link2[R] = -1; ws.row_x[R] = p.x; ws.row_y[R] = p.y;
-		ws.row_dx[R] = p.nx; ws.row_dy[R] = p.ny; ws.row_tgt[R] = fmin(t, kVDepenMax);
+		ws.row_dx[R] = p.nx; ws.row_dy[R] = p.ny; ws.row_tgt[R] = normal_row_target(p.depth, inv_h);
+		ws.row_id[R] = ground_row_id(pt, 0); ws.row_id[R + 1] = ground_row_id(pt, 1);
 		ws.row_kind[R + 1] = 2; ws.row_link[R + 1] = j; ws.row_link2[R + 1] = -1; ws.row_x[R + 1] = p.x; ws.row_y[R + 1] = p.y;
 		ws.row_dx[R + 1] = p.ny; ws.row_dy[R + 1] = -p.nx; ws.row_tgt[R + 1] = 0;
 	}
@@ -443,11 +446,11 @@ __device__ __forceinline__ void build_rows_fast(WSFast& ws, const DevModel& gm, 
 	const unsigned long long ml = __ballot(lim != 0);
 	const int rl = __popcll(ml & below);
 	int R0 = __popcll(ml); if (R0 > kMaxRows) R0 = kMaxRows;
-	if (lim != 0 && rl < kMaxRows) { ws.row_kind[rl] = 0; ws.row_link[rl] = lane; ws.row_link2[rl] = -1; ws.row_dx[rl] = lim; ws.row_tgt[rl] = tgt; }
+	if (lim != 0 && rl < kMaxRows) { ws.row_kind[rl] = 0; ws.row_link[rl] = lane; ws.row_link2[rl] = -1; ws.row_dx[rl] = lim; ws.row_tgt[rl] = tgt; ws.row_id[rl] = kNoRowId; }
 	// contacts, ordered by sample-point index
 	const int cap = (kMaxRows - R0) / 2;
 	if (__builtin_expect(__popcll(c.m0) + __popcll(c.m1) + __popcll(c.m2) > cap, 0)) {   // wave-uniform
-		const unsigned drop = row_cap_drop_mask(ws, c.p0.active ? c.p0.depth : -1.0, c.p1.active ? c.p1.depth : -1.0, c.p2.active ? c.p2.depth : -1.0, cap);
+		const unsigned drop = row_cap_drop_mask(ws, c.p0.active ? c.p0.depth : kNoPoint, c.p1.active ? c.p1.depth : kNoPoint, c.p2.active ? c.p2.depth : kNoPoint, cap);
 		if (drop & 1u) c.p0.active = 0;
 		if (drop & 2u) c.p1.active = 0;
 		if (drop & 4u) c.p2.active = 0;
@@ -578,8 +581,10 @@ __device__ __forceinline__ void pgs_rows_load(real (&a)[K], const WSFast& ws, in
 }
 // one sweep over rows r, r + 1, ...: rows below K read the lane's Delassus entry from registers, rows K .. kMaxRows - 1 (the tail only characters lying on the
 // ground reach) from LDS, fetched one row update ahead (a_pref) so that the load's latency sits under the previous row's dependent chain
+// Bullet's contact persistence: `actR` is the set of rows this pass resolves (limits + normals, or the friction rows), and a friction lane with `holdable` set leaves
+// its impulse alone while the normal row before it carries none (lo = hi = lambda: the candidate update is exactly zero)
 template <int r, int K, int kEnd>
-__device__ __forceinline__ void pgs_rows_sweep(const real (&a)[K], const WSFast& ws, real& w, real& lam, real rinv, bool tang, bool mine, unsigned long long actR, int lane, int R, real a_pref)
+__device__ __forceinline__ void pgs_rows_sweep(const real (&a)[K], const WSFast& ws, real& w, real& lam, real rinv, bool tang, bool holdable, bool mine, unsigned long long actR, int lane, int R, real a_pref)
 {
 	if constexpr (r < kEnd) {
 		if (r < R) {
@@ -594,16 +599,51 @@ __device__ __forceinline__ void pgs_rows_sweep(const real (&a)[K], const WSFast&
 			if ((actR >> r) & 1ull) {
 				// (a wave-uniform branch on the kind of row r -- normal rows need neither the friction bound nor the upper clamp -- was measured twice, round 1 and
 				// round 4 under the ILP scheduler: -6 % / -3 %. The selects are cheaper than the branch.)
-				const real lim = kMu * wave_shr1(lam);
-				const real lo = tang ? -lim : 0.0, hi = tang ? lim : __builtin_huge_val();
+				const real ln = wave_shr1(lam);
+				const real lim = kMu * ln;
+				const bool hold = holdable && !(ln > kHoldEps);
+				const real lo = hold ? lam : (tang ? -lim : 0.0), hi = hold ? lam : (tang ? lim : __builtin_huge_val());
 				const real nl = fmin(fmax(fmadd(-w, rinv, lam), lo), hi);
 				const real dl = bcast(nl - lam, r);
 				if (lane == r) lam = nl;
 				w = fmadd(a_sr, dl, w);
 			}
-			pgs_rows_sweep<r + 1, K, kEnd>(a, ws, w, lam, rinv, tang, mine, actR, lane, R, a_nx);
+			pgs_rows_sweep<r + 1, K, kEnd>(a, ws, w, lam, rinv, tang, holdable, mine, actR, lane, R, a_nx);
 		}
 	}
+}
+// w += A lambda_0 (the warm-started impulses), column by column in row order: the same fused operations as pgs_solve()'s first loop
+template <int r, int K, int kEnd>
+__device__ __forceinline__ void pgs_rows_warm(const real (&a)[K], const WSFast& ws, real& w, real lam, bool mine, int lane, int R)
+{
+	if constexpr (r < kEnd) {
+		if (r < R) {
+			real a_sr;
+			if constexpr (r < K) a_sr = a[r];
+			else { const int mx = lane > r ? lane : r, mn = lane < r ? lane : r; a_sr = ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0]; }
+			w = fmadd(a_sr, bcast(lam, r), w);
+			pgs_rows_warm<r + 1, K, kEnd>(a, ws, w, lam, mine, lane, R);
+		}
+	}
+}
+// Bullet's persistent contact points on the wave (warm_match() of dtrl_kernel.h): lane r looks the identity of fresh row r up among the rows of the last solved
+// substep (<= 24 broadcast reads of 16-bit ids) and starts from kWarmFactor x that row's impulse; the fresh list then becomes the cache
+__device__ __forceinline__ void warm_match_fast(WSFast& ws)
+{
+	const int lane = opaque_lane();
+	const int R = ws.R, Rp = ws.st.ws_R;   // wave-uniform
+	int id = kNoRowId;
+	if (lane < R) id = ws.row_id[lane];
+	real l0 = 0.0;
+	if (ws.M.warm_start != 0 && Rp > 0) {
+		int hit = -1;
+		for (int p = 0; p < Rp; ++p) hit = (ws.st.ws_id[p] == id) ? p : hit;
+		if (id < kFirstPairRowId && hit >= 0) l0 = kWarmFactor * ws.st.ws_lam[hit];   // ground contact rows only
+	}
+	env_sync();
+	if (lane < R) { ws.st.ws_lam[lane] = l0; ws.st.ws_id[lane] = static_cast<uint16_t>(id); }
+	if (lane == 0) ws.st.ws_R = R;
+	env_sync();
 }
 template <int kPgsRegRows, bool kTailInSweep>
 __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
@@ -611,11 +651,17 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 	const int lane = opaque_lane();
 	const int R = ws.R;
 	const bool mine = lane < R;
-	real w = mine ? ws.wv[lane] : 0.0, lam = 0.0;
+	real w = mine ? ws.wv[lane] : 0.0;
 	real rinv = 0.0;
 	if (mine) { const real ass = ws.Apk[lane * (lane + 3) / 2]; rinv = (ass >= 1e-12) ? 1.0 / ass : 0.0; }
+	real lam = (mine && rinv != 0.0) ? ws.st.ws_lam[lane] : 0.0;   // warm_match_fast(): kWarmFactor x the row's previous impulse; rows with a vanishing effective mass stay at zero
 	const bool tang = mine && ws.row_kind[lane] == 2;
 	const unsigned long long act = __ballot(rinv != 0.0);
+	// Bullet's contact persistence: a sweep resolves the limit and normal rows (list order), then the friction rows; a friction row only under a loaded normal row
+	const bool warm = ws.M.warm_start != 0;   // wave-uniform
+	const bool holdable = warm && tang;
+	const unsigned long long tmask = __ballot(tang);
+	const bool any_l0 = __ballot(lam != 0.0) != 0ull;
 	// The lane's Delassus row: the first kPgsRegRows entries (per skeleton, dtrl_topo.h; eight until round 3, twelve in round 3) live in registers for all sweeps
 	// -- no LDS read and no packed-index arithmetic per row update -- and the entries of the tail rows come from LDS one update ahead. Same operations on the
 	// same values in the same order as pgs_solve() of dtrl_kernel.h. The rare substeps with many rows matter out of proportion: they are what the slowest envs of
@@ -629,29 +675,41 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 		real a[kPgsRegRows];
 		pgs_rows_load<0, kPgsRegRows>(a, ws, lane, mine, R);
 		const unsigned long long actR = act & ((R < 64) ? ((1ull << R) - 1ull) : ~0ull);
-		for (int it = 0; it < kPgsIters; ++it) pgs_rows_sweep<0, kPgsRegRows, (kTailInSweep ? kMaxRows : kPgsRegRows)>(a, ws, w, lam, rinv, tang, mine, actR, lane, R, 0.0);
-		if (mine) ws.lam[lane] = lam;
+		constexpr int kEnd = kTailInSweep ? kMaxRows : kPgsRegRows;
+		if (any_l0) pgs_rows_warm<0, kPgsRegRows, kEnd>(a, ws, w, lam, mine, lane, R);
+		const unsigned long long pass0 = warm ? (actR & ~tmask) : actR, pass1 = actR & tmask;
+		for (int it = 0; it < kPgsIters; ++it) {
+			pgs_rows_sweep<0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, tang, holdable, mine, pass0, lane, R, 0.0);
+			if (warm && pass1 != 0ull) pgs_rows_sweep<0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, tang, holdable, mine, pass1, lane, R, 0.0);
+		}
+		if (mine) ws.st.ws_lam[lane] = lam;
 		env_sync();
 		return;
 	}
 	const int tri = lane * (lane + 1) / 2;
 	const real inf = __builtin_huge_val();
+	if (any_l0) for (int r = 0; r < R; ++r) { const int mx = lane > r ? lane : r, mn = lane < r ? lane : r; w = fmadd(ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0], bcast(lam, r), w); }
 	real a_nx = mine ? ws.Apk[tri] : 0.0;   // column 0; the column of the next row update is fetched one update ahead
 	for (int it = 0; it < kPgsIters; ++it) {
-		for (int r = 0; r < R; ++r) {
-			const real a_sr = a_nx;
-			const int rn = (r + 1 < R) ? r + 1 : 0;
-			{ const int mx = lane > rn ? lane : rn, mn = lane < rn ? lane : rn; a_nx = ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0]; }   // branch-free packed index
-			if (!((act >> r) & 1ull)) continue;
-			const real lim = kMu * wave_shr1(lam);
-			const real lo = tang ? -lim : 0.0, hi = tang ? lim : inf;
-			const real nl = fmin(fmax(fmadd(-w, rinv, lam), lo), hi);
-			const real dl = bcast(nl - lam, r);
-			if (lane == r) lam = nl;
-			w = fmadd(a_sr, dl, w);
+		for (int pass = 0; pass < (warm ? 2 : 1); ++pass) {
+			for (int r = 0; r < R; ++r) {
+				const real a_sr = a_nx;
+				const int rn = (r + 1 < R) ? r + 1 : 0;
+				{ const int mx = lane > rn ? lane : rn, mn = lane < rn ? lane : rn; a_nx = ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0]; }   // branch-free packed index
+				if (!((act >> r) & 1ull)) continue;
+				if (warm && ((pass == 0) == (((tmask >> r) & 1ull) != 0ull))) continue;
+				const real ln = wave_shr1(lam);
+				const real lim = kMu * ln;
+				const bool hold = holdable && !(ln > kHoldEps);
+				const real lo = hold ? lam : (tang ? -lim : 0.0), hi = hold ? lam : (tang ? lim : inf);
+				const real nl = fmin(fmax(fmadd(-w, rinv, lam), lo), hi);
+				const real dl = bcast(nl - lam, r);
+				if (lane == r) lam = nl;
+				w = fmadd(a_sr, dl, w);
+			}
 		}
 	}
-	if (mine) ws.lam[lane] = lam;
+	if (mine) ws.st.ws_lam[lane] = lam;
 	env_sync();
 }
 
@@ -678,6 +736,7 @@ struct FastPath {
 			{ PROF_T0(); cp = eval_points<false>(ws, gm, g); PROF_ADD(ws, kProfDetect); }   // the per-link contact flags are the post-step pass's business (contacts() below)
 			{ PROF_T0(); build_rows_fast(ws, gm, cp, h); PROF_ADD(ws, kProfRows); }
 		}
+		{ PROF_T0(); warm_match_fast(ws); PROF_ADD(ws, kProfRows); }
 		real hrow[D];
 		{ PROF_T0(); mass_row<D>(ws, hrow); PROF_ADD(ws, kProfMass); }
 		real dinv;
@@ -738,7 +797,7 @@ struct FastPath {
 			real u = 0;
 			if (lane < D) {
 				real s = h * ws.Z[R][lane];
-				for (int r = 0; r < R; ++r) s = fmadd(ws.Z[r][lane], ws.lam[r], s);
+				for (int r = 0; r < R; ++r) s = fmadd(ws.Z[r][lane], ws.st.ws_lam[r], s);
 				u = s * dinv;
 			}
 			u = utsolve_regs<D>(hrow, u);

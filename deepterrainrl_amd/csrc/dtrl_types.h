@@ -39,6 +39,11 @@ constexpr real kVDepenMax = 1.0;
 constexpr real kLimitErp = 0.2;
 constexpr real kLimitSlop = 0.005;
 constexpr int kPgsIters = 10;
+constexpr real kWarmFactor = 0.85;   // btContactSolverInfo::m_warmstartingFactor
+// Bullet's `if (totalImpulse > 0)` in front of a friction row is a float compare. Redundant contact points (three collinear sample points of a foot flat on the ground) leave a
+// normal row whose exact impulse is zero at +-1e-17 N s by rounding, and the rule would then decide between KEEPING a cached friction impulse and clamping it to mu x 1e-17 on the
+// sign of that rounding error. An impulse below kHoldEps = 1e-9 N s (a resting dog foot carries 6e-2 per substep: this is below float resolution of that) counts as none
+constexpr real kHoldEps = 1e-9;
 constexpr real kGravityY = -9.8;
 constexpr real kMaxTurnPerSubstep = 1.5707963267948966;   // Bullet clamps a body's angular velocity so that it turns at most MAX_ANGVEL = pi / 2 per internal step (btRigidBody::integrateVelocities); here: every hinge rate and the root's spin
 
@@ -81,6 +86,16 @@ struct DevModel {
 	// half extent) in world-scaled units (Bullet >= 2.80; the reference needs >= 2.82: sim/World.cpp:4-5 includes MLCPSolvers), e.g. 2.5 mm for a dog / goat toe and
 	// 7.5 mm for the torso at ANY world scale. -safe_margin= 0 gives every link contact_margin (the round-3 model)
 	real link_margin[kMaxL];
+	// Bullet's contact persistence (round 5; sim/World.cpp:61-77 builds a default btSequentialImpulseConstraintSolver: SOLVER_USE_WARMSTARTING, factor 0.85 on the
+	// persistent manifold points' normal and friction impulses). warm_start 1 (default): GROUND contact rows keep their identity across substeps and env-steps and start
+	// the sweeps from kWarmFactor x the impulse they ended the last substep with, a sweep takes limits -> normals -> friction rows, and a friction row is resolved
+	// only while its normal row carries an impulse (solveSingleIteration's `if (totalImpulse > 0)`); 0: every row from zero, one interleaved sweep (rounds 1-4).
+	// Link--link contact rows start from zero: the comparator's ablations show its friction warm start acts through the ground contacts alone (ground-only
+	// reproduces it, pair-only changes nothing: DESIGN 4), and a cached friction impulse between two links that no longer press on each other is 200 N of free force.
+	// link_brk[j]: a ground sample point of link j carries rows while it is within contact_breaking (0.02, gContactBreakingThreshold, relative by the dispatcher's
+	// default CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD) x |half extents| above the surface; -contact_breaking= 0: only while it penetrates
+	real link_brk[kMaxL];
+	int32_t warm_start, pad_ws_;
 	real eff_joint[kMaxL][2];               // body-local (0, -size_y/2) in the joint frame (end-effector contact position)
 	real init_pos_x, target_vel_x, total_mass;
 	real world_scale;
@@ -134,7 +149,14 @@ struct EnvState {
 	int32_t pert_on;         // applied during the current env-step (set at the env-step's start)
 	int32_t pad_;
 	real pert_f[2], pert_lp[2], pert_torque, pert_time, pert_dur;   // pert_lp: application point relative to the COM, in the link's joint frame
+	// Bullet's persistent contact points (DevModel::warm_start): the rows of the last solved substep by identity, with the impulses they ended with. Row ids
+	// (16 bit, shared with oracle/or_sim.h): ground contact 2 x sample point + (0 normal, 1 tangent); link--link contact 512 + 2 x (pair x 12 + candidate) + (0, 1);
+	// limit rows 0xffff (never matched). Carried across env-steps and frames; emptied by a reset
+	real ws_lam[kMaxRows];
+	uint16_t ws_id[kMaxRows];
+	int32_t ws_R, pad_ws_;
 };
+static_assert(sizeof(EnvState) % 8 == 0, "EnvState is copied as 64-bit words");
 
 struct GroundRec {
 	// logical order: slot 0 = min segment, slot 1 = max segment (the host resolves the reference's mFlipSeg)

@@ -188,6 +188,15 @@ dtrl_status dtrl_get_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, doub
 dtrl_status dtrl_command_action(dtrl_batch* b, const int32_t* env_ids, int n, const int32_t* action_ids);
 /* Replaces: cSimCharacter::SetPose / SetVel (sim/SimCharacter.cpp:665-683, 227-315). */
 dtrl_status dtrl_set_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, const double* q, const double* qd);
+/* Replaces: the state Bullet's collision world keeps BETWEEN stepSimulation calls besides the bodies' poses and velocities: the persistent contact points of
+ * the dispatcher's manifolds with their applied normal / friction impulses (btManifoldPoint::m_appliedImpulse, m_appliedImpulseLateral1), which the default
+ * btSequentialImpulseConstraintSolver the reference builds (sim/World.cpp:61-77) warm-starts from with factor 0.85. A character's dynamic state is (q, qd) PLUS this
+ * cache: whoever saves, restores or transplants a character mid-run (checkpointing, the side-by-side parity tests) moves both. Per env i: count[i] rows
+ * (<= DTRL_MAX_CONTACT_ROWS), ids[i][k] = identity of row k (ground contact 2 x sample point + (0 normal, 1 tangent); link--link contact 512 + 2 x (pair x 12 +
+ * candidate) + (0, 1); 65535 = a joint-limit row, never matched) and lambda[i][k] = the impulse it ended the last substep with. cWorld::Reset empties it. */
+#define DTRL_MAX_CONTACT_ROWS 24
+dtrl_status dtrl_get_contact_cache(dtrl_batch* b, const int32_t* env_ids, int n, int32_t* count, int32_t* ids, double* lambda);
+dtrl_status dtrl_set_contact_cache(dtrl_batch* b, const int32_t* env_ids, int n, const int32_t* count, const int32_t* ids, const double* lambda);
 
 /* Replaces: cScenarioSimChar::AddPerturb -> cWorld::AddPerturb (scenarios/ScenarioSimChar.cpp:204-207, sim/World.cpp:256-259) with a
  * tPerturb of type ePerturbForce (sim/Perturb.cpp:52-79, sim/World.cpp:445-470): a world-frame force[n][2] on body part link[n] at the

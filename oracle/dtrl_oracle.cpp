@@ -74,6 +74,19 @@ void orc_set_pose_vel(void* p, const double* q, const double* qd)
 	for (int i = 0; i < e.D; ++i) { e.q[i] = q[i]; e.qd[i] = qd[i]; }
 	ForwardKin(e.M, e.q, e.qd, e.B);
 }
+// the integrator's persistent contact rows (or_sim.h Integrator::prev_*): identities and the impulses the last substep ended with; 24 slots
+int orc_get_warm(void* p, int32_t* ids, double* lam)
+{
+	Env& e = static_cast<OrcHandle*>(p)->env;
+	for (int k = 0; k < SimConst::max_rows; ++k) { ids[k] = k < e.integ.prev_R ? e.integ.prev_id[k] : 0xffff; lam[k] = k < e.integ.prev_R ? e.integ.prev_lam[k] : 0.0; }
+	return e.integ.prev_R;
+}
+void orc_set_warm(void* p, int R, const int32_t* ids, const double* lam)
+{
+	Env& e = static_cast<OrcHandle*>(p)->env;
+	e.integ.prev_R = R;
+	for (int k = 0; k < R && k < SimConst::max_rows; ++k) { e.integ.prev_id[k] = ids[k]; e.integ.prev_lam[k] = lam[k]; }
+}
 void orc_add_perturb(void* p, int link, double lx, double ly, double fx, double fy, double dur) { static_cast<OrcHandle*>(p)->env.AddPerturb(link, lx, ly, fx, fy, dur); }
 void orc_get_tau(void* p, double* tau_ctrl, double* tau_applied)
 {

@@ -272,7 +272,8 @@ def build_model(arg_file, root, overrides=None):
     m.warm_start = int(args.get("warm_start", 1))
     brk = float(args.get("contact_breaking", 0.02))   # gContactBreakingThreshold x the box's angular-motion disc |half extents| (the world scale cancels)
     for j in range(L):
-        m.link_brk[j] = brk * 0.5 * (m.body_size[j][0] ** 2 + m.body_size[j][1] ** 2 + m.body_size[j][2] ** 2) ** 0.5
+        hx, hy, hz = (0.5 * m.body_size[j][k] for k in range(3))
+        m.link_brk[j] = brk * math.sqrt(hx * hx + hy * hy + hz * hz)
     m.mass_matrix_every = max(1, int(args.get("mass_matrix_every", 1)))
     m.terrain_type = 0
     m.n_terrain_sets = 1
@@ -437,6 +438,8 @@ def lib():
         L.orc_get_pose_vel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_set_pose_vel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_add_perturb.argtypes = [C.c_void_p, C.c_int] + [C.c_double] * 5
+        L.orc_get_warm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; L.orc_get_warm.restype = C.c_int
+        L.orc_set_warm.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_get_tau.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_get_contacts.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_get_flags.restype = C.c_uint32
@@ -514,6 +517,16 @@ class OracleEnv:
     def set_pose_vel(self, q, qd):
         q = np.ascontiguousarray(q, np.float64); qd = np.ascontiguousarray(qd, np.float64)
         self.L_.orc_set_pose_vel(self.h, _p(q), _p(qd))
+
+    def warm_cache(self):
+        """(count, ids[24], lambda[24]): the integrator's persistent contact rows -- with (q, qd) the whole dynamic state (the product: dtrl_get_contact_cache)"""
+        ids = np.zeros(24, np.int32); lam = np.zeros(24)
+        n = self.L_.orc_get_warm(self.h, _p(ids), _p(lam))
+        return n, ids, lam
+
+    def set_warm_cache(self, count, ids, lam):
+        ids = np.ascontiguousarray(ids, np.int32); lam = np.ascontiguousarray(lam, np.float64)
+        self.L_.orc_set_warm(self.h, int(count), _p(ids), _p(lam))
 
     def add_perturb(self, link, local_pos, force, duration):
         self.L_.orc_add_perturb(self.h, int(link), float(local_pos[0]), float(local_pos[1]), float(force[0]), float(force[1]), float(duration))

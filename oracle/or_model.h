@@ -72,9 +72,10 @@ struct OrcModel {
 	double link_margin[ORC_MAXL];
 	// Bullet's contact persistence (round 5; sim/World.cpp:61-77 builds a default btSequentialImpulseConstraintSolver, whose btContactSolverInfo has
 	// SOLVER_USE_WARMSTARTING with factor 0.85 on the persistent manifold points' applied NORMAL and FRICTION impulses):
-	//   warm_start 1 (default, what the product kernels run): a contact row (ground: sample point; link--link: pair + candidate) keeps its identity across substeps
+	//   warm_start 1 (default, what the product kernels run): a GROUND contact row (sample point) keeps its identity across substeps
 	//     and env-steps and starts the sweeps from 0.85 x the impulse it ended the previous substep with (limit rows start from zero: the solver zeroes the rows of
-	//     typed constraints); a sweep resolves the limit rows, then every normal row, then every friction row (solveSingleIteration's order), and a friction row
+	//     typed constraints; link--link contact rows too: the comparator's friction warm start acts through the ground contacts alone -- ground-only reproduces it,
+	//     pair-only changes nothing, DESIGN 4 -- and a cached friction impulse between two links that no longer press on each other is free force); a sweep resolves the limit rows, then every normal row, then every friction row (solveSingleIteration's order), and a friction row
 	//     only while its normal row carries an impulse (`if (totalImpulse > 0)`), so that the cached friction impulse of a contact without normal force stays applied;
 	//   warm_start 0: every row from zero, one interleaved sweep (rounds 1-4).
 	//   Oracle-only ablations (tools/a2_deviation.py): 2 = as 1 with the interleaved sweep; 3 = as 1 with Bullet's friction direction (along the pre-solve

@@ -48,6 +48,7 @@ struct SimConst {
 	static constexpr double contact_dist_tol = 0.001;   // world-scaled units (sim/ContactManager.cpp:74)
 	static constexpr double max_turn_per_substep = 1.5707963267948966;
 	static constexpr double warmstart_factor = 0.85;   // btContactSolverInfo::m_warmstartingFactor
+	static constexpr double hold_eps = 1e-9;           // a normal impulse below this counts as none for the friction rule (see dtrl_types.h kHoldEps)
 };
 
 struct Bodies {
@@ -253,7 +254,7 @@ struct Integrator {
 	double Arr[SimConst::max_rows], tgt[SimConst::max_rows], lam[SimConst::max_rows];
 	int kind[SimConst::max_rows];  // 0 = limit (lambda >= 0), 1 = contact normal, 2 = contact tangent (paired with previous row)
 	// warm starting (M.warm_start, or_model.h): a row keeps its identity across substeps -- 16-bit ids shared with the kernels (dtrl_kernel.h row_id): ground contact
-	// 2 x sample point + (0 normal, 1 tangent); link--link contact 256 + 2 x (pair x 12 + candidate) + (0, 1); limit rows 32768 + 2 x joint + side (never matched under
+	// 2 x sample point + (0 normal, 1 tangent); link--link contact 512 + 2 x (pair x 12 + candidate) + (0, 1); limit rows 32768 + 2 x joint + side (never matched under
 	// Bullet's rule) -- and starts the sweeps from warmstart_factor x the impulse it ended the previous substep with (btContactSolverInfo::m_warmstartingFactor 0.85 on
 	// the persistent manifold points' m_appliedImpulse / m_appliedImpulseLateral1)
 	int id[SimConst::max_rows], prev_id[SimConst::max_rows], prev_R = 0;
@@ -338,7 +339,7 @@ struct Integrator {
 				PointJacobian(M, B, pc.a, pc.x, pc.y, dx, dy, Jr[R], D);
 				PointJacobian(M, B, pc.b, pc.x, pc.y, dx, dy, jb, D);
 				for (int i = 0; i < D; ++i) Jr[R][i] -= jb[i];
-				kind[R] = 1 + t; id[R] = 256 + 2 * (pc.pair * 2 * SimConst::pts_per_link + pc.cand) + t;
+				kind[R] = 1 + t; id[R] = 512 + 2 * (pc.pair * 2 * SimConst::pts_per_link + pc.cand) + t;
 				tgt[R] = 0.0;   // velocity-level non-penetration only (see DetectPairContacts)
 				++R;
 			}
@@ -360,7 +361,7 @@ struct Integrator {
 		if (ws) {
 			for (int r = 0; r < R; ++r) {
 				if (Arr[r] < 1e-12) continue;
-				if (rule && kind[r] == 0) continue;
+				if (rule && (kind[r] == 0 || id[r] >= 512)) continue;   // Bullet's rule here: ground contact rows only (limit rows: the solver zeroes typed constraints' rows; link--link rows: see or_model.h)
 				for (int p = 0; p < prev_R; ++p) if (prev_id[p] == id[r]) { lam[r] = SimConst::warmstart_factor * prev_lam[p]; break; }
 			}
 			for (int r = 0; r < R; ++r) if (lam[r] != 0) for (int i = 0; i < D; ++i) v[i] += Yr[r][i] * lam[r];
@@ -372,7 +373,7 @@ struct Integrator {
 				if (passes == 2 && ((pass == 0) == (kind[r] == 2))) continue;
 				if (Arr[r] < 1e-12) continue;
 				// a friction row is resolved only while its normal row carries an impulse: the cached friction impulse of a contact without normal force stays applied
-				if (rule && kind[r] == 2 && !(lam[r - 1] > 0)) continue;
+				if (rule && kind[r] == 2 && !(lam[r - 1] > SimConst::hold_eps)) continue;
 				double w = 0; for (int i = 0; i < D; ++i) w += Jr[r][i] * v[i];
 				double nl = lam[r] + (tgt[r] - w) / Arr[r];
 				if (kind[r] == 2) { double lim = SimConst::mu * lam[r - 1]; nl = std::min(std::max(nl, -lim), lim); }

@@ -3,6 +3,7 @@
 oracle/_ref_build/Makefile) computes in the lock-step runs of tests/test_reference_sim.py on the scenes of the BASELINE configurations, so that the PRODUCT
 can be stepped against the reference on a box without /root/reference (the MI355X box): tests/golden/ref_golden_configs.npz
 
+  <run>/frame/{ws_n, ws_id, ws_lam}    the integrator's persistent contact rows at the end of every outer frame (identities + impulses: dtrl_set_contact_cache)
   <run>/frame/{q, qd}                  the motion both sides rode (oracle/or_sim.h supplies it: the inside of Bullet's stepSimulation is the one part of
                                        the reference that cannot be compiled here), at the end of every outer frame, after the frame's fall / reset logic
   <run>/frame/{tau, contacts, state, phase, action_id, params, pd_targets, flags, after_reset, cycles, episodes, avg_dist}
@@ -53,7 +54,7 @@ def freeze(out, tag, kind, arg, seed, frames, pol, S, O, global_seed, explore_of
     if command is not None:
         r.command_action(command); e.command_action(command)
     ls = rs.LockStep(r, e)
-    F = {k: [] for k in ("q", "qd", "tau", "contacts", "state", "phase", "action_id", "params", "pd_targets", "flags", "after_reset", "cycles", "episodes", "avg_dist")}
+    F = {k: [] for k in ("q", "qd", "tau", "contacts", "state", "phase", "action_id", "params", "pd_targets", "flags", "after_reset", "cycles", "episodes", "avg_dist", "ws_n", "ws_id", "ws_lam")}
     cyc_f, cyc_s = [], []
     t_rows, t_flags, t_frame = [], [], []
     prev_cycles = 0
@@ -62,6 +63,7 @@ def freeze(out, tag, kind, arg, seed, frames, pol, S, O, global_seed, explore_of
         q, qd = e.pose_vel()
         _, rr = ls.records[-1]
         F["q"].append(q); F["qd"].append(qd)
+        wn, wid, wlam = e.warm_cache(); F["ws_n"].append(wn); F["ws_id"].append(wid.copy()); F["ws_lam"].append(wlam.copy())   # the persistent contact rows: with (q, qd) the whole dynamic state
         F["tau"].append(rr["tau"]); F["contacts"].append(rr["contacts"].astype(np.int8)); F["state"].append(rr["state"]); F["phase"].append(rr["phase"])
         F["action_id"].append(rr["action_id"]); F["params"].append(rr["params"]); F["pd_targets"].append(rr["pd_targets"]); F["flags"].append(rr["flags"])
         F["after_reset"].append(bool(rr.get("after_reset")))

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import EMUL_LIB, HIP_LIB, REFDATA, REFERENCE, REPO, EmulScenario, dog_policy
+from conftest import EMUL_LIB, HIP_LIB, REFDATA, REFERENCE, REPO, EmulScenario, dog_policy, pin_to_oracle
 
 Scenario = EmulScenario   # the GPU twin points this at the product class
 SHIM_DIR = os.path.join(REPO, "tests", "shim")
@@ -196,6 +196,7 @@ def test_dist_log_avg_dist_and_output_results(da, om, tmp_path):
         b.Update()
         for e in es:
             e.update()
+        pin_to_oracle(b, es)   # every frame from a common state (conftest.pin_to_oracle): an episode's distance then agrees to the growth of its last frame
     d, ids = b.GetDistLog()
     st = b.EvalStats()
     assert len(d) == st["episodes"] >= 3 and np.all(np.diff(ids) >= 0)

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import REFDATA, REPO, EmulScenario, GOLDEN, dog_policy
+from conftest import REFDATA, REPO, EmulScenario, GOLDEN, dog_policy, pin_to_oracle, pin_to_trace
 
 Scenario = EmulScenario   # the GPU twin (tests/test_gpu_parity.py) points this at the product class
 
@@ -124,10 +124,11 @@ def test_ground_bit_exact_vs_oracle(da, om, arg, seed):
     for f in range(480):
         b.Update(); e.update()
         if f % 30 == 29:
-            # chaotic contact dynamics amplify rounding differences between the planar and the 6-D formulation while a
-            # character tumbles; the grounds are compared whenever both sides are still on the same trajectory
+            # chaotic contact dynamics amplify rounding differences while a character tumbles; the grounds are compared whenever both sides are
+            # still on the same trajectory (every frame starts from a common state: conftest.pin_to_oracle)
             if np.abs(b.BuildPose()[0] - e.pose_vel()[0]).max() < 1e-5:
                 sweep(); sweeps += 1
+        pin_to_oracle(b, [e])
     assert sweeps >= 8 and e.stats()["terrain_builds"] > 2
 
 
@@ -253,6 +254,7 @@ def run_synced_episodes(b, es, frames, tol_q=1e-6):
                 assert fl[i] == e.flags()
                 if f - last_sync[i] == 12:
                     windows += 1
+        pin_to_oracle(b, es, tol=tol_q)   # compared first, then put on a common state (conftest.pin_to_oracle)
     return windows, coincide, resets
 
 
@@ -510,6 +512,7 @@ def test_cacla_action_selection_and_tuples_vs_oracle(da, om):
             e.update()
         r, fl, ei = b.DrainTuples()
         rows.append(r); flags.append(fl); ids.append(ei)
+        pin_to_oracle(b, es)
         if f == 30:
             st, ph, aid, prm, tg = b.Ctrl()
             for i, e in enumerate(es):
@@ -565,6 +568,7 @@ def test_raptor_cacla_action_selection_and_tuples_vs_oracle(da, om, tmp_path):
             e.update()
         r, fl, ei = b.DrainTuples()
         rows.append(r); flags.append(fl); ids.append(ei); when.append(np.full(len(ei), f))
+        pin_to_oracle(b, es)
         stum = (b.Flags() & 2) != 0
         first_stumble = np.where(stum & (first_stumble > f), f, first_stumble)
         if f in (8, 20):                                  # (env 1 stumbles at frame 22: contact switching amplifies rounding differences from there on)
@@ -617,6 +621,7 @@ def test_q_head_action_selection_and_tuples_vs_oracle(da, om):
             e.update()
         r, fl, ei = b.DrainTuples()
         rows.append(r); flags.append(fl); ids.append(ei)
+        pin_to_oracle(b, es)
         if f % 10 == 5:
             st, ph, aid, prm, tg = b.Ctrl()
             for i, e in enumerate(es):
@@ -732,7 +737,7 @@ def run_product_vs_frozen_reference_config(da, om, tag, arg, seed, polname, extr
     pol = dog_policy(om) if polname == "dog" else raptor_policy(om)
     b = (scenario or Scenario)(arg, 1, data_root=REFDATA, extra_args=dict(terrain_seed=seed, **extra))
     b.SetPolicy(pol[1], *pol[2:])
-    q_ref, tau_ref, con_ref = G("frame/q"), G("frame/tau"), G("frame/contacts")
+    q_ref, qd_ref, tau_ref, con_ref = G("frame/q"), G("frame/qd"), G("frame/tau"), G("frame/contacts")
     F = len(q_ref); L = tau_ref.shape[1]; P = b.P
     cyc_frames = {int(f): i for i, f in enumerate(G("cycle/frame"))}
     tracking = True
@@ -758,6 +763,7 @@ def run_product_vs_frozen_reference_config(da, om, tag, arg, seed, polname, extr
             n_resets_tracked += 1
             assert dq < 1e-9, (tag, f, dq)                          # the reference's reset pose
             continue
+        pin_to_trace(b, lambda k: G("frame/" + k), f)              # compared (dq above), then onto the frozen motion for the next frame (conftest.pin_to_oracle); the reads below are of this frame's state
         assert np.array_equal(b.Contacts()[0][:L], con_ref[f][:L]), (tag, f)
         s_, ph, aid, prm, tg = b.Ctrl()
         assert s_[0] == G("frame/state")[f] and abs(ph[0] - G("frame/phase")[f]) < 1e-9, (tag, f)
@@ -840,7 +846,7 @@ def test_product_vs_frozen_reference_tuples(da, om, run, scenario=None):
         b.SetPolicy(pol[1], *pol[2:])
     b.SetExplore(False, 0.2, 0.025, 0.002)
     b.CommandAction(cmd)
-    q_ref = g[tag + "/frame/q"]
+    q_ref, qd_ref = g[tag + "/frame/q"], g[tag + "/frame/qd"]
     got = 0; tracking = True
     for f in range(len(q_ref)):
         b.Update()
@@ -850,6 +856,8 @@ def test_product_vs_frozen_reference_tuples(da, om, run, scenario=None):
             tracking = False
         if not tracking:
             break
+        if not g[tag + "/frame/after_reset"][f]:
+            pin_to_trace(b, lambda k: g[tag + "/frame/" + k], f)     # compared, then onto the frozen motion (conftest.pin_to_oracle)
         idx = np.nonzero(fr_ref == f)[0]
         assert len(r) == len(idx), (tag, f, len(r), len(idx))
         for j, (k, row) in enumerate(zip(idx, r)):
