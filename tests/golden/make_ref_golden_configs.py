@@ -110,7 +110,7 @@ def main():
     freeze(out, "raptor_ng", "poli_eval", "args/raptor_narrow_gaps_args.txt", 11, 90, rap, 275, 87, 2)
     freeze(out, "goat_cliffs", "poli_eval", "args/goat_cliffs_args.txt", 8, 120, dog, 283, 90, 3)
     freeze(out, "exp_mace", "exp_mace", "args/opt_args_train_mace.txt", 21, 120, dog, 283, 90, 4, explore_off=True, command=2, overrides={"policy_model": ""}, stop_after_reset=True)
-    freeze(out, "raptor_exp_mace", "exp_mace", "args/opt_args_train_raptor_mace.txt", 29, 150, rap, 275, 87, 7, explore_off=True, command=0, overrides={"policy_model": ""}, stop_after_reset=True)
+    freeze(out, "raptor_exp_mace", "exp_mace", "args/opt_args_train_raptor_mace.txt", 28, 150, rap, 275, 87, 7, explore_off=True, command=0, overrides={"policy_model": ""}, stop_after_reset=True)
     # Q head: the oracle holds the single-head net in the padded MACE form (one unused critic slot in front)
     desc = om.parse_deploy_prototxt(os.path.join(REF, "data/policies/dog/nets/dog_q_deploy.prototxt"))
     w = om.actor_xavier_weights(desc, 5)

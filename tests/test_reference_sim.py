@@ -40,9 +40,10 @@ def check_records(records, D, n_min, tau_tol=1e-8, prm_tol=1e-9, ctx="", action_
         dq = np.abs(np.concatenate([o["q"][:2] - r["q"][:2], wrap(o["q"][2:] - r["q"][2:])])).max()   # BuildPose reports angles in (-pi, pi]
         dqd = np.abs(o["qd"] - r["qd"]).max()
         # SetPose/SetVel -> rigid bodies -> BuildPose/BuildVel round trip: exact to rounding, except where a link's WORLD angle is within ~1e-7 of pi
-        # (btMatrix3x3 <-> btQuaternion loses digits there: sqrt(trace + 1) with trace -> -1; one step in several hundred, 1e-7 .. 1e-5 rad in the double build)
+        # (btMatrix3x3 <-> btQuaternion loses digits there: sqrt(trace + 1) with trace -> -1; 1e-9 .. 1e-5 rad in the double build. With round 5's contact model the dog's
+        # toe lingers near that angle: a tenth of the steps lose the ninth digit, which the torque tolerance below carries as 400 x dq; steps looser than 1e-6 stay rare)
         assert dq < 1e-4 and dqd < 1e-9, (ctx, k, dq, dqd)
-        n_loose += dq > 1e-9
+        n_loose += dq > 1e-6
         assert np.array_equal(o["contacts"], r["contacts"]), (ctx, k, o["contacts"], r["contacts"])   # cContactManager::Update (distance <= 0.001 scaled)
         assert o["state"] == r["state"] and abs(o["phase"] - r["phase"]) < 1e-12, (ctx, k, o["state"], r["state"], o["phase"], r["phase"])
         assert o["flags"] == r["flags"], (ctx, k, hex(o["flags"]), hex(r["flags"]))   # fallen | stumbled | new cycle | FSM state
@@ -54,7 +55,7 @@ def check_records(records, D, n_min, tau_tol=1e-8, prm_tol=1e-9, ctx="", action_
         assert dt < tau_tol * max(1.0, np.abs(o["tau"]).max()) + 400 * dq, (ctx, k, dt, dq)   # (gains up to 300 N m / rad turn a pose rounding into a torque one)
         worst_tau = max(worst_tau, dt); worst_q = max(worst_q, dq)
         n_contact += int(o["contacts"].any()); n_new_cycle += (o["flags"] >> 2) & 1; states.add(o["state"])
-    assert n_loose <= max(2, len(records) // 100), (ctx, n_loose)
+    assert n_loose <= max(2, len(records) // 20), (ctx, n_loose)
     return dict(worst_tau=worst_tau, worst_q=worst_q, n_contact=n_contact, n_new_cycle=n_new_cycle, states=states, n_loose=n_loose)
 
 
@@ -344,28 +345,29 @@ def test_ground_window_bit_exact_in_the_float_build(om, arg, seed):
 
 
 def _in_band(v1, si, key, rel=None, absolute=None, nse=3.0):
-    """|v1 - SI| inside the stated band (relative to SI, or absolute), or inside `nse` standard errors of the difference over the seeds (the statistics of a
-    stumbling character under a synthetic policy are noisy: tools/a2_deviation.py prints both for the 32-seed study)"""
+    """|v1 - SI| inside the stated band (relative to SI, or absolute), or -- nse > 0 -- inside `nse` standard errors of the difference over the seeds (the statistics of a
+    stumbling character under a synthetic policy are noisy: tools/a2_deviation.py prints both for the 32-seed study). nse = 0: the band alone decides."""
     d = abs(v1[key] - si[key])
     band = rel * abs(si[key]) if rel is not None else absolute
     se = float(np.hypot(v1["se"][key], si["se"][key]))
-    return d <= band or (np.isfinite(se) and d <= nse * se)
+    return d <= band or (nse > 0 and np.isfinite(se) and d <= nse * se)
 
 
 def test_integrator_v1_vs_bullet_shaped_sequential_impulse_bands(om):
-    """SURVEY 8a row a2 quantified on ALL FIVE scenes of the study: the REFERENCE'S OWN controllers (compiled, oracle/_ref/libref_sim.so) driven once by
-    Integrator v1 (the product's model, through the lock-step harness) and once by oracle/or_bullet_si.h (maximal coordinates, sequential impulse with Bullet 2.8x's
-    published structure and defaults) must produce the same gait within stated bands. Full study with ablations and standard errors: tools/a2_deviation.py ->
-    profiles/r04_a2_deviation.txt (32 seeds x 300 frames per cell). Bands below are on short samples; a statistic passes inside its band OR inside 3 standard errors of
-    the difference over the seeds.
+    """SURVEY 8a row a2 quantified on ALL FIVE scenes of the study: the REFERENCE'S OWN controllers (compiled, oracle/_ref/libref_sim.so) driven once by Integrator v1 AS THE
+    PRODUCT SHIPS IT (default arguments, through the lock-step harness) and once by oracle/or_bullet_si.h WITH BULLET'S DEFAULTS (maximal coordinates, sequential impulse
+    with Bullet 2.8x's published structure: warm-started normal and friction impulses included) must produce the same gait within stated bands. Full study with ablations and
+    standard errors: tools/a2_deviation.py -> profiles/r05_a2_deviation.txt (32 seeds x 300 frames per cell).
       flat FSM scenes (deterministic)           cycle 2 %, speed 3 %, reward 3 %, duty 0.01
-      dog + slopes_mixed + MACE net  configs[1] cycle 5 %, speed 10 %, reward 10 %, duty 0.03, falls 3 s.e.
-      goat + cliffs_rugged           configs[4] cycle 12 %, reward 15 %, duty 0.05, speed / falls 3 s.e.
-      raptor + narrow_gaps           configs[2] the one scene with an attributed gap: the comparator WARM-STARTS ITS FRICTION ROWS (Bullet >= 2.81 covers them with
-                                                SOLVER_USE_WARMSTARTING) and resolves a friction row only while its normal row carries an impulse, so a stance foot's friction
-                                                impulse persists; Integrator v1 re-solves every row from zero. Held two ways: (a) v1 vs the comparator with normals-only warm
-                                                start: cycle 5 %, speed 10 %, reward 10 %, duty 0.03, falls 25 %; (b) v1 with the oracle-only switch -warm_start= 2 (the same
-                                                rule restated in the reduced-coordinate sweep) vs the comparator as it is: cycle 10 %, speed 15 %, reward 20 %, duty 0.04, falls 30 %."""
+      dog + slopes_mixed + MACE net  configs[1] cycle 5 %, speed 10 %, reward 10 %, duty 0.03, falls 3 s.e.                      (8 seeds x 150 frames; band or 3 s.e.)
+      goat + cliffs_rugged           configs[4] cycle 12 %, reward 15 %, duty 0.05, speed / falls 3 s.e.                         (16 seeds x 200 frames; band or 3 s.e.)
+      raptor + narrow_gaps           configs[2] cycle 5 %, speed 10 %, reward 10 %, duty 0.03, falls 25 % -- THE BAND ALONE, no standard-error escape (ADVICE r4:
+                                                rounds 3-4 held this scene only against a comparator with its friction warm start switched off). 32 seeds x 300 frames, the
+                                                sample size of the study, because at 8 x 150 the standard error of the fall rate alone is 10 %. Since round 5 the product
+                                                carries Bullet's contact persistence itself (DevModel::warm_start, link_brk). The median cycle must agree to 2 % as well: the
+                                                MEAN cycle is carried by a tail of long cycles (a character balancing on a glued stance foot while the FSM waits for the swing
+                                                toe to land), 10 % of the comparator's cycles and 3-4 % of v1's -- on the study's seed set 101..132 that puts the mean at
+                                                -8 % (DESIGN 4 says so; pooled over both seed sets -6 %), on this test's set 201..232 at -4 %."""
     import sys
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import a2_deviation as a2
@@ -377,15 +379,15 @@ def test_integrator_v1_vs_bullet_shaped_sequential_impulse_bands(om):
         print(scene[0], si_opts, v1_overrides); print("  v1 " + a2.fmt(v1)); print("  SI " + a2.fmt(si)); print("  rel " + a2.rel_line(v1, si))
         return v1, si
 
-    def hold(v1, si, tag, cycle, speed, reward, duty, falls):
+    def hold(v1, si, tag, cycle, speed, reward, duty, falls, nse=3.0):
         bad = []
         for key, rel in (("cycle_s", cycle), ("speed", speed), ("reward", reward), ("falls_k", falls)):
-            if rel is not None and not _in_band(v1, si, key, rel=rel):
+            if rel is not None and not _in_band(v1, si, key, rel=rel, nse=nse):
                 bad.append(key)
             if rel is None and not _in_band(v1, si, key, absolute=0.0):
                 bad.append(key)
         for key in ("duty_front", "duty_back"):
-            if not _in_band(v1, si, key, absolute=duty):
+            if not _in_band(v1, si, key, absolute=duty, nse=nse):
                 bad.append(key)
         assert not bad, (tag, bad, {k: (v1[k], si[k]) for k in bad})
     # (i) the clean gait comparison: FSM controllers on flat ground, no network, no falls
@@ -401,11 +403,10 @@ def test_integrator_v1_vs_bullet_shaped_sequential_impulse_bands(om):
     # (ii) BASELINE configs[1]'s scene with the (synthetic) MACE policy
     v1, si = pair(a2.SCENES[2], seeds8, 150)
     hold(v1, si, "dog slopes_mixed", 0.05, 0.10, 0.10, 0.03, None)
-    # (iii) configs[2]'s scene: the attributed gap, held from both sides
-    v1, si = pair(a2.SCENES[3], seeds8, 150, si_opts=dict(friction_warmstart=0))
-    hold(v1, si, "raptor narrow_gaps vs SI with normals-only warm start", 0.05, 0.10, 0.10, 0.03, 0.25)
-    v1w, sid = pair(a2.SCENES[3], seeds8, 150, v1_overrides=dict(warm_start=2))
-    hold(v1w, sid, "raptor narrow_gaps, v1 with Bullet's friction warm-start rule vs SI", 0.10, 0.15, 0.20, 0.04, 0.30)
+    # (iii) configs[2]'s scene: the product's default model against the comparator's defaults, the band alone
+    v1, si = pair(a2.SCENES[3], list(range(201, 233)), 300)
+    hold(v1, si, "raptor narrow_gaps, default v1 vs default SI", 0.05, 0.10, 0.10, 0.03, 0.25, nse=0.0)
+    assert abs(v1["cycle_median"] - si["cycle_median"]) <= 0.02 * si["cycle_median"], (v1["cycle_median"], si["cycle_median"])
     # (iv) configs[4]'s scene (goat, world scale 1, one substep of 1/600 s per env-step): a slow, often-falling character under this policy -> a larger sample
     v1, si = pair(a2.SCENES[4], list(range(201, 217)), 200)
     hold(v1, si, "goat cliffs_rugged", 0.12, None, 0.15, 0.05, None)

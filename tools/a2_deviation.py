@@ -92,7 +92,7 @@ class Stats:
     def summary(self):
         n = max(self.steps, 1)
         c = np.array(self.cycles) if self.cycles else np.zeros(1)
-        return dict(env_steps=self.steps, cycle_s=float(c.mean()), cycle_sd=float(c.std()), n_cycles=len(self.cycles), speed=self.speed / n, falls_k=1000.0 * self.falls / n,
+        return dict(env_steps=self.steps, cycle_s=float(c.mean()), cycle_median=float(np.median(c)), cycle_long=float((c > 0.6).mean()), cycle_sd=float(c.std()), n_cycles=len(self.cycles), speed=self.speed / n, falls_k=1000.0 * self.falls / n,
                     duty_front=float(self.duty[0] / n), duty_back=float(self.duty[1] / n), ep_dist=float(np.mean(self.dists)) if self.dists else float("nan"),
                     n_episodes=len(self.dists), reward=float(np.nanmean(self.rewards)) if self.rewards else float("nan"))
 
