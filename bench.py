@@ -257,6 +257,7 @@ def main():
     ap.add_argument("--exchange-steps", type=int, default=-1, help="timed frames of the exchange leg (default: half of --steps, at least 50; 0 = skip)")
     ap.add_argument("--bcast-every", type=int, default=10, help="exchange leg: policy broadcast every K frames")
     ap.add_argument("--no-rccl-leg", action="store_true", help="1-GPU run: do not open a one-rank RCCL group for the exchange leg (the leg then runs without any collective)")
+    ap.add_argument("--model-args", default="", help="ABLATIONS ONLY: comma-separated overrides of the physics model's creation arguments, e.g. warm_start=0,contact_breaking=0 (the round-4 model); the line then carries config.model_overrides and is not the headline")
     ap.add_argument("--dry-launch", action="store_true", help="every rank prints its placement (rank, local rank, world, global env offset, host threads) as one JSON line and exits: checks the launch path without a GPU")
     a = ap.parse_args()
 
@@ -294,8 +295,9 @@ def main():
         torch.cuda.set_device(local_rank)
 
     import deepterrainrl_amd as da
+    model_overrides = dict(kv.split("=", 1) for kv in a.model_args.split(",") if kv)
     b = da.BatchScenario(cfg["arg_file"], n, data_root=ROOT, device_id=local_rank,
-                         extra_args={"terrain_seed": 20260925, "rand_seed": 1, "global_env_offset": rank * n, "terrain_gen": a.terrain_gen})
+                         extra_args=dict({"terrain_seed": 20260925, "rand_seed": 1, "global_env_offset": rank * n, "terrain_gen": a.terrain_gen}, **model_overrides))
     w = xavier_weights(b.PolicyNumParams(), cfg["n_char"], cfg["frag"])
     scale = load_scale(cfg)
     b.SetPolicy(w, *scale)
@@ -383,7 +385,7 @@ def main():
             "window_s": {"median": dt, "min": float(min(windows)), "max": float(max(windows)), "total": wall}, "preroll": preroll,
             "config": {"workload": cfg["workload"] % n, "baseline_config_index": a.config,
                        "envs_per_gpu": n, "global_envs": n * world, "env_steps_per_step": n * world * STEPS_PER_FRAME,
-                       "substeps_per_env_step": 5, "parallelism": "env-sharded x%d, no data-path collective" % world, "terrain_gen": a.terrain_gen, "link_contacts": 1,
+                       "substeps_per_env_step": 5, "parallelism": "env-sharded x%d, no data-path collective" % world, "terrain_gen": a.terrain_gen, "link_contacts": 1, "contact_model": "Bullet contact persistence: warm-started ground contact rows (0.85), friction held under an unloaded normal, rows within the breaking threshold (DESIGN 4)" if not model_overrides else "ABLATION", "model_overrides": model_overrides,
                        "host_threads_per_rank": host_threads},
             "rccl": rccl,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

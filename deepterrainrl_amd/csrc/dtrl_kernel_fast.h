@@ -640,7 +640,7 @@ __device__ __forceinline__ void warm_match_fast(WSFast& ws)
 		for (int p = 0; p < Rp; ++p) hit = (ws.st.ws_id[p] == id) ? p : hit;
 		if (id < kFirstPairRowId && hit >= 0) l0 = kWarmFactor * ws.st.ws_lam[hit];   // ground contact rows only
 	}
-	env_sync();
+	// (no barrier between the reads above and the writes below: one wavefront, and its LDS operations complete in issue order)
 	if (lane < R) { ws.st.ws_lam[lane] = l0; ws.st.ws_id[lane] = static_cast<uint16_t>(id); }
 	if (lane == 0) ws.st.ws_R = R;
 	env_sync();
@@ -678,9 +678,12 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 		constexpr int kEnd = kTailInSweep ? kMaxRows : kPgsRegRows;
 		if (any_l0) pgs_rows_warm<0, kPgsRegRows, kEnd>(a, ws, w, lam, mine, lane, R);
 		const unsigned long long pass0 = warm ? (actR & ~tmask) : actR, pass1 = actR & tmask;
-		for (int it = 0; it < kPgsIters; ++it) {
-			pgs_rows_sweep<0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, tang, holdable, mine, pass0, lane, R, 0.0);
-			if (warm && pass1 != 0ull) pgs_rows_sweep<0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, tang, holdable, mine, pass1, lane, R, 0.0);
+		// one call site for both passes (the unrolled sweep is the largest piece of straight-line code in the substep: two copies of it cost instruction-cache room)
+		const int n_sweeps = warm ? 2 * kPgsIters : kPgsIters;
+#pragma unroll 1
+		for (int sw = 0; sw < n_sweeps; ++sw) {
+			const unsigned long long rows = (warm && (sw & 1)) ? pass1 : pass0;
+			if (rows != 0ull) pgs_rows_sweep<0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, tang, holdable, mine, rows, lane, R, 0.0);
 		}
 		if (mine) ws.st.ws_lam[lane] = lam;
 		env_sync();

@@ -3,8 +3,8 @@
 
 SURVEY 8a row a2 -- what happens inside Bullet's stepSimulation -- is the one part of the hot path that cannot be pinned: Bullet is absent. This tool
 quantifies the modelling gap instead of leaving it open: the REFERENCE'S OWN scenario + controllers (compiled unchanged, oracle/_ref/libref_sim.so) are
-driven once by Integrator v1 (oracle/or_sim.h = the product kernel's model: reduced coordinates, Delassus-space PGS, Bullet's per-box safe margin, no warm
-start / split impulse; lock-step harness of oracle/refsim.py) and once by oracle/or_bullet_si.h (maximal coordinates, sequential impulse with Bullet 2.8x's published
+driven once by Integrator v1 (oracle/or_sim.h = the product kernel's model: reduced coordinates, Delassus-space PGS, Bullet's per-box safe margin and -- since round 5 -- its contact
+persistence: warm-started ground contact rows, friction held under an unloaded normal, rows within the breaking threshold; no split impulse; lock-step harness of oracle/refsim.py) and once by oracle/or_bullet_si.h (maximal coordinates, sequential impulse with Bullet 2.8x's published
 structure and defaults: ERP joints, 10 sweeps, warm-started persistent contacts, margins + breaking threshold, split impulse, angular-limit rows), on the
 same scenes, seeds and (synthetic) policies, and distribution-level statistics of the resulting behaviour are compared:
 
@@ -165,7 +165,7 @@ def run_seed(job):
     return st.raw()
 
 
-KEYS = ("cycle_s", "speed", "falls_k", "duty_front", "duty_back", "ep_dist", "reward")
+KEYS = ("cycle_s", "cycle_median", "cycle_long", "speed", "falls_k", "duty_front", "duty_back", "ep_dist", "reward")
 _POOL = None
 
 
@@ -210,10 +210,17 @@ def rel_line(a, b):
 SI_ABLATIONS = (("no margin", dict(use_margin=0)), ("no warm start", dict(warmstarting=0)), ("no split impulse", dict(split_impulse=0)),
                 ("no link contacts", dict(link_contacts=0)), ("1 point per pair", dict(max_points=1)), ("erp 0.8 joints", dict(erp=0.8)), ("20 iterations", dict(iterations=20)),
                 ("no FRICTION warm start (normals only)", dict(friction_warmstart=0)), ("no terrain-vertex contacts", dict(vertex_contacts=0)),
-                ("round-3 comparator: margin 0.04 + breaking 0.02 on every box", dict(safe_margin=0, relative_breaking=0)))
-V1_ABLATIONS = (("warm start 0.85 (oracle-only switch)", dict(warm_start=1)),
-                ("warm start 0.85 with Bullet's rule that a friction row is resolved only while its normal row carries an impulse (oracle-only switch -warm_start= 2)", dict(warm_start=2)), ("sharp boxes (-collision_margin= 0)", dict(collision_margin=0)),
-                ("round-3 model: 0.04 / world_scale on every link (-safe_margin= 0)", dict(safe_margin=0)), ("no link contacts", dict(link_contacts=0)))
+                ("round-3 comparator: margin 0.04 + breaking 0.02 on every box", dict(safe_margin=0, relative_breaking=0)),
+                ("diagnostic: friction rows always resolved (no `if (totalImpulse > 0)`)", dict(friction_skip=0)), ("diagnostic: friction along the plane-space vector only", dict(friction_dir=0)),
+                ("diagnostic: normal and friction row of a contact interleaved", dict(interleave=1)), ("diagnostic: friction warm start on GROUND contacts only", dict(friction_ws_lifted=3)),
+                ("diagnostic: friction warm start on LINK--LINK contacts only", dict(friction_ws_lifted=4)))
+V1_ABLATIONS = (("round-4 model: no warm start, rows only while penetrating (-warm_start= 0 -contact_breaking= 0)", dict(warm_start=0, contact_breaking=0)),
+                ("no warm start / friction rule (-warm_start= 0), rows within the breaking threshold", dict(warm_start=0)),
+                ("Bullet's rule, rows only while penetrating (-contact_breaking= 0)", dict(contact_breaking=0)),
+                ("Bullet's rule with the interleaved sweep (oracle-only -warm_start= 2)", dict(warm_start=2)),
+                ("Bullet's rule with Bullet's friction direction: along the pre-solve tangential velocity (oracle-only -warm_start= 3)", dict(warm_start=3)),
+                ("plain warm start of every row, no friction rule (oracle-only -warm_start= 4)", dict(warm_start=4)),
+                ("sharp boxes (-collision_margin= 0)", dict(collision_margin=0)), ("no link contacts", dict(link_contacts=0)))
 
 
 def main():
