@@ -83,14 +83,18 @@ def feed_chunks(t, rows, flags, chunk, ph=None, poll=None):
 
 
 def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, device_id=-1, extra_args=None, seed=0, log_every=0, out_scale_file=None,
-          trainer_device=None, overlap=False, frames_per_drain=1, scenario_cls=BatchScenario, trainer="torch", trainer_lib=None, poll=False):
+          trainer_device=None, overlap=False, frames_per_drain=1, scenario_cls=BatchScenario, trainer="torch", trainer_lib=None, poll=False,
+          eval_every=None, eval_fn=None, out_model_file=None):
     """extra_args override / extend the arg file (both for the engine and for the -trainer_* keys read here).
     overlap=True trains on frame f's tuples while the GPU already rolls out frame f+1 (dtrl_step_begin / dtrl_step_end): the policy
     each frame runs with is one frame staler, as with the reference's concurrent env threads; overlap=False is the strictly
     sequential, reproducible schedule. frames_per_drain > 1 rolls out several outer frames per drain / policy sync (RunFrames: the env
     groups then run without a frame barrier between them, which is where the rollout engine is fastest). poll=True (with overlap) relaunches an env group
     whose frame ends while the trainer is busy between two Train() calls (dtrl_step_poll) -- measured on one GPU: ~2 early relaunches per frame and no gain
-    (dog 9.95-11.2 M with, 11.2-11.4 M without: the trainer's kernels and the frame waves share the same wavefront slots either way), so it is off by default."""
+    (dog 9.95-11.2 M with, 11.2-11.4 M without: the trainer's kernels and the frame waves share the same wavefront slots either way), so it is off by default.
+    eval_every / eval_fn: eval_fn(iteration, trainer, batch) is called before the first iteration and then whenever the iteration counter has passed another
+    eval_every (cScenarioTrain's intermediate output every trainer_int_iter, scenarios/ScenarioTrain.cpp:376-410, with an evaluation in its place: tools/learn_curve.py).
+    out_model_file: the trainer's net as a Caffe HDF5 model at the end (cNeuralNetTrainer::OutputModel), next to out_scale_file."""
     if overlap:
         extra_args = dict({"tuple_ring": "host"}, **(extra_args or {}))    # drains beside a running frame must not queue copies behind it (include/dtrl.h: dtrl_drain_tuples)
     args = parse_arg_file(os.path.join(data_root, arg_file))
@@ -142,6 +146,9 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
 
     sync(0)
     frames = tuples = 0
+    next_eval = [0 if eval_fn else None]
+    if eval_fn:
+        eval_fn(0, t, b); next_eval[0] = eval_every
     t0 = time.time()
     stats = {"log": []}
     ph = {"rollout": 0.0, "drain": 0.0, "policy_sync": 0.0, "add_tuples": 0.0, "train": 0.0}   # host wall-clock seconds by phase (stats["phases"])
@@ -152,6 +159,9 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
         return feed_chunks(t, rows[o], flags[o], chunk, ph, poll)
 
     def log():
+        if next_eval[0] is not None and t.GetIter() >= next_eval[0]:
+            eval_fn(t.GetIter(), t, b)
+            next_eval[0] = (t.GetIter() // eval_every + 1) * eval_every if eval_every else None
         if log_every and frames % log_every == 0:
             stats["log"].append((frames, t.GetIter(), t.GetNumTuples(), t.last_loss, b.EvalStats()))
             print("frame %d iter %d tuples %d critic-loss %s actor-iters %d" % (frames, t.GetIter(), t.GetNumTuples(), t.last_loss, t.actor_iter), flush=True)
@@ -205,6 +215,8 @@ def train(arg_file, data_root, num_envs=4096, max_iters=None, max_frames=None, d
     dt = time.time() - t0
     if out_scale_file:
         b.WriteOffsetScale(out_scale_file)
+    if out_model_file:
+        t.OutputModel(out_model_file)
     stats.update(frames=frames, iters=t.GetIter(), tuples=tuples, seconds=dt, env_steps_per_s=frames * 20.0 * num_envs / dt,
                  trainer_iters_per_s=t.GetIter() / dt, weights=t.GetWeights(), offset_scale=t.GetOffsetScale(), phases=ph, side_stream_delay_us=side[1])
     return stats

@@ -243,3 +243,137 @@ def test_two_rank_data_parallel_training(tmp_path, da):
     assert np.abs(a["hist"]).max() > 0                                                   # updates happened
     assert int(a["tuples"]) == int(a["drained"]) >= 10 and int(b["tuples"]) == int(b["drained"]) >= 10     # each rank kept exactly what its own engine produced
     assert not np.array_equal(a["stats"], b["stats"])                                    # ... and the two replay memories hold different experience
+
+
+# ---- the 8-rank shape: the node the path is written for has 8 GPUs and the builder has none with more than one, so the first real 8-GPU run must
+# ---- not also be the first 8-rank run. gloo, lane-loop backend, small shards (the collectives, block sizing, carry-over, the remainder split and the gather list of
+# ---- eight are what is under test, not the kernels)
+WORKER8 = r'''
+import os, sys, zlib, numpy as np
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import torch, torch.distributed as dist
+from conftest import REFDATA, EmulScenario, dog_policy
+from oracle import model as om
+from deepterrainrl_amd.sharding import ShardedRollout, shard_range, default_block_rows
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+G = {global_envs}
+def make(n, off):
+    assert (off, n) == shard_range(G, world, rank)
+    return EmulScenario("args/opt_args_train_mace.txt", n, data_root=REFDATA, extra_args=dict(terrain_seed=300, rand_seed=9, global_env_offset=off))
+sr = ShardedRollout(make, G, dist=dist, block_rows={block_rows!r})
+assert sr.cap == ({block_rows!r} or default_block_rows(G, world))
+pol = dog_policy(om)
+if rank == 0:
+    sr.broadcast_policy(pol[1], pol[2], pol[3], pol[4], pol[5], src=0)
+else:
+    sr.broadcast_policy(src=0)
+rows, flags, ids = [], [], []
+for f in range({frames}):
+    sr.Update()
+    g = sr.gather_tuples(dst=0)
+    if rank == 0:
+        rows.append(g[0]); flags.append(g[1]); ids.append(g[2])
+for f in range(40):                      # flush what small blocks carried over
+    g = sr.gather_tuples(dst=0)
+    if rank == 0:
+        rows.append(g[0]); flags.append(g[1]); ids.append(g[2])
+ts = sr.batch.TupleStats()
+assert ts["pending"] == 0 and ts["dropped"] == 0
+q, qd = sr.batch.PoseVel()
+np.savez(os.path.join({out!r}, "w%d_rank%d.npz" % (world, rank)), q=q, off=shard_range(G, world, rank)[0], drained=ts["drained"], pol=sr.batch.PolicyOutput())
+if rank == 0:
+    np.savez(os.path.join({out!r}, "w%d_tuples.npz" % world), rows=np.concatenate(rows), flags=np.concatenate(flags), ids=np.concatenate(ids))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _launch(script, nproc, port, timeout=1500):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("block_rows", [None, 1], ids=["default_block", "one_row_block"])
+def test_eight_rank_gather_is_independent_of_the_world_size(tmp_path, da, om, block_rows):
+    """19 global envs on 8 ranks (shards of 3, 3, 3, 2, 2, 2, 2, 2: shard_range with a remainder), on 2 ranks and in one process: the same trajectories per global env,
+    every tuple delivered to rank 0 exactly once, each env's tuples in time order and bit-identical across the three world sizes -- with the default send block
+    (default_block_rows) and with a one-row block (seven of eight ranks carry rows from frame to frame; the run ends with the flush). The broadcast policy is the same
+    on every rank: all shards ride the single-process trajectories, and the nets' last outputs (dtrl_get_policy_output) are those of the single process."""
+    from conftest import dog_policy
+    G, frames = 19, 40
+    for world, port in ((8, 29631 + (block_rows or 0) * 10), (2, 29633 + (block_rows or 0) * 10)):
+        script = tmp_path / ("worker_w%d.py" % world)
+        script.write_text(WORKER8.format(repo=REPO, out=str(tmp_path), block_rows=block_rows, global_envs=G, frames=frames))
+        _launch(script, world, port)
+    pol = dog_policy(om)
+    b = Scenario("args/opt_args_train_mace.txt", G, data_root=REFDATA, extra_args=dict(terrain_seed=300, rand_seed=9))
+    b.SetPolicy(pol[1], *pol[2:])
+    rows, flags, ids = [], [], []
+    for f in range(frames):
+        b.Update()
+        rr, ff, ii = b.DrainTuples()
+        rows.append(rr); flags.append(ff); ids.append(ii)
+    rows = np.concatenate(rows); flags = np.concatenate(flags); ids = np.concatenate(ids)
+    q, _ = b.PoseVel(); po = b.PolicyOutput()
+    assert len(rows) >= 19
+    for world in (8, 2):
+        drained = 0
+        for r in range(world):
+            d = np.load(tmp_path / ("w%d_rank%d.npz" % (world, r)))
+            off, n = int(d["off"]), len(d["q"])
+            assert np.array_equal(d["q"], q[off:off + n]) and np.array_equal(d["pol"], po[off:off + n]), (world, r)
+            drained += int(d["drained"])
+        t = np.load(tmp_path / ("w%d_tuples.npz" % world))
+        assert drained == len(t["rows"]) == len(rows), (world, drained, len(t["rows"]), len(rows))       # every tuple exactly once
+        for e in range(G):
+            assert np.array_equal(t["rows"][t["ids"] == e], rows[ids == e]) and np.array_equal(t["flags"][t["ids"] == e], flags[ids == e]), (world, e)
+
+
+DP8_WORKER = r'''
+import os, sys, numpy as np
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import torch, torch.distributed as dist
+from conftest import REFDATA, EmulScenario
+from deepterrainrl_amd import train_loop
+dist.init_process_group(backend="gloo")
+rank = dist.get_rank()
+st = train_loop.train_distributed("args/opt_args_train_mace.txt", REFDATA, {global_envs}, dist, max_frames={frames}, trainer_device="cpu", scenario_cls=EmulScenario, extra_args={extra!r},
+                                  trainer="hip", trainer_lib={lib!r}, mode="data_parallel")
+t = st["trainer"]
+X = t.mem[:t.num_tuples, 1:1 + t.S].to(torch.float64)
+stats = torch.cat([torch.tensor([float(X.shape[0])], dtype=torch.float64), X.sum(0), (X * X).sum(0)])
+t.UpdateOffsetScale()          # the pooled normaliser (one all-reduce of count / sum / sum of squares): every rank calls it, after the training it did not feed
+off, sc = t.GetOffsetScale()[:2]
+np.savez(os.path.join({out!r}, "dp8_rank%d.npz" % rank), weights=st["weights"], iters=st["iters"], actor_iters=st["actor_iters"], tuples=st["tuples"], frames=st["frames"],
+         hist=t.nt.get_params(2), stats=stats.numpy(), drained=st["batch"].TupleStats()["drained"], pooled_off=np.asarray(off), pooled_scale=np.asarray(sc))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_eight_rank_data_parallel_training(tmp_path, da):
+    """train_distributed(mode="data_parallel") on EIGHT gloo ranks (native trainer's check build; 43 global envs = shards of 6, 6, 6, 5, 5, 5, 5, 5): the per-frame
+    agreement on the number of Train() calls, the two gradient all-reduces per call and the pooled input normaliser run with eight participants; all ranks end with
+    bit-identical weights and solver history and the same counters, each kept exactly the tuples its own engine produced, and the normaliser every rank computes is
+    the one of the POOLED begin states (ADVICE r4: HipMACETrainerDP.UpdateOffsetScale was never exercised)."""
+    lib = os.path.join(REPO, "tests", "emul", "libdtrl_trainer_emul.so")
+    extra = {"terrain_seed": 3, "trainer_num_init_samples": 48, "trainer_replay_mem_size": 256, "trainer_freeze_target_iters": 2, "tuple_buffer_size": 4,
+             "init_exp_rate": 0.3, "init_exp_base_rate": 0.1, "trainer_init_input_offset_scale": "false"}
+    script = tmp_path / "dp8_worker.py"
+    script.write_text(DP8_WORKER.format(repo=REPO, out=str(tmp_path), extra=extra, lib=lib, global_envs=43, frames=50))
+    _launch(script, 8, 29651, timeout=2400)
+    R = [np.load(tmp_path / ("dp8_rank%d.npz" % r)) for r in range(8)]
+    a = R[0]
+    assert int(a["frames"]) == 50 and int(a["iters"]) >= 2 and np.abs(a["hist"]).max() > 0 and np.all(np.isfinite(a["weights"]))
+    pooled = sum(r["stats"] for r in R)
+    S = (len(pooled) - 1) // 2
+    n = pooled[0]; mean = pooled[1:1 + S] / n
+    std = np.sqrt(np.maximum(pooled[1 + S:] / n - mean * mean, 0.0))
+    exp_scale = np.where(std == 0, 0.0, 1.0 / np.where(std == 0, 1.0, std))
+    for k, r in enumerate(R):
+        assert int(r["iters"]) == int(a["iters"]) and int(r["actor_iters"]) == int(a["actor_iters"]) and int(r["frames"]) == 50, k
+        assert np.array_equal(r["weights"], a["weights"]) and np.array_equal(r["hist"], a["hist"]), k
+        assert int(r["tuples"]) == int(r["drained"]) >= 1, k
+        assert np.allclose(r["pooled_off"], -mean, rtol=1e-6, atol=1e-9) and np.allclose(r["pooled_scale"], exp_scale, rtol=1e-5, atol=1e-9), k
+    assert len({float(r["stats"][0]) for r in R} | {tuple(r["stats"][1:4]) for r in R}) > 2        # the replay memories hold different experience
