@@ -56,7 +56,7 @@ VALU_CYCLES = 4         # one wave64 VALU instruction occupies a SIMD16 for 4 cy
 EXCHANGE_ARG_FILE = "args/opt_args_train_mace.txt"
 STEPS_PER_FRAME = 20
 PREROLL_MIN, PREROLL_MAX, PREROLL_BLOCK = 60, 200, 20
-MIN_TIMED_S = 1.0
+MIN_TIMED_S = 5.0   # (round 5: long enough for the driver's SMI sampler to land inside the timed region; 1 s until round 4)
 
 # B_alg / F_alg: algorithmic bytes / flops per env-step (SURVEY 8d / BASELINE.md 4)
 CONFIGS = {
@@ -110,6 +110,29 @@ def host_parallelism():
     except Exception:
         pass
     return max(1, n)
+
+
+TRAINED_POLICY = {1: "tests/golden/policies/dog_mace3_slopes_mixed_model.h5", 2: "tests/golden/policies/raptor_mace3_narrow_gaps_model.h5"}   # tools/learn_curve.py, round 5
+
+
+def trained_policy_leg(da, torch, cfg, n, local_rank, a, path):
+    """The same workload under a TRAINED policy (the regime the reference lives in: a character that crosses the terrain instead of stumbling every few cycles). A side
+    figure next to the headline, never the headline: the headline keeps the seeded xavier weights every earlier round was measured on."""
+    b = da.BatchScenario(cfg["arg_file"], n, data_root=ROOT, device_id=local_rank, extra_args={"terrain_seed": 20260925, "rand_seed": 1, "terrain_gen": a.terrain_gen})
+    b.LoadModel(path)                       # Caffe HDF5 weights + <model>_scale.txt (cNeuralNet::LoadModel)
+    b.RunFrames(100 + a.warmup)
+    st0 = b.EvalStats(); b.KernelTimeMs()
+    wins = []
+    while sum(wins) < 2.0 and len(wins) < 40:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        b.RunFrames(a.steps)
+        torch.cuda.synchronize(); wins.append(time.perf_counter() - t0)
+    kern_ms, launches = b.KernelTimeMs()
+    st1 = b.EvalStats(); b.close()
+    dt = float(np.median(wins)); frames = a.steps * len(wins)
+    return {"policy": path, "source": "tools/learn_curve.py: 60 000 trainer iterations through this engine (profiles/r05_learning_curve_*.txt)", "env_steps_per_s": n * a.steps * STEPS_PER_FRAME / dt,
+            "ms_per_step": dt / a.steps * 1e3, "kernel_avg_ms": kern_ms, "windows": len(wins), "resets_per_frame": (st1["resets"] - st0["resets"]) / float(frames),
+            "falls_per_1000_env_steps": 1000.0 * (st1["resets"] - st0["resets"]) / (frames * STEPS_PER_FRAME * float(n)), "policy_forwards_per_frame": (st1["cycles"] - st0["cycles"]) / float(frames)}
 
 
 def cpu_baseline(cfg, frames=60):
@@ -257,6 +280,7 @@ def main():
     ap.add_argument("--exchange-steps", type=int, default=-1, help="timed frames of the exchange leg (default: half of --steps, at least 50; 0 = skip)")
     ap.add_argument("--bcast-every", type=int, default=10, help="exchange leg: policy broadcast every K frames")
     ap.add_argument("--no-rccl-leg", action="store_true", help="1-GPU run: do not open a one-rank RCCL group for the exchange leg (the leg then runs without any collective)")
+    ap.add_argument("--no-trained-leg", action="store_true", help="skip the side figure under the trained policy (tests/golden/policies)")
     ap.add_argument("--model-args", default="", help="ABLATIONS ONLY: comma-separated overrides of the physics model's creation arguments, e.g. warm_start=0,contact_breaking=0 (the round-4 model); the line then carries config.model_overrides and is not the headline")
     ap.add_argument("--dry-launch", action="store_true", help="every rank prints its placement (rank, local rank, world, global env offset, host threads) as one JSON line and exits: checks the launch path without a GPU")
     a = ap.parse_args()
@@ -294,6 +318,8 @@ def main():
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
+    # the CPU leg FIRST (round 5): 16 s of host work no longer sit between the timed GPU region and the end of the process, where the driver's SMI samples fell
+    cpu_rec = cpu_baseline(cfg, a.cpu_frames) if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
     import deepterrainrl_amd as da
     model_overrides = dict(kv.split("=", 1) for kv in a.model_args.split(",") if kv)
     b = da.BatchScenario(cfg["arg_file"], n, data_root=ROOT, device_id=local_rank,
@@ -340,7 +366,7 @@ def main():
             dt = agree(dt, dist.ReduceOp.MAX)
         windows.append(dt)
         if repeats <= 0:
-            repeats = int(min(25, max(3, np.ceil(MIN_TIMED_S / max(dt, 1e-6)))))
+            repeats = int(min(60, max(3, np.ceil(MIN_TIMED_S / max(dt, 1e-6)))))
         if len(windows) >= repeats:
             break
     kern_ms, launches = b.KernelTimeMs()
@@ -382,7 +408,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "repeats": len(windows), "value_min": total_env_steps / max(windows), "value_max": total_env_steps / min(windows),
-            "window_s": {"median": dt, "min": float(min(windows)), "max": float(max(windows)), "total": wall}, "preroll": preroll,
+            "window_s": {"median": dt, "min": float(min(windows)), "max": float(max(windows)), "total": wall, "each": [round(float(x), 6) for x in windows]}, "preroll": preroll,
             "config": {"workload": cfg["workload"] % n, "baseline_config_index": a.config,
                        "envs_per_gpu": n, "global_envs": n * world, "env_steps_per_step": n * world * STEPS_PER_FRAME,
                        "substeps_per_env_step": 5, "parallelism": "env-sharded x%d, no data-path collective" % world, "terrain_gen": a.terrain_gen, "link_contacts": 1, "contact_model": "Bullet contact persistence: warm-started ground contact rows (0.85), friction held under an unloaded normal, rows within the breaking threshold (DESIGN 4)" if not model_overrides else "ABLATION", "model_overrides": model_overrides,
@@ -413,6 +439,13 @@ def main():
                              "note": "rank 0's envs over all %d windows: %d falls (terrain regeneration + reset launch each) and %d policy forwards happened inside the timed region; the pre-roll ran until the reset rate was stationary" % (len(windows), resets, cycles)},
         }
     b.close()
+    if rank == 0 and world == 1 and not model_overrides and not a.no_trained_leg:
+        pth = os.path.join(REPO, TRAINED_POLICY[a.config])
+        if os.path.exists(pth) and n == cfg["envs"]:
+            try:
+                line["trained_policy"] = trained_policy_leg(da, torch, cfg, n, local_rank, a, pth)
+            except Exception as exc:
+                line["trained_policy"] = {"error": repr(exc)}
     ex_steps = a.exchange_steps if a.exchange_steps >= 0 else max(a.steps // 2, 50)
     legs = []
     if ex_steps > 0 and a.config == 1:
@@ -458,8 +491,8 @@ def main():
         line["exchange"] = legs[0] if legs else None
         if len(legs) > 1:
             line["exchange_alt"] = legs[1]
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, a.cpu_frames)
+        if cpu_rec is not None:
+            line["cpu_baseline"] = cpu_rec
         import ctypes
         try:
             ctypes.CDLL(None).fflush(None)   # RCCL's version banner sits in the C stdio buffer: out with it first, the JSON line is the last line

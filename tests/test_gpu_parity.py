@@ -238,6 +238,21 @@ def test_bench_contract_line():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
 
 
+def test_bench_trained_policy_leg_and_policy_files():
+    """The policies tools/learn_curve.py trained THROUGH this engine (tests/golden/policies: Caffe HDF5 + _scale.txt, written by the package's own writer) load through
+    cNeuralNet::LoadModel's route and carry the dog across slopes_mixed: the bench's side figure under the trained policy has a fall rate far below the headline's
+    (seeded xavier weights), and the headline itself is untouched by the leg."""
+    import json, subprocess, sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--exchange-steps", "0", "--no-rccl-leg"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    tp = d["trained_policy"]
+    assert "error" not in tp and tp["env_steps_per_s"] > 1e6 and tp["policy"].endswith("dog_mace3_slopes_mixed_model.h5")
+    assert tp["resets_per_frame"] < 0.2 * d["timed_window"]["resets_per_frame"], (tp["resets_per_frame"], d["timed_window"]["resets_per_frame"])
+    assert d["window_s"]["total"] >= 4.5 and len(d["window_s"]["each"]) == d["repeats"]     # the timed region is long enough for an SMI sample to land in it
+
+
 def test_bench_under_a_launcher_with_the_rccl_path_on_one_rank():
     """The N > 1 code path as far as one GPU can take it: bench.py started by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
     launcher's environment, as the driver starts it) with a one-rank RCCL group (DTRL_FORCE_COLLECTIVES=1): process-group start-up, the barrier / all-reduce of

@@ -36,9 +36,21 @@ FEET = {"dog": (16, 20), "raptor": (14, 18)}   # front / back end effector: dog 
 
 
 def policies():
+    """synthetic (seeded xavier weights: what rounds 1-4 measured on) or -- A2_POLICY=trained / --policy trained -- the policies tools/learn_curve.py trained through
+    the product on the MI355X (tests/golden/policies: Caffe HDF5 + _scale.txt): the regime the reference lives in, a character that crosses the terrain"""
     from conftest import dog_policy
     import test_host_and_emul as T
-    return {"dog": dog_policy(om), "raptor": T.raptor_policy(om)}
+    if os.environ.get("A2_POLICY", "synthetic") != "trained":
+        return {"dog": dog_policy(om), "raptor": T.raptor_policy(om)}
+    from deepterrainrl_amd import caffe_hdf5
+    out = {}
+    for name, net, stem in (("dog", "data/policies/dog/nets/dog_mace3_deploy.prototxt", "dog_mace3_slopes_mixed_model"),
+                            ("raptor", "data/policies/raptor/nets/raptor_mace3_deploy.prototxt", "raptor_mace3_narrow_gaps_model")):
+        desc = om.parse_deploy_prototxt(os.path.join(REF, net))
+        base = os.path.join(REPO, "tests", "golden", "policies", stem)
+        w = caffe_hdf5.load_mace_weights(base + ".h5", desc.n_frags)
+        out[name] = (desc, w) + tuple(om.load_scale_file(base + "_scale.txt"))
+    return out
 
 
 SCENES = [  # tag, arg file, character, policy?, dims
@@ -234,13 +246,17 @@ def main():
     ap.add_argument("--v1-ablate", action="store_true", help="Integrator v1 with one modelling switch changed at a time")
     ap.add_argument("--null", action="store_true", help="also run SI on a DISJOINT seed set: the SI-vs-SI line is what sampling alone produces")
     ap.add_argument("--scenes", default="", help="comma-separated scene indices (default: all)")
+    ap.add_argument("--policy", choices=["synthetic", "trained"], default="synthetic", help="trained: tests/golden/policies (scenes 2 and 3 are the ones they were trained for)")
     a = ap.parse_args()
     assert rs.available(), "oracle/_ref/libref_sim.so missing: make -C oracle/_ref_build"
+    os.environ["A2_POLICY"] = a.policy       # (read by the pool's workers)
     seeds = list(range(a.seed0, a.seed0 + a.seeds))
     scenes = [SCENES[int(i)] for i in a.scenes.split(",")] if a.scenes else SCENES
     lines = ["# Integrator v1 (product model) vs Bullet-shaped sequential impulse (oracle/or_bullet_si.h), both driven by the REFERENCE'S OWN controllers",
              "# %d seeds x %d outer frames (%d env-steps) per cell; value (standard error over seeds); rel = (v1 - SI) / SI with the difference in standard errors; tools/a2_deviation.py"
              % (a.seeds, a.frames, a.seeds * a.frames * 20)]
+    if a.policy == "trained":
+        lines.append("# POLICIES: trained through the product (tools/learn_curve.py, 60 000 iterations; tests/golden/policies), not the seeded xavier weights of the other studies")
     results = {}
     for sc in scenes:
         t0 = time.time(); n0 = len(lines)
