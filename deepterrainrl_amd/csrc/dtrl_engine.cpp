@@ -682,6 +682,7 @@ int Engine::SetPolicy(const float* w, size_t n, const double* io, const double* 
 	const NetDesc& d = cfg_.net;
 	if (!w || n != static_cast<size_t>(cfg_.user_num_params)) return Fail(DTRL_ERR_ARG, "weight count does not match the deploy prototxt");
 	be_->Sync();
+	if (!policy_wait_.empty()) { if (!be_->SyncPolicyReady()) return Fail(DTRL_ERR_DEVICE, be_->error()); policy_wait_.assign(policy_wait_.size(), 0); }   // (an asynchronous hand-over still on its way: let it land, then supersede it)
 	policy_flip_pending_ = false;   // (a deferred device hand-over is superseded)
 	std::vector<float> dev_w(relayout_.size());
 	for (size_t i = 0; i < relayout_.size(); ++i) dev_w[i] = relayout_[i] >= 0 ? w[relayout_[i]] : 0.0f;
@@ -735,6 +736,9 @@ int Engine::SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, 
 	if (step_pending_ && policy_set_ && weights_alt_ && !io_dev && !is_dev && !oo_dev && !os_dev) {
 		struct Restore { Backend* b; ~Restore() { b->SelectStream(0); } } restore{be_};
 		be_->SelectStream(be_->NumStreams() - 1);
+		// an ASYNCHRONOUS hand-over (dtrl_set_policy_device_async) may still be gathering into this very buffer on another stream: order behind it, and drop the
+		// frame launches' wait on its event -- this gather is the newer one
+		if (!policy_wait_.empty()) { if (!be_->SyncPolicyReady()) return Fail(DTRL_ERR_DEVICE, be_->error()); policy_wait_.assign(policy_wait_.size(), 0); }
 		// (synchronised: the caller may change w_dev when this returns. On the caller's stream -- the trainer's -- the gather follows the steps queued there and
 		// ONE wait covers both; on the drain stream it would wait for a wavefront slot of its own behind the frame in flight)
 		// a frame kernel may still be READING the buffer about to be overwritten: a group dtrl_step_poll relaunched ran its launch on the buffer that the

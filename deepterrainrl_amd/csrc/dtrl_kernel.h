@@ -75,6 +75,9 @@ namespace dtrl {
 #ifndef DTRL_WAVE_SYNC
 #define DTRL_WAVE_SYNC 1
 #endif
+#if DTRL_WAVE_SYNC && !defined(__GFX9__)
+#error "env_sync(): wavefront-scope fences are only a barrier when the 64-thread workgroup is ONE wavefront (GFX9 / CDNA: wave64). On a wave32 target the workgroup is two waves: build with -DDTRL_WAVE_SYNC=0 (ADVICE r4)"
+#endif
 __device__ __forceinline__ void env_sync()
 {
 #if DTRL_WAVE_SYNC

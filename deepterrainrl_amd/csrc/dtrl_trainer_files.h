@@ -133,6 +133,7 @@ inline bool ParseTrainerFiles(const std::string& net_file, const std::string& so
 		d.fc_trunk = ips["ip1"]->num_output; d.fc_head = ips["ip2"]->num_output; d.n_heads = 1; d.n_frags = 0; d.frag_size = ips["output"]->num_output; d.head_out[0] = d.frag_size;
 		order.push_back("ip1"); order.push_back("ip2"); order.push_back("output");
 	} else { err = net_file + ": neither the MACE heads (ip0, val_ip0 / val_ip1, a<f>_ip0 / a<f>_ip1) nor the single head (ip1, ip2, output)"; return false; }
+	for (size_t k = 3; k < order.size(); ++k) if (!ips.count(order[k])) { err = net_file + ": missing layer " + order[k]; return false; }   // (a net with fewer actor heads than val_ip1 outputs, a malformed prototxt: ADVICE r4)
 	d.max_eval = 3 * d.batch;
 	// per-element multipliers in blob order (weight blob, then bias blob, per layer)
 	std::map<std::string, const Layer*> tl;

@@ -47,6 +47,7 @@ inline FusedPlan fused_plan(const NetDims& d)
 	if (d.fc_terr + d.n_char > 16 * 12 || d.fc_trunk > 16 * 16 || d.fc_head > 8 * 16) return p;
 	for (int f = 0; f < d.n_heads; ++f) if (d.head_out[f] > 32) return p;
 	if (d.n_flat % 4 != 0 || d.fc_terr <= 0 || kFT % d.fc_terr != 0 || kFT / d.fc_terr < 1) return p;
+	if (kFT / d.fc_terr > 64) return p;   // terr_ip0 sums kFT / fc_terr lanes per output with a shuffle reduction: the group must fit in one wavefront; narrower nets take the layer-by-layer path
 	if (d.fc_trunk <= 0 || kFT % d.fc_trunk != 0 || kFT / d.fc_trunk > 4 || d.wo_terr % 4 != 0) return p;
 	const int nhz = d.n_heads * d.fc_head;
 	if (nhz <= 0 || nhz > kFT || d.out_size * 8 > kFT || d.fc_terr > 64 || (d.fc_terr & (d.fc_terr - 1)) != 0) return p;

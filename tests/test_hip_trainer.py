@@ -513,3 +513,25 @@ def test_gpu_data_parallel_trainer_and_loop_on_a_one_rank_rccl_group(tmp_path):
     assert d["maps"] and all(all(x) for x in d["book"]) and d["iters"] == 6 and d["actor_iters"] >= 1, d
     assert d["rel"] < 2e-6, d
     assert d["loop_frames"] == 70 and d["loop_iters"] >= 2 and d["loop_finite"] and d["loop_hist"] > 0 and d["loop_tuples"] == d["loop_drained"] >= 120, d
+
+
+def test_create_from_files_rejects_a_net_with_a_missing_head_instead_of_crashing(tmp_path):
+    """ADVICE r4: ParseTrainerFiles looked every a<f>_ip0 / a<f>_ip1 of val_ip1's fragment count up with std::map::operator[] -- a net with fewer actor heads (or a
+    malformed prototxt) dereferenced a null layer inside dtrl_trainer_create_from_files / cBatchNeuralNet::LoadNet. Now: an error naming the layer."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(REPO, "tests", "emul", "libdtrl_trainer_emul.so"))
+    lib.dtrl_trainer_create_from_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.dtrl_trainer_last_error.restype = C.c_char_p; lib.dtrl_trainer_last_error.argtypes = [C.c_void_p]
+    lib.dtrl_trainer_destroy.argtypes = [C.c_void_p]
+    src = open(os.path.join(REFDATA, "data/policies/dog/nets/dog_mace3_deploy.prototxt")).read()
+    good = tmp_path / "good_deploy.prototxt"; good.write_text(src)
+    h = C.c_void_p()
+    assert lib.dtrl_trainer_create_from_files(str(good).encode(), b"", REFDATA.encode(), 0.9, 0, -1, C.byref(h)) == 0 and h.value
+    lib.dtrl_trainer_destroy(h)
+    cut = "\n".join(l for l in src.splitlines() if '"a2_ip1"' not in l)          # the third actor head's output layer removed; val_ip1 still announces 3 fragments
+    assert cut != src and '"a2_ip1"' not in cut
+    bad = tmp_path / "bad_deploy.prototxt"; bad.write_text(cut)
+    h = C.c_void_p()
+    rc = lib.dtrl_trainer_create_from_files(str(bad).encode(), b"", REFDATA.encode(), 0.9, 0, -1, C.byref(h))
+    assert rc != 0 and not h.value
+    assert b"a2_ip1" in lib.dtrl_trainer_last_error(None)
