@@ -92,6 +92,10 @@ def test_set_pose_reset(da, om):
     T.test_set_pose_vel_and_reset_roundtrip(da, om)
 
 
+def test_contact_cache_and_model_switches(da, om):
+    T.test_contact_cache_is_part_of_the_state_and_model_switches(da, om)
+
+
 def test_row_cap_prone_character(da, om):
     T.test_row_cap_prone_character_vs_oracle(da, om)
 

@@ -1027,6 +1027,51 @@ def test_set_pose_vel_and_reset_roundtrip(da, om):
     assert b.EvalStats()["resets"] == 1
 
 
+def test_contact_cache_is_part_of_the_state_and_model_switches(da, om):
+    """dtrl_get_contact_cache / dtrl_set_contact_cache (round 5: the persistent contact points' identities and applied impulses, Bullet's manifolds between two
+    stepSimulation calls): the cache equals the oracle's after a run, is part of the dynamic state (emptied, the next frame takes another course; restored, it does not),
+    a reset empties it, malformed caches and model switches outside their range are refused; -warm_start= 0 -contact_breaking= 0 is another (the round-4) model."""
+    arg = "args/sim_dog_args.txt"
+    m, _ = om.build_model(arg, REFDATA)
+    e = om.OracleEnv(m, terrain_seed=5)
+    a = batch(da, arg, 2, terrain_seed=5); b = batch(da, arg, 2, terrain_seed=5)
+    for _ in range(6):
+        a.Update(); b.Update(); e.update()
+    for _ in range(200):                                               # (the bounding dog is airborne at some frame ends: on to an env-step that ends with a foot down)
+        c_, i_, l_ = a.ContactCache()
+        if c_[0] >= 4 and np.abs(l_[0][:c_[0]][i_[0][:c_[0]] < 512]).max(initial=0.0) > 1e-3:      # a ground contact row that carries an impulse (limit rows are never warm-started)
+            break
+        a.StepUpdates(1); b.StepUpdates(1); e.step(1)
+    cnt, ids, lam = a.ContactCache()
+    no, ido, lamo = e.warm_cache()
+    assert cnt.shape == (2,) and ids.shape == (2, 24) and lam.shape == (2, 24) and 0 < cnt[0] <= 24
+    assert cnt[0] == no and np.array_equal(ids[0][:no][ido[:no] < 32768], ido[:no][ido[:no] < 32768])      # same contact rows (limit rows carry 65535 here, 32768 + 2 j + side there)
+    assert np.abs(lam[0][:no] - lamo[:no]).max() < 1e-9 * max(1.0, np.abs(lamo[:no]).max())
+    assert np.all(ids[0][cnt[0]:] == 65535) and np.all(lam[0][cnt[0]:] == 0) and np.abs(lam[0][:cnt[0]]).max() > 0
+    b.SetContactCache(cnt, ids, lam)                                   # identity: no effect
+    b.SetContactCache([0], np.full((1, 24), 65535), np.zeros((1, 24)), env_ids=[1])    # env 1 loses its persistent contact points
+    assert b.ContactCache()[0].tolist() == [int(cnt[0]), 0]
+    a.Update(); b.Update()
+    qa, qb = a.PoseVel()[0], b.PoseVel()[0]
+    assert np.array_equal(qa[0], qb[0]) and np.abs(qa[1] - qb[1]).max() > 1e-9
+    b.Reset([0])
+    assert b.ContactCache()[0][0] == 0                                 # cWorld::Reset
+    for bad in (dict(count=[25], ids=np.zeros((1, 24)), lam=np.zeros((1, 24))), dict(count=[-1], ids=np.zeros((1, 24)), lam=np.zeros((1, 24))),
+                dict(count=[2], ids=np.full((1, 24), 70000), lam=np.zeros((1, 24)))):
+        with pytest.raises(da.DtrlError):
+            b.SetContactCache(bad["count"], bad["ids"], bad["lam"], env_ids=[0])
+    for extra in (dict(warm_start=2), dict(contact_breaking=-0.5)):
+        with pytest.raises(da.DtrlError):
+            batch(da, arg, 1, terrain_seed=5, **extra)
+    # the round-4 model is another model -- and still follows ITS oracle
+    m0, _ = om.build_model(arg, REFDATA, overrides=dict(warm_start=0, contact_breaking=0))
+    e0 = om.OracleEnv(m0, terrain_seed=5)
+    c = batch(da, arg, 1, terrain_seed=5, warm_start=0, contact_breaking=0)
+    for _ in range(6):
+        c.Update(); e0.update()
+    assert np.abs(c.PoseVel()[0][0] - e0.pose_vel()[0]).max() < 1e-8 and np.abs(c.PoseVel()[0][0] - qa[0]).max() > 1e-6
+
+
 def test_row_cap_prone_character_vs_oracle(da, om):
     """Maximum-size case of the constraint solver: a character dropped flat on the ground penetrates with far more sample
     points than the 24-row cap admits; kernel and oracle must truncate the ordered row list identically (limits first,
