@@ -27,6 +27,7 @@ for stage in "$@"; do
         python tools/train_mace.py --arg-file $1 --envs $2 --frames 600 --trainer hip --overlap 2>&1 | tail -2 >> $O/train_loops.log
       done; cat $O/train_loops.log ;;
     learn_dog) python tools/learn_curve.py --char dog --out $O/learning_curve_dog.txt ${LEARN_ARGS} > $O/learn_dog.log 2>&1; tail -5 $O/learn_dog.log ;;
+    learn_goat) python tools/learn_curve.py --char goat --out $O/learning_curve_goat.txt ${LEARN_ARGS} > $O/learn_goat.log 2>&1; tail -5 $O/learn_goat.log ;;
     learn_raptor) python tools/learn_curve.py --char raptor --out $O/learning_curve_raptor.txt ${LEARN_ARGS} > $O/learn_raptor.log 2>&1; tail -5 $O/learn_raptor.log ;;
     ab:*)
       spec=${stage#ab:}; var=${spec%%=*}; vals=${spec#*=}

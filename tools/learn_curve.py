@@ -21,7 +21,9 @@ import deepterrainrl_amd as da
 from deepterrainrl_amd import train_loop
 
 CHARS = {"dog": dict(train="args/opt_args_train_mace.txt", evalf="args/dog_slopes_mixed_args.txt", terrain="data/terrain/slopes_mixed.txt", envs=4096),
-         "raptor": dict(train="args/opt_args_train_raptor_mace.txt", evalf="args/raptor_narrow_gaps_args.txt", terrain="data/terrain/narrow_gaps.txt", envs=8192)}
+         "raptor": dict(train="args/opt_args_train_raptor_mace.txt", evalf="args/raptor_narrow_gaps_args.txt", terrain="data/terrain/narrow_gaps.txt", envs=8192),
+         # BASELINE configs[4]'s loop as the reference ships it (its own terrain: cliffs_rugged; one substep of 1/600 s per env-step, world scale 1)
+         "goat": dict(train="args/opt_args_train_goat_mace.txt", evalf="args/goat_cliffs_args.txt", terrain="data/terrain/cliffs_rugged.txt", envs=8192)}
 
 
 SCENARIO = da.BatchScenario
@@ -83,7 +85,7 @@ def main():
     stem = None
     if a.save:
         os.makedirs(a.save, exist_ok=True)
-        stem = os.path.join(a.save, "%s_mace3_%s_model" % (a.char, os.path.splitext(os.path.basename(c["terrain"]))[0]))
+        stem = os.path.join(a.save, "%s_mace3_%s_model" % (a.char, os.path.splitext(os.path.basename(c["terrain"]))[0].replace("cliffs_rugged", "cliffs")))
     st = train_loop.train(c["train"], a.data_root, envs, max_iters=a.iters, overlap=not a.sequential, trainer=a.trainer, scenario_cls=SCENARIO,
                           extra_args=dict({"terrain_file": c["terrain"]}, **({"trainer_num_init_samples": a.init_samples} if a.init_samples is not None else {})),
                           eval_every=a.eval_every, eval_fn=eval_fn, out_model_file=(stem + ".h5") if stem else None, out_scale_file=(stem + "_scale.txt") if stem else None)
