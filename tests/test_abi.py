@@ -95,3 +95,23 @@ def test_bench_starts_its_own_ranks():
     r1 = [json.loads(l) for l in one.splitlines() if l.startswith("{") and "dry_launch" in l]
     assert len(r1) == 1 and r1[0]["world"] == 1 and r1[0]["envs_per_gpu"] == 4096
     assert recs[0]["host_threads"] == max(1, min(16, (os.cpu_count() or 2) // 4)) and r1[0]["host_threads"] == max(1, min(16, (os.cpu_count() or 2) // 2))
+
+
+def test_bench_starts_eight_ranks_the_way_the_driver_does():
+    """The 8-GPU shape of the scaling run, twice: `python bench.py --gpus 8` on its own (self-launch) and under the driver's launcher line
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...`): eight ranks, local ranks 0..7 on
+    devices cuda:0..7, global env offsets 0, 4096, ..., 28672 (BASELINE configs[3]: 32768 envs sharded over 8 GPUs), the node's host worker threads divided by eight."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DTRL_HOST_THREADS")}
+    bench = os.path.join(repo, "bench.py")
+    for cmd in ([sys.executable, bench, "--gpus", "8", "--dry-launch"],
+                [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29671", bench, "--gpus", "8", "--steps", "5", "--warmup", "2", "--dry-launch"]):
+        out = subprocess.check_output(cmd, env=env, stderr=subprocess.STDOUT, timeout=900).decode()
+        recs = sorted((json.loads(l) for l in out.splitlines() if l.startswith("{") and "dry_launch" in l), key=lambda r: r["rank"])
+        assert len(recs) == 8, out
+        assert [r["rank"] for r in recs] == list(range(8)) and [r["local_rank"] for r in recs] == list(range(8)) and all(r["world"] == 8 and r["gpus_arg"] == 8 for r in recs)
+        assert [r["global_env_offset"] for r in recs] == [4096 * k for k in range(8)] and [r["device"] for r in recs] == ["cuda:%d" % k for k in range(8)]
+        assert len({r["host_threads"] for r in recs}) == 1 and recs[0]["host_threads"] >= 1
