@@ -682,7 +682,14 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 		const int n_sweeps = warm ? 2 * kPgsIters : kPgsIters;
 #pragma unroll 1
 		for (int sw = 0; sw < n_sweeps; ++sw) {
-			const unsigned long long rows = (warm && (sw & 1)) ? pass1 : pass0;
+			unsigned long long rows = pass0;
+			if (warm && (sw & 1)) {
+				// friction pass: every normal row is final for this sweep, so which friction rows Bullet's rule HOLDS (normal row without impulse: their update is exactly
+				// zero) is known up front -- they leave the pass instead of walking through a row step each (the rows of points hovering inside the breaking threshold
+				// are held in nearly every sweep)
+				const real ln = wave_shr1(lam);   // (all lanes: a DPP move under a narrowed EXEC does not see the lanes that are switched off)
+				rows = pass1 & __ballot(tang && ln > kHoldEps);
+			}
 			if (rows != 0ull) pgs_rows_sweep<0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, tang, holdable, mine, rows, lane, R, 0.0);
 		}
 		if (mine) ws.st.ws_lam[lane] = lam;
@@ -695,12 +702,15 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 	real a_nx = mine ? ws.Apk[tri] : 0.0;   // column 0; the column of the next row update is fetched one update ahead
 	for (int it = 0; it < kPgsIters; ++it) {
 		for (int pass = 0; pass < (warm ? 2 : 1); ++pass) {
+			const real ln_pass = wave_shr1(lam);
+			const unsigned long long held = (warm && pass == 1) ? ~__ballot(tang && ln_pass > kHoldEps) : 0ull;   // (see the unrolled form above)
 			for (int r = 0; r < R; ++r) {
 				const real a_sr = a_nx;
 				const int rn = (r + 1 < R) ? r + 1 : 0;
 				{ const int mx = lane > rn ? lane : rn, mn = lane < rn ? lane : rn; a_nx = ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0]; }   // branch-free packed index
 				if (!((act >> r) & 1ull)) continue;
 				if (warm && ((pass == 0) == (((tmask >> r) & 1ull) != 0ull))) continue;
+				if ((held >> r) & 1ull) continue;
 				const real ln = wave_shr1(lam);
 				const real lim = kMu * ln;
 				const bool hold = holdable && !(ln > kHoldEps);
