@@ -612,17 +612,47 @@ __device__ __forceinline__ void pgs_rows_sweep(const real (&a)[K], const WSFast&
 		}
 	}
 }
-// w += A lambda_0 (the warm-started impulses), column by column in row order: the same fused operations as pgs_solve()'s first loop
-template <int r, int K, int kEnd>
-__device__ __forceinline__ void pgs_rows_warm(const real (&a)[K], const WSFast& ws, real& w, real lam, bool mine, int lane, int R)
+// The two passes of a sweep under Bullet's contact persistence as their own row steps (round 5). kFric = false: limit and normal rows, projection onto [0, inf) -- fma, max,
+// sub, readlane, fma. kFric = true: the friction rows that are not held; their bounds +-mu lambda_n are LANE REGISTERS set once per pass (every normal row is final for
+// the sweep by then) -- fma, max, min, sub, readlane, fma. Same operations on the same operands as the generic step above, without its per-step DPP move, multiply,
+// compare and selects.
+template <bool kFric, int r, int K, int kEnd>
+__device__ __forceinline__ void pgs_rows_pass(const real (&a)[K], const WSFast& ws, real& w, real& lam, real rinv, real lo, real hi, bool mine, unsigned long long rows, int lane, int R, real a_pref)
 {
 	if constexpr (r < kEnd) {
 		if (r < R) {
 			real a_sr;
-			if constexpr (r < K) a_sr = a[r];
-			else { const int mx = lane > r ? lane : r, mn = lane < r ? lane : r; a_sr = ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0]; }
-			w = fmadd(a_sr, bcast(lam, r), w);
-			pgs_rows_warm<r + 1, K, kEnd>(a, ws, w, lam, mine, lane, R);
+			if constexpr (r < K) a_sr = a[r]; else a_sr = a_pref;
+			real a_nx = 0.0;
+			if constexpr (r + 1 >= K && r + 1 < kEnd) {
+				constexpr int rn = r + 1;
+				const int mx = lane > rn ? lane : rn, mn = lane < rn ? lane : rn;
+				a_nx = ws.Apk[(mine && rn < R) ? mx * (mx + 1) / 2 + mn : 0];
+			}
+			if ((rows >> r) & 1ull) {
+				real nl = fmadd(-w, rinv, lam);
+				if constexpr (kFric) nl = fmin(fmax(nl, lo), hi); else nl = fmax(nl, 0.0);   // (pgs_solve(): normal and limit rows are projected onto [0, inf))
+				const real dl = bcast(nl - lam, r);
+				if (lane == r) lam = nl;
+				w = fmadd(a_sr, dl, w);
+			}
+			pgs_rows_pass<kFric, r + 1, K, kEnd>(a, ws, w, lam, rinv, lo, hi, mine, rows, lane, R, a_nx);
+		}
+	}
+}
+// w += A lambda_0 (the warm-started impulses), column by column in row order: the same fused operations as pgs_solve()'s first loop
+template <int r, int K, int kEnd>
+__device__ __forceinline__ void pgs_rows_warm(const real (&a)[K], const WSFast& ws, real& w, real lam, bool mine, unsigned long long nz, int lane, int R)
+{
+	if constexpr (r < kEnd) {
+		if (r < R) {
+			if ((nz >> r) & 1ull) {   // (rows that start from zero -- limit rows, link--link rows, new contacts -- add exactly nothing)
+				real a_sr;
+				if constexpr (r < K) a_sr = a[r];
+				else { const int mx = lane > r ? lane : r, mn = lane < r ? lane : r; a_sr = ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0]; }
+				w = fmadd(a_sr, bcast(lam, r), w);
+			}
+			pgs_rows_warm<r + 1, K, kEnd>(a, ws, w, lam, mine, nz, lane, R);
 		}
 	}
 }
@@ -661,7 +691,8 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 	const bool warm = ws.M.warm_start != 0;   // wave-uniform
 	const bool holdable = warm && tang;
 	const unsigned long long tmask = __ballot(tang);
-	const bool any_l0 = __ballot(lam != 0.0) != 0ull;
+	const unsigned long long nz_l0 = __ballot(lam != 0.0);
+	const bool any_l0 = nz_l0 != 0ull;
 	// The lane's Delassus row: the first kPgsRegRows entries (per skeleton, dtrl_topo.h; eight until round 3, twelve in round 3) live in registers for all sweeps
 	// -- no LDS read and no packed-index arithmetic per row update -- and the entries of the tail rows come from LDS one update ahead. Same operations on the
 	// same values in the same order as pgs_solve() of dtrl_kernel.h. The rare substeps with many rows matter out of proportion: they are what the slowest envs of
@@ -676,21 +707,22 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 		pgs_rows_load<0, kPgsRegRows>(a, ws, lane, mine, R);
 		const unsigned long long actR = act & ((R < 64) ? ((1ull << R) - 1ull) : ~0ull);
 		constexpr int kEnd = kTailInSweep ? kMaxRows : kPgsRegRows;
-		if (any_l0) pgs_rows_warm<0, kPgsRegRows, kEnd>(a, ws, w, lam, mine, lane, R);
+		if (any_l0) pgs_rows_warm<0, kPgsRegRows, kEnd>(a, ws, w, lam, mine, nz_l0, lane, R);
 		const unsigned long long pass0 = warm ? (actR & ~tmask) : actR, pass1 = actR & tmask;
-		// one call site for both passes (the unrolled sweep is the largest piece of straight-line code in the substep: two copies of it cost instruction-cache room)
-		const int n_sweeps = warm ? 2 * kPgsIters : kPgsIters;
+		if (warm) {
 #pragma unroll 1
-		for (int sw = 0; sw < n_sweeps; ++sw) {
-			unsigned long long rows = pass0;
-			if (warm && (sw & 1)) {
-				// friction pass: every normal row is final for this sweep, so which friction rows Bullet's rule HOLDS (normal row without impulse: their update is exactly
-				// zero) is known up front -- they leave the pass instead of walking through a row step each (the rows of points hovering inside the breaking threshold
-				// are held in nearly every sweep)
+			for (int it = 0; it < kPgsIters; ++it) {
+				if (pass0 != 0ull) pgs_rows_pass<false, 0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, 0.0, 0.0, mine, pass0, lane, R, 0.0);
+				// friction pass: every normal row is final for this sweep, so the bounds +-mu lambda_n are fixed for the pass, and which friction rows Bullet's rule HOLDS
+				// (normal row without impulse: their update is exactly zero) is known up front -- they leave the pass instead of walking through a row step each
 				const real ln = wave_shr1(lam);   // (all lanes: a DPP move under a narrowed EXEC does not see the lanes that are switched off)
-				rows = pass1 & __ballot(tang && ln > kHoldEps);
+				const real lim = kMu * ln;
+				const unsigned long long rows = pass1 & __ballot(tang && ln > kHoldEps);
+				if (rows != 0ull) pgs_rows_pass<true, 0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, -lim, lim, mine, rows, lane, R, 0.0);
 			}
-			if (rows != 0ull) pgs_rows_sweep<0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, tang, holdable, mine, rows, lane, R, 0.0);
+		} else {
+#pragma unroll 1
+			for (int it = 0; it < kPgsIters; ++it) pgs_rows_sweep<0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, tang, false, mine, actR, lane, R, 0.0);   // (-warm_start= 0: one interleaved sweep, rounds 1-4)
 		}
 		if (mine) ws.st.ws_lam[lane] = lam;
 		env_sync();
@@ -698,23 +730,46 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 	}
 	const int tri = lane * (lane + 1) / 2;
 	const real inf = __builtin_huge_val();
-	if (any_l0) for (int r = 0; r < R; ++r) { const int mx = lane > r ? lane : r, mn = lane < r ? lane : r; w = fmadd(ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0], bcast(lam, r), w); }
+	if (any_l0) for (int r = 0; r < R; ++r) if ((nz_l0 >> r) & 1ull) { const int mx = lane > r ? lane : r, mn = lane < r ? lane : r; w = fmadd(ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0], bcast(lam, r), w); }
 	real a_nx = mine ? ws.Apk[tri] : 0.0;   // column 0; the column of the next row update is fetched one update ahead
-	for (int it = 0; it < kPgsIters; ++it) {
-		for (int pass = 0; pass < (warm ? 2 : 1); ++pass) {
-			const real ln_pass = wave_shr1(lam);
-			const unsigned long long held = (warm && pass == 1) ? ~__ballot(tang && ln_pass > kHoldEps) : 0ull;   // (see the unrolled form above)
+	const unsigned long long actR = act & ((R < 64) ? ((1ull << R) - 1ull) : ~0ull);
+	if (warm) {
+		// the two passes with their own row steps, as in the unrolled form above (pgs_rows_pass)
+		const unsigned long long pass0 = actR & ~tmask, pass1 = actR & tmask;
+		for (int it = 0; it < kPgsIters; ++it) {
 			for (int r = 0; r < R; ++r) {
 				const real a_sr = a_nx;
 				const int rn = (r + 1 < R) ? r + 1 : 0;
 				{ const int mx = lane > rn ? lane : rn, mn = lane < rn ? lane : rn; a_nx = ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0]; }   // branch-free packed index
+				if (!((pass0 >> r) & 1ull)) continue;
+				const real nl = fmax(fmadd(-w, rinv, lam), 0.0);
+				const real dl = bcast(nl - lam, r);
+				if (lane == r) lam = nl;
+				w = fmadd(a_sr, dl, w);
+			}
+			const real ln = wave_shr1(lam);
+			const real lim = kMu * ln;
+			const unsigned long long rows = pass1 & __ballot(tang && ln > kHoldEps);
+			for (int r = 0; r < R; ++r) {
+				const real a_sr = a_nx;
+				const int rn = (r + 1 < R) ? r + 1 : 0;
+				{ const int mx = lane > rn ? lane : rn, mn = lane < rn ? lane : rn; a_nx = ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0]; }
+				if (!((rows >> r) & 1ull)) continue;
+				const real nl = fmin(fmax(fmadd(-w, rinv, lam), -lim), lim);
+				const real dl = bcast(nl - lam, r);
+				if (lane == r) lam = nl;
+				w = fmadd(a_sr, dl, w);
+			}
+		}
+	} else {
+		for (int it = 0; it < kPgsIters; ++it) {
+			for (int r = 0; r < R; ++r) {   // (-warm_start= 0: one interleaved sweep, rounds 1-4)
+				const real a_sr = a_nx;
+				const int rn = (r + 1 < R) ? r + 1 : 0;
+				{ const int mx = lane > rn ? lane : rn, mn = lane < rn ? lane : rn; a_nx = ws.Apk[mine ? mx * (mx + 1) / 2 + mn : 0]; }   // branch-free packed index
 				if (!((act >> r) & 1ull)) continue;
-				if (warm && ((pass == 0) == (((tmask >> r) & 1ull) != 0ull))) continue;
-				if ((held >> r) & 1ull) continue;
-				const real ln = wave_shr1(lam);
-				const real lim = kMu * ln;
-				const bool hold = holdable && !(ln > kHoldEps);
-				const real lo = hold ? lam : (tang ? -lim : 0.0), hi = hold ? lam : (tang ? lim : inf);
+				const real lim = kMu * wave_shr1(lam);
+				const real lo = tang ? -lim : 0.0, hi = tang ? lim : inf;
 				const real nl = fmin(fmax(fmadd(-w, rinv, lam), lo), hi);
 				const real dl = bcast(nl - lam, r);
 				if (lane == r) lam = nl;
