@@ -16,10 +16,13 @@ struct TopoDog {
 	// (16.7 -> 17.8 M env-steps/s), with nested row sequences -> 4.33 ms (18.1 M), with 20 register rows + the tail rows from LDS -> 4.26 ms (18.4 M): same-box A/Bs in
 	// profiles/r04_pgs_rows_ab.txt
 #ifndef DTRL_PGS_ROWS_DOG
-#define DTRL_PGS_ROWS_DOG 20
+#define DTRL_PGS_ROWS_DOG 24   // (round 5, with the per-pass row steps: 17.22 M at 24 against 16.9 M at 20 + tail, 16.8 M at 16 + tail, 14.4 M at 20 + plain loop: profiles/r05_pgs_rows_ab.txt)
 #endif
 	static constexpr int kPgsRegRows = DTRL_PGS_ROWS_DOG;
-	static constexpr bool kPgsTailInSweep = true;    // rows 20-23 inside the same unrolled sweep, their entries from LDS one update ahead (18.26 -> 18.42 M against 20 + plain loop)
+#ifndef DTRL_PGS_TAIL_DOG
+#define DTRL_PGS_TAIL_DOG 1
+#endif
+	static constexpr bool kPgsTailInSweep = DTRL_PGS_TAIL_DOG != 0;    // rows 20-23 inside the same unrolled sweep, their entries from LDS one update ahead (18.26 -> 18.42 M against 20 + plain loop)
 	static constexpr int parent(int l) { constexpr int p[L] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 0, 9, 10, 11, 5, 13, 14, 15, 0, 17, 18, 19}; return p[l]; }
 };
 struct TopoRaptor {
@@ -28,7 +31,10 @@ struct TopoRaptor {
 #ifndef DTRL_PGS_ROWS_RAPTOR
 #define DTRL_PGS_ROWS_RAPTOR 16
 #endif
-	static constexpr bool kPgsTailInSweep = false;   // (18.85 M with 16 + plain loop, 18.33 M with the tail rows in the sweep: spills)
+#ifndef DTRL_PGS_TAIL_RAPTOR
+#define DTRL_PGS_TAIL_RAPTOR 0
+#endif
+	static constexpr bool kPgsTailInSweep = DTRL_PGS_TAIL_RAPTOR != 0;   // (18.85 M with 16 + plain loop, 18.33 M with the tail rows in the sweep: spills)
 	static constexpr int kPgsRegRows = DTRL_PGS_ROWS_RAPTOR;   // (nested row sequences, round 4: 18.65 M at 12, 18.88 M at 16, 18.82 M at 24 -- the raptor's instance pays for the registers of 24; flat sequences had 18.4 / 18.1 / 17.2 M at 12 / 18 / 24)
 	static constexpr int parent(int l) { constexpr int p[L] = {-1, 0, 1, 2, 3, 4, 0, 6, 7, 8, 9, 0, 11, 12, 13, 0, 15, 16, 17}; return p[l]; }
 };
