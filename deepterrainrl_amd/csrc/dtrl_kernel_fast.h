@@ -662,6 +662,7 @@ __device__ __forceinline__ void warm_match_fast(WSFast& ws)
 {
 	const int lane = opaque_lane();
 	const int R = ws.R, Rp = ws.st.ws_R;   // wave-uniform
+	if (R == 0) { if (Rp != 0 && lane == 0) ws.st.ws_R = 0; return; }   // (a fifth of the substeps: airborne)
 	int id = kNoRowId;
 	if (lane < R) id = ws.row_id[lane];
 	real l0 = 0.0;
@@ -673,7 +674,7 @@ __device__ __forceinline__ void warm_match_fast(WSFast& ws)
 	// (no barrier between the reads above and the writes below: one wavefront, and its LDS operations complete in issue order)
 	if (lane < R) { ws.st.ws_lam[lane] = l0; ws.st.ws_id[lane] = static_cast<uint16_t>(id); }
 	if (lane == 0) ws.st.ws_R = R;
-	env_sync();
+	// (no fence behind the writes either: their next reader is the Gauss-Seidel solve, several phase boundaries further on)
 }
 template <int kPgsRegRows, bool kTailInSweep>
 __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
