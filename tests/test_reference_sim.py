@@ -410,3 +410,39 @@ def test_integrator_v1_vs_bullet_shaped_sequential_impulse_bands(om):
     # (iv) configs[4]'s scene (goat, world scale 1, one substep of 1/600 s per env-step): a slow, often-falling character under this policy -> a larger sample
     v1, si = pair(a2.SCENES[4], list(range(201, 217)), 200)
     hold(v1, si, "goat cliffs_rugged", 0.12, None, 0.15, 0.05, None)
+
+
+def test_integrator_v1_vs_bullet_shaped_comparator_under_the_trained_policies(om):
+    """rounds 1-4 compared the two integrators under seeded xavier weights only -- characters that stumble every few cycles. The regime the reference lives
+    in is a TRAINED policy crossing the terrain. tests/golden/policies holds the MACE policies tools/learn_curve.py trained THROUGH the product on the MI355X (dog +
+    slopes_mixed 60 000 iterations, raptor + narrow_gaps 160 000): the reference's own controllers driven by them on Integrator v1 as shipped and on the comparator with
+    Bullet's defaults, 32 seeds x 300 frames per cell (= profiles/r05_a2_deviation_trained_policies.txt). Bands, the band alone: mean AND median cycle 3 %, speed 5 %,
+    reward 5 %, duty 0.02; falls: both below 0.15 per 1000 env-steps (a handful of episodes per cell: the policies were trained on v1's physics and fall 0.02 / 0.08 times
+    per 1000 env-steps on v1 / on the comparator; under xavier weights the raptor fell 1.3 times)."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import a2_deviation as a2
+    if not os.path.exists(os.path.join(REPO, "tests", "golden", "policies", "dog_mace3_slopes_mixed_model.h5")):
+        pytest.skip("tests/golden/policies missing")
+    jobs = min(8, os.cpu_count() or 1)
+    prev = os.environ.get("A2_POLICY"); os.environ["A2_POLICY"] = "trained"
+    a2._POLS = None; a2._POOL = None      # (a pool forked by an earlier test holds the synthetic policies)
+    try:
+        seeds = list(range(101, 133))       # the study's seed set (16 seeds leave the raptor's speed at 1.9 s.e. = 8 %: a fall costs a second of travel, and there are a dozen per cell)
+        for scene in (a2.SCENES[2], a2.SCENES[3]):
+            v1 = a2.run(scene, "v1", seeds, 300, jobs=jobs); si = a2.run(scene, "si", seeds, 300, jobs=jobs)
+            print(scene[0], "trained policy"); print("  v1 " + a2.fmt(v1)); print("  SI " + a2.fmt(si)); print("  rel " + a2.rel_line(v1, si))
+            for key, band in (("cycle_s", 0.03), ("cycle_median", 0.03), ("speed", 0.05), ("reward", 0.05)):
+                assert abs(v1[key] - si[key]) <= band * abs(si[key]), (scene[0], key, v1[key], si[key])
+            for key in ("duty_front", "duty_back"):
+                assert abs(v1[key] - si[key]) <= 0.02, (scene[0], key, v1[key], si[key])
+            assert v1["falls_k"] < 0.15 and si["falls_k"] < 0.15, (scene[0], v1["falls_k"], si["falls_k"])
+            assert v1["speed"] > 3.0 and v1["n_cycles"] > 200          # they do cross the terrain
+    finally:
+        if a2._POOL is not None:
+            a2._POOL.close(); a2._POOL = None
+        a2._POLS = None
+        if prev is None:
+            os.environ.pop("A2_POLICY", None)
+        else:
+            os.environ["A2_POLICY"] = prev
