@@ -353,7 +353,7 @@ dist.barrier(); dist.destroy_process_group()
 
 
 def test_eight_rank_data_parallel_training(tmp_path, da):
-    """train_distributed(mode="data_parallel") on EIGHT gloo ranks (native trainer's check build; 43 global envs = shards of 6, 6, 6, 5, 5, 5, 5, 5): the per-frame
+    """train_distributed(mode="data_parallel") on EIGHT gloo ranks (native trainer's check build; 131 global envs = shards of 17, 17, 17, 16, 16, 16, 16, 16: a rank's replay memory must hold a minibatch of 32 before its trainer steps): the per-frame
     agreement on the number of Train() calls, the two gradient all-reduces per call and the pooled input normaliser run with eight participants; all ranks end with
     bit-identical weights and solver history and the same counters, each kept exactly the tuples its own engine produced, and the normaliser every rank computes is
     the one of the POOLED begin states (HipMACETrainerDP.UpdateOffsetScale was never exercised)."""
@@ -361,18 +361,18 @@ def test_eight_rank_data_parallel_training(tmp_path, da):
     extra = {"terrain_seed": 3, "trainer_num_init_samples": 48, "trainer_replay_mem_size": 256, "trainer_freeze_target_iters": 2, "tuple_buffer_size": 4,
              "init_exp_rate": 0.3, "init_exp_base_rate": 0.1, "trainer_init_input_offset_scale": "false"}
     script = tmp_path / "dp8_worker.py"
-    script.write_text(DP8_WORKER.format(repo=REPO, out=str(tmp_path), extra=extra, lib=lib, global_envs=43, frames=50))
+    script.write_text(DP8_WORKER.format(repo=REPO, out=str(tmp_path), extra=extra, lib=lib, global_envs=131, frames=120))
     _launch(script, 8, 29651, timeout=2400)
     R = [np.load(tmp_path / ("dp8_rank%d.npz" % r)) for r in range(8)]
     a = R[0]
-    assert int(a["frames"]) == 50 and int(a["iters"]) >= 2 and np.abs(a["hist"]).max() > 0 and np.all(np.isfinite(a["weights"]))
+    assert int(a["frames"]) == 120 and int(a["iters"]) >= 2 and np.abs(a["hist"]).max() > 0 and np.all(np.isfinite(a["weights"]))
     pooled = sum(r["stats"] for r in R)
     S = (len(pooled) - 1) // 2
     n = pooled[0]; mean = pooled[1:1 + S] / n
     std = np.sqrt(np.maximum(pooled[1 + S:] / n - mean * mean, 0.0))
     exp_scale = np.where(std == 0, 0.0, 1.0 / np.where(std == 0, 1.0, std))
     for k, r in enumerate(R):
-        assert int(r["iters"]) == int(a["iters"]) and int(r["actor_iters"]) == int(a["actor_iters"]) and int(r["frames"]) == 50, k
+        assert int(r["iters"]) == int(a["iters"]) and int(r["actor_iters"]) == int(a["actor_iters"]) and int(r["frames"]) == 120, k
         assert np.array_equal(r["weights"], a["weights"]) and np.array_equal(r["hist"], a["hist"]), k
         assert int(r["tuples"]) == int(r["drained"]) >= 1, k
         assert np.allclose(r["pooled_off"], -mean, rtol=1e-6, atol=1e-9) and np.allclose(r["pooled_scale"], exp_scale, rtol=1e-5, atol=1e-9), k
