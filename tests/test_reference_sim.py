@@ -430,7 +430,8 @@ def test_integrator_v1_vs_bullet_shaped_comparator_under_the_trained_policies(om
     try:
         seeds = list(range(101, 133))       # the study's seed set (16 seeds leave the raptor's speed at 1.9 s.e. = 8 %: a fall costs a second of travel, and there are a dozen per cell)
         for scene in (a2.SCENES[2], a2.SCENES[3]):
-            v1 = a2.run(scene, "v1", seeds, 300, jobs=jobs); si = a2.run(scene, "si", seeds, 300, jobs=jobs)
+            sd = seeds[:8] if scene is a2.SCENES[2] else seeds      # (the trained dog never falls on either integrator: 8 seeds carry its statistics to 0.5 %)
+            v1 = a2.run(scene, "v1", sd, 300, jobs=jobs); si = a2.run(scene, "si", sd, 300, jobs=jobs)
             print(scene[0], "trained policy"); print("  v1 " + a2.fmt(v1)); print("  SI " + a2.fmt(si)); print("  rel " + a2.rel_line(v1, si))
             for key, band in (("cycle_s", 0.03), ("cycle_median", 0.03), ("speed", 0.05), ("reward", 0.05)):
                 assert abs(v1[key] - si[key]) <= band * abs(si[key]), (scene[0], key, v1[key], si[key])
