@@ -438,7 +438,7 @@ def test_integrator_v1_vs_bullet_shaped_comparator_under_the_trained_policies(om
             for key in ("duty_front", "duty_back"):
                 assert abs(v1[key] - si[key]) <= 0.02, (scene[0], key, v1[key], si[key])
             assert v1["falls_k"] < 0.15 and si["falls_k"] < 0.15, (scene[0], v1["falls_k"], si["falls_k"])
-            assert v1["speed"] > 3.0 and v1["n_cycles"] > 200          # they do cross the terrain
+            assert v1["speed"] > 3.0 and v1["n_cycles"] > 150          # they do cross the terrain
     finally:
         if a2._POOL is not None:
             a2._POOL.close(); a2._POOL = None
