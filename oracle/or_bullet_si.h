@@ -67,7 +67,8 @@ struct Params {
 	int link_contacts = 1;           // box-box contacts between same-group, not hinge-linked links
 	int friction_skip = 1;           // diagnostic: Bullet resolves a friction row only while its normal row carries an impulse (solveSingleIteration: `if (totalImpulse > 0)`); 0 = always (the box clamps to +-mu x 0)
 	int friction_dir = 1;            // diagnostic: 1 = Bullet's direction (along the relative tangential velocity, else plane space); 0 = always the plane-space vector
-	int friction_ws_lifted = 1;      // diagnostic: 0 = a point above the surface (dist > 0) does not warm start its friction row
+	int friction_ws_lifted = 1;      // diagnostic: which contact points warm start their FRICTION row: 1 = all (Bullet), 0 = only points that penetrate (dist <= 0), 2 = only points above the
+	                                 // surface, 3 = ground contacts only, 4 = link--link contacts only (3 reproduces the default, 4 the comparator without friction warm start: profiles/r05_a2_deviation.txt)
 	int interleave = 0;              // diagnostic: 1 = each contact's normal row followed by its friction row (Integrator v1's order) instead of all normals, then all friction rows
 	double limit_bias = 0.3, limit_relax = 1.0;   // btHingeConstraint::setLimit defaults (_biasFactor, _relaxationFactor)
 };
