@@ -41,10 +41,12 @@ def policies():
     from conftest import dog_policy
     import test_host_and_emul as T
     if os.environ.get("A2_POLICY", "synthetic") != "trained":
-        return {"dog": dog_policy(om), "raptor": T.raptor_policy(om)}
+        d = dog_policy(om)
+        return {"dog": d, "goat": d, "raptor": T.raptor_policy(om)}      # (the goat scene runs on the dog's net shape: args/goat_cliffs_args.txt names dog_mace3_deploy.prototxt)
     from deepterrainrl_amd import caffe_hdf5
     out = {}
     for name, net, stem in (("dog", "data/policies/dog/nets/dog_mace3_deploy.prototxt", "dog_mace3_slopes_mixed_model"),
+                            ("goat", "data/policies/dog/nets/dog_mace3_deploy.prototxt", "goat_mace3_cliffs_model"),
                             ("raptor", "data/policies/raptor/nets/raptor_mace3_deploy.prototxt", "raptor_mace3_narrow_gaps_model")):
         desc = om.parse_deploy_prototxt(os.path.join(REF, net))
         base = os.path.join(REPO, "tests", "golden", "policies", stem)
@@ -58,7 +60,7 @@ SCENES = [  # tag, arg file, character, policy?, dims
     ("raptor flat FSM", "args/sim_raptor_args.txt", "raptor", None),
     ("dog slopes_mixed + MACE net (configs[1])", "args/dog_slopes_mixed_args.txt", "dog", "dog"),
     ("raptor narrow_gaps + MACE net (configs[2])", "args/raptor_narrow_gaps_args.txt", "raptor", "raptor"),
-    ("goat cliffs_rugged + MACE net (configs[4] scene)", "args/goat_cliffs_args.txt", "dog", "dog"),
+    ("goat cliffs_rugged + MACE net (configs[4] scene)", "args/goat_cliffs_args.txt", "dog", "goat"),
 ]
 
 
