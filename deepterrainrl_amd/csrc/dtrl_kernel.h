@@ -18,7 +18,9 @@
 //   * per-env working set (kinematics, H, constraint rows, Delassus matrix) is staged in LDS; lanes map to links / DoFs /
 //     constraint rows / contact sample points; tree sweeps become path walks and subtree-mask sums with no level barriers;
 //   * the contact solve is projected Gauss-Seidel in lambda space on the dense Delassus matrix so a row update is one
-//     broadcast + one FMA per lane (see pgs_solve; the register/readlane form is pgs_solve_fast in dtrl_kernel_fast.h);
+//     broadcast + one FMA per lane (see pgs_solve; the register/readlane form is pgs_solve_fast in dtrl_kernel_fast.h); since round 5 with Bullet's contact
+//     persistence -- ground contact rows warm-started from the cache in EnvState (warm_match), a sweep = limit + normal rows, then the friction rows, a friction
+//     row held while its normal row carries no impulse, rows for sample points within the manifold's breaking threshold (DevModel::warm_start, link_brk);
 //   * one kernel launch advances a whole outer frame (20 env-steps); state touches HBM only at frame boundaries.
 //
 // The code is written once in "lane-phase" form: LANES_BEGIN/LANES_END delimit a phase executed by every lane, with a

@@ -557,8 +557,8 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 }
 
 // projected Gauss-Seidel in lambda space with the row state in registers: lane s owns row s (w_s, lambda_s, 1/A_ss, kind).
-// The solve is one long dependent chain (10 sweeps x R row updates), so what matters is the number of DEPENDENT instructions
-// per update, not the instruction count. Every lane evaluates its own candidate update each step (lane r's is the one that
+// The solve is one long dependent chain (10 sweeps x R row updates): the number of DEPENDENT instructions per update matters -- and, with two waves per SIMD, so does the
+// instruction count (round 5: the 27-instruction generic step was issue-bound; the per-pass steps below are 9-11). Every lane evaluates its own candidate update each step (lane r's is the one that
 // counts): the projection bounds [lo, hi] (normal rows [0, inf), tangent rows +-mu * lambda of the row before it, fetched with
 // a wave_shr:1 DPP move) are off the chain, leaving w -> mul -> sub -> max -> min -> sub -> readlane -> mul -> add.
 // Same operations on the same operands as pgs_solve(), hence the same bits; rows with a vanishing effective mass are skipped.
@@ -581,10 +581,10 @@ __device__ __forceinline__ void pgs_rows_load(real (&a)[K], const WSFast& ws, in
 }
 // one sweep over rows r, r + 1, ...: rows below K read the lane's Delassus entry from registers, rows K .. kMaxRows - 1 (the tail only characters lying on the
 // ground reach) from LDS, fetched one row update ahead (a_pref) so that the load's latency sits under the previous row's dependent chain
-// Bullet's contact persistence: `actR` is the set of rows this pass resolves (limits + normals, or the friction rows), and a friction lane with `holdable` set leaves
-// its impulse alone while the normal row before it carries none (lo = hi = lambda: the candidate update is exactly zero)
+// The generic row step of rounds 1-4: ONE interleaved sweep over all rows, the bounds of row r evaluated per step (normal rows [0, inf), tangent rows +-mu * lambda of the
+// row before it). Only -warm_start= 0 (the round-4 contact model, an ablation) still runs it; the shipped model's sweep is the two passes below.
 template <int r, int K, int kEnd>
-__device__ __forceinline__ void pgs_rows_sweep(const real (&a)[K], const WSFast& ws, real& w, real& lam, real rinv, bool tang, bool holdable, bool mine, unsigned long long actR, int lane, int R, real a_pref)
+__device__ __forceinline__ void pgs_rows_sweep(const real (&a)[K], const WSFast& ws, real& w, real& lam, real rinv, bool tang, bool mine, unsigned long long actR, int lane, int R, real a_pref)
 {
 	if constexpr (r < kEnd) {
 		if (r < R) {
@@ -599,16 +599,14 @@ __device__ __forceinline__ void pgs_rows_sweep(const real (&a)[K], const WSFast&
 			if ((actR >> r) & 1ull) {
 				// (a wave-uniform branch on the kind of row r -- normal rows need neither the friction bound nor the upper clamp -- was measured twice, round 1 and
 				// round 4 under the ILP scheduler: -6 % / -3 %. The selects are cheaper than the branch.)
-				const real ln = wave_shr1(lam);
-				const real lim = kMu * ln;
-				const bool hold = holdable && !(ln > kHoldEps);
-				const real lo = hold ? lam : (tang ? -lim : 0.0), hi = hold ? lam : (tang ? lim : __builtin_huge_val());
+				const real lim = kMu * wave_shr1(lam);
+				const real lo = tang ? -lim : 0.0, hi = tang ? lim : __builtin_huge_val();
 				const real nl = fmin(fmax(fmadd(-w, rinv, lam), lo), hi);
 				const real dl = bcast(nl - lam, r);
 				if (lane == r) lam = nl;
 				w = fmadd(a_sr, dl, w);
 			}
-			pgs_rows_sweep<r + 1, K, kEnd>(a, ws, w, lam, rinv, tang, holdable, mine, actR, lane, R, a_nx);
+			pgs_rows_sweep<r + 1, K, kEnd>(a, ws, w, lam, rinv, tang, mine, actR, lane, R, a_nx);
 		}
 	}
 }
@@ -690,7 +688,6 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 	const unsigned long long act = __ballot(rinv != 0.0);
 	// Bullet's contact persistence: a sweep resolves the limit and normal rows (list order), then the friction rows; a friction row only under a loaded normal row
 	const bool warm = ws.M.warm_start != 0;   // wave-uniform
-	const bool holdable = warm && tang;
 	const unsigned long long tmask = __ballot(tang);
 	const unsigned long long nz_l0 = __ballot(lam != 0.0);
 	const bool any_l0 = nz_l0 != 0ull;
@@ -723,7 +720,7 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 			}
 		} else {
 #pragma unroll 1
-			for (int it = 0; it < kPgsIters; ++it) pgs_rows_sweep<0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, tang, false, mine, actR, lane, R, 0.0);   // (-warm_start= 0: one interleaved sweep, rounds 1-4)
+			for (int it = 0; it < kPgsIters; ++it) pgs_rows_sweep<0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, tang, mine, actR, lane, R, 0.0);   // (-warm_start= 0: one interleaved sweep, rounds 1-4)
 		}
 		if (mine) ws.st.ws_lam[lane] = lam;
 		env_sync();
