@@ -13,7 +13,7 @@
 // and two additions a caller of the rollout engine needs: GetTrainer() (the dtrl_trainer handle, e.g. for dtrl_trainer_params_device -> dtrl_set_policy_device)
 // and GetParamsFlat / SetParamsFlat (the Caffe-blob-order weight vector).
 // Not provided (they are Caffe objects): GetParams() blobs, BuildNetParams, ForwardBackward / CopyGrad / StepSolver of the asynchronous trainers (their
-// data-parallel counterpart is dtrl_trainer_*_grad / dtrl_trainer_apply_grad), layer-state accessors, Backward (only cCaclaTrainer.s TD / PTD modes would need it, and nothing in the reference selects them: dead code).
+// data-parallel counterpart is dtrl_trainer_*_grad / dtrl_trainer_apply_grad), layer-state accessors, Backward (only cCaclaTrainer's TD / PTD modes would need it, and nothing in the reference selects them: dead code).
 //
 // Written against the reference's headers as they are (util/MathUtil.h brings Eigen in); a maintainer compiles it inside the reference tree. Two ways to use it:
 //   (a) new code holds cBatchNeuralNet objects directly;
