@@ -708,15 +708,19 @@ __device__ __forceinline__ void pgs_solve_fast(WSFast& ws)
 		if (any_l0) pgs_rows_warm<0, kPgsRegRows, kEnd>(a, ws, w, lam, mine, nz_l0, lane, R);
 		const unsigned long long pass0 = warm ? (actR & ~tmask) : actR, pass1 = actR & tmask;
 		if (warm) {
+			// a pass leaves the nested row sequence behind its LAST row (not at R): the rows of the other pass that follow it are not even looked at
+			// (with tail rows in the sweep the row count also guards the LDS prefetch of the next column: that instance keeps R)
+			constexpr bool kPrefetch = kTailInSweep && kPgsRegRows < kMaxRows;
+			const int end0 = (kPrefetch || pass0 == 0ull) ? R : 64 - __builtin_clzll(pass0);
 #pragma unroll 1
 			for (int it = 0; it < kPgsIters; ++it) {
-				if (pass0 != 0ull) pgs_rows_pass<false, 0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, 0.0, 0.0, mine, pass0, lane, R, 0.0);
+				if (pass0 != 0ull) pgs_rows_pass<false, 0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, 0.0, 0.0, mine, pass0, lane, end0, 0.0);
 				// friction pass: every normal row is final for this sweep, so the bounds +-mu lambda_n are fixed for the pass, and which friction rows Bullet's rule HOLDS
 				// (normal row without impulse: their update is exactly zero) is known up front -- they leave the pass instead of walking through a row step each
 				const real ln = wave_shr1(lam);   // (all lanes: a DPP move under a narrowed EXEC does not see the lanes that are switched off)
 				const real lim = kMu * ln;
 				const unsigned long long rows = pass1 & __ballot(tang && ln > kHoldEps);
-				if (rows != 0ull) pgs_rows_pass<true, 0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, -lim, lim, mine, rows, lane, R, 0.0);
+				if (rows != 0ull) pgs_rows_pass<true, 0, kPgsRegRows, kEnd>(a, ws, w, lam, rinv, -lim, lim, mine, rows, lane, kPrefetch ? R : 64 - __builtin_clzll(rows), 0.0);
 			}
 		} else {
 #pragma unroll 1
