@@ -45,7 +45,8 @@ def default_block_rows(global_envs, world_size):
 
 class ShardedRollout:
     """One rank's shard of a global batch + the two exchange steps. `dist` is torch.distributed (already initialised) or None.
-    `device`: torch device of the exchange buffers -- the GPU the batch runs on (RCCL), or None / "cpu" with a gloo group.
+    `device`: torch device of the exchange buffers -- the GPU the batch runs on (RCCL; with a gloo group the collectives are staged through
+    pinned host memory), or None / "cpu" with a gloo group and the lane-loop test backend.
     `block_rows`: rows per rank and gather (default_block_rows); every rank must pass the same value."""
 
     def __init__(self, make_batch, global_envs, dist=None, device=None, force_collectives=None, pipelined=False, block_rows=None):
@@ -87,6 +88,11 @@ class ShardedRollout:
         self._handed = None        # index of the block whose views the last gather_tuples_end handed to the caller (one-rank runs)
         self.gathered = None       # receive side, trainer rank only: allocated by the first gather_tuples_end(dst) on that rank
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        # a gloo group over DEVICE buffers (two ranks sharing one GPU on a box without a second one; debugging without RCCL): gloo's gather takes host
+        # tensors only, so the block / the policy buffer are staged through pinned host memory around the collective. Never taken with RCCL.
+        self.staged = bool(self.coll and self.on_gpu and dist.get_backend() == "gloo")
+        self._stage = [torch.zeros((self.cap + 1, W + 2), dtype=torch.float32).pin_memory() for _ in range(nblk)] if self.staged else None
+        self._stage_recv = None
         self._pending = None
         self.carried_rows = 0      # rows the engine kept back for a later frame because the block was full (sum of the headers seen on this rank)
         # policy buffer: [weights f32 | in_off | in_scale | out_off | out_scale f64], 8-byte aligned sections
@@ -143,7 +149,12 @@ class ShardedRollout:
                 if self.gathered is None:
                     self.gathered = [torch.zeros_like(self.block) for _ in range(self.world)]
                 recv = self.gathered
-            if self.on_gpu:
+            if self.staged:
+                self._stage[bi].copy_(self.block)                                       # blocking copy: the device block is free again when it returns
+                if self.rank == dst and self._stage_recv is None:
+                    self._stage_recv = [torch.zeros_like(self._stage[0]) for _ in range(self.world)]
+                work = self.dist.gather(self._stage[bi], gather_list=self._stage_recv if self.rank == dst else None, dst=dst, async_op=True)
+            elif self.on_gpu:
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))   # readers of the previous gather result (queued on the caller's stream) come first
                 with torch.cuda.stream(self.comm_stream):
                     work = self.dist.gather(self.block, gather_list=recv, dst=dst, async_op=True)
@@ -164,7 +175,11 @@ class ShardedRollout:
         t0 = time.perf_counter()
         if work is not None:
             work.wait()
-            if self.on_gpu:
+            if self.staged:
+                if self.rank == dst:
+                    for g, h in zip(self.gathered, self._stage_recv):
+                        g.copy_(h)
+            elif self.on_gpu:
                 cur = torch.cuda.current_stream(self.device)
                 cur.wait_stream(self.comm_stream)
                 # behind the collective itself: this rank's stream now follows RCCL's kernel, so an event recorded here fires only after the send block was read
@@ -224,7 +239,11 @@ class ShardedRollout:
                     continue
                 t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a, np.float32 if v.dtype == torch.float32 else np.float64))
                 v.copy_(t.to(self.device, dtype=v.dtype).reshape(-1))
-        if self.coll:
+        if self.coll and self.staged:
+            host = self.pol_buf.cpu()
+            self.dist.broadcast(host, src=src)
+            self.pol_buf.copy_(host)
+        elif self.coll:
             self.dist.broadcast(self.pol_buf, src=src)
         if not normalizers:
             # no host wait: the re-layout kernel is queued on this stream behind the broadcast (a synchronous-mode collective blocks the CURRENT stream on RCCL's),

@@ -669,3 +669,91 @@ def test_sharded_rollout_pipelined_protocol_on_gpu(om):
         total += len(seq[f][0])
     assert total >= 40
     assert b.batch.TupleStats()["dropped"] == 0
+
+
+TWO_RANK_WORKER = r'''
+import os, sys, numpy as np
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import torch, torch.distributed as dist
+from conftest import REFDATA, dog_policy
+from oracle import model as om
+import deepterrainrl_amd as da
+from deepterrainrl_amd.sharding import ShardedRollout
+dist.init_process_group(backend="gloo")
+rank = dist.get_rank()
+def make(n, off):
+    return da.BatchScenario("args/opt_args_train_mace.txt", n, data_root=REFDATA, extra_args=dict(terrain_seed=300, rand_seed=9, global_env_offset=off))
+sr = ShardedRollout(make, {n}, dist=dist, device="cuda:0", pipelined={pipelined}, block_rows=128)   # (a block that takes the lock-step burst of the first cycles whole)
+assert sr.staged and sr.world == 2 and "libdtrl.so" in open("/proc/self/maps").read()
+pol = dog_policy(om)
+if rank == 0:
+    sr.broadcast_policy(pol[1], pol[2], pol[3], pol[4], pol[5], src=0)
+else:
+    sr.broadcast_policy(src=0)
+sr.batch.SetExplore(True, 0.2, 0.025, 0.002)
+rows, flags, ids = [], [], []
+def keep(g):
+    if rank == 0:
+        rows.append(g[0].cpu().numpy().copy()); flags.append(g[1].cpu().numpy().copy()); ids.append(g[2].cpu().numpy().copy())
+if {pipelined}:
+    sr.UpdateBegin()
+    for f in range({frames} - 1):
+        sr.UpdateEndBegin()
+        if sr._pending is not None:
+            keep(sr.gather_tuples_end(dst=0))
+        sr.gather_tuples_begin()
+    sr.UpdateEnd()
+    keep(sr.gather_tuples_end(dst=0))
+    sr.gather_tuples_begin(); keep(sr.gather_tuples_end(dst=0))      # the last frame's ring
+else:
+    for f in range({frames}):
+        sr.Update()
+        sr.gather_tuples_begin(); keep(sr.gather_tuples_end(dst=0))
+for f in range(4):                       # rows a full block carried over
+    sr.gather_tuples_begin(); keep(sr.gather_tuples_end(dst=0))
+st = sr.batch.TupleStats()
+assert st["pending"] == 0 and st["dropped"] == 0, st
+q, qd = sr.batch.PoseVel()
+np.savez(os.path.join({out!r}, "rank%d.npz" % rank), q=q, qd=qd, off=sr.offset)
+if rank == 0:
+    np.savez(os.path.join({out!r}, "tuples.npz"), rows=np.concatenate(rows), flags=np.concatenate(flags), ids=np.concatenate(ids))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_two_ranks_sharing_the_gpu_over_gloo(tmp_path, om, pipelined):
+    """The N > 1 path on the HIP engine (there is one GPU on the box, and RCCL refuses two ranks on one device): two processes, each with its own libdtrl.so batch on
+    cuda:0 and its contiguous range of the 97 global envs (49 + 48), a gloo group whose collectives are staged through pinned host memory (ShardedRollout.staged).
+    Rank 0 broadcasts the policy; every frame's tuples are packed on the device and gathered to rank 0. Against ONE process stepping the 97 envs on the same GPU:
+    the final pose / velocity of every env is bit-identical (shard-invariant trajectories: terrain and exploration streams are keyed by the global env id), and rank 0
+    received every env's tuples, bit for bit and in time order."""
+    import subprocess
+    import sys
+    import deepterrainrl_amd as da_mod
+    from conftest import REPO
+    n, frames = 97, 60
+    script = tmp_path / "worker.py"
+    script.write_text(TWO_RANK_WORKER.format(repo=REPO, out=str(tmp_path), n=n, frames=frames, pipelined=bool(pipelined)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(29671 + int(pipelined)), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    pol = dog_policy(om)
+    b = da_mod.BatchScenario("args/opt_args_train_mace.txt", n, data_root=REFDATA, extra_args=dict(terrain_seed=300, rand_seed=9))
+    b.SetPolicy(pol[1], *pol[2:])
+    b.SetExplore(True, 0.2, 0.025, 0.002)
+    rows, flags, ids = [], [], []
+    for f in range(frames):
+        b.Update()
+        rr, ff, ii = b.DrainTuples()
+        rows.append(rr); flags.append(ff); ids.append(ii)
+    rows = np.concatenate(rows); flags = np.concatenate(flags); ids = np.concatenate(ids)
+    q, qd = b.PoseVel()
+    r0 = np.load(tmp_path / "rank0.npz"); r1 = np.load(tmp_path / "rank1.npz")
+    assert int(r0["off"]) == 0 and int(r1["off"]) == 49 and len(r0["q"]) == 49 and len(r1["q"]) == 48
+    assert np.array_equal(q, np.concatenate([r0["q"], r1["q"]])) and np.array_equal(qd, np.concatenate([r0["qd"], r1["qd"]]))
+    t = np.load(tmp_path / "tuples.npz")
+    assert len(t["rows"]) == len(rows) and len(rows) >= 100, (len(t["rows"]), len(rows))
+    for e in range(n):
+        assert np.array_equal(t["rows"][t["ids"] == e], rows[ids == e]) and np.array_equal(t["flags"][t["ids"] == e].astype(np.uint32), flags[ids == e].astype(np.uint32)), e
