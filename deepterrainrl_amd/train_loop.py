@@ -353,6 +353,7 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
         return scenario_cls(arg_file, n, data_root=data_root, device_id=local_device_id, extra_args=ea)
     sr = ShardedRollout(make, global_envs, dist=dist, device=device, pipelined=overlap, block_rows=block_rows)
     b = sr.batch
+    hdr_dev = torch.device("cpu") if sr.staged else sr.device     # (a gloo group over device buffers: the loop's small headers stay on the host)
     t = None
     if rank == 0:
         solver = os.path.join(data_root, args["policy_solver"])
@@ -379,7 +380,7 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
             norm_new = 0 if (last_norm[0] is not None and all(np.array_equal(a, c) for a, c in zip(norm, last_norm[0]))) else 1
             last_norm[0] = norm
         hdr = np.array([1 if push else 0, t.GetIter() if t is not None else 0, norm_new], np.int64)
-        th = torch.from_numpy(hdr).to(sr.device)
+        th = torch.from_numpy(hdr).to(hdr_dev)
         dist.broadcast(th, src=0)
         push, it, norm_new = (int(x) for x in th.tolist())
         if push:
@@ -427,7 +428,7 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
             # flush: rows a small block carried over (bursts above block_rows) still sit in some rank's ring; every rank takes part in every gather
             got = False
             while True:
-                tl = torch.tensor([b.TupleStats()["pending"]], dtype=torch.int64, device=sr.device)
+                tl = torch.tensor([b.TupleStats()["pending"]], dtype=torch.int64, device=hdr_dev)
                 dist.all_reduce(tl)
                 if int(tl.item()) == 0:
                     break
@@ -459,7 +460,7 @@ def train_distributed(arg_file, data_root, global_envs, dist, max_iters=None, ma
             while left > 0:
                 consume(sr.gather_tuples_end(dst=0))
                 st = b.TupleStats()
-                tl = torch.tensor([st["pending"]], dtype=torch.int64, device=sr.device)
+                tl = torch.tensor([st["pending"]], dtype=torch.int64, device=hdr_dev)
                 dist.all_reduce(tl)
                 left = int(tl.item())
                 if left > 0:

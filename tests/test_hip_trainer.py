@@ -515,6 +515,46 @@ def test_gpu_data_parallel_trainer_and_loop_on_a_one_rank_rccl_group(tmp_path):
     assert d["loop_frames"] == 70 and d["loop_iters"] >= 2 and d["loop_finite"] and d["loop_hist"] > 0 and d["loop_tuples"] == d["loop_drained"] >= 120, d
 
 
+TWO_RANK_TRAIN_WORKER = r"""
+import os, sys, numpy as np
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import torch, torch.distributed as dist
+from conftest import REFDATA
+from deepterrainrl_amd import train_loop
+torch.cuda.set_device(0)
+dist.init_process_group(backend="gloo")
+st = train_loop.train_distributed("args/opt_args_train_mace.txt", REFDATA, {envs}, dist, max_frames={frames}, device="cuda:0", trainer_device="cuda:0", local_device_id=0,
+                                  trainer="hip", extra_args={extra!r}, seed=5, block_rows={envs})
+assert "libdtrl.so" in open("/proc/self/maps").read()
+if dist.get_rank() == 0:
+    np.savez(os.path.join({out!r}, "dist_train.npz"), weights=st["weights"], iters=st["iters"], tuples=st["tuples"], in_off=st["offset_scale"][0], frames=st["frames"])
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_gpu_two_rank_training_sharing_the_gpu_equals_single_process(tmp_path):
+    """cScenarioTrain's loop across two ranks ON THE HIP ENGINE AND THE HIP TRAINER (the box has one GPU and RCCL refuses two ranks on one device: a gloo group whose
+    collectives are staged through pinned host memory): both processes roll out their half of the 192 global envs on cuda:0, every frame's tuples are packed on the
+    device and gathered to rank 0, rank 0 runs the native MACE trainer step and broadcasts [weights | normalisers] back. The run must equal train() in ONE process on the
+    same GPU bit for bit -- iterations, tuples, every weight -- as its CPU twin (tests/test_multi_gpu_gloo.py, lane-loop backends) does."""
+    from deepterrainrl_amd import train_loop
+    envs, frames = 192, 60
+    extra = {"terrain_seed": 3, "trainer_num_init_samples": 300, "trainer_replay_mem_size": 4096, "trainer_freeze_target_iters": 8,
+             "init_exp_rate": 0.3, "init_exp_base_rate": 0.1, "trainer_init_input_offset_scale": "false"}
+    script = tmp_path / "two_rank_train_worker.py"
+    script.write_text(TWO_RANK_TRAIN_WORKER.format(repo=REPO, out=str(tmp_path), envs=envs, frames=frames, extra=extra))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29681", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = np.load(tmp_path / "dist_train.npz")
+    st = train_loop.train("args/opt_args_train_mace.txt", REFDATA, num_envs=envs, max_frames=frames, trainer_device="cuda", extra_args=dict(extra), trainer="hip", seed=5)
+    assert int(d["frames"]) == st["frames"] == frames
+    assert int(d["iters"]) == int(st["iters"]) >= 5 and int(d["tuples"]) == int(st["tuples"]) >= 300, (int(d["iters"]), st["iters"], int(d["tuples"]), st["tuples"])
+    assert np.all(np.isfinite(d["weights"])) and np.array_equal(d["weights"], st["weights"]) and np.array_equal(d["in_off"], st["offset_scale"][0])
+
+
 def test_create_from_files_rejects_a_net_with_a_missing_head_instead_of_crashing(tmp_path):
     """ADVICE r4: ParseTrainerFiles looked every a<f>_ip0 / a<f>_ip1 of val_ip1's fragment count up with std::map::operator[] -- a net with fewer actor heads (or a
     malformed prototxt) dereferenced a null layer inside dtrl_trainer_create_from_files / cBatchNeuralNet::LoadNet. Now: an error naming the layer."""
