@@ -451,17 +451,19 @@ class HipMACETrainerDP(HipMACETrainer):
     def _allreduce_grad(self):
         if self.dist is None or self.world == 1 and not getattr(self, "force_collectives", False):
             return
+        from .sharding import all_reduce
         if self._stream is not None:
             with torch.cuda.stream(self._stream):     # behind the gradient kernels on the trainer's stream; the update queued next follows the collective
-                self.dist.all_reduce(self.grad)
+                all_reduce(self.dist, self.grad)
         else:
-            self.dist.all_reduce(self.grad)
+            all_reduce(self.dist, self.grad)
 
     def _agree(self, value, op):
         if self.dist is None or self.world == 1:
             return value
         t = torch.tensor([value], dtype=torch.int64, device=self.device if self.device.type == "cuda" else "cpu")
-        self.dist.all_reduce(t, op=op)
+        from .sharding import all_reduce
+        all_reduce(self.dist, t, op=op)
         return int(t.item())
 
     def UpdateOffsetScale(self):
@@ -471,7 +473,8 @@ class HipMACETrainerDP(HipMACETrainer):
         X = self.mem[:self.num_tuples, 1:1 + self.S].to(torch.float64)
         pooled = torch.cat([torch.tensor([float(X.shape[0])], dtype=torch.float64, device=X.device), X.sum(0), (X * X).sum(0)])
         if self.dist is not None and self.world > 1:
-            self.dist.all_reduce(pooled)
+            from .sharding import all_reduce
+            all_reduce(self.dist, pooled)
         n = pooled[0]; mean = pooled[1:1 + self.S] / n
         var = (pooled[1 + self.S:] / n - mean * mean).clamp_min(0.0)
         std = var.sqrt()

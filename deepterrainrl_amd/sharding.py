@@ -43,6 +43,28 @@ def default_block_rows(global_envs, world_size):
     return max(64, -(-n_max // 8))
 
 
+def host_staged(dist, t):
+    """gloo's collectives are taken with host tensors here (two ranks sharing one GPU on a one-GPU box, debugging without RCCL): a device tensor goes through
+    the host around the collective. Never true with RCCL (backend "nccl") or with the CPU test backends."""
+    return dist is not None and bool(getattr(t, "is_cuda", False)) and dist.get_backend() == "gloo"
+
+
+def all_reduce(dist, t, op=None):
+    """dist.all_reduce(t) on the CURRENT stream; staged through the host for a gloo group over device tensors (the blocking copies order it on that stream)."""
+    kw = {} if op is None else {"op": op}
+    if host_staged(dist, t):
+        h = t.cpu(); dist.all_reduce(h, **kw); t.copy_(h)
+    else:
+        dist.all_reduce(t, **kw)
+
+
+def broadcast(dist, t, src):
+    if host_staged(dist, t):
+        h = t.cpu(); dist.broadcast(h, src=src); t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+
+
 class ShardedRollout:
     """One rank's shard of a global batch + the two exchange steps. `dist` is torch.distributed (already initialised) or None.
     `device`: torch device of the exchange buffers -- the GPU the batch runs on (RCCL; with a gloo group the collectives are staged through

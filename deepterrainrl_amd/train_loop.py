@@ -235,6 +235,7 @@ def train_data_parallel(arg_file, data_root, global_envs, dist, max_iters=None, 
     import torch
     from .hip_trainer import HipMACETrainerDP
     from .sharding import shard_range
+    from . import sharding as _sh
     args = parse_arg_file(os.path.join(data_root, arg_file))
     args.update({k: str(v) for k, v in (extra_args or {}).items()})
     geti = lambda k, d: int(args.get(k, d)); getf = lambda k, d: float(args.get(k, d))
@@ -256,7 +257,7 @@ def train_data_parallel(arg_file, data_root, global_envs, dist, max_iters=None, 
     # identical initial weights: rank 0's
     w = torch.from_numpy(np.ascontiguousarray(t.GetWeights(), np.float32))
     wd = w.to(t.device) if t.device.type == "cuda" else w
-    dist.broadcast(wd, src=0)
+    _sh.broadcast(dist, wd, 0)
     t.SetWeights(wd.cpu().numpy())
     t.SetOutputOffsetScale(*b.BuildNNOutputOffsetScale())
     exp = dict(rate=getf("exp_rate", 0.2), temp=getf("exp_temp", 0.025), base=getf("exp_base_rate", 0.002))
@@ -308,7 +309,7 @@ def train_data_parallel(arg_file, data_root, global_envs, dist, max_iters=None, 
                 k += st
         tuples += len(rows); carry += len(rows)
         count[0] = carry // chunk
-        dist.all_reduce(count, op=dist.ReduceOp.MAX)
+        _sh.all_reduce(dist, count, op=dist.ReduceOp.MAX)
         n_train = int(count.item())
         carry = max(0, carry - n_train * chunk)
         for _ in range(n_train):

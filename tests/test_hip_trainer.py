@@ -555,6 +555,61 @@ def test_gpu_two_rank_training_sharing_the_gpu_equals_single_process(tmp_path):
     assert np.all(np.isfinite(d["weights"])) and np.array_equal(d["weights"], st["weights"]) and np.array_equal(d["in_off"], st["offset_scale"][0])
 
 
+TWO_RANK_DP_WORKER = r"""
+import os, sys, numpy as np
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import torch, torch.distributed as dist
+from conftest import REFDATA
+from deepterrainrl_amd import train_loop
+torch.cuda.set_device(0)
+dist.init_process_group(backend="gloo")
+rank = dist.get_rank()
+st = train_loop.train_distributed("args/opt_args_train_mace.txt", REFDATA, {envs}, dist, max_frames={frames}, trainer_device="cuda:0", local_device_id=0, trainer="hip",
+                                  mode="data_parallel", extra_args={extra!r})
+assert "libdtrl.so" in open("/proc/self/maps").read()
+t = st["trainer"]
+t._order_staged()
+X = t.mem[:t.num_tuples, 1:1 + t.S].to(torch.float64)
+stats = torch.cat([torch.tensor([float(X.shape[0])], dtype=torch.float64, device=X.device), X.sum(0), (X * X).sum(0)]).cpu()
+t.UpdateOffsetScale()          # the pooled normaliser (one all-reduce of count / sum / sum of squares, staged here): every rank calls it, after the training it did not feed
+off, sc = t.GetOffsetScale()[:2]
+np.savez(os.path.join({out!r}, "dp_rank%d.npz" % rank), weights=st["weights"], iters=st["iters"], actor_iters=st["actor_iters"], tuples=st["tuples"], frames=st["frames"],
+         pooled_off=np.asarray(off), pooled_scale=np.asarray(sc), hist=t.nt.get_params(2), stats=stats.numpy(), drained=st["batch"].TupleStats()["drained"])
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_gpu_two_rank_data_parallel_training_sharing_the_gpu(tmp_path):
+    """train_distributed(mode="data_parallel") on two ranks with the HIP engine and the HIP trainer's gradient / apply kernels on both (sharing the one MI355X; gloo
+    group, the two gradient all-reduces per Train() and the pooled normaliser staged through the host): no tuple gather and no weight broadcast, yet both ranks end
+    with bit-identical weights and solver history and the same counters; the input normaliser both carry is the one of the POOLED begin states; each rank trained on
+    its own envs' tuples only. The GPU twin of tests/test_multi_gpu_gloo.py::test_two_rank_data_parallel_training."""
+    envs, frames = 512, 70
+    extra = {"terrain_seed": 3, "trainer_num_init_samples": 600, "trainer_replay_mem_size": 8192, "trainer_freeze_target_iters": 4,
+             "init_exp_rate": 0.3, "init_exp_base_rate": 0.1, "trainer_init_input_offset_scale": "false"}
+    script = tmp_path / "two_rank_dp_worker.py"
+    script.write_text(TWO_RANK_DP_WORKER.format(repo=REPO, out=str(tmp_path), envs=envs, frames=frames, extra=extra))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29683", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    a, b = np.load(tmp_path / "dp_rank0.npz"), np.load(tmp_path / "dp_rank1.npz")
+    assert int(a["frames"]) == int(b["frames"]) == frames
+    assert int(a["iters"]) == int(b["iters"]) >= 2 and int(a["actor_iters"]) == int(b["actor_iters"]), (int(a["iters"]), int(b["iters"]))
+    assert np.array_equal(a["weights"], b["weights"]) and np.array_equal(a["hist"], b["hist"]) and np.all(np.isfinite(a["weights"]))
+    assert np.abs(a["hist"]).max() > 0
+    assert int(a["tuples"]) == int(a["drained"]) >= 300 and int(b["tuples"]) == int(b["drained"]) >= 300
+    assert not np.array_equal(a["stats"], b["stats"])
+    pooled = a["stats"] + b["stats"]
+    S = (len(pooled) - 1) // 2
+    n = pooled[0]; mean = pooled[1:1 + S] / n
+    std = np.sqrt(np.maximum(pooled[1 + S:] / n - mean * mean, 0.0))
+    exp_scale = np.where(std == 0, 0.0, 1.0 / np.where(std == 0, 1.0, std))
+    for r in (a, b):
+        assert np.allclose(r["pooled_off"], -mean, rtol=1e-6, atol=1e-9) and np.allclose(r["pooled_scale"], exp_scale, rtol=1e-5, atol=1e-9)
+
+
 def test_create_from_files_rejects_a_net_with_a_missing_head_instead_of_crashing(tmp_path):
     """ADVICE r4: ParseTrainerFiles looked every a<f>_ip0 / a<f>_ip1 of val_ip1's fragment count up with std::map::operator[] -- a net with fewer actor heads (or a
     malformed prototxt) dereferenced a null layer inside dtrl_trainer_create_from_files / cBatchNeuralNet::LoadNet. Now: an error naming the layer."""
