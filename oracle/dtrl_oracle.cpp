@@ -301,4 +301,42 @@ double orc_batch_eval(const OrcModel* m, int n_envs, int n_threads, int n_frames
 	return sec;
 }
 
+// full-width parity record (tests/test_gpu_parity.py::test_config*_full_width_*): n_envs free-running oracle envs on n_threads host threads; after every outer
+// frame f the pose and velocity of env i go to out_q / out_qd [n_frames][n_envs][D]; out_diag [n_envs][8] = the integrator's diagnostic counters (or_sim.h
+// Integrator::diag, 7 entries) + the env's reset count.
+// out_ws_n [n_frames][n_envs], out_ws_id / out_ws_lam [n_frames][n_envs][24] (may be
+// null): the persistent contact rows after every frame (orc_get_warm); out_resets [n_frames][n_envs] (may be null): the env's reset count so far. Returns wall seconds.
+double orc_batch_trace(const OrcModel* m, int n_envs, int n_threads, int n_frames, uint64_t terrain_seed0, uint64_t rng_seed, uint64_t env_id0,
+					   const OrcNetDesc* d, const float* weights, const double* in_off, const double* in_scale, const double* out_off, const double* out_scale,
+					   double* out_q, double* out_qd, int64_t* out_diag, int32_t* out_ws_n, int32_t* out_ws_id, double* out_ws_lam, int32_t* out_resets)
+{
+	std::vector<OrcHandle*> hs(n_envs);
+	for (int i = 0; i < n_envs; ++i)
+		hs[i] = static_cast<OrcHandle*>(d ? orc_create_with_policy(m, terrain_seed0 + i, rng_seed, env_id0 + i, d, weights, in_off, in_scale, out_off, out_scale)
+										  : orc_create(m, terrain_seed0 + i, rng_seed, env_id0 + i));
+	const int D = hs.empty() ? 0 : hs[0]->env.D;
+	auto t0 = std::chrono::steady_clock::now();
+	std::vector<std::thread> th;
+	for (int t = 0; t < n_threads; ++t) th.emplace_back([&, t]() {
+		for (int i = t; i < n_envs; i += n_threads) {
+			Env& e = hs[i]->env;
+			for (int f = 0; f < n_frames; ++f) {
+				e.Update(1.0 / 30.0);
+				double* q = out_q + (static_cast<size_t>(f) * n_envs + i) * D;
+				double* qd = out_qd + (static_cast<size_t>(f) * n_envs + i) * D;
+				for (int k = 0; k < D; ++k) { q[k] = e.q[k]; qd[k] = e.qd[k]; }
+				const size_t fi = static_cast<size_t>(f) * n_envs + i;
+				if (out_ws_n) out_ws_n[fi] = orc_get_warm(hs[i], out_ws_id + fi * SimConst::max_rows, out_ws_lam + fi * SimConst::max_rows);
+				if (out_resets) out_resets[fi] = static_cast<int32_t>(e.num_resets);
+			}
+			for (int k = 0; k < 7; ++k) out_diag[i * 8 + k] = e.integ.diag[k];
+			out_diag[i * 8 + 7] = e.num_resets;
+		}
+	});
+	for (auto& x : th) x.join();
+	const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	for (int i = 0; i < n_envs; ++i) delete hs[i];
+	return sec;
+}
+
 }  // extern "C"

@@ -473,6 +473,8 @@ def lib():
         L.orc_batch_run.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(OrcNetDesc)] + [C.c_void_p] * 5 + [C.POINTER(C.c_int64)] * 2
         L.orc_batch_eval.restype = C.c_double
         L.orc_batch_eval.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(OrcNetDesc)] + [C.c_void_p] * 6
+        L.orc_batch_trace.restype = C.c_double
+        L.orc_batch_trace.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(OrcNetDesc)] + [C.c_void_p] * 12
         _lib = L
     return _lib
 
@@ -634,3 +636,25 @@ def batch_eval(model, n_envs, n_threads, n_frames, terrain_seed0=0, rng_seed=0, 
     io, isc, oo, osc = (np.ascontiguousarray(x, np.float64) for x in (io, isc, oo, osc))
     sec = lib().orc_batch_eval(C.byref(model), n_envs, n_threads, n_frames, terrain_seed0, rng_seed, env_id0, C.byref(desc), _p(w), _p(io), _p(isc), _p(oo), _p(osc), _p(out))
     return dict(resets=out[0], cycles=out[1], episodes=out[2], dist_sum=out[3], dist_sq_sum=out[4], env_steps=out[5], seconds=sec)
+
+
+DIAG_KEYS = ("link_cap_substeps", "row_cap_substeps", "rows_ge_16_substeps", "pair_row_substeps", "substeps", "max_rows", "sum_rows", "resets")
+
+
+def batch_trace(model, n_envs, n_threads, n_frames, terrain_seed0=0, rng_seed=0, env_id0=0, policy=None, contact_cache=False):
+    """n_envs free-running oracle envs on n_threads host threads: dict(q, qd [frames, envs, D], diag [envs, 8] per DIAG_KEYS, resets [frames, envs], seconds) and, with
+    contact_cache, ws_n [frames, envs], ws_id / ws_lam [frames, envs, 24]: the persistent contact rows after every frame."""
+    D = int(model.D)
+    q = np.zeros((n_frames, n_envs, D)); qd = np.zeros((n_frames, n_envs, D)); diag = np.zeros((n_envs, 8), np.int64); resets = np.zeros((n_frames, n_envs), np.int32)
+    ws_n = np.zeros((n_frames, n_envs), np.int32) if contact_cache else None
+    ws_id = np.zeros((n_frames, n_envs, 24), np.int32) if contact_cache else None
+    ws_lam = np.zeros((n_frames, n_envs, 24)) if contact_cache else None
+    pa = [None] * 6
+    if policy is not None:
+        desc, w, io, isc, oo, osc = policy
+        w = np.ascontiguousarray(w, np.float32)
+        io, isc, oo, osc = (np.ascontiguousarray(x, np.float64) for x in (io, isc, oo, osc))
+        pa = [C.byref(desc), _p(w), _p(io), _p(isc), _p(oo), _p(osc)]
+    sec = lib().orc_batch_trace(C.byref(model), n_envs, n_threads, n_frames, terrain_seed0, rng_seed, env_id0, *pa, _p(q), _p(qd), _p(diag),
+                                _p(ws_n) if contact_cache else None, _p(ws_id) if contact_cache else None, _p(ws_lam) if contact_cache else None, _p(resets))
+    return dict(q=q, qd=qd, diag=diag, resets=resets, ws_n=ws_n, ws_id=ws_id, ws_lam=ws_lam, seconds=sec)

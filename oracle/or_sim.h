@@ -134,7 +134,8 @@ inline void ContactDistances(const OrcModel& M, const Bodies& B, const Ground& g
 
 // contact detection at the current configuration; fills in-contact flags per link and the list of points that get constraint rows
 // (ordered by link, then sample point): per link the deepest max_pts_per_link penetrating points; overall the deepest `cap`
-inline int DetectContacts(const OrcModel& M, const Bodies& B, const Ground& g, ContactPoint* out, int cap, bool* flags)
+// diag (may be null; test diagnostics only): [0] += 1 when a link had more active points than max_pts_per_link, [1] += 1 when the row budget dropped points
+inline int DetectContacts(const OrcModel& M, const Bodies& B, const Ground& g, ContactPoint* out, int cap, bool* flags, long long* diag = nullptr)
 {
 	const int npts = M.L * SimConst::pts_per_link;
 	ContactPoint all[ORC_MAXL * SimConst::pts_per_link];
@@ -172,7 +173,9 @@ inline int DetectContacts(const OrcModel& M, const Bodies& B, const Ground& g, C
 		for (int k = 0; k < SimConst::pts_per_link; ++k) { const int o = j * SimConst::pts_per_link + k; if (o != pt && active[o] && outranks(o, pt)) ++rank; }
 		keep[pt] = rank < SimConst::max_pts_per_link;
 		n_keep += keep[pt];
+		if (diag && !keep[pt] && rank == SimConst::max_pts_per_link) ++diag[0];
 	}
+	if (diag && n_keep > cap) ++diag[1];
 	if (n_keep > cap) {
 		bool keep2[ORC_MAXL * SimConst::pts_per_link];
 		for (int pt = 0; pt < npts; ++pt) {
@@ -278,6 +281,9 @@ struct Integrator {
 	// the body's COM plus the torque rel_pos x force evaluated when cWorld::Update applies it, and holds both over the substeps
 	struct PerturbForce { int link = -1; double fx = 0, fy = 0, torque = 0; bool on = false; };
 
+	// diagnostics for the full-width parity record (tests only; no effect on the arithmetic): [0] substeps with a link over its point cap, [1] substeps over the row
+	// budget, [2] substeps with R >= 16 (the kernels' general Delassus path), [3] substeps with link--link rows, [4] substeps, [5] max R, [6] sum of R
+	long long diag[7] = {0, 0, 0, 0, 0, 0, 0};
 	int sub_ix = 0;                       // index of the substep within its env-step
 	double Hm[ORC_MAXD * ORC_MAXD];       // joint-space inertia the substep solves with
 	void Substep(const OrcModel& M, RBDModel& rbd, const Ground& ground, double h, double* q, double* qd, const double* tau, const PerturbForce* pf = nullptr)
@@ -318,7 +324,7 @@ struct Integrator {
 		ContactPoint cps[SimConst::max_rows / 2];
 		bool flags[ORC_MAXL];
 		int cap = (SimConst::max_rows - R) / 2;
-		int nc = DetectContacts(M, B, ground, cps, cap, flags);
+		int nc = DetectContacts(M, B, ground, cps, cap, flags, diag);
 		for (int c = 0; c < nc; ++c) {
 			const ContactPoint& cp = cps[c];
 			PointJacobian(M, B, cp.link, cp.x, cp.y, cp.nx, cp.ny, Jr[R], D);
@@ -344,6 +350,7 @@ struct Integrator {
 				++R;
 			}
 		}
+		diag[2] += R >= 16; diag[3] += npc > 0; ++diag[4]; diag[5] = std::max<long long>(diag[5], R); diag[6] += R;
 		for (int r = 0; r < R; ++r) {
 			SolveLDLT(D, Hm, D, Jr[r], Yr[r]);
 			double a = 0; for (int i = 0; i < D; ++i) a += Jr[r][i] * Yr[r][i];

@@ -86,6 +86,23 @@ def dog_policy(om, scale="data/policies/dog/models/dog_mace3_slopes_mixed_model_
     return desc, w, io, isc, oo, osc
 
 
+TRAINED = {  # policies tools/learn_curve.py trained THROUGH the product (tests/golden/policies: Caffe HDF5 + _scale.txt written by the package's own writer)
+    "dog": ("data/policies/dog/nets/dog_mace3_deploy.prototxt", "dog_mace3_slopes_mixed_model"),
+    "goat": ("data/policies/dog/nets/dog_mace3_deploy.prototxt", "goat_mace3_cliffs_model"),
+    "raptor": ("data/policies/raptor/nets/raptor_mace3_deploy.prototxt", "raptor_mace3_narrow_gaps_model"),
+}
+
+
+def trained_policy(om, name):
+    """(desc, weights, in_off, in_scale, out_off, out_scale) of a committed trained policy, in the form OracleEnv / SetPolicy take."""
+    from deepterrainrl_amd import caffe_hdf5
+    net, stem = TRAINED[name]
+    desc = om.parse_deploy_prototxt(os.path.join(REFDATA, net))
+    base = os.path.join(GOLDEN, "policies", stem)
+    w = caffe_hdf5.load_mace_weights(base + ".h5", desc.n_frags)
+    return (desc, w) + tuple(om.load_scale_file(base + "_scale.txt"))
+
+
 def pin_to_oracle(b, es, tol=1e-4):
     """Teacher forcing for long side-by-side runs (round 5). With Bullet's contact persistence in Integrator v1 (warm-started contact rows, a friction row held while
     its normal row carries no impulse, rows within the breaking threshold) the contact dynamics amplify rounding differences far faster than the round-1..4 model did:

@@ -161,6 +161,36 @@ def test_config1_slopes_mixed_1200_substeps_64_envs(da, om):
     print("config1 64 envs x 1200 substeps: max |dq| = %.3e" % worst)
 
 
+FULL_WIDTH = [  # tag, arg file, envs (the width BASELINE.json states for the config), policy, terrain seed 0
+    ("config1_dog_slopes_mixed_4096_xavier", "args/dog_slopes_mixed_args.txt", 4096, "dog_xavier", 1000),
+    ("config2_raptor_narrow_gaps_8192_xavier", "args/raptor_narrow_gaps_args.txt", 8192, "raptor_xavier", 5000),
+    ("config1_dog_slopes_mixed_4096_trained", "args/dog_slopes_mixed_args.txt", 4096, "dog_trained", 1000),
+    ("config2_raptor_narrow_gaps_8192_trained", "args/raptor_narrow_gaps_args.txt", 8192, "raptor_trained", 5000),
+]
+
+
+@pytest.mark.parametrize("run", FULL_WIDTH, ids=[r[0] for r in FULL_WIDTH])
+def test_config_full_width_1200_substeps(da, om, run):
+    """VERDICT r5 #1a: pointwise HIP-vs-oracle parity at the widths BASELINE configs[1] / configs[2] state (4096 dogs, 8192 raptors), under the seeded xavier weights AND
+    under the policies trained through the engine (long contact-rich episodes without falls). Every env against its own free-running oracle env (all host cores):
+    phase A = 12 frames = 1200 substeps FREE-RUNNING, max |dq|, |dqd| < 1e-4 for EVERY env (north star); phase B = 36 more frames followed frame by frame from the
+    oracle's state (through stumbles, prone characters at the row caps, falls, resets, terrain slides). The record (distribution, how many envs went through R >= 16,
+    a row cap, link--link rows, a reset) goes to gpurun_out/full_width_parity/<tag>.txt -> profiles/r06_full_width_parity.txt."""
+    from conftest import trained_policy
+    tag, arg, n, which, seed = run
+    pol = {"dog_xavier": lambda: dog_policy(om), "raptor_xavier": lambda: T.raptor_policy(om),
+           "dog_trained": lambda: trained_policy(om, "dog"), "raptor_trained": lambda: trained_policy(om, "raptor")}[which]()
+    r = T.run_full_width_parity(da, om, arg, n, pol, seed, free_frames=12, forced_frames=36, label=tag)
+    from conftest import REPO
+    out = os.path.join(REPO, "gpurun_out", "full_width_parity")
+    try:
+        os.makedirs(out, exist_ok=True)
+        open(os.path.join(out, tag + ".txt"), "w").write(r["text"] + "\n")
+    except OSError:
+        pass
+    T.check_full_width(r, min_tracked=0.85, min_within6=0.9)
+
+
 def test_full_size_4096_properties(da, om):
     """BASELINE config 1 at full size (4096 envs): determinism across two batches, shard invariance (2 x 2048 with global
     offsets == 1 x 4096), finite state, resets accounted, terrain indices valid."""

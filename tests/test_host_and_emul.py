@@ -1172,3 +1172,79 @@ def test_raptor_gravity_comp_and_virtual_forces_paths(da, om, tmp_path):
         q, qd = b.PoseVel(); qo, qdo = e.pose_vel()
         tc, _ = b.Torques(); tco, _ = e.tau()
         assert np.abs(q[0] - qo).max() < 1e-9 and np.abs(tc[0] - tco).max() < 1e-6, k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# parity at the width the BASELINE configs state (VERDICT r5 #1a): every env of the batch against its own oracle env
+
+def _dist(e):
+    return "median %.2e  99.9 %% %.2e  max %.2e" % (np.median(e), np.quantile(e, 0.999), e.max())
+
+
+def run_full_width_parity(da, om, arg, n, pol, seed, free_frames=12, forced_frames=24, threads=None, label=""):
+    """n product envs against n free-running oracle envs (om.batch_trace on all host cores), env by env.
+    Phase A -- FREE-RUNNING over the north-star horizon (12 outer frames = 1200 substeps from the reset): max |dq|, |dqd| of EVERY env < 1e-4 (north star), asserted
+    by the caller on the returned numbers; the distribution is recorded.
+    Phase B -- the oracle run continues for forced_frames more frames (characters stumble, fall, lie prone at the row caps, reset, terrain windows slide); the product
+    follows it frame by frame, each frame COMPARED first (one frame = 100 substeps from a common state) and then put onto the oracle's pose, velocity and persistent
+    contact rows (conftest.pin_to_oracle, batched). An env further than 1e-4 from its oracle env after a frame is dropped from the comparison (counted, never hidden).
+    Returns a dict with the numbers and the text record."""
+    m, _ = om.build_model(arg, REFDATA)
+    threads = threads or min(32, os.cpu_count() or 1)
+    F = free_frames + forced_frames
+    tr = om.batch_trace(m, n, threads, F, terrain_seed0=seed, policy=pol, contact_cache=True)
+    b = batch(da, arg, n, terrain_seed=seed)
+    b.SetPolicy(pol[1], *pol[2:])
+    free = np.zeros((free_frames, n))
+    for f in range(free_frames):
+        b.Update()
+        q, qd = b.PoseVel()
+        free[f] = np.maximum(np.abs(q - tr["q"][f]).max(1), np.abs(qd - tr["qd"][f]).max(1))
+    lines = ["%s: %s, %d envs, terrain seeds %d.., oracle %d threads %.1f s" % (label or arg, arg, n, seed, threads, tr["seconds"])]
+    lines.append("  A free-running %d frames (= %d substeps): worst frame of each env: %s" % (free_frames, free_frames * 100, _dist(free.max(0))))
+    lines.append("    per frame max: " + " ".join("%.1e" % x for x in free.max(1)))
+    lines.append("    envs > 1e-6: %d, > 1e-4: %d of %d" % ((free.max(0) > 1e-6).sum(), (free.max(0) > 1e-4).sum(), n))
+    tracked = free[-1] < 1e-4
+    forced_max = np.zeros(n); within6 = []; dropped = 0
+    for f in range(free_frames, F):
+        ids = np.nonzero(tracked)[0]
+        if ids.size:   # onto the oracle's state of the previous frame
+            b.SetPoseVel(tr["q"][f - 1][ids], tr["qd"][f - 1][ids], env_ids=ids)
+            b.SetContactCache(tr["ws_n"][f - 1][ids], tr["ws_id"][f - 1][ids], tr["ws_lam"][f - 1][ids], env_ids=ids)
+        b.Update()
+        q, qd = b.PoseVel()
+        e = np.maximum(np.abs(q - tr["q"][f]).max(1), np.abs(qd - tr["qd"][f]).max(1))
+        forced_max[ids] = np.maximum(forced_max[ids], np.where(e[ids] < 1e-4, e[ids], 0))
+        within6.append(((e[ids] < 1e-6).sum(), ids.size))
+        lost = tracked & ~(e < 1e-4)
+        dropped += int(lost.sum()); tracked &= ~lost
+    d = tr["diag"]
+    st = b.EvalStats()
+    if forced_frames:
+        lines.append("  B %d more frames, every frame from the oracle's state: tracked at the end %d of %d (dropped %d); per-frame deviation of tracked envs: %s" %
+                     (forced_frames, tracked.sum(), n, dropped, _dist(forced_max)))
+        lines.append("    within 1e-6 after a frame: min over frames %.4f of the tracked envs" % min(a / max(b_, 1) for a, b_ in within6))
+    lines.append("  oracle envs over the %d frames: went through a reset %d; substeps with R >= 16 in %d envs (%d substeps of %d); a link over its 4-point cap in %d envs; "
+                 "over the 24-row budget in %d envs; link--link rows in %d envs; max rows %d, mean rows %.2f; product resets %d" %
+                 (F, (d[:, 7] > 0).sum(), (d[:, 2] > 0).sum(), d[:, 2].sum(), d[:, 4].sum(), (d[:, 0] > 0).sum(), (d[:, 1] > 0).sum(), (d[:, 3] > 0).sum(), d[:, 5].max(),
+                  d[:, 6].sum() / max(d[:, 4].sum(), 1), st["resets"]))
+    text = "\n".join(lines)
+    print(text)
+    return dict(free=free, tracked=int(tracked.sum()), dropped=dropped, within6=within6, diag=d, text=text, n=n, oracle_resets=int((d[:, 7] > 0).sum()))
+
+
+def check_full_width(r, min_tracked=0.97, min_within6=0.99):
+    assert r["free"].max() < 1e-4, r["text"]                       # north star: per-step state error < 1e-4 over 1200 substeps, EVERY env
+    assert r["tracked"] >= min_tracked * r["n"], r["text"]         # (an env is dropped when a discrete event -- a fall, a cycle end -- lands on different env-steps)
+    assert min(a / max(b_, 1) for a, b_ in r["within6"]) >= min_within6, r["text"]
+
+
+@pytest.mark.parametrize("arg,which,seed", [("args/dog_slopes_mixed_args.txt", "dog_xavier", 1000), ("args/raptor_narrow_gaps_args.txt", "raptor_xavier", 5000),
+                                            ("args/dog_slopes_mixed_args.txt", "dog_trained", 1000), ("args/raptor_narrow_gaps_args.txt", "raptor_trained", 5000)])
+def test_batch_parity_env_by_env_reduced_width(da, om, arg, which, seed):
+    """The full-width GPU tests (tests/test_gpu_parity.py::test_config*_full_width_*) at a width the CPU suite affords, on the lane-loop build."""
+    from conftest import trained_policy
+    pol = {"dog_xavier": lambda: dog_policy(om), "raptor_xavier": lambda: raptor_policy(om),
+           "dog_trained": lambda: trained_policy(om, "dog"), "raptor_trained": lambda: trained_policy(om, "raptor")}[which]()
+    r = run_full_width_parity(da, om, arg, 96, pol, seed, forced_frames=18, label=which)
+    check_full_width(r, min_tracked=0.85, min_within6=0.9)
