@@ -305,10 +305,11 @@ double orc_batch_eval(const OrcModel* m, int n_envs, int n_threads, int n_frames
 // frame f the pose and velocity of env i go to out_q / out_qd [n_frames][n_envs][D]; out_diag [n_envs][8] = the integrator's diagnostic counters (or_sim.h
 // Integrator::diag, 7 entries) + the env's reset count.
 // out_ws_n [n_frames][n_envs], out_ws_id / out_ws_lam [n_frames][n_envs][24] (may be
-// null): the persistent contact rows after every frame (orc_get_warm); out_resets [n_frames][n_envs] (may be null): the env's reset count so far. Returns wall seconds.
+// null): the persistent contact rows after every frame (orc_get_warm); out_resets [n_frames][n_envs] (may be null): the env's reset count so far. nudge != 0: every
+// env starts with its first joint angle moved by that much (the oracle's own sensitivity to a perturbation below rounding: the chaos floor). Returns wall seconds.
 double orc_batch_trace(const OrcModel* m, int n_envs, int n_threads, int n_frames, uint64_t terrain_seed0, uint64_t rng_seed, uint64_t env_id0,
 					   const OrcNetDesc* d, const float* weights, const double* in_off, const double* in_scale, const double* out_off, const double* out_scale,
-					   double* out_q, double* out_qd, int64_t* out_diag, int32_t* out_ws_n, int32_t* out_ws_id, double* out_ws_lam, int32_t* out_resets)
+					   double* out_q, double* out_qd, int64_t* out_diag, int32_t* out_ws_n, int32_t* out_ws_id, double* out_ws_lam, int32_t* out_resets, double nudge)
 {
 	std::vector<OrcHandle*> hs(n_envs);
 	for (int i = 0; i < n_envs; ++i)
@@ -320,6 +321,7 @@ double orc_batch_trace(const OrcModel* m, int n_envs, int n_threads, int n_frame
 	for (int t = 0; t < n_threads; ++t) th.emplace_back([&, t]() {
 		for (int i = t; i < n_envs; i += n_threads) {
 			Env& e = hs[i]->env;
+			if (nudge != 0) { e.q[3] += nudge; ForwardKin(e.M, e.q, e.qd, e.B); }   // sensitivity probe: the first joint angle moved by `nudge` (1e-13: below the last bit that matters anywhere else)
 			for (int f = 0; f < n_frames; ++f) {
 				e.Update(1.0 / 30.0);
 				double* q = out_q + (static_cast<size_t>(f) * n_envs + i) * D;

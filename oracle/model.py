@@ -474,7 +474,7 @@ def lib():
         L.orc_batch_eval.restype = C.c_double
         L.orc_batch_eval.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(OrcNetDesc)] + [C.c_void_p] * 6
         L.orc_batch_trace.restype = C.c_double
-        L.orc_batch_trace.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(OrcNetDesc)] + [C.c_void_p] * 12
+        L.orc_batch_trace.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(OrcNetDesc)] + [C.c_void_p] * 12 + [C.c_double]
         _lib = L
     return _lib
 
@@ -641,9 +641,10 @@ def batch_eval(model, n_envs, n_threads, n_frames, terrain_seed0=0, rng_seed=0, 
 DIAG_KEYS = ("link_cap_substeps", "row_cap_substeps", "rows_ge_16_substeps", "pair_row_substeps", "substeps", "max_rows", "sum_rows", "resets")
 
 
-def batch_trace(model, n_envs, n_threads, n_frames, terrain_seed0=0, rng_seed=0, env_id0=0, policy=None, contact_cache=False):
+def batch_trace(model, n_envs, n_threads, n_frames, terrain_seed0=0, rng_seed=0, env_id0=0, policy=None, contact_cache=False, nudge=0.0):
     """n_envs free-running oracle envs on n_threads host threads: dict(q, qd [frames, envs, D], diag [envs, 8] per DIAG_KEYS, resets [frames, envs], seconds) and, with
-    contact_cache, ws_n [frames, envs], ws_id / ws_lam [frames, envs, 24]: the persistent contact rows after every frame."""
+    contact_cache, ws_n [frames, envs], ws_id / ws_lam [frames, envs, 24]: the persistent contact rows after every frame. nudge: every env starts with its first joint
+    angle moved by that much (sensitivity probe)."""
     D = int(model.D)
     q = np.zeros((n_frames, n_envs, D)); qd = np.zeros((n_frames, n_envs, D)); diag = np.zeros((n_envs, 8), np.int64); resets = np.zeros((n_frames, n_envs), np.int32)
     ws_n = np.zeros((n_frames, n_envs), np.int32) if contact_cache else None
@@ -656,5 +657,5 @@ def batch_trace(model, n_envs, n_threads, n_frames, terrain_seed0=0, rng_seed=0,
         io, isc, oo, osc = (np.ascontiguousarray(x, np.float64) for x in (io, isc, oo, osc))
         pa = [C.byref(desc), _p(w), _p(io), _p(isc), _p(oo), _p(osc)]
     sec = lib().orc_batch_trace(C.byref(model), n_envs, n_threads, n_frames, terrain_seed0, rng_seed, env_id0, *pa, _p(q), _p(qd), _p(diag),
-                                _p(ws_n) if contact_cache else None, _p(ws_id) if contact_cache else None, _p(ws_lam) if contact_cache else None, _p(resets))
+                                _p(ws_n) if contact_cache else None, _p(ws_id) if contact_cache else None, _p(ws_lam) if contact_cache else None, _p(resets), float(nudge))
     return dict(q=q, qd=qd, diag=diag, resets=resets, ws_n=ws_n, ws_id=ws_id, ws_lam=ws_lam, seconds=sec)

@@ -126,6 +126,23 @@ def pin_to_oracle(b, es, tol=1e-4):
     return len(ids)
 
 
+class Pinned:
+    """Bookkeeping for pin_to_oracle in long side-by-side tests: how many env-frames were still within tolerance of their oracle env and went back onto a
+    common state. A test that walks product and oracle for hundreds of frames asserts a floor on that fraction, so that 'compared while tracking' cannot quietly
+    become 'compared almost never'."""
+    def __init__(self):
+        self.pinned = 0; self.total = 0
+
+    def add(self, n_pinned, n_envs):
+        self.pinned += int(n_pinned); self.total += int(n_envs)
+        return n_pinned
+
+    def check(self, min_fraction, what=""):
+        frac = self.pinned / max(self.total, 1)
+        print("pinned %d of %d env-frames (%.3f) %s" % (self.pinned, self.total, frac, what))
+        assert frac >= min_fraction, (what, self.pinned, self.total, min_fraction)
+
+
 def pin_to_trace(b, G, f, env=0):
     """pin_to_oracle() against a frozen trace: G(key) reads tests/golden/ref_golden_configs.npz "<run>/frame/<key>" (q, qd, ws_n, ws_id, ws_lam), f = the frame.
     Joint angles are moved by the wrapped difference."""

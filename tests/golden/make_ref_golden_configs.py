@@ -15,7 +15,8 @@ can be stepped against the reference on a box without /root/reference (the MI355
   <run>/step/{tau, contacts, state, phase}   the first 240 env-steps at env-step resolution (no fall happens that early)
 
 Runs: dog_sm32 / dog_sm9 (configs[1]: dog + slopes_mixed + MACE net, poli_eval, through falls and resets), raptor_ng (configs[2]: raptor + narrow_gaps,
-stance-mirrored state), goat_cliffs (configs[4]'s scene: goat + cliffs_rugged, one substep per env-step), exp_mace / exp_q / raptor_exp_mace (tuples).
+stance-mirrored state), goat_cliffs (configs[4]'s scene: goat + cliffs_rugged, one substep per env-step), exp_mace / exp_q / raptor_exp_mace (tuples);
+round 6: dog_sm_trained / raptor_ng_trained / goat_trained = the three scenes under the policies trained through the engine (tests/golden/policies).
 Run from the repo root in the container that has /root/reference:  python tests/golden/make_ref_golden_configs.py
 """
 import os
@@ -27,7 +28,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 from oracle import model as om  # noqa: E402
 from oracle import refsim as rs  # noqa: E402
-from conftest import dog_policy  # noqa: E402
+from conftest import dog_policy, trained_policy  # noqa: E402
 import test_host_and_emul as T  # noqa: E402
 
 REF = "/root/reference"
@@ -109,8 +110,13 @@ def main():
     freeze(out, "dog_sm9", "poli_eval", "args/dog_slopes_mixed_args.txt", 9, 150, dog, 283, 90, 9)       # falls at frames 85 and 119
     freeze(out, "raptor_ng", "poli_eval", "args/raptor_narrow_gaps_args.txt", 11, 90, rap, 275, 87, 2)
     freeze(out, "goat_cliffs", "poli_eval", "args/goat_cliffs_args.txt", 8, 120, dog, 283, 90, 3)
+    # round 6: the same scenes under the policies trained THROUGH the engine (tests/golden/policies): long contact-rich episodes, the regime the reference lives in
+    freeze(out, "dog_sm_trained", "poli_eval", "args/dog_slopes_mixed_args.txt", 41, 150, trained_policy(om, "dog"), 283, 90, 9)
+    freeze(out, "raptor_ng_trained", "poli_eval", "args/raptor_narrow_gaps_args.txt", 42, 150, trained_policy(om, "raptor"), 275, 87, 2)
+    freeze(out, "goat_trained", "poli_eval", "args/goat_cliffs_args.txt", 43, 150, trained_policy(om, "goat"), 283, 90, 3)
     freeze(out, "exp_mace", "exp_mace", "args/opt_args_train_mace.txt", 21, 120, dog, 283, 90, 4, explore_off=True, command=2, overrides={"policy_model": ""}, stop_after_reset=True)
     freeze(out, "raptor_exp_mace", "exp_mace", "args/opt_args_train_raptor_mace.txt", 28, 150, rap, 275, 87, 7, explore_off=True, command=0, overrides={"policy_model": ""}, stop_after_reset=True)
+    freeze(out, "raptor_exp_mace29", "exp_mace", "args/opt_args_train_raptor_mace.txt", 29, 150, rap, 275, 87, 7, explore_off=True, command=0, overrides={"policy_model": ""}, stop_after_reset=True)   # rounds 3-4's seed, kept beside 28
     # Q head: the oracle holds the single-head net in the padded MACE form (one unused critic slot in front)
     desc = om.parse_deploy_prototxt(os.path.join(REF, "data/policies/dog/nets/dog_q_deploy.prototxt"))
     w = om.actor_xavier_weights(desc, 5)
