@@ -880,7 +880,7 @@ def test_product_vs_frozen_reference_tuples(da, om, run, scenario=None):
     b.SetExplore(False, 0.2, 0.025, 0.002)
     b.CommandAction(cmd)
     q_ref, qd_ref = g[tag + "/frame/q"], g[tag + "/frame/qd"]
-    got = 0; tracking = True; glitches = 0; skipped = 0
+    got = 0; tracking = True; glitches = 0; skipped = 0; dirty = False   # dirty: the cycle in progress went through a glitch frame (its reward and end state carry it)
     for f in range(len(q_ref)):
         b.Update()
         r, fl, _ = b.DrainTuples()
@@ -892,7 +892,7 @@ def test_product_vs_frozen_reference_tuples(da, om, run, scenario=None):
                 # which rode the reference's torques (2e-5 off the product's: its Bullet-side transforms are floats), lands differently: frames 21-22 and 45-50 end up to 5e-2
                 # from the frozen motion after ONE frame from a common state. Nothing of such a frame is compared,
                 # the product goes back onto the frozen motion, the run continues; the tuples that arrived in it are taken off the required count
-                glitches += 1; skipped += int((fr_ref == f).sum())
+                glitches += 1; skipped += int((fr_ref == f).sum()); dirty = True
                 pin_to_trace(b, lambda k: g[tag + "/frame/" + k], f)
                 continue
             tracking = False
@@ -902,6 +902,9 @@ def test_product_vs_frozen_reference_tuples(da, om, run, scenario=None):
             pin_to_trace(b, lambda k: g[tag + "/frame/" + k], f)     # compared, then onto the frozen motion (conftest.pin_to_oracle)
         idx = np.nonzero(fr_ref == f)[0]
         assert len(r) == len(idx), (tag, f, len(r), len(idx))
+        if dirty and len(r):
+            dirty = False; skipped += len(r)
+            continue
         for j, (k, row) in enumerate(zip(idx, r)):
             assert fl[j] == fl_ref[k], (tag, f)
             d = np.abs(row.astype(np.float64) - rows_ref[k].astype(np.float64)).max()

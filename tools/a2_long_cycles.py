@@ -41,7 +41,8 @@ def run_seed(job):
         # stance: the controller mirrors the state by stance; the swing toe is the one whose contact ends the step. Not exposed: infer both toes
         gy = r.sample_ground(q[0])[0]
         clr = [p[t][1] - r.sample_ground(p[t][0])[0] for t in (R_TOE, L_TOE)]
-        steps.append((st, 1 if fl & 4 else 0, int(con[R_TOE]), int(con[L_TOE]), int(sum(con[j] for j in TORSO)), q[1] - gy, q[2], qd[0], clr[0], clr[1]))
+        slip = [abs(v[t][0]) if con[t] else np.nan for t in (R_TOE, L_TOE)]     # tangential speed of a toe that is flagged in contact (world x: the terrain is near level between gaps)
+        steps.append((st, 1 if fl & 4 else 0, int(con[R_TOE]), int(con[L_TOE]), int(sum(con[j] for j in TORSO)), q[1] - gy, q[2], qd[0], clr[0], clr[1], np.nanmin(slip) if np.isfinite(slip).any() else np.nan, r.com()[1][1]))
     falls = []
     if integrator == "v1":
         ls = rs.LockStep(r, e)
@@ -88,6 +89,11 @@ def cycles_of(steps, falls):
         seg = steps[s:e_]
         up = seg[seg[:, 0] == 3]
         d = dict(dur=len(seg) / 600.0, up=len(up) / 600.0, ended="fall" if e_ in fallset else ("toe" if e_ in starts else "run end"))
+        on = (seg[:, 2] + seg[:, 3]) > 0
+        if on.any():
+            d["slip"] = float(np.nanmean(seg[on, 10])); d["stance"] = float(on.mean() * len(seg) / 600.0)
+            last = np.nonzero(on)[0][-1]
+            d["vy_off"] = float(seg[last, 11])                       # COM vertical velocity at the last env-step of the cycle with a toe on the ground (take-off)
         if len(up):
             d.update(root_h=up[:, 5].mean(), pitch=up[:, 6].mean(), torso=float((up[:, 4] > 0).mean()), vx=up[:, 7].mean(), toes_down=float(((up[:, 2] + up[:, 3]) > 0).mean()),
                      clr_min=float(np.minimum(up[:, 8], up[:, 9]).mean()), clr_max=float(np.maximum(up[:, 8], up[:, 9]).mean()))
@@ -104,9 +110,11 @@ def describe(tag, cyc):
             lines.append("  %-9s none" % name); continue
         g = lambda k: np.mean([c[k] for c in cs])
         ended = {k: sum(1 for c in cs if c["ended"] == k) for k in ("toe", "fall", "run end")}
+        sl = [c["slip"] for c in cs if "slip" in c]; vo = np.array([c["vy_off"] for c in cs if "vy_off" in c])
+        extra = "" if not sl else " | toe slip speed while in contact %.3f m/s, stance %.3f s, COM vy at take-off: mean %.2f, 90 %% %.2f, share > 2 m/s %.3f" % (np.mean(sl), np.mean([c["stance"] for c in cs if "stance" in c]), vo.mean(), np.quantile(vo, 0.9), (vo > 2).mean())
         lines.append("  %-9s n %4d (%.3f of cycles)  mean %.3f s, in Up %.3f s | over Up: root height %.3f m, pitch %+.2f rad, a torso link on the ground %.2f of the time, a toe on the ground %.2f, "
                      "lower / higher toe clearance %.3f / %.3f m, vx %.2f m/s | ended by swing-toe contact %d, fall %d, end of run %d" %
-                     (name, len(cs), len(cs) / max(len(cyc), 1), g("dur"), g("up"), g("root_h"), g("pitch"), g("torso"), g("toes_down"), g("clr_min"), g("clr_max"), g("vx"), ended["toe"], ended["fall"], ended["run end"]))
+                     (name, len(cs), len(cs) / max(len(cyc), 1), g("dur"), g("up"), g("root_h"), g("pitch"), g("torso"), g("toes_down"), g("clr_min"), g("clr_max"), g("vx"), ended["toe"], ended["fall"], ended["run end"]) + extra)
     return ["%s: %d cycles" % (tag, len(cyc))] + lines
 
 
