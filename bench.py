@@ -158,10 +158,44 @@ def cpu_baseline(cfg, frames=60):
             "logical_cpus": os.cpu_count() or 1}
 
 
+class _Dev:
+    """Where the batch lives: cuda:<local rank> (the product) or -- --backend emul-tests-only -- the host, with the package's BatchScenario bound to the lane-loop check build
+    (tests/emul/libdtrl_emul.so). Keeps the measurement code below free of backend switches."""
+    device = None; emul = False; torch = None
+
+    def setup(self, torch, emul, local_rank):
+        self.torch, self.emul = torch, emul
+        self.device = torch.device("cpu") if emul else torch.device("cuda", local_rank)
+
+    def sync(self):
+        if not self.emul:
+            self.torch.cuda.synchronize()
+
+    def side_stream(self):
+        import contextlib
+        if self.emul:
+            return contextlib.nullcontext()
+        return self.torch.cuda.stream(self.torch.cuda.Stream(device=self.device))
+
+    def package(self, da):
+        if not self.emul:
+            return da
+        lib = os.path.join(REPO, "tests", "emul", "libdtrl_emul.so")
+
+        class EmulScenario(da.BatchScenario):
+            def _library(self):
+                return da._bind(lib)
+        import types
+        return types.SimpleNamespace(BatchScenario=EmulScenario)
+
+
+DEV = _Dev()
+
+
 def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bcast_every, w, scale, reserve_cus, force_collectives=None):
     """BASELINE configs[3] at this world size: exploration rollouts + the two exchange steps, overlapped with stepping."""
     from deepterrainrl_amd.sharding import ShardedRollout
-    dev = torch.device("cuda", local_rank)
+    dev = DEV.device
     prev = os.environ.get("DTRL_RESERVE_CUS")
     if reserve_cus is not None:
         os.environ["DTRL_RESERVE_CUS"] = str(reserve_cus)      # read by the engine when the batch is created
@@ -193,7 +227,7 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
     def fence():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        DEV.sync()
 
     def frame(k):
         nonlocal cursor, tuples
@@ -221,8 +255,7 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
         sr.gather_tuples_begin(dst=0)                    # ... while frame k's tuples are drained device-to-device, packed and put on the wire
     # the framework ops of this loop (replay append, count read-backs) go to a stream of their own: the legacy default stream would serialise them with
     # every blocking stream of the process (the engine's CU-masked frame streams are such, DTRL_RESERVE_CUS)
-    side = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(side):
+    with DEV.side_stream():
         sr.UpdateBegin()
         for k in range(warmup):
             frame(k)
@@ -248,7 +281,7 @@ def exchange_leg(da, dist, torch, world, rank, local_rank, n, steps, warmup, bca
            "collective_bytes_per_frame": {"sent_per_rank": sr.block_bytes if sr.coll else 0, "received_by_rank0": sr.block_bytes * (world if sr.coll else 0)},
            "carried_rows": sr.carried_rows, "policy_bytes": int(sr.pol_bytes), "reserve_cus_per_xcd": int(reserve_cus or 0),
            "bcast_every": bcast_every, "dropped_tuples": b.TupleStats()["dropped"] - drop0, "kernel_avg_ms": kern_ms,
-           "collective": ("gather to rank 0 (RCCL)" + ("" if world > 1 else " on a one-rank group")) if sr.coll else "none (1 rank: device drain + replay append only)"}
+           "collective": ("gather to rank 0 (%s)" % ("RCCL" if DEV.device.type == "cuda" else "gloo, tests only") + ("" if world > 1 else " on a one-rank group")) if sr.coll else "none (1 rank: device drain + replay append only)"}
     b.close()
     return res
 
@@ -282,9 +315,17 @@ def main():
     ap.add_argument("--no-rccl-leg", action="store_true", help="1-GPU run: do not open a one-rank RCCL group for the exchange leg (the leg then runs without any collective)")
     ap.add_argument("--no-trained-leg", action="store_true", help="skip the side figure under the trained policy (tests/golden/policies)")
     ap.add_argument("--model-args", default="", help="ABLATIONS ONLY: comma-separated overrides of the physics model's creation arguments, e.g. warm_start=0,contact_breaking=0 (the round-4 model); the line then carries config.model_overrides and is not the headline")
+    ap.add_argument("--backend", choices=["hip", "emul-tests-only"], default="hip",
+                    help="hip = the product (libdtrl.so on the GPUs). emul-tests-only: tests/emul/libdtrl_emul.so (the lane-loop CPU build of the kernel source) over a gloo group -- "
+                         "NOT a measurement and not a fallback: it exists so that the N-rank protocol of this script (self-launch, sharding, barriers, max over ranks, exchange "
+                         "leg, the one JSON line) runs end to end on a box without GPUs (tests/test_abi.py); the line says so in `backend` and `data`. Needs DTRL_TESTS_ONLY_EMUL=1.")
+    ap.add_argument("--preroll-max", type=int, default=PREROLL_MAX, help="upper bound of the untimed pre-roll in frames (tests shorten it)")
     ap.add_argument("--dry-launch", action="store_true", help="every rank prints its placement (rank, local rank, world, global env offset, host threads) as one JSON line and exits: checks the launch path without a GPU")
     a = ap.parse_args()
 
+    emul = a.backend != "hip"
+    if emul and os.environ.get("DTRL_TESTS_ONLY_EMUL") != "1":
+        sys.exit("--backend emul-tests-only is the CPU check build for tests (set DTRL_TESTS_ONLY_EMUL=1); measurements run on the HIP library only")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a.gpus, sys.argv[1:]))
 
@@ -306,21 +347,27 @@ def main():
 
     dist = None
     import torch
+    DEV.setup(torch, emul, local_rank)
     force = os.environ.get("DTRL_FORCE_COLLECTIVES") == "1"   # validation hook: a one-rank RCCL group, so that a 1-GPU box runs the collective code path
     if world > 1 or force:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        if not emul:
+            torch.cuda.set_device(local_rank)
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
         import datetime
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=EXCHANGE_GUARD_S + 60))
+        if emul:
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=EXCHANGE_GUARD_S + 60))
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=EXCHANGE_GUARD_S + 60))
         world = dist.get_world_size()
-    elif torch.cuda.is_available():
+    elif torch.cuda.is_available() and not emul:
         torch.cuda.set_device(local_rank)
 
     # the CPU leg FIRST (round 5): 16 s of host work no longer sit between the timed GPU region and the end of the process, where the driver's SMI samples fell
     cpu_rec = cpu_baseline(cfg, a.cpu_frames) if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
     import deepterrainrl_amd as da
+    da = DEV.package(da)
     model_overrides = dict(kv.split("=", 1) for kv in a.model_args.split(",") if kv)
     b = da.BatchScenario(cfg["arg_file"], n, data_root=ROOT, device_id=local_rank,
                          extra_args=dict({"terrain_seed": 20260925, "rand_seed": 1, "global_env_offset": rank * n, "terrain_gen": a.terrain_gen}, **model_overrides))
@@ -331,20 +378,20 @@ def main():
     def fence():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        DEV.sync()
 
     def agree(x, op):
         """the same decision on every rank (max / min over ranks)"""
         if dist is None:
             return x
-        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([float(x)], dtype=torch.float64, device=DEV.device)
         dist.all_reduce(t, op=op)
         return float(t.item())
 
     # (1) pre-roll to the steady state: blocks of 20 frames until the reset rate of the last block is within 25 % of the block before it (and non-zero)
     preroll = 0; rates = []
     r_prev = b.EvalStats()["resets"]
-    while preroll < PREROLL_MAX:
+    while preroll < a.preroll_max:
         b.RunFrames(PREROLL_BLOCK); preroll += PREROLL_BLOCK
         r = b.EvalStats()["resets"]; rates.append((r - r_prev) / float(PREROLL_BLOCK)); r_prev = r
         steady = preroll >= PREROLL_MIN and len(rates) >= 2 and rates[-1] > 0 and abs(rates[-1] - rates[-2]) <= 0.25 * max(rates[-1], rates[-2])
@@ -381,6 +428,7 @@ def main():
         # the engine splits the batch into env groups (own stream each, no frame barrier between them): a launch covers one group
         env_steps_per_launch = n * frames_timed * STEPS_PER_FRAME / max(launches, 1)
         concurrent = max(1, int(round(launches / float(frames_timed))))
+        kern_ms = kern_ms if kern_ms > 0 else float("nan")     # (the lane-loop check build has no kernel clock)
         ach = B_ALG * env_steps_per_launch / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure comes from the latest committed
         # rocprofv3 --pmc passes of this same command (tools/gpu_profile.sh -> tools/rocpd_summary.py -> profiles/hbm_traffic_config<N>.json)
@@ -400,13 +448,14 @@ def main():
         rccl = None
         if dist is not None:
             try:
-                rccl = {"ranks": world, "version": ".".join(str(x) for x in torch.cuda.nccl.version()), "backend": dist.get_backend()}
+                rccl = {"ranks": world, "version": "n/a (gloo)" if emul else ".".join(str(x) for x in torch.cuda.nccl.version()), "backend": dist.get_backend()}
             except Exception as exc:
                 rccl = {"ranks": world, "version": repr(exc)}
         line = {
             "metric": "env-steps/sec (batched rollout) %s" % cfg["name"], "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not emul else "synthetic; NOT A MEASUREMENT: lane-loop CPU check build over gloo (protocol test)",
+            "backend": "hip (libdtrl.so, gfx950)" if not emul else "emul-tests-only (tests/emul/libdtrl_emul.so on the host, gloo)",
             "repeats": len(windows), "value_min": total_env_steps / max(windows), "value_max": total_env_steps / min(windows),
             "window_s": {"median": dt, "min": float(min(windows)), "max": float(max(windows)), "total": wall, "each": [round(float(x), 6) for x in windows]}, "preroll": preroll,
             "config": {"workload": cfg["workload"] % n, "baseline_config_index": a.config,
@@ -439,7 +488,7 @@ def main():
                              "note": "rank 0's envs over all %d windows: %d falls (terrain regeneration + reset launch each) and %d policy forwards happened inside the timed region; the pre-roll ran until the reset rate was stationary" % (len(windows), resets, cycles)},
         }
     b.close()
-    if rank == 0 and world == 1 and not model_overrides and not a.no_trained_leg:
+    if rank == 0 and world == 1 and not model_overrides and not a.no_trained_leg and not emul:
         pth = os.path.join(REPO, TRAINED_POLICY[a.config])
         if os.path.exists(pth) and n == cfg["envs"]:
             try:
@@ -465,7 +514,7 @@ def main():
         # own, so that the record exercises the collective code path (gather + broadcast through RCCL) -- the no-group figure stays beside it as exchange_alt
         leg_dist, leg_force = dist, None
         plan = [1, 0] if (dist is not None) else [None]
-        if dist is None and world == 1 and not a.no_rccl_leg:
+        if dist is None and world == 1 and not a.no_rccl_leg and not emul:
             try:
                 import datetime
                 import socket

@@ -1074,6 +1074,11 @@ int Engine::SetPoseVel(const int32_t* env_ids, int n, const double* q, const dou
 		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
 		if (!be_->D2H(&st, &buf_.st[e], sizeof(EnvState))) return Fail(DTRL_ERR_DEVICE, be_->error());
 		for (int k = 0; k < D; ++k) { st.q[k] = q[i * D + k]; st.qd[k] = qd[i * D + k]; }
+		// a teleported character drops its persistent contact rows (Bullet's refreshContactPoints removes manifold points that moved out of the breaking
+		// threshold): cached impulses of the old pose would warm-start whichever sample points happen to touch in the new one. A caller that restores a
+		// saved state calls dtrl_set_contact_cache AFTER this (include/dtrl.h)
+		st.ws_R = 0;
+		for (int k = 0; k < kMaxRows; ++k) { st.ws_id[k] = 0xffff; st.ws_lam[k] = 0.0; }
 		if (!be_->H2D(&buf_.st[e], &st, sizeof(EnvState))) return Fail(DTRL_ERR_DEVICE, be_->error());
 	}
 	return DTRL_OK;
@@ -1095,8 +1100,9 @@ int Engine::GetContactCache(const int32_t* env_ids, int n, int32_t* count, int32
 int Engine::SetContactCache(const int32_t* env_ids, int n, const int32_t* count, const int32_t* ids, const double* lambda)
 {
 	if (n < 0 || !count || !ids || !lambda) return Fail(DTRL_ERR_ARG, "bad arguments");
+	if (!env_ids && n > n_) return Fail(DTRL_ERR_ARG, "more rows than envs");
 	be_->Sync();
-	const int cnt = env_ids ? n : n_;
+	const int cnt = n;                       // env_ids == NULL: envs 0 .. n - 1, like dtrl_get_contact_cache and dtrl_set_pose_vel
 	EnvState st;
 	for (int i = 0; i < cnt; ++i) {
 		const int e = EnvIndex(env_ids, i);

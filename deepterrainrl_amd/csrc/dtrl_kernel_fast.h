@@ -19,6 +19,10 @@
 
 #if defined(__HIP_DEVICE_COMPILE__)
 
+#if !DTRL_WAVE_SYNC
+#error "dtrl_kernel_fast.h: the register-resident path is ONE wavefront per env by construction (v_readlane broadcasts, ballots, and LDS read-then-write sequences such as warm_match_fast() that rely on a wave's LDS operations completing in issue order). -DDTRL_WAVE_SYNC=0 builds the lane-phase reference path only (ADVICE r5)"
+#endif
+
 namespace dtrl {
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x); }

@@ -43,24 +43,71 @@ def default_block_rows(global_envs, world_size):
     return max(64, -(-n_max // 8))
 
 
+_STAGED_LOGGED = False
+_PIN = {}
+
+
 def host_staged(dist, t):
     """gloo's collectives are taken with host tensors here (two ranks sharing one GPU on a one-GPU box, debugging without RCCL): a device tensor goes through
-    the host around the collective. Never true with RCCL (backend "nccl") or with the CPU test backends."""
-    return dist is not None and bool(getattr(t, "is_cuda", False)) and dist.get_backend() == "gloo"
+    the host around the collective. Never true with RCCL (backend "nccl") or with the CPU test backends. The first time it IS true a line goes to stderr: it is a
+    debug path (a host sync per collective), and check_backend_for_devices() refuses it outright when the ranks sit on different GPUs."""
+    global _STAGED_LOGGED
+    on = dist is not None and bool(getattr(t, "is_cuda", False)) and dist.get_backend() == "gloo"
+    if on and not _STAGED_LOGGED:
+        import sys
+        _STAGED_LOGGED = True
+        print("[dtrl] collectives over DEVICE tensors on a gloo group: staged through pinned host memory (one-GPU debug path, a host sync per collective; "
+              "use the nccl backend = RCCL on a multi-GPU node)", file=sys.stderr)
+    return on
+
+
+def _pinned_like(t):
+    """one page-locked staging buffer per (shape, dtype), reused (the gradient all-reduce of the data-parallel trainer runs twice per Train())"""
+    import torch
+    key = (tuple(t.shape), t.dtype)
+    h = _PIN.get(key)
+    if h is None:
+        h = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        _PIN[key] = h
+    return h
+
+
+def check_backend_for_devices(dist, device):
+    """Start-up guard (VERDICT r5 #6b): with more than one rank and exchange buffers on GPUs, the backend must be nccl (= RCCL) unless the ranks SHARE one device
+    (the one-GPU box's two-rank tests): the host-staged gloo path can never be picked silently on a real node. Returns True when host staging will be used."""
+    import os
+    import torch
+    if dist is None or dist.get_world_size() < 2 or device is None or torch.device(device).type != "cuda":
+        return False
+    if dist.get_backend() == "nccl":
+        return False
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    try:
+        uid = str(torch.cuda.get_device_properties(idx).uuid)
+    except Exception:
+        uid = "%s:%d" % (os.uname().nodename, idx)
+    mine = (os.uname().nodename, os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "")), idx, uid)
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    if len(set(everyone)) > 1:
+        raise RuntimeError("ShardedRollout: %d ranks on DIFFERENT GPUs %s with backend '%s': the exchange must run over RCCL (init_process_group(backend='nccl')); the "
+                           "host-staged gloo path is a one-GPU debug path" % (dist.get_world_size(), sorted(set(everyone)), dist.get_backend()))
+    return True
 
 
 def all_reduce(dist, t, op=None):
     """dist.all_reduce(t) on the CURRENT stream; staged through the host for a gloo group over device tensors (the blocking copies order it on that stream)."""
     kw = {} if op is None else {"op": op}
     if host_staged(dist, t):
-        h = t.cpu(); dist.all_reduce(h, **kw); t.copy_(h)
+        h = _pinned_like(t); h.copy_(t); dist.all_reduce(h, **kw); t.copy_(h)
     else:
         dist.all_reduce(t, **kw)
 
 
 def broadcast(dist, t, src):
     if host_staged(dist, t):
-        h = t.cpu(); dist.broadcast(h, src=src); t.copy_(h)
+        h = _pinned_like(t); h.copy_(t); dist.broadcast(h, src=src); t.copy_(h)
     else:
         dist.broadcast(t, src=src)
 
@@ -113,6 +160,8 @@ class ShardedRollout:
         # a gloo group over DEVICE buffers (two ranks sharing one GPU on a box without a second one; debugging without RCCL): gloo's gather takes host
         # tensors only, so the block / the policy buffer are staged through pinned host memory around the collective. Never taken with RCCL.
         self.staged = bool(self.coll and self.on_gpu and dist.get_backend() == "gloo")
+        if self.coll and self.on_gpu:
+            check_backend_for_devices(dist, self.device)     # raises when ranks on different GPUs would go through the host
         self._stage = [torch.zeros((self.cap + 1, W + 2), dtype=torch.float32).pin_memory() for _ in range(nblk)] if self.staged else None
         self._stage_recv = None
         self._pending = None

@@ -186,7 +186,8 @@ dtrl_status dtrl_get_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, doub
  * all envs, action_ids then holds num_envs entries. The reference keeps a stack of commands; the engine keeps its top only (one pending command per env,
  * a new one replaces it -- also the random first action cScenarioExp::Reset queues, scenarios/ScenarioExp.cpp:63-73). */
 dtrl_status dtrl_command_action(dtrl_batch* b, const int32_t* env_ids, int n, const int32_t* action_ids);
-/* Replaces: cSimCharacter::SetPose / SetVel (sim/SimCharacter.cpp:665-683, 227-315). */
+/* Replaces: cSimCharacter::SetPose / SetVel (sim/SimCharacter.cpp:665-683, 227-315). A teleported character drops its persistent contact rows (what Bullet's
+ * refreshContactPoints does to manifold points that moved out of the breaking threshold): restoring a saved state = dtrl_set_pose_vel, THEN dtrl_set_contact_cache. */
 dtrl_status dtrl_set_pose_vel(dtrl_batch* b, const int32_t* env_ids, int n, const double* q, const double* qd);
 /* Replaces: the state Bullet's collision world keeps BETWEEN stepSimulation calls besides the bodies' poses and velocities: the persistent contact points of
  * the dispatcher's manifolds with their applied normal / friction impulses (btManifoldPoint::m_appliedImpulse, m_appliedImpulseLateral1), which the default

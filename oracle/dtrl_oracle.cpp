@@ -73,6 +73,7 @@ void orc_set_pose_vel(void* p, const double* q, const double* qd)
 	Env& e = static_cast<OrcHandle*>(p)->env;
 	for (int i = 0; i < e.D; ++i) { e.q[i] = q[i]; e.qd[i] = qd[i]; }
 	ForwardKin(e.M, e.q, e.qd, e.B);
+	e.integ.ResetWarmStart();   // a teleported character drops its persistent contact rows, as dtrl_set_pose_vel does (orc_set_warm afterwards restores a saved set)
 }
 // the integrator's persistent contact rows (or_sim.h Integrator::prev_*): identities and the impulses the last substep ended with; 24 slots
 int orc_get_warm(void* p, int32_t* ids, double* lam)

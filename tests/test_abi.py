@@ -115,3 +115,38 @@ def test_bench_starts_eight_ranks_the_way_the_driver_does():
         assert [r["rank"] for r in recs] == list(range(8)) and [r["local_rank"] for r in recs] == list(range(8)) and all(r["world"] == 8 and r["gpus_arg"] == 8 for r in recs)
         assert [r["global_env_offset"] for r in recs] == [4096 * k for k in range(8)] and [r["device"] for r in recs] == ["cuda:%d" % k for k in range(8)]
         assert len({r["host_threads"] for r in recs}) == 1 and recs[0]["host_threads"] >= 1
+
+
+def test_bench_eight_ranks_end_to_end_on_the_check_build_over_gloo():
+    """VERDICT r5 #6a: the first 8-GPU run must be boring. `bench.py --gpus 8` END TO END (not --dry-launch) on a box without GPUs: eight ranks of the lane-loop check build
+    (--backend emul-tests-only, tests/emul/libdtrl_emul.so) over a gloo group walk the whole protocol -- self-launch through torch.distributed.run, env-id sharding with
+    global offsets, the pre-roll agreement, barrier + max-over-ranks timing of exactly --steps frames, the exchange leg (pipelined tuple gather to rank 0 + packed policy
+    broadcast, configs[3] shape) -- and rank 0 prints ONE line: n_gpus 8, a `rccl`-shaped record with 8 ranks, scaling weak, value = all ranks' env-steps over the slowest
+    rank's time, every exploration tuple exactly once. The line is marked NOT A MEASUREMENT; on the GPU node the same code runs on libdtrl.so over RCCL."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DTRL_HOST_THREADS")}
+    env["DTRL_TESTS_ONLY_EMUL"] = "1"
+    bench = os.path.join(repo, "bench.py")
+    # without the switch the check build is refused (it is not a fallback)
+    refused = subprocess.run([sys.executable, bench, "--backend", "emul-tests-only", "--dry-launch"], env={k: v for k, v in env.items() if k != "DTRL_TESTS_ONLY_EMUL"},
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert refused.returncode != 0 and b"DTRL_TESTS_ONLY_EMUL" in refused.stdout
+    n, steps = 6, 3
+    out = subprocess.check_output([sys.executable, bench, "--gpus", "8", "--backend", "emul-tests-only", "--envs-per-gpu", str(n), "--steps", str(steps), "--warmup", "1", "--repeats", "2",
+                                   "--preroll-max", "20", "--exchange-steps", "45", "--bcast-every", "10", "--no-cpu-baseline"], env=env, stderr=subprocess.STDOUT, timeout=1500).decode()
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, out[-3000:]                   # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["higher_is_better"] is True and d["steps"] == steps and d["repeats"] == 2
+    assert d["rccl"]["ranks"] == 8 and d["rccl"]["backend"] == "gloo" and "NOT A MEASUREMENT" in d["data"] and d["backend"].startswith("emul-tests-only")
+    assert d["config"]["global_envs"] == 8 * n and d["config"]["env_steps_per_step"] == 8 * n * 20 and "x8" in d["config"]["parallelism"]
+    # value = the units ALL ranks processed / the (max over ranks) time of the median window
+    assert abs(d["value"] - 8 * n * steps * 20 / d["window_s"]["median"]) < 1e-6 * d["value"]
+    assert abs(d["ms_per_step"] - d["window_s"]["median"] / steps * 1e3) < 1e-9
+    ex = d["exchange"]
+    assert "error" not in ex and ex["steps"] == 45 and ex["dropped_tuples"] == 0 and "8 GPUs" in ex["workload"] and "gather to rank 0" in ex["collective"]
+    assert ex["collective_bytes_per_frame"]["received_by_rank0"] == 8 * ex["collective_bytes_per_frame"]["sent_per_rank"] > 0
+    assert ex["tuples"] > 0                                # 48 envs x 45 frames past the two warm-up cycles: tuples from every shard reached rank 0's replay ring
