@@ -319,6 +319,7 @@ def main():
                     help="hip = the product (libdtrl.so on the GPUs). emul-tests-only: tests/emul/libdtrl_emul.so (the lane-loop CPU build of the kernel source) over a gloo group -- "
                          "NOT a measurement and not a fallback: it exists so that the N-rank protocol of this script (self-launch, sharding, barriers, max over ranks, exchange "
                          "leg, the one JSON line) runs end to end on a box without GPUs (tests/test_abi.py); the line says so in `backend` and `data`. Needs DTRL_TESTS_ONLY_EMUL=1.")
+    ap.add_argument("--lib", default="", help="EXPERIMENTS ONLY: another build of the HIP library (tools/occupancy_ab.sh: lib/libdtrl_dyn3.so ...); the line then carries config.library and is not the headline")
     ap.add_argument("--preroll-max", type=int, default=PREROLL_MAX, help="upper bound of the untimed pre-roll in frames (tests shorten it)")
     ap.add_argument("--dry-launch", action="store_true", help="every rank prints its placement (rank, local rank, world, global env offset, host threads) as one JSON line and exits: checks the launch path without a GPU")
     a = ap.parse_args()
@@ -367,6 +368,8 @@ def main():
     # the CPU leg FIRST (round 5): 16 s of host work no longer sit between the timed GPU region and the end of the process, where the driver's SMI samples fell
     cpu_rec = cpu_baseline(cfg, a.cpu_frames) if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
     import deepterrainrl_amd as da
+    if a.lib:
+        da.LIB_PATH = os.path.abspath(a.lib)
     da = DEV.package(da)
     model_overrides = dict(kv.split("=", 1) for kv in a.model_args.split(",") if kv)
     b = da.BatchScenario(cfg["arg_file"], n, data_root=ROOT, device_id=local_rank,
@@ -461,7 +464,7 @@ def main():
             "config": {"workload": cfg["workload"] % n, "baseline_config_index": a.config,
                        "envs_per_gpu": n, "global_envs": n * world, "env_steps_per_step": n * world * STEPS_PER_FRAME,
                        "substeps_per_env_step": 5, "parallelism": "env-sharded x%d, no data-path collective" % world, "terrain_gen": a.terrain_gen, "link_contacts": 1, "contact_model": "Bullet contact persistence: warm-started ground contact rows (0.85), friction held under an unloaded normal, rows within the breaking threshold (DESIGN 4)" if not model_overrides else "ABLATION", "model_overrides": model_overrides,
-                       "host_threads_per_rank": host_threads},
+                       "host_threads_per_rank": host_threads, "library": a.lib or "deepterrainrl_amd/lib/libdtrl.so", "lds_pad_bytes": int(os.environ.get("DTRL_LDS_PAD", "0"))},
             "rccl": rccl,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": float(traffic) if traffic else None, "traffic_source": traffic_source,

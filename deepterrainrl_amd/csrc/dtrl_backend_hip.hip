@@ -29,10 +29,22 @@ __global__ void __launch_bounds__(kGroup) dtrl_frame_kernel(const DevModel* __re
 }
 
 // register-resident fast path (dtrl_kernel_fast.h), one instantiation per skeleton of the shipped characters (dtrl_topo.h)
+// Experiment builds (docs/EXPERIMENTS.md 13, tools/occupancy_ab.sh; never the shipped library): -DDTRL_DYN_LDS puts the workspace into DYNAMIC LDS, so that the compiler no
+// longer derives "two waves per SIMD at most" from the 20 KB static allocation and honours -DDTRL_WAVES_PER_EU=3 (<= 168 registers per lane): the register diet a third wave
+// per SIMD would need, priced at unchanged occupancy. Run-time knob of the shipped kernel: DTRL_LDS_PAD=<bytes> of dynamic LDS on top (fewer workgroups per CU: the
+// throughput-vs-occupancy curve from the other side).
+#ifndef DTRL_WAVES_PER_EU
+#define DTRL_WAVES_PER_EU 2
+#endif
 template <class Topo>
-__global__ void __launch_bounds__(kGroup, 2) dtrl_frame_kernel_fast(const DevModel* __restrict__ gm, RunParams rp, DevBuffers buf, int n_envs, int n_steps, real dt, int frame_end)
+__global__ void __launch_bounds__(kGroup, DTRL_WAVES_PER_EU) dtrl_frame_kernel_fast(const DevModel* __restrict__ gm, RunParams rp, DevBuffers buf, int n_envs, int n_steps, real dt, int frame_end)
 {
+#if defined(DTRL_DYN_LDS)
+	extern __shared__ __align__(16) unsigned char dtrl_dyn_lds[];
+	WSFast& ws = *reinterpret_cast<WSFast*>(dtrl_dyn_lds);
+#else
 	__shared__ WSFast ws;
+#endif
 	if (static_cast<int>(blockIdx.x) >= n_envs) return;
 	const int env = buf.env_list ? buf.env_list[blockIdx.x] : static_cast<int>(blockIdx.x);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -372,6 +384,19 @@ public:
 		hipLaunchKernelGGL(dtrl_order_by_cost, dim3(1), dim3(kOrderBuckets), 0, stream_, status, e0, n, order);
 		return Check(hipGetLastError(), "order launch");
 	}
+	// dynamic LDS of a fast-path launch: 0 in the shipped library; the workspace itself in a -DDTRL_DYN_LDS experiment build; plus DTRL_LDS_PAD bytes (occupancy experiments)
+	static unsigned FastDynLds()
+	{
+		static const unsigned bytes = []() {
+			unsigned b = 0;
+#if defined(DTRL_DYN_LDS)
+			b = static_cast<unsigned>(sizeof(WSFast));
+#endif
+			if (const char* e = std::getenv("DTRL_LDS_PAD")) b += static_cast<unsigned>(std::atoi(e));
+			return b;
+		}();
+		return bytes;
+	}
 	bool Launch(const DevModel* gm, const RunParams& rp, const DevBuffers& buf, int n_envs, int n_steps, real dt, bool frame_end) override
 	{
 		// only stepping launches are timed (the compact 0-step reset launches would skew the per-frame average)
@@ -386,9 +411,9 @@ public:
 		const char* sel = std::getenv("DTRL_KERNEL");
 		const bool use_ref = sel && std::strcmp(sel, "ref") == 0;
 		if (!use_ref && buf.model_topo == TopoDog::kId)
-			hipLaunchKernelGGL(dtrl_frame_kernel_fast<TopoDog>, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
+			hipLaunchKernelGGL(dtrl_frame_kernel_fast<TopoDog>, dim3(n_envs), dim3(kGroup), FastDynLds(), stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
 		else if (!use_ref && buf.model_topo == TopoRaptor::kId)
-			hipLaunchKernelGGL(dtrl_frame_kernel_fast<TopoRaptor>, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
+			hipLaunchKernelGGL(dtrl_frame_kernel_fast<TopoRaptor>, dim3(n_envs), dim3(kGroup), FastDynLds(), stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
 		else
 			hipLaunchKernelGGL(dtrl_frame_kernel, dim3(n_envs), dim3(kGroup), 0, stream_, gm, rp, buf, n_envs, n_steps, dt, frame_end ? 1 : 0);
 		if (timed) {
