@@ -135,6 +135,33 @@ def trained_policy_leg(da, torch, cfg, n, local_rank, a, path):
             "falls_per_1000_env_steps": 1000.0 * (st1["resets"] - st0["resets"]) / (frames * STEPS_PER_FRAME * float(n)), "policy_forwards_per_frame": (st1["cycles"] - st0["cycles"]) / float(frames)}
 
 
+def fp32_physics_leg(da, torch, cfg, n, local_rank, a, w, scale):
+    """The same workload (same seeds, same xavier weights) on the OPT-IN fp32 build of the kernel source (deepterrainrl_amd/lib/libdtrl_f32.so, -physics_precision= f32):
+    `real` = float through physics, controller and policy forward -- half the registers and LDS per env, more wave slots per CU. A side figure, never the headline:
+    the headline computes in fp64 (the reference's controller / network precision); this mode holds distribution-level parity only (tests/test_fp32_mode.py)."""
+    if not os.path.exists(da.LIB_PATH_F32):
+        return {"error": "deepterrainrl_amd/lib/libdtrl_f32.so not built"}
+    if a.lib_f32:
+        da.LIB_PATH_F32 = os.path.abspath(a.lib_f32)
+    b = da.BatchScenario(cfg["arg_file"], n, data_root=ROOT, device_id=local_rank,
+                         extra_args={"terrain_seed": 20260925, "rand_seed": 1, "terrain_gen": a.terrain_gen, "physics_precision": "f32"})
+    b.SetPolicy(w, *scale)
+    b.RunFrames(100 + a.warmup)
+    st0 = b.EvalStats(); b.KernelTimeMs()
+    wins = []
+    while sum(wins) < 2.0 and len(wins) < 40:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        b.RunFrames(a.steps)
+        torch.cuda.synchronize(); wins.append(time.perf_counter() - t0)
+    kern_ms, launches = b.KernelTimeMs()
+    st1 = b.EvalStats(); b.close()
+    dt = float(np.median(wins)); frames = a.steps * len(wins)
+    return {"library": os.path.relpath(da.LIB_PATH_F32, REPO), "dtype": "f32", "note": "opt-in mode (-physics_precision= f32), distribution-level parity only; NOT the headline",
+            "env_steps_per_s": n * a.steps * STEPS_PER_FRAME / dt, "ms_per_step": dt / a.steps * 1e3, "kernel_avg_ms": kern_ms, "windows": len(wins),
+            "resets_per_frame": (st1["resets"] - st0["resets"]) / float(frames), "falls_per_1000_env_steps": 1000.0 * (st1["resets"] - st0["resets"]) / (frames * STEPS_PER_FRAME * float(n)),
+            "policy_forwards_per_frame": (st1["cycles"] - st0["cycles"]) / float(frames)}
+
+
 def cpu_baseline(cfg, frames=60):
     """The oracle restatement (NOT Bullet -- the reference cannot be built here) timed on the host cores, bounded sample."""
     from oracle import model as om
@@ -319,6 +346,8 @@ def main():
                     help="hip = the product (libdtrl.so on the GPUs). emul-tests-only: tests/emul/libdtrl_emul.so (the lane-loop CPU build of the kernel source) over a gloo group -- "
                          "NOT a measurement and not a fallback: it exists so that the N-rank protocol of this script (self-launch, sharding, barriers, max over ranks, exchange "
                          "leg, the one JSON line) runs end to end on a box without GPUs (tests/test_abi.py); the line says so in `backend` and `data`. Needs DTRL_TESTS_ONLY_EMUL=1.")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the side figure on the opt-in fp32 build (lib/libdtrl_f32.so)")
+    ap.add_argument("--lib-f32", default="", help="EXPERIMENTS ONLY: another build of the fp32 library for the fp32_physics leg")
     ap.add_argument("--lib", default="", help="EXPERIMENTS ONLY: another build of the HIP library (tools/occupancy_ab.sh: lib/libdtrl_dyn3.so ...); the line then carries config.library and is not the headline")
     ap.add_argument("--preroll-max", type=int, default=PREROLL_MAX, help="upper bound of the untimed pre-roll in frames (tests shorten it)")
     ap.add_argument("--dry-launch", action="store_true", help="every rank prints its placement (rank, local rank, world, global env offset, host threads) as one JSON line and exits: checks the launch path without a GPU")
@@ -498,6 +527,11 @@ def main():
                 line["trained_policy"] = trained_policy_leg(da, torch, cfg, n, local_rank, a, pth)
             except Exception as exc:
                 line["trained_policy"] = {"error": repr(exc)}
+    if rank == 0 and world == 1 and not model_overrides and not a.no_fp32_leg and not emul and n == cfg["envs"]:
+        try:
+            line["fp32_physics"] = fp32_physics_leg(da, torch, cfg, n, local_rank, a, w, scale)
+        except Exception as exc:
+            line["fp32_physics"] = {"error": repr(exc)}
     ex_steps = a.exchange_steps if a.exchange_steps >= 0 else max(a.steps // 2, 50)
     legs = []
     if ex_steps > 0 and a.config == 1:

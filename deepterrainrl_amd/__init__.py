@@ -47,6 +47,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdtrl.so")
+LIB_PATH_F32 = os.path.join(_HERE, "lib", "libdtrl_f32.so")   # the opt-in fp32 build of the same source (-physics_precision= f32): distribution-level parity only
 
 DTRL_OK = 0
 FLAG_FALLEN, FLAG_STUMBLED, FLAG_NEW_CYCLE, FLAG_STATE_SHIFT = 1, 2, 4, 8
@@ -139,10 +140,12 @@ class BatchScenario:
     """N reference-shaped scenarios (cScenarioExp / cScenarioPoliEval / cScenarioSimChar) stepped as one batch on one GPU."""
 
     def _library(self):
-        """The HIP library; there is no other backend in the product (tests of the host logic subclass this from tests/conftest.py)."""
-        return _bind(LIB_PATH)
+        """The HIP library; there is no other backend in the product (tests of the host logic subclass this from tests/conftest.py). `-physics_precision= f32`
+        (extra_args) selects the fp32 build of the same source; the library itself refuses a precision it was not built for."""
+        return _bind(LIB_PATH_F32 if self._precision == "f32" else LIB_PATH)
 
     def __init__(self, arg_file=None, num_envs=1, data_root=None, device_id=-1, extra_args=None):
+        self._precision = str((extra_args or {}).get("physics_precision", "f64"))
         self._lib = self._library()
         _warn_hw_queues()
         argv = []

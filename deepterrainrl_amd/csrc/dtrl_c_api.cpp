@@ -32,7 +32,7 @@ static int dtrl_on_exception(const dtrl_batch* b)
 
 extern "C" {
 
-const char* dtrl_version(void) { return "dtrl-mi355x 0.2 (round 2)"; }
+const char* dtrl_version(void) { return sizeof(dtrl::real) == 4 ? "dtrl-mi355x 0.6 (round 6), fp32 build (opt-in: -physics_precision= f32)" : "dtrl-mi355x 0.6 (round 6), fp64"; }
 
 const char* dtrl_last_error(const dtrl_batch* b) { return b ? b->eng.error().c_str() : g_create_error.c_str(); }
 

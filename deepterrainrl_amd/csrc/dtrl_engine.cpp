@@ -757,6 +757,7 @@ int Engine::SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, 
 	if (in_off_.empty()) { in_off_.assign(d.in_size, 0.0); in_scale_.assign(d.in_size, 1.0); out_off_.assign(d.out_size, 0.0); out_scale_.assign(d.out_size, 1.0); int rc = UploadNormalizers(); if (rc != DTRL_OK) return rc; }
 	const int pad = d.out_size - cfg_.user_out_size;
 	bool ok = true;
+	if (sizeof(real) != sizeof(double) && (io_dev || is_dev || oo_dev || os_dev)) return Fail(DTRL_ERR_ARG, "the fp32 build takes device-resident WEIGHTS only; hand the normalisers over through dtrl_set_policy (host doubles)");
 	if (io_dev) ok = ok && be_->D2D(const_cast<real*>(buf_.in_off), io_dev, sizeof(real) * d.in_size) && be_->D2H(in_off_.data(), buf_.in_off, sizeof(real) * d.in_size);
 	if (is_dev) ok = ok && be_->D2D(const_cast<real*>(buf_.in_scale), is_dev, sizeof(real) * d.in_size) && be_->D2H(in_scale_.data(), buf_.in_scale, sizeof(real) * d.in_size);
 	if (oo_dev) ok = ok && be_->D2D(const_cast<real*>(buf_.out_off) + pad, oo_dev, sizeof(real) * cfg_.user_out_size) && be_->D2H(out_off_.data(), buf_.out_off, sizeof(real) * d.out_size);
@@ -769,10 +770,12 @@ int Engine::SetPolicyDevice(const float* w_dev, size_t n, const double* io_dev, 
 int Engine::UploadNormalizers()
 {
 	const NetDesc& d = cfg_.net;
-	bool ok = be_->H2D(const_cast<real*>(buf_.in_off), in_off_.data(), sizeof(real) * d.in_size)
-		&& be_->H2D(const_cast<real*>(buf_.in_scale), in_scale_.data(), sizeof(real) * d.in_size)
-		&& be_->H2D(const_cast<real*>(buf_.out_off), out_off_.data(), sizeof(real) * d.out_size)
-		&& be_->H2D(const_cast<real*>(buf_.out_scale), out_scale_.data(), sizeof(real) * d.out_size);
+	// (the host copies are double whatever the kernel's arithmetic type: dtrl_types.h `real`)
+	const std::vector<real> a(in_off_.begin(), in_off_.end()), b(in_scale_.begin(), in_scale_.end()), c(out_off_.begin(), out_off_.end()), e(out_scale_.begin(), out_scale_.end());
+	bool ok = be_->H2D(const_cast<real*>(buf_.in_off), a.data(), sizeof(real) * d.in_size)
+		&& be_->H2D(const_cast<real*>(buf_.in_scale), b.data(), sizeof(real) * d.in_size)
+		&& be_->H2D(const_cast<real*>(buf_.out_off), c.data(), sizeof(real) * d.out_size)
+		&& be_->H2D(const_cast<real*>(buf_.out_scale), e.data(), sizeof(real) * d.out_size);
 	return ok ? DTRL_OK : Fail(DTRL_ERR_DEVICE, be_->error());
 }
 
@@ -1195,6 +1198,16 @@ int Engine::ApplyRandForce(const int32_t* env_ids, int n, uint64_t seed)
 	return AddPerturb(env_ids, cnt, link.data(), nullptr, f.data(), dur.data());
 }
 
+// n values of the kernel's arithmetic type from device memory into the ABI's doubles
+bool Engine::D2HReal(double* dst, const real* src, size_t n)
+{
+	if (sizeof(real) == sizeof(double)) return be_->D2H(dst, src, sizeof(real) * n);
+	std::vector<real> tmp(n);
+	if (!be_->D2H(tmp.data(), src, sizeof(real) * n)) return false;
+	for (size_t k = 0; k < n; ++k) dst[k] = static_cast<double>(tmp[k]);
+	return true;
+}
+
 int Engine::GetPoliState(const int32_t* env_ids, int n, double* s)
 {
 	if (n < 0 || !s) return Fail(DTRL_ERR_ARG, "bad arguments");
@@ -1202,7 +1215,7 @@ int Engine::GetPoliState(const int32_t* env_ids, int n, double* s)
 	for (int i = 0; i < n; ++i) {
 		int e = EnvIndex(env_ids, i);
 		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
-		if (!be_->D2H(s + static_cast<size_t>(i) * S_, buf_.poli_state + static_cast<size_t>(e) * S_, sizeof(real) * S_)) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (!D2HReal(s + static_cast<size_t>(i) * S_, buf_.poli_state + static_cast<size_t>(e) * S_, S_)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	}
 	return DTRL_OK;
 }
@@ -1216,7 +1229,7 @@ int Engine::GetPolicyOutput(const int32_t* env_ids, int n, double* y)
 	for (int i = 0; i < n; ++i) {
 		int e = EnvIndex(env_ids, i);
 		if (e < 0 || e >= n_) return Fail(DTRL_ERR_ARG, "env id out of range");
-		if (!be_->D2H(y + static_cast<size_t>(i) * cfg_.user_out_size, buf_.nn_out + static_cast<size_t>(e) * cfg_.net.out_size + pad, sizeof(real) * cfg_.user_out_size)) return Fail(DTRL_ERR_DEVICE, be_->error());
+		if (!D2HReal(y + static_cast<size_t>(i) * cfg_.user_out_size, buf_.nn_out + static_cast<size_t>(e) * cfg_.net.out_size + pad, cfg_.user_out_size)) return Fail(DTRL_ERR_DEVICE, be_->error());
 	}
 	return DTRL_OK;
 }

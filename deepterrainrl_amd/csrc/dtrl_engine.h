@@ -168,6 +168,7 @@ private:
 	TerrainCfg* d_tcfg_ = nullptr;
 	PackScratch pack_;                  // allocated by the first packed drain
 	static constexpr int kDistRingCap = 1 << 20;
+	bool D2HReal(double* dst, const real* src, size_t n);
 	std::vector<double> in_off_, in_scale_, out_off_, out_scale_;   // host copies of the policy normalisers (identity until set)
 	int UploadNormalizers();
 	void BuildRelayoutMap(std::vector<int32_t>& map) const;

@@ -608,6 +608,13 @@ bool LoadScenario(const ArgParser& args, ScenarioConfig& cfg, std::string& err)
 	args.ParseDouble("min_pertrub_duration", cfg.min_perturb_duration); args.ParseDouble("max_perturb_duration", cfg.max_perturb_duration);
 	int seed = 0; if (args.ParseInt("terrain_seed", seed)) cfg.terrain_seed = static_cast<uint64_t>(seed);
 	{
+		{
+			// -physics_precision= f64 | f32: WHICH LIBRARY must be loaded, checked here: libdtrl.so computes in fp64 (the default and the parity-tested product),
+			// libdtrl_f32.so is the same source built with `real` = float (dtrl_types.h) -- an opt-in mode with distribution-level parity only
+			const std::string built = sizeof(real) == 4 ? "f32" : "f64";
+			std::string prec = built; args.ParseString("physics_precision", prec);
+			if (prec != built) { err = "-physics_precision= " + prec + ": this library computes in " + built + " (fp64 = libdtrl.so, fp32 = libdtrl_f32.so)"; return false; }
+		}
 		std::string gen = "host"; args.ParseString("terrain_gen", gen);
 		if (gen != "host" && gen != "device") { err = "-terrain_gen= must be host (the reference's generator streams, bit-exact) or device (counter-based streams, generated on the GPU)"; return false; }
 		cfg.device_terrain = gen == "device";

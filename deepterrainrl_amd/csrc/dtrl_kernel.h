@@ -222,6 +222,36 @@ struct WSFast : WSBase {
 // fused multiply-add a*b + c, spelled out (the build runs with -ffp-contract=off): the SAME fused operations in the lane-loop,
 // reference and register-resident builds keep the three bit-identical, and the solver's dependent chains are one op shorter per step
 DTRL_HD_INLINE real fmadd(real a, real b, real c) { return __builtin_fma(a, b, c); }
+DTRL_HD_INLINE void sincos_r(real x, real* s, real* c)
+{
+#if defined(DTRL_REAL_F32)
+	sincosf(x, s, c);
+#else
+	sincos(x, s, c);
+#endif
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+// one 16 x 16 x 4 step of the matrix pipe in the kernel's arithmetic type. Operands: A[i = lane % 16][k = lane / 16], B[k = lane / 16][n = lane % 16] in both types;
+// the RESULT registers differ: register r of lane group g = lane / 16 holds row 4 r + g of the tile in fp64 (v_mfma_f64_16x16x4_f64) and row 4 g + r in fp32
+// (v_mfma_f32_16x16x4_f32) -- mfma_row(). Both accumulate in k order with fused multiply-adds (tools/microbench/mfma_f64_check.hip).
+typedef real v4r_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4r_t mfma_16x16x4(real a, real b, v4r_t acc)
+{
+#if defined(DTRL_REAL_F32)
+	return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+#else
+	return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ constexpr int mfma_row(int r, int g)
+{
+#if defined(DTRL_REAL_F32)
+	return 4 * g + r;
+#else
+	return 4 * r + g;
+#endif
+}
+#endif
 // 1/x and 1/sqrt(x) for the solver's pivots and the contact normals. An IEEE fp64 division on gfx950 is a 14-instruction VALU sequence
 // (div_scale x2, rcp, Newton, div_fmas, div_fixup) and the frame kernel is bound by VALU issue; the hardware seed + two Newton steps
 // (5 / 9 instructions) is within an ulp or two for the normal, positive arguments that occur here (inertias, 1 + slope^2).
@@ -381,7 +411,7 @@ DTRL_HD inline void kin_dyn_terms(W& ws)
 			phi = fmadd(qa, on, phi); w = fmadd(wa, on, w);
 		}
 		ws.phi[j] = phi; ws.w[j] = w;
-		real s, c; sincos(phi, &s, &c);
+		real s, c; sincos_r(phi, &s, &c);
 		ws.cs[j] = c; ws.sn[j] = s;
 	}
 	LANES_END
@@ -438,7 +468,7 @@ DTRL_HD inline void kin_dyn_terms(W& ws)
 	// Operand layout (same check): A[i = lane % 16][k = lane / 16], B[k = lane / 16][n = lane % 16], D register r = D[4 r + lane / 16][lane % 16].
 #if defined(__HIP_DEVICE_COMPILE__)
 	{
-		typedef double v4d_t __attribute__((ext_vector_type(4)));
+		typedef v4r_t v4d_t;
 		const int l = static_cast<int>(threadIdx.x), g = l >> 4, c = l & 15;
 		const int nL = ws.M.L;
 		const real* V = &ws.fx[0];                                              // [6][kMaxL]: fx, fy, fn, mcx, mcy, Io
@@ -452,14 +482,14 @@ DTRL_HD inline void kin_dyn_terms(W& ws)
 			const real bv = V[live ? c * kMaxL + k : 0];
 			const real b = live ? bv : 0.0;
 			const real a0 = ((m0 >> k) & 1u) ? 1.0 : 0.0, a1 = ((m1 >> k) & 1u) ? 1.0 : 0.0;
-			acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc0, 0, 0, 0);
-			acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc1, 0, 0, 0);
+			acc0 = mfma_16x16x4(a0, b, acc0);
+			acc1 = mfma_16x16x4(a1, b, acc1);
 		}
 		if (c < 6) {
 			real* out = (c < 3) ? &ws.sfs[c][0] : (&ws.smx[0] + (c - 3) * kMaxL);   // smx, smy, sI are contiguous
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
-				const int j0 = 4 * r + g, j1 = 16 + 4 * r + g;
+				const int j0 = mfma_row(r, g), j1 = 16 + mfma_row(r, g);
 				if (j0 < nL) out[j0] = acc0[r];
 				if (j1 < nL) out[j1] = acc1[r];
 			}
@@ -1179,12 +1209,12 @@ DTRL_HD inline void conv_tile(W& ws, const float* Wd, const float* bias, int co,
 	(void)ws;
 #if defined(__HIP_DEVICE_COMPILE__)
 	// operand layout: A[i = lane % 16][k = lane / 16], B[k = lane / 16][n = lane % 16], D register r = D[4 r + lane / 16][lane % 16]
-	typedef double v4d_t __attribute__((ext_vector_type(4)));
+	typedef v4r_t v4d_t;
 	const int l = static_cast<int>(threadIdx.x), g = l >> 4, j = l & 15;
 	const bool two = co > kConvTile;                 // a 16-channel layer runs the second tile on the first one's weights and drops the result
 	v4d_t acc0, acc1;
 #pragma unroll
-	for (int r = 0; r < 4; ++r) { acc0[r] = static_cast<real>(bias[4 * r + g]); acc1[r] = static_cast<real>(bias[two ? 16 + 4 * r + g : 0]); }
+	for (int r = 0; r < 4; ++r) { acc0[r] = static_cast<real>(bias[mfma_row(r, g)]); acc1[r] = static_cast<real>(bias[two ? 16 + mfma_row(r, g) : 0]); }
 	const int nk = cin * k, ksh = (k == 8) ? 3 : 2;  // kernel widths are 4 or 8 (host check)
 	const float* w0 = Wd + g * co + j;              // this lane's A entries: W[kk + g][j] and W[kk + g][16 + j]
 	const float* w1 = w0 + (two ? kConvTile : 0);
@@ -1203,8 +1233,8 @@ DTRL_HD inline void conv_tile(W& ws, const float* Wd, const float* bias, int co,
 		}
 #pragma unroll
 		for (int q = 0; q < NB; ++q) {
-			acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(static_cast<real>(a0[q]), b[q], acc0, 0, 0, 0);
-			acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(static_cast<real>(a1[q]), b[q], acc1, 0, 0, 0);
+			acc0 = mfma_16x16x4(static_cast<real>(a0[q]), b[q], acc0);
+			acc1 = mfma_16x16x4(static_cast<real>(a1[q]), b[q], acc1);
 		}
 #pragma unroll
 		for (int q = 0; q < NB; ++q) { a0[q] = n0[q]; a1[q] = n1[q]; }
@@ -1212,7 +1242,7 @@ DTRL_HD inline void conv_tile(W& ws, const float* Wd, const float* bias, int co,
 	env_sync();
 #pragma unroll
 	for (int r = 0; r < 4; ++r) {
-		const int o0 = 4 * r + g, o1 = 16 + o0;
+		const int o0 = mfma_row(r, g), o1 = 16 + o0;
 		const real v0 = acc0[r] < 0 ? 0 : acc0[r], v1 = acc1[r] < 0 ? 0 : acc1[r];
 		if (nv < 0) { out[o0 * os + j] = v0; if (two) out[o1 * os + j] = v1; }
 		else if (j < nv) { out[o0 * nv + j] = v0; if (two) out[o1 * nv + j] = v1; }

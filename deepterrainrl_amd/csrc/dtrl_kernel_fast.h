@@ -26,11 +26,23 @@
 namespace dtrl {
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x); }
+// the EXEC-window helpers below are spelled per arithmetic type (dtrl_types.h: fp64 shipped, fp32 opt-in build)
+#if defined(DTRL_REAL_F32)
+#define DTRL_VFMA "v_fma_f32"
+#define DTRL_VMOV "v_mov_b32"
+#else
+#define DTRL_VFMA "v_fma_f64"
+#define DTRL_VMOV "v_mov_b64"
+#endif
 __device__ __forceinline__ real bcast(real v, int src)   // src must be wave-uniform
 {
+#if defined(DTRL_REAL_F32)
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+#else
 	int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
 	int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
 	return __hiloint2double(hi, lo);
+#endif
 }
 
 // row `lane` of the joint-space inertia matrix from the composite quantities in LDS (same formulas and operand order as
@@ -52,8 +64,9 @@ __device__ __forceinline__ void mass_row(WSFast& ws, real (&h)[D])
 	const bool hinge = d >= 2 && d < D;
 	real* T = ws.Apk;
 	{
-		double2* T2 = reinterpret_cast<double2*>(T);
-		const double2 z2 = {0.0, 0.0};
+		struct alignas(2 * sizeof(real)) real2 { real x, y; };
+		real2* T2 = reinterpret_cast<real2*>(T);
+		const real2 z2 = {0.0, 0.0};
 #pragma unroll
 		for (int e = 0; e < (kFill / 2 + kGroup - 1) / kGroup; ++e) if (d + e * kGroup < kFill / 2) T2[d + e * kGroup] = z2;
 	}
@@ -106,7 +119,7 @@ template <int J>
 __device__ __forceinline__ void fnma_lanes_ge(real& acc, real a, real b)
 {
 	unsigned long long sv, m;
-	asm("s_lshl_b64 %2, -1, %5\n\ts_and_saveexec_b64 %1, %2\n\tv_fma_f64 %0, -%3, %4, %0\n\ts_mov_b64 exec, %1"
+	asm("s_lshl_b64 %2, -1, %5\n\ts_and_saveexec_b64 %1, %2\n\t" DTRL_VFMA " %0, -%3, %4, %0\n\ts_mov_b64 exec, %1"
 	    : "+v"(acc), "=&s"(sv), "=&s"(m) : "v"(a), "s"(b), "n"(J) : "scc");
 }
 template <int J>
@@ -115,15 +128,15 @@ template <int J>
 __device__ __forceinline__ void fnma_lanes_ge(real (&acc)[2], real a, const real (&b)[2])
 {
 	unsigned long long sv, m;
-	asm("s_lshl_b64 %3, -1, %7\n\ts_and_saveexec_b64 %2, %3\n\tv_fma_f64 %0, -%4, %5, %0\n\tv_fma_f64 %1, -%4, %6, %1\n\ts_mov_b64 exec, %2"
+	asm("s_lshl_b64 %3, -1, %7\n\ts_and_saveexec_b64 %2, %3\n\t" DTRL_VFMA " %0, -%4, %5, %0\n\t" DTRL_VFMA " %1, -%4, %6, %1\n\ts_mov_b64 exec, %2"
 	    : "+v"(acc[0]), "+v"(acc[1]), "=&s"(sv), "=&s"(m) : "v"(a), "s"(b[0]), "s"(b[1]), "n"(J) : "scc");
 }
 template <int J>
 __device__ __forceinline__ void fnma_lanes_ge(real (&acc)[4], real a, const real (&b)[4])
 {
 	unsigned long long sv, m;
-	asm("s_lshl_b64 %5, -1, %11\n\ts_and_saveexec_b64 %4, %5\n\tv_fma_f64 %0, -%6, %7, %0\n\tv_fma_f64 %1, -%6, %8, %1\n\t"
-	    "v_fma_f64 %2, -%6, %9, %2\n\tv_fma_f64 %3, -%6, %10, %3\n\ts_mov_b64 exec, %4"
+	asm("s_lshl_b64 %5, -1, %11\n\ts_and_saveexec_b64 %4, %5\n\t" DTRL_VFMA " %0, -%6, %7, %0\n\t" DTRL_VFMA " %1, -%6, %8, %1\n\t"
+	    "" DTRL_VFMA " %2, -%6, %9, %2\n\t" DTRL_VFMA " %3, -%6, %10, %3\n\ts_mov_b64 exec, %4"
 	    : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "=&s"(sv), "=&s"(m)
 	    : "v"(a), "s"(b[0]), "s"(b[1]), "s"(b[2]), "s"(b[3]), "n"(J) : "scc");
 }
@@ -132,7 +145,7 @@ template <int I>
 __device__ __forceinline__ void fnma_lanes_lt(real& acc, real a, real b)
 {
 	unsigned long long sv, m;
-	asm("s_bfm_b64 %2, %5, 0\n\ts_and_saveexec_b64 %1, %2\n\tv_fma_f64 %0, -%3, %4, %0\n\ts_mov_b64 exec, %1"
+	asm("s_bfm_b64 %2, %5, 0\n\ts_and_saveexec_b64 %1, %2\n\t" DTRL_VFMA " %0, -%3, %4, %0\n\ts_mov_b64 exec, %1"
 	    : "+v"(acc), "=&s"(sv), "=&s"(m) : "v"(a), "s"(b), "n"(I) : "scc");
 }
 // dst = src on lane K only / on lanes < I
@@ -140,14 +153,14 @@ template <int K>
 __device__ __forceinline__ void mov_lane_eq(real& dst, real src)
 {
 	unsigned long long sv, m;
-	asm("s_lshl_b64 %2, 1, %4\n\ts_and_saveexec_b64 %1, %2\n\tv_mov_b64 %0, %3\n\ts_mov_b64 exec, %1"
+	asm("s_lshl_b64 %2, 1, %4\n\ts_and_saveexec_b64 %1, %2\n\t" DTRL_VMOV " %0, %3\n\ts_mov_b64 exec, %1"
 	    : "+v"(dst), "=&s"(sv), "=&s"(m) : "v"(src), "n"(K) : "scc");
 }
 template <int I>
 __device__ __forceinline__ void mov_lanes_lt(real& dst, real src)
 {
 	unsigned long long sv, m;
-	asm("s_bfm_b64 %2, %4, 0\n\ts_and_saveexec_b64 %1, %2\n\tv_mov_b64 %0, %3\n\ts_mov_b64 exec, %1"
+	asm("s_bfm_b64 %2, %4, 0\n\ts_and_saveexec_b64 %1, %2\n\t" DTRL_VMOV " %0, %3\n\ts_mov_b64 exec, %1"
 	    : "+v"(dst), "=&s"(sv), "=&s"(m) : "v"(src), "n"(I) : "scc");
 }
 // dst = src on lanes >= J
@@ -155,7 +168,7 @@ template <int J>
 __device__ __forceinline__ void mov_lanes_ge(real& dst, real src)
 {
 	unsigned long long sv, m;
-	asm("s_lshl_b64 %2, -1, %4\n\ts_and_saveexec_b64 %1, %2\n\tv_mov_b64 %0, %3\n\ts_mov_b64 exec, %1"
+	asm("s_lshl_b64 %2, -1, %4\n\ts_and_saveexec_b64 %1, %2\n\t" DTRL_VMOV " %0, %3\n\ts_mov_b64 exec, %1"
 	    : "+v"(dst), "=&s"(sv), "=&s"(m) : "v"(src), "n"(J) : "scc");
 }
 
@@ -165,15 +178,15 @@ template <int I>
 __device__ __forceinline__ void fnma_lanes_lt(real (&acc)[2], real a, const real (&b)[2])
 {
 	unsigned long long sv, m;
-	asm("s_bfm_b64 %3, %7, 0\n\ts_and_saveexec_b64 %2, %3\n\tv_fma_f64 %0, -%4, %5, %0\n\tv_fma_f64 %1, -%4, %6, %1\n\ts_mov_b64 exec, %2"
+	asm("s_bfm_b64 %3, %7, 0\n\ts_and_saveexec_b64 %2, %3\n\t" DTRL_VFMA " %0, -%4, %5, %0\n\t" DTRL_VFMA " %1, -%4, %6, %1\n\ts_mov_b64 exec, %2"
 	    : "+v"(acc[0]), "+v"(acc[1]), "=&s"(sv), "=&s"(m) : "v"(a), "s"(b[0]), "s"(b[1]), "n"(I) : "scc");
 }
 template <int I>
 __device__ __forceinline__ void fnma_lanes_lt(real (&acc)[4], real a, const real (&b)[4])
 {
 	unsigned long long sv, m;
-	asm("s_bfm_b64 %5, %11, 0\n\ts_and_saveexec_b64 %4, %5\n\tv_fma_f64 %0, -%6, %7, %0\n\tv_fma_f64 %1, -%6, %8, %1\n\t"
-	    "v_fma_f64 %2, -%6, %9, %2\n\tv_fma_f64 %3, -%6, %10, %3\n\ts_mov_b64 exec, %4"
+	asm("s_bfm_b64 %5, %11, 0\n\ts_and_saveexec_b64 %4, %5\n\t" DTRL_VFMA " %0, -%6, %7, %0\n\t" DTRL_VFMA " %1, -%6, %8, %1\n\t"
+	    "" DTRL_VFMA " %2, -%6, %9, %2\n\t" DTRL_VFMA " %3, -%6, %10, %3\n\ts_mov_b64 exec, %4"
 	    : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "=&s"(sv), "=&s"(m)
 	    : "v"(a), "s"(b[0]), "s"(b[1]), "s"(b[2]), "s"(b[3]), "n"(I) : "scc");
 }
@@ -488,7 +501,7 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 		// column R is ONE 16x16 tile of the fp64 matrix pipe, six k-steps of v_mfma_f64_16x16x4_f64 (k = DoF, padded to 24). The MFMA
 		// accumulates in k order with fused multiply-adds, i.e. the sequence of the scalar loops (tools/microbench/mfma_f64_check.hip).
 		// Operand layout: A[i = lane % 16][k = lane / 16], B[k = lane / 16][n = lane % 16], D register r = D[4 r + lane / 16][lane % 16].
-		typedef double v4d_t __attribute__((ext_vector_type(4)));
+		typedef v4r_t v4d_t;
 		const int g = lane >> 4, c = lane & 15;
 		// row residual's velocity term, on the lanes that finish wv below (independent of the product: overlaps it)
 		real jv = 0;
@@ -506,11 +519,11 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 			const real z = ws.Z[zrow][live ? k : 0], dk = ws.dinv[live ? k : 0];
 			const real b = live ? z : 0.0;
 			const real a = live ? z * dk : 0.0;
-			acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+			acc = mfma_16x16x4(a, b, acc);
 		}
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
-			const int i = 4 * r + g;                               // D[i][c]
+			const int i = mfma_row(r, g);                          // D[i][c]
 			if (i < R && c <= i) ws.Apk[i * (i + 1) / 2 + c] = acc[r];
 			if (i < R && c == R) ws.wv[i] = acc[r];               // zz_i, finished below
 		}
@@ -568,9 +581,13 @@ __device__ __forceinline__ void build_delassus_fast(WSFast& ws, real h, real din
 // Same operations on the same operands as pgs_solve(), hence the same bits; rows with a vanishing effective mass are skipped.
 __device__ __forceinline__ real wave_shr1(real v)
 {
+#if defined(DTRL_REAL_F32)
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));   // DPP wave_shr:1
+#else
 	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);   // DPP wave_shr:1
 	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
 	return __hiloint2double(hi, lo);
+#endif
 }
 template <int r, int K>
 __device__ __forceinline__ void pgs_rows_load(real (&a)[K], const WSFast& ws, int lane, bool mine, int R)

@@ -11,7 +11,14 @@
 
 namespace dtrl {
 
+// Arithmetic type of the whole frame kernel. The shipped library (libdtrl.so) computes in fp64: the reference's controller / RBD / network precision.
+// -DDTRL_REAL_F32 builds the OPT-IN fp32 library (libdtrl_f32.so, `-physics_precision= f32`; Bullet's own state is float: premake4.lua:115-124): same source, same
+// operation order, half the registers and half the LDS per env -> more wave slots per CU. Trajectories then agree with the fp64 build in DISTRIBUTION only.
+#if defined(DTRL_REAL_F32)
+typedef float real;
+#else
 typedef double real;
+#endif
 
 constexpr int kGroup = 64;       // lanes per env = one CDNA wavefront
 constexpr int kMaxL = 24;        // links

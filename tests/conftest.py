@@ -10,6 +10,7 @@ if REPO not in sys.path:
 REFDATA = os.path.join(REPO, "tests", "golden", "refdata")
 GOLDEN = os.path.join(REPO, "tests", "golden")
 EMUL_LIB = os.path.join(REPO, "tests", "emul", "libdtrl_emul.so")   # lane-loop build of the kernel source: TESTS ONLY, lives outside the product package
+EMUL_LIB_F32 = os.path.join(REPO, "tests", "emul", "libdtrl_emul_f32.so")   # the same with `real` = float: the check build of the opt-in fp32 library
 HIP_LIB = os.path.join(REPO, "deepterrainrl_amd", "lib", "libdtrl.so")
 REFERENCE = "/root/reference"
 # the test process's own choice, before any HIP runtime starts (the package leaves the environment alone: deepterrainrl_amd.configure_hw_queues)
@@ -47,6 +48,16 @@ def _emul_scenario_cls():
 class _Lazy:
     def __call__(self, *a, **k):
         return _emul_scenario_cls()(*a, **k)
+
+
+def emul_f32_scenario(*a, **k):
+    """BatchScenario on the lane-loop build of the fp32 library (tests/emul/libdtrl_emul_f32.so)"""
+    import deepterrainrl_amd
+
+    class EmulScenarioF32(deepterrainrl_amd.BatchScenario):
+        def _library(self):
+            return deepterrainrl_amd._bind(EMUL_LIB_F32)
+    return EmulScenarioF32(*a, **k)
 
 
 EmulScenario = _Lazy()   # callable like the class; resolved lazily so that importing conftest does not import the package
