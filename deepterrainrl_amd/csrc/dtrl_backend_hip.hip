@@ -36,8 +36,17 @@ __global__ void __launch_bounds__(kGroup) dtrl_frame_kernel(const DevModel* __re
 #ifndef DTRL_WAVES_PER_EU
 #define DTRL_WAVES_PER_EU 2
 #endif
+#ifndef DTRL_WAVES_DOG
+#define DTRL_WAVES_DOG DTRL_WAVES_PER_EU
+#endif
+#ifndef DTRL_WAVES_RAPTOR
+#define DTRL_WAVES_RAPTOR DTRL_WAVES_PER_EU
+#endif
+template <class Topo> struct WavesPerEu { static constexpr int value = DTRL_WAVES_PER_EU; };
+template <> struct WavesPerEu<TopoDog> { static constexpr int value = DTRL_WAVES_DOG; };          // (the fp32 build gives each skeleton's instance its own register budget:
+template <> struct WavesPerEu<TopoRaptor> { static constexpr int value = DTRL_WAVES_RAPTOR; };    //  profiles/r06_fp32_physics.txt)
 template <class Topo>
-__global__ void __launch_bounds__(kGroup, DTRL_WAVES_PER_EU) dtrl_frame_kernel_fast(const DevModel* __restrict__ gm, RunParams rp, DevBuffers buf, int n_envs, int n_steps, real dt, int frame_end)
+__global__ void __launch_bounds__(kGroup, WavesPerEu<Topo>::value) dtrl_frame_kernel_fast(const DevModel* __restrict__ gm, RunParams rp, DevBuffers buf, int n_envs, int n_steps, real dt, int frame_end)
 {
 #if defined(DTRL_DYN_LDS)
 	extern __shared__ __align__(16) unsigned char dtrl_dyn_lds[];

@@ -2100,6 +2100,9 @@ DTRL_HD inline void load_hot_model(W& ws, const DevModel& gm)
 }
 
 // the whole per-env frame: load -> (reset) -> n_steps env-steps -> frame-end logic -> store
+#ifndef DTRL_COST_MODE
+#define DTRL_COST_MODE 1   // (round 6: the last substep's rows; +1.0 % dog, +0.3 % raptor in 6 of 6 same-box pairs, results unchanged bit for bit -- profiles/r06_launch_order_ab.txt)
+#endif
 template <class Path, class W>
 DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, const DevBuffers& buf, int env, int n_steps, real dt, bool do_frame_end)
 {
@@ -2149,7 +2152,17 @@ DTRL_HD inline void env_frame(W& ws, const DevModel& gm, const RunParams& rp, co
 			// length of the previous one within the next frame (one forward ~ 400 row-substep units, tools/gpu_sections.py)
 			const real frame_t = n_steps * dt;
 			const bool forward_due = gm.has_net != 0 && (ws.st.first_cycle != 0 || ws.st.curr_cycle_time + frame_t >= 0.9 * ws.st.prev_cycle_time);
-			buf.status[env].cost = ws.cost + (forward_due ? 400 : 0); }
+			// DTRL_COST_MODE (A/B, profiles/r06_launch_order_ab.txt): 0 = the frame's row sum (shipped until round 5: finds 43 % of the next frame's slowest 5 %, rank
+			// correlation 0.49); 1 = the row count of the frame's LAST substep x the substeps of a frame (50 %, 0.66: a character that just went down is expensive for the
+			// WHOLE next frame, one that just got up is not); 2 = the mean of both
+#if DTRL_COST_MODE == 1
+			const int row_cost = n_steps * gm.num_sim_substeps * (8 + ws.st.ws_R);
+#elif DTRL_COST_MODE == 2
+			const int row_cost = (ws.cost + n_steps * gm.num_sim_substeps * (8 + ws.st.ws_R)) / 2;
+#else
+			const int row_cost = ws.cost;
+#endif
+			buf.status[env].cost = row_cost + (forward_due ? 400 : 0); }
 		LANES_END
 	}
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DTRL_PROFILE)

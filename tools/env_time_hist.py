@@ -28,7 +28,7 @@ pred = []       # (predictor A: the previous frame's constraint-row sum = what E
 prev_rows = None
 for f in range(10):
     r0 = read(); res0 = b.CycleInfo()[1].copy()
-    last_R = b.GetContactCache()[0].astype(np.float64)       # EnvState::ws_R = rows of the last substep
+    last_R = b.ContactCache()[0].astype(np.float64)       # EnvState::ws_R = rows of the last substep
     b.Update()
     r1 = read(); res1 = b.CycleInfo()[1]
     d = {k: r1[k] - r0[k] for k in K}

@@ -2,11 +2,11 @@
 # (GPU box) The opt-in fp32 build: tests, then the bench side figure for each register budget / scheduler variant of its frame kernel -> profiles/r06_fp32_physics.txt
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-fp32}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
-python -m pytest tests/test_fp32_mode.py -m gpu -q -s > $O/pytest_fp32.log 2>&1; grep -E "passed|failed|HIP fp32|fp32 \{" $O/pytest_fp32.log | cut -c1-420
+[ -n "$SKIP_TESTS" ] || python -m pytest tests/test_fp32_mode.py -m gpu -q -s > $O/pytest_fp32.log 2>&1; [ -n "$SKIP_TESTS" ] || grep -E "passed|failed|HIP fp32|fp32 \{" $O/pytest_fp32.log | cut -c1-420
 OUT=$O/fp32_ab.txt; : > $OUT
 for cfg in 1 2; do
   echo "== configs[$cfg]" >> $OUT
-  for lib in libdtrl_f32_w2_ilp libdtrl_f32_w3_ilp libdtrl_f32_w4_ilp libdtrl_f32_w3_def libdtrl_f32_w4_def; do
+  for lib in ${FP32_LIBS:-libdtrl_f32}; do
     echo -n "$lib: " >> $OUT
     python bench.py --config $cfg --no-cpu-baseline --no-trained-leg --exchange-steps 0 --no-rccl-leg --lib-f32 deepterrainrl_amd/lib/$lib.so 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); f=d['fp32_physics']
