@@ -10,9 +10,9 @@ cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --config $CFG --steps 60 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 1500 $OUT/bench.json
 # the kernel-trace pass runs the SAME command as the bench line above (minus the CPU leg) so the timed launches can be compared 1:1: 3 windows of 60 frames
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $R/bench.py --config $CFG --steps 60 --warmup 20 --repeats 3 --no-cpu-baseline --no-trained-leg --exchange-steps 0 > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $R/bench.py --config $CFG --steps 60 --warmup 20 --repeats 3 --no-cpu-baseline --no-trained-leg --no-fp32-leg --exchange-steps 0 > $OUT/stats.log 2>&1
 # counter passes: one window of 20 frames behind the same pre-roll (every frame launch of the run is averaged: pre-roll + warm-up + window)
-BARGS="--config $CFG --steps 20 --warmup 10 --repeats 1 --no-cpu-baseline --no-trained-leg --exchange-steps 0"
+BARGS="--config $CFG --steps 20 --warmup 10 --repeats 1 --no-cpu-baseline --no-trained-leg --no-fp32-leg --exchange-steps 0"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- python $R/bench.py $BARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -- python $R/bench.py $BARGS > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/pmc_sq -o pmc -- python $R/bench.py $BARGS > $OUT/pmc_sq.log 2>&1

@@ -35,7 +35,7 @@ for stage in "$@"; do
     model_ab)
       for margs in "" "warm_start=0" "contact_breaking=0" "warm_start=0,contact_breaking=0"; do for cfg in 1 2; do
         echo -n "config $cfg model-args [$margs]: " >> $O/model_ab.txt
-        python bench.py --config $cfg --no-cpu-baseline --no-trained-leg --exchange-steps 0 --no-rccl-leg ${margs:+--model-args $margs} 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['timed_window']['resets_per_frame'])" >> $O/model_ab.txt
+        python bench.py --config $cfg --no-cpu-baseline --no-trained-leg --no-fp32-leg --exchange-steps 0 --no-rccl-leg ${margs:+--model-args $margs} 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['timed_window']['resets_per_frame'])" >> $O/model_ab.txt
       done; done; cat $O/model_ab.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
