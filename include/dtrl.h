@@ -49,7 +49,10 @@ typedef enum {
  * i.e. cScenarioTrain::BuildScenePool (scenarios/ScenarioTrain.cpp:197-222).
  * Relative paths inside the arg file resolve against the value of "-data_root=" if given, else the current directory
  * (the reference is run from its repo root). Extra keys understood: -data_root=, -terrain_seed= (env i uses seed+i),
- * -rand_seed= (exploration streams), -global_env_offset= (first global env id of this shard).
+ * -rand_seed= (exploration streams), -global_env_offset= (first global env id of this shard),
+ * -physics_precision= f64 | f32: a CHECK, not a switch -- libdtrl.so computes in fp64 (default; the parity-tested product), libdtrl_f32.so is the same
+ * source built with float arithmetic (opt-in; Bullet's own state is float, premake4.lua:115-124; distribution-level parity only) behind this same ABI
+ * (doubles in, doubles out); each library fails dtrl_create with DTRL_ERR_ARG when asked for the other precision.
  * device_id < 0 selects the current HIP device. */
 dtrl_status dtrl_create(const char* const* argv, int argc, int num_envs, int device_id, dtrl_batch** out);
 

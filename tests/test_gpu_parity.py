@@ -166,6 +166,9 @@ FULL_WIDTH = [  # tag, arg file, envs (the width BASELINE.json states for the co
     ("config2_raptor_narrow_gaps_8192_xavier", "args/raptor_narrow_gaps_args.txt", 8192, "raptor_xavier", 5000),
     ("config1_dog_slopes_mixed_4096_trained", "args/dog_slopes_mixed_args.txt", 4096, "dog_trained", 1000),
     ("config2_raptor_narrow_gaps_8192_trained", "args/raptor_narrow_gaps_args.txt", 8192, "raptor_trained", 5000),
+    # configs[4]'s scene at its per-GPU width (65 536 goats over 8 GPUs): goat + cliffs_rugged, one substep of 1/600 s per env-step
+    ("config4_goat_cliffs_8192_xavier", "args/goat_cliffs_args.txt", 8192, "goat_xavier", 9000),
+    ("config4_goat_cliffs_8192_trained", "args/goat_cliffs_args.txt", 8192, "goat_trained", 9000),
 ]
 
 
@@ -179,7 +182,8 @@ def test_config_full_width_1200_substeps(da, om, run):
     from conftest import trained_policy
     tag, arg, n, which, seed = run
     pol = {"dog_xavier": lambda: dog_policy(om), "raptor_xavier": lambda: T.raptor_policy(om),
-           "dog_trained": lambda: trained_policy(om, "dog"), "raptor_trained": lambda: trained_policy(om, "raptor")}[which]()
+           "dog_trained": lambda: trained_policy(om, "dog"), "raptor_trained": lambda: trained_policy(om, "raptor"),
+           "goat_xavier": lambda: dog_policy(om), "goat_trained": lambda: trained_policy(om, "goat")}[which]()
     r = T.run_full_width_parity(da, om, arg, n, pol, seed, free_frames=12, forced_frames=36, label=tag)
     from conftest import REPO
     out = os.path.join(REPO, "gpurun_out", "full_width_parity")

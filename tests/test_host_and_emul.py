@@ -1247,7 +1247,7 @@ def run_full_width_parity(da, om, arg, n, pol, seed, free_frames=12, forced_fram
         q, qd = b.PoseVel()
         free[f] = np.maximum(np.abs(q - tr["q"][f]).max(1), np.abs(qd - tr["qd"][f]).max(1))
     lines = ["%s: %s, %d envs, terrain seeds %d.., oracle %d threads %.1f s" % (label or arg, arg, n, seed, threads, tr["seconds"])]
-    lines.append("  A free-running %d frames (= %d substeps): worst frame of each env: %s" % (free_frames, free_frames * 100, _dist(free.max(0))))
+    lines.append("  A free-running %d frames (= %d substeps): worst frame of each env: %s" % (free_frames, free_frames * 20 * int(m.num_sim_substeps), _dist(free.max(0))))
     lines.append("    per frame max: " + " ".join("%.1e" % x for x in free.max(1)))
     lines.append("    envs > 1e-6: %d, > 1e-4: %d of %d" % ((free.max(0) > 1e-6).sum(), (free.max(0) > 1e-4).sum(), n))
     tn = om.batch_trace(m, n, threads, free_frames, terrain_seed0=seed, policy=pol, nudge=1e-13)
@@ -1296,11 +1296,12 @@ def check_full_width(r, min_tracked=0.97, min_within6=0.99):
 
 
 @pytest.mark.parametrize("arg,which,seed", [("args/dog_slopes_mixed_args.txt", "dog_xavier", 1000), ("args/raptor_narrow_gaps_args.txt", "raptor_xavier", 5000),
-                                            ("args/dog_slopes_mixed_args.txt", "dog_trained", 1000), ("args/raptor_narrow_gaps_args.txt", "raptor_trained", 5000)])
+                                            ("args/dog_slopes_mixed_args.txt", "dog_trained", 1000), ("args/raptor_narrow_gaps_args.txt", "raptor_trained", 5000),
+                                            ("args/goat_cliffs_args.txt", "goat_xavier", 9000)])
 def test_batch_parity_env_by_env_reduced_width(da, om, arg, which, seed):
     """The full-width GPU tests (tests/test_gpu_parity.py::test_config*_full_width_*) at a width the CPU suite affords, on the lane-loop build."""
     from conftest import trained_policy
     pol = {"dog_xavier": lambda: dog_policy(om), "raptor_xavier": lambda: raptor_policy(om),
-           "dog_trained": lambda: trained_policy(om, "dog"), "raptor_trained": lambda: trained_policy(om, "raptor")}[which]()
+           "dog_trained": lambda: trained_policy(om, "dog"), "raptor_trained": lambda: trained_policy(om, "raptor"), "goat_xavier": lambda: dog_policy(om)}[which]()
     r = run_full_width_parity(da, om, arg, 96, pol, seed, forced_frames=18, label=which)
     check_full_width(r, min_tracked=0.85, min_within6=0.9)
