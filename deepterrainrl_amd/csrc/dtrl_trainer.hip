@@ -131,6 +131,24 @@ __global__ void __launch_bounds__(256) tr_terr_reduce_kernel(const NetDims* __re
 	if (o < n_out && lane16 == 0) { s += wk.w[d.bo_terr + o % d.fc_terr]; wk.t3[o] = s > 0 ? s : 0.0f; }
 }
 
+// one workgroup: an optional pre-pass (the critic step's targets: new_q of the batch and the candidates' test), then the labels / loss gradient of every output
+// element and the loss = scale x sum of the squared errors -- three dependent launches of 5-7 us each (targets, labels, sum) as one (round 6). The sum runs in a fixed
+// order (thread-strided partial sums, then a tree): deterministic.
+template <class FP, class FL>
+__global__ void __launch_bounds__(1024) tr_pre_label_loss_kernel(int n_pre, FP fp, int n_lab, FL fl, const float* sq, float scale, float* out)   // (no __restrict__: fl writes sq[i] through its own copy of the pointer)
+{
+	__shared__ float part[1024];
+	const int t = static_cast<int>(threadIdx.x);
+	for (int i = t; i < n_pre; i += 1024) fp(i);
+	if (n_pre > 0) __syncthreads();           // the labels read new_q: block-wide visibility of the pre-pass's global writes
+	float s = 0.0f;
+	for (int i = t; i < n_lab; i += 1024) { fl(i); s += sq[i]; }
+	part[t] = s;
+	__syncthreads();
+	for (int d = 512; d > 0; d >>= 1) { if (t < d) part[t] += part[t + d]; __syncthreads(); }
+	if (t == 0) *out = scale * part[0];
+}
+
 template <class F>
 __global__ void tr_foreach_kernel(int64_t n, F f)
 {
@@ -256,6 +274,11 @@ struct HipTrainerBE {
 		// (the loss reduction on the second stream beside the backward pass: measured slower, 2190-2280 vs 2330/s -- the fork / join events cost more than its 6 us)
 		for_each(n, f); loss_sum(sq, n, scale, out);
 	}
+	template <class FP, class FL> void pre_label_loss(int n_pre, const FP& fp, int n_lab, const FL& fl, const float* sq, float scale, float* out)
+	{
+		hipLaunchKernelGGL((tr_pre_label_loss_kernel<FP, FL>), dim3(1), dim3(1024), 0, stream, n_pre, fp, n_lab, fl, sq, scale, out);
+		chk(hipGetLastError(), "pre/label/loss launch");
+	}
 	// *out = scale * sum(x[0 .. n)): one workgroup, tree reduction in LDS
 	void loss_sum(const float* x, int n, float scale, float* out)
 	{
@@ -273,11 +296,29 @@ struct HipTrainerBE {
 		const char* e = std::getenv("DTRL_TRAINER_FUSED");
 		const int mode = e ? std::atoi(e) : 1;
 		if (mode == 0) plan_.ok = false;
-		fused_bwd_ = mode >= 2;
+		fused_bwd_ = mode == 2;
+		split_fwd_ = mode == 3;
+	}
+	bool split_fwd_ = false;
+	// DTRL_TRAINER_FUSED=3 (round 6): the forward pass as conv stack (one workgroup per sample) -> terr_ip0 as ONE split-K GEMM over all rows -> FC chain (per sample)
+	bool fused_forward_part(const NetDims* d, const Work* wk, int rows, bool store, int part)
+	{
+		if (!plan_.ok || !split_fwd_ || rows <= 0) return false;
+		if (part == 1) {
+			static const int dbg = []() { const char* e = std::getenv("DTRL_TRAINER_DBG"); return e ? std::atoi(e) : 0; }();   // timing experiments only (results are garbage)
+			const int sb = plan_.size_b | (dbg << 24);
+			if (store) hipLaunchKernelGGL((tr_fused_forward_kernel<true, 1>), dim3(rows), dim3(kFT), plan_.lds_bytes, stream, d, wk, plan_.size_a, sb);
+			else hipLaunchKernelGGL((tr_fused_forward_kernel<false, 1>), dim3(rows), dim3(kFT), plan_.lds_bytes, stream, d, wk, plan_.size_a, sb);
+		} else {
+			if (store) hipLaunchKernelGGL((tr_fused_forward_kernel<true, 3>), dim3(rows), dim3(kFT), plan_.lds_bytes, stream, d, wk, plan_.size_a, plan_.size_b);
+			else hipLaunchKernelGGL((tr_fused_forward_kernel<false, 3>), dim3(rows), dim3(kFT), plan_.lds_bytes, stream, d, wk, plan_.size_a, plan_.size_b);
+		}
+		chk(hipGetLastError(), "fused forward part launch");
+		return true;
 	}
 	bool fused_forward(const NetDims* d, const Work* wk, int rows, bool store)
 	{
-		if (!plan_.ok || rows <= 0) return false;
+		if (!plan_.ok || split_fwd_ || rows <= 0) return false;
 		if (store) hipLaunchKernelGGL(tr_fused_forward_kernel<true>, dim3(rows), dim3(kFT), plan_.lds_bytes, stream, d, wk, plan_.size_a, plan_.size_b);
 		else hipLaunchKernelGGL(tr_fused_forward_kernel<false>, dim3(rows), dim3(kFT), plan_.lds_bytes, stream, d, wk, plan_.size_a, plan_.size_b);
 		chk(hipGetLastError(), "fused forward launch");

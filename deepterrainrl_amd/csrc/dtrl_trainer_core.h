@@ -216,6 +216,11 @@ public:
 	{
 		const NetDims& d = cfg.dims;
 		if (be.fused_forward(d_dims, wk, rows, wk == d_train)) return;     // one launch, one workgroup per sample (dtrl_trainer_fused.h); the check build takes the layer-by-layer form below
+		if (be.fused_forward_part(d_dims, wk, rows, wk == d_train, 1)) {   // DTRL_TRAINER_FUSED=3: conv stack per sample -> terr_ip0 as one split-K GEMM over all rows -> FC chain per sample
+			be.gemm(d_dims, wk, make_gemm(d, rows, kTerrFwd));
+			be.fused_forward_part(d_dims, wk, rows, wk == d_train, 3);
+			return;
+		}
 		for (int l = 0; l < 3; ++l) be.gemm(d_dims, wk, make_gemm(d, rows, kConvFwd, l));
 		be.gemm(d_dims, wk, make_gemm(d, rows, kTerrFwd));
 		be.terr_reduce(d_dims, wk, rows * d.fc_terr, FTerrReduce{d_dims, wk});
@@ -314,12 +319,12 @@ public:
 			be.fork();
 			be.for_each(static_cast<int64_t>(3 * n) * S, FGatherMulti{S, norm(), mem_, W_, n, {idx_host, cand, cand, nullptr}, {1 + S + A, 1, 1 + S + A, 0}, eval.xin});
 			Forward(d_eval_tgt, 3 * n);
-			be.for_each(2 * n, FFusedTargets{norm(), mem_, W_, idx_host, cand, flags_, eval.out, d.out_size, cfg.n_frags, n, cfg.discount, newq, better_host});
 			be.resume();
 			be.for_each(static_cast<int64_t>(n) * S, FGatherNorm{S, norm(), mem_, W_, idx_host, 1, train.xin});
 			Forward(d_train, n);
-			be.join();                     // the labels need new_q
-			be.label_loss(n * d.out_size, FLabelDout{d.out_size, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host);
+			be.join();                     // the targets need the target net's outputs, the labels the targets: ONE launch for targets, labels and loss (round 6)
+			be.pre_label_loss(2 * n, FFusedTargets{norm(), mem_, W_, idx_host, cand, flags_, eval.out, d.out_size, cfg.n_frags, n, cfg.discount, newq, better_host},
+				n * d.out_size, FLabelDout{d.out_size, norm(), 1, nullptr, mem_, W_, S, idx_host, newq, cfg.n_frags, cfg.frag_size, n, train.out, train.dout, sq}, sq, 0.5f / static_cast<float>(n), loss_host);
 			BackwardAndUpdate();
 		});
 		return be.ok();

@@ -87,23 +87,128 @@ __device__ __forceinline__ float row_dot(const float* __restrict__ W, const floa
 	return group_sum(s, kLanes);
 }
 
+// A fully connected layer of one sample with kRows weight rows per lane group IN FLIGHT: group g (kLanes consecutive lanes) owns output rows g, g + G, g + 2 G, ... (G groups
+// per workgroup) and handles kRows of them per trip -- all their weight loads are issued before the first FMA, so a layer pays the L2 latency once per kRows rows instead of
+// once per row (round 6: the FC chain was 24 us of the 70 us forward, ~13 dependent trips of one row each). Per output the summation order is row_dot()'s: bit-identical.
+template <int kLanes, int kPer, int kRows, class RowPtr, class Store>
+__device__ __forceinline__ void fc_rows(int n_rows, int K, const float* __restrict__ x, RowPtr row_ptr, Store store)
+{
+	const int tid = static_cast<int>(threadIdx.x), g = tid / kLanes, r = tid % kLanes;
+	constexpr int G = kFT / kLanes;
+	float xv[kPer];
+#pragma unroll
+	for (int q = 0; q < kPer; ++q) { const int k = r + kLanes * q; xv[q] = x[k < K ? k : 0]; }
+	for (int n0 = g; n0 < n_rows; n0 += G * kRows) {
+		float w[kRows][kPer];
+#pragma unroll
+		for (int t = 0; t < kRows; ++t) {
+			const int n = n0 + t * G;
+			const float* __restrict__ Wr = row_ptr(n < n_rows ? n : n0);
+#pragma unroll
+			for (int q = 0; q < kPer; ++q) { const int k = r + kLanes * q; w[t][q] = k < K ? Wr[k] : 0.0f; }
+		}
+#pragma unroll
+		for (int t = 0; t < kRows; ++t) {
+			const int n = n0 + t * G;
+			float acc = 0.0f;
+#pragma unroll
+			for (int q = 0; q < kPer; ++q) acc = fmaf(w[t][q], xv[q], acc);
+			acc = group_sum(acc, kLanes);
+			if (r == 0 && n < n_rows) store(n, acc);
+		}
+	}
+}
+
 // one conv layer of one sample: in [Cin][Tin] (LDS or the input row), out [Cout][Tout] (LDS) = relu(W * in + b); optionally mirrored to global for the backward pass.
 // A wavefront owns Cout / 16 output channels (wave-uniform -> their weights arrive as SCALAR loads through the constant cache and feed the FMAs as SGPR operands;
 // a per-lane weight address would put one vector load with an L1 / L2 round trip into every step of the dependent chain), its lanes own the positions lane + 64 j;
 // an LDS read of the input serves every channel of the wave
 constexpr int kFMaxCh = 2, kFMaxJ = 4;
-__device__ __forceinline__ void fused_conv(const NetDims& d, const Work& wk, int l, const float* __restrict__ in, float* __restrict__ out, float* __restrict__ gout)
+// Round 6: the kernel width is a template parameter. The round-4 form walked (input channel, tap) in a doubly nested run-time loop with ONE scalar weight load and four LDS
+// reads in front of every eight FMAs -- each trip paid the scalar-load and LDS latencies in sequence (rocprofv3: 40 us of the 70 us forward were the conv stack, 80+ cycles
+// per multiply-add and thread). Now all taps of an input channel are in flight together: 2 KW scalar weights (they arrive as s_load_dwordx4 / x8) and 4 KW LDS values per
+// lane, then 8 KW FMAs; the channel loop is unrolled by two so that the next channel's loads overlap the current one's FMAs.
+template <int KW, int J>
+__device__ __forceinline__ void fused_conv_t(const NetDims& d, const Work& wk, int l, const float* __restrict__ in, float* __restrict__ out, float* __restrict__ gout)
 {
 	const int tid = static_cast<int>(threadIdx.x), lane = tid & 63;
-	const int Cin = d.C[l], Cout = d.C[l + 1], Kw = d.Kw[l], Tin = d.T[l], Tout = d.T[l + 1];
+	const int Cin = d.C[l], Cout = d.C[l + 1], Tin = d.T[l], Tout = d.T[l + 1];
 	const int cpw = Cout / (kFT / 64);                                        // channels per wave (1 or 2)
+	const int co0 = __builtin_amdgcn_readfirstlane((tid >> 6) * cpw);
+	const int K = Cin * KW;
+	const float* __restrict__ W = wk.w + d.wo_conv[l] + static_cast<int64_t>(co0) * K;
+	float acc[kFMaxCh][J];
+	int tt[J];
+#pragma unroll
+	for (int j = 0; j < J; ++j) { const int t = lane + 64 * j; tt[j] = t < Tout ? t : Tout - 1; acc[0][j] = 0.0f; acc[1][j] = 0.0f; }   // clamped: a surplus slot recomputes the last position and is not stored
+	const bool two = cpw > 1;
+	const float* __restrict__ W1 = two ? W + K : W;
+	// software pipeline over the input channels: channel ci + 1's weights (scalar loads) and inputs (LDS) are requested before channel ci's FMAs are issued
+	float w0[KW], w1[KW], a[J][KW], nw0[KW], nw1[KW], na[J][KW];
+	// The weights are wave-uniform, but they are fetched with VECTOR loads on purpose (an opaque zero in a VGPR hides the uniformity): scalar loads and LDS reads share
+	// one completion counter (lgkmcnt) and return out of order with respect to each other, so a wave that has both in flight can only wait for ALL of them -- the prefetch
+	// of channel ci + 1 would be waited for in front of channel ci's FMAs. Vector loads count on vmcnt: the two streams pipeline independently. All lanes read the same
+	// 16 bytes (one cache line, a broadcast).
+	int vzero;
+	asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+	static_assert(KW % 4 == 0, "float4 weight loads");
+	auto fetch = [&](int ci, float (&x0)[KW], float (&x1)[KW], float (&xa)[J][KW]) {
+		const float* __restrict__ row = in + ci * Tin;
+		const float4* __restrict__ p0 = reinterpret_cast<const float4*>(W + ci * KW) + vzero;
+		const float4* __restrict__ p1 = reinterpret_cast<const float4*>(W1 + ci * KW) + vzero;
+#pragma unroll
+		for (int q = 0; q < KW / 4; ++q) {
+			const float4 v0 = p0[q], v1 = p1[q];
+			x0[4 * q] = v0.x; x0[4 * q + 1] = v0.y; x0[4 * q + 2] = v0.z; x0[4 * q + 3] = v0.w;
+			x1[4 * q] = v1.x; x1[4 * q + 1] = v1.y; x1[4 * q + 2] = v1.z; x1[4 * q + 3] = v1.w;
+		}
+#pragma unroll
+		for (int j = 0; j < J; ++j)
+#pragma unroll
+			for (int u = 0; u < KW; ++u) xa[j][u] = row[tt[j] + u];
+	};
+	fetch(0, w0, w1, a);
+	for (int ci = 0; ci < Cin; ++ci) {
+		fetch(ci + 1 < Cin ? ci + 1 : ci, nw0, nw1, na);   // (the last trip re-reads itself: no branch around the loads)
+#pragma unroll
+		for (int u = 0; u < KW; ++u)
+#pragma unroll
+			for (int j = 0; j < J; ++j) { acc[0][j] = fmaf(w0[u], a[j][u], acc[0][j]); acc[1][j] = fmaf(w1[u], a[j][u], acc[1][j]); }
+#pragma unroll
+		for (int u = 0; u < KW; ++u) { w0[u] = nw0[u]; w1[u] = nw1[u]; }
+#pragma unroll
+		for (int j = 0; j < J; ++j)
+#pragma unroll
+			for (int u = 0; u < KW; ++u) a[j][u] = na[j][u];
+	}
+	for (int c = 0; c < cpw; ++c) {
+		const int co = co0 + c;
+		const float b = wk.w[d.bo_conv[l] + co];
+#pragma unroll
+		for (int j = 0; j < J; ++j) {
+			const int t = lane + 64 * j;
+			if (t < Tout) { float v = (c == 0 ? acc[0][j] : acc[1][j]) + b; v = v > 0 ? v : 0.0f; out[co * Tout + t] = v; if (gout) gout[co * Tout + t] = v; }
+		}
+	}
+}
+__device__ __forceinline__ void fused_conv(const NetDims& d, const Work& wk, int l, const float* __restrict__ in, float* __restrict__ out, float* __restrict__ gout)
+{
+	const int Kw = d.Kw[l];   // wave-uniform: 8 / 4 / 4 in every shipped net; other widths take the general loop
+	const int slots = (d.T[l + 1] + 63) / 64;   // position slots a lane owns: 3 for conv1 / conv2 of the shipped nets (190 / 187 outputs), 4 for conv0 (193)
+	if (Kw == 4 && slots <= 3) { fused_conv_t<4, 3>(d, wk, l, in, out, gout); return; }
+	if (Kw == 4) { fused_conv_t<4, 4>(d, wk, l, in, out, gout); return; }
+	if (Kw == 8 && slots <= 3) { fused_conv_t<8, 3>(d, wk, l, in, out, gout); return; }
+	if (Kw == 8) { fused_conv_t<8, 4>(d, wk, l, in, out, gout); return; }
+	const int tid = static_cast<int>(threadIdx.x), lane = tid & 63;
+	const int Cin = d.C[l], Cout = d.C[l + 1], Tin = d.T[l], Tout = d.T[l + 1];
+	const int cpw = Cout / (kFT / 64);
 	const int co0 = __builtin_amdgcn_readfirstlane((tid >> 6) * cpw);
 	const int K = Cin * Kw;
 	const float* __restrict__ W = wk.w + d.wo_conv[l] + static_cast<int64_t>(co0) * K;
 	float acc[kFMaxCh][kFMaxJ];
 	int tt[kFMaxJ];
 #pragma unroll
-	for (int j = 0; j < kFMaxJ; ++j) { const int t = lane + 64 * j; tt[j] = t < Tout ? t : Tout - 1; acc[0][j] = 0.0f; acc[1][j] = 0.0f; }   // clamped: a surplus slot recomputes the last position and is not stored
+	for (int j = 0; j < kFMaxJ; ++j) { const int t = lane + 64 * j; tt[j] = t < Tout ? t : Tout - 1; acc[0][j] = 0.0f; acc[1][j] = 0.0f; }
 	const bool two = cpw > 1;
 	for (int ci = 0; ci < Cin; ++ci) {
 		const float* __restrict__ row = in + ci * Tin;
@@ -125,23 +230,43 @@ __device__ __forceinline__ void fused_conv(const NetDims& d, const Work& wk, int
 	}
 }
 
-// kStore: the train pass (activations kept for the backward pass); else only `out`
-template <bool kStore>
-__global__ void __launch_bounds__(kFT) tr_fused_forward_kernel(const NetDims* __restrict__ dp, const Work* __restrict__ wp, int size_a, int size_b)
+// kStore: the train pass (activations kept for the backward pass); else only `out`.
+// kPart (round 6): 0 = the whole net in one launch (rounds 4-5); 1 = the conv stack alone -- conv2's output always goes to global memory, where 2 = the split-K GEMM of
+// terr_ip0 over ALL rows of the pass (tr_gemm_kernel<kTerrFwd>: the 1.5 MB matrix is read once per 32-row tile instead of once per SAMPLE through one compute unit) finds
+// it; 3 = the FC chain: t3 = relu(sum of the GEMM's partials + bias), concat, trunk, heads. DTRL_TRAINER_FUSED=3 selects 1 + GEMM + 3.
+template <bool kStore, int kPart = 0>
+__global__ void __launch_bounds__(kFT) tr_fused_forward_kernel(const NetDims* __restrict__ dp, const Work* __restrict__ wp, int size_a, int size_b_dbg)
 {
 	extern __shared__ float sm[];
 	const NetDims& d = *dp; const Work& wk = *wp;
+	const int size_b = size_b_dbg & 0xffffff, dbg = size_b_dbg >> 24;   // dbg (timing experiments only, DTRL_TRAINER_DBG): 1..3 = leave after conv layer dbg - 1; 4 = after loading x
 	const int z = static_cast<int>(blockIdx.x), tid = static_cast<int>(threadIdx.x);
 	const int nhz = d.n_heads * d.fc_head, kc = d.fc_terr + d.n_char;
 	float* x = sm; float* bufA = x + pad4(d.S); float* bufB = bufA + size_a; float* v = bufB + size_b; float* h = v + pad4(kc); float* hz = h + pad4(d.fc_trunk);
 	for (int i = tid; i < d.S; i += kFT) x[i] = wk.xin[static_cast<size_t>(z) * d.S + i];
 	__syncthreads();
+	if (dbg == 4) return;
+	if (kPart != 3) {
 	fused_conv(d, wk, 0, x, bufA, kStore ? wk.act[0] + static_cast<size_t>(z) * d.C[1] * d.T[1] : nullptr);
 	__syncthreads();
+	if (dbg == 1) return;
 	fused_conv(d, wk, 1, bufA, bufB, kStore ? wk.act[1] + static_cast<size_t>(z) * d.C[2] * d.T[2] : nullptr);
 	__syncthreads();
-	fused_conv(d, wk, 2, bufB, bufA, kStore ? wk.act[2] + static_cast<size_t>(z) * d.n_flat : nullptr);
+	if (dbg == 2) return;
+	fused_conv(d, wk, 2, bufB, bufA, (kStore || kPart == 1) ? wk.act[2] + static_cast<size_t>(z) * d.n_flat : nullptr);
+	if (kPart == 1) return;
 	__syncthreads();
+	}
+	if (kPart == 3) {   // t3 from the split-K partials [row][fc_terr][n_slabs]: 16 lanes per output read its contiguous run of partials
+		const int per = kFT / 16;
+		for (int n = tid >> 4; n < d.fc_terr; n += per) {
+			const float* __restrict__ pp = wk.tp + (static_cast<size_t>(z) * d.fc_terr + n) * d.n_slabs;
+			float s = 0.0f;
+			for (int q = tid & 15; q < d.n_slabs; q += 16) s += pp[q];
+			s = group_sum(s, 16);
+			if ((tid & 15) == 0) { float t = s + wk.w[d.bo_terr + n]; t = t > 0 ? t : 0.0f; v[n] = t; if (kStore) wk.t3[static_cast<size_t>(z) * d.fc_terr + n] = t; }
+		}
+	} else
 	{   // terr_ip0: fc_terr outputs x n_flat inputs; kFT / fc_terr lanes per output walk the weight row in float4 steps (coalesced), the flattened conv2 output sits in LDS
 		const int tpo = kFT / d.fc_terr, n = tid / tpo, p = tid - n * tpo;
 		const float4* __restrict__ W4 = reinterpret_cast<const float4*>(wk.w + d.wo_terr + static_cast<int64_t>(n) * d.n_flat);
@@ -162,16 +287,15 @@ __global__ void __launch_bounds__(kFT) tr_fused_forward_kernel(const NetDims* __
 	for (int j = tid; j < d.n_char; j += kFT) v[d.fc_terr + j] = x[d.n_terr + j];
 	__syncthreads();
 	// trunk, head0, head1: 16 (8) lanes per output row, 64 (128) rows per pass
-	for (int n = tid >> 4; n < d.fc_trunk; n += kFT / 16) {      // K = fc_terr + n_char <= 16 x 12
-		const float s = row_dot<16, 12>(wk.w + d.wo_ip0 + static_cast<int64_t>(n) * kc, v, kc, tid & 15);
-		if ((tid & 15) == 0) { float t = s + wk.w[d.bo_ip0 + n]; t = t > 0 ? t : 0.0f; h[n] = t; if (kStore) wk.h[static_cast<size_t>(z) * d.fc_trunk + n] = t; }
-	}
+	// trunk (K = fc_terr + n_char <= 16 x 12) and head0 (K = fc_trunk <= 16 x 16): 16 lanes per output row, four rows of a lane group in flight (fc_rows)
+	fc_rows<16, 12, 4>(d.fc_trunk, kc, v,
+		[&](int n) { return wk.w + d.wo_ip0 + static_cast<int64_t>(n) * kc; },
+		[&](int n, float s) { float t = s + wk.w[d.bo_ip0 + n]; t = t > 0 ? t : 0.0f; h[n] = t; if (kStore) wk.h[static_cast<size_t>(z) * d.fc_trunk + n] = t; });
 	__syncthreads();
-	for (int o = tid >> 4; o < nhz; o += kFT / 16) {             // K = fc_trunk <= 16 x 16
-		const int f = o / d.fc_head, n = o - f * d.fc_head;
-		const float s = row_dot<16, 16>(wk.w + d.wo_h0[f] + static_cast<int64_t>(n) * d.fc_trunk, h, d.fc_trunk, tid & 15);
-		if ((tid & 15) == 0) { float t = s + wk.w[d.bo_h0[f] + n]; t = t > 0 ? t : 0.0f; hz[o] = t; if (kStore) wk.hz[(static_cast<size_t>(f) * wk.max_rows + z) * d.fc_head + n] = t; }
-	}
+	fc_rows<16, 16, 4>(nhz, d.fc_trunk, h,
+		[&](int o) { const int f = o / d.fc_head, n = o - f * d.fc_head; return wk.w + d.wo_h0[f] + static_cast<int64_t>(n) * d.fc_trunk; },
+		[&](int o, float s) { const int f = o / d.fc_head, n = o - f * d.fc_head; float t = s + wk.w[d.bo_h0[f] + n]; t = t > 0 ? t : 0.0f; hz[o] = t;
+		                       if (kStore) wk.hz[(static_cast<size_t>(f) * wk.max_rows + z) * d.fc_head + n] = t; });
 	__syncthreads();
 	{   // head1: out_size outputs x fc_head (<= 8 x 16), 8 lanes each
 		const int o = tid >> 3, p = tid & 7;

@@ -145,7 +145,7 @@ TR_HD inline float load_a(const NetDims& d, const Work& wk, const GemmDesc& g, i
 	case kHead1Bx: return k < d.head_out[z] ? wk.dout[static_cast<size_t>(m) * d.out_size + d.out_off[z] + k] : 0.0f;
 	case kHead0Bw: return wk.dhz[(static_cast<size_t>(z) * wk.max_rows + k) * d.fc_head + m];
 	case kHead0Bx: return wk.dhz[(static_cast<size_t>(z) * wk.max_rows + m) * d.fc_head + k];
-	case kIp0Bw: return wk.dhs[static_cast<size_t>(k) * d.fc_trunk + m];
+	case kIp0Bw: return wk.dhs[static_cast<size_t>(k) * d.fc_trunk + m];   // (round 6 tried dh_at() here to drop the 5 us dh_sum launch: five loads per operand element made the pair of products 40 us slower)
 	case kIp0Bx: return wk.dhs[static_cast<size_t>(m) * d.fc_trunk + k];
 	case kTerrBw: return wk.dt3[static_cast<size_t>(k) * d.fc_terr + m];
 	case kTerrBx: return wk.dt3[static_cast<size_t>(m) * d.fc_terr + k];

@@ -18,6 +18,7 @@ struct EmulTrainerBE {
 	// (the per-sample fused passes are device code: the check build always runs the layer-by-layer form, which is what the fused kernels are tested against)
 	void setup_fused(const NetDims&) {}
 	bool fused_forward(const NetDims*, const Work*, int, bool) { return false; }
+	bool fused_forward_part(const NetDims*, const Work*, int, bool, int) { return false; }
 	template <class A> bool fused_backward(const NetDims*, const Work*, const NetDims&, int, const A&) { return false; }
 	void fork() {}
 	void resume() {}
@@ -34,6 +35,7 @@ struct EmulTrainerBE {
 	template <class Fn> void run_graph(int, Fn fn) { fn(); }
 	template <class F> void terr_reduce(const NetDims*, const Work*, int n, const F& f) { for_each(n, f); }
 	template <class F> void label_loss(int n, const F& f, const float* sq, float scale, float* out) { for_each(n, f); loss_sum(sq, n, scale, out); }
+	template <class FP, class FL> void pre_label_loss(int n_pre, const FP& fp, int n_lab, const FL& fl, const float* sq, float scale, float* out) { for_each(n_pre, fp); for_each(n_lab, fl); loss_sum(sq, n_lab, scale, out); }
 	void loss_sum(const float* x, int n, float scale, float* out) { float s = 0; for (int i = 0; i < n; ++i) s += x[i]; *out = scale * s; }
 	// (the operand switch is folded per instantiation, as in the HIP kernel: the check build is what the CPU suite spends its trainer time in)
 	template <int OP> static void gemm_t(const NetDims& d, const Work& wk, GemmDesc g)
