@@ -56,13 +56,13 @@ def test_fp32_short_horizon_vs_oracle(da, om):
 
 @pytest.mark.parametrize("arg,which", [("args/dog_slopes_mixed_args.txt", "dog_trained"), ("args/raptor_narrow_gaps_args.txt", "raptor_xavier"), ("args/goat_cliffs_args.txt", "goat_xavier")])
 def test_fp32_distribution_level_parity_check_builds(da, om, arg, which):
-    """fp32 vs fp64 lane-loop builds, 192 envs x 200 frames from the same seeds and policy: falls, gait cycles, episode distance (the full-size twin runs on the GPU)"""
+    """fp32 vs fp64 lane-loop builds, 160 envs x 160 frames from the same seeds and policy: falls, gait cycles, episode distance (the full-size twin runs on the GPU)"""
     pol = {"dog_trained": lambda: trained_policy(om, "dog"), "raptor_xavier": lambda: T.raptor_policy(om), "goat_xavier": lambda: dog_policy(om)}[which]()
     out = []
     for make in (emul_f32_scenario, EmulScenario):
-        b = make(arg, 192, data_root=REFDATA, extra_args={"terrain_seed": 900})
+        b = make(arg, 160, data_root=REFDATA, extra_args={"terrain_seed": 900})
         b.SetPolicy(pol[1], *pol[2:])
-        out.append(_stats(b, 200)); b.close()
+        out.append(_stats(b, 160)); b.close()
     print(which, "fp32", out[0], "fp64", out[1])
     check_distribution(out[0], out[1], which)
 

@@ -210,16 +210,16 @@ def test_train_loop_end_to_end_on_cpu(da):
     from conftest import EmulScenario
     a = train_loop.parse_arg_file(os.path.join(REFDATA, "args/opt_args_train_mace.txt"))
     assert a["trainer_replay_mem_size"] == "500000" and a["tuple_buffer_size"] == "32" and a["init_exp_temp"] == "20"
-    st = train_loop.train("args/opt_args_train_mace.txt", REFDATA, num_envs=64, max_frames=90, trainer_device="cpu", scenario_cls=EmulScenario,
+    st = train_loop.train("args/opt_args_train_mace.txt", REFDATA, num_envs=64, max_frames=75, trainer_device="cpu", scenario_cls=EmulScenario,
                           extra_args={"terrain_seed": 3, "trainer_num_init_samples": 30, "trainer_replay_mem_size": 512, "trainer_freeze_target_iters": 4, "init_exp_rate": 0.3, "init_exp_base_rate": 0.1, "trainer_init_input_offset_scale": "false"})   # (with the file's 0.9 / 0.9 nearly every early tuple is an actor-exploration tuple and the critic buffer fills slowly, as in the reference)
-    assert st["frames"] == 90 and st["tuples"] >= 40 and st["iters"] >= 1
+    assert st["frames"] == 75 and st["tuples"] >= 30 and st["iters"] >= 1
     assert np.all(np.isfinite(st["weights"])) and st["weights"].size == 570474
     io, isc, oo, osc = st["offset_scale"]
     assert np.allclose(io, 0) and np.all(isc == 1)                     # identity input normaliser here: estimated from 30 tuples a near-constant terrain feature gets a scale of 1e9 and the float32 net overflows on its first batch (cNeuralNet::CalcOffsetScale has no floor either); UpdateOffsetScale is covered by the unit tests above
     # overlapped schedule (dtrl_step_begin / dtrl_step_end): same data path, policy one frame staler
-    st2 = train_loop.train("args/opt_args_train_mace.txt", REFDATA, num_envs=64, max_frames=90, trainer_device="cpu", scenario_cls=EmulScenario, overlap=True,
+    st2 = train_loop.train("args/opt_args_train_mace.txt", REFDATA, num_envs=64, max_frames=75, trainer_device="cpu", scenario_cls=EmulScenario, overlap=True,
                            extra_args={"terrain_seed": 3, "trainer_num_init_samples": 30, "trainer_replay_mem_size": 512, "trainer_freeze_target_iters": 4, "init_exp_rate": 0.3, "init_exp_base_rate": 0.1, "trainer_init_input_offset_scale": "false"})
-    assert st2["frames"] == 90 and st2["tuples"] >= 40 and st2["iters"] >= 1 and np.all(np.isfinite(st2["weights"]))
+    assert st2["frames"] == 75 and st2["tuples"] >= 30 and st2["iters"] >= 1 and np.all(np.isfinite(st2["weights"]))
 
 
 @pytest.mark.parametrize("arg,nparams", [("args/opt_args_train_goat_mace.txt", 570474), ("args/opt_args_train_raptor_mace.txt", 568039)])
