@@ -89,6 +89,13 @@ struct GemmDesc {
 	int a_kfast, b_kfast;   // which index of the operand is contiguous in memory (tile loads walk it with consecutive lanes)
 };
 
+// k = q Kw + r. The shipped nets' kernel widths are powers of two (8, 4, 4): shift and mask instead of an integer division by a run-time value (~30 instructions on the
+// device) in front of every operand element of the conv layers' GEMMs (round 6)
+TR_HD inline void div_kw(int k, int Kw, int& q, int& r)
+{
+	if ((Kw & (Kw - 1)) == 0) { const int sh = __builtin_ctz(static_cast<unsigned>(Kw)); q = k >> sh; r = k & (Kw - 1); }
+	else { q = k / Kw; r = k - q * Kw; }
+}
 TR_HD inline float conv_in(const NetDims& d, const Work& wk, int l, int z, int ci, int t)
 {
 	return l == 0 ? wk.xin[static_cast<size_t>(z) * d.S + t] : wk.act[l - 1][(static_cast<size_t>(z) * d.C[l] + ci) * d.T[l] + t];
@@ -150,7 +157,7 @@ TR_HD inline float load_a(const NetDims& d, const Work& wk, const GemmDesc& g, i
 	case kTerrBw: return wk.dt3[static_cast<size_t>(k) * d.fc_terr + m];
 	case kTerrBx: return wk.dt3[static_cast<size_t>(m) * d.fc_terr + k];
 	case kConvBw: return wk.dy[l][(static_cast<size_t>(z) * d.C[l + 1] + m) * d.T[l + 1] + k];
-	case kConvBx: { const int co = k / d.Kw[l], u = k % d.Kw[l]; return wk.w[d.wo_conv[l] + (static_cast<int64_t>(co) * d.C[l] + m) * d.Kw[l] + u]; }
+	case kConvBx: { int co, u; div_kw(k, d.Kw[l], co, u); return wk.w[d.wo_conv[l] + (static_cast<int64_t>(co) * d.C[l] + m) * d.Kw[l] + u]; }
 	}
 	return 0.0f;
 }
@@ -159,7 +166,7 @@ TR_HD inline float load_b(const NetDims& d, const Work& wk, const GemmDesc& g, i
 {
 	const int l = g.layer;
 	switch (g.op) {
-	case kConvFwd: return conv_in(d, wk, l, z, k / d.Kw[l], n + k % d.Kw[l]);
+	case kConvFwd: { int ci, u; div_kw(k, d.Kw[l], ci, u); return conv_in(d, wk, l, z, ci, n + u); }
 	case kTerrFwd: return wk.w[d.wo_terr + static_cast<int64_t>(n) * d.n_flat + k];
 	case kIp0Fwd: return wk.w[d.wo_ip0 + static_cast<int64_t>(n) * g.K + k];
 	case kHead0Fwd: return wk.w[d.wo_h0[z] + static_cast<int64_t>(n) * d.fc_trunk + k];
@@ -172,8 +179,8 @@ TR_HD inline float load_b(const NetDims& d, const Work& wk, const GemmDesc& g, i
 	case kIp0Bx: return wk.w[d.wo_ip0 + static_cast<int64_t>(k) * (d.fc_terr + d.n_char) + n];
 	case kTerrBw: return n < d.n_flat ? wk.act[2][static_cast<size_t>(k) * d.n_flat + n] : 1.0f;
 	case kTerrBx: return wk.w[d.wo_terr + static_cast<int64_t>(k) * d.n_flat + n];
-	case kConvBw: return n < g.N - 1 ? conv_in(d, wk, l, z, n / d.Kw[l], k + n % d.Kw[l]) : 1.0f;
-	case kConvBx: { const int co = k / d.Kw[l], u = k % d.Kw[l], t = n - u; return (t >= 0 && t < d.T[l + 1]) ? wk.dy[l][(static_cast<size_t>(z) * d.C[l + 1] + co) * d.T[l + 1] + t] : 0.0f; }
+	case kConvBw: { if (!(n < g.N - 1)) return 1.0f; int ci, u; div_kw(n, d.Kw[l], ci, u); return conv_in(d, wk, l, z, ci, k + u); }
+	case kConvBx: { int co, u; div_kw(k, d.Kw[l], co, u); const int t = n - u; return (t >= 0 && t < d.T[l + 1]) ? wk.dy[l][(static_cast<size_t>(z) * d.C[l + 1] + co) * d.T[l + 1] + t] : 0.0f; }
 	}
 	return 0.0f;
 }
