@@ -1097,6 +1097,23 @@ def test_contact_cache_is_part_of_the_state_and_model_switches(da, om):
     assert np.array_equal(qa[0], qb[0]) and np.abs(qa[1] - qb[1]).max() > 1e-9
     b.Reset([0])
     assert b.ContactCache()[0][0] == 0                                 # cWorld::Reset
+    # env_ids == NULL with n < num_envs means envs 0 .. n - 1 in the setter as in the getter (it used to read num_envs entries from the caller's n-entry
+    # buffers); more rows than envs is refused. Through the raw ABI: the Python mirror always passes either ids or all envs.
+    import ctypes as C
+    P = lambda x: x.ctypes.data_as(C.c_void_p)
+    c1 = np.array([int(cnt[0])], np.int32); i1 = np.ascontiguousarray(ids[:1], np.int32); l1 = np.ascontiguousarray(lam[:1], np.float64)
+    keep1 = a.ContactCache()
+    assert a._lib.dtrl_set_contact_cache(a._h, None, 1, P(c1), P(i1), P(l1)) == 0
+    after = a.ContactCache()
+    assert after[0][0] == cnt[0] and after[0][1] == keep1[0][1] and np.array_equal(after[2][1], keep1[2][1])      # env 1 untouched
+    c3 = np.zeros(3, np.int32); i3 = np.full((3, 24), 65535, np.int32); l3 = np.zeros((3, 24))
+    assert a._lib.dtrl_set_contact_cache(a._h, None, 3, P(c3), P(i3), P(l3)) != 0
+    # dtrl_set_pose_vel drops the persistent contact rows of a teleported character (Bullet's refreshContactPoints); the oracle's setter does the same
+    qq, qqd = a.PoseVel()
+    assert a.ContactCache()[0][0] > 0
+    a.SetPoseVel(qq[:1], qqd[:1], env_ids=[0])
+    assert a.ContactCache()[0][0] == 0
+    e.set_pose_vel(*e.pose_vel()); assert e.warm_cache()[0] == 0
     for bad in (dict(count=[25], ids=np.zeros((1, 24)), lam=np.zeros((1, 24))), dict(count=[-1], ids=np.zeros((1, 24)), lam=np.zeros((1, 24))),
                 dict(count=[2], ids=np.full((1, 24), 70000), lam=np.zeros((1, 24)))):
         with pytest.raises(da.DtrlError):
