@@ -229,6 +229,7 @@ struct HipTrainerBE {
 	void gemm2(const NetDims* d, const Work* wk, const GemmDesc& ga, const GemmDesc& gb)
 	{
 		if (ga.op == kHead1Bw && gb.op == kHead1Bx) launch2<kHead1Bw, kHead1Bx>(d, wk, ga, gb);
+		else if (ga.op == kHead1Bw && gb.op == kHead0Bw) launch2<kHead1Bw, kHead0Bw>(d, wk, ga, gb);
 		else if (ga.op == kHead0Bw && gb.op == kHead0Bx) launch2<kHead0Bw, kHead0Bx>(d, wk, ga, gb);
 		else if (ga.op == kIp0Bw && gb.op == kIp0Bx) launch2<kIp0Bw, kIp0Bx>(d, wk, ga, gb);
 		else if (ga.op == kTerrBw && gb.op == kTerrBx) launch2<kTerrBw, kTerrBx>(d, wk, ga, gb);
@@ -298,6 +299,16 @@ struct HipTrainerBE {
 		if (mode == 0) plan_.ok = false;
 		fused_bwd_ = mode == 2;
 		split_fwd_ = mode == 3;
+		fc_bwd_ = mode == 4;
+	}
+	bool fc_bwd_ = false;
+	// DTRL_TRAINER_FUSED=4 (round 6): fused forward + the FC part of the data-gradient chain per sample in one launch (tr_fused_backward_x_kernel, fc_only)
+	bool fused_backward_fc(const NetDims* d, const Work* wk, int rows)
+	{
+		if (!plan_.ok || !fc_bwd_ || rows <= 0) return false;
+		hipLaunchKernelGGL(tr_fused_backward_x_kernel, dim3(rows), dim3(kFT), plan_.lds_bytes, stream, d, wk, plan_.size_a, plan_.size_b | (1 << 24));
+		chk(hipGetLastError(), "fused FC backward launch");
+		return true;
 	}
 	bool split_fwd_ = false;
 	// DTRL_TRAINER_FUSED=3 (round 6): the forward pass as conv stack (one workgroup per sample) -> terr_ip0 as ONE split-K GEMM over all rows -> FC chain (per sample)

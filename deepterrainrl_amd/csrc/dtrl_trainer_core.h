@@ -249,6 +249,21 @@ public:
 		const NetDims& d = cfg.dims;
 		const Work* wk = d_train;
 		const int rows = cfg.batch;
+		if (be.fused_backward_fc(d_dims, wk, rows)) {
+			// DTRL_TRAINER_FUSED=4: dhz / dhs / dt3 of every sample from ONE launch; the FC layers' weight gradients then depend on nothing downstream and run beside the
+			// terr_ip0 / conv launches (a second branch of the recorded graph), joined in front of the update
+			be.fork();
+			be.gemm2(d_dims, wk, make_gemm(d, rows, kHead1Bw), make_gemm(d, rows, kHead0Bw));
+			be.gemm(d_dims, wk, make_gemm(d, rows, kIp0Bw));
+			be.resume();
+			be.gemm2(d_dims, wk, make_gemm(d, rows, kTerrBw), make_gemm(d, rows, kTerrBx));
+			for (int l = 2; l >= 0; --l) {
+				GemmDesc g = make_gemm(d, rows, kConvBw, l); g.b_kfast = 1;
+				if (l > 0) be.gemm2(d_dims, wk, g, make_gemm(d, rows, kConvBx, l)); else be.gemm(d_dims, wk, g);
+			}
+			be.join();
+			return;
+		}
 		// a layer's weight gradient and data gradient read the same incoming gradient and are independent of each other: one launch per pair
 		be.gemm2(d_dims, wk, make_gemm(d, rows, kHead1Bw), make_gemm(d, rows, kHead1Bx));
 		be.gemm2(d_dims, wk, make_gemm(d, rows, kHead0Bw), make_gemm(d, rows, kHead0Bx));

@@ -309,10 +309,13 @@ __global__ void __launch_bounds__(kFT) tr_fused_forward_kernel(const NetDims* __
 }
 
 // data gradients of one sample, dout -> dy0. Everything the weight-gradient pass reads is written to global: dhz, dhs, dt3, dy[2], dy[1], dy[0]
-__global__ void __launch_bounds__(kFT) tr_fused_backward_x_kernel(const NetDims* __restrict__ dp, const Work* __restrict__ wp, int size_a, int size_b)
+// fc_only (round 6, DTRL_TRAINER_FUSED=4): stop behind dt3 -- the sample's data-gradient chain through heads and trunk (dhz, dhs, dt3: 0.18 M multiply-adds) in ONE launch
+// instead of the four dependent GEMM launches head1 / head0 / dh_sum / trunk; terr_ip0 and the conv layers stay layer-by-layer (whole-part GEMMs)
+__global__ void __launch_bounds__(kFT) tr_fused_backward_x_kernel(const NetDims* __restrict__ dp, const Work* __restrict__ wp, int size_a, int size_b_fc)
 {
 	extern __shared__ float sm[];
 	const NetDims& d = *dp; const Work& wk = *wp;
+	const int size_b = size_b_fc & 0xffffff; const bool fc_only = (size_b_fc >> 24) != 0;
 	const int z = static_cast<int>(blockIdx.x), tid = static_cast<int>(threadIdx.x);
 	const int nhz = d.n_heads * d.fc_head, kc = d.fc_terr + d.n_char;
 	float* dout = sm; float* dhz = dout + pad4(d.out_size); float* part = dhz + pad4(nhz); float* dhs = part + pad4(4 * d.fc_trunk); float* dt3 = dhs + pad4(d.fc_trunk);
@@ -375,6 +378,7 @@ __global__ void __launch_bounds__(kFT) tr_fused_backward_x_kernel(const NetDims*
 			dt3[tid] = t; wk.dt3[static_cast<size_t>(z) * d.fc_terr + tid] = t;
 		}
 	}
+	if (fc_only) return;
 	__syncthreads();
 	{   // terr_ip0^T: dy2[i] = relu'(act2) sum_k Wt[k][i] dt3[k]  (threads along i: coalesced); a thread's outputs i = tid + 1024 j advance together, so that
 		// kFMaxPos x 2 weight loads are in flight instead of one

@@ -19,6 +19,7 @@ struct EmulTrainerBE {
 	void setup_fused(const NetDims&) {}
 	bool fused_forward(const NetDims*, const Work*, int, bool) { return false; }
 	bool fused_forward_part(const NetDims*, const Work*, int, bool, int) { return false; }
+	bool fused_backward_fc(const NetDims*, const Work*, int) { return false; }
 	template <class A> bool fused_backward(const NetDims*, const Work*, const NetDims&, int, const A&) { return false; }
 	void fork() {}
 	void resume() {}
