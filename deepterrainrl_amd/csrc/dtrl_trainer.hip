@@ -306,7 +306,8 @@ struct HipTrainerBE {
 	bool fused_backward_fc(const NetDims* d, const Work* wk, int rows)
 	{
 		if (!plan_.ok || !fc_bwd_ || rows <= 0) return false;
-		hipLaunchKernelGGL(tr_fused_backward_x_kernel, dim3(rows), dim3(kFT), plan_.lds_bytes, stream, d, wk, plan_.size_a, plan_.size_b | (1 << 24));
+		static const int stage = []() { const char* e = std::getenv("DTRL_TRAINER_DBG"); const int v = e ? std::atoi(e) : 0; return (v == 2 || v == 3) ? v : 1; }();   // (2 / 3: timing experiments, results garbage)
+		hipLaunchKernelGGL(tr_fused_backward_x_kernel, dim3(rows), dim3(kFT), plan_.lds_bytes, stream, d, wk, plan_.size_a, plan_.size_b | (stage << 24));
 		chk(hipGetLastError(), "fused FC backward launch");
 		return true;
 	}

@@ -315,37 +315,56 @@ __global__ void __launch_bounds__(kFT) tr_fused_backward_x_kernel(const NetDims*
 {
 	extern __shared__ float sm[];
 	const NetDims& d = *dp; const Work& wk = *wp;
-	const int size_b = size_b_fc & 0xffffff; const bool fc_only = (size_b_fc >> 24) != 0;
+	const int size_b = size_b_fc & 0xffffff; const int fc_stage = size_b_fc >> 24; const bool fc_only = fc_stage != 0;   // (fc_stage 2 / 3: timing experiments, leave after head1^T / head0^T)
 	const int z = static_cast<int>(blockIdx.x), tid = static_cast<int>(threadIdx.x);
 	const int nhz = d.n_heads * d.fc_head, kc = d.fc_terr + d.n_char;
 	float* dout = sm; float* dhz = dout + pad4(d.out_size); float* part = dhz + pad4(nhz); float* dhs = part + pad4(4 * d.fc_trunk); float* dt3 = dhs + pad4(d.fc_trunk);
 	float* part2 = dt3 + pad4(d.fc_terr); float* bufA = part2 + pad4(16 * d.fc_terr); float* bufB = bufA + size_a;
 	for (int i = tid; i < d.out_size; i += kFT) dout[i] = wk.dout[static_cast<size_t>(z) * d.out_size + i];
+	// per-head offsets as LDS tables (round 6): indexed by a per-lane head number they were global loads IN FRONT of every weight load (a load waiting for a load)
+	__shared__ long long s_wo_h1[kMaxHeads];
+	__shared__ int s_head_out[kMaxHeads], s_out_off[kMaxHeads];
+	if (tid < d.n_heads) { s_wo_h1[tid] = d.wo_h1[tid]; s_head_out[tid] = d.head_out[tid]; s_out_off[tid] = d.out_off[tid]; }
 	__syncthreads();
 	if (tid < nhz) {   // head1^T: dhz[f][n] = relu'(hz) sum_j W1_f[j][n] dout[off_f + j]   (threads along n: coalesced weight reads)
 		const int f = tid / d.fc_head, n = tid - f * d.fc_head;
-		const float* __restrict__ W = wk.w + d.wo_h1[f] + n;
-		const int nj = d.head_out[f];                 // <= 32 (plan)
+		const float* __restrict__ W = wk.w + s_wo_h1[f] + n;
+		const int nj = s_head_out[f];                 // <= 32 (plan)
 		float w[32];
 #pragma unroll
 		for (int j = 0; j < 32; ++j) w[j] = j < nj ? W[static_cast<int64_t>(j) * d.fc_head] : 0.0f;
 		float s = 0.0f;
+		const int o0 = s_out_off[f];
 #pragma unroll
-		for (int j = 0; j < 32; ++j) s = fmaf(w[j], dout[d.out_off[f] + (j < nj ? j : 0)], s);
+		for (int j = 0; j < 32; ++j) s = fmaf(w[j], dout[o0 + (j < nj ? j : 0)], s);
 		const size_t gi = (static_cast<size_t>(f) * wk.max_rows + z) * d.fc_head + n;
 		s = wk.hz[gi] > 0 ? s : 0.0f;
 		dhz[tid] = s; wk.dhz[gi] = s;
 	}
+	if (fc_stage == 2) return;
 	__syncthreads();
 	{   // head0^T, summed over the heads: dhs[n] = relu'(h) sum_{f, m} W0_f[m][n] dhz[f][m]; kFT / fc_trunk partial sums per n (threads along n)
+		// Round 6: the weight row of flat index q = f fc_head + m is found with a shift (fc_head is a power of two in every shipped net) and a head-offset table in LDS -- the
+		// round-4 form divided by fc_head and fetched d.wo_h0[f] from global memory per element, i.e. every weight load waited for ANOTHER load (46 us for this kernel's FC
+		// part); and a thread's whole share of the sum (nhz / parts weights, <= 128) is requested in two trips of 64 loads instead of eight trips of 16.
+		__shared__ long long s_wo_h0[kMaxHeads];
+		if (tid < d.n_heads) s_wo_h0[tid] = d.wo_h0[tid];
+		__syncthreads();
 		const int parts = kFT / d.fc_trunk, n = tid % d.fc_trunk, p = tid / d.fc_trunk;
+		const bool pow2 = (d.fc_head & (d.fc_head - 1)) == 0;
+		const int sh = pow2 ? __builtin_ctz(static_cast<unsigned>(d.fc_head)) : 0;
 		float s = 0.0f;
-		for (int q0 = p; q0 < nhz; q0 += 16 * parts) {         // sixteen weight loads in flight
-			float w[16];
+		constexpr int kIn = 64;                                 // weight loads in flight per trip
+		for (int q0 = p; q0 < nhz; q0 += kIn * parts) {
+			float w[kIn];
 #pragma unroll
-			for (int r = 0; r < 16; ++r) { const int q = q0 + r * parts; const int qq = q < nhz ? q : p; const int f = qq / d.fc_head, m = qq - f * d.fc_head; w[r] = q < nhz ? wk.w[d.wo_h0[f] + static_cast<int64_t>(m) * d.fc_trunk + n] : 0.0f; }
+			for (int r = 0; r < kIn; ++r) {
+				const int q = q0 + r * parts; const int qq = q < nhz ? q : p;
+				const int f = pow2 ? (qq >> sh) : (qq / d.fc_head), m = qq - f * d.fc_head;
+				w[r] = q < nhz ? wk.w[s_wo_h0[f] + static_cast<int64_t>(m) * d.fc_trunk + n] : 0.0f;
+			}
 #pragma unroll
-			for (int r = 0; r < 16; ++r) { const int q = q0 + r * parts; s = fmaf(w[r], dhz[q < nhz ? q : p], s); }
+			for (int r = 0; r < kIn; ++r) { const int q = q0 + r * parts; s = fmaf(w[r], dhz[q < nhz ? q : p], s); }
 		}
 		part[p * d.fc_trunk + n] = s;
 		__syncthreads();
@@ -356,6 +375,7 @@ __global__ void __launch_bounds__(kFT) tr_fused_backward_x_kernel(const NetDims*
 			dhs[tid] = t; wk.dhs[static_cast<size_t>(z) * d.fc_trunk + tid] = t;
 		}
 	}
+	if (fc_stage == 3) return;
 	__syncthreads();
 	{   // trunk^T (terrain part only): dt3[k] = relu'(t3) sum_n Wip0[n][k] dhs[n]; 16 partial sums per k
 		const int k = tid % d.fc_terr, p = tid / d.fc_terr;      // p < kFT / fc_terr (>= 16)
