@@ -266,6 +266,18 @@ def test_gpu_iterations_vs_numpy_oracle(om, freeze):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 2, 3, 4])
+def test_gpu_every_fused_mode_of_the_native_step(om, monkeypatch, mode):
+    """DTRL_TRAINER_FUSED selects how the native step is cut into launches (0 layer by layer, 1 fused forward = the default the other tests run, 2 fused forward and
+    backward, 3 forward split into conv stack / split-K GEMM / FC chain, 4 fused forward + fused FC data-gradient chain with the weight gradients on a second graph
+    branch). The non-default cuts are kept as measured alternatives (profiles/r06_trainer.txt): each must compute the same step -- forward and two solver steps against
+    the PyTorch peer, six cMACETrainer iterations against the numpy restatement."""
+    monkeypatch.setenv("DTRL_TRAINER_FUSED", str(mode))
+    run_forward_and_step_vs_torch_peer(HIP_LIB, "cuda", 2e-4)
+    run_iterations_vs_numpy_oracle(om, HIP_LIB, "cuda", 2, 2e-4)
+
+
+@pytest.mark.gpu
 def test_gpu_equals_the_plain_loop_build(om):
     """HIP kernels vs the plain-loop build of the same operand definitions: six iterations, identical decisions, weights within fp32 contraction noise."""
     rng = np.random.RandomState(9)
