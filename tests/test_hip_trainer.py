@@ -273,8 +273,8 @@ def test_gpu_every_fused_mode_of_the_native_step(om, monkeypatch, mode):
     branch). The non-default cuts are kept as measured alternatives (profiles/r06_trainer.txt): each must compute the same step -- forward and two solver steps against
     the PyTorch peer, six cMACETrainer iterations against the numpy restatement."""
     monkeypatch.setenv("DTRL_TRAINER_FUSED", str(mode))
-    run_forward_and_step_vs_torch_peer(HIP_LIB, "cuda", 2e-4)
-    run_iterations_vs_numpy_oracle(om, HIP_LIB, "cuda", 2, 2e-4)
+    run_forward_and_step_vs_torch_peer(None, "cuda", 2e-4)
+    run_iterations_vs_numpy_oracle(om, None, "cuda", 2, 2e-4)
 
 
 @pytest.mark.gpu
